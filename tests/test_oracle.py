@@ -1,0 +1,193 @@
+"""Pins the CPU oracle (oracle/) before anything is compared against it.
+
+1. against the reference's own known-answer tests (tests/golden/reference_known_answers.json, from
+   /root/reference/test/unit-test.jl) -- both the exact KKT oracle and the C restatement of the iterative back-end;
+2. the C restatement's LSQR / CRAIG / MINRES against independent implementations (scipy) and the exact solve.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import fps_amd  # noqa: F401
+from fps_amd import problems
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))["cases"]
+SE = np.sqrt(np.finfo(float).eps)
+
+
+def _case_matrix(case):
+    A = sp.csr_matrix((case["jac_vals"], (case["jac_rows"], case["jac_cols"])), shape=(case["m"], case["n"]))
+    A.sort_indices()
+    return A
+
+
+def _hprod(case, y, v, obj_weight):
+    """(obj_weight * Hess f + sum y_i Hess c_i) v for the two golden models (what ADNLPModel's hprod! returns)."""
+    x = np.array(case["x"])
+    v = np.asarray(v)
+    if case["model"] == "sumsq":
+        return obj_weight * 2.0 * v
+    x1, x2 = x
+    Hf = np.array([[2 - 400 * (x2 - x1 ** 2) + 800 * x1 ** 2, -400 * x1], [-400 * x1, 200.0]])
+    return obj_weight * (Hf @ v) + y[0] * 2.0 * v
+
+
+def _penalty_from_solution(case, p1, q1, p2, q2):
+    """obj / grad! epilogue, model-Fletcherpenaltynlp.jl:244-248, 364, 382-397."""
+    sigma, rho = case["sigma"], case["rho"]
+    g, c, f = np.array(case["g"]), np.array(case["c"]), case["f"]
+    A = _case_matrix(case)
+    gs, ys, v, w = p1 + sigma * p2, q1 + sigma * q2, p2, q2
+    obj = f - c @ ys + rho / 2 * (c @ c)
+    Hsv = _hprod(case, ys, v, 1.0)
+    Sstw = _hprod(case, w, gs, 0.0)
+    grad = gs - Hsv + sigma * v + Sstw
+    if rho > 0:
+        grad = grad + rho * (A.T @ c)
+    return dict(obj=obj, fx=f, gx=g, ys=ys, cx=c, grad=grad)
+
+
+@pytest.mark.parametrize("case", GOLD, ids=[c["name"] for c in GOLD])
+@pytest.mark.parametrize("backend", ["exact", "c_iterative"])
+def test_oracle_matches_reference_known_answers(oracle, case, backend):
+    A = _case_matrix(case)
+    g, c = np.array(case["g"]), np.array(case["c"])
+    if backend == "exact":
+        p1, q1, p2, q2 = oracle.exact_two_mixed(A, case["delta"], g, c)
+        slack = 1.0
+    else:
+        # tolerances far below the reference's sqrt(eps) defaults so the iterative restatement can be held to the
+        # LDLt-level assertions of the reference's tests
+        o = oracle.default_options(case["n"], case["m"], ls_atol=1e-15, ls_rtol=1e-15, ln_atol=1e-15, ln_rtol=1e-15,
+                                   ln_btol=1e-15, ls_axtol=1e-15, ls_btol=1e-15, ls_etol=1e-15)
+        p1, q1, p2, q2, st, rc = oracle.solve_two_mixed(case["m"], case["n"], A.indptr, A.indices, A.data,
+                                                          case["delta"], g, c, o)
+        assert rc == 0 and st[0].solved and st[1].solved
+        slack = 4.0
+    got = _penalty_from_solution(case, p1, q1, p2, q2)
+    for key, want in case["expect"].items():
+        atol = max(case["atol"][key], 1e-15) * slack
+        np.testing.assert_allclose(got[key], want, rtol=0, atol=atol, err_msg=f"{case['name']}:{key}")
+
+
+def _rand_problem(m, n, density, seed):
+    rng = np.random.default_rng(seed)
+    A = sp.random(m, n, density=density, random_state=rng, format="csr", data_rvs=lambda k: rng.uniform(-1, 1, k))
+    A = A + sp.eye(m, n, format="csr") * 3.0
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    return A, rng
+
+
+@pytest.mark.parametrize("damp", [0.0, 0.3])
+def test_c_lsqr_matches_scipy_lsqr(oracle, damp):
+    A, rng = _rand_problem(40, 120, 0.1, 1)
+    b = rng.standard_normal(120)
+    # LSQR on the operator A' (120 x 40), as the reference calls it (solve_linear_system.jl:123)
+    x, st = oracle.lsqr(40, 120, A.indptr, A.indices, A.data, b, lam=damp, atol=1e-14, rtol=1e-14, transposed=True,
+                        axtol=1e-14, btol=1e-14, etol=1e-14, conlim=1e14)
+    ref = spla.lsqr(A.T.tocsr(), b, damp=damp, atol=1e-15, btol=1e-15, conlim=1e12, iter_lim=5000)[0]
+    assert st.solved
+    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-10 * np.linalg.norm(ref))
+    # normal equations residual: (A A' + damp^2 I) x = A b
+    M = (A @ A.T).toarray() + damp ** 2 * np.eye(40)
+    np.testing.assert_allclose(M @ x, A @ b, rtol=0, atol=1e-9 * np.linalg.norm(A @ b))
+
+
+def test_c_lsqr_iterates_track_scipy(oracle):
+    """Same Golub-Kahan recurrences => the k-th iterate agrees with scipy's k-th iterate."""
+    A, rng = _rand_problem(30, 90, 0.15, 2)
+    b = rng.standard_normal(90)
+    for k in (1, 3, 7):
+        x, st = oracle.lsqr(30, 90, A.indptr, A.indices, A.data, b, lam=0.1, atol=0, rtol=0, itmax=k, transposed=True,
+                            axtol=0, btol=0, etol=0, conlim=0)
+        ref = spla.lsqr(A.T.tocsr(), b, damp=0.1, atol=0, btol=0, conlim=0, iter_lim=k)[0]
+        assert st.niter == k
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-12 * max(1.0, np.linalg.norm(ref)))
+
+
+@pytest.mark.parametrize("delta", [0.0, 0.25, 1e-8])
+def test_c_craig_matches_exact(oracle, delta):
+    A, rng = _rand_problem(35, 100, 0.12, 3)
+    c = rng.standard_normal(35)
+    x, y, st = oracle.craig(35, 100, A.indptr, A.indices, A.data, -c, delta=delta, atol=1e-15, rtol=1e-15, btol=1e-15,
+                            conlim=0.0)  # conlim=0 disables the condition-number stop (it fires first for tiny delta)
+    assert st.solved and not st.inconsistent
+    _, _, p2, q2 = oracle.exact_two_mixed(A, delta, np.zeros(100), c)
+    # solve_linear_system.jl:132-133: p2 = -x, q2 = y
+    np.testing.assert_allclose(-x, p2, rtol=0, atol=1e-10 * np.linalg.norm(p2))
+    np.testing.assert_allclose(y, q2, rtol=0, atol=1e-10 * np.linalg.norm(q2))
+
+
+@pytest.mark.parametrize("lam", [1e-14, 0.25])
+def test_c_minres_matches_exact(oracle, lam):
+    A, rng = _rand_problem(30, 80, 0.15, 4)
+    b = rng.standard_normal(30)
+    x, st = oracle.minres_aat(30, 80, A.indptr, A.indices, A.data, b, lam=lam, atol=1e-14, rtol=1e-14, etol=1e-14)
+    assert st.solved
+    M = (A @ A.T).toarray() + lam * np.eye(30)
+    ref = np.linalg.solve(M, b)
+    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-9 * np.linalg.norm(ref))
+
+
+def test_c_two_systems_default_tolerances_vs_exact(oracle):
+    """SURVEY.md §7 parity definition: at the reference's default sqrt(eps) tolerances the iterative path is within
+    1e-6 (relative, inf-norm) of the direct solve."""
+    qp = problems.pde_control_like(n=4000, m=400, per_row=20, window=512, seed=7)
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    for delta in (0.0, SE):
+        p1, q1, p2, q2, st, rc = oracle.solve_two_mixed(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, c)
+        assert rc == 0
+        e = oracle.exact_two_mixed(A, delta, g, c)
+        for got, want in zip((p1, q1, p2, q2), e):
+            assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
+        assert 0 < st[0].niter < 200 and 0 < st[1].niter < 200
+
+
+def test_c_two_least_squares_and_extras_vs_exact(oracle):
+    qp = problems.random_eqqp(n=600, m=60, per_row=12, seed=5)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(0)
+    r1, r2, r3 = rng.standard_normal(qp.n), rng.standard_normal(qp.n), rng.standard_normal(qp.m)
+    tight = dict(ls_atol=1e-14, ls_rtol=1e-14, ls_axtol=1e-14, ls_btol=1e-14, ls_etol=1e-14,
+                 ne_atol=1e-14, ne_rtol=1e-14, ne_etol=1e-14)
+    o = oracle.default_options(qp.n, qp.m, **tight)
+    p1, q1, p2, q2, st, rc = oracle.solve_two_least_squares(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, 0.01, r1, r2, o)
+    e = oracle.exact_two_least_squares(A, 0.01, r1, r2)
+    for got, want in zip((p1, q1, p2, q2), e):
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.linalg.norm(want))
+    a, b, st, rc = oracle.solve_two_extras(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, 0.01, r1, r3, o)
+    ea, eb = oracle.exact_two_extras(A, 0.01, r1, r3)
+    np.testing.assert_allclose(a, ea, rtol=0, atol=1e-9 * np.linalg.norm(ea))
+    np.testing.assert_allclose(b, eb, rtol=0, atol=1e-9 * np.linalg.norm(eb))
+
+
+def test_c_qp_objgrad_vs_exact(oracle):
+    qp = problems.pde_control_like(n=3000, m=300, per_row=16, window=256, seed=11)
+    o = oracle.default_options(qp.n, qp.m, ls_atol=1e-13, ls_rtol=1e-13, ls_axtol=1e-13, ls_btol=1e-13, ls_etol=1e-13,
+                               ln_atol=1e-13, ln_rtol=1e-13, ln_btol=1e-13, ln_conlim=0.0)
+    xk = qp.xhat
+    got = oracle.qp_objgrad(qp, qp.x, sigma=1e3, rho=1.0, delta=SE, eta=0.5, xk=xk, opts=o)
+    want = oracle.exact_qp_objgrad(qp, qp.x, sigma=1e3, rho=1.0, delta=SE, eta=0.5, xk=xk)
+    assert got["rc"] == 0
+    np.testing.assert_allclose(got["ys"], want["ys"], rtol=0, atol=1e-8 * np.linalg.norm(want["ys"]))
+    np.testing.assert_allclose(got["gx"], want["gx"], rtol=0, atol=1e-8 * np.linalg.norm(want["gx"]))
+    assert abs(got["fx"] - want["fx"]) <= 1e-8 * abs(want["fx"])
+
+
+def test_lsqr_zero_rhs_and_zero_atb_edge_cases(oracle):
+    A, rng = _rand_problem(5, 12, 0.3, 9)
+    x, st = oracle.lsqr(5, 12, A.indptr, A.indices, A.data, np.zeros(12), transposed=True)
+    assert st.solved and st.niter == 0 and np.all(x == 0)
+    # b orthogonal to range(A') => A b = 0 => x = 0 is the least-squares solution
+    Ad = A.toarray()
+    b = rng.standard_normal(12)
+    b -= Ad.T @ np.linalg.lstsq(Ad.T, b, rcond=None)[0]
+    x, st = oracle.lsqr(5, 12, A.indptr, A.indices, A.data, b, atol=SE, rtol=SE, transposed=True)
+    assert st.solved and np.linalg.norm(x) < 1e-12
