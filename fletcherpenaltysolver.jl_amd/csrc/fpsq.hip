@@ -1,0 +1,926 @@
+// fpsq.hip -- host side of libfpsq.so: the C ABI of include/fpsq.h, Jacobian storage (CSR of A and of A'),
+// and the stream orchestration of the device-resident Krylov recurrences.
+//
+// Reference path replaced: src/solve_linear_system.jl:45-140 + src/solve_two_systems_struct.jl:167-244
+// (FletcherPenaltySolver.jl v0.3.0), whose arithmetic runs in Krylov.jl on the CPU.
+#include "../../include/fpsq.h"
+#include "fpsq_krylov.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace fpsq;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevCsr {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colind = nullptr;
+  double* vals = nullptr;
+  int32_t* rowblk = nullptr;
+  int32_t nblk = 0;
+  CsrView view() const { return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows}; }
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct fpsq_solver_s {
+  int64_t n = 0, m = 0, nnz = 0;
+  fpsq_options opt{};
+  double delta = 0.0;
+  hipStream_t stream = nullptr;
+  bool have_structure = false, have_values = false;
+  std::string err;
+
+  DevCsr A, AT;
+  int32_t* permT = nullptr;     // AT.vals[t] = A.vals[permT[t]]
+  int64_t nnz_in = 0;           // length of the caller's value array (COO entries or CSR nnz)
+  int32_t* in_perm = nullptr;   // COO path: sorted position -> caller index
+  int32_t* in_slotptr = nullptr;// COO path with duplicates: CSR slot -> range of sorted positions
+  double* in_vals = nullptr;    // staging of the caller's values (COO path)
+
+  std::vector<void*> allocs;
+  // n-vectors
+  double *Lu, *Cv, *Cx, *Cw2, *in_n1, *in_n2, *p1, *p2b, *gs, *gx, *jc, *g, *xin, *xk;
+  // m-vectors
+  double *Lv, *Lw, *Lx, *Lx2, *Cmu, *Cw, *Cy, *in_m, *ys, *c;
+  // partial-sum buffers
+  double *pS, *pS2, *pW, *pE, *pE2, *pE3;
+  int npS = 0;
+  LsqrState* lsqr[2];
+  CraigState* craig;
+  LaneCtl* ctl_tmp;
+  double* dscal;               // small device scalar scratch
+  Progress* prog_host = nullptr;  // host-mapped
+  Progress* prog_dev = nullptr;
+  fpsq_stats* hstats = nullptr;   // pinned
+  double* hscal = nullptr;        // pinned
+
+  // instrumentation
+  bool profile = false;
+  std::vector<EventPair> ev_pool;
+  size_t ev_used = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  fpsq_info info{};
+  int64_t launches = 0, spmv_launches = 0;
+};
+
+struct fpsq_qp_s {
+  fpsq_handle h;
+  double *q, *d, *b;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return FPSQ_ERR_HIP;                                                                       \
+    }                                                                                            \
+  } while (0)
+
+template <class T>
+int dalloc(fpsq_handle h, T** p, size_t count) {
+  void* q = nullptr;
+  HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+inline int ew_grid(int64_t n) {
+  int64_t g = (n + kBlock - 1) / kBlock;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, kEwBlocksMax));
+}
+
+// ------------------------------------------------------------------ host-side sparse set-up
+
+struct HostCsr {
+  int64_t nrows, ncols;
+  std::vector<int32_t> rowptr, colind;
+};
+
+std::vector<int32_t> make_rowblocks(const std::vector<int32_t>& rowptr, int64_t nrows) {
+  std::vector<int32_t> rb;
+  rb.push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t r1 = r;
+    int64_t nz = 0;
+    while (r1 < nrows && (r1 - r) < kMaxRowsPerBlk) {
+      const int64_t len = rowptr[r1 + 1] - rowptr[r1];
+      if (nz + len > kSpmvNnz) break;
+      nz += len;
+      ++r1;
+    }
+    if (r1 == r) r1 = r + 1;  // a single row longer than kSpmvNnz gets a block of its own
+    rb.push_back((int32_t)r1);
+    r = r1;
+  }
+  return rb;
+}
+
+// transpose structure: returns CSR of A' and perm with AT slot t <- A slot perm[t]
+void transpose_structure(const HostCsr& A, HostCsr& T, std::vector<int32_t>& perm) {
+  const int64_t nnz = (int64_t)A.colind.size();
+  T.nrows = A.ncols;
+  T.ncols = A.nrows;
+  T.rowptr.assign(T.nrows + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) T.rowptr[A.colind[k] + 1]++;
+  for (int64_t j = 0; j < T.nrows; ++j) T.rowptr[j + 1] += T.rowptr[j];
+  T.colind.resize(nnz);
+  perm.resize(nnz);
+  std::vector<int32_t> next(T.rowptr.begin(), T.rowptr.end() - 1);
+  for (int64_t i = 0; i < A.nrows; ++i)
+    for (int32_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+      const int32_t t = next[A.colind[k]]++;
+      T.colind[t] = (int32_t)i;
+      perm[t] = k;
+    }
+}
+
+int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
+  D.nrows = H.nrows;
+  D.ncols = H.ncols;
+  D.nnz = (int64_t)H.colind.size();
+  std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows);
+  D.nblk = (int32_t)rb.size() - 1;
+  if (int rc = dalloc(h, &D.rowptr, H.rowptr.size())) return rc;
+  if (int rc = dalloc(h, &D.colind, H.colind.size())) return rc;
+  if (int rc = dalloc(h, &D.vals, H.colind.size())) return rc;
+  if (int rc = dalloc(h, &D.rowblk, rb.size())) return rc;
+  HIPCHK(h, hipMemcpy(D.rowptr, H.rowptr.data(), H.rowptr.size() * 4, hipMemcpyHostToDevice));
+  if (!H.colind.empty())
+    HIPCHK(h, hipMemcpy(D.colind, H.colind.data(), H.colind.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(D.rowblk, rb.data(), rb.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int alloc_workspaces(fpsq_handle h) {
+  const size_t n = (size_t)h->n, m = (size_t)h->m;
+  double** nv[] = {&h->Lu, &h->Cv, &h->Cx, &h->Cw2, &h->in_n1, &h->in_n2, &h->p1, &h->p2b,
+                   &h->gs, &h->gx, &h->jc, &h->g, &h->xin, &h->xk};
+  for (auto p : nv)
+    if (int rc = dalloc(h, p, n)) return rc;
+  double** mv[] = {&h->Lv, &h->Lw, &h->Lx, &h->Lx2, &h->Cmu, &h->Cw, &h->Cy, &h->in_m, &h->ys, &h->c};
+  for (auto p : mv)
+    if (int rc = dalloc(h, p, m)) return rc;
+  h->npS = std::max(h->A.nblk, h->AT.nblk);
+  if (int rc = dalloc(h, &h->pS, (size_t)h->npS * 2)) return rc;
+  if (int rc = dalloc(h, &h->pS2, (size_t)h->npS * 2)) return rc;
+  double** ev[] = {&h->pW, &h->pE, &h->pE2, &h->pE3};
+  for (auto p : ev)
+    if (int rc = dalloc(h, p, (size_t)kEwBlocksMax * 2)) return rc;
+  return 0;
+}
+
+// after the structure (host CSR of A) is known: transposed copy, uploads, workspaces
+int finish_structure(fpsq_handle h, const HostCsr& HA) {
+  HostCsr HT;
+  std::vector<int32_t> perm;
+  transpose_structure(HA, HT, perm);
+  if (int rc = upload_csr(h, HA, h->A)) return rc;
+  if (int rc = upload_csr(h, HT, h->AT)) return rc;
+  if (int rc = dalloc(h, &h->permT, perm.size())) return rc;
+  if (!perm.empty()) HIPCHK(h, hipMemcpy(h->permT, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+  h->nnz = h->A.nnz;
+  if (int rc = alloc_workspaces(h)) return rc;
+  h->have_structure = true;
+  h->have_values = false;
+  h->info.n = h->n;
+  h->info.m = h->m;
+  h->info.nnz = h->nnz;
+  h->info.spmv_a_blocks = h->A.nblk;
+  h->info.spmv_at_blocks = h->AT.nblk;
+  return 0;
+}
+
+// ------------------------------------------------------------------ launch helpers
+
+enum { TAG_A = 0, TAG_AT = 1 };
+
+void prof_begin(fpsq_handle h) {
+  if (!h->profile) return;
+  if (h->ev_used == h->ev_pool.size()) {
+    EventPair p;
+    hipEventCreate(&p.a);
+    hipEventCreate(&p.b);
+    h->ev_pool.push_back(p);
+  }
+  hipEventRecord(h->ev_pool[h->ev_used].a, h->stream);
+}
+void prof_end(fpsq_handle h) {
+  if (!h->profile) return;
+  hipEventRecord(h->ev_pool[h->ev_used].b, h->stream);
+  h->ev_used++;
+}
+
+template <int NL>
+void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, double* yout, const LaneCtl* c0,
+                 const LaneCtl* c1, double* partials) {
+  const DevCsr& M = tag == TAG_A ? h->A : h->AT;
+  const int per_xcd = (M.nblk + 7) / 8;
+  const dim3 grid(per_xcd * 8), block(kBlock);
+  prof_begin(h);
+  if (tag == TAG_A)
+    hipLaunchKernelGGL((k_spmv<NL, TAG_A>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials, per_xcd);
+  else
+    hipLaunchKernelGGL((k_spmv<NL, TAG_AT>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
+                       per_xcd);
+  prof_end(h);
+  h->launches++;
+  h->spmv_launches++;
+}
+
+__global__ void k_set_ctl(LaneCtl* c, double ca, double cb) {
+  c->ca = ca;
+  c->cb = cb;
+  c->done = 0;
+  c->skip = 0;
+  c->upd_iter = -1;
+}
+
+// out = ca * op(A) x + cb * yin with host-given constants
+void spmv_const(fpsq_handle h, int tag, double ca, const double* x, double cb, const double* yin, double* yout) {
+  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, h->stream, h->ctl_tmp, ca, cb);
+  h->launches++;
+  launch_spmv<1>(h, tag, x, yin, yout, h->ctl_tmp, h->ctl_tmp, nullptr);
+}
+
+// Bounded wait until the device has reached `target` iterations (or finished).  The progress word lives in
+// host-mapped memory and is stored by the scalar kernels; if the stream drains without the word moving (which
+// would mean the mapped store is not visible) we fall back to reading the device state explicitly.
+int wait_progress(fpsq_handle h, int lane, int target, const int32_t* dev_done, const int32_t* dev_iter) {
+  volatile Progress* p = &h->prog_host[lane];
+  const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
+  while (!p->done && p->iter < target) {
+    if ((++spins & 63) == 0) {
+      hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        if (p->done || p->iter >= target) break;
+        int32_t d = 0, it = 0;
+        HIPCHK(h, hipMemcpy(&d, dev_done, 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(&it, dev_iter, 4, hipMemcpyDeviceToHost));
+        p->done = d;
+        p->iter = it;
+        break;
+      } else if (q != hipErrorNotReady) {
+        h->err = std::string("stream failed while iterating: ") + hipGetErrorString(q);
+        return FPSQ_ERR_HIP;
+      }
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > 120.0) {
+        h->err = "timeout waiting for device progress";
+        return FPSQ_ERR_TIMEOUT;
+      }
+      if (el > 0.002) std::this_thread::yield();
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ Krylov drivers (one recurrence at a time)
+
+struct LsqrParams {
+  double lambda, atol, rtol, axtol, btol, etol, conlim;
+  int64_t itmax;
+};
+
+__global__ void k_lsqr_params(LsqrState* S, LsqrParams P) {
+  S->lambda = P.lambda;
+  S->atol = P.atol;
+  S->rtol = P.rtol;
+  S->axtol = P.axtol;
+  S->btol = P.btol;
+  S->etol = P.etol;
+  S->ctol = P.conlim > 0.0 ? 1.0 / P.conlim : 0.0;
+  S->itmax = P.itmax;
+  S->ctl.done = 0;
+  S->ctl.skip = 0;
+  S->ctl.upd_iter = -1;
+}
+
+struct CraigParams {
+  double mu, lambda, atol, rtol, btol, conlim, xsign;
+  int64_t itmax;
+};
+
+__global__ void k_craig_params(CraigState* S, CraigParams P) {
+  S->mu = P.mu;
+  S->lambda = P.lambda;
+  S->atol = P.atol;
+  S->rtol = P.rtol;
+  S->btol = P.btol;
+  S->ctol = P.conlim > 0.0 ? 1.0 / P.conlim : 0.0;
+  S->xsign = P.xsign;
+  S->itmax = P.itmax;
+  S->ctl.done = 0;
+  S->ctl.skip = 0;
+  S->ctl.upd_iter = -1;
+}
+
+// LSQR on B = A' (n x m): min ||A'x - b||^2 + lambda^2 ||x||^2, b (n, device) -> x (m, device).
+// src/solve_two_systems_struct.jl:167-185.
+int run_lsqr(fpsq_handle h, int slot, const double* b, double lambda, double* x, fpsq_stats* st_out) {
+  const int64_t n = h->n, m = h->m;
+  LsqrState* S = h->lsqr[slot];
+  Progress* prog = &h->prog_dev[slot];
+  h->prog_host[slot].iter = 0;
+  h->prog_host[slot].done = 0;
+  const fpsq_options& o = h->opt;
+  int64_t itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
+  LsqrParams P{lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, itmax};
+  hipStream_t s = h->stream;
+  const int gn = ew_grid(n), gm = ew_grid(m);
+  hipLaunchKernelGGL(k_lsqr_params, dim3(1), dim3(1), 0, s, S, P);
+  HIPCHK(h, hipMemsetAsync(x, 0, (size_t)m * 8, s));
+  hipLaunchKernelGGL(k_load_lane<1>, dim3(gn), dim3(kBlock), 0, s, b, 1.0, h->Lu, 0, n, h->pE);
+  hipLaunchKernelGGL(k_lsqr_begin, dim3(1), dim3(kBlock), 0, s, S, h->pE, gn, prog);
+  launch_spmv<1>(h, TAG_A, h->Lu, nullptr, h->Lv, &S->ctl, &S->ctl, h->pS2);
+  hipLaunchKernelGGL(k_lsqr_begin2, dim3(1), dim3(kBlock), 0, s, S, h->pS2, h->A.nblk, prog);
+  hipLaunchKernelGGL(k_lsqr_winit<1>, dim3(gm), dim3(kBlock), 0, s, &S->ctl, h->Lv, 0, h->Lw, m, h->pW);
+  h->launches += 6;
+  const int look = std::max(1, o.lookahead);
+  for (int64_t it = 1; it <= itmax; ++it) {
+    launch_spmv<1>(h, TAG_AT, h->Lv, h->Lu, h->Lu, &S->ctl, &S->ctl, h->pS);
+    hipLaunchKernelGGL(k_lsqr_sa, dim3(1), dim3(kBlock), 0, s, S, h->pS, h->AT.nblk);
+    launch_spmv<1>(h, TAG_A, h->Lu, h->Lv, h->Lv, &S->ctl, &S->ctl, h->pS2);
+    hipLaunchKernelGGL(k_lsqr_sb, dim3(1), dim3(kBlock), 0, s, S, h->pS2, h->A.nblk, h->pW, gm, (int)it, prog);
+    hipLaunchKernelGGL(k_lsqr_update<1>, dim3(gm), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Lv, 0, x, h->Lw, m, h->pW);
+    h->launches += 3;
+    if (h->prog_host[slot].done) break;
+    if (it - h->prog_host[slot].iter >= look) {
+      if (int rc = wait_progress(h, slot, (int)(it - look + 1), &S->ctl.done, &S->iter)) return rc;
+      if (h->prog_host[slot].done) break;
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(st_out, &S->stats, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+// CRAIG on B = A (m x n): src/solve_two_systems_struct.jl:210-244.  b (m, device) -> xs = xsign * x (n), y (m).
+int run_craig(fpsq_handle h, const double* b, double bscale, double delta, double xsign, double* xs, double* y,
+              fpsq_stats* st_out) {
+  const int64_t n = h->n, m = h->m;
+  CraigState* S = h->craig;
+  const int slot = 1;
+  Progress* prog = &h->prog_dev[slot];
+  h->prog_host[slot].iter = 0;
+  h->prog_host[slot].done = 0;
+  const fpsq_options& o = h->opt;
+  const bool reg = delta != 0.0;
+  int64_t itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
+  CraigParams P{reg ? 1.0 / delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim, xsign, itmax};
+  hipStream_t s = h->stream;
+  const int gn = ew_grid(n), gm = ew_grid(m);
+  hipLaunchKernelGGL(k_craig_params, dim3(1), dim3(1), 0, s, S, P);
+  HIPCHK(h, hipMemsetAsync(xs, 0, (size_t)n * 8, s));
+  HIPCHK(h, hipMemsetAsync(y, 0, (size_t)m * 8, s));
+  HIPCHK(h, hipMemsetAsync(h->Cw, 0, (size_t)m * 8, s));
+  if (reg) HIPCHK(h, hipMemsetAsync(h->Cw2, 0, (size_t)n * 8, s));
+  hipLaunchKernelGGL(k_load_lane<1>, dim3(gm), dim3(kBlock), 0, s, b, bscale, h->Cmu, 0, m, h->pE);
+  hipLaunchKernelGGL(k_craig_begin, dim3(1), dim3(kBlock), 0, s, S, h->pE, gm, prog);
+  h->launches += 3;
+  const int look = std::max(1, o.lookahead);
+  for (int64_t it = 1; it <= itmax; ++it) {
+    launch_spmv<1>(h, TAG_AT, h->Cmu, h->Cv, h->Cv, &S->ctl, &S->ctl, h->pS);
+    hipLaunchKernelGGL(k_craig_sa, dim3(1), dim3(kBlock), 0, s, S, h->pS, h->AT.nblk, (int)it, prog);
+    if (reg)
+      hipLaunchKernelGGL((k_craig_update_long<1, true>), dim3(gn), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Cv, 0, xs,
+                         h->Cw2, n);
+    else
+      hipLaunchKernelGGL((k_craig_update_long<1, false>), dim3(gn), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Cv, 0, xs,
+                         h->Cw2, n);
+    hipLaunchKernelGGL(k_craig_update_short<1>, dim3(gm), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Cmu, 0, h->Cw, y, m,
+                       h->pW);
+    launch_spmv<1>(h, TAG_A, h->Cv, h->Cmu, h->Cmu, &S->ctl, &S->ctl, h->pS2);
+    hipLaunchKernelGGL(k_craig_sb, dim3(1), dim3(kBlock), 0, s, S, h->pS2, h->A.nblk, h->pW, gm, (int)it, prog);
+    h->launches += 4;
+    if (h->prog_host[slot].done) break;
+    if (it - h->prog_host[slot].iter >= look) {
+      if (int rc = wait_progress(h, slot, (int)(it - look + 1), &S->ctl.done, &S->iter)) return rc;
+      if (h->prog_host[slot].done) break;
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(st_out, &S->stats, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+int check_ready(fpsq_handle h) {
+  if (!h) return FPSQ_ERR_ARG;
+  if (!h->have_structure || !h->have_values) {
+    h->err = "Jacobian structure/values not set";
+    return FPSQ_ERR_STATE;
+  }
+  return 0;
+}
+
+void call_begin(fpsq_handle h) {
+  h->launches = 0;
+  h->spmv_launches = 0;
+  h->ev_used = 0;
+  hipEventRecord(h->ev0, h->stream);
+}
+
+int call_end(fpsq_handle h) {
+  hipEventRecord(h->ev1, h->stream);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, h->ev0, h->ev1);
+  h->info.last_solve_ms = ms;
+  h->info.last_kernel_launches = h->launches;
+  h->info.last_spmv_launches = h->spmv_launches;
+  double sp = 0.0;
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float t = 0.f;
+    hipEventElapsedTime(&t, h->ev_pool[i].a, h->ev_pool[i].b);
+    sp += t;
+  }
+  h->info.last_spmv_ms = sp;
+  return 0;
+}
+
+int soft_rc(const fpsq_stats st[2]) { return (st[0].solved ? 0 : 1) | (st[1].solved ? 0 : 2); }
+
+// device-side solve_two_mixed: g (n), c (m) device pointers; results left in h->p1, h->Lx (q1), h->Cx (p2), h->Cy (q2)
+int two_mixed_device(fpsq_handle h, const double* g, const double* c) {
+  // (q1, stats1) = solve_least_square(qds, Aop', rhs1, sqrt(delta))      src/solve_linear_system.jl:123
+  if (int rc = run_lsqr(h, 0, g, std::sqrt(h->delta), h->Lx, &h->hstats[0])) return rc;
+  // p1 = rhs1 - Aop' q1                                                   :126-127
+  spmv_const(h, TAG_AT, -1.0, h->Lx, 1.0, g, h->p1);
+  // (p2, q2, stats2) = solve_least_norm(qds, Aop, -rhs2, delta); p2 = -p2 :132-133
+  if (int rc = run_craig(h, c, -1.0, h->delta, -1.0, h->Cx, h->Cy, &h->hstats[1])) return rc;
+  return 0;
+}
+
+}  // namespace
+
+// ===================================================================================== C ABI
+
+extern "C" {
+
+const char* fpsq_version(void) { return "fpsq 0.1.0 (gfx950)"; }
+
+void fpsq_default_options(int64_t n, int64_t m, fpsq_options* o) {
+  const double se = std::sqrt(2.220446049250313e-16);
+  std::memset(o, 0, sizeof *o);
+  o->ls_atol = se;
+  o->ls_rtol = se;
+  o->ls_itmax = 5 * (m + n);
+  o->ln_atol = se;
+  o->ln_rtol = se;
+  o->ln_btol = se;
+  o->ln_conlim = 1.0 / se;
+  o->ln_itmax = 5 * (m + n);
+  o->ne_atol = se;
+  o->ne_rtol = se;
+  o->ne_etol = se;
+  o->ne_itmax = 0;
+  o->ne_conlim = 1.0 / se;
+  o->ls_axtol = se;
+  o->ls_btol = se;
+  o->ls_etol = se;
+  o->ls_conlim = 1.0 / se;
+  o->fuse_two_rhs = 1;
+  o->lookahead = 4;
+  o->device = 0;
+}
+
+const char* fpsq_last_error(fpsq_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts) {
+  if (!out || n <= 0 || m <= 0 || n >= INT32_MAX || m >= INT32_MAX) {
+    g_create_error = "fpsq_create: bad arguments";
+    return FPSQ_ERR_ARG;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    g_create_error = std::string("fpsq_create: no HIP device (") + hipGetErrorString(e) +
+                     "); libfpsq has no CPU fallback";
+    return FPSQ_ERR_HIP;
+  }
+  fpsq_handle h = new fpsq_solver_s();
+  h->n = n;
+  h->m = m;
+  if (opts) h->opt = *opts; else fpsq_default_options(n, m, &h->opt);
+  auto fail = [&](const char* what, hipError_t err) {
+    g_create_error = std::string("fpsq_create: ") + what + ": " + hipGetErrorString(err);
+    delete h;
+    return FPSQ_ERR_HIP;
+  };
+  if ((e = hipSetDevice(h->opt.device)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  if ((e = hipHostMalloc((void**)&h->prog_host, 4 * sizeof(Progress), hipHostMallocMapped | hipHostMallocCoherent)) !=
+      hipSuccess)
+    return fail("hipHostMalloc", e);
+  std::memset(h->prog_host, 0, 4 * sizeof(Progress));
+  if ((e = hipHostGetDevicePointer((void**)&h->prog_dev, h->prog_host, 0)) != hipSuccess)
+    return fail("hipHostGetDevicePointer", e);
+  if ((e = hipHostMalloc((void**)&h->hstats, 4 * sizeof(fpsq_stats), 0)) != hipSuccess) return fail("hipHostMalloc", e);
+  if ((e = hipHostMalloc((void**)&h->hscal, 16 * sizeof(double), 0)) != hipSuccess) return fail("hipHostMalloc", e);
+  hipEventCreate(&h->ev0);
+  hipEventCreate(&h->ev1);
+  void* p = nullptr;
+  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
+    return fail("hipMalloc", e);
+  h->allocs.push_back(p);
+  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(LaneCtl) + 64 * sizeof(double));
+  char* cp = (char*)p;
+  h->lsqr[0] = (LsqrState*)cp;
+  h->lsqr[1] = h->lsqr[0] + 1;
+  cp += sizeof(LsqrState) * 2;
+  h->craig = (CraigState*)cp;
+  cp += sizeof(CraigState);
+  h->ctl_tmp = (LaneCtl*)cp;
+  cp += sizeof(LaneCtl);
+  h->dscal = (double*)cp;
+  *out = h;
+  return FPSQ_OK;
+}
+
+int fpsq_destroy(fpsq_handle h) {
+  if (!h) return FPSQ_ERR_ARG;
+  hipSetDevice(h->opt.device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) hipFree(p);
+  for (auto& e : h->ev_pool) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->prog_host) hipHostFree(h->prog_host);
+  if (h->hstats) hipHostFree(h->hstats);
+  if (h->hscal) hipHostFree(h->hscal);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return FPSQ_OK;
+}
+
+int fpsq_set_jacobian_structure_csr(fpsq_handle h, const int32_t* rowptr, const int32_t* colind) {
+  if (!h || !rowptr || h->have_structure) {
+    if (h) h->err = "set_jacobian_structure: bad arguments or structure already set";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  HostCsr HA;
+  HA.nrows = h->m;
+  HA.ncols = h->n;
+  HA.rowptr.resize(h->m + 1);
+  HIPCHK(h, hipMemcpy(HA.rowptr.data(), rowptr, (size_t)(h->m + 1) * 4, hipMemcpyDefault));
+  const int64_t nnz = HA.rowptr[h->m];
+  if (HA.rowptr[0] != 0 || nnz < 0) {
+    h->err = "set_jacobian_structure_csr: rowptr must be 0-based";
+    return FPSQ_ERR_ARG;
+  }
+  HA.colind.resize(nnz);
+  if (nnz) HIPCHK(h, hipMemcpy(HA.colind.data(), colind, (size_t)nnz * 4, hipMemcpyDefault));
+  for (int64_t i = 0; i < h->m; ++i)
+    if (HA.rowptr[i + 1] < HA.rowptr[i]) {
+      h->err = "set_jacobian_structure_csr: rowptr not monotone";
+      return FPSQ_ERR_ARG;
+    }
+  for (int64_t k = 0; k < nnz; ++k)
+    if (HA.colind[k] < 0 || HA.colind[k] >= h->n) {
+      h->err = "set_jacobian_structure_csr: column index out of range";
+      return FPSQ_ERR_ARG;
+    }
+  h->nnz_in = nnz;
+  return finish_structure(h, HA);
+}
+
+int fpsq_set_jacobian_structure_coo(fpsq_handle h, int64_t nnz, const int64_t* rows, const int64_t* cols,
+                                    int32_t index_base) {
+  if (!h || nnz < 0 || nnz >= INT32_MAX || (nnz > 0 && (!rows || !cols)) || h->have_structure) {
+    if (h) h->err = "set_jacobian_structure_coo: bad arguments or structure already set";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  std::vector<int64_t> r(nnz), c(nnz);
+  if (nnz) {
+    HIPCHK(h, hipMemcpy(r.data(), rows, (size_t)nnz * 8, hipMemcpyDefault));
+    HIPCHK(h, hipMemcpy(c.data(), cols, (size_t)nnz * 8, hipMemcpyDefault));
+  }
+  const int64_t m = h->m, n = h->n;
+  std::vector<int32_t> cnt(m + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    r[k] -= index_base;
+    c[k] -= index_base;
+    if (r[k] < 0 || r[k] >= m || c[k] < 0 || c[k] >= n) {
+      h->err = "set_jacobian_structure_coo: index out of range";
+      return FPSQ_ERR_ARG;
+    }
+    cnt[r[k] + 1]++;
+  }
+  for (int64_t i = 0; i < m; ++i) cnt[i + 1] += cnt[i];
+  // bucket by row (stable), then sort each row by column (stable: duplicates keep the caller's order)
+  std::vector<int32_t> order(nnz);
+  {
+    std::vector<int32_t> next(cnt.begin(), cnt.end() - 1);
+    for (int64_t k = 0; k < nnz; ++k) order[next[r[k]]++] = (int32_t)k;
+  }
+  for (int64_t i = 0; i < m; ++i)
+    std::stable_sort(order.begin() + cnt[i], order.begin() + cnt[i + 1],
+                     [&](int32_t a, int32_t b) { return c[a] < c[b]; });
+  HostCsr HA;
+  HA.nrows = m;
+  HA.ncols = n;
+  HA.rowptr.assign(m + 1, 0);
+  std::vector<int32_t> slotptr;
+  slotptr.push_back(0);
+  for (int64_t i = 0; i < m; ++i) {
+    for (int32_t k = cnt[i]; k < cnt[i + 1]; ++k) {
+      const int64_t col = c[order[k]];
+      if (k > cnt[i] && col == c[order[k - 1]]) {
+        slotptr.back() = k + 1;  // duplicate: extend the current slot
+      } else {
+        HA.colind.push_back((int32_t)col);
+        slotptr.push_back(k + 1);
+      }
+    }
+    HA.rowptr[i + 1] = (int32_t)HA.colind.size();
+  }
+  const bool dup = (int64_t)HA.colind.size() != nnz;
+  h->nnz_in = nnz;
+  if (int rc = dalloc(h, &h->in_perm, (size_t)nnz)) return rc;
+  if (int rc = dalloc(h, &h->in_vals, (size_t)nnz)) return rc;
+  if (nnz) HIPCHK(h, hipMemcpy(h->in_perm, order.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+  if (dup) {
+    if (int rc = dalloc(h, &h->in_slotptr, slotptr.size())) return rc;
+    HIPCHK(h, hipMemcpy(h->in_slotptr, slotptr.data(), slotptr.size() * 4, hipMemcpyHostToDevice));
+  }
+  return finish_structure(h, HA);
+}
+
+int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
+  if (!h || !h->have_structure || (!vals && h->nnz_in > 0)) {
+    if (h) h->err = "set_jacobian_values: structure not set or null values";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  if (h->nnz_in > 0) {
+    if (h->in_perm) {
+      HIPCHK(h, hipMemcpyAsync(h->in_vals, vals, (size_t)h->nnz_in * 8, hipMemcpyDefault, s));
+      if (h->in_slotptr)
+        hipLaunchKernelGGL(k_gather_sum, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->in_vals, h->in_perm,
+                           h->in_slotptr, h->A.vals, h->nnz);
+      else
+        hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->in_vals, h->in_perm, h->A.vals,
+                           h->nnz);
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->A.vals, vals, (size_t)h->nnz * 8, hipMemcpyDefault, s));
+    }
+    hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->A.vals, h->permT, h->AT.vals, h->nnz);
+  }
+  HIPCHK(h, hipStreamSynchronize(s));
+  h->have_values = true;
+  return FPSQ_OK;
+}
+
+int fpsq_set_delta(fpsq_handle h, double delta) {
+  if (!h || !(delta >= 0.0)) {
+    if (h) h->err = "set_delta: delta must be >= 0";
+    return FPSQ_ERR_ARG;
+  }
+  h->delta = delta;
+  return FPSQ_OK;
+}
+
+int fpsq_solve_two_mixed(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1, double* p2,
+                         double* q2, fpsq_stats st[2]) {
+  if (int rc = check_ready(h)) return rc;
+  if (!rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2 || !st) {
+    h->err = "solve_two_mixed: null argument";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
+  HIPCHK(h, hipMemcpyAsync(h->in_n1, rhs1, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(h->in_m, rhs2, mb, hipMemcpyDefault, s));
+  call_begin(h);
+  if (int rc = two_mixed_device(h, h->in_n1, h->in_m)) return rc;
+  HIPCHK(h, hipMemcpyAsync(p1, h->p1, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(q1, h->Lx, mb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(p2, h->Cx, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(q2, h->Cy, mb, hipMemcpyDefault, s));
+  if (int rc = call_end(h)) return rc;
+  st[0] = h->hstats[0];
+  st[1] = h->hstats[1];
+  return soft_rc(st);
+}
+
+int fpsq_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1,
+                                 double* p2, double* q2, fpsq_stats st[2]) {
+  if (int rc = check_ready(h)) return rc;
+  if (!rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2 || !st) {
+    h->err = "solve_two_least_squares: null argument";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
+  HIPCHK(h, hipMemcpyAsync(h->in_n1, rhs1, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(h->in_n2, rhs2, nb, hipMemcpyDefault, s));
+  call_begin(h);
+  const double lam = std::sqrt(h->delta);
+  // src/solve_linear_system.jl:87-91 and :96-100
+  if (int rc = run_lsqr(h, 0, h->in_n1, lam, h->Lx, &h->hstats[0])) return rc;
+  spmv_const(h, TAG_AT, -1.0, h->Lx, 1.0, h->in_n1, h->p1);
+  if (int rc = run_lsqr(h, 1, h->in_n2, lam, h->Lx2, &h->hstats[1])) return rc;
+  spmv_const(h, TAG_AT, -1.0, h->Lx2, 1.0, h->in_n2, h->p2b);
+  HIPCHK(h, hipMemcpyAsync(p1, h->p1, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(q1, h->Lx, mb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(p2, h->p2b, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(q2, h->Lx2, mb, hipMemcpyDefault, s));
+  if (int rc = call_end(h)) return rc;
+  st[0] = h->hstats[0];
+  st[1] = h->hstats[1];
+  return soft_rc(st);
+}
+
+int fpsq_solve_two_extras(fpsq_handle h, const double*, const double*, double*, double*, fpsq_stats*) {
+  if (!h) return FPSQ_ERR_ARG;
+  h->err = "solve_two_extras: not implemented yet";
+  return FPSQ_ERR_STATE;
+}
+
+int fpsq_ys_gs(fpsq_handle h, const double* g, const double* c, double sigma, double* gs, double* ys, double* v,
+               double* w, fpsq_stats st[2]) {
+  if (int rc = check_ready(h)) return rc;
+  if (!g || !c || !gs || !ys || !v || !w || !st) {
+    h->err = "ys_gs: null argument";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
+  HIPCHK(h, hipMemcpyAsync(h->in_n1, g, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(h->in_m, c, mb, hipMemcpyDefault, s));
+  call_begin(h);
+  if (int rc = two_mixed_device(h, h->in_n1, h->in_m)) return rc;
+  // src/model-Fletcherpenaltynlp.jl:244-248
+  hipLaunchKernelGGL(k_gs, dim3(ew_grid(h->n)), dim3(kBlock), 0, s, h->p1, h->Cx, sigma, h->gs, h->n);
+  hipLaunchKernelGGL(k_ys, dim3(ew_grid(h->m)), dim3(kBlock), 0, s, h->Lx, h->Cy, (const double*)nullptr, sigma, h->ys,
+                     h->m, (double*)nullptr, (double*)nullptr);
+  h->launches += 2;
+  HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(v, h->Cx, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(w, h->Cy, mb, hipMemcpyDefault, s));
+  if (int rc = call_end(h)) return rc;
+  st[0] = h->hstats[0];
+  st[1] = h->hstats[1];
+  return soft_rc(st);
+}
+
+int fpsq_jac_mul(fpsq_handle h, int32_t trans, double alpha, const double* x, double beta, double* y) {
+  if (int rc = check_ready(h)) return rc;
+  if (!x || !y) {
+    h->err = "jac_mul: null argument";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  const size_t xb = (size_t)(trans ? h->m : h->n) * 8, yb = (size_t)(trans ? h->n : h->m) * 8;
+  double* dx = trans ? h->in_m : h->in_n1;
+  double* dy = trans ? h->in_n2 : h->c;
+  HIPCHK(h, hipMemcpyAsync(dx, x, xb, hipMemcpyDefault, s));
+  if (beta != 0.0) HIPCHK(h, hipMemcpyAsync(dy, y, yb, hipMemcpyDefault, s));
+  call_begin(h);
+  spmv_const(h, trans ? TAG_AT : TAG_A, alpha, dx, beta, dy, dy);
+  HIPCHK(h, hipMemcpyAsync(y, dy, yb, hipMemcpyDefault, s));
+  return call_end(h);
+}
+
+// ---------------------------------------------------------------- device-resident equality-QP model
+
+int fpsq_qp_create(fpsq_handle h, const double* qdiag, const double* d, const double* b, fpsq_qp* out) {
+  if (!h || !qdiag || !d || !b || !out) return FPSQ_ERR_ARG;
+  hipSetDevice(h->opt.device);
+  fpsq_qp qp = new fpsq_qp_s();
+  qp->h = h;
+  if (dalloc(h, &qp->q, (size_t)h->n) || dalloc(h, &qp->d, (size_t)h->n) || dalloc(h, &qp->b, (size_t)h->m)) {
+    delete qp;
+    return FPSQ_ERR_HIP;
+  }
+  HIPCHK(h, hipMemcpy(qp->q, qdiag, (size_t)h->n * 8, hipMemcpyDefault));
+  HIPCHK(h, hipMemcpy(qp->d, d, (size_t)h->n * 8, hipMemcpyDefault));
+  HIPCHK(h, hipMemcpy(qp->b, b, (size_t)h->m * 8, hipMemcpyDefault));
+  *out = qp;
+  return FPSQ_OK;
+}
+
+int fpsq_qp_destroy(fpsq_qp qp) {
+  if (!qp) return FPSQ_ERR_ARG;
+  delete qp;  // device arrays are owned by the solver handle's arena
+  return FPSQ_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// fx = f - c'ys + rho/2 c'c + eta/2 ||x - xk||^2 from the partial sums   (src/model-Fletcherpenaltynlp.jl:419-433)
+__global__ __launch_bounds__(kBlock) void k_qp_fx(const double* pf, const double* pdx, int np_n, const double* pcy,
+                                                  const double* pcc, int np_m, double rho, double eta, double* out) {
+  __shared__ double red[4];
+  const double f = reduce_partials(pf, np_n, red);
+  const double dx = reduce_partials(pdx, np_n, red);
+  const double cy = reduce_partials(pcy, np_m, red);
+  const double cc = reduce_partials(pcc, np_m, red);
+  if (threadIdx.x == 0) {
+    double fx = f - cy;
+    if (rho > 0.0) fx += rho / 2 * cc;
+    if (eta > 0.0) fx += eta / 2 * dx;
+    out[0] = fx;
+    out[1] = f;
+    out[2] = cc;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, double rho, double eta,
+                    const double* xk, double* fx, double* gx, double* ys, double* gs, fpsq_stats st[2]) {
+  if (int rc = check_ready(h)) return rc;
+  if (!qp || qp->h != h || !x || !st || (eta > 0.0 && !xk)) {
+    h->err = "qp_objgrad: bad argument";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  const int64_t n = h->n, m = h->m;
+  const size_t nb = (size_t)n * 8, mb = (size_t)m * 8;
+  const int gn = ew_grid(n), gm = ew_grid(m);
+  HIPCHK(h, hipMemcpyAsync(h->xin, x, nb, hipMemcpyDefault, s));
+  const double* dxk = nullptr;
+  if (eta > 0.0) {
+    HIPCHK(h, hipMemcpyAsync(h->xk, xk, nb, hipMemcpyDefault, s));
+    dxk = h->xk;
+  }
+  call_begin(h);
+  // user-model evaluations of _compute_ys_gs!  (src/model-Fletcherpenaltynlp.jl:238-240)
+  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, h->xin, dxk, h->g, n, h->pE2, h->pE3);
+  h->launches++;
+  spmv_const(h, TAG_A, 1.0, h->xin, -1.0, qp->b, h->c);  // c = A x - b
+  if (int rc = two_mixed_device(h, h->g, h->c)) return rc;
+  // ys = q1 + sigma q2 and the dots of objgrad!
+  hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx, h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax);
+  h->launches++;
+  if (rho > 0.0) spmv_const(h, TAG_AT, 1.0, h->c, 0.0, nullptr, h->jc);  // J'c   (:424-428)
+  hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn), dim3(kBlock), 0, s, h->p1, h->Cx, qp->q, h->jc, h->xin, dxk, sigma,
+                     rho, eta, h->gs, h->gx, n);
+  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pE2, h->pE3, gn, h->pE, h->pE + kEwBlocksMax, gm, rho,
+                     eta, h->dscal);
+  h->launches += 2;
+  HIPCHK(h, hipMemcpyAsync(h->hscal, h->dscal, 3 * 8, hipMemcpyDeviceToHost, s));
+  if (gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
+  if (ys) HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
+  if (gs) HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
+  if (int rc = call_end(h)) return rc;
+  if (fx) *fx = h->hscal[0];
+  st[0] = h->hstats[0];
+  st[1] = h->hstats[1];
+  return soft_rc(st);
+}
+
+int fpsq_comm_unique_id(uint8_t*) { return FPSQ_ERR_COMM; }
+int fpsq_comm_init(fpsq_handle h, int32_t, int32_t, const uint8_t*) {
+  if (h) h->err = "comm_init: not implemented yet";
+  return FPSQ_ERR_COMM;
+}
+
+int fpsq_get_info(fpsq_handle h, fpsq_info* info) {
+  if (!h || !info) return FPSQ_ERR_ARG;
+  *info = h->info;
+  return FPSQ_OK;
+}
+
+int fpsq_set_profiling(fpsq_handle h, int32_t on) {
+  if (!h) return FPSQ_ERR_ARG;
+  h->profile = on != 0;
+  return FPSQ_OK;
+}
+
+}  // extern "C"

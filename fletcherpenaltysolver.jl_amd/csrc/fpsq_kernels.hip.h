@@ -1,0 +1,389 @@
+// fpsq_kernels.hip.h -- gfx950 device code for libfpsq: CSR-stream SpMV/SpMM with fused axpby + norm partials,
+// vector update kernels, deterministic reductions.  fp64 values, int32 indices, wave64.
+//
+// Layout of every Krylov vector: [len][NL] interleaved "lanes" (NL = 1: a plain vector; NL = 2: the two
+// recurrences of a fused solve_two_* call side by side, so one 16-byte gather feeds both).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fpsq {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 waves)
+constexpr int kSpmvNnz = 2048;     // nonzeros staged through LDS per workgroup
+constexpr int kMaxRowsPerBlk = 1024;
+constexpr int kEwBlocksMax = 1024; // grid cap for element-wise kernels (grid-stride beyond)
+
+// Per-recurrence control block read by the generic kernels; written only by that recurrence's scalar kernels.
+struct LaneCtl {
+  double ca, cb;   // next product kernel: out = ca * (Mat x) + cb * yin
+  double e[8];     // coefficients of the next element-wise update kernel
+  int32_t done;    // recurrence finished: its kernels become no-ops
+  int32_t upd_iter;// iteration whose update kernel still has to run after `done` was raised
+  int32_t skip;    // skip the next product (its input vector is exactly zero)
+  int32_t pad;
+};
+
+struct CsrView {
+  const int32_t* rowptr;
+  const int32_t* colind;
+  const double* vals;
+  const int32_t* rowblk;  // nblk + 1 row boundaries; a block has <= kSpmvNnz nonzeros unless it is ONE long row
+  int32_t nblk;
+  int32_t nrows;
+};
+
+// ------------------------------------------------------------------------------------------------ reductions
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over the workgroup; result valid in thread 0.  Fixed order => bitwise reproducible.
+__device__ __forceinline__ double block_sum(double v, double* red /* >= 4 doubles of LDS */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// Deterministic sum of a partials array by ONE workgroup (used by the scalar kernels). Valid in thread 0.
+__device__ __forceinline__ double reduce_partials(const double* p, int n, double* red) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += kBlock) s += p[i];
+  return block_sum(s, red);
+}
+
+// ------------------------------------------------------------------------------------------------ SpMV / SpMM
+//
+// out[r][l] = ca_l * sum_k vals[k] * x[colind[k]][l] + cb_l * yin[r][l],  partial[l][blk] = sum_r out[r][l]^2
+//
+// CSR-stream: a workgroup owns a run of consecutive rows holding <= kSpmvNnz nonzeros.  Phase 1 streams that
+// run's (colind, vals) with unit-stride, fully coalesced loads (every lane busy whatever the row lengths), gathers
+// x and parks the products in LDS; phase 2 reduces each row's LDS segment with G lanes per row (G = power of two
+// chosen from the block's row count: ~100-nnz rows of A get 8 lanes each, ~10-nnz rows of A' one lane each).
+// blockIdx is remapped so that each XCD walks a contiguous eighth of the matrix: its private L2 then caches one
+// slice of x instead of all of it.  Summation order is a pure function of the sparsity => reproducible.
+template <int NL, int TAG>
+__global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
+                                                 double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
+                                                 double* partials, int blk_per_xcd) {
+  const int L = (blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3);
+  if (L >= A.nblk) return;
+  bool act[NL];
+  double ca[NL], cb[NL];
+  {
+    const LaneCtl* c[2] = {ctl0, ctl1};
+    bool any = false;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      act[l] = !(c[l]->done | c[l]->skip);
+      ca[l] = c[l]->ca;
+      cb[l] = c[l]->cb;
+      any |= act[l];
+    }
+    if (!any) return;
+  }
+  __shared__ double prod[kSpmvNnz * NL];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int r0 = A.rowblk[L], r1 = A.rowblk[L + 1];
+  const int s = A.rowptr[r0], e = A.rowptr[r1];
+  const int nr = r1 - r0;
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+
+  if (e - s > kSpmvNnz) {
+    // one long row (nr == 1): every thread strides over it, no LDS staging
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    for (int i = s + tid; i < e; i += kBlock) {
+      const int c = A.colind[i];
+      const double v = A.vals[i];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] += v * x[(size_t)c * NL + l];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double t = block_sum(acc[l], red);
+      if (tid == 0 && act[l]) {
+        const double o = ca[l] * t + (cb[l] != 0.0 ? cb[l] * yin[(size_t)r0 * NL + l] : 0.0);
+        yout[(size_t)r0 * NL + l] = o;
+        sq[l] = o * o;
+      }
+    }
+  } else {
+    // phase 1: coalesced stream of the block's nonzeros -> products in LDS
+    constexpr int kPer = kSpmvNnz / kBlock;
+    int cidx[kPer];
+    double v[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = s + tid + k * kBlock;
+      const bool ok = i < e;
+      cidx[k] = ok ? A.colind[i] : -1;
+      v[k] = ok ? A.vals[i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (cidx[k] >= 0) {
+        const int j = tid + k * kBlock;
+        if (NL == 1) {
+          prod[j] = v[k] * x[cidx[k]];
+        } else {
+          const double2 xv = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+          *reinterpret_cast<double2*>(prod + 2 * j) = make_double2(v[k] * xv.x, v[k] * xv.y);
+        }
+      }
+    }
+    __syncthreads();
+    // phase 2: G lanes per row
+    int G = 1;
+    while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
+    const int rows_per_pass = kBlock / G;
+    const int g = tid / G, gl = tid % G;
+    for (int base = 0; base < nr; base += rows_per_pass) {
+      const int rr = base + g;
+      const bool valid = rr < nr;
+      double acc[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+      if (valid) {
+        const int a = A.rowptr[r0 + rr] - s, b = A.rowptr[r0 + rr + 1] - s;
+        for (int j = a + gl; j < b; j += G) {
+          if (NL == 1) {
+            acc[0] += prod[j];
+          } else {
+            const double2 pv = *reinterpret_cast<const double2*>(prod + 2 * j);
+            acc[0] += pv.x;
+            acc[NL - 1] += pv.y;
+          }
+        }
+      }
+      for (int off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) acc[l] += __shfl_down(acc[l], off, 64);
+      }
+      if (valid && gl == 0) {
+        const size_t row = (size_t)(r0 + rr);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          if (act[l]) {
+            const double o = ca[l] * acc[l] + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0);
+            yout[row * NL + l] = o;
+            sq[l] += o * o;
+          }
+        }
+      }
+    }
+  }
+  if (partials != nullptr) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double t = block_sum(sq[l], red);
+      if (tid == 0) partials[(size_t)l * A.nblk + L] = t;
+    }
+  }
+}
+
+// vals_out[t] = vals_in[perm[t]]  (refresh of the A' copy when the Jacobian values change)
+__global__ __launch_bounds__(kBlock) void k_gather(const double* __restrict__ in, const int32_t* __restrict__ perm,
+                                                   double* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = in[perm[i]];
+}
+
+// CSR slot value = sum of the COO entries that map to it, in sorted (fixed) order: duplicates are summed like
+// SparseArrays.sparse does, deterministically.
+__global__ __launch_bounds__(kBlock) void k_gather_sum(const double* __restrict__ coo, const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ slotptr, double* __restrict__ out,
+                                                       int64_t nslots) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nslots; i += (int64_t)gridDim.x * kBlock) {
+    double s = 0.0;
+    for (int k = slotptr[i]; k < slotptr[i + 1]; ++k) s += coo[perm[k]];
+    out[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ vector kernels
+
+// dst[i][lane] = src[i] (plain -> interleaved lane), with the squared-norm partial of what was stored
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_load_lane(const double* __restrict__ src, double scale, double* dst,
+                                                      int lane, int64_t n, double* partials) {
+  __shared__ double red[4];
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double v = scale * src[i];
+    dst[i * NL + lane] = v;
+    sq += v * v;
+  }
+  const double t = block_sum(sq, red);
+  if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
+}
+
+// out[i] = a * x[i][lane] + b * y[i]   (de-interleave with an affine combination; y may be null when b == 0)
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_store_lane(const double* __restrict__ x, int lane, double a,
+                                                       const double* y, double b, double* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = a * x[i * NL + lane] + (b != 0.0 ? b * y[i] : 0.0);
+}
+
+// LSQR direction/solution update (Krylov.jl lsqr!: x += (phi/rho) w; w = v - (theta/rho) w) with v = vt / alpha
+// deferred, plus the partial of ||w_new||^2 that the next iteration's dNorm^2 needs.
+//   e[0] = phi/rho, e[1] = theta/rho, e[2] = 1/alpha
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_lsqr_update(const LaneCtl* ctl, int it, const double* __restrict__ vt,
+                                                        int lane, double* x, double* w, int64_t n, double* partials) {
+  if (ctl->done && ctl->upd_iter != it) return;
+  __shared__ double red[4];
+  const double sg = ctl->e[0], tr = ctl->e[1], ia = ctl->e[2];
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double wi = w[i];
+    x[i] += sg * wi;
+    const double wn = vt[i * NL + lane] * ia - tr * wi;
+    w[i] = wn;
+    sq += wn * wn;
+  }
+  const double t = block_sum(sq, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// w = vt / alpha (LSQR start: w_1 = v_1), partial of ||w||^2.  e[2] = 1/alpha
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_lsqr_winit(const LaneCtl* ctl, const double* __restrict__ vt, int lane,
+                                                       double* w, int64_t n, double* partials) {
+  if (ctl->done) return;
+  __shared__ double red[4];
+  const double ia = ctl->e[2];
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double wn = vt[i * NL + lane] * ia;
+    w[i] = wn;
+    sq += wn * wn;
+  }
+  const double t = block_sum(sq, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// CRAIG updates (Krylov.jl craig!), long (n) part.  `xs` accumulates s * x (s = -1 gives p2 = -x directly,
+// src/solve_linear_system.jl:133).  With v = vt / alpha and the true w2 = omega * w2s (scaling by s2 deferred):
+//   lambda > 0:  xs += e0 * vt + e1 * w2s;   w2s = e2 * vt + e3 * w2s
+//       e0 = s xi c1 / alpha, e1 = s xi s1 omega, e2 = s1 / alpha, e3 = -c1 omega
+//   lambda = 0:  xs += e0 * vt                      (e0 = s xi / alpha)
+template <int NL, bool REG>
+__global__ __launch_bounds__(kBlock) void k_craig_update_long(const LaneCtl* ctl, int it, const double* __restrict__ vt,
+                                                              int lane, double* xs, double* w2s, int64_t n) {
+  if (ctl->done && ctl->upd_iter != it) return;
+  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double v = vt[i * NL + lane];
+    if (REG) {
+      const double w2 = w2s[i];
+      xs[i] += e0 * v + e1 * w2;
+      w2s[i] = e2 * v + e3 * w2;
+    } else {
+      xs[i] += e0 * v;
+    }
+  }
+}
+
+// CRAIG updates, short (m) part:  w = u - (theta/rho_prev) w with u = e4 * mut (= mu Mu~ / beta);  y += e6 * w;
+// partial of ||w||^2.   e4 = mu/beta, e5 = theta/rho_prev, e6 = xi/rho
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_craig_update_short(const LaneCtl* ctl, int it, const double* __restrict__ mut,
+                                                               int lane, double* w, double* y, int64_t m,
+                                                               double* partials) {
+  if (ctl->done && ctl->upd_iter != it) return;
+  __shared__ double red[4];
+  const double e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6];
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double wn = e4 * mut[i * NL + lane] - e5 * w[i];
+    w[i] = wn;
+    y[i] += e6 * wn;
+    sq += wn * wn;
+  }
+  const double t = block_sum(sq, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ---- equality-QP user model + penalty epilogues (src/model-Fletcherpenaltynlp.jl:238-248, 385-397, 419-433)
+
+// g = q .* x + d ;  partial of f = sum x (q x / 2 + d) ;  partial of ||x - xk||^2 when xk != null
+__global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q, const double* __restrict__ d,
+                                                    const double* __restrict__ x, const double* xk, double* g,
+                                                    int64_t n, double* pf, double* pdx) {
+  __shared__ double red[4];
+  double f = 0.0, dx2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double xi = x[i], qi = q[i], di = d[i];
+    g[i] = qi * xi + di;
+    f += xi * (0.5 * qi * xi + di);
+    if (xk) {
+      const double t = xi - xk[i];
+      dx2 += t * t;
+    }
+  }
+  const double tf = block_sum(f, red);
+  if (threadIdx.x == 0) pf[blockIdx.x] = tf;
+  const double td = block_sum(dx2, red);
+  if (threadIdx.x == 0) pdx[blockIdx.x] = td;
+}
+
+// ys = q1 + sigma q2 ; partials of c'ys and c'c            (m-vectors)
+__global__ __launch_bounds__(kBlock) void k_ys(const double* __restrict__ q1, const double* __restrict__ q2,
+                                               const double* __restrict__ c, double sigma, double* ys, int64_t m,
+                                               double* pcy, double* pcc) {
+  __shared__ double red[4];
+  double cy = 0.0, cc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const double y = q1[i] + sigma * q2[i];
+    ys[i] = y;
+    if (c) {
+      const double ci = c[i];
+      cy += ci * y;
+      cc += ci * ci;
+    }
+  }
+  if (pcy) {
+    const double a = block_sum(cy, red);
+    if (threadIdx.x == 0) pcy[blockIdx.x] = a;
+    const double b = block_sum(cc, red);
+    if (threadIdx.x == 0) pcc[blockIdx.x] = b;
+  }
+}
+
+// gs = p1 + sigma p2                                        (n-vectors; v aliases p2)
+__global__ __launch_bounds__(kBlock) void k_gs(const double* __restrict__ p1, const double* __restrict__ p2,
+                                               double sigma, double* gs, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    gs[i] = p1[i] + sigma * p2[i];
+}
+
+// QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2
+__global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __restrict__ p1, const double* __restrict__ v,
+                                                            const double* __restrict__ q, const double* jc,
+                                                            const double* x, const double* xk, double sigma,
+                                                            double rho, double eta, double* gs, double* gx,
+                                                            int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double vi = v[i];
+    const double gsi = p1[i] + sigma * vi;
+    gs[i] = gsi;
+    double g = gsi - q[i] * vi + sigma * vi;
+    if (rho > 0.0) g += jc[i] * rho;
+    if (eta > 0.0) g += eta * (x[i] - xk[i]);
+    gx[i] = g;
+  }
+}
+
+}  // namespace fpsq

@@ -1,0 +1,442 @@
+// fpsq_krylov.hip.h -- device-resident scalar recurrences of LSQR / CRAIG / MINRES.
+//
+// Each Krylov recurrence ("lane") keeps ALL of its scalars (Golub-Kahan alpha/beta, Givens state, norm estimates,
+// stopping tests) in one device struct.  After every product kernel a one-workgroup "scalar step" kernel reduces
+// that product's norm partials in a fixed order, advances the recurrences, writes the coefficients the next
+// vector kernels will read (LaneCtl) and, once a stopping test fires, raises `done`: every later kernel of the lane
+// then exits at its first instruction.  The host never reads a scalar inside the loop; it only watches a progress
+// word in host-mapped memory to bound how far ahead it enqueues.
+//
+// Algorithms: Paige & Saunders LSQR (1982) and MINRES (1975), Craig's method in the Golub-Kahan form with the SQD
+// extension of Arioli & Orban; stopping rules and variable names follow Krylov.jl 0.10 (lsqr!, craig!, minres!),
+// which is what the reference calls (src/solve_two_systems_struct.jl:173-181, :217-239;
+// src/solve_linear_system.jl:60-70).  Vector normalisations are DEFERRED: the stored Golub-Kahan vectors are
+// beta*u / alpha*v and the 1/alpha, 1/beta factors ride in the coefficients of the next fused kernel.
+#pragma once
+#include "fpsq_kernels.hip.h"
+#include "../../include/fpsq.h"
+
+namespace fpsq {
+
+struct Progress {  // host-mapped, written by the device, polled by the host
+  int32_t iter;
+  int32_t done;
+};
+
+__device__ __forceinline__ void publish(Progress* p, int iter, int done) {
+  __hip_atomic_store(&p->iter, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&p->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+}
+
+__device__ __forceinline__ double dsign(double a) { return (double)((a > 0.0) - (a < 0.0)); }
+
+// Symmetric Givens reflection [c s; s -c][a; b] = [rho; 0] (Choi's SymOrtho, as Krylov.jl's sym_givens)
+__device__ __forceinline__ void sym_givens(double a, double b, double& c, double& s, double& rho) {
+  if (b == 0.0) {
+    c = (a == 0.0) ? 1.0 : dsign(a);
+    s = 0.0;
+    rho = fabs(a);
+  } else if (a == 0.0) {
+    c = 0.0;
+    s = dsign(b);
+    rho = fabs(b);
+  } else if (fabs(b) > fabs(a)) {
+    const double t = a / b;
+    s = dsign(b) / sqrt(1.0 + t * t);
+    c = s * t;
+    rho = b / s;
+  } else {
+    const double t = b / a;
+    c = dsign(a) / sqrt(1.0 + t * t);
+    s = c * t;
+    rho = a / c;
+  }
+}
+
+// =============================================================================================== LSQR
+// min ||b - Bx||^2 + lambda^2 ||x||^2.  In the reference B = A' (n x m): "long" u in R^n, "short" v, w, x in R^m.
+struct LsqrState {
+  LaneCtl ctl;
+  // parameters
+  double lambda, atol, rtol, axtol, btol, etol, ctol;
+  int64_t itmax;
+  // recurrences
+  double alpha, beta, beta1, Anorm2, dNorm2, xNorm2, c2, s2, z, xENorm2, phibar, rhobar, res2, ArNorm0;
+  double err_vec[5];
+  int32_t iter;
+  int32_t pad;
+  fpsq_stats stats;
+};
+
+__device__ __forceinline__ void lane_finish(LaneCtl& c, int it) {
+  c.done = 1;
+  c.upd_iter = it;
+}
+
+// after u~ = b: beta1 = ||b||
+__global__ __launch_bounds__(kBlock) void k_lsqr_begin(LsqrState* S, const double* pb, int npb, Progress* prog) {
+  __shared__ double red[4];
+  const double bb = reduce_partials(pb, npb, red);
+  if (threadIdx.x != 0) return;
+  const double beta1 = sqrt(bb);
+  S->beta1 = beta1;
+  S->beta = beta1;
+  S->iter = 0;
+  S->ctl.skip = 0;
+  S->ctl.upd_iter = -1;
+  S->stats = fpsq_stats{0, 0, 0, FPSQ_ST_UNKNOWN, beta1, 0.0};
+  if (beta1 == 0.0) {
+    S->stats.solved = 1;
+    S->stats.status = FPSQ_ST_ZERO_RHS;
+    S->ctl.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  S->ctl.done = 0;
+  S->ctl.ca = 1.0 / beta1;  // v~_1 = B' u~_1 / beta1
+  S->ctl.cb = 0.0;
+  publish(prog, 0, 0);
+}
+
+// after v~_1 = B'u_1: alpha_1 = ||v~_1||; start-up tests of lsqr!
+__global__ __launch_bounds__(kBlock) void k_lsqr_begin2(LsqrState* S, const double* pa, int npa, Progress* prog) {
+  if (S->ctl.done) return;
+  __shared__ double red[4];
+  const double aa = reduce_partials(pa, npa, red);
+  if (threadIdx.x != 0) return;
+  const double alpha = sqrt(aa), beta1 = S->beta1;
+  S->alpha = alpha;
+  S->Anorm2 = aa;
+  S->dNorm2 = 0.0;
+  S->xNorm2 = 0.0;
+  S->c2 = -1.0;
+  S->s2 = 0.0;
+  S->z = 0.0;
+  S->xENorm2 = 0.0;
+  S->res2 = 0.0;
+  for (int i = 0; i < 5; ++i) S->err_vec[i] = 0.0;
+  const double ArNorm = alpha * beta1;
+  S->ArNorm0 = ArNorm;
+  S->stats.arnorm = ArNorm;
+  if (alpha == 0.0) {
+    S->stats.solved = 1;
+    S->stats.status = FPSQ_ST_ZERO_ATB;
+    S->stats.arnorm = 0.0;
+    S->ctl.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  S->phibar = beta1;
+  S->rhobar = alpha;
+  const double Anorm = alpha, rNorm = beta1;
+  const bool solved = (ArNorm / (Anorm * rNorm) <= S->axtol) | (1.0 + ArNorm / (Anorm * rNorm) <= 1.0);
+  const bool tired = 0 >= S->itmax;
+  if (solved | tired) {
+    S->stats.solved = solved;
+    S->stats.inconsistent = 1;
+    S->stats.status = solved ? FPSQ_ST_SOLVED : FPSQ_ST_MAXITER;
+    S->ctl.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  S->ctl.e[2] = 1.0 / alpha;     // w_1 = v_1 = v~_1 / alpha
+  S->ctl.ca = 1.0 / alpha;       // u~_2 = B v~_1 / alpha - (alpha / beta) u~_1
+  S->ctl.cb = -alpha / beta1;
+}
+
+// after u~ <- B v - alpha u: beta = ||u~||
+__global__ __launch_bounds__(kBlock) void k_lsqr_sa(LsqrState* S, const double* pb, int npb) {
+  if (S->ctl.done) return;
+  __shared__ double red[4];
+  const double bb = reduce_partials(pb, npb, red);
+  if (threadIdx.x != 0) return;
+  const double beta = sqrt(bb), alpha = S->alpha;
+  S->beta = beta;
+  if (beta != 0.0) {
+    S->Anorm2 += alpha * alpha + beta * beta;
+    if (S->lambda > 0.0) S->Anorm2 += S->lambda * S->lambda;
+    S->ctl.ca = 1.0 / beta;  // v~ <- B'u~ / beta - (beta / alpha) v~
+    S->ctl.cb = -beta / alpha;
+    S->ctl.skip = 0;
+  } else {
+    S->ctl.skip = 1;  // u = 0: lsqr! skips the second half-step, alpha and v stay
+  }
+}
+
+// after v~ <- B'u - beta v: alpha = ||v~||, then the QR update, norm estimates and stopping tests of lsqr!
+__global__ __launch_bounds__(kBlock) void k_lsqr_sb(LsqrState* S, const double* pa, int npa, const double* pww,
+                                                    int npww, int it, Progress* prog) {
+  if (S->ctl.done) return;
+  __shared__ double red[4];
+  const double aa = reduce_partials(pa, npa, red);
+  const double ww = reduce_partials(pww, npww, red);
+  if (threadIdx.x != 0) return;
+  const double beta = S->beta, lambda = S->lambda;
+  double alpha = S->alpha;
+  if (!S->ctl.skip) alpha = sqrt(aa);
+  S->alpha = alpha;
+  S->ctl.skip = 0;
+  S->iter = it;
+
+  double c1, s1, rhobar1;
+  sym_givens(S->rhobar, lambda, c1, s1, rhobar1);
+  const double psi = s1 * S->phibar;
+  double phibar = c1 * S->phibar;
+  double c, s, rho;
+  sym_givens(rhobar1, beta, c, s, rho);
+  const double phi = c * phibar;
+  phibar = s * phibar;
+  S->phibar = phibar;
+
+  S->xENorm2 += phi * phi;
+  S->err_vec[it % 5] = phi;
+  double err_lbnd = 0.0;
+  if (it >= 5) {
+    double t = 0.0;
+    for (int i = 0; i < 5; ++i) t += S->err_vec[i] * S->err_vec[i];
+    err_lbnd = sqrt(t);
+  }
+  const double tau = s * phi;
+  const double theta = s * alpha;
+  S->rhobar = -c * alpha;
+  S->dNorm2 += ww / (rho * rho);
+
+  // coefficients of the update kernel and of the next first half-step
+  S->ctl.e[0] = phi / rho;
+  S->ctl.e[1] = theta / rho;
+  S->ctl.e[2] = (alpha != 0.0) ? 1.0 / alpha : 0.0;
+  S->ctl.ca = (alpha != 0.0) ? 1.0 / alpha : 0.0;
+  S->ctl.cb = (beta != 0.0) ? -alpha / beta : 0.0;
+
+  const double delta = S->s2 * rho;
+  const double gammabar = -S->c2 * rho;
+  const double rhs = phi - delta * S->z;
+  const double zbar = rhs / gammabar;
+  const double xNorm = sqrt(S->xNorm2 + zbar * zbar);
+  double c2, s2, gamma;
+  sym_givens(gammabar, theta, c2, s2, gamma);
+  S->c2 = c2;
+  S->s2 = s2;
+  S->z = rhs / gamma;
+  S->xNorm2 += S->z * S->z;
+
+  const double Anorm = sqrt(S->Anorm2);
+  const double Acond = Anorm * sqrt(S->dNorm2);
+  const double res1 = phibar * phibar;
+  S->res2 += psi * psi;
+  const double rNorm = sqrt(res1 + S->res2);
+  const double ArNorm = alpha * fabs(tau);
+  const double beta1 = S->beta1;
+
+  const double test1 = rNorm / beta1;
+  const double test2 = ArNorm / (Anorm * rNorm);
+  const double test3 = 1.0 / Acond;
+  const double t1 = test1 / (1.0 + Anorm * xNorm / beta1);
+  const double rNormtol = S->btol + S->axtol * Anorm * xNorm / beta1;
+
+  const bool ill_cond_mach = (1.0 + test3 <= 1.0);
+  const bool solved_mach = (1.0 + test2 <= 1.0);
+  const bool zero_resid_mach = (1.0 + t1 <= 1.0);
+  const bool tired = it >= S->itmax;
+  const bool ill_cond_lim = (test3 <= S->ctol);
+  const bool solved_lim = (test2 <= S->axtol);
+  const bool solved_opt = ArNorm <= S->atol + S->rtol * S->ArNorm0;
+  const bool zero_resid_lim = (test1 <= rNormtol);
+  const bool fwd_err = (it >= 5) && (err_lbnd <= S->etol * sqrt(S->xENorm2));
+  const bool ill_cond = ill_cond_mach | ill_cond_lim;
+  const bool zero_resid = zero_resid_mach | zero_resid_lim;
+  const bool solved = solved_mach | solved_lim | solved_opt | zero_resid | fwd_err;
+
+  S->stats.niter = it;
+  S->stats.rnorm = rNorm;
+  S->stats.arnorm = ArNorm;
+  if (solved | tired | ill_cond) {
+    int status = FPSQ_ST_UNKNOWN;
+    if (tired) status = FPSQ_ST_MAXITER;
+    if (ill_cond) status = FPSQ_ST_ILL_COND;
+    if (solved) status = FPSQ_ST_SOLVED;
+    if (zero_resid) status = FPSQ_ST_ZERO_RESID;
+    if (fwd_err) status = FPSQ_ST_FWD_ERR;
+    S->stats.status = status;
+    S->stats.solved = solved;
+    S->stats.inconsistent = !zero_resid;
+    lane_finish(S->ctl, it);
+    publish(prog, it, 1);
+  } else {
+    publish(prog, it, 0);
+  }
+}
+
+// =============================================================================================== CRAIG
+// min ||x|| s.t. Bx = b; with delta != 0 the reference passes M = (1/delta) I and sqd = true
+// (src/solve_two_systems_struct.jl:216-228): [-I B'; B delta I][x; y] = [0; b].  B = A (m x n):
+// "short" Mu~, w, y in R^m, "long" v~, x, w2 in R^n.  mu = 1/delta (or 1), lambda = 1 (or 0).
+struct CraigState {
+  LaneCtl ctl;
+  double mu, lambda, atol, rtol, btol, ctol, xsign;
+  int64_t itmax;
+  double alpha, beta, beta1, theta, xi, deltag, rho_prev, omega, c1, s1, rho;
+  double Anorm2, Dnorm2, xNorm2, eps_c;
+  int32_t iter;
+  int32_t pad;
+  fpsq_stats stats;
+};
+
+// after Mu~ = b: beta1 = sqrt(mu) ||b||
+__global__ __launch_bounds__(kBlock) void k_craig_begin(CraigState* S, const double* pb, int npb, Progress* prog) {
+  __shared__ double red[4];
+  const double bb = reduce_partials(pb, npb, red);
+  if (threadIdx.x != 0) return;
+  const double beta1 = sqrt(S->mu * bb);
+  S->beta1 = beta1;
+  S->beta = beta1;
+  S->theta = beta1;
+  S->xi = -1.0;
+  S->deltag = S->lambda;
+  S->rho_prev = 1.0;
+  S->omega = 1.0;
+  S->c1 = 1.0;
+  S->s1 = 0.0;
+  S->Anorm2 = 0.0;
+  S->Dnorm2 = 0.0;
+  S->xNorm2 = 0.0;
+  S->iter = 0;
+  S->ctl.skip = 0;
+  S->ctl.upd_iter = -1;
+  S->stats = fpsq_stats{0, 0, 0, FPSQ_ST_UNKNOWN, beta1, 0.0};
+  if (beta1 == 0.0) {
+    S->stats.solved = 1;
+    S->stats.status = FPSQ_ST_ZERO_RHS;
+    S->ctl.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  S->eps_c = S->atol + S->rtol * beta1;
+  // start-up tests of craig! (bkwerr = 1, Anorm = xNorm = 0)
+  const bool solved = (1.0 <= S->btol) | (beta1 <= S->eps_c) | (beta1 <= S->btol);
+  const bool tired = 0 >= S->itmax;
+  if (solved | tired) {
+    S->stats.solved = solved;
+    S->stats.status = solved ? FPSQ_ST_SOLVED : FPSQ_ST_MAXITER;
+    S->ctl.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  S->ctl.done = 0;
+  S->ctl.ca = S->mu / beta1;  // v~_1 = B'u_1 = (mu / beta1) B' Mu~
+  S->ctl.cb = 0.0;            // Nv_0 = 0
+  publish(prog, 0, 0);
+}
+
+// after v~ <- B'u - beta v: alpha = ||v~||, first Givens, xi; coefficients of the x / w2 / w / y updates
+__global__ __launch_bounds__(kBlock) void k_craig_sa(CraigState* S, const double* pa, int npa, int it, Progress* prog) {
+  if (S->ctl.done) return;
+  __shared__ double red[4];
+  const double aa = reduce_partials(pa, npa, red);
+  if (threadIdx.x != 0) return;
+  const double alpha = sqrt(aa);
+  if (alpha == 0.0) {  // craig!: inconsistent = true; leave the loop without touching x, y
+    S->stats.inconsistent = 1;
+    S->stats.solved = 0;
+    S->stats.status = FPSQ_ST_INCONSISTENT;
+    S->stats.niter = S->iter;
+    S->ctl.done = 1;
+    S->ctl.upd_iter = -1;
+    publish(prog, it, 1);
+    return;
+  }
+  S->alpha = alpha;
+  const double lambda = S->lambda;
+  S->Anorm2 += alpha * alpha + lambda * lambda;
+  double c1 = 1.0, s1 = 0.0, rho = alpha;
+  if (lambda > 0.0) sym_givens(alpha, S->deltag, c1, s1, rho);
+  S->c1 = c1;
+  S->s1 = s1;
+  S->rho = rho;
+  const double xi = -S->theta / rho * S->xi;
+  S->xi = xi;
+  const double sx = S->xsign;
+  if (lambda > 0.0) {
+    S->ctl.e[0] = sx * xi * c1 / alpha;
+    S->ctl.e[1] = sx * xi * s1 * S->omega;
+    S->ctl.e[2] = s1 / alpha;
+    S->ctl.e[3] = -c1 * S->omega;
+  } else {
+    S->ctl.e[0] = sx * xi / alpha;
+    S->ctl.e[1] = S->ctl.e[2] = S->ctl.e[3] = 0.0;
+  }
+  S->ctl.e[4] = S->mu / S->beta;          // u = mu Mu~ / beta
+  S->ctl.e[5] = S->theta / S->rho_prev;
+  S->ctl.e[6] = xi / rho;
+  S->ctl.upd_iter = it;                    // the updates of this iteration always run
+  S->ctl.ca = 1.0 / alpha;                 // Mu~ <- B v~ / alpha - (alpha / beta) Mu~
+  S->ctl.cb = -alpha / S->beta;
+}
+
+// after Mu~ <- B v - alpha Mu: beta, second Givens, estimates and the stopping tests of craig!
+__global__ __launch_bounds__(kBlock) void k_craig_sb(CraigState* S, const double* pb, int npb, const double* pww,
+                                                     int npww, int it, Progress* prog) {
+  if (S->ctl.done) return;
+  __shared__ double red[4];
+  const double bb = reduce_partials(pb, npb, red);
+  const double ww = reduce_partials(pww, npww, red);
+  if (threadIdx.x != 0) return;
+  const double lambda = S->lambda, alpha = S->alpha;
+  S->Dnorm2 += sqrt(ww);  // craig! accumulates ||w||, not ||w||^2
+  const double beta = sqrt(S->mu * bb);
+  S->beta = beta;
+  double theta = beta;
+  if (lambda > 0.0) {
+    theta = beta * S->c1;
+    const double gamma = beta * S->s1;
+    double c2, s2, dg;
+    sym_givens(lambda, gamma, c2, s2, dg);
+    S->deltag = dg;
+    S->omega = s2;  // w2 <- s2 w2, applied lazily by the next update
+  }
+  S->theta = theta;
+  S->Anorm2 += beta * beta;
+  const double Anorm = sqrt(S->Anorm2);
+  const double Acond = Anorm * sqrt(S->Dnorm2);
+  S->xNorm2 += S->xi * S->xi;
+  const double xNorm = sqrt(S->xNorm2);
+  double rNorm = beta * fabs(S->xi);
+  if (lambda > 0.0) rNorm *= fabs(S->c1);
+  S->iter = it;
+  const double beta1 = S->beta1;
+  const double bkwerr = rNorm / sqrt(beta1 * beta1 + S->Anorm2 * S->xNorm2);
+  S->rho_prev = S->rho;
+  (void)alpha;
+
+  const bool solved_lim = bkwerr <= S->btol;
+  const bool solved_mach = 1.0 + bkwerr <= 1.0;
+  const bool solved_resid_tol = rNorm <= S->eps_c;
+  const bool solved_resid_lim = rNorm <= S->btol + S->atol * Anorm * xNorm / beta1;
+  const bool solved = solved_mach | solved_lim | solved_resid_tol | solved_resid_lim;
+  const bool ill_cond_mach = 1.0 + 1.0 / Acond <= 1.0;
+  const bool ill_cond_lim = 1.0 / Acond <= S->ctol;
+  const bool ill_cond = ill_cond_mach | ill_cond_lim;
+  const bool tired = it >= S->itmax;
+
+  S->stats.niter = it;
+  S->stats.rnorm = rNorm;
+  // next first half-step: v~ <- (mu / beta) B' Mu~ - (beta / alpha) v~
+  S->ctl.ca = (beta != 0.0) ? S->mu / beta : 0.0;
+  S->ctl.cb = -beta / alpha;
+  if (solved | ill_cond | tired) {
+    int status = FPSQ_ST_UNKNOWN;
+    if (tired) status = FPSQ_ST_MAXITER;
+    if (solved) status = FPSQ_ST_SOLVED;
+    if (ill_cond) status = FPSQ_ST_ILL_COND;
+    S->stats.status = status;
+    S->stats.solved = solved;
+    S->stats.inconsistent = 0;
+    S->ctl.done = 1;
+    publish(prog, it, 1);
+  } else {
+    publish(prog, it, 0);
+  }
+}
+
+}  // namespace fpsq

@@ -1,0 +1,101 @@
+"""Host-side mirror of `FletcherPenaltyNLP` (src/model-Fletcherpenaltynlp.jl:58-103) -- the hot part only:
+`_compute_ys_gs!` (:234-252), `obj` (:352-370), `grad!` (:372-401), `objgrad!` (:403-437).  The Hessian part
+(hprod!/hess_coord!) is the next row of SURVEY.md §8f and is not built yet.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .qdsolver import HIPQDSolver, QDSolver
+
+
+class FletcherPenaltyNLP:
+    """FletcherPenaltyNLP(nlp, sigma, rho, delta, hessian_approx; qds = HIPQDSolver(nlp, 0.0))
+
+    Defaults follow the keyword constructor at :194-204 (sigma_0 = 1, rho_0 = delta_0 = 0, Val(2)); the
+    reference's default `qds` is the CPU LDLtSolver (:113), here it is the MI355X back-end."""
+
+    def __init__(self, nlp, sigma=1.0, rho=0.0, delta=0.0, hessian_approx=2, x0=None, *, qds: QDSolver | None = None):
+        self.nlp = nlp
+        self.sigma, self.rho, self.delta, self.eta = sigma, rho, delta, 0.0
+        self.hessian_approx = hessian_approx
+        n, m = nlp.meta.nvar, nlp.meta.ncon
+        self.meta = type(nlp.meta)(nvar=n, ncon=0, x0=np.asarray(nlp.meta.x0 if x0 is None else x0, float),
+                                   name=f"Fletcher penalization of {nlp.meta.name}")
+        self.qdsolver = qds if qds is not None else HIPQDSolver(nlp, 0.0)
+        self.shahx = None
+        self.fx = float("nan")
+        self.cx, self.gx = np.empty(m), np.empty(n)
+        self.ys, self.gs = np.empty(m), np.empty(n)
+        self.v, self.w = np.empty(n), np.empty(m)
+        self.xk = np.zeros(n)
+        self.counters = dict(neval_obj=0, neval_grad=0)
+
+    # :260-269
+    def cons_norhs(self, x):
+        return self.nlp.cons(x) - self.nlp.meta.lcon
+
+    # :215-227
+    def linear_system2(self, x):
+        return self.qdsolver.solve_two_mixed(self, x, self.gx, self.cx)
+
+    # :234-252.  The reference memoises on Julia's hash(x); the key here is the full byte content.
+    def _compute_ys_gs(self, x):
+        key = hash(np.asarray(x, float).tobytes())
+        if key != self.shahx:
+            self.shahx = key
+            self.fx = self.nlp.obj(x)
+            self.gx[:] = self.nlp.grad(x)
+            self.cx[:] = self.cons_norhs(x)
+            p1, q1, p2, q2 = self.linear_system2(x)
+            self.gs[:] = p1 + self.sigma * p2
+            self.ys[:] = q1 + self.sigma * q2
+            self.v[:] = p2
+            self.w[:] = q2
+        return self.gs, self.ys, self.v, self.w
+
+    # :352-370
+    def obj(self, x):
+        x = np.asarray(x, float)
+        assert x.size == self.meta.nvar
+        self.counters["neval_obj"] += 1
+        self._compute_ys_gs(x)
+        c = self.cx
+        fx = self.fx - c @ self.ys + self.rho / 2 * (c @ c)
+        if self.eta > 0.0:
+            fx += self.eta / 2 * np.linalg.norm(x - self.xk) ** 2
+        return fx
+
+    # :372-401  (grad!)
+    def grad_(self, x, gx):
+        x = np.asarray(x, float)
+        assert x.size == self.meta.nvar and gx.size == self.meta.nvar
+        self.counters["neval_grad"] += 1
+        gs, ys, v, w = self._compute_ys_gs(x)
+        Hsv = self.nlp.hprod(x, ys, v, obj_weight=1.0)
+        Sstw = self.nlp.hprod(x, w, gs, obj_weight=0.0)
+        gx[:] = gs - Hsv + self.sigma * v + Sstw
+        if self.rho > 0.0:
+            gx += self.nlp.jtprod(x, self.cx) * self.rho
+        if self.eta > 0.0:
+            gx += self.eta * (x - self.xk)
+        return gx
+
+    def grad(self, x):
+        return self.grad_(x, np.empty(self.meta.nvar))
+
+    # :403-437  (objgrad!)
+    def objgrad_(self, x, gx):
+        x = np.asarray(x, float)
+        self.counters["neval_obj"] += 1
+        self.grad_(x, gx)
+        c = self.cx
+        fx = self.fx - c @ self.ys
+        if self.rho > 0.0:
+            fx += self.rho / 2 * (c @ c)
+        if self.eta > 0.0:
+            fx += self.eta / 2 * np.linalg.norm(x - self.xk) ** 2
+        return fx, gx
+
+    def objgrad(self, x):
+        return self.objgrad_(x, np.empty(self.meta.nvar))

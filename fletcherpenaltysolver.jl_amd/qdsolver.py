@@ -1,0 +1,144 @@
+"""Host-side mirror of the reference's QDSolver plug-in seam, backed by libfpsq (MI355X).
+
+Reference: src/solve_two_systems_struct.jl:16 (`abstract type QDSolver`), the three generic functions
+`solve_two_extras` / `solve_two_least_squares` / `solve_two_mixed` (src/solve_linear_system.jl:9,25,43) and the
+constructor contract `QDS(nlp, ::T; explicit_linear_constraints = false, kwargs...)` (struct.jl:94-98, call site
+src/parameters.jl:299).  Same names, same argument meaning, same error behaviour (numerical failure only warns).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+
+
+class QDSolver:
+    """Abstract back-end for the two systems [I A'; A -delta I] (struct.jl:1-16)."""
+
+    def solve_two_extras(self, nlp, x, rhs1, rhs2):
+        raise NotImplementedError
+
+    def solve_two_least_squares(self, nlp, x, rhs1, rhs2):
+        raise NotImplementedError
+
+    def solve_two_mixed(self, nlp, x, rhs1, rhs2):
+        raise NotImplementedError
+
+
+class FpsqError(RuntimeError):
+    pass
+
+
+class HIPQDSolver(QDSolver):
+    """`HIPQDSolver(nlp, T(0); kwargs...)`: the MI355X back-end.  Keyword names are those of `IterativeSolver`
+    (struct.jl:99-115): ls_atol, ls_rtol, ls_itmax, ln_atol, ln_rtol, ln_btol, ln_conlim, ln_itmax, ne_atol, ne_rtol,
+    ne_etol, ne_itmax, ne_conlim; unknown keywords are swallowed like the reference's `kwargs...`."""
+
+    def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, **kwargs):
+        if explicit_linear_constraints:
+            raise NotImplementedError("explicit_linear_constraints=True is outside this build's hot-path scope")
+        self._lib = _lib.load()
+        self.nvar, self.ncon = int(nlp.meta.nvar), int(nlp.meta.ncon)
+        opts = _lib.Options()
+        self._lib.fpsq_default_options(self.nvar, self.ncon, C.byref(opts))
+        names = {f for f, _ in _lib.Options._fields_}
+        for k, v in kwargs.items():
+            if k in names:
+                setattr(opts, k, v)
+        self.opts = opts
+        h = C.c_void_p()
+        rc = self._lib.fpsq_create(C.byref(h), self.nvar, self.ncon, C.byref(opts))
+        if rc != 0:
+            raise FpsqError(self._lib.fpsq_last_error(None).decode())
+        self._h = h
+        # structure once, like LDLtSolver's jac_structure! (struct.jl:331-337); COO, 1-based like NLPModels
+        rows, cols = nlp.jac_structure()
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        self._check(self._lib.fpsq_set_jacobian_structure_coo(h, rows.size, rows.ctypes.data, cols.ctypes.data, 1))
+        self._delta = None
+        self.stats = (_lib.Stats * 2)()
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc < 0:
+            raise FpsqError(self._lib.fpsq_last_error(self._h).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fpsq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _refresh(self, nlp, x, values=True):
+        if values:
+            vals = np.ascontiguousarray(nlp.nlp.jac_coord(x), dtype=np.float64)
+            self._check(self._lib.fpsq_set_jacobian_values(self._h, vals.ctypes.data))
+        if self._delta != nlp.delta:
+            self._check(self._lib.fpsq_set_delta(self._h, float(nlp.delta)))
+            self._delta = nlp.delta
+
+    # -- the seam
+    def solve_two_mixed(self, nlp, x, rhs1, rhs2):
+        """p1, q1, p2, q2 = solve_two_mixed(nlp, x, rhs1, rhs2)   (src/solve_linear_system.jl:107-140)"""
+        self._refresh(nlp, x)  # the reference rebuilds nlp.Aop at x here (:118-122)
+        n, m = self.nvar, self.ncon
+        rhs1 = np.ascontiguousarray(rhs1, dtype=np.float64)
+        rhs2 = np.ascontiguousarray(rhs2, dtype=np.float64)
+        p1, q1, p2, q2 = np.empty(n), np.empty(m), np.empty(n), np.empty(m)
+        rc = self._check(self._lib.fpsq_solve_two_mixed(self._h, rhs1.ctypes.data, rhs2.ctypes.data, p1.ctypes.data,
+                                                        q1.ctypes.data, p2.ctypes.data, q2.ctypes.data, self.stats))
+        if rc & 1:
+            warnings.warn("Failed solving 1st linear system lsqr in mixed.")
+        if rc & 2:
+            warnings.warn("Failed solving 2nd linear system craig in mixed.")
+        return p1, q1, p2, q2
+
+    def solve_two_least_squares(self, nlp, x, rhs1, rhs2):
+        """p1, q1, p2, q2 = solve_two_least_squares(nlp, x, rhs1, rhs2)   (:79-105; Aop is NOT refreshed, :85-86)"""
+        self._refresh(nlp, x, values=False)
+        n, m = self.nvar, self.ncon
+        rhs1 = np.ascontiguousarray(rhs1, dtype=np.float64)
+        rhs2 = np.ascontiguousarray(rhs2, dtype=np.float64)
+        p1, q1, p2, q2 = np.empty(n), np.empty(m), np.empty(n), np.empty(m)
+        rc = self._check(self._lib.fpsq_solve_two_least_squares(self._h, rhs1.ctypes.data, rhs2.ctypes.data,
+                                                                p1.ctypes.data, q1.ctypes.data, p2.ctypes.data,
+                                                                q2.ctypes.data, self.stats))
+        if rc & 1:
+            warnings.warn("Failed solving 1st linear system lsqr.")
+        if rc & 2:
+            warnings.warn("Failed solving 2nd linear system lsqr.")
+        return p1, q1, p2, q2
+
+    def solve_two_extras(self, nlp, x, rhs1, rhs2):
+        """invJtJJv, invJtJSsv = solve_two_extras(nlp, x, rhs1, rhs2)   (:45-77)"""
+        self._refresh(nlp, x, values=False)
+        m = self.ncon
+        rhs1 = np.ascontiguousarray(rhs1, dtype=np.float64)
+        rhs2 = np.ascontiguousarray(rhs2, dtype=np.float64)
+        o1, o2 = np.empty(m), np.empty(m)
+        rc = self._check(self._lib.fpsq_solve_two_extras(self._h, rhs1.ctypes.data, rhs2.ctypes.data, o1.ctypes.data,
+                                                         o2.ctypes.data, self.stats))
+        if rc & 1:
+            warnings.warn("Failed solving 1st linear system lsqr in extra.")
+        if rc & 2:
+            warnings.warn("Failed solving 2nd linear system minres in extra.")
+        return o1, o2
+
+    def info(self):
+        i = _lib.Info()
+        self._check(self._lib.fpsq_get_info(self._h, C.byref(i)))
+        return i.as_dict()
+
+
+# src/parameters.jl:197 -- the registry fps_solve(...; qds_solver = :sym) looks back-ends up in
+qdsolver_correspondence = {"hip": HIPQDSolver}

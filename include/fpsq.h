@@ -1,0 +1,183 @@
+/*
+ * fpsq.h -- C ABI of libfpsq.so: the MI355X (gfx950) back-end for the two regularised KKT saddle-point
+ * solves  [I A'; A -delta I]  that FletcherPenaltySolver.jl performs on every obj/grad of FletcherPenaltyNLP.
+ *
+ * This is the drop-in boundary: what a `struct HIPQDSolver <: QDSolver` on the Julia side binds with `ccall`
+ * (see INTEGRATION.md).  Plain C, opaque handle, plain pointers and sizes; no C++/torch types.
+ * Reference = JuliaSmoothOptimizers/FletcherPenaltySolver.jl v0.3.0; citations are file:line in that repo.
+ *
+ * Conventions
+ *   n = nvar, m = number of penalised constraints, A = constraint Jacobian (m x n), fp64 throughout.
+ *   Every `double*` / index pointer argument may point to HOST or DEVICE memory; the library inspects it
+ *   (hipPointerGetAttributes) and stages host data itself.  Output buffers are CALLER-owned (the reference hands
+ *   out aliases of solver-owned buffers, src/solve_linear_system.jl:139; callers copy out immediately,
+ *   src/model-Fletcherpenaltynlp.jl:244-248, so caller-owned outputs are equivalent and remove the aliasing).
+ *   All calls are synchronous: on return the outputs are complete (the solver's stream has been synchronised).
+ *   One handle is non-re-entrant, exactly like one reference QDSolver (shared mutable workspaces).
+ *
+ * Return codes
+ *   0            success
+ *   > 0          soft numerical failure, bit 0: first system `solved == false`, bit 1: second system.  The
+ *                reference only `@warn`s in that case and returns what was computed
+ *                (src/solve_linear_system.jl:54-56,73-75,92-94,101-103,128-130,136-138); so does this library.
+ *   < 0          hard error (bad handle/argument, HIP/RCCL failure); message via fpsq_last_error().
+ */
+#ifndef FPSQ_H
+#define FPSQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fpsq_solver_s *fpsq_handle;
+
+enum {
+  FPSQ_OK = 0,
+  FPSQ_ERR_ARG = -1,
+  FPSQ_ERR_HIP = -2,
+  FPSQ_ERR_STATE = -3, /* e.g. solve before the Jacobian was set */
+  FPSQ_ERR_COMM = -4,
+  FPSQ_ERR_TIMEOUT = -5
+};
+
+/* Krylov termination status (Krylov.jl `stats.status` strings, as an enum) */
+enum {
+  FPSQ_ST_UNKNOWN = 0,
+  FPSQ_ST_ZERO_RHS = 1,     /* "x = 0 is a zero-residual solution" */
+  FPSQ_ST_ZERO_ATB = 2,     /* "x = 0 is a minimum least-squares solution" */
+  FPSQ_ST_SOLVED = 3,       /* tolerances met */
+  FPSQ_ST_ZERO_RESID = 4,   /* "found approximate zero-residual solution" */
+  FPSQ_ST_FWD_ERR = 5,      /* "truncated forward error small enough" */
+  FPSQ_ST_ILL_COND = 6,     /* condition number limit */
+  FPSQ_ST_MAXITER = 7,      /* "maximum number of iterations exceeded" */
+  FPSQ_ST_INCONSISTENT = 8  /* "system may be inconsistent" (CRAIG) */
+};
+
+/* The fields of Krylov.jl's `stats` that the reference reads
+ * (src/solve_two_systems_struct.jl:183,242,279; src/solve_linear_system.jl:71). */
+typedef struct {
+  int32_t solved;
+  int32_t inconsistent;
+  int32_t niter;
+  int32_t status;
+  double rnorm;  /* last residual-norm estimate */
+  double arnorm; /* last ||A'r|| estimate (LSQR, MINRES), 0 for CRAIG */
+} fpsq_stats;
+
+/* Replaces the keyword arguments of `IterativeSolver(nlp, ::T; ...)`, src/solve_two_systems_struct.jl:94-131.
+ * Same names, same defaults (fpsq_default_options). */
+typedef struct {
+  double ls_atol, ls_rtol; /* LSQR, :99-100 */
+  int64_t ls_itmax;        /* 5 (m + n), :101-103 */
+  double ln_atol, ln_rtol, ln_btol, ln_conlim; /* CRAIG, :104-107 */
+  int64_t ln_itmax;                            /* 5 (m + n), :108-110 */
+  double ne_atol, ne_rtol, ne_etol;            /* MINRES on A A' + tau I, :111-113 */
+  int64_t ne_itmax;                            /* 0 => 2 m, :114 */
+  double ne_conlim;                            /* :115 */
+  /* Krylov.jl lsqr! keywords the reference leaves at their defaults (sqrt(eps), 1/sqrt(eps)) */
+  double ls_axtol, ls_btol, ls_etol, ls_conlim;
+  /* execution knobs (no reference counterpart) */
+  int32_t fuse_two_rhs;  /* 1: run the two recurrences of a solve_two_* call in lock-step, one SpMM(k=2) per
+                            product instead of two SpMVs; results per system are identical to the unfused run */
+  int32_t lookahead;     /* Krylov iterations the host may enqueue ahead of the device's progress word */
+  int32_t device;        /* HIP device ordinal */
+  int32_t reserved;
+} fpsq_options;
+
+/* defaults of src/solve_two_systems_struct.jl:99-115 for an (n, m) problem; fuse_two_rhs = 1 */
+void fpsq_default_options(int64_t n, int64_t m, fpsq_options *opts);
+
+/* Replaces the constructor contract `QDS(nlp, ::T; kwargs...)` (src/solve_two_systems_struct.jl:94-98;
+ * call site src/parameters.jl:299).  `opts == NULL` => defaults. */
+int fpsq_create(fpsq_handle *out, int64_t n, int64_t m, const fpsq_options *opts);
+int fpsq_destroy(fpsq_handle h);
+const char *fpsq_last_error(fpsq_handle h); /* h may be NULL: error of the last failed fpsq_create */
+
+/* Jacobian sparsity, once per model.  Replaces `jac_structure!(nlp, rows, cols)` at
+ * src/solve_two_systems_struct.jl:331-337: COO triplets in the model's fixed order, `index_base` 1 for
+ * Julia.  Duplicates are allowed and are summed, as in SparseArrays.sparse (src/solve_linear_system.jl:233).
+ * Builds CSR(A), CSR(A') and the value permutations on the device. */
+int fpsq_set_jacobian_structure_coo(fpsq_handle h, int64_t nnz, const int64_t *rows, const int64_t *cols,
+                                    int32_t index_base);
+/* Same for a caller that already holds 0-based CSR (rowptr: m+1, colind: rowptr[m]); values then come in
+ * CSR order. */
+int fpsq_set_jacobian_structure_csr(fpsq_handle h, const int32_t *rowptr, const int32_t *colind);
+
+/* Jacobian values at the current x, in the order of the structure call.  Replaces `jac_coord!(nlp, x, vals)`
+ * at src/solve_linear_system.jl:223-228 and the per-x operator rebuild `jac_op!` at :118-122. */
+int fpsq_set_jacobian_values(fpsq_handle h, const double *vals);
+
+/* `nlp.delta`, mutated by the outer loop (src/algo.jl:389-393). */
+int fpsq_set_delta(fpsq_handle h, double delta);
+
+/* solve_two_mixed (src/solve_linear_system.jl:28-43, iterative method :107-140):
+ *   K [p1; q1] = [rhs1; 0],  K [p2; q2] = [0; rhs2];   rhs1: n, rhs2: m;  p*: n, q*: m.
+ * st[0] = LSQR stats, st[1] = CRAIG stats. */
+int fpsq_solve_two_mixed(fpsq_handle h, const double *rhs1, const double *rhs2, double *p1, double *q1,
+                         double *p2, double *q2, fpsq_stats st[2]);
+
+/* solve_two_least_squares (src/solve_linear_system.jl:12-25, :79-105):
+ *   K [p1; q1] = [rhs1; 0],  K [p2; q2] = [rhs2; 0];   rhs1, rhs2: n.  Uses the Jacobian of the last
+ *   fpsq_set_jacobian_values (the reference does not refresh `nlp.Aop` either, :85-86). */
+int fpsq_solve_two_least_squares(fpsq_handle h, const double *rhs1, const double *rhs2, double *p1, double *q1,
+                                 double *p2, double *q2, fpsq_stats st[2]);
+
+/* solve_two_extras (src/solve_linear_system.jl:2-9, :45-77), tau = max(delta, 1e-14):
+ *   out1 = argmin ||A'q - rhs1||^2 + tau ||q||^2  (LSQR, lambda = sqrt(tau)),  out2 = (A A' + tau I)^-1 rhs2 (MINRES).
+ *   rhs1: n, rhs2: m; out1, out2: m. */
+int fpsq_solve_two_extras(fpsq_handle h, const double *rhs1, const double *rhs2, double *out1, double *out2,
+                          fpsq_stats st[2]);
+
+/* Fused convenience for `_compute_ys_gs!` after the user-model evaluations
+ * (src/model-Fletcherpenaltynlp.jl:242-248): solve_two_mixed(g, c) then
+ *   gs = p1 + sigma p2, ys = q1 + sigma q2, v = p2, w = q2  in one epilogue kernel. */
+int fpsq_ys_gs(fpsq_handle h, const double *g, const double *c, double sigma, double *gs, double *ys, double *v,
+               double *w, fpsq_stats st[2]);
+
+/* y = alpha * op(A) x + beta * y with the handle's Jacobian; trans = 0: A (x: n, y: m), 1: A' (x: m, y: n).
+ * The device `jprod!` / `jtprod!` (e.g. the rho A'c term, src/model-Fletcherpenaltynlp.jl:388-395). */
+int fpsq_jac_mul(fpsq_handle h, int32_t trans, double alpha, const double *x, double beta, double *y);
+
+/* ---- device-resident equality-QP user model (the synthetic workloads of BASELINE.json):
+ *        f(x) = 1/2 x' diag(q) x + d'x,   c(x) = A x - b,   A = the handle's Jacobian.
+ * fpsq_qp_objgrad is one `objgrad!(::FletcherPenaltyNLP, x, gx)` at a fresh x
+ * (src/model-Fletcherpenaltynlp.jl:403-437) run entirely on the device: g, c, the two solves, the ys/gs
+ * epilogue, Hsv = q .* v (constraints are linear, so S(x,w) gs = 0), + rho A'c, + eta (x - xk).
+ * Any of gx, ys, gs may be NULL.  xk may be NULL when eta == 0. */
+typedef struct fpsq_qp_s *fpsq_qp;
+int fpsq_qp_create(fpsq_handle h, const double *qdiag, const double *d, const double *b, fpsq_qp *out);
+int fpsq_qp_destroy(fpsq_qp qp);
+int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double *x, double sigma, double rho, double eta,
+                    const double *xk, double *fx, double *gx, double *ys, double *gs, fpsq_stats st[2]);
+
+/* ---- multi-GPU: 1-D row sharding of A across ranks.  Each rank creates its handle with
+ * the GLOBAL n and its LOCAL m (its block of constraints), passes its local rows to set_jacobian_*, and
+ * m-vectors (rhs2, q1, q2, ys, w, c, b) are the rank's slices.  n-vectors are replicated.  Partial A'u
+ * products and m-vector dot products are all-reduced with RCCL on the solver's stream.
+ * fpsq_comm_unique_id fills a 128-byte id on rank 0; the caller broadcasts it and every rank calls
+ * fpsq_comm_init.  Without fpsq_comm_init the handle is single-GPU. */
+int fpsq_comm_unique_id(uint8_t id[128]);
+int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id[128]);
+
+/* ---- introspection for benchmarks / profiling */
+typedef struct {
+  int64_t n, m, nnz;
+  int64_t spmv_a_blocks, spmv_at_blocks; /* workgroups per A / A' product */
+  double last_solve_ms;                  /* device time of the last solve_two_* / qp_objgrad (HIP events) */
+  double last_spmv_ms;                   /* device time inside SpMV/SpMM kernels during that call */
+  int64_t last_spmv_launches;
+  int64_t last_kernel_launches;
+} fpsq_info;
+int fpsq_get_info(fpsq_handle h, fpsq_info *info);
+/* on != 0: bracket every SpMV/SpMM launch with HIP events on the solver's stream so that last_spmv_ms is filled
+ * (adds event records between kernels; leave off when timing whole evaluations) */
+int fpsq_set_profiling(fpsq_handle h, int32_t on);
+
+const char *fpsq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPSQ_H */

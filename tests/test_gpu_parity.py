@@ -1,0 +1,334 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+ (a) the reference's own known-answer tests (tests/golden/),
+ (b) the C restatement of the reference's iterative back-end (oracle/fps_oracle.c), iteration for iteration,
+ (c) the exact KKT solve.
+Tolerances are written at each assertion; everything is fp64."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import fps_amd  # noqa: F401
+from fps_amd import _lib, nlpmodels, problems
+from fps_amd.device_qp import DeviceEqQP
+from fps_amd.penalty_nlp import FletcherPenaltyNLP
+from fps_amd.qdsolver import HIPQDSolver
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))["cases"]
+SE = np.sqrt(np.finfo(float).eps)
+TIGHT = dict(ls_atol=1e-15, ls_rtol=1e-15, ls_axtol=1e-15, ls_btol=1e-15, ls_etol=1e-15,
+             ln_atol=1e-15, ln_rtol=1e-15, ln_btol=1e-15, ln_conlim=0.0)
+
+
+class _Handle:
+    """Thin test helper around the raw C ABI for a CSR matrix."""
+
+    def __init__(self, A, delta=0.0, **opts):
+        self.lib = _lib.load()
+        A = sp.csr_matrix(A)
+        self.m, self.n = A.shape
+        o = _lib.Options()
+        self.lib.fpsq_default_options(self.n, self.m, C.byref(o))
+        for k, v in opts.items():
+            setattr(o, k, v)
+        self.h = C.c_void_p()
+        assert self.lib.fpsq_create(C.byref(self.h), self.n, self.m, C.byref(o)) == 0, self.lib.fpsq_last_error(None)
+        rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+        assert self.lib.fpsq_set_jacobian_structure_csr(self.h, rp.ctypes.data, ci.ctypes.data) == 0, self.err()
+        v = np.ascontiguousarray(A.data, dtype=np.float64)
+        assert self.lib.fpsq_set_jacobian_values(self.h, v.ctypes.data) == 0, self.err()
+        assert self.lib.fpsq_set_delta(self.h, delta) == 0
+        self.st = (_lib.Stats * 2)()
+
+    def err(self):
+        return self.lib.fpsq_last_error(self.h)
+
+    def jac_mul(self, trans, alpha, x, beta, y):
+        y = np.array(y, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert self.lib.fpsq_jac_mul(self.h, trans, alpha, x.ctypes.data, beta, y.ctypes.data) == 0, self.err()
+        return y
+
+    def two(self, fn, r1, r2, sizes):
+        r1 = np.ascontiguousarray(r1, dtype=np.float64)
+        r2 = np.ascontiguousarray(r2, dtype=np.float64)
+        outs = [np.empty(k) for k in sizes]
+        rc = fn(self.h, r1.ctypes.data, r2.ctypes.data, *[o.ctypes.data for o in outs], self.st)
+        assert rc >= 0, self.err()
+        return (*outs, rc)
+
+    def solve_two_mixed(self, r1, r2):
+        return self.two(self.lib.fpsq_solve_two_mixed, r1, r2, (self.n, self.m, self.n, self.m))
+
+    def solve_two_least_squares(self, r1, r2):
+        return self.two(self.lib.fpsq_solve_two_least_squares, r1, r2, (self.n, self.m, self.n, self.m))
+
+    def close(self):
+        self.lib.fpsq_destroy(self.h)
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+# ---------------------------------------------------------------------------------------------- SpMV
+
+def _spmv_cases():
+    rng = np.random.default_rng(0)
+    cases = {}
+    cases["random"] = sp.random(300, 1000, density=0.02, random_state=rng, format="csr")
+    A = sp.random(64, 5000, density=0.3, random_state=rng, format="lil")
+    A[3, :] = rng.standard_normal(5000)  # one row longer than the 2048-nnz LDS stage
+    A[10, :] = 0  # and empty rows
+    A[11, :] = 0
+    cases["long_and_empty_rows"] = A.tocsr()
+    cases["single_row"] = sp.csr_matrix(np.ones((1, 10)))
+    cases["ragged"] = sp.vstack([sp.random(1, 3000, density=d, random_state=rng, format="csr")
+                                 for d in (0.0, 0.001, 0.9, 0.0, 0.3, 0.001, 0.7, 0.0)]).tocsr()
+    cases["tall"] = sp.random(5000, 40, density=0.1, random_state=rng, format="csr")
+    return cases
+
+
+@pytest.mark.parametrize("name", list(_spmv_cases()))
+def test_spmv_matches_oracle(oracle, name):
+    A = sp.csr_matrix(_spmv_cases()[name])
+    A.sort_indices()
+    m, n = A.shape
+    rng = np.random.default_rng(1)
+    H = _Handle(A)
+    x, u = rng.standard_normal(n), rng.standard_normal(m)
+    y0, z0 = rng.standard_normal(m), rng.standard_normal(n)
+    want = 1.5 * oracle.spmv(m, n, A.indptr, A.indices, A.data, x) - 0.5 * y0
+    got = H.jac_mul(0, 1.5, x, -0.5, y0)
+    # different summation order only: 1e-13 relative to the row's |a|.|x| mass
+    scale = np.abs(A) @ np.abs(x) + np.abs(y0) + 1e-300
+    assert np.max(np.abs(got - want) / scale) < 1e-13
+    want = -2.0 * oracle.spmv(m, n, A.indptr, A.indices, A.data, u, transposed=True)
+    got = H.jac_mul(1, -2.0, u, 0.0, np.full(n, np.nan))  # beta = 0 must not read y
+    scale = np.abs(A).T @ np.abs(u) + 1e-300
+    assert np.all(np.isfinite(got)) and np.max(np.abs(got - want) / scale) < 1e-13
+    got2 = H.jac_mul(1, -2.0, u, 0.0, z0)
+    assert np.array_equal(got, got2), "SpMV must be bitwise reproducible"
+    H.close()
+
+
+def test_coo_structure_with_duplicates_matches_sparse_sum():
+    """jac_structure! may repeat (i, j); SparseArrays.sparse sums duplicates (src/solve_linear_system.jl:233)."""
+    rng = np.random.default_rng(3)
+    m, n, k = 50, 200, 900
+    rows = rng.integers(1, m + 1, k).astype(np.int64)
+    cols = rng.integers(1, n + 1, k).astype(np.int64)
+    vals = rng.standard_normal(k)
+    A = sp.coo_matrix((vals, (rows - 1, cols - 1)), shape=(m, n)).tocsr()
+    assert A.nnz < k  # duplicates present
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.fpsq_create(C.byref(h), n, m, None) == 0
+    assert lib.fpsq_set_jacobian_structure_coo(h, k, rows.ctypes.data, cols.ctypes.data, 1) == 0
+    assert lib.fpsq_set_jacobian_values(h, vals.ctypes.data) == 0
+    x = rng.standard_normal(n)
+    y = np.zeros(m)
+    assert lib.fpsq_jac_mul(h, 0, 1.0, x.ctypes.data, 0.0, y.ctypes.data) == 0
+    np.testing.assert_allclose(y, A @ x, rtol=0, atol=1e-12 * np.linalg.norm(x))
+    u = rng.standard_normal(m)
+    z = np.zeros(n)
+    assert lib.fpsq_jac_mul(h, 1, 1.0, u.ctypes.data, 0.0, z.ctypes.data) == 0
+    np.testing.assert_allclose(z, A.T @ u, rtol=0, atol=1e-12 * np.linalg.norm(u))
+    lib.fpsq_destroy(h)
+
+
+# ---------------------------------------------------------------------------------------------- golden vectors
+
+_MODELS = {"sumsq": lambda: nlpmodels.SumSquares(10), "rosenbrock_circle": nlpmodels.RosenbrockCircle}
+
+
+@pytest.mark.parametrize("case", GOLD, ids=[c["name"] for c in GOLD])
+def test_reference_known_answers_through_hip_backend(case):
+    """The reference's own assertions (test/unit-test.jl, cited in the fixture) with the MI355X back-end plugged
+    into the QDSolver seam.  Krylov tolerances are tightened so the LDLt-level atol of the reference test applies
+    (x4 slack for the iterative path)."""
+    nlp = _MODELS[case["model"]]()
+    qds = HIPQDSolver(nlp, 0.0, **TIGHT)
+    fp = FletcherPenaltyNLP(nlp, case["sigma"], case["rho"], case["delta"], 1, qds=qds)
+    x = np.array(case["x"])
+    got = dict(obj=fp.obj(x), fx=fp.fx, gx=fp.gx.copy(), ys=fp.ys.copy(), cx=fp.cx.copy())
+    if "grad" in case["expect"]:
+        got["grad"] = fp.grad(x)
+    fobj, g2 = fp.objgrad(x)
+    assert fobj == pytest.approx(got["obj"], abs=1e-14)  # unit-test.jl:128-129
+    for key, want in case["expect"].items():
+        atol = max(case["atol"][key], 1e-15) * 4
+        np.testing.assert_allclose(got[key], want, rtol=0, atol=atol, err_msg=f"{case['name']}:{key}")
+    assert qds.stats[0].solved and qds.stats[1].solved
+    qds.close()
+
+
+def test_hs6_plumbing_kkt_3x3(oracle):
+    """BASELINE configs[0]: HS6 at x0; K is 3x3; the two solves against the exact KKT solution."""
+    nlp = nlpmodels.HS6()
+    qds = HIPQDSolver(nlp, 0.0, **TIGHT)
+    fp = FletcherPenaltyNLP(nlp, 1e3, 1.0, 0.0, 2, qds=qds)
+    x0 = nlp.meta.x0
+    fp.obj(x0)
+    A = sp.csr_matrix(np.array([[-20 * x0[0], 10.0]]))
+    e = oracle.exact_two_mixed(A, 0.0, nlp.grad(x0), nlp.cons(x0))
+    np.testing.assert_allclose(fp.ys, e[1] + 1e3 * e[3], rtol=1e-12)
+    np.testing.assert_allclose(fp.gs, e[0] + 1e3 * e[2], rtol=0, atol=1e-10)
+    qds.close()
+
+
+# ---------------------------------------------------------------------------------------------- Krylov parity
+
+def _small_pde(seed=7, n=4000, m=400):
+    return problems.pde_control_like(n=n, m=m, per_row=20, window=512, seed=seed)
+
+
+@pytest.mark.parametrize("delta", [0.0, SE, 0.25])
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_solve_two_mixed_iteration_parity_with_c_restatement(oracle, delta, fuse):
+    """Default reference tolerances: same iteration counts / statuses as the CPU restatement, vectors equal to
+    1e-9 (relative inf-norm: only the summation order differs), and within 1e-6 of the exact solve."""
+    qp = _small_pde()
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    H = _Handle(A, delta=delta, fuse_two_rhs=fuse)
+    p1, q1, p2, q2, rc = H.solve_two_mixed(g, c)
+    o = oracle.solve_two_mixed(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, c)
+    assert rc == o[5]
+    for k in range(2):
+        assert H.st[k].niter == o[4][k].niter and H.st[k].status == o[4][k].status
+        assert H.st[k].solved == o[4][k].solved and H.st[k].inconsistent == o[4][k].inconsistent
+        assert H.st[k].rnorm == pytest.approx(o[4][k].rnorm, rel=1e-6, abs=1e-300)
+    e = oracle.exact_two_mixed(A, delta, g, c)
+    for got, want_c, want_e in zip((p1, q1, p2, q2), o[:4], e):
+        assert _rel(got, want_c) < 1e-9
+        assert _rel(got, want_e) < 1e-6
+    H.close()
+
+
+def test_solve_two_mixed_tight_tolerance_vs_exact(oracle):
+    qp = _small_pde(seed=9)
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    for delta in (0.0, 1e-3):
+        H = _Handle(A, delta=delta, **{**TIGHT, "ls_atol": 1e-13, "ls_rtol": 1e-13, "ls_axtol": 1e-13,
+                                       "ls_btol": 1e-13, "ls_etol": 1e-13, "ln_atol": 1e-13, "ln_rtol": 1e-13,
+                                       "ln_btol": 1e-13})
+        p1, q1, p2, q2, rc = H.solve_two_mixed(g, c)
+        assert rc == 0
+        e = oracle.exact_two_mixed(A, delta, g, c)
+        for got, want in zip((p1, q1, p2, q2), e):
+            assert _rel(got, want) < 1e-10
+        # K sol = rhs residuals
+        r1 = np.linalg.norm(p1 + A.T @ q1 - g) / np.linalg.norm(g)
+        r2 = np.linalg.norm(A @ p2 - delta * q2 - c) / np.linalg.norm(c)
+        assert r1 < 1e-11 and r2 < 1e-11
+        H.close()
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_solve_two_least_squares_parity(oracle, fuse):
+    qp = problems.random_eqqp(n=3000, m=300, per_row=24, seed=5)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(0)
+    r1, r2 = rng.standard_normal(qp.n), rng.standard_normal(qp.n)
+    H = _Handle(A, delta=0.01, fuse_two_rhs=fuse)
+    p1, q1, p2, q2, rc = H.solve_two_least_squares(r1, r2)
+    o = oracle.solve_two_least_squares(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, 0.01, r1, r2)
+    assert rc == o[5] == 0
+    for k in range(2):
+        assert H.st[k].niter == o[4][k].niter and H.st[k].status == o[4][k].status
+    e = oracle.exact_two_least_squares(A, 0.01, r1, r2)
+    for got, want_c, want_e in zip((p1, q1, p2, q2), o[:4], e):
+        assert _rel(got, want_c) < 1e-9 and _rel(got, want_e) < 1e-6
+    H.close()
+
+
+def test_zero_right_hand_sides():
+    """Edge cases of lsqr!/craig!: b = 0 returns x = 0, solved, 0 iterations."""
+    qp = _small_pde(n=600, m=60)
+    H = _Handle(qp.scipy_csr())
+    p1, q1, p2, q2, rc = H.solve_two_mixed(np.zeros(qp.n), np.zeros(qp.m))
+    assert rc == 0 and H.st[0].niter == 0 and H.st[1].niter == 0
+    assert H.st[0].status == 1 and H.st[1].status == 1
+    assert not p1.any() and not q1.any() and not p2.any() and not q2.any()
+    H.close()
+
+
+def test_itmax_reports_unsolved_softly():
+    """Numerical failure is a soft return code (the reference only @warns), never an exception."""
+    qp = _small_pde(n=600, m=60)
+    A = qp.scipy_csr()
+    H = _Handle(A, ls_itmax=2, ln_itmax=2)
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    *_, rc = H.solve_two_mixed(g, c)
+    assert rc == 3 and H.st[0].niter == 2 and H.st[1].niter == 2 and H.st[0].status == 7 and H.st[1].status == 7
+    H.close()
+
+
+# ---------------------------------------------------------------------------------------------- penalty gradient
+
+@pytest.mark.parametrize("delta,eta", [(0.0, 0.0), (SE, 0.0), (1e-2, 0.5)])
+def test_device_qp_objgrad_matches_oracle(oracle, delta, eta):
+    qp = _small_pde(seed=11, n=3000, m=300)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, eta=eta)
+    gx, ys, gs = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n)
+    xk = qp.xhat.copy()
+    fx, rc = dev.objgrad(qp.x, gx=gx, ys=ys, gs=gs, xk=xk if eta > 0 else None)
+    o = oracle.qp_objgrad(qp, qp.x, 1e3, 1.0, delta, eta, xk)
+    assert rc == o["rc"] == 0
+    assert dev.stats[0].niter == o["stats"][0].niter and dev.stats[1].niter == o["stats"][1].niter
+    # same algorithm, same tolerances: differences are summation-order rounding amplified by sigma = 1e3
+    assert _rel(ys, o["ys"]) < 1e-8 and _rel(gs, o["gs"]) < 1e-8 and _rel(gx, o["gx"]) < 1e-8
+    assert abs(fx - o["fx"]) <= 1e-8 * abs(o["fx"])
+    e = oracle.exact_qp_objgrad(qp, qp.x, 1e3, 1.0, delta, eta, xk)
+    assert _rel(ys, e["ys"]) < 1e-5 and _rel(gx, e["gx"]) < 1e-5
+    dev.close()
+
+
+def test_device_qp_matches_host_mirror(oracle):
+    """The device-resident evaluation and FletcherPenaltyNLP + HIPQDSolver with a host model agree."""
+    qp = _small_pde(seed=13, n=2000, m=200)
+    model = nlpmodels.EqQPModel(qp)
+    fp = FletcherPenaltyNLP(model, 1e3, 1.0, SE, 2, qds=HIPQDSolver(model, 0.0))
+    f_host, g_host = fp.objgrad(qp.x)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=SE)
+    g_dev = np.empty(qp.n)
+    f_dev, rc = dev.objgrad(qp.x, gx=g_dev)
+    assert rc == 0
+    assert _rel(g_dev, g_host) < 1e-9 and abs(f_dev - f_host) <= 1e-9 * abs(f_host)
+    dev.close()
+    fp.qdsolver.close()
+
+
+def test_torch_device_pointers_accepted():
+    import torch
+
+    qp = _small_pde(seed=15, n=2000, m=200)
+    dev = DeviceEqQP(qp)
+    x = torch.from_numpy(qp.x).cuda()
+    gx = torch.empty(qp.n, dtype=torch.float64, device="cuda")
+    fx, rc = dev.objgrad(x, gx=gx)
+    torch.cuda.synchronize()
+    g2 = np.empty(qp.n)
+    fx2, _ = dev.objgrad(qp.x, gx=g2)
+    assert rc == 0 and fx == fx2 and np.array_equal(gx.cpu().numpy(), g2)
+    dev.close()
+
+
+def test_repeat_calls_are_bitwise_reproducible():
+    qp = _small_pde(seed=17, n=3000, m=300)
+    dev = DeviceEqQP(qp, delta=SE)
+    a, b = np.empty(qp.n), np.empty(qp.n)
+    f1, _ = dev.objgrad(qp.x, gx=a)
+    dev.objgrad(qp.point(1), gx=b)
+    f2, _ = dev.objgrad(qp.x, gx=b)
+    assert f1 == f2 and np.array_equal(a, b)
+    dev.close()
