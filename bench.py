@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- penalty grad(phi) evaluations per second on the BASELINE.json headline workload.
+
+One "step" = one `objgrad!(::FletcherPenaltyNLP, x, gx)` at a FRESH x (a memo miss, model-Fletcherpenaltynlp.jl:236)
+on the synthetic PDE-control-like equality QP  n = 1e6, m = 1e5, nnz(A) = 1e7, fp64:
+user-model f, g, c  +  solve_two_mixed (the two KKT solves)  +  the ys/gs epilogue  +  Hsv  +  rho A'c.
+Inputs (A, q, d, b and all evaluation points) are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel = the CSR-stream
+SpMV/SpMM, algorithmic bytes / HIP-event time) and `cpu_baseline` (the single-threaded C restatement of the
+reference's iterative path, oracle/fps_oracle.c, on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # first: one HIP runtime per process (see fps_amd/_lib.py)
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import fps_amd  # noqa: E402,F401
+from fps_amd import problems  # noqa: E402
+from fps_amd.device_qp import DeviceEqQP  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (generator, kwargs)
+    "pde-control-like n=1e6 m=1e5 nnz=1e7": (problems.pde_control_like, dict(n=1_000_000, m=100_000)),
+    "random-eqqp n=1e5 m=1e4 nnz=1e6": (problems.random_eqqp, dict(n=100_000, m=10_000)),
+}
+
+
+def product_bytes(n, m, nnz, nrhs):
+    """Algorithmic HBM bytes of ONE product-kernel launch (DESIGN.md "Roofline accounting"): matrix stream
+    (8 B value + 4 B column per nonzero + row pointers) + gathered input vector + fused axpby read + output write.
+    nrhs = 1 or 2 right-hand sides (the 2-RHS launch streams the matrix once for both)."""
+    a = 12 * nnz + 4 * (m + 1) + 8 * nrhs * (n + 2 * m)   # y(m) = ca * A x(n) + cb * y(m)
+    at = 12 * nnz + 4 * (n + 1) + 8 * nrhs * (m + 2 * n)  # y(n) = ca * A'x(m) + cb * y(n)
+    return a, at
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pde-control-like n=1e6 m=1e5 nnz=1e7", choices=list(WORKLOADS))
+    ap.add_argument("--delta", type=float, default=0.0, help="regularisation; 0 = first outer iteration (algo.jl:46)")
+    ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--cpu-evals", type=int, default=6, help="evaluations timed for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    gen, kw = WORKLOADS[args.workload]
+    qp = gen(**kw)
+    n, m, nnz = qp.n, qp.m, qp.nnz
+    sigma, rho = 1e3, 1.0  # parameters.jl:71,75 (first outer iteration)
+    model = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=args.delta, device=local_rank, fuse_two_rhs=args.fuse)
+
+    # distinct evaluation points, resident in HBM (rank r evaluates its own sequence when world > 1)
+    K, W = args.steps, args.warmup
+    xs = torch.empty((K + W, n), dtype=torch.float64, device=dev)
+    for t in range(K + W):
+        xs[t].copy_(torch.from_numpy(qp.point(1 + t + rank * (K + W))))
+    gx = torch.empty(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    its = []
+    for t in range(W):
+        model.objgrad(xs[t], gx=gx)
+    barrier()
+    t0 = time.perf_counter()
+    soft = 0
+    for t in range(W, W + K):
+        _, rc = model.objgrad(xs[t], gx=gx)
+        soft |= rc
+        its.append((model.stats[0].niter, model.stats[1].niter))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    evals = K * world  # every rank evaluates K points (independent replicas of the evaluation)
+    value = evals / elapsed
+
+    # ---- roofline of the dominant kernel: a second pass over the same K points with per-launch HIP events
+    model.set_profiling(True)
+    pa, pat, t_ms, tot_ms = np.zeros(2), np.zeros(2), 0.0, 0.0
+    for t in range(W, W + K):
+        model.objgrad(xs[t], gx=gx)
+        info = model.info()
+        pa += info["last_prod_a"]
+        pat += info["last_prod_at"]
+        t_ms += info["last_spmv_ms"]
+        tot_ms += info["last_solve_ms"]
+    model.set_profiling(False)
+    nbytes = 0.0
+    for k in (1, 2):
+        ba, bat = product_bytes(n, m, nnz, k)
+        nbytes += pa[k - 1] * ba + pat[k - 1] * bat
+    launches = int(pa.sum() + pat.sum())
+    achieved = nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "fpsq::k_spmv (CSR-stream SpMV/SpMM + fused axpby + norm partials)",
+                "launches_per_eval": launches / K, "avg_launch_us": round(1e3 * t_ms / max(launches, 1), 2),
+                "algorithmic_bytes_per_launch": round(nbytes / max(launches, 1)),
+                "spmv_share_of_eval_time": round(t_ms / tot_ms, 3) if tot_ms > 0 else None}
+
+    out = {
+        "metric": "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "evals/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "n": n, "m": m, "nnz": nnz, "sigma": sigma, "rho": rho,
+                   "delta": args.delta, "fuse_two_rhs": args.fuse,
+                   "krylov": "LSQR+CRAIG, atol=rtol=sqrt(eps) (reference defaults)",
+                   "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
+                   "all_solved": soft == 0,
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (row sharding: next)"},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the C restatement of the reference's iterative path, one thread, bounded sample
+    if rank == 0 and world == 1 and args.cpu_evals > 0:
+        from oracle import oracle
+
+        oracle.build()
+        t0 = time.perf_counter()
+        done = 0
+        for t in range(args.cpu_evals):
+            oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, args.delta)
+            done += 1
+            if time.perf_counter() - t0 > 30.0:
+                break
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(done / dt, 4), "unit": "evals/s", "cores": 1, "kind": "port",
+                               "sample": f"{done} evaluations of the same workload (same points as the first timed "
+                                         "steps), oracle/fps_oracle.c, gcc -O3 -march=native, single thread "
+                                         "(the reference is single-threaded Julia; Julia is not installed)"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,10 +37,14 @@ class Info(C.Structure):
     _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("nnz", C.c_int64),
                 ("spmv_a_blocks", C.c_int64), ("spmv_at_blocks", C.c_int64),
                 ("last_solve_ms", C.c_double), ("last_spmv_ms", C.c_double),
-                ("last_spmv_launches", C.c_int64), ("last_kernel_launches", C.c_int64)]
+                ("last_spmv_launches", C.c_int64), ("last_kernel_launches", C.c_int64),
+                ("last_prod_a", C.c_int64 * 2), ("last_prod_at", C.c_int64 * 2)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["last_prod_a"] = list(d["last_prod_a"])
+        d["last_prod_at"] = list(d["last_prod_at"])
+        return d
 
 
 # every symbol include/fpsq.h declares: (name, restype, argtypes)
@@ -74,7 +78,11 @@ _LIB = None
 
 
 def load():
-    """dlopen libfpsq.so and type every entry point.  Raises if the library was not built."""
+    """dlopen libfpsq.so and type every entry point.  Raises if the library was not built.
+
+    A process that also uses torch must `import torch` BEFORE the first load(): torch ships its own
+    libamdhip64.so.7 / libhsa-runtime64 and two HIP runtimes in one process cannot both own the GPU; with torch
+    imported first the dynamic linker resolves libfpsq's libamdhip64.so.7 to the copy already loaded."""
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):

@@ -78,6 +78,7 @@ struct fpsq_solver_s {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   fpsq_info info{};
   int64_t launches = 0, spmv_launches = 0;
+  int64_t prod_a[2] = {0, 0}, prod_at[2] = {0, 0};
 };
 
 struct fpsq_qp_s {
@@ -247,6 +248,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
   prof_end(h);
   h->launches++;
   h->spmv_launches++;
+  (tag == TAG_A ? h->prod_a : h->prod_at)[NL - 1]++;
 }
 
 __global__ void k_set_ctl(LaneCtl* c, double ca, double cb) {
@@ -436,6 +438,7 @@ int check_ready(fpsq_handle h) {
 void call_begin(fpsq_handle h) {
   h->launches = 0;
   h->spmv_launches = 0;
+  h->prod_a[0] = h->prod_a[1] = h->prod_at[0] = h->prod_at[1] = 0;
   h->ev_used = 0;
   hipEventRecord(h->ev0, h->stream);
 }
@@ -448,6 +451,10 @@ int call_end(fpsq_handle h) {
   h->info.last_solve_ms = ms;
   h->info.last_kernel_launches = h->launches;
   h->info.last_spmv_launches = h->spmv_launches;
+  for (int i = 0; i < 2; ++i) {
+    h->info.last_prod_a[i] = h->prod_a[i];
+    h->info.last_prod_at[i] = h->prod_at[i];
+  }
   double sp = 0.0;
   for (size_t i = 0; i < h->ev_used; ++i) {
     float t = 0.f;

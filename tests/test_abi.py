@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Stats) == 32
     assert C.sizeof(_lib.Options) == 8 * 17 + 16
-    assert C.sizeof(_lib.Info) == 72
+    assert C.sizeof(_lib.Info) == 72 + 32
 
 
 def test_default_options_follow_reference_defaults():
