@@ -55,12 +55,14 @@ struct fpsq_solver_s {
   double* in_vals = nullptr;    // staging of the caller's values (COO path)
 
   std::vector<void*> allocs;
+  // Golub-Kahan vectors, [len][2] interleaved: LP = "long" (n) pair, SP = "short" (m) pair
+  double *LP, *SP;
   // n-vectors
-  double *Lu, *Cv, *Cx, *Cw2, *in_n1, *in_n2, *p1, *p2b, *gs, *gx, *jc, *g, *xin, *xk;
+  double *Cx, *Cw2, *in_n1, *in_n2, *p1, *p2b, *gs, *gx, *jc, *g, *xin, *xk;
   // m-vectors
-  double *Lv, *Lw, *Lx, *Lx2, *Cmu, *Cw, *Cy, *in_m, *ys, *c;
+  double *Lw[2], *Lx[2], *Cw, *Cy, *in_m, *ys, *c;
   // partial-sum buffers
-  double *pS, *pS2, *pW, *pE, *pE2, *pE3;
+  double *pS, *pS2, *pW[2], *pE, *pE2, *pE3, *pQ[2];
   int npS = 0;
   LsqrState* lsqr[2];
   CraigState* craig;
@@ -176,17 +178,19 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
 
 int alloc_workspaces(fpsq_handle h) {
   const size_t n = (size_t)h->n, m = (size_t)h->m;
-  double** nv[] = {&h->Lu, &h->Cv, &h->Cx, &h->Cw2, &h->in_n1, &h->in_n2, &h->p1, &h->p2b,
+  if (int rc = dalloc(h, &h->LP, 2 * n)) return rc;
+  if (int rc = dalloc(h, &h->SP, 2 * m)) return rc;
+  double** nv[] = {&h->Cx, &h->Cw2, &h->in_n1, &h->in_n2, &h->p1, &h->p2b,
                    &h->gs, &h->gx, &h->jc, &h->g, &h->xin, &h->xk};
   for (auto p : nv)
     if (int rc = dalloc(h, p, n)) return rc;
-  double** mv[] = {&h->Lv, &h->Lw, &h->Lx, &h->Lx2, &h->Cmu, &h->Cw, &h->Cy, &h->in_m, &h->ys, &h->c};
+  double** mv[] = {&h->Lw[0], &h->Lw[1], &h->Lx[0], &h->Lx[1], &h->Cw, &h->Cy, &h->in_m, &h->ys, &h->c};
   for (auto p : mv)
     if (int rc = dalloc(h, p, m)) return rc;
   h->npS = std::max(h->A.nblk, h->AT.nblk);
   if (int rc = dalloc(h, &h->pS, (size_t)h->npS * 2)) return rc;
   if (int rc = dalloc(h, &h->pS2, (size_t)h->npS * 2)) return rc;
-  double** ev[] = {&h->pW, &h->pE, &h->pE2, &h->pE3};
+  double** ev[] = {&h->pW[0], &h->pW[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1]};
   for (auto p : ev)
     if (int rc = dalloc(h, p, (size_t)kEwBlocksMax * 2)) return rc;
   return 0;
@@ -299,7 +303,7 @@ int wait_progress(fpsq_handle h, int lane, int target, const int32_t* dev_done, 
   return 0;
 }
 
-// ------------------------------------------------------------------ Krylov drivers (one recurrence at a time)
+// ------------------------------------------------------------------ Krylov drivers
 
 struct LsqrParams {
   double lambda, atol, rtol, axtol, btol, etol, conlim;
@@ -323,6 +327,7 @@ __global__ void k_lsqr_params(LsqrState* S, LsqrParams P) {
 struct CraigParams {
   double mu, lambda, atol, rtol, btol, conlim, xsign;
   int64_t itmax;
+  int32_t start_skipped;
 };
 
 __global__ void k_craig_params(CraigState* S, CraigParams P) {
@@ -335,94 +340,268 @@ __global__ void k_craig_params(CraigState* S, CraigParams P) {
   S->xsign = P.xsign;
   S->itmax = P.itmax;
   S->ctl.done = 0;
-  S->ctl.skip = 0;
+  S->ctl.skip = P.start_skipped;  // stays out of the LSQR lane's start-up product; craig_begin clears it
   S->ctl.upd_iter = -1;
 }
 
-// LSQR on B = A' (n x m): min ||A'x - b||^2 + lambda^2 ||x||^2, b (n, device) -> x (m, device).
-// src/solve_two_systems_struct.jl:167-185.
-int run_lsqr(fpsq_handle h, int slot, const double* b, double lambda, double* x, fpsq_stats* st_out) {
+enum { LANE_LSQR = 1, LANE_CRAIG = 2 };
+
+// One Krylov recurrence of a (possibly fused) run.
+struct Lane {
+  int kind = 0;
+  const double* rhs = nullptr;  // LSQR: n-vector b;  CRAIG: m-vector b
+  double rhs_scale = 1.0;
+  double lambda = 0.0;          // LSQR regularisation
+  double delta = 0.0;           // CRAIG: M = (1/delta) I, sqd when != 0
+  double xsign = 1.0;           // CRAIG: xs accumulates xsign * x
+  double* x = nullptr;          // LSQR: solution (m).  CRAIG: xs (n)
+  double* y = nullptr;          // CRAIG: y (m)
+  fpsq_stats* st = nullptr;     // pinned host destination of the final stats
+  // filled by run_krylov
+  void* state = nullptr;
+  LaneCtl* ctl = nullptr;
+  int64_t itmax = 0;
+};
+
+StepArgs step_args(int kind, const Lane& L, int it, const double* p0, int n0, const double* p1, int n1, Progress* prog) {
+  StepArgs a;
+  a.kind = kind;
+  a.it = it;
+  a.state = L.state;
+  a.p0 = p0;
+  a.p1 = p1;
+  a.n0 = n0;
+  a.n1 = n1;
+  a.prog = prog;
+  return a;
+}
+
+void launch_step(fpsq_handle h, const StepArgs& a0, const StepArgs& a1) {
+  const int nb = a1.kind != STEP_NONE ? 2 : 1;
+  hipLaunchKernelGGL(k_step, dim3(nb), dim3(kStepThreads), 0, h->stream, a0, a1);
+  h->launches++;
+}
+
+template <int NL>
+void launch_updates(fpsq_handle h, const UpdSeg& s0, const UpdSeg& s1, const UpdSeg& s2) {
+  const int nb = s0.nblk + s1.nblk + s2.nblk;
+  if (nb == 0) return;
+  hipLaunchKernelGGL(k_updates<NL>, dim3(nb), dim3(kBlock), 0, h->stream, s0, s1, s2);
+  h->launches++;
+}
+
+UpdSeg seg_none() {
+  UpdSeg s{};
+  s.kind = UPD_NONE;
+  s.nblk = 0;
+  return s;
+}
+
+// Runs 1 or 2 recurrences in lock-step on the interleaved Golub-Kahan pairs LP (n) / SP (m):
+//   A' product: LP <- ca A' SP + cb LP      (LSQR: u~ <- B v - alpha u;     CRAIG: v~ <- B'u - beta v)
+//   A  product: SP <- ca A  LP + cb SP      (LSQR: v~ <- B'u - beta v;      CRAIG: Mu~ <- B v - alpha Mu)
+// Each lane is exactly Krylov.jl's lsqr! / craig! on its own right-hand side (its results do not depend on the
+// other lane); running them side by side turns two SpMVs into one SpMM with k = 2.
+template <int NL>
+int run_krylov(fpsq_handle h, Lane* lanes) {
   const int64_t n = h->n, m = h->m;
-  LsqrState* S = h->lsqr[slot];
-  Progress* prog = &h->prog_dev[slot];
-  h->prog_host[slot].iter = 0;
-  h->prog_host[slot].done = 0;
   const fpsq_options& o = h->opt;
-  int64_t itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
-  LsqrParams P{lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, itmax};
   hipStream_t s = h->stream;
   const int gn = ew_grid(n), gm = ew_grid(m);
-  hipLaunchKernelGGL(k_lsqr_params, dim3(1), dim3(1), 0, s, S, P);
-  HIPCHK(h, hipMemsetAsync(x, 0, (size_t)m * 8, s));
-  hipLaunchKernelGGL(k_load_lane<1>, dim3(gn), dim3(kBlock), 0, s, b, 1.0, h->Lu, 0, n, h->pE);
-  hipLaunchKernelGGL(k_lsqr_begin, dim3(1), dim3(kBlock), 0, s, S, h->pE, gn, prog);
-  launch_spmv<1>(h, TAG_A, h->Lu, nullptr, h->Lv, &S->ctl, &S->ctl, h->pS2);
-  hipLaunchKernelGGL(k_lsqr_begin2, dim3(1), dim3(kBlock), 0, s, S, h->pS2, h->A.nblk, prog);
-  hipLaunchKernelGGL(k_lsqr_winit<1>, dim3(gm), dim3(kBlock), 0, s, &S->ctl, h->Lv, 0, h->Lw, m, h->pW);
-  h->launches += 6;
+  const int nbA = h->A.nblk, nbT = h->AT.nblk;
+  double* LP = h->LP;
+  double* SP = h->SP;
+  bool any_lsqr = false;
+  int64_t itmax_all = 0;
+  Progress* prog[2];
+  int nlsqr = 0;
+  for (int l = 0; l < NL; ++l) {
+    Lane& L = lanes[l];
+    prog[l] = &h->prog_dev[l];
+    h->prog_host[l].iter = 0;
+    h->prog_host[l].done = 0;
+    if (L.kind == LANE_LSQR) {
+      any_lsqr = true;
+      LsqrState* S = h->lsqr[nlsqr++];
+      L.state = S;
+      L.ctl = &S->ctl;
+      L.itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
+      LsqrParams P{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax};
+      hipLaunchKernelGGL(k_lsqr_params, dim3(1), dim3(1), 0, s, S, P);
+    } else {
+      CraigState* S = h->craig;
+      L.state = S;
+      L.ctl = &S->ctl;
+      L.itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
+      const bool reg = L.delta != 0.0;
+      CraigParams P{reg ? 1.0 / L.delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim,
+                    L.xsign, L.itmax, NL == 2 ? 1 : 0};
+      hipLaunchKernelGGL(k_craig_params, dim3(1), dim3(1), 0, s, S, P);
+    }
+    h->launches++;
+    itmax_all = std::max(itmax_all, L.itmax);
+  }
+  const LaneCtl* c0 = lanes[0].ctl;
+  const LaneCtl* c1 = lanes[NL - 1].ctl;
+
+  // ---- start-up: load right-hand sides, beta_1, (LSQR) alpha_1 and w_1
+  StepArgs none{};
+  none.kind = STEP_NONE;
+  StepArgs b0 = none, b1 = none;
+  for (int l = 0; l < NL; ++l) {
+    Lane& L = lanes[l];
+    double* pe = l == 0 ? h->pE : h->pE2;
+    if (L.kind == LANE_LSQR) {
+      HIPCHK(h, hipMemsetAsync(L.x, 0, (size_t)m * 8, s));
+      hipLaunchKernelGGL(k_load_lane<NL>, dim3(gn), dim3(kBlock), 0, s, L.rhs, L.rhs_scale, LP, l, n, pe);
+      (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
+    } else {
+      HIPCHK(h, hipMemsetAsync(L.x, 0, (size_t)n * 8, s));
+      HIPCHK(h, hipMemsetAsync(L.y, 0, (size_t)m * 8, s));
+      HIPCHK(h, hipMemsetAsync(h->Cw, 0, (size_t)m * 8, s));
+      if (L.delta != 0.0) HIPCHK(h, hipMemsetAsync(h->Cw2, 0, (size_t)n * 8, s));
+      hipLaunchKernelGGL(k_load_lane<NL>, dim3(gm), dim3(kBlock), 0, s, L.rhs, L.rhs_scale, SP, l, m, pe);
+    }
+    h->launches++;
+  }
+  if (any_lsqr) {
+    launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none);
+    // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes (CRAIG lane parked by ctl.skip)
+    launch_spmv<NL>(h, TAG_A, LP, SP, SP, c0, c1, h->pS2);
+    StepArgs s0 = none, s1 = none;
+    UpdSeg w0 = seg_none(), w1 = seg_none();
+    for (int l = 0; l < NL; ++l) {
+      Lane& L = lanes[l];
+      if (L.kind != LANE_LSQR) continue;
+      (s0.kind ? s1 : s0) = step_args(STEP_LSQR_BEGIN2, L, 0, h->pS2 + (size_t)l * nbA, nbA, nullptr, 0, prog[l]);
+      UpdSeg u{};
+      u.kind = UPD_LSQR_WINIT;
+      u.it = 0;
+      u.ctl = L.ctl;
+      u.src = SP;
+      u.lane = l;
+      u.nblk = gm;
+      u.a = L.x;
+      u.b = h->Lw[l];
+      u.len = m;
+      u.partials = h->pW[l];
+      (w0.nblk ? w1 : w0) = u;
+    }
+    launch_step(h, s0, s1);
+    launch_updates<NL>(h, w0, w1, seg_none());
+  }
+  for (int l = 0; l < NL; ++l)
+    if (lanes[l].kind == LANE_CRAIG)
+      launch_step(h, step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]), none);
+
+  // ---- main loop
   const int look = std::max(1, o.lookahead);
-  for (int64_t it = 1; it <= itmax; ++it) {
-    launch_spmv<1>(h, TAG_AT, h->Lv, h->Lu, h->Lu, &S->ctl, &S->ctl, h->pS);
-    hipLaunchKernelGGL(k_lsqr_sa, dim3(1), dim3(kBlock), 0, s, S, h->pS, h->AT.nblk);
-    launch_spmv<1>(h, TAG_A, h->Lu, h->Lv, h->Lv, &S->ctl, &S->ctl, h->pS2);
-    hipLaunchKernelGGL(k_lsqr_sb, dim3(1), dim3(kBlock), 0, s, S, h->pS2, h->A.nblk, h->pW, gm, (int)it, prog);
-    hipLaunchKernelGGL(k_lsqr_update<1>, dim3(gm), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Lv, 0, x, h->Lw, m, h->pW);
-    h->launches += 3;
-    if (h->prog_host[slot].done) break;
-    if (it - h->prog_host[slot].iter >= look) {
-      if (int rc = wait_progress(h, slot, (int)(it - look + 1), &S->ctl.done, &S->iter)) return rc;
-      if (h->prog_host[slot].done) break;
+  int64_t it = 0;
+  auto lsqr_upd_seg = [&](int l, int64_t it_of_update) {
+    UpdSeg u{};
+    u.kind = UPD_LSQR;
+    u.it = (int)it_of_update;
+    u.ctl = lanes[l].ctl;
+    u.src = SP;
+    u.lane = l;
+    u.nblk = gm;
+    u.a = lanes[l].x;
+    u.b = h->Lw[l];
+    u.len = m;
+    u.partials = h->pW[l];
+    return u;
+  };
+  auto all_done = [&]() {
+    for (int l = 0; l < NL; ++l)
+      if (!h->prog_host[l].done) return false;
+    return true;
+  };
+  while (it < itmax_all) {
+    ++it;
+    // first half-step of every lane: one A' product
+    launch_spmv<NL>(h, TAG_AT, SP, LP, LP, c0, c1, h->pS);
+    StepArgs sa[2] = {none, none};
+    for (int l = 0; l < NL; ++l)
+      sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : STEP_CRAIG_SA, lanes[l], (int)it,
+                        h->pS + (size_t)l * nbT, nbT, nullptr, 0, prog[l]);
+    launch_step(h, sa[0], sa[1]);
+    // vector updates: LSQR's x/w update of the PREVIOUS iteration, CRAIG's updates of this one
+    UpdSeg seg[3] = {seg_none(), seg_none(), seg_none()};
+    int ns = 0;
+    for (int l = 0; l < NL; ++l) {
+      const Lane& L = lanes[l];
+      if (L.kind == LANE_LSQR) {
+        if (it > 1) seg[ns++] = lsqr_upd_seg(l, it - 1);
+      } else {
+        UpdSeg u{};
+        u.kind = L.delta != 0.0 ? UPD_CRAIG_LONG_REG : UPD_CRAIG_LONG;
+        u.it = (int)it;
+        u.ctl = L.ctl;
+        u.src = LP;
+        u.lane = l;
+        u.nblk = gn;
+        u.a = L.x;
+        u.b = h->Cw2;
+        u.len = n;
+        seg[ns++] = u;
+        UpdSeg v{};
+        v.kind = UPD_CRAIG_SHORT;
+        v.it = (int)it;
+        v.ctl = L.ctl;
+        v.src = SP;
+        v.lane = l;
+        v.nblk = gm;
+        v.a = h->Cw;
+        v.b = L.y;
+        v.len = m;
+        v.partials = h->pW[l];
+        seg[ns++] = v;
+      }
+    }
+    launch_updates<NL>(h, seg[0], seg[1], seg[2]);
+    // second half-step: one A product
+    launch_spmv<NL>(h, TAG_A, LP, SP, SP, c0, c1, h->pS2);
+    StepArgs sb[2] = {none, none};
+    for (int l = 0; l < NL; ++l)
+      sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : STEP_CRAIG_SB, lanes[l], (int)it,
+                        h->pS2 + (size_t)l * nbA, nbA, h->pW[l], gm, prog[l]);
+    launch_step(h, sb[0], sb[1]);
+    if (all_done()) break;
+    // bound the run-ahead of the host on the slowest unfinished lane
+    int slow = INT32_MAX;
+    for (int l = 0; l < NL; ++l)
+      if (!h->prog_host[l].done) slow = std::min(slow, (int)h->prog_host[l].iter);
+    if (it - slow >= look) {
+      for (int l = 0; l < NL; ++l) {
+        if (h->prog_host[l].done) continue;
+        const int32_t* ddone = &lanes[l].ctl->done;
+        const int32_t* diter = lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->iter
+                                                          : &((CraigState*)lanes[l].state)->iter;
+        if (int rc = wait_progress(h, l, (int)(it - look + 1), ddone, diter)) return rc;
+      }
+      if (all_done()) break;
     }
   }
-  HIPCHK(h, hipMemcpyAsync(st_out, &S->stats, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
+  // the last LSQR update (iteration `it`) has not been enqueued yet
+  {
+    UpdSeg seg[2] = {seg_none(), seg_none()};
+    int ns = 0;
+    for (int l = 0; l < NL; ++l)
+      if (lanes[l].kind == LANE_LSQR && it >= 1) seg[ns++] = lsqr_upd_seg(l, it);
+    launch_updates<NL>(h, seg[0], seg[1], seg_none());
+  }
+  for (int l = 0; l < NL; ++l) {
+    const fpsq_stats* src = lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->stats
+                                                       : &((CraigState*)lanes[l].state)->stats;
+    HIPCHK(h, hipMemcpyAsync(lanes[l].st, src, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
+  }
   return 0;
 }
 
-// CRAIG on B = A (m x n): src/solve_two_systems_struct.jl:210-244.  b (m, device) -> xs = xsign * x (n), y (m).
-int run_craig(fpsq_handle h, const double* b, double bscale, double delta, double xsign, double* xs, double* y,
-              fpsq_stats* st_out) {
-  const int64_t n = h->n, m = h->m;
-  CraigState* S = h->craig;
-  const int slot = 1;
-  Progress* prog = &h->prog_dev[slot];
-  h->prog_host[slot].iter = 0;
-  h->prog_host[slot].done = 0;
-  const fpsq_options& o = h->opt;
-  const bool reg = delta != 0.0;
-  int64_t itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
-  CraigParams P{reg ? 1.0 / delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim, xsign, itmax};
-  hipStream_t s = h->stream;
-  const int gn = ew_grid(n), gm = ew_grid(m);
-  hipLaunchKernelGGL(k_craig_params, dim3(1), dim3(1), 0, s, S, P);
-  HIPCHK(h, hipMemsetAsync(xs, 0, (size_t)n * 8, s));
-  HIPCHK(h, hipMemsetAsync(y, 0, (size_t)m * 8, s));
-  HIPCHK(h, hipMemsetAsync(h->Cw, 0, (size_t)m * 8, s));
-  if (reg) HIPCHK(h, hipMemsetAsync(h->Cw2, 0, (size_t)n * 8, s));
-  hipLaunchKernelGGL(k_load_lane<1>, dim3(gm), dim3(kBlock), 0, s, b, bscale, h->Cmu, 0, m, h->pE);
-  hipLaunchKernelGGL(k_craig_begin, dim3(1), dim3(kBlock), 0, s, S, h->pE, gm, prog);
-  h->launches += 3;
-  const int look = std::max(1, o.lookahead);
-  for (int64_t it = 1; it <= itmax; ++it) {
-    launch_spmv<1>(h, TAG_AT, h->Cmu, h->Cv, h->Cv, &S->ctl, &S->ctl, h->pS);
-    hipLaunchKernelGGL(k_craig_sa, dim3(1), dim3(kBlock), 0, s, S, h->pS, h->AT.nblk, (int)it, prog);
-    if (reg)
-      hipLaunchKernelGGL((k_craig_update_long<1, true>), dim3(gn), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Cv, 0, xs,
-                         h->Cw2, n);
-    else
-      hipLaunchKernelGGL((k_craig_update_long<1, false>), dim3(gn), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Cv, 0, xs,
-                         h->Cw2, n);
-    hipLaunchKernelGGL(k_craig_update_short<1>, dim3(gm), dim3(kBlock), 0, s, &S->ctl, (int)it, h->Cmu, 0, h->Cw, y, m,
-                       h->pW);
-    launch_spmv<1>(h, TAG_A, h->Cv, h->Cmu, h->Cmu, &S->ctl, &S->ctl, h->pS2);
-    hipLaunchKernelGGL(k_craig_sb, dim3(1), dim3(kBlock), 0, s, S, h->pS2, h->A.nblk, h->pW, gm, (int)it, prog);
-    h->launches += 4;
-    if (h->prog_host[slot].done) break;
-    if (it - h->prog_host[slot].iter >= look) {
-      if (int rc = wait_progress(h, slot, (int)(it - look + 1), &S->ctl.done, &S->iter)) return rc;
-      if (h->prog_host[slot].done) break;
-    }
-  }
-  HIPCHK(h, hipMemcpyAsync(st_out, &S->stats, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
+int run_lanes(fpsq_handle h, Lane* lanes, int nlanes) {
+  if (nlanes == 2 && h->opt.fuse_two_rhs) return run_krylov<2>(h, lanes);
+  for (int l = 0; l < nlanes; ++l)
+    if (int rc = run_krylov<1>(h, lanes + l)) return rc;
   return 0;
 }
 
@@ -467,14 +646,45 @@ int call_end(fpsq_handle h) {
 
 int soft_rc(const fpsq_stats st[2]) { return (st[0].solved ? 0 : 1) | (st[1].solved ? 0 : 2); }
 
-// device-side solve_two_mixed: g (n), c (m) device pointers; results left in h->p1, h->Lx (q1), h->Cx (p2), h->Cy (q2)
+// device-side solve_two_mixed: g (n), c (m) device pointers; results left in h->p1, h->Lx[0] (q1), h->Cx (p2), h->Cy (q2)
 int two_mixed_device(fpsq_handle h, const double* g, const double* c) {
+  Lane lanes[2];
   // (q1, stats1) = solve_least_square(qds, Aop', rhs1, sqrt(delta))      src/solve_linear_system.jl:123
-  if (int rc = run_lsqr(h, 0, g, std::sqrt(h->delta), h->Lx, &h->hstats[0])) return rc;
-  // p1 = rhs1 - Aop' q1                                                   :126-127
-  spmv_const(h, TAG_AT, -1.0, h->Lx, 1.0, g, h->p1);
+  lanes[0].kind = LANE_LSQR;
+  lanes[0].rhs = g;
+  lanes[0].lambda = std::sqrt(h->delta);
+  lanes[0].x = h->Lx[0];
+  lanes[0].st = &h->hstats[0];
   // (p2, q2, stats2) = solve_least_norm(qds, Aop, -rhs2, delta); p2 = -p2 :132-133
-  if (int rc = run_craig(h, c, -1.0, h->delta, -1.0, h->Cx, h->Cy, &h->hstats[1])) return rc;
+  lanes[1].kind = LANE_CRAIG;
+  lanes[1].rhs = c;
+  lanes[1].rhs_scale = -1.0;
+  lanes[1].delta = h->delta;
+  lanes[1].xsign = -1.0;
+  lanes[1].x = h->Cx;
+  lanes[1].y = h->Cy;
+  lanes[1].st = &h->hstats[1];
+  if (int rc = run_lanes(h, lanes, 2)) return rc;
+  // p1 = rhs1 - Aop' q1                                                   :126-127
+  spmv_const(h, TAG_AT, -1.0, h->Lx[0], 1.0, g, h->p1);
+  return 0;
+}
+
+// device-side solve_two_least_squares: results in h->p1, h->Lx[0], h->p2b, h->Lx[1]
+int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2) {
+  Lane lanes[2];
+  const double* rhs[2] = {r1, r2};
+  for (int l = 0; l < 2; ++l) {
+    lanes[l].kind = LANE_LSQR;
+    lanes[l].rhs = rhs[l];
+    lanes[l].lambda = std::sqrt(h->delta);
+    lanes[l].x = h->Lx[l];
+    lanes[l].st = &h->hstats[l];
+  }
+  if (int rc = run_lanes(h, lanes, 2)) return rc;
+  // src/solve_linear_system.jl:90-91 and :99-100
+  spmv_const(h, TAG_AT, -1.0, h->Lx[0], 1.0, r1, h->p1);
+  spmv_const(h, TAG_AT, -1.0, h->Lx[1], 1.0, r2, h->p2b);
   return 0;
 }
 
@@ -728,7 +938,7 @@ int fpsq_solve_two_mixed(fpsq_handle h, const double* rhs1, const double* rhs2, 
   call_begin(h);
   if (int rc = two_mixed_device(h, h->in_n1, h->in_m)) return rc;
   HIPCHK(h, hipMemcpyAsync(p1, h->p1, nb, hipMemcpyDefault, s));
-  HIPCHK(h, hipMemcpyAsync(q1, h->Lx, mb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(q1, h->Lx[0], mb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(p2, h->Cx, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(q2, h->Cy, mb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;
@@ -750,16 +960,11 @@ int fpsq_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double
   HIPCHK(h, hipMemcpyAsync(h->in_n1, rhs1, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(h->in_n2, rhs2, nb, hipMemcpyDefault, s));
   call_begin(h);
-  const double lam = std::sqrt(h->delta);
-  // src/solve_linear_system.jl:87-91 and :96-100
-  if (int rc = run_lsqr(h, 0, h->in_n1, lam, h->Lx, &h->hstats[0])) return rc;
-  spmv_const(h, TAG_AT, -1.0, h->Lx, 1.0, h->in_n1, h->p1);
-  if (int rc = run_lsqr(h, 1, h->in_n2, lam, h->Lx2, &h->hstats[1])) return rc;
-  spmv_const(h, TAG_AT, -1.0, h->Lx2, 1.0, h->in_n2, h->p2b);
+  if (int rc = two_least_squares_device(h, h->in_n1, h->in_n2)) return rc;
   HIPCHK(h, hipMemcpyAsync(p1, h->p1, nb, hipMemcpyDefault, s));
-  HIPCHK(h, hipMemcpyAsync(q1, h->Lx, mb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(q1, h->Lx[0], mb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(p2, h->p2b, nb, hipMemcpyDefault, s));
-  HIPCHK(h, hipMemcpyAsync(q2, h->Lx2, mb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(q2, h->Lx[1], mb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;
   st[0] = h->hstats[0];
   st[1] = h->hstats[1];
@@ -788,7 +993,7 @@ int fpsq_ys_gs(fpsq_handle h, const double* g, const double* c, double sigma, do
   if (int rc = two_mixed_device(h, h->in_n1, h->in_m)) return rc;
   // src/model-Fletcherpenaltynlp.jl:244-248
   hipLaunchKernelGGL(k_gs, dim3(ew_grid(h->n)), dim3(kBlock), 0, s, h->p1, h->Cx, sigma, h->gs, h->n);
-  hipLaunchKernelGGL(k_ys, dim3(ew_grid(h->m)), dim3(kBlock), 0, s, h->Lx, h->Cy, (const double*)nullptr, sigma, h->ys,
+  hipLaunchKernelGGL(k_ys, dim3(ew_grid(h->m)), dim3(kBlock), 0, s, h->Lx[0], h->Cy, (const double*)nullptr, sigma, h->ys,
                      h->m, (double*)nullptr, (double*)nullptr);
   h->launches += 2;
   HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
@@ -888,17 +1093,17 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   }
   call_begin(h);
   // user-model evaluations of _compute_ys_gs!  (src/model-Fletcherpenaltynlp.jl:238-240)
-  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, h->xin, dxk, h->g, n, h->pE2, h->pE3);
+  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, h->xin, dxk, h->g, n, h->pQ[0], h->pQ[1]);
   h->launches++;
   spmv_const(h, TAG_A, 1.0, h->xin, -1.0, qp->b, h->c);  // c = A x - b
   if (int rc = two_mixed_device(h, h->g, h->c)) return rc;
   // ys = q1 + sigma q2 and the dots of objgrad!
-  hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx, h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax);
+  hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax);
   h->launches++;
   if (rho > 0.0) spmv_const(h, TAG_AT, 1.0, h->c, 0.0, nullptr, h->jc);  // J'c   (:424-428)
   hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn), dim3(kBlock), 0, s, h->p1, h->Cx, qp->q, h->jc, h->xin, dxk, sigma,
                      rho, eta, h->gs, h->gx, n);
-  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pE2, h->pE3, gn, h->pE, h->pE + kEwBlocksMax, gm, rho,
+  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pQ[0], h->pQ[1], gn, h->pE, h->pE + kEwBlocksMax, gm, rho,
                      eta, h->dscal);
   h->launches += 2;
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->dscal, 3 * 8, hipMemcpyDeviceToHost, s));

@@ -236,84 +236,109 @@ __global__ __launch_bounds__(kBlock) void k_store_lane(const double* __restrict_
     out[i] = a * x[i * NL + lane] + (b != 0.0 ? b * y[i] : 0.0);
 }
 
-// LSQR direction/solution update (Krylov.jl lsqr!: x += (phi/rho) w; w = v - (theta/rho) w) with v = vt / alpha
-// deferred, plus the partial of ||w_new||^2 that the next iteration's dNorm^2 needs.
-//   e[0] = phi/rho, e[1] = theta/rho, e[2] = 1/alpha
-template <int NL>
-__global__ __launch_bounds__(kBlock) void k_lsqr_update(const LaneCtl* ctl, int it, const double* __restrict__ vt,
-                                                        int lane, double* x, double* w, int64_t n, double* partials) {
-  if (ctl->done && ctl->upd_iter != it) return;
-  __shared__ double red[4];
+// ---- Krylov vector updates.  Several independent updates (the LSQR x/w update of the previous iteration, the CRAIG
+// long and short updates of this one) are merged into ONE launch: consecutive workgroup ranges run different bodies.
+
+enum UpdKind : int32_t { UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT };
+
+struct UpdSeg {
+  int32_t kind;
+  int32_t it;        // iteration this update belongs to (see LaneCtl::upd_iter)
+  const LaneCtl* ctl;
+  const double* src; // interleaved Golub-Kahan vector [len][NL]
+  int32_t lane;      // which interleaved lane of src
+  int32_t nblk;      // workgroups assigned to this segment
+  double* a;         // LSQR: x      CRAIG long: xs      CRAIG short: w
+  double* b;         // LSQR: w      CRAIG long: w2s     CRAIG short: y
+  int64_t len;
+  double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
+};
+
+// LSQR (Krylov.jl lsqr!): x += (phi/rho) w; w = v - (theta/rho) w, with v = vt / alpha deferred.
+//   e[0] = phi/rho, e[1] = theta/rho, e[2] = 1/alpha.   WINIT: w = vt / alpha only (w_1 = v_1).
+template <int NL, bool WINIT>
+__device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red) {
+  const LaneCtl* ctl = s.ctl;
+  if (WINIT ? (ctl->done != 0) : (ctl->done && ctl->upd_iter != s.it)) return;
   const double sg = ctl->e[0], tr = ctl->e[1], ia = ctl->e[2];
   double sq = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double wi = w[i];
-    x[i] += sg * wi;
-    const double wn = vt[i * NL + lane] * ia - tr * wi;
-    w[i] = wn;
-    sq += wn * wn;
-  }
-  const double t = block_sum(sq, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
-
-// w = vt / alpha (LSQR start: w_1 = v_1), partial of ||w||^2.  e[2] = 1/alpha
-template <int NL>
-__global__ __launch_bounds__(kBlock) void k_lsqr_winit(const LaneCtl* ctl, const double* __restrict__ vt, int lane,
-                                                       double* w, int64_t n, double* partials) {
-  if (ctl->done) return;
-  __shared__ double red[4];
-  const double ia = ctl->e[2];
-  double sq = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double wn = vt[i * NL + lane] * ia;
-    w[i] = wn;
-    sq += wn * wn;
-  }
-  const double t = block_sum(sq, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
-}
-
-// CRAIG updates (Krylov.jl craig!), long (n) part.  `xs` accumulates s * x (s = -1 gives p2 = -x directly,
-// src/solve_linear_system.jl:133).  With v = vt / alpha and the true w2 = omega * w2s (scaling by s2 deferred):
-//   lambda > 0:  xs += e0 * vt + e1 * w2s;   w2s = e2 * vt + e3 * w2s
-//       e0 = s xi c1 / alpha, e1 = s xi s1 omega, e2 = s1 / alpha, e3 = -c1 omega
-//   lambda = 0:  xs += e0 * vt                      (e0 = s xi / alpha)
-template <int NL, bool REG>
-__global__ __launch_bounds__(kBlock) void k_craig_update_long(const LaneCtl* ctl, int it, const double* __restrict__ vt,
-                                                              int lane, double* xs, double* w2s, int64_t n) {
-  if (ctl->done && ctl->upd_iter != it) return;
-  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3];
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double v = vt[i * NL + lane];
-    if (REG) {
-      const double w2 = w2s[i];
-      xs[i] += e0 * v + e1 * w2;
-      w2s[i] = e2 * v + e3 * w2;
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    double wn;
+    if (WINIT) {
+      wn = s.src[i * NL + s.lane] * ia;
     } else {
-      xs[i] += e0 * v;
+      const double wi = s.b[i];
+      s.a[i] += sg * wi;
+      wn = s.src[i * NL + s.lane] * ia - tr * wi;
+    }
+    s.b[i] = wn;
+    sq += wn * wn;
+  }
+  const double t = block_sum(sq, red);
+  if (threadIdx.x == 0) s.partials[blk] = t;
+}
+
+// CRAIG (Krylov.jl craig!), long (n) part.  `xs` accumulates sgn * x (sgn = -1 gives p2 = -x directly,
+// src/solve_linear_system.jl:133).  With v = vt / alpha and the true w2 = omega * w2s (the scaling by s2 is deferred):
+//   lambda > 0:  xs += e0 * vt + e1 * w2s;   w2s = e2 * vt + e3 * w2s
+//       e0 = sgn xi c1 / alpha, e1 = sgn xi s1 omega, e2 = s1 / alpha, e3 = -c1 omega
+//   lambda = 0:  xs += e0 * vt                      (e0 = sgn xi / alpha)
+template <int NL, bool REG>
+__device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk) {
+  const LaneCtl* ctl = s.ctl;
+  if (ctl->done && ctl->upd_iter != s.it) return;
+  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3];
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    const double v = s.src[i * NL + s.lane];
+    if (REG) {
+      const double w2 = s.b[i];
+      s.a[i] += e0 * v + e1 * w2;
+      s.b[i] = e2 * v + e3 * w2;
+    } else {
+      s.a[i] += e0 * v;
     }
   }
 }
 
-// CRAIG updates, short (m) part:  w = u - (theta/rho_prev) w with u = e4 * mut (= mu Mu~ / beta);  y += e6 * w;
-// partial of ||w||^2.   e4 = mu/beta, e5 = theta/rho_prev, e6 = xi/rho
+// CRAIG short (m) part:  w = u - (theta/rho_prev) w with u = e4 * mut (= mu Mu~ / beta);  y += e6 * w.
+//   e4 = mu/beta, e5 = theta/rho_prev, e6 = xi/rho
 template <int NL>
-__global__ __launch_bounds__(kBlock) void k_craig_update_short(const LaneCtl* ctl, int it, const double* __restrict__ mut,
-                                                               int lane, double* w, double* y, int64_t m,
-                                                               double* partials) {
-  if (ctl->done && ctl->upd_iter != it) return;
-  __shared__ double red[4];
+__device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double* red) {
+  const LaneCtl* ctl = s.ctl;
+  if (ctl->done && ctl->upd_iter != s.it) return;
   const double e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6];
   double sq = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-    const double wn = e4 * mut[i * NL + lane] - e5 * w[i];
-    w[i] = wn;
-    y[i] += e6 * wn;
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    const double wn = e4 * s.src[i * NL + s.lane] - e5 * s.a[i];
+    s.a[i] = wn;
+    s.b[i] += e6 * wn;
     sq += wn * wn;
   }
   const double t = block_sum(sq, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  if (threadIdx.x == 0) s.partials[blk] = t;
+}
+
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_updates(UpdSeg s0, UpdSeg s1, UpdSeg s2) {
+  __shared__ double red[4];
+  int blk = blockIdx.x;
+  const UpdSeg* s = &s0;
+  if (blk >= s0.nblk) {
+    blk -= s0.nblk;
+    s = &s1;
+    if (blk >= s1.nblk) {
+      blk -= s1.nblk;
+      s = &s2;
+    }
+  }
+  switch (s->kind) {
+    case UPD_LSQR: upd_lsqr<NL, false>(*s, blk, red); break;
+    case UPD_LSQR_WINIT: upd_lsqr<NL, true>(*s, blk, red); break;
+    case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true>(*s, blk); break;
+    case UPD_CRAIG_LONG: upd_craig_long<NL, false>(*s, blk); break;
+    case UPD_CRAIG_SHORT: upd_craig_short<NL>(*s, blk, red); break;
+    default: break;
+  }
 }
 
 // ---- equality-QP user model + penalty epilogues (src/model-Fletcherpenaltynlp.jl:238-248, 385-397, 419-433)

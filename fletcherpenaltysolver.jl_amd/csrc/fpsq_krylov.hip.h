@@ -75,10 +75,7 @@ __device__ __forceinline__ void lane_finish(LaneCtl& c, int it) {
 }
 
 // after u~ = b: beta1 = ||b||
-__global__ __launch_bounds__(kBlock) void k_lsqr_begin(LsqrState* S, const double* pb, int npb, Progress* prog) {
-  __shared__ double red[4];
-  const double bb = reduce_partials(pb, npb, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void lsqr_begin_step(LsqrState* S, double bb, Progress* prog) {
   const double beta1 = sqrt(bb);
   S->beta1 = beta1;
   S->beta = beta1;
@@ -100,11 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_begin(LsqrState* S, const doubl
 }
 
 // after v~_1 = B'u_1: alpha_1 = ||v~_1||; start-up tests of lsqr!
-__global__ __launch_bounds__(kBlock) void k_lsqr_begin2(LsqrState* S, const double* pa, int npa, Progress* prog) {
-  if (S->ctl.done) return;
-  __shared__ double red[4];
-  const double aa = reduce_partials(pa, npa, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void lsqr_begin2_step(LsqrState* S, double aa, Progress* prog) {
   const double alpha = sqrt(aa), beta1 = S->beta1;
   S->alpha = alpha;
   S->Anorm2 = aa;
@@ -146,11 +139,7 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_begin2(LsqrState* S, const doub
 }
 
 // after u~ <- B v - alpha u: beta = ||u~||
-__global__ __launch_bounds__(kBlock) void k_lsqr_sa(LsqrState* S, const double* pb, int npb) {
-  if (S->ctl.done) return;
-  __shared__ double red[4];
-  const double bb = reduce_partials(pb, npb, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void lsqr_sa_step(LsqrState* S, double bb) {
   const double beta = sqrt(bb), alpha = S->alpha;
   S->beta = beta;
   if (beta != 0.0) {
@@ -165,13 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_sa(LsqrState* S, const double* 
 }
 
 // after v~ <- B'u - beta v: alpha = ||v~||, then the QR update, norm estimates and stopping tests of lsqr!
-__global__ __launch_bounds__(kBlock) void k_lsqr_sb(LsqrState* S, const double* pa, int npa, const double* pww,
-                                                    int npww, int it, Progress* prog) {
-  if (S->ctl.done) return;
-  __shared__ double red[4];
-  const double aa = reduce_partials(pa, npa, red);
-  const double ww = reduce_partials(pww, npww, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void lsqr_sb_step(LsqrState* S, double aa, double ww, int it, Progress* prog) {
   const double beta = S->beta, lambda = S->lambda;
   double alpha = S->alpha;
   if (!S->ctl.skip) alpha = sqrt(aa);
@@ -284,10 +267,7 @@ struct CraigState {
 };
 
 // after Mu~ = b: beta1 = sqrt(mu) ||b||
-__global__ __launch_bounds__(kBlock) void k_craig_begin(CraigState* S, const double* pb, int npb, Progress* prog) {
-  __shared__ double red[4];
-  const double bb = reduce_partials(pb, npb, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void craig_begin_step(CraigState* S, double bb, Progress* prog) {
   const double beta1 = sqrt(S->mu * bb);
   S->beta1 = beta1;
   S->beta = beta1;
@@ -330,11 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_craig_begin(CraigState* S, const dou
 }
 
 // after v~ <- B'u - beta v: alpha = ||v~||, first Givens, xi; coefficients of the x / w2 / w / y updates
-__global__ __launch_bounds__(kBlock) void k_craig_sa(CraigState* S, const double* pa, int npa, int it, Progress* prog) {
-  if (S->ctl.done) return;
-  __shared__ double red[4];
-  const double aa = reduce_partials(pa, npa, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void craig_sa_step(CraigState* S, double aa, int it, Progress* prog) {
   const double alpha = sqrt(aa);
   if (alpha == 0.0) {  // craig!: inconsistent = true; leave the loop without touching x, y
     S->stats.inconsistent = 1;
@@ -375,13 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_craig_sa(CraigState* S, const double
 }
 
 // after Mu~ <- B v - alpha Mu: beta, second Givens, estimates and the stopping tests of craig!
-__global__ __launch_bounds__(kBlock) void k_craig_sb(CraigState* S, const double* pb, int npb, const double* pww,
-                                                     int npww, int it, Progress* prog) {
-  if (S->ctl.done) return;
-  __shared__ double red[4];
-  const double bb = reduce_partials(pb, npb, red);
-  const double ww = reduce_partials(pww, npww, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void craig_sb_step(CraigState* S, double bb, double ww, int it, Progress* prog) {
   const double lambda = S->lambda, alpha = S->alpha;
   S->Dnorm2 += sqrt(ww);  // craig! accumulates ||w||, not ||w||^2
   const double beta = sqrt(S->mu * bb);
@@ -436,6 +406,98 @@ __global__ __launch_bounds__(kBlock) void k_craig_sb(CraigState* S, const double
     publish(prog, it, 1);
   } else {
     publish(prog, it, 0);
+  }
+}
+
+
+// =============================================================================================== step kernel
+// One launch advances up to two recurrences: workgroup b handles step[b].  1024 threads so that the <= ~5000 norm
+// partials of a product are summed with a handful of independent loads per thread (fixed order => reproducible).
+enum StepKind : int32_t {
+  STEP_NONE = 0,
+  STEP_LSQR_BEGIN, STEP_LSQR_BEGIN2, STEP_LSQR_SA, STEP_LSQR_SB,
+  STEP_CRAIG_BEGIN, STEP_CRAIG_SA, STEP_CRAIG_SB,
+  STEP_MINRES_BEGIN, STEP_MINRES_A, STEP_MINRES_B
+};
+
+struct StepArgs {
+  int32_t kind;
+  int32_t it;
+  void* state;
+  const double* p0;  // partials of the product that just ran
+  const double* p1;  // second partial array (||w||^2 of the last update), may be null
+  int32_t n0, n1;
+  Progress* prog;
+};
+
+constexpr int kStepThreads = 1024;
+
+// sums of two partial arrays at once; results valid in thread 0
+__device__ __forceinline__ void reduce_two(const double* p0, int n0, const double* p1, int n1, double* red,
+                                           double& s0, double& s1) {
+  double a = 0.0, b = 0.0;
+  const int t = threadIdx.x;
+  constexpr int U = 8;
+  for (int base = 0; base < n0; base += kStepThreads * U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kStepThreads + t;
+      v[u] = (i < n0) ? p0[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) a += v[u];
+  }
+  for (int base = 0; base < n1; base += kStepThreads * U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kStepThreads + t;
+      v[u] = (i < n1) ? p1[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) b += v[u];
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = t & 63, w = t >> 6;
+  if (lane == 0) {
+    red[w] = a;
+    red[16 + w] = b;
+  }
+  __syncthreads();
+  if (t == 0) {
+    s0 = 0.0;
+    s1 = 0.0;
+    for (int k = 0; k < kStepThreads / 64; ++k) {
+      s0 += red[k];
+      s1 += red[16 + k];
+    }
+  }
+}
+
+__device__ __forceinline__ bool lane_done(const StepArgs& a) {
+  // LaneCtl is the first member of every state struct
+  return a.kind != STEP_LSQR_BEGIN && a.kind != STEP_CRAIG_BEGIN && a.kind != STEP_MINRES_BEGIN &&
+         reinterpret_cast<const LaneCtl*>(a.state)->done;
+}
+
+__global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1) {
+  const StepArgs& a = blockIdx.x == 0 ? a0 : a1;
+  if (a.kind == STEP_NONE || lane_done(a)) return;
+  __shared__ double red[32];
+  double s0 = 0.0, s1 = 0.0;
+  reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);
+  if (threadIdx.x != 0) return;
+  switch (a.kind) {
+    case STEP_LSQR_BEGIN: lsqr_begin_step((LsqrState*)a.state, s0, a.prog); break;
+    case STEP_LSQR_BEGIN2: lsqr_begin2_step((LsqrState*)a.state, s0, a.prog); break;
+    case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)a.state, s0); break;
+    case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)a.state, s0, s1, a.it, a.prog); break;
+    case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)a.state, s0, a.prog); break;
+    case STEP_CRAIG_SA: craig_sa_step((CraigState*)a.state, s0, a.it, a.prog); break;
+    case STEP_CRAIG_SB: craig_sb_step((CraigState*)a.state, s0, s1, a.it, a.prog); break;
+    default: break;
   }
 }
 
