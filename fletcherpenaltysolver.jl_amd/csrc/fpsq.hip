@@ -166,8 +166,11 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
   std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows);
   D.nblk = (int32_t)rb.size() - 1;
   if (int rc = dalloc(h, &D.rowptr, H.rowptr.size())) return rc;
-  if (int rc = dalloc(h, &D.colind, H.colind.size())) return rc;
-  if (int rc = dalloc(h, &D.vals, H.colind.size())) return rc;
+  // one padding entry (column 0, value 0): the product kernels read index `s` of an empty row block unconditionally
+  if (int rc = dalloc(h, &D.colind, H.colind.size() + 1)) return rc;
+  if (int rc = dalloc(h, &D.vals, H.colind.size() + 1)) return rc;
+  HIPCHK(h, hipMemset(D.colind + H.colind.size(), 0, 4));
+  HIPCHK(h, hipMemset(D.vals + H.colind.size(), 0, 8));
   if (int rc = dalloc(h, &D.rowblk, rb.size())) return rc;
   HIPCHK(h, hipMemcpy(D.rowptr, H.rowptr.data(), H.rowptr.size() * 4, hipMemcpyHostToDevice));
   if (!H.colind.empty())

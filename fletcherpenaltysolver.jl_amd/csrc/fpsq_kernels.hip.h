@@ -58,6 +58,44 @@ __device__ __forceinline__ double reduce_partials(const double* p, int n, double
   return block_sum(s, red);
 }
 
+// Sum of LDS products prod[j], j = first, first + stride, ... < end (NL interleaved values each), accumulated into
+// acc.  Four independent LDS reads are kept in flight per step: a one-read-per-iteration loop exposes the full LDS
+// latency on every element and dominated the A' product (rows of ~10 nonzeros, one lane per row).
+template <int NL>
+__device__ __forceinline__ void row_segment_sum(const double* prod, int first, int end, int stride, double* acc) {
+  int j = first;
+  for (; j + 3 * stride < end; j += 4 * stride) {
+    if (NL == 1) {
+      const double d0 = prod[j], d1 = prod[j + stride], d2 = prod[j + 2 * stride], d3 = prod[j + 3 * stride];
+      acc[0] += (d0 + d1) + (d2 + d3);
+    } else {
+      const double2 d0 = *reinterpret_cast<const double2*>(prod + 2 * j);
+      const double2 d1 = *reinterpret_cast<const double2*>(prod + 2 * (j + stride));
+      const double2 d2 = *reinterpret_cast<const double2*>(prod + 2 * (j + 2 * stride));
+      const double2 d3 = *reinterpret_cast<const double2*>(prod + 2 * (j + 3 * stride));
+      acc[0] += (d0.x + d1.x) + (d2.x + d3.x);
+      acc[NL - 1] += (d0.y + d1.y) + (d2.y + d3.y);
+    }
+  }
+  // tail: up to 3 elements, still issued together
+  {
+    const bool k0 = j < end, k1 = j + stride < end, k2 = j + 2 * stride < end;
+    const int j0 = k0 ? j : first, j1 = k1 ? j + stride : first, j2 = k2 ? j + 2 * stride : first;
+    if (first < end) {
+      if (NL == 1) {
+        const double d0 = prod[j0], d1 = prod[j1], d2 = prod[j2];
+        acc[0] += ((k0 ? d0 : 0.0) + (k1 ? d1 : 0.0)) + (k2 ? d2 : 0.0);
+      } else {
+        const double2 d0 = *reinterpret_cast<const double2*>(prod + 2 * j0);
+        const double2 d1 = *reinterpret_cast<const double2*>(prod + 2 * j1);
+        const double2 d2 = *reinterpret_cast<const double2*>(prod + 2 * j2);
+        acc[0] += ((k0 ? d0.x : 0.0) + (k1 ? d1.x : 0.0)) + (k2 ? d2.x : 0.0);
+        acc[NL - 1] += ((k0 ? d0.y : 0.0) + (k1 ? d1.y : 0.0)) + (k2 ? d2.y : 0.0);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ SpMV / SpMM
 //
 // out[r][l] = ca_l * sum_k vals[k] * x[colind[k]][l] + cb_l * yin[r][l],  partial[l][blk] = sum_r out[r][l]^2
@@ -119,7 +157,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
       }
     }
   } else {
-    // phase 1: coalesced stream of the block's nonzeros -> products in LDS
+    // phase 1: coalesced stream of the block's nonzeros -> products in LDS.  Every lane issues all of its loads and
+    // all of its gathers unconditionally (out-of-range lanes use column 0 with value 0 and park a zero in an unused
+    // slot): a per-element branch would make hipcc wait for each gather before issuing the next one.
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
     double v[kPer];
@@ -127,20 +167,23 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     for (int k = 0; k < kPer; ++k) {
       const int i = s + tid + k * kBlock;
       const bool ok = i < e;
-      cidx[k] = ok ? A.colind[i] : -1;
-      v[k] = ok ? A.vals[i] : 0.0;
+      const int ii = ok ? i : s;
+      cidx[k] = A.colind[ii];
+      v[k] = ok ? A.vals[ii] : 0.0;
     }
+    if (NL == 1) {
+      double xv[kPer];
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      if (cidx[k] >= 0) {
-        const int j = tid + k * kBlock;
-        if (NL == 1) {
-          prod[j] = v[k] * x[cidx[k]];
-        } else {
-          const double2 xv = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
-          *reinterpret_cast<double2*>(prod + 2 * j) = make_double2(v[k] * xv.x, v[k] * xv.y);
-        }
-      }
+      for (int k = 0; k < kPer; ++k) xv[k] = x[cidx[k]];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) prod[tid + k * kBlock] = v[k] * xv[k];
+    } else {
+      double2 xv[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+#pragma unroll
+      for (int k = 0; k < kPer; ++k)
+        *reinterpret_cast<double2*>(prod + 2 * (tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
     }
     __syncthreads();
     // phase 2: G lanes per row
@@ -156,15 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
       for (int l = 0; l < NL; ++l) acc[l] = 0.0;
       if (valid) {
         const int a = A.rowptr[r0 + rr] - s, b = A.rowptr[r0 + rr + 1] - s;
-        for (int j = a + gl; j < b; j += G) {
-          if (NL == 1) {
-            acc[0] += prod[j];
-          } else {
-            const double2 pv = *reinterpret_cast<const double2*>(prod + 2 * j);
-            acc[0] += pv.x;
-            acc[NL - 1] += pv.y;
-          }
-        }
+        row_segment_sum<NL>(prod, a + gl, b, G, acc);
       }
       for (int off = G >> 1; off > 0; off >>= 1) {
 #pragma unroll
@@ -319,25 +354,28 @@ __device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double
 }
 
 template <int NL>
-__global__ __launch_bounds__(kBlock) void k_updates(UpdSeg s0, UpdSeg s1, UpdSeg s2) {
-  __shared__ double red[4];
-  int blk = blockIdx.x;
-  const UpdSeg* s = &s0;
-  if (blk >= s0.nblk) {
-    blk -= s0.nblk;
-    s = &s1;
-    if (blk >= s1.nblk) {
-      blk -= s1.nblk;
-      s = &s2;
-    }
-  }
-  switch (s->kind) {
-    case UPD_LSQR: upd_lsqr<NL, false>(*s, blk, red); break;
-    case UPD_LSQR_WINIT: upd_lsqr<NL, true>(*s, blk, red); break;
-    case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true>(*s, blk); break;
-    case UPD_CRAIG_LONG: upd_craig_long<NL, false>(*s, blk); break;
-    case UPD_CRAIG_SHORT: upd_craig_short<NL>(*s, blk, red); break;
+__device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
+  switch (s.kind) {
+    case UPD_LSQR: upd_lsqr<NL, false>(s, blk, red); break;
+    case UPD_LSQR_WINIT: upd_lsqr<NL, true>(s, blk, red); break;
+    case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true>(s, blk); break;
+    case UPD_CRAIG_LONG: upd_craig_long<NL, false>(s, blk); break;
+    case UPD_CRAIG_SHORT: upd_craig_short<NL>(s, blk, red); break;
     default: break;
+  }
+}
+
+// (the segments are kernel arguments: select by branch, never through a pointer, or they are spilled to scratch)
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_updates(const UpdSeg s0, const UpdSeg s1, const UpdSeg s2) {
+  __shared__ double red[4];
+  const int blk = blockIdx.x;
+  if (blk < s0.nblk) {
+    upd_run<NL>(s0, blk, red);
+  } else if (blk < s0.nblk + s1.nblk) {
+    upd_run<NL>(s1, blk - s0.nblk, red);
+  } else {
+    upd_run<NL>(s2, blk - s0.nblk - s1.nblk, red);
   }
 }
 

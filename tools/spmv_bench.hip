@@ -287,6 +287,203 @@ __global__ __launch_bounds__(kBlock) void k_spmv_ntgather(CsrView A, const doubl
   const double t = block_sum(sq, red); if (tid == 0) partials[L] = t;
 }
 
+// ---------------------------------------------------------------- candidate: RGCS = row groups, column-sorted tiles
+// Entries of a row group are stored sorted by COLUMN (so the 64 gathers of a wave instruction fall in a handful
+// of cache lines) and carry, packed with the group-relative column, their slot in the tile's ROW-major order, so
+// the products land in LDS grouped by row and are reduced exactly like in the CSR-stream kernel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int kTile = 2048;
+constexpr int kColBits = 21;
+constexpr int kMaxPass = 4;
+struct RgcsView {
+  const uint32_t* pidx; const double* vals;
+  const int32_t* grow; const int32_t* gent; const int32_t* gcmin; const int32_t* gtp; const uint16_t* tptr;
+  int ng; int nrows;
+};
+template <int NL>
+struct TileRegs {   // everything one tile needs from global memory, kept raw until consumed
+  uint32_t pk[kTile / kBlock];
+  double v[kTile / kBlock];
+  uint32_t traw[kMaxPass];
+};
+
+template <int NL, int ABL = 0>
+__global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin, double* yout,
+                                                      const LaneCtl* ctl0, const LaneCtl* ctl1, double* partials, int grp_per_xcd) {
+  const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
+  if (g >= M.ng) return;
+  const LaneCtl* c[2] = {ctl0, ctl1};
+  double ca[NL], cb[NL]; bool act[NL]; bool any = false;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) { act[l] = !(c[l]->done | c[l]->skip); ca[l] = c[l]->ca; cb[l] = c[l]->cb; any |= act[l]; }
+  if (!any) return;
+  __shared__ double prod[kTile * NL];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int r0 = M.grow[g], R = M.grow[g + 1] - r0;
+  const int e0 = M.gent[g], e1 = M.gent[g + 1];
+  const int cmin = M.gcmin[g];
+  const uint16_t* tp = M.tptr + M.gtp[g];
+  int G = 1; while (G < 64 && G * 2 * R <= kBlock) G <<= 1;
+  const int rpp = kBlock / G, gid = tid / G, gl = tid % G;
+  double acc[kMaxPass][NL];
+#pragma unroll
+  for (int p = 0; p < kMaxPass; ++p)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[p][l] = 0.0;
+  constexpr int kPer = kTile / kBlock;
+  // Software pipeline, two register sets: while tile j is gathered / multiplied / reduced, the loads of tile j+1 are
+  // already in flight.  Issue order inside an iteration is  gathers(j) -> loads(j+1)  so that waiting for the
+  // gathers (s_waitcnt vmcnt(#loads of j+1)) leaves the younger streaming loads outstanding.
+  auto fetch = [&](TileRegs<NL>& T, int base, int tile) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = base + tid + k * kBlock; const int ii = i < e1 ? i : e0;
+      T.pk[k] = M.pidx[ii]; T.v[k] = M.vals[ii];
+    }
+    const uint16_t* tpt = tp + (size_t)tile * (R + 1);
+#pragma unroll
+    for (int p = 0; p < kMaxPass; ++p) {
+      const int rr = p * rpp + gid; const int rq = rr < R ? rr : 0;
+      __builtin_memcpy(&T.traw[p], tpt + rq, 4);
+    }
+  };
+  auto process = [&](TileRegs<NL>& C, TileRegs<NL>& N, int base, int tile) {
+    int sa[kMaxPass], sb[kMaxPass];
+    double2 xv[kPer]; uint32_t pq[kPer]; double vq[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const bool ok = base + tid + k * kBlock < e1;
+      pq[k] = ok ? C.pk[k] : ((uint32_t)(tid + k * kBlock) << kColBits); vq[k] = ok ? C.v[k] : 0.0;
+      const int col = (ABL & 1) ? (int)(pq[k] & 15u) : cmin + (int)(pq[k] & ((1u << kColBits) - 1));
+      if (NL == 1) xv[k].x = x[col]; else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
+    }
+#pragma unroll
+    for (int p = 0; p < kMaxPass; ++p) { const bool valid = p * rpp + gid < R; sa[p] = (int)(C.traw[p] & 0xffffu); sb[p] = valid ? (int)(C.traw[p] >> 16) : sa[p]; }
+    __builtin_amdgcn_sched_barrier(0);   // gathers(j) must be OLDER than loads(j+1): vmcnt retires in order
+    // unconditional (addresses are clamped inside): a branch here would make the waitcnt pass assume the loads might
+    // not have been issued and wait for vmcnt(0)
+    fetch(N, base + kTile, base + kTile < e1 ? tile + 1 : 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int slot = (ABL & 2) ? tid + k * kBlock : (int)(pq[k] >> kColBits);
+      if (NL == 1) prod[slot] = vq[k] * xv[k].x;
+      else *reinterpret_cast<double2*>(prod + 2 * slot) = make_double2(vq[k] * xv[k].x, vq[k] * xv[k].y);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int p = 0; p < kMaxPass; ++p) {
+      const int a = (ABL & 4) ? tid : sa[p], b = (ABL & 4) ? tid + (p == 0) : sb[p];
+      row_segment_sum<NL>(prod, a + gl, b, G, acc[p]);
+    }
+    lds_barrier();
+  };
+  TileRegs<NL> RA, RB;
+  fetch(RA, e0, 0);
+  int tile = 0;
+  for (int base = e0; base < e1; base += 2 * kTile, tile += 2) {
+    process(RA, RB, base, tile);
+    if (base + kTile < e1) process(RB, RA, base + kTile, tile + 1);
+  }
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+#pragma unroll
+  for (int p = 0; p < kMaxPass; ++p) {
+    for (int off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[p][l] += __shfl_down(acc[p][l], off, 64);
+    }
+    const int rr = p * rpp + gid;
+    if (rr < R && gl == 0) {
+      const size_t row = (size_t)(r0 + rr);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) if (act[l]) { const double o = ca[l] * acc[p][l] + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0); yout[row * NL + l] = o; sq[l] += o * o; }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) { const double t = block_sum(sq[l], red); if (tid == 0) partials[(size_t)l * M.ng + g] = t; }
+}
+
+struct RgcsDev { RgcsView view; };
+static RgcsDev build_rgcs(const Host& H, int group_nnz, int max_rows) {
+  std::vector<int32_t> grow{0}, gent{0}, gcmin, gtp{0};
+  std::vector<uint32_t> pidx(H.ci.size()); std::vector<double> vals(H.ci.size()); std::vector<uint16_t> tptr;
+  int64_t r = 0;
+  std::vector<int32_t> ord, rank;
+  while (r < H.nr) {
+    int64_t r1 = r, nz = 0;
+    while (r1 < H.nr && r1 - r < max_rows) { int64_t len = H.rp[r1 + 1] - H.rp[r1]; if (nz + len > group_nnz && r1 > r) break; nz += len; ++r1; if (nz >= group_nnz) break; }
+    const int R = r1 - r; const int e0 = H.rp[r], e1 = H.rp[r1]; const int cnt = e1 - e0;
+    int cmin = INT32_MAX; for (int k = e0; k < e1; ++k) cmin = std::min(cmin, H.ci[k]); if (cnt == 0) cmin = 0;
+    // local row of each entry
+    std::vector<int32_t> lrow(cnt); for (int rr = 0; rr < R; ++rr) for (int k = H.rp[r + rr]; k < H.rp[r + rr + 1]; ++k) lrow[k - e0] = rr;
+    ord.resize(cnt); for (int k = 0; k < cnt; ++k) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return H.ci[e0 + a] < H.ci[e0 + b]; });
+    const int ntile = (cnt + kTile - 1) / kTile;
+    for (int t = 0; t < ntile; ++t) {
+      const int a = t * kTile, b = std::min(cnt, a + kTile);
+      // slot = rank of the entry within the tile in (row, col) order: counting by row (entries of a row keep column order)
+      std::vector<int32_t> cntr(R + 1, 0);
+      for (int k = a; k < b; ++k) cntr[lrow[ord[k]] + 1]++;
+      for (int rr = 0; rr < R; ++rr) cntr[rr + 1] += cntr[rr];
+      for (int rr = 0; rr <= R; ++rr) tptr.push_back((uint16_t)cntr[rr]);
+      std::vector<int32_t> nxt(cntr.begin(), cntr.end() - 1);
+      for (int k = a; k < b; ++k) {
+        const int src = ord[k]; const int slot = nxt[lrow[src]]++;
+        const uint32_t crel = (uint32_t)(H.ci[e0 + src] - cmin);
+        if (crel >= (1u << kColBits)) { printf("column span too large for RGCS\n"); exit(1); }
+        pidx[e0 + k] = ((uint32_t)slot << kColBits) | crel; vals[e0 + k] = H.v[e0 + src];
+      }
+    }
+    grow.push_back((int32_t)r1); gent.push_back(e1); gcmin.push_back(cmin); gtp.push_back((int32_t)tptr.size());
+    r = r1;
+  }
+  RgcsDev D; RgcsView& V = D.view; V.ng = gcmin.size(); V.nrows = H.nr;
+  uint32_t* dp; double* dv; int32_t *d1, *d2, *d3, *d4; uint16_t* d5;
+  CK(hipMalloc(&dp, pidx.size() * 4)); CK(hipMalloc(&dv, vals.size() * 8)); CK(hipMalloc(&d1, grow.size() * 4)); CK(hipMalloc(&d2, gent.size() * 4));
+  CK(hipMalloc(&d3, gcmin.size() * 4)); CK(hipMalloc(&d4, gtp.size() * 4)); CK(hipMalloc(&d5, tptr.size() * 2 + 16));
+  CK(hipMemcpy(dp, pidx.data(), pidx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dv, vals.data(), vals.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d1, grow.data(), grow.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d2, gent.data(), gent.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d3, gcmin.data(), gcmin.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d4, gtp.data(), gtp.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d5, tptr.data(), tptr.size() * 2, hipMemcpyHostToDevice));
+  V.pidx = dp; V.vals = dv; V.grow = d1; V.gent = d2; V.gcmin = d3; V.gtp = d4; V.tptr = d5;
+  printf("RGCS: %d groups (group_nnz=%d max_rows=%d), tptr %.2f MB\n", V.ng, group_nnz, max_rows, tptr.size() * 2 / 1e6);
+  return D;
+}
+
+// ---------------------------------------------------------------- structure probes: what costs the 10 us between pure streaming and a tile kernel?
+// FEAT bit0: LDS write of the products + 2 barriers per tile; bit1: XCD swizzle; bit2: single tile per block (grid = ntiles)
+template <int FEAT>
+__global__ __launch_bounds__(kBlock) void k_probe(const uint32_t* __restrict__ pidx, const double* __restrict__ vals, int ntiles, int tiles_per_blk,
+                                                  int blk_per_xcd, double* out) {
+  __shared__ double prod[kTile * 2];
+  int b = blockIdx.x;
+  if (FEAT & 2) b = (blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3);
+  const int t0 = b * tiles_per_blk, t1 = min(ntiles, t0 + tiles_per_blk);
+  const int tid = threadIdx.x;
+  double acc = 0;
+  constexpr int kPer = kTile / kBlock;
+  for (int t = t0; t < t1; ++t) {
+    uint32_t pk[kPer]; double v[kPer];
+    const size_t base = (size_t)t * kTile;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { pk[k] = pidx[base + tid + k * kBlock]; v[k] = vals[base + tid + k * kBlock]; }
+    if (FEAT & 1) {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) *reinterpret_cast<double2*>(prod + 2 * (tid + k * kBlock)) = make_double2(v[k] * (double)pk[k], v[k]);
+      lds_barrier();
+      acc += prod[2 * ((tid * 7) & (kTile - 1))];
+      lds_barrier();
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) acc += v[k] * (double)pk[k];
+    }
+  }
+  if (acc == 1.2345e-300) out[0] = acc;
+}
+
 __global__ void k_ctl(LaneCtl* c, double ca, double cb) { c->ca = ca; c->cb = cb; c->done = 0; c->skip = 0; c->upd_iter = -1; }
 
 int main(int argc, char** argv) {
@@ -398,7 +595,47 @@ int main(int argc, char** argv) {
     }
   }
 
+#define ADD_RGCS(NLv, GNA, RA, GNT, RT)                                                                                   \
+  { RgcsDev ra = build_rgcs(A, GNA, RA), rt = build_rgcs(T, GNT, RT);                                                     \
+    Variant v; v.name = "rgcs NL=" #NLv " A(" #GNA "," #RA ") AT(" #GNT "," #RT ")"; v.nl = NLv;                         \
+    int pa = (ra.view.ng + 7) / 8, pt = (rt.view.ng + 7) / 8;                                                             \
+    v.launchA = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv>), dim3(pa * 8), dim3(kBlock), 0, 0, ra.view, xn, ym, ym, ctl, ctl, part, pa); }; \
+    v.launchT = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv>), dim3(pt * 8), dim3(kBlock), 0, 0, rt.view, xm, yn, yn, ctl, ctl, part, pt); }; \
+    vs.push_back(v); }
+  ADD_RGCS(1, 6400, 64, 8192, 1024) ADD_RGCS(2, 6400, 64, 8192, 1024) ADD_RGCS(2, 12800, 128, 4096, 512) ADD_RGCS(2, 3200, 32, 2048, 256)
+  ADD_RGCS(2, 25600, 256, 16384, 1024)
+
+#define ADD_RGCS_ABL(NLv, ABLv, GNA, RA)                                                                                  \
+  { RgcsDev ra = build_rgcs(A, GNA, RA);                                                                                  \
+    Variant v; v.name = "rgcs ABL=" #ABLv " NL=" #NLv " A(" #GNA "," #RA ")"; v.nl = NLv;                                 \
+    int pa = (ra.view.ng + 7) / 8, pt = (dT.nblk + 7) / 8;                                                                \
+    v.launchA = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv, ABLv>), dim3(pa * 8), dim3(kBlock), 0, 0, ra.view, xn, ym, ym, ctl, ctl, part, pa); }; \
+    v.launchT = [=]() { hipLaunchKernelGGL((k_spmv<NLv, 1>), dim3(pt * 8), dim3(kBlock), 0, 0, dT.view, xm, yn, yn, ctl, ctl, part, pt); }; \
+    vs.push_back(v); }
+  ADD_RGCS_ABL(2, 0, 12800, 128) ADD_RGCS_ABL(2, 8, 12800, 128) ADD_RGCS_ABL(2, 15, 12800, 128) ADD_RGCS_ABL(2, 8, 6400, 64) ADD_RGCS_ABL(2, 8, 25600, 256)
+  ADD_RGCS_ABL(1, 8, 12800, 128) ADD_RGCS_ABL(1, 15, 12800, 128)
+
+#define ADD_PROBE(F, TPB)                                                                                                 \
+  { Variant v; v.name = "probe FEAT=" #F " tiles/blk=" #TPB; v.nl = 0; int nt = nnz / kTile; int nb = (nt + TPB - 1) / TPB; int px = (nb + 7) / 8; \
+    int grid = (F & 2) ? px * 8 : nb;                                                                                     \
+    v.launchA = [=]() { hipLaunchKernelGGL((k_probe<F>), dim3(grid), dim3(kBlock), 0, 0, (const uint32_t*)dA.ci, dA.v, nt, TPB, px, part); }; \
+    v.launchT = [=]() { hipLaunchKernelGGL((k_probe<F>), dim3(grid), dim3(kBlock), 0, 0, (const uint32_t*)dT.ci, dT.v, nt, TPB, px, part); }; \
+    vs.push_back(v); }
+  ADD_PROBE(0, 1) ADD_PROBE(0, 4) ADD_PROBE(1, 1) ADD_PROBE(1, 4) ADD_PROBE(2, 1) ADD_PROBE(2, 4) ADD_PROBE(3, 4) ADD_PROBE(3, 1) ADD_PROBE(0, 19) ADD_PROBE(1, 19)
+
+#define ADD_RGCS_ABL_T(NLv, ABLv, GNT, RT)                                                                                \
+  { RgcsDev rt = build_rgcs(T, GNT, RT);                                                                                  \
+    Variant v; v.name = "rgcsT ABL=" #ABLv " NL=" #NLv " AT(" #GNT "," #RT ")"; v.nl = NLv;                               \
+    int pa = (dA.nblk + 7) / 8, pt = (rt.view.ng + 7) / 8;                                                                \
+    v.launchA = [=]() { hipLaunchKernelGGL((k_spmv<NLv, 0>), dim3(pa * 8), dim3(kBlock), 0, 0, dA.view, xn, ym, ym, ctl, ctl, part, pa); }; \
+    v.launchT = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv, ABLv>), dim3(pt * 8), dim3(kBlock), 0, 0, rt.view, xm, yn, yn, ctl, ctl, part, pt); }; \
+    vs.push_back(v); }
+  ADD_RGCS_ABL_T(2, 8, 2048, 256) ADD_RGCS_ABL_T(2, 9, 2048, 256) ADD_RGCS_ABL_T(2, 10, 2048, 256) ADD_RGCS_ABL_T(2, 12, 2048, 256) ADD_RGCS_ABL_T(2, 15, 2048, 256)
+  ADD_RGCS_ABL_T(2, 8, 8192, 1024) ADD_RGCS_ABL_T(2, 12, 8192, 1024) ADD_RGCS_ABL_T(2, 15, 8192, 1024) ADD_RGCS_ABL_T(1, 8, 8192, 1024)
+
+  const char* filt = argc > 6 ? argv[6] : nullptr;
   for (auto& v : vs) {
+    if (filt && v.name.find(filt) == std::string::npos) continue;
     for (int w = 0; w < 3; ++w) { v.launchA(); v.launchT(); }
     CK(hipDeviceSynchronize());
     double ta = 0, tt = 0;
@@ -418,5 +655,15 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(r1.data(), ym, m * 8, hipMemcpyDeviceToHost));
   double md = 0; for (int64_t i = 0; i < m; ++i) md = std::max(md, std::fabs(r0[i] - r1[i]));
   printf("max |stream - vec| on A product: %.3e\n", md);
+  for (auto& v : vs) if (v.name.rfind("rgcs NL=1", 0) == 0) {
+    CK(hipMemset(ym, 0, m * 16)); v.launchA(); CK(hipMemcpy(r1.data(), ym, m * 8, hipMemcpyDeviceToHost));
+    double md2 = 0; for (int64_t i = 0; i < m; ++i) md2 = std::max(md2, std::fabs(r0[i] - r1[i]));
+    printf("max |stream - %s| on A product: %.3e\n", v.name.c_str(), md2);
+    std::vector<double> t0(n), t1(n);
+    CK(hipMemset(yn, 0, n * 16)); vs[0].launchT(); CK(hipMemcpy(t0.data(), yn, n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemset(yn, 0, n * 16)); v.launchT(); CK(hipMemcpy(t1.data(), yn, n * 8, hipMemcpyDeviceToHost));
+    md2 = 0; for (int64_t i = 0; i < n; ++i) md2 = std::max(md2, std::fabs(t0[i] - t1[i]));
+    printf("max |stream - %s| on AT product: %.3e\n", v.name.c_str(), md2);
+  }
   return 0;
 }
