@@ -60,12 +60,13 @@ struct fpsq_solver_s {
   // n-vectors
   double *Cx, *Cw2, *in_n1, *in_n2, *p1, *p2b, *gs, *gx, *jc, *g, *xin, *xk;
   // m-vectors
-  double *Lw[2], *Lx[2], *Cw, *Cy, *in_m, *ys, *c;
+  double *Lw[2], *Lx[2], *Cw, *Cy, *in_m, *ys, *c, *Mr[2], *Mw[2], *Mx;
   // partial-sum buffers
   double *pS, *pS2, *pW[2], *pE, *pE2, *pE3, *pQ[2];
   int npS = 0;
   LsqrState* lsqr[2];
   CraigState* craig;
+  MinresState* minres;
   LaneCtl* ctl_tmp;
   double* dscal;               // small device scalar scratch
   Progress* prog_host = nullptr;  // host-mapped
@@ -187,7 +188,8 @@ int alloc_workspaces(fpsq_handle h) {
                    &h->gs, &h->gx, &h->jc, &h->g, &h->xin, &h->xk};
   for (auto p : nv)
     if (int rc = dalloc(h, p, n)) return rc;
-  double** mv[] = {&h->Lw[0], &h->Lw[1], &h->Lx[0], &h->Lx[1], &h->Cw, &h->Cy, &h->in_m, &h->ys, &h->c};
+  double** mv[] = {&h->Lw[0], &h->Lw[1], &h->Lx[0], &h->Lx[1], &h->Cw, &h->Cy, &h->in_m, &h->ys, &h->c,
+                   &h->Mr[0], &h->Mr[1], &h->Mw[0], &h->Mw[1], &h->Mx};
   for (auto p : mv)
     if (int rc = dalloc(h, p, m)) return rc;
   h->npS = std::max(h->A.nblk, h->AT.nblk);
@@ -601,6 +603,82 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   return 0;
 }
 
+struct MinresParams {
+  double lambda, atol, rtol, etol, conlim;
+  int64_t itmax;
+};
+
+__global__ void k_minres_params(MinresState* S, MinresParams P) {
+  S->lambda = P.lambda;
+  S->atol = P.atol;
+  S->rtol = P.rtol;
+  S->etol = P.etol;
+  S->ctol = P.conlim > 0.0 ? 1.0 / P.conlim : 0.0;
+  S->itmax = P.itmax;
+  S->ctl.done = 0;
+  S->ctl.skip = 0;
+  S->ctl.upd_iter = -1;
+  S->ctlT.done = 0;
+  S->ctlT.skip = 0;
+  S->ctlT.ca = 1.0;
+  S->ctlT.cb = 0.0;
+}
+
+// MINRES on (A A' + lambda I) x = b: src/solve_linear_system.jl:58-72.  b (m, device) -> h->Mx.
+int run_minres(fpsq_handle h, const double* b, double lambda, fpsq_stats* st_out) {
+  const int64_t m = h->m;
+  const fpsq_options& o = h->opt;
+  hipStream_t s = h->stream;
+  MinresState* S = h->minres;
+  const LaneCtl* ctl = &S->ctl;
+  Progress* prog = &h->prog_dev[0];
+  h->prog_host[0].iter = 0;
+  h->prog_host[0].done = 0;
+  const int gm = ew_grid(m);
+  const int64_t itmax = o.ne_itmax == 0 ? 2 * m : o.ne_itmax;
+  MinresParams P{lambda, o.ne_atol, o.ne_rtol, o.ne_etol, o.ne_conlim, itmax};
+  hipLaunchKernelGGL(k_minres_params, dim3(1), dim3(1), 0, s, S, P);
+  HIPCHK(h, hipMemsetAsync(h->Mx, 0, (size_t)m * 8, s));
+  HIPCHK(h, hipMemsetAsync(h->Mw[0], 0, (size_t)m * 8, s));
+  HIPCHK(h, hipMemsetAsync(h->Mw[1], 0, (size_t)m * 8, s));
+  HIPCHK(h, hipMemsetAsync(h->Mr[0], 0, (size_t)m * 8, s));
+  // r1 = r2 = b: r2 sits in Mr[1] (iteration 1 reads r2 from Mr[it % 2]) and in the short pair SP (lane 0)
+  HIPCHK(h, hipMemcpyAsync(h->Mr[1], b, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_load_lane<1>, dim3(gm), dim3(kBlock), 0, s, b, 1.0, h->SP, 0, m, h->pE);
+  Lane L;
+  L.state = S;
+  StepArgs none{};
+  none.kind = STEP_NONE;
+  launch_step(h, step_args(STEP_MINRES_BEGIN, L, 0, h->pE, gm, nullptr, 0, prog), none);
+  h->launches += 3;
+  const int look = std::max(1, o.lookahead);
+  for (int64_t it = 1; it <= itmax; ++it) {
+    double* r2 = h->Mr[it % 2];
+    double* r1 = h->Mr[(it + 1) % 2];  // also receives the new r2
+    double* w1 = h->Mw[it % 2];        // w_{k-2}, overwritten by w_k
+    double* w2 = h->Mw[(it + 1) % 2];
+    launch_spmv<1>(h, TAG_AT, h->SP, nullptr, h->LP, &S->ctlT, &S->ctlT, nullptr);  // tmp = A' r2
+    launch_spmv<1>(h, TAG_A, h->LP, h->SP, h->SP, ctl, ctl, nullptr);     // q = ca A tmp + cb r2
+    hipLaunchKernelGGL((k_minres_ew<1, 1>), dim3(gm), dim3(kBlock), 0, s, ctl, h->SP, 0, r1, r2, r1, w1, w2, w1, h->Mx, m,
+                       h->pW[0]);
+    launch_step(h, step_args(STEP_MINRES_A, L, (int)it, h->pW[0], gm, nullptr, 0, prog), none);
+    hipLaunchKernelGGL((k_minres_ew<1, 2>), dim3(gm), dim3(kBlock), 0, s, ctl, h->SP, 0, r1, r2, r1, w1, w2, w1, h->Mx, m,
+                       h->pW[1]);
+    launch_step(h, step_args(STEP_MINRES_B, L, (int)it, h->pW[1], gm, nullptr, 0, prog), none);
+    hipLaunchKernelGGL((k_minres_ew<1, 3>), dim3(gm), dim3(kBlock), 0, s, ctl, h->SP, 0, r1, r2, r1, w1, w2, w1, h->Mx, m,
+                       h->pW[0]);
+    launch_step(h, step_args(STEP_MINRES_C, L, (int)it, h->pW[0], gm, nullptr, 0, prog), none);
+    h->launches += 3;
+    if (h->prog_host[0].done) break;
+    if (it - h->prog_host[0].iter >= look) {
+      if (int rc = wait_progress(h, 0, (int)(it - look + 1), &S->ctl.done, &S->iter)) return rc;
+      if (h->prog_host[0].done) break;
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(st_out, &S->stats, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
 int run_lanes(fpsq_handle h, Lane* lanes, int nlanes) {
   if (nlanes == 2 && h->opt.fuse_two_rhs) return run_krylov<2>(h, lanes);
   for (int l = 0; l < nlanes; ++l)
@@ -760,16 +838,18 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
+  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
     return fail("hipMalloc", e);
   h->allocs.push_back(p);
-  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(LaneCtl) + 64 * sizeof(double));
+  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + sizeof(LaneCtl) + 64 * sizeof(double));
   char* cp = (char*)p;
   h->lsqr[0] = (LsqrState*)cp;
   h->lsqr[1] = h->lsqr[0] + 1;
   cp += sizeof(LsqrState) * 2;
   h->craig = (CraigState*)cp;
   cp += sizeof(CraigState);
+  h->minres = (MinresState*)cp;
+  cp += sizeof(MinresState);
   h->ctl_tmp = (LaneCtl*)cp;
   cp += sizeof(LaneCtl);
   h->dscal = (double*)cp;
@@ -974,10 +1054,36 @@ int fpsq_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double
   return soft_rc(st);
 }
 
-int fpsq_solve_two_extras(fpsq_handle h, const double*, const double*, double*, double*, fpsq_stats*) {
-  if (!h) return FPSQ_ERR_ARG;
-  h->err = "solve_two_extras: not implemented yet";
-  return FPSQ_ERR_STATE;
+int fpsq_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2, double* out1, double* out2,
+                          fpsq_stats st[2]) {
+  if (int rc = check_ready(h)) return rc;
+  if (!rhs1 || !rhs2 || !out1 || !out2 || !st) {
+    h->err = "solve_two_extras: null argument";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
+  HIPCHK(h, hipMemcpyAsync(h->in_n1, rhs1, nb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(h->in_m, rhs2, mb, hipMemcpyDefault, s));
+  call_begin(h);
+  const double tau = std::max(h->delta, 1e-14);  // src/solve_linear_system.jl:51
+  // (invJtJJv, stats) = solve_least_square(qds, Aop', rhs1, sqrt(tau))          :53
+  Lane L;
+  L.kind = LANE_LSQR;
+  L.rhs = h->in_n1;
+  L.lambda = std::sqrt(tau);
+  L.x = h->Lx[0];
+  L.st = &h->hstats[0];
+  if (int rc = run_krylov<1>(h, &L)) return rc;
+  // minres(JtJ, rhs2, lambda = tau)                                              :58-72
+  if (int rc = run_minres(h, h->in_m, tau, &h->hstats[1])) return rc;
+  HIPCHK(h, hipMemcpyAsync(out1, h->Lx[0], mb, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(out2, h->Mx, mb, hipMemcpyDefault, s));
+  if (int rc = call_end(h)) return rc;
+  st[0] = h->hstats[0];
+  st[1] = h->hstats[1];
+  return soft_rc(st);
 }
 
 int fpsq_ys_gs(fpsq_handle h, const double* g, const double* c, double sigma, double* gs, double* ys, double* v,

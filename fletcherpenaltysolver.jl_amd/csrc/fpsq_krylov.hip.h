@@ -410,6 +410,226 @@ __device__ __forceinline__ void craig_sb_step(CraigState* S, double bb, double w
 }
 
 
+
+// =============================================================================================== MINRES
+// (A A' + lambda I) x = b, all vectors in R^m; Krylov.jl minres! with M = I (src/solve_linear_system.jl:58-70).
+// Per iteration: tmp = A' r2 (n), q = (A tmp + lambda r2) / beta, then three short element-wise stages:
+//   E1: y0 = q - (beta/oldbeta) r1            partial <r2, y0>      -> alpha
+//   E2: y = y0 - (alpha/beta) r2; w~ = r2/beta - delta w2 - eps w1  partial ||y||^2 -> beta_new, rotation
+//   E3: w = w~ / gamma; x += phi w                                  partial ||x||^2 -> tests
+struct MinresState {
+  LaneCtl ctl;   // ca/cb: coefficients of the A product (q = ca A tmp + cb r2); e[0..6]: stage coefficients
+  LaneCtl ctlT;  // the A' product tmp = A' r2 (ca = 1, cb = 0); `done` mirrors ctl.done
+  double lambda, atol, rtol, etol, ctol;
+  int64_t itmax;
+  double beta1, beta, oldbeta, alpha, deltabar, epsln, delta, phibar, rhs1, rhs2, gmax, gmin, cs, sn;
+  double ANorm2, xENorm2, root, gammabar, phi, gamma;
+  double err_vec[5];
+  int32_t iter;
+  int32_t pad;
+  fpsq_stats stats;
+};
+
+__device__ __forceinline__ void minres_begin_step(MinresState* S, double bb, Progress* prog) {
+  S->iter = 0;
+  S->ctl.skip = 0;
+  S->ctl.upd_iter = -1;
+  S->stats = fpsq_stats{0, 0, 0, FPSQ_ST_UNKNOWN, 0.0, 0.0};
+  if (bb == 0.0) {
+    S->stats.solved = 1;
+    S->stats.status = FPSQ_ST_ZERO_RHS;
+    S->ctl.done = 1;
+    S->ctlT.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  const double beta1 = sqrt(bb);
+  S->beta1 = beta1;
+  S->beta = beta1;
+  S->oldbeta = 0.0;
+  S->deltabar = 0.0;
+  S->epsln = 0.0;
+  S->phibar = beta1;
+  S->rhs1 = beta1;
+  S->rhs2 = 0.0;
+  S->gmax = 0.0;
+  S->gmin = INFINITY;
+  S->cs = -1.0;
+  S->sn = 0.0;
+  S->ANorm2 = 0.0;
+  S->xENorm2 = 0.0;
+  for (int i = 0; i < 5; ++i) S->err_vec[i] = 0.0;
+  S->stats.rnorm = beta1;
+  const double eps_tol = S->atol + S->rtol * beta1;
+  const bool solved = beta1 <= S->rtol;
+  const bool tired = 0 >= S->itmax;
+  if (solved | tired) {
+    S->stats.solved = solved;
+    S->stats.inconsistent = !(beta1 <= eps_tol);
+    S->stats.status = solved ? FPSQ_ST_SOLVED : FPSQ_ST_MAXITER;
+    S->ctl.done = 1;
+    S->ctlT.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  S->ctl.done = 0;
+  S->ctlT.done = 0;
+  S->ctlT.skip = 0;
+  S->ctlT.ca = 1.0;
+  S->ctlT.cb = 0.0;
+  S->ctl.ca = 1.0 / beta1;         // q = (A tmp + lambda r2) / beta
+  S->ctl.cb = S->lambda / beta1;
+  S->ctl.e[0] = 0.0;               // E1: beta/oldbeta (no r1 term at iteration 1)
+  publish(prog, 0, 0);
+}
+
+// after E1: alpha = <r2, y0> / beta
+__device__ __forceinline__ void minres_a_step(MinresState* S, double dot) {
+  const double beta = S->beta;
+  const double alpha = dot / beta;
+  S->alpha = alpha;
+  const double delta = S->cs * S->deltabar + S->sn * alpha;
+  S->delta = delta;
+  S->ctl.e[1] = alpha / beta;  // E2: y = y0 - e1 r2
+  S->ctl.e[2] = 1.0 / beta;    //     w~ = e2 r2 - e3 w2 - e4 w1
+  S->ctl.e[3] = delta;
+  S->ctl.e[4] = S->epsln;
+}
+
+// after E2: beta_new = ||y||, plane rotation, phi
+__device__ __forceinline__ void minres_b_step(MinresState* S, double yy, int it) {
+  const double epsM = 2.220446049250313e-16;
+  const double alpha = S->alpha;
+  S->oldbeta = S->beta;
+  const double beta = sqrt(yy);
+  S->beta = beta;
+  S->ANorm2 += alpha * alpha + S->oldbeta * S->oldbeta + beta * beta;
+  const double gammabar = S->sn * S->deltabar - S->cs * alpha;
+  S->epsln = S->sn * beta;
+  S->deltabar = -S->cs * beta;
+  S->root = sqrt(gammabar * gammabar + S->deltabar * S->deltabar);
+  S->gammabar = gammabar;
+  double gamma = sqrt(gammabar * gammabar + beta * beta);
+  gamma = fmax(gamma, epsM);
+  S->gamma = gamma;
+  S->stats.arnorm = S->phibar * S->root;
+  S->cs = gammabar / gamma;
+  S->sn = beta / gamma;
+  const double phi = S->cs * S->phibar;
+  S->phibar = S->sn * S->phibar;
+  S->phi = phi;
+  S->xENorm2 += phi * phi;
+  S->err_vec[it % 5] = phi;
+  S->ctl.e[5] = 1.0 / gamma;  // E3: w = e5 w~; x += e6 w
+  S->ctl.e[6] = phi;
+  S->ctl.upd_iter = it;
+}
+
+// after E3: ||x||, estimates and the stopping tests of minres!
+__device__ __forceinline__ void minres_c_step(MinresState* S, double xx, int it, Progress* prog) {
+  const double epsM = 2.220446049250313e-16;
+  S->iter = it;
+  double err_lbnd = 0.0;
+  if (it >= 5) {
+    double t = 0.0;
+    for (int i = 0; i < 5; ++i) t += S->err_vec[i] * S->err_vec[i];
+    err_lbnd = sqrt(t);
+  }
+  const double gamma = S->gamma;
+  S->gmax = fmax(S->gmax, gamma);
+  S->gmin = fmin(S->gmin, gamma);
+  const double zeta = S->rhs1 / gamma;
+  S->rhs1 = S->rhs2 - S->delta * zeta;
+  S->rhs2 = -S->epsln * zeta;
+  const double ANorm = sqrt(S->ANorm2);
+  const double xNorm = sqrt(xx);
+  const double rNorm = S->phibar;
+  const double test1 = rNorm / (ANorm * xNorm);
+  const double test2 = S->root / ANorm;
+  const double Acond = S->gmax / S->gmin;
+  const double beta = S->beta, beta1 = S->beta1;
+  S->stats.niter = it;
+  S->stats.rnorm = rNorm;
+  if (it == 1 && beta / beta1 <= 10 * epsM) {
+    S->stats.solved = 1;
+    S->stats.inconsistent = 1;
+    S->stats.status = FPSQ_ST_ZERO_ATB;
+    S->ctl.done = 1;
+    S->ctlT.done = 1;
+    publish(prog, it, 1);
+    return;
+  }
+  const double eps_tol = S->atol + S->rtol * beta1;
+  const bool ill_cond_mach = (1.0 + 1.0 / Acond <= 1.0);
+  const bool solved_mach = (1.0 + test2 <= 1.0);
+  const bool zero_resid_mach = (1.0 + test1 <= 1.0);
+  const bool resid_decrease_mach = (rNorm + 1.0 <= 1.0);
+  const bool tired = it >= S->itmax;
+  const bool ill_cond_lim = (1.0 / Acond <= S->ctol);
+  const bool solved_lim = (test2 <= eps_tol);
+  const bool zero_resid_lim = (test1 <= epsM);
+  const bool resid_decrease_lim = (rNorm <= eps_tol);
+  const bool fwd_err = (it >= 5) && (err_lbnd <= S->etol * sqrt(S->xENorm2));
+  const bool zero_resid = zero_resid_mach | zero_resid_lim;
+  const bool resid_decrease = resid_decrease_mach | resid_decrease_lim;
+  const bool ill_cond = ill_cond_mach | ill_cond_lim;
+  const bool solved = solved_mach | solved_lim | zero_resid | fwd_err | resid_decrease;
+  // next iteration's coefficients
+  S->ctl.ca = (beta != 0.0) ? 1.0 / beta : 0.0;
+  S->ctl.cb = (beta != 0.0) ? S->lambda / beta : 0.0;
+  S->ctl.e[0] = (S->oldbeta != 0.0) ? beta / S->oldbeta : 0.0;
+  if (solved | tired | ill_cond) {
+    int status = FPSQ_ST_UNKNOWN;
+    if (tired) status = FPSQ_ST_MAXITER;
+    if (ill_cond) status = FPSQ_ST_ILL_COND;
+    if (solved) status = FPSQ_ST_SOLVED;
+    if (zero_resid) status = FPSQ_ST_ZERO_RESID;
+    if (fwd_err) status = FPSQ_ST_FWD_ERR;
+    S->stats.status = status;
+    S->stats.solved = solved;
+    S->stats.inconsistent = !zero_resid;
+    S->ctl.done = 1;
+    S->ctlT.done = 1;
+    publish(prog, it, 1);
+  } else {
+    publish(prog, it, 0);
+  }
+}
+
+// MINRES element-wise stages (m-vectors).  q lives in the short Golub-Kahan pair (lane `lane` of `sp`).
+template <int NL, int STAGE>
+__global__ __launch_bounds__(kBlock) void k_minres_ew(const LaneCtl* ctl, double* sp, int lane, const double* r1,
+                                                      double* r2, double* rnew, const double* w1old, const double* w2,
+                                                      double* wnew, double* x, int64_t m, double* partials) {
+  if (ctl->done) return;
+  __shared__ double red[4];
+  double acc = 0.0;
+  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3], e4 = ctl->e[4], e5 = ctl->e[5],
+               e6 = ctl->e[6];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    if (STAGE == 1) {  // y0 = q - (beta/oldbeta) r1 ; <r2, y0>
+      const double y0 = sp[i * NL + lane] - (e0 != 0.0 ? e0 * r1[i] : 0.0);
+      sp[i * NL + lane] = y0;
+      acc += r2[i] * y0;
+    } else if (STAGE == 2) {  // y = y0 - (alpha/beta) r2 ; w~ ; the new r2 goes to rnew AND back into the pair
+      const double r = r2[i];
+      const double y = sp[i * NL + lane] - e1 * r;
+      sp[i * NL + lane] = y;
+      rnew[i] = y;
+      wnew[i] = e2 * r - e3 * w2[i] - e4 * w1old[i];
+      acc += y * y;
+    } else {  // w = w~ / gamma ; x += phi w ; ||x||^2
+      const double w = wnew[i] * e5;
+      wnew[i] = w;
+      const double xn = x[i] + e6 * w;
+      x[i] = xn;
+      acc += xn * xn;
+    }
+  }
+  const double t = block_sum(acc, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
 // =============================================================================================== step kernel
 // One launch advances up to two recurrences: workgroup b handles step[b].  1024 threads so that the <= ~5000 norm
 // partials of a product are summed with a handful of independent loads per thread (fixed order => reproducible).
@@ -417,7 +637,7 @@ enum StepKind : int32_t {
   STEP_NONE = 0,
   STEP_LSQR_BEGIN, STEP_LSQR_BEGIN2, STEP_LSQR_SA, STEP_LSQR_SB,
   STEP_CRAIG_BEGIN, STEP_CRAIG_SA, STEP_CRAIG_SB,
-  STEP_MINRES_BEGIN, STEP_MINRES_A, STEP_MINRES_B
+  STEP_MINRES_BEGIN, STEP_MINRES_A, STEP_MINRES_B, STEP_MINRES_C
 };
 
 struct StepArgs {
@@ -497,6 +717,10 @@ __global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1)
     case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)a.state, s0, a.prog); break;
     case STEP_CRAIG_SA: craig_sa_step((CraigState*)a.state, s0, a.it, a.prog); break;
     case STEP_CRAIG_SB: craig_sb_step((CraigState*)a.state, s0, s1, a.it, a.prog); break;
+    case STEP_MINRES_BEGIN: minres_begin_step((MinresState*)a.state, s0, a.prog); break;
+    case STEP_MINRES_A: minres_a_step((MinresState*)a.state, s0); break;
+    case STEP_MINRES_B: minres_b_step((MinresState*)a.state, s0, a.it); break;
+    case STEP_MINRES_C: minres_c_step((MinresState*)a.state, s0, a.it, a.prog); break;
     default: break;
   }
 }

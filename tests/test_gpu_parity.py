@@ -67,6 +67,9 @@ class _Handle:
     def solve_two_least_squares(self, r1, r2):
         return self.two(self.lib.fpsq_solve_two_least_squares, r1, r2, (self.n, self.m, self.n, self.m))
 
+    def solve_two_extras(self, r1, r2):
+        return self.two(self.lib.fpsq_solve_two_extras, r1, r2, (self.m, self.m))
+
     def close(self):
         self.lib.fpsq_destroy(self.h)
 
@@ -248,6 +251,33 @@ def test_solve_two_least_squares_parity(oracle, fuse):
     for got, want_c, want_e in zip((p1, q1, p2, q2), o[:4], e):
         assert _rel(got, want_c) < 1e-9 and _rel(got, want_e) < 1e-6
     H.close()
+
+
+@pytest.mark.parametrize("delta", [0.0, 0.01])
+def test_solve_two_extras_parity(oracle, delta):
+    """LSQR + MINRES on A A' + tau I (src/solve_linear_system.jl:45-77): iteration parity with the C restatement at
+    the reference's default tolerances, and agreement with the exact solve."""
+    qp = problems.random_eqqp(n=3000, m=300, per_row=24, seed=5)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(1)
+    r1, r2 = rng.standard_normal(qp.n), rng.standard_normal(qp.m)
+    H = _Handle(A, delta=delta)
+    a, b, rc = H.solve_two_extras(r1, r2)
+    o = oracle.solve_two_extras(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, r1, r2)
+    assert rc == o[3]
+    for k in range(2):
+        assert H.st[k].niter == o[2][k].niter and H.st[k].status == o[2][k].status
+        assert H.st[k].solved == o[2][k].solved
+    ea, eb = oracle.exact_two_extras(A, delta, r1, r2)
+    assert _rel(a, o[0]) < 1e-9 and _rel(b, o[1]) < 1e-9
+    assert _rel(a, ea) < 1e-6 and _rel(b, eb) < 1e-6
+    # tight tolerances: 1e-10 of the exact solution
+    Ht = _Handle(A, delta=delta, ls_atol=1e-14, ls_rtol=1e-14, ls_axtol=1e-14, ls_btol=1e-14, ls_etol=1e-14,
+                 ne_atol=1e-14, ne_rtol=1e-14, ne_etol=1e-14)
+    a, b, rc = Ht.solve_two_extras(r1, r2)
+    assert _rel(a, ea) < 1e-10 and _rel(b, eb) < 1e-9
+    H.close()
+    Ht.close()
 
 
 def test_zero_right_hand_sides():
