@@ -7,4 +7,4 @@ Import as `fps_amd` (see /fps_amd.py: the directory name carries a dot).  Submod
   penalty_nlp   FletcherPenaltyNLP (obj / grad! / objgrad!)
   device_qp     device-resident eq-QP evaluation (the benchmark's unit of work)
 """
-__all__ = ["problems", "nlpmodels", "qdsolver", "penalty_nlp", "device_qp"]
+__all__ = ["problems", "nlpmodels", "qdsolver", "penalty_nlp", "device_qp", "distributed"]

@@ -70,6 +70,9 @@ SYMBOLS = [
                                   C.POINTER(Stats)]),
     ("fpsq_comm_unique_id", C.c_int, [_DP]),
     ("fpsq_comm_init", C.c_int, [_VP, _I32, _I32, _DP]),
+    ("fpsq_local_group_create", C.c_int, [_I32, C.POINTER(_VP)]),
+    ("fpsq_local_group_destroy", C.c_int, [_VP]),
+    ("fpsq_comm_init_local", C.c_int, [_VP, _VP, _I32]),
     ("fpsq_get_info", C.c_int, [_VP, C.POINTER(Info)]),
     ("fpsq_set_profiling", C.c_int, [_VP, _I32]),
 ]

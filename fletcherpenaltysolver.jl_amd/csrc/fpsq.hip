@@ -7,9 +7,14 @@
 #include "fpsq_krylov.hip.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only; the library is dlopen'ed on first use
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +40,109 @@ struct DevCsr {
 
 struct EventPair {
   hipEvent_t a, b;
+};
+
+// ------------------------------------------------------------------ communicators (row-sharded A)
+// Collectives are enqueued on the solver's stream; every rank issues the same sequence (the Krylov loop takes
+// its exit decision from replicated, bitwise-identical device state at fixed iteration boundaries).
+struct Comm {
+  int nranks = 1, rank = 0;
+  std::string err;
+  virtual int allreduce_sum(double* buf, size_t count, hipStream_t s) = 0;
+  virtual ~Comm() {}
+};
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string& err) {
+    if (lib) return true;
+    // by SONAME first: a process that imported torch already holds librccl.so.1 and must keep using that copy
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names)
+      if ((lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) {
+      err = std::string("cannot dlopen librccl: ") + dlerror();
+      return false;
+    }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+      err = "librccl is missing a required symbol";
+      return false;
+    }
+    return true;
+  }
+};
+RcclApi g_rccl;
+
+struct RcclComm : Comm {
+  ncclComm_t c = nullptr;
+  int allreduce_sum(double* buf, size_t count, hipStream_t s) override {
+    ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, c, s);
+    if (r != ncclSuccess) {
+      err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r);
+      return FPSQ_ERR_COMM;
+    }
+    return 0;
+  }
+  ~RcclComm() override {
+    if (c) g_rccl.CommDestroy(c);
+  }
+};
+
+// P logical shards in ONE process on ONE device (each handle driven by its own host thread): the sum is a kernel.
+struct LocalGroup {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  double* bufs[8] = {};
+  hipEvent_t ready[8] = {};
+  hipEvent_t done = nullptr;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++arrived == n) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
+struct LocalComm : Comm {
+  LocalGroup* g = nullptr;
+  int allreduce_sum(double* buf, size_t count, hipStream_t s) override {
+    g->bufs[rank] = buf;
+    hipEventRecord(g->ready[rank], s);
+    g->barrier();
+    if (rank == 0) {
+      ShardBufs B;
+      B.n = g->n;
+      for (int r = 0; r < g->n; ++r) {
+        hipStreamWaitEvent(s, g->ready[r], 0);
+        B.b[r] = g->bufs[r];
+      }
+      const int grid = (int)std::max<size_t>(1, std::min<size_t>((count + kBlock - 1) / kBlock, 2048));
+      hipLaunchKernelGGL(k_local_allreduce, dim3(grid), dim3(kBlock), 0, s, B, (int64_t)count);
+      hipEventRecord(g->done, s);
+    }
+    g->barrier();
+    hipStreamWaitEvent(s, g->done, 0);
+    g->barrier();  // nobody may start the next collective (and overwrite bufs[] / re-record events) before all queued the wait
+    return 0;
+  }
 };
 
 }  // namespace
@@ -68,6 +176,10 @@ struct fpsq_solver_s {
   CraigState* craig;
   MinresState* minres;
   LaneCtl* ctl_tmp;
+  LaneCtl* ctl_raw;             // constant {ca = 1, cb = 0, done = 0}: raw partial products before an all-reduce
+  Comm* comm = nullptr;         // null: single GPU
+  double* comm_vec = nullptr;   // [n][2] all-reduce payload (partial A' products)
+  double* comm_scal = nullptr;  // 8 doubles: scalar all-reduce payload
   double* dscal;               // small device scalar scratch
   Progress* prog_host = nullptr;  // host-mapped
   Progress* prog_dev = nullptr;
@@ -184,6 +296,7 @@ int alloc_workspaces(fpsq_handle h) {
   const size_t n = (size_t)h->n, m = (size_t)h->m;
   if (int rc = dalloc(h, &h->LP, 2 * n)) return rc;
   if (int rc = dalloc(h, &h->SP, 2 * m)) return rc;
+  if (int rc = dalloc(h, &h->comm_vec, 2 * n)) return rc;
   double** nv[] = {&h->Cx, &h->Cw2, &h->in_n1, &h->in_n2, &h->p1, &h->p2b,
                    &h->gs, &h->gx, &h->jc, &h->g, &h->xin, &h->xk};
   for (auto p : nv)
@@ -192,7 +305,7 @@ int alloc_workspaces(fpsq_handle h) {
                    &h->Mr[0], &h->Mr[1], &h->Mw[0], &h->Mw[1], &h->Mx};
   for (auto p : mv)
     if (int rc = dalloc(h, p, m)) return rc;
-  h->npS = std::max(h->A.nblk, h->AT.nblk);
+  h->npS = std::max(std::max(h->A.nblk, h->AT.nblk), kEwBlocksMax);
   if (int rc = dalloc(h, &h->pS, (size_t)h->npS * 2)) return rc;
   if (int rc = dalloc(h, &h->pS2, (size_t)h->npS * 2)) return rc;
   double** ev[] = {&h->pW[0], &h->pW[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1]};
@@ -273,6 +386,46 @@ void spmv_const(fpsq_handle h, int tag, double ca, const double* x, double cb, c
   hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, h->stream, h->ctl_tmp, ca, cb);
   h->launches++;
   launch_spmv<1>(h, tag, x, yin, yout, h->ctl_tmp, h->ctl_tmp, nullptr);
+}
+
+int comm_allreduce(fpsq_handle h, double* buf, size_t count) {
+  if (int rc = h->comm->allreduce_sum(buf, count, h->stream)) {
+    h->err = h->comm->err;
+    return rc;
+  }
+  return 0;
+}
+
+// LP <- ca A' SP + cb LP with norm partials (count returned in *np).  Sharded: every rank holds a row block A_r, so
+// A'x = sum_r A_r' x_r: raw partial product -> all-reduce -> fused axpby + norm on the replicated result.
+template <int NL>
+int at_product(fpsq_handle h, const double* x, double* y, const LaneCtl* c0, const LaneCtl* c1, double* partials,
+               int* np) {
+  if (!h->comm) {
+    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials);
+    *np = h->AT.nblk;
+    return 0;
+  }
+  launch_spmv<NL>(h, TAG_AT, x, nullptr, h->comm_vec, h->ctl_raw, h->ctl_raw, nullptr);
+  if (int rc = comm_allreduce(h, h->comm_vec, (size_t)h->n * NL)) return rc;
+  const int g = ew_grid(h->n);
+  hipLaunchKernelGGL(k_axpby_norm<NL>, dim3(g), dim3(kBlock), 0, h->stream, h->comm_vec, y, c0, c1, h->n, partials);
+  h->launches++;
+  *np = g;
+  return 0;
+}
+
+// out = ca A' x + cb yin (plain vectors, host constants), all-reduced when sharded
+int at_product_const(fpsq_handle h, double ca, const double* x, double cb, const double* yin, double* yout) {
+  if (!h->comm) {
+    spmv_const(h, TAG_AT, ca, x, cb, yin, yout);
+    return 0;
+  }
+  launch_spmv<1>(h, TAG_AT, x, nullptr, h->comm_vec, h->ctl_raw, h->ctl_raw, nullptr);
+  if (int rc = comm_allreduce(h, h->comm_vec, (size_t)h->n)) return rc;
+  hipLaunchKernelGGL(k_axpby_plain, dim3(ew_grid(h->n)), dim3(kBlock), 0, h->stream, h->comm_vec, ca, yin, cb, yout, h->n);
+  h->launches++;
+  return 0;
 }
 
 // Bounded wait until the device has reached `target` iterations (or finished).  The progress word lives in
@@ -381,10 +534,41 @@ StepArgs step_args(int kind, const Lane& L, int it, const double* p0, int n0, co
   return a;
 }
 
-void launch_step(fpsq_handle h, const StepArgs& a0, const StepArgs& a1) {
+void launch_step_raw(fpsq_handle h, const StepArgs& a0, const StepArgs& a1) {
   const int nb = a1.kind != STEP_NONE ? 2 : 1;
   hipLaunchKernelGGL(k_step, dim3(nb), dim3(kStepThreads), 0, h->stream, a0, a1);
   h->launches++;
+}
+
+// `sharded`: the partial arrays of these steps are sums over m-vectors, of which a rank only holds its rows:
+// local sums -> one scalar all-reduce (4 doubles) -> the step kernel reads the global sums.
+int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false) {
+  if (h->comm && sharded) {
+    PresumArgs P{};
+    const StepArgs* a[2] = {&a0, &a1};
+    for (int k = 0; k < 2; ++k) {
+      if (a[k]->kind == STEP_NONE) continue;
+      P.p[2 * k] = a[k]->p0;
+      P.n[2 * k] = a[k]->n0;
+      P.p[2 * k + 1] = a[k]->p1;
+      P.n[2 * k + 1] = a[k]->n1;
+    }
+    hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, h->stream, P, h->comm_scal);
+    h->launches++;
+    if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
+    StepArgs* w[2] = {&a0, &a1};
+    for (int k = 0; k < 2; ++k) {
+      if (w[k]->kind == STEP_NONE) continue;
+      w[k]->p0 = h->comm_scal + 2 * k;
+      w[k]->n0 = 1;
+      if (w[k]->p1) {
+        w[k]->p1 = h->comm_scal + 2 * k + 1;
+        w[k]->n1 = 1;
+      }
+    }
+  }
+  launch_step_raw(h, a0, a1);
+  return 0;
 }
 
 template <int NL>
@@ -492,12 +676,14 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       u.partials = h->pW[l];
       (w0.nblk ? w1 : w0) = u;
     }
-    launch_step(h, s0, s1);
+    if (int rc = launch_step(h, s0, s1, /*sharded=*/true)) return rc;
     launch_updates<NL>(h, w0, w1, seg_none());
   }
   for (int l = 0; l < NL; ++l)
     if (lanes[l].kind == LANE_CRAIG)
-      launch_step(h, step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]), none);
+      if (int rc = launch_step(h, step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]),
+                               none, /*sharded=*/true))
+        return rc;
 
   // ---- main loop
   const int look = std::max(1, o.lookahead);
@@ -524,12 +710,13 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   while (it < itmax_all) {
     ++it;
     // first half-step of every lane: one A' product
-    launch_spmv<NL>(h, TAG_AT, SP, LP, LP, c0, c1, h->pS);
+    int npT = 0;
+    if (int rc = at_product<NL>(h, SP, LP, c0, c1, h->pS, &npT)) return rc;
     StepArgs sa[2] = {none, none};
     for (int l = 0; l < NL; ++l)
       sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : STEP_CRAIG_SA, lanes[l], (int)it,
-                        h->pS + (size_t)l * nbT, nbT, nullptr, 0, prog[l]);
-    launch_step(h, sa[0], sa[1]);
+                        h->pS + (size_t)l * npT, npT, nullptr, 0, prog[l]);
+    launch_step(h, sa[0], sa[1]);  // sums over replicated n-vectors: no all-reduce
     // vector updates: LSQR's x/w update of the PREVIOUS iteration, CRAIG's updates of this one
     UpdSeg seg[3] = {seg_none(), seg_none(), seg_none()};
     int ns = 0;
@@ -570,7 +757,16 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     for (int l = 0; l < NL; ++l)
       sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : STEP_CRAIG_SB, lanes[l], (int)it,
                         h->pS2 + (size_t)l * nbA, nbA, h->pW[l], gm, prog[l]);
-    launch_step(h, sb[0], sb[1]);
+    if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
+    if (h->comm) {
+      // every rank must enqueue the same collectives: decide at fixed iteration boundaries from the (replicated,
+      // bitwise identical) device state, never from the timing of the progress word
+      if (it % look == 0 || it == itmax_all) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (all_done()) break;
+      }
+      continue;
+    }
     if (all_done()) break;
     // bound the run-ahead of the host on the slowest unfinished lane
     int slow = INT32_MAX;
@@ -747,7 +943,7 @@ int two_mixed_device(fpsq_handle h, const double* g, const double* c) {
   lanes[1].st = &h->hstats[1];
   if (int rc = run_lanes(h, lanes, 2)) return rc;
   // p1 = rhs1 - Aop' q1                                                   :126-127
-  spmv_const(h, TAG_AT, -1.0, h->Lx[0], 1.0, g, h->p1);
+  if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, g, h->p1)) return rc;
   return 0;
 }
 
@@ -764,8 +960,8 @@ int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2) 
   }
   if (int rc = run_lanes(h, lanes, 2)) return rc;
   // src/solve_linear_system.jl:90-91 and :99-100
-  spmv_const(h, TAG_AT, -1.0, h->Lx[0], 1.0, r1, h->p1);
-  spmv_const(h, TAG_AT, -1.0, h->Lx[1], 1.0, r2, h->p2b);
+  if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, r1, h->p1)) return rc;
+  if (int rc = at_product_const(h, -1.0, h->Lx[1], 1.0, r2, h->p2b)) return rc;
   return 0;
 }
 
@@ -838,10 +1034,10 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
+  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 2 * sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
     return fail("hipMalloc", e);
   h->allocs.push_back(p);
-  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + sizeof(LaneCtl) + 64 * sizeof(double));
+  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 2 * sizeof(LaneCtl) + 64 * sizeof(double));
   char* cp = (char*)p;
   h->lsqr[0] = (LsqrState*)cp;
   h->lsqr[1] = h->lsqr[0] + 1;
@@ -852,7 +1048,17 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   cp += sizeof(MinresState);
   h->ctl_tmp = (LaneCtl*)cp;
   cp += sizeof(LaneCtl);
+  h->ctl_raw = (LaneCtl*)cp;
+  cp += sizeof(LaneCtl);
   h->dscal = (double*)cp;
+  h->comm_scal = h->dscal + 32;
+  {
+    LaneCtl raw{};
+    raw.ca = 1.0;
+    raw.cb = 0.0;
+    raw.upd_iter = -1;
+    hipMemcpy(h->ctl_raw, &raw, sizeof raw, hipMemcpyHostToDevice);
+  }
   *out = h;
   return FPSQ_OK;
 }
@@ -861,6 +1067,7 @@ int fpsq_destroy(fpsq_handle h) {
   if (!h) return FPSQ_ERR_ARG;
   hipSetDevice(h->opt.device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  delete h->comm;
   for (void* p : h->allocs) hipFree(p);
   for (auto& e : h->ev_pool) {
     hipEventDestroy(e.a);
@@ -1061,6 +1268,10 @@ int fpsq_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2,
     h->err = "solve_two_extras: null argument";
     return FPSQ_ERR_ARG;
   }
+  if (h->comm) {
+    h->err = "solve_two_extras: not available on a row-sharded handle yet";
+    return FPSQ_ERR_STATE;
+  }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
   const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
@@ -1129,7 +1340,11 @@ int fpsq_jac_mul(fpsq_handle h, int32_t trans, double alpha, const double* x, do
   HIPCHK(h, hipMemcpyAsync(dx, x, xb, hipMemcpyDefault, s));
   if (beta != 0.0) HIPCHK(h, hipMemcpyAsync(dy, y, yb, hipMemcpyDefault, s));
   call_begin(h);
-  spmv_const(h, trans ? TAG_AT : TAG_A, alpha, dx, beta, dy, dy);
+  if (trans) {
+    if (int rc = at_product_const(h, alpha, dx, beta, dy, dy)) return rc;
+  } else {
+    spmv_const(h, TAG_A, alpha, dx, beta, dy, dy);
+  }
   HIPCHK(h, hipMemcpyAsync(y, dy, yb, hipMemcpyDefault, s));
   return call_end(h);
 }
@@ -1209,11 +1424,25 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   // ys = q1 + sigma q2 and the dots of objgrad!
   hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax);
   h->launches++;
-  if (rho > 0.0) spmv_const(h, TAG_AT, 1.0, h->c, 0.0, nullptr, h->jc);  // J'c   (:424-428)
+  if (rho > 0.0)
+    if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
   hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn), dim3(kBlock), 0, s, h->p1, h->Cx, qp->q, h->jc, h->xin, dxk, sigma,
                      rho, eta, h->gs, h->gx, n);
-  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pQ[0], h->pQ[1], gn, h->pE, h->pE + kEwBlocksMax, gm, rho,
-                     eta, h->dscal);
+  const double *pcy = h->pE, *pcc = h->pE + kEwBlocksMax;
+  int npm = gm;
+  if (h->comm) {  // c'ys and c'c are sums over the rank's rows only
+    PresumArgs P{};
+    P.p[0] = pcy;
+    P.n[0] = gm;
+    P.p[1] = pcc;
+    P.n[1] = gm;
+    hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
+    if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
+    pcy = h->comm_scal;
+    pcc = h->comm_scal + 1;
+    npm = 1;
+  }
+  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pQ[0], h->pQ[1], gn, pcy, pcc, npm, rho, eta, h->dscal);
   h->launches += 2;
   HIPCHK(h, hipMemcpyAsync(h->hscal, h->dscal, 3 * 8, hipMemcpyDeviceToHost, s));
   if (gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
@@ -1226,10 +1455,77 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   return soft_rc(st);
 }
 
-int fpsq_comm_unique_id(uint8_t*) { return FPSQ_ERR_COMM; }
-int fpsq_comm_init(fpsq_handle h, int32_t, int32_t, const uint8_t*) {
-  if (h) h->err = "comm_init: not implemented yet";
-  return FPSQ_ERR_COMM;
+int fpsq_comm_unique_id(uint8_t id[128]) {
+  std::string err;
+  if (!id || !g_rccl.load(err)) {
+    g_create_error = err.empty() ? "comm_unique_id: null argument" : err;
+    return FPSQ_ERR_COMM;
+  }
+  ncclUniqueId u;
+  ncclResult_t r = g_rccl.GetUniqueId(&u);
+  if (r != ncclSuccess) {
+    g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r);
+    return FPSQ_ERR_COMM;
+  }
+  static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id, &u, 128);
+  return FPSQ_OK;
+}
+
+int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id[128]) {
+  if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks || h->comm) {
+    if (h) h->err = "comm_init: bad arguments or communicator already set";
+    return FPSQ_ERR_ARG;
+  }
+  if (!g_rccl.load(h->err)) return FPSQ_ERR_COMM;
+  hipSetDevice(h->opt.device);
+  ncclUniqueId u;
+  std::memcpy(&u, id, 128);
+  RcclComm* c = new RcclComm();
+  c->nranks = nranks;
+  c->rank = rank;
+  ncclResult_t r = g_rccl.CommInitRank(&c->c, nranks, u, rank);
+  if (r != ncclSuccess) {
+    h->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
+    c->c = nullptr;
+    delete c;
+    return FPSQ_ERR_COMM;
+  }
+  h->comm = c;
+  return FPSQ_OK;
+}
+
+int fpsq_local_group_create(int32_t nshards, void** out) {
+  if (!out || nshards < 1 || nshards > 8) return FPSQ_ERR_ARG;
+  LocalGroup* g = new LocalGroup();
+  g->n = nshards;
+  for (int r = 0; r < nshards; ++r) hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming);
+  hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
+  *out = g;
+  return FPSQ_OK;
+}
+
+int fpsq_local_group_destroy(void* group) {
+  LocalGroup* g = (LocalGroup*)group;
+  if (!g) return FPSQ_ERR_ARG;
+  for (int r = 0; r < g->n; ++r) hipEventDestroy(g->ready[r]);
+  hipEventDestroy(g->done);
+  delete g;
+  return FPSQ_OK;
+}
+
+int fpsq_comm_init_local(fpsq_handle h, void* group, int32_t shard) {
+  LocalGroup* g = (LocalGroup*)group;
+  if (!h || !g || shard < 0 || shard >= g->n || h->comm) {
+    if (h) h->err = "comm_init_local: bad arguments or communicator already set";
+    return FPSQ_ERR_ARG;
+  }
+  LocalComm* c = new LocalComm();
+  c->nranks = g->n;
+  c->rank = shard;
+  c->g = g;
+  h->comm = c;
+  return FPSQ_OK;
 }
 
 int fpsq_get_info(fpsq_handle h, fpsq_info* info) {

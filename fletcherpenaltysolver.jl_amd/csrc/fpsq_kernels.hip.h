@@ -379,6 +379,82 @@ __global__ __launch_bounds__(kBlock) void k_updates(const UpdSeg s0, const UpdSe
   }
 }
 
+// ---- multi-GPU (row-sharded A) helpers
+
+// After the all-reduce of the raw partial products P = sum_r A_r' x_r:  y = ca * P + cb * y with the squared-norm
+// partials -- the epilogue the single-GPU product kernel fuses.  Runs on replicated n-vectors.
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_axpby_norm(const double* __restrict__ P, double* y, const LaneCtl* ctl0,
+                                                       const LaneCtl* ctl1, int64_t len, double* partials) {
+  const LaneCtl* c[2] = {ctl0, ctl1};
+  bool act[NL];
+  double ca[NL], cb[NL];
+  bool any = false;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    act[l] = !(c[l]->done | c[l]->skip);
+    ca[l] = c[l]->ca;
+    cb[l] = c[l]->cb;
+    any |= act[l];
+  }
+  if (!any) return;
+  __shared__ double red[4];
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (act[l]) {
+        const double o = ca[l] * P[i * NL + l] + (cb[l] != 0.0 ? cb[l] * y[i * NL + l] : 0.0);
+        y[i * NL + l] = o;
+        sq[l] += o * o;
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const double t = block_sum(sq[l], red);
+    if (threadIdx.x == 0) partials[(size_t)l * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// out = a * P + b * y (plain vectors, host-given constants), for the p1 = g - A'q1 and J'c products
+__global__ __launch_bounds__(kBlock) void k_axpby_plain(const double* __restrict__ P, double a, const double* y,
+                                                        double b, double* out, int64_t len) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock)
+    out[i] = a * P[i] + (b != 0.0 ? b * y[i] : 0.0);
+}
+
+// Local sums of up to four partial arrays into out[0..3] (the payload of the scalar all-reduce). One workgroup.
+struct PresumArgs {
+  const double* p[4];
+  int32_t n[4];
+};
+__global__ __launch_bounds__(kBlock) void k_presum(PresumArgs a, double* out) {
+  __shared__ double red[4];
+  for (int k = 0; k < 4; ++k) {
+    double s = 0.0;
+    if (a.p[k]) s = reduce_partials(a.p[k], a.n[k], red);
+    if (threadIdx.x == 0) out[k] = s;
+    __syncthreads();
+  }
+}
+
+// In-process "all-reduce" over up to 8 logical shards that live on the same GPU (validation of the sharded
+// code path on a one-GPU box): every buffer receives the sum in rank order.
+struct ShardBufs {
+  double* b[8];
+  int32_t n;
+};
+__global__ __launch_bounds__(kBlock) void k_local_allreduce(ShardBufs B, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock) {
+    double s = 0.0;
+    for (int r = 0; r < B.n; ++r) s += B.b[r][i];
+    for (int r = 0; r < B.n; ++r) B.b[r][i] = s;
+  }
+}
+
 // ---- equality-QP user model + penalty epilogues (src/model-Fletcherpenaltynlp.jl:238-248, 385-397, 419-433)
 
 // g = q .* x + d ;  partial of f = sum x (q x / 2 + d) ;  partial of ||x - xk||^2 when xk != null

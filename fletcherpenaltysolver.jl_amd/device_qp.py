@@ -14,7 +14,10 @@ from .qdsolver import FpsqError
 
 
 class DeviceEqQP:
-    def __init__(self, qp, sigma=1e3, rho=1.0, delta=0.0, eta=0.0, device=0, **opt_overrides):
+    """`comm`: None (single GPU), ("rccl", nranks, rank, id_bytes) or ("local", group_ptr, shard) for a row-sharded
+    model; `qp` is then the rank's row block (distributed.shard_qp)."""
+
+    def __init__(self, qp, sigma=1e3, rho=1.0, delta=0.0, eta=0.0, device=0, comm=None, **opt_overrides):
         self._lib = _lib.load()
         self.qp, self.sigma, self.rho, self.delta, self.eta = qp, sigma, rho, delta, eta
         opts = _lib.Options()
@@ -36,6 +39,15 @@ class DeviceEqQP:
         self._check(self._lib.fpsq_qp_create(h, qp.qdiag.ctypes.data, qp.d.ctypes.data, qp.b.ctypes.data, C.byref(q)))
         self._q = q
         self.stats = (_lib.Stats * 2)()
+        if comm is not None:
+            if comm[0] == "rccl":
+                _, nranks, rank, ident = comm
+                buf = (C.c_uint8 * 128).from_buffer_copy(bytes(ident))
+                self._check(self._lib.fpsq_comm_init(h, nranks, rank, C.addressof(buf)))
+            elif comm[0] == "local":
+                self._check(self._lib.fpsq_comm_init_local(h, comm[1], comm[2]))
+            else:
+                raise ValueError(comm[0])
 
     def _check(self, rc):
         if rc < 0:
@@ -74,3 +86,50 @@ class DeviceEqQP:
             self.close()
         except Exception:
             pass
+
+
+def rccl_unique_id() -> bytes:
+    """128-byte RCCL id (call on rank 0, broadcast, pass to every rank's DeviceEqQP(comm=("rccl", ...)))."""
+    lib = _lib.load()
+    buf = (C.c_uint8 * 128)()
+    if lib.fpsq_comm_unique_id(C.addressof(buf)) != 0:
+        raise FpsqError(lib.fpsq_last_error(None).decode())
+    return bytes(buf)
+
+
+class LocalGroup:
+    """In-process stand-in for RCCL: `nshards` row-shard models on ONE GPU, one host thread each."""
+
+    def __init__(self, nshards):
+        self._lib = _lib.load()
+        g = C.c_void_p()
+        if self._lib.fpsq_local_group_create(nshards, C.byref(g)) != 0:
+            raise FpsqError("local_group_create failed")
+        self.ptr, self.nshards = g, nshards
+
+    def run(self, fns):
+        """Run one callable per shard concurrently (collectives rendezvous across the threads)."""
+        import threading
+
+        out, err = [None] * len(fns), [None] * len(fns)
+
+        def work(i):
+            try:
+                out[i] = fns[i]()
+            except BaseException as e:  # noqa: BLE001
+                err[i] = e
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(fns))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def close(self):
+        if self.ptr:
+            self._lib.fpsq_local_group_destroy(self.ptr)
+            self.ptr = None

@@ -160,6 +160,12 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double *x, double sigma, do
  * fpsq_comm_init.  Without fpsq_comm_init the handle is single-GPU. */
 int fpsq_comm_unique_id(uint8_t id[128]);
 int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id[128]);
+/* In-process stand-in for RCCL: `nshards` (<= 8) row-shard handles living in ONE process on ONE GPU, each driven
+ * by its own host thread; the all-reduce is a summation kernel.  Lets the sharded numerics be parity-tested on a
+ * one-GPU box.  Create the group, attach every shard handle, run the same call on all shards concurrently. */
+int fpsq_local_group_create(int32_t nshards, void **group);
+int fpsq_local_group_destroy(void *group);
+int fpsq_comm_init_local(fpsq_handle h, void *group, int32_t shard);
 
 /* ---- introspection for benchmarks / profiling */
 typedef struct {

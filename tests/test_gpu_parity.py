@@ -362,3 +362,58 @@ def test_repeat_calls_are_bitwise_reproducible():
     f2, _ = dev.objgrad(qp.x, gx=b)
     assert f1 == f2 and np.array_equal(a, b)
     dev.close()
+
+
+# ---------------------------------------------------------------------------------------------- row sharding
+
+@pytest.mark.parametrize("nshards", [2, 3])
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_row_sharded_objgrad_matches_single_gpu(oracle, nshards, delta):
+    """The sharded code path (raw partial A' products -> all-reduce -> fused axpby + norm; scalar all-reduce of the
+    m-vector sums) with the in-process loopback communicator: same iteration counts and the same grad(phi) as the
+    unsharded handle (only the summation order of the reductions differs: 1e-9)."""
+    from fps_amd.device_qp import LocalGroup
+    from fps_amd.distributed import row_partition, shard_qp
+
+    qp = _small_pde(seed=21, n=4000, m=400)
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    g_ref, ys_ref = np.empty(qp.n), np.empty(qp.m)
+    f_ref, rc_ref = ref.objgrad(qp.x, gx=g_ref, ys=ys_ref)
+    it_ref = (ref.stats[0].niter, ref.stats[1].niter)
+    ref.close()
+
+    bounds = row_partition(qp.rowptr, nshards)
+    assert bounds[0] == 0 and bounds[-1] == qp.m and np.all(np.diff(bounds) > 0)
+    group = LocalGroup(nshards)
+    shards = [DeviceEqQP(shard_qp(qp, bounds[r], bounds[r + 1]), sigma=1e3, rho=1.0, delta=delta,
+                         comm=("local", group.ptr, r)) for r in range(nshards)]
+    gs = [np.empty(qp.n) for _ in range(nshards)]
+    yss = [np.empty(bounds[r + 1] - bounds[r]) for r in range(nshards)]
+    res = group.run([lambda r=r: shards[r].objgrad(qp.x, gx=gs[r], ys=yss[r]) for r in range(nshards)])
+    for r in range(nshards):
+        f, rc = res[r]
+        assert rc == rc_ref == 0
+        assert (shards[r].stats[0].niter, shards[r].stats[1].niter) == it_ref
+        assert abs(f - f_ref) <= 1e-9 * abs(f_ref)
+        assert _rel(gs[r], g_ref) < 1e-9
+        assert np.array_equal(gs[r], gs[0]), "replicated n-vectors must be bitwise identical on every shard"
+    assert _rel(np.concatenate(yss), ys_ref) < 1e-9
+    for sh in shards:
+        sh.close()
+    group.close()
+
+
+def test_rccl_single_rank_communicator():
+    """world_size = 1 through the real RCCL path (the only RCCL configuration a one-GPU box can run)."""
+    from fps_amd.device_qp import rccl_unique_id
+
+    qp = _small_pde(seed=23, n=3000, m=300)
+    a = DeviceEqQP(qp, delta=SE)
+    b = DeviceEqQP(qp, delta=SE, comm=("rccl", 1, 0, rccl_unique_id()))
+    ga, gb = np.empty(qp.n), np.empty(qp.n)
+    fa, _ = a.objgrad(qp.x, gx=ga)
+    fb, _ = b.objgrad(qp.x, gx=gb)
+    assert (a.stats[0].niter, a.stats[1].niter) == (b.stats[0].niter, b.stats[1].niter)
+    assert _rel(gb, ga) < 1e-9 and abs(fa - fb) <= 1e-9 * abs(fa)
+    a.close()
+    b.close()
