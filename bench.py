@@ -55,10 +55,11 @@ def main():
     ap.add_argument("--delta", type=float, default=0.0, help="regularisation; 0 = first outer iteration (algo.jl:46)")
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--cpu-evals", type=int, default=6, help="evaluations timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--parallel", default="shard", choices=["shard", "replicas"],
+    ap.add_argument("--parallel", default="auto", choices=["auto", "shard", "replicas"],
                     help="N > 1: 'shard' = rows of A sharded over the ranks, RCCL all-reduce per Krylov iteration "
-                         "(fixed total work: strong scaling); 'replicas' = every rank evaluates its own points")
-    ap.add_argument("--force-shard", action="store_true",
+                         "(fixed total work: strong scaling); 'replicas' = every rank evaluates its own points; "
+                         "'auto' = shard only when the local product outweighs the all-reduce (DESIGN.md, Multi-GPU)")
+    ap.add_argument("--force-shard", action="store_true", default=False,
                     help="rehearsal on one GPU: run the sharded code path (RCCL communicator of size 1)")
     args = ap.parse_args()
 
@@ -74,7 +75,12 @@ def main():
     qp = gen(**kw)
     n, m, nnz = qp.n, qp.m, qp.nnz
     sigma, rho = 1e3, 1.0  # parameters.jl:71,75 (first outer iteration)
-    sharded = (world > 1 or args.force_shard) and args.parallel == "shard"
+    # Row sharding exchanges an n x 2 fp64 all-reduce per Krylov iteration (ring: 2 (P-1)/P * 16 n bytes over one
+    # ~50 GB/s xGMI link direction) against a local product of 12 nnz / P bytes at ~5 TB/s: it pays only when
+    # nnz / n >~ 130 P.  The headline (nnz / n = 10) is far below that at every P, so 'auto' runs replicas.
+    shard_pays = (12.0 * nnz / max(world, 1)) / 5e12 > (2.0 * 16.0 * n) / 50e9
+    want_shard = args.parallel == "shard" or (args.parallel == "auto" and shard_pays)
+    sharded = (world > 1 or args.force_shard) and want_shard
     if sharded:
         from fps_amd.device_qp import rccl_unique_id
         from fps_amd.distributed import row_partition, shard_qp
@@ -162,7 +168,8 @@ def main():
                    "parallelism": "single GPU" if world == 1 else
                    (f"rows of A sharded over {world} GPUs, RCCL all-reduce of the partial A'u products (n x 2 fp64) and "
                     "of the m-vector norm partials every Krylov iteration" if sharded else
-                    f"{world} independent replicas, no collective")},
+                    f"{world} independent replicas (each rank evaluates its own points), no data-path collective; row "
+                    "sharding (--parallel shard) is implemented but communication-bound at nnz/n = 10")},
         "roofline": roofline,
     }
 

@@ -1,0 +1,110 @@
+# HIPQDSolver.jl -- the reference-side binding of libfpsq.so (UNEXECUTED: julia is not available in the build
+# pipeline; kept in sync with include/fpsq.h by hand).  Drop this file next to src/solve_two_systems_struct.jl of
+# FletcherPenaltySolver.jl, `include` it from src/FletcherPenaltySolver.jl after solve_two_systems_struct.jl, and
+#     FletcherPenaltySolver.qdsolver_correspondence[:hip] = HIPQDSolver       # src/parameters.jl:197
+# so that `fps_solve(nlp; qds_solver = :hip)` (src/parameters.jl:290,299) builds it.
+
+const libfpsq = get(ENV, "LIBFPSQ", "libfpsq.so")
+
+struct FpsqStats            # fpsq_stats
+  solved::Int32
+  inconsistent::Int32
+  niter::Int32
+  status::Int32
+  rnorm::Float64
+  arnorm::Float64
+end
+
+mutable struct FpsqOptions  # fpsq_options (same field order as include/fpsq.h)
+  ls_atol::Float64; ls_rtol::Float64; ls_itmax::Int64
+  ln_atol::Float64; ln_rtol::Float64; ln_btol::Float64; ln_conlim::Float64; ln_itmax::Int64
+  ne_atol::Float64; ne_rtol::Float64; ne_etol::Float64; ne_itmax::Int64; ne_conlim::Float64
+  ls_axtol::Float64; ls_btol::Float64; ls_etol::Float64; ls_conlim::Float64
+  fuse_two_rhs::Int32; lookahead::Int32; device::Int32; reserved::Int32
+  FpsqOptions() = new()
+end
+
+"""
+    HIPQDSolver(nlp::AbstractNLPModel, ::T; kwargs...) <: QDSolver
+
+MI355X back-end for the systems `[I A'; A -δI]`; same constructor contract as `IterativeSolver`
+(src/solve_two_systems_struct.jl:94-131): the `ls_*`, `ln_*`, `ne_*` keywords are honoured, others are swallowed.
+"""
+mutable struct HIPQDSolver{T, S} <: QDSolver
+  handle::Ptr{Cvoid}
+  nvar::Int
+  ncon::Int
+  vals::S            # jac_coord! output buffer (COO order of jac_structure!)
+  p1::S; q1::S; p2::S; q2::S
+  stats::Vector{FpsqStats}
+  δ::T
+end
+
+function HIPQDSolver(nlp::AbstractNLPModel{T, S}, ::T; explicit_linear_constraints = false, kwargs...) where {T, S}
+  T == Float64 || error("HIPQDSolver is fp64 only")
+  explicit_linear_constraints && error("HIPQDSolver: explicit_linear_constraints is not supported yet")
+  nvar, ncon, nnzj = nlp.meta.nvar, nlp.meta.ncon, nlp.meta.nnzj
+  opts = FpsqOptions()
+  ccall((:fpsq_default_options, libfpsq), Cvoid, (Int64, Int64, Ref{FpsqOptions}), nvar, ncon, opts)
+  for (k, v) in kwargs
+    hasfield(FpsqOptions, k) && setfield!(opts, k, convert(fieldtype(FpsqOptions, k), v))
+  end
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  rc = ccall((:fpsq_create, libfpsq), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Ref{FpsqOptions}), h, nvar, ncon, opts)
+  rc == 0 || error(unsafe_string(ccall((:fpsq_last_error, libfpsq), Cstring, (Ptr{Cvoid},), C_NULL)))
+  rows, cols = jac_structure(nlp)                       # replaces struct.jl:331-337
+  rc = ccall((:fpsq_set_jacobian_structure_coo, libfpsq), Cint,
+             (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnzj, Int64.(rows), Int64.(cols), 1)
+  rc == 0 || error(unsafe_string(ccall((:fpsq_last_error, libfpsq), Cstring, (Ptr{Cvoid},), h[])))
+  qds = HIPQDSolver{T, S}(h[], nvar, ncon, S(undef, nnzj), S(undef, nvar), S(undef, ncon), S(undef, nvar),
+                          S(undef, ncon), Vector{FpsqStats}(undef, 2), T(NaN))
+  finalizer(q -> ccall((:fpsq_destroy, libfpsq), Cint, (Ptr{Cvoid},), q.handle), qds)
+  return qds
+end
+
+function _refresh!(qds::HIPQDSolver, nlp, x; values = true)
+  if values                                             # replaces linear_system.jl:118-122 / :223-228
+    jac_coord!(nlp.nlp, x, qds.vals)
+    ccall((:fpsq_set_jacobian_values, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}), qds.handle, qds.vals)
+  end
+  if qds.δ != nlp.δ
+    ccall((:fpsq_set_delta, libfpsq), Cint, (Ptr{Cvoid}, Float64), qds.handle, nlp.δ)
+    qds.δ = nlp.δ
+  end
+end
+
+function solve_two_mixed(nlp::FletcherPenaltyNLP{T, S, A, P, HIPQDSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
+  qds = nlp.qdsolver
+  _refresh!(qds, nlp, x)
+  rc = ccall((:fpsq_solve_two_mixed, libfpsq), Cint,
+             (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{FpsqStats}),
+             qds.handle, rhs1, rhs2, qds.p1, qds.q1, qds.p2, qds.q2, qds.stats)
+  rc < 0 && error(unsafe_string(ccall((:fpsq_last_error, libfpsq), Cstring, (Ptr{Cvoid},), qds.handle)))
+  (rc & 1) != 0 && @warn "Failed solving 1st linear system lsqr in mixed."
+  (rc & 2) != 0 && @warn "Failed solving 2nd linear system craig in mixed."
+  return qds.p1, qds.q1, qds.p2, qds.q2
+end
+
+function solve_two_least_squares(nlp::FletcherPenaltyNLP{T, S, A, P, HIPQDSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
+  qds = nlp.qdsolver
+  _refresh!(qds, nlp, x; values = false)               # the reference trusts the cached operator, linear_system.jl:85-86
+  rc = ccall((:fpsq_solve_two_least_squares, libfpsq), Cint,
+             (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{FpsqStats}),
+             qds.handle, rhs1, rhs2, qds.p1, qds.q1, qds.p2, qds.q2, qds.stats)
+  rc < 0 && error(unsafe_string(ccall((:fpsq_last_error, libfpsq), Cstring, (Ptr{Cvoid},), qds.handle)))
+  (rc & 1) != 0 && @warn "Failed solving 1st linear system lsqr."
+  (rc & 2) != 0 && @warn "Failed solving 2nd linear system lsqr."
+  return qds.p1, qds.q1, qds.p2, qds.q2
+end
+
+function solve_two_extras(nlp::FletcherPenaltyNLP{T, S, A, P, HIPQDSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
+  qds = nlp.qdsolver
+  _refresh!(qds, nlp, x; values = false)
+  rc = ccall((:fpsq_solve_two_extras, libfpsq), Cint,
+             (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{FpsqStats}),
+             qds.handle, rhs1, rhs2, qds.q1, qds.q2, qds.stats)
+  rc < 0 && error(unsafe_string(ccall((:fpsq_last_error, libfpsq), Cstring, (Ptr{Cvoid},), qds.handle)))
+  (rc & 1) != 0 && @warn "Failed solving 1st linear system lsqr in extra."
+  (rc & 2) != 0 && @warn "Failed solving 2nd linear system minres in extra."
+  return qds.q1, qds.q2
+end
