@@ -10,7 +10,10 @@
 namespace fpsq {
 
 constexpr int kBlock = 256;        // threads per workgroup (4 waves)
-constexpr int kSpmvNnz = 2048;     // nonzeros staged through LDS per workgroup
+#ifndef FPSQ_SPMV_NNZ
+#define FPSQ_SPMV_NNZ 2048
+#endif
+constexpr int kSpmvNnz = FPSQ_SPMV_NNZ;  // nonzeros staged through LDS per workgroup
 constexpr int kMaxRowsPerBlk = 1024;
 constexpr int kEwBlocksMax = 1024; // grid cap for element-wise kernels (grid-stride beyond)
 

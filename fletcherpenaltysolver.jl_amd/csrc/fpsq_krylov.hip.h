@@ -24,9 +24,11 @@ struct Progress {  // host-mapped, written by the device, polled by the host
 };
 
 __device__ __forceinline__ void publish(Progress* p, int iter, int done) {
+  // relaxed system-scope stores, no fence: the host only needs to see them eventually (it bounds its run-ahead with
+  // them and re-reads the device state itself if the stream drains first); a fence here would hold the kernel for a
+  // PCIe round trip on every step
   __hip_atomic_store(&p->iter, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&p->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();
 }
 
 __device__ __forceinline__ double dsign(double a) { return (double)((a > 0.0) - (a < 0.0)); }

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     if (rr < R && gl == 0) {
       const size_t row = (size_t)(r0 + rr);
 #pragma unroll
-      for (int l = 0; l < NL; ++l) if (act[l]) { const double o = ca[l] * acc[p][l] + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0); yout[row * NL + l] = o; sq[l] += o * o; }
+      for (int l = 0; l < NL; ++l) if (act[l]) { if (ABL & 32) { sq[l] += acc[p][l]; } else { const double o = ca[l] * acc[p][l] + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0); yout[row * NL + l] = o; sq[l] += o * o; } }
     }
   }
 #pragma unroll
@@ -612,6 +612,7 @@ int main(int argc, char** argv) {
     v.launchA = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv, ABLv>), dim3(pa * 8), dim3(kBlock), 0, 0, ra.view, xn, ym, ym, ctl, ctl, part, pa); }; \
     v.launchT = [=]() { hipLaunchKernelGGL((k_spmv<NLv, 1>), dim3(pt * 8), dim3(kBlock), 0, 0, dT.view, xm, yn, yn, ctl, ctl, part, pt); }; \
     vs.push_back(v); }
+  ADD_RGCS_ABL(2, 31, 12800, 128) ADD_RGCS_ABL(2, 63, 12800, 128) ADD_RGCS_ABL(2, 47, 12800, 128) ADD_RGCS_ABL(2, 63, 3200, 32) ADD_RGCS_ABL(2, 63, 51200, 512)
   ADD_RGCS_ABL(2, 0, 12800, 128) ADD_RGCS_ABL(2, 8, 12800, 128) ADD_RGCS_ABL(2, 15, 12800, 128) ADD_RGCS_ABL(2, 8, 6400, 64) ADD_RGCS_ABL(2, 8, 25600, 256)
   ADD_RGCS_ABL(1, 8, 12800, 128) ADD_RGCS_ABL(1, 15, 12800, 128)
 
