@@ -47,6 +47,14 @@ class Info(C.Structure):
         return d
 
 
+class DenseInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("last_syrk_ms", C.c_double), ("last_chol_ms", C.c_double),
+                ("last_solve_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 # every symbol include/fpsq.h declares: (name, restype, argtypes)
 _VP, _DP, _I32, _I64, _D = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SYMBOLS = [
@@ -73,6 +81,15 @@ SYMBOLS = [
     ("fpsq_local_group_create", C.c_int, [_I32, C.POINTER(_VP)]),
     ("fpsq_local_group_destroy", C.c_int, [_VP]),
     ("fpsq_comm_init_local", C.c_int, [_VP, _VP, _I32]),
+    ("fpsq_dense_create", C.c_int, [C.POINTER(_VP), _I64, _I64, _I32]),
+    ("fpsq_dense_destroy", C.c_int, [_VP]),
+    ("fpsq_dense_last_error", C.c_char_p, [_VP]),
+    ("fpsq_dense_set_jacobian", C.c_int, [_VP, _DP]),
+    ("fpsq_dense_factorize", C.c_int, [_VP, _D, C.POINTER(C.c_int32)]),
+    ("fpsq_dense_solve_two_mixed", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
+    ("fpsq_dense_solve_two_least_squares", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
+    ("fpsq_dense_get_factor", C.c_int, [_VP, _DP]),
+    ("fpsq_dense_get_info", C.c_int, [_VP, C.POINTER(DenseInfo)]),
     ("fpsq_get_info", C.c_int, [_VP, C.POINTER(Info)]),
     ("fpsq_set_profiling", C.c_int, [_VP, _I32]),
 ]

@@ -325,6 +325,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   if (!perm.empty()) HIPCHK(h, hipMemcpy(h->permT, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
   h->nnz = h->A.nnz;
   if (int rc = alloc_workspaces(h)) return rc;
+  HIPCHK(h, hipDeviceSynchronize());  // the set-up used null-stream copies/memsets; the solver stream is non-blocking
   h->have_structure = true;
   h->have_values = false;
   h->info.n = h->n;
@@ -1059,6 +1060,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     raw.upd_iter = -1;
     hipMemcpy(h->ctl_raw, &raw, sizeof raw, hipMemcpyHostToDevice);
   }
+  hipDeviceSynchronize();
   *out = h;
   return FPSQ_OK;
 }

@@ -1,0 +1,280 @@
+// fpsq_dense.hip -- host side of the dense-block direct back-end (C ABI: include/fpsq.h, "dense" section).
+#include "../../include/fpsq.h"
+#include "fpsq_dense.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fpsq;
+
+struct fpsq_dense_s {
+  int64_t n = 0, m = 0, npad = 0, mpad = 0, nb = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool have_jac = false, factored = false;
+  double* A = nullptr;     // mpad x npad, row-major, zero padded
+  double* M = nullptr;     // mpad x mpad: lower triangle holds the Cholesky factor after factorize
+  double* invs = nullptr;  // nb inverses of the diagonal 128 x 128 blocks of L
+  double *r2 = nullptr, *y2 = nullptr, *x2 = nullptr, *part = nullptr;  // [mpad][2], [mpad][2], [npad][2], gemvt partials
+  double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
+  int* info_dev = nullptr;
+  int nchunk = 16;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  fpsq_dense_info info{};
+  std::vector<void*> allocs;
+};
+
+namespace {
+thread_local std::string g_dense_create_error;
+
+#define DCHK(d, call)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      (d)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+      return FPSQ_ERR_HIP;                                                     \
+    }                                                                          \
+  } while (0)
+
+template <class T>
+int dmalloc(fpsq_dense d, T** p, size_t count) {
+  void* q = nullptr;
+  DCHK(d, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  d->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+// q (m x 2 in d->r2, overwritten) <- M^-1 r2 via L y = r, L' q = y; result in d->y2 after the backward sweep
+void solve_two_rhs(fpsq_dense d) {
+  hipStream_t s = d->stream;
+  const int nb = (int)d->nb, ld = (int)d->mpad;
+  for (int k = 0; k < nb; ++k)
+    hipLaunchKernelGGL(k_trsv_step<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->r2, d->y2, k);
+  for (int k = nb - 1; k >= 0; --k)
+    hipLaunchKernelGGL(k_trsv_step<false>, dim3(k + 1), dim3(256), 0, s, d->M, ld, d->invs, d->y2, d->r2, k);
+  // solution now in d->r2
+}
+
+// common tail: Q in d->r2 ([mpad][2]); P = [a0, a1] - A' Q
+int finish(fpsq_dense d, const double* a0, const double* a1, double* p1, double* q1, double* p2, double* q2) {
+  hipStream_t s = d->stream;
+  const int rows_per_chunk = (int)((d->mpad + d->nchunk - 1) / d->nchunk);
+  hipLaunchKernelGGL(k_dense_gemvt_part<2>, dim3((unsigned)((d->npad + 255) / 256), d->nchunk), dim3(256), 0, s, d->A,
+                     (int)d->npad, (int)d->mpad, (int)d->npad, d->r2, d->part, rows_per_chunk);
+  hipLaunchKernelGGL(k_dense_finish_p, dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, s, d->part, d->nchunk,
+                     (int)d->npad, (int)d->n, a0, a1, d->o_p1, d->o_p2);
+  hipLaunchKernelGGL(k_dense_unpack2, dim3((unsigned)((d->m + 255) / 256)), dim3(256), 0, s, d->r2, d->o_q1, d->o_q2,
+                     (int)d->m);
+  hipEventRecord(d->e1, s);
+  DCHK(d, hipMemcpyAsync(p1, d->o_p1, (size_t)d->n * 8, hipMemcpyDefault, s));
+  DCHK(d, hipMemcpyAsync(p2, d->o_p2, (size_t)d->n * 8, hipMemcpyDefault, s));
+  DCHK(d, hipMemcpyAsync(q1, d->o_q1, (size_t)d->m * 8, hipMemcpyDefault, s));
+  DCHK(d, hipMemcpyAsync(q2, d->o_q2, (size_t)d->m * 8, hipMemcpyDefault, s));
+  DCHK(d, hipStreamSynchronize(s));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, d->e0, d->e1);
+  d->info.last_solve_ms = ms;
+  return FPSQ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* fpsq_dense_last_error(fpsq_dense d) { return d ? d->err.c_str() : g_dense_create_error.c_str(); }
+
+int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
+  if (!out || n <= 0 || m <= 0 || n > (1 << 20) || m > (1 << 16)) {
+    g_dense_create_error = "fpsq_dense_create: bad arguments (n <= 2^20, m <= 2^16)";
+    return FPSQ_ERR_ARG;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    g_dense_create_error = std::string("fpsq_dense_create: no HIP device (") + hipGetErrorString(e) +
+                           "); libfpsq has no CPU fallback";
+    return FPSQ_ERR_HIP;
+  }
+  fpsq_dense d = new fpsq_dense_s();
+  d->n = n;
+  d->m = m;
+  d->device = device;
+  d->mpad = (m + kDB - 1) / kDB * kDB;
+  d->npad = (n + kDK - 1) / kDK * kDK;
+  d->nb = d->mpad / kDB;
+  d->nchunk = (int)std::min<int64_t>(32, d->nb * 4);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_dense_create_error = "fpsq_dense_create: cannot initialise device";
+    delete d;
+    return FPSQ_ERR_HIP;
+  }
+  hipEventCreate(&d->e0);
+  hipEventCreate(&d->e1);
+  hipEventCreate(&d->e2);
+  int rc = 0;
+  rc |= dmalloc(d, &d->A, (size_t)d->mpad * d->npad);
+  rc |= dmalloc(d, &d->M, (size_t)d->mpad * d->mpad);
+  rc |= dmalloc(d, &d->invs, (size_t)d->nb * kDB * kDB);
+  rc |= dmalloc(d, &d->r2, (size_t)d->mpad * 2);
+  rc |= dmalloc(d, &d->y2, (size_t)d->mpad * 2);
+  rc |= dmalloc(d, &d->x2, (size_t)d->npad * 2);
+  rc |= dmalloc(d, &d->part, (size_t)d->nchunk * d->npad * 2);
+  rc |= dmalloc(d, &d->in_a, (size_t)d->npad);
+  rc |= dmalloc(d, &d->in_b, (size_t)std::max(d->npad, d->mpad));
+  rc |= dmalloc(d, &d->o_p1, (size_t)d->npad);
+  rc |= dmalloc(d, &d->o_p2, (size_t)d->npad);
+  rc |= dmalloc(d, &d->o_q1, (size_t)d->mpad);
+  rc |= dmalloc(d, &d->o_q2, (size_t)d->mpad);
+  rc |= dmalloc(d, &d->info_dev, 4);
+  if (rc) {
+    g_dense_create_error = d->err;
+    fpsq_dense_destroy(d);
+    return FPSQ_ERR_HIP;
+  }
+  // on the solver's own (non-blocking) stream: a null-stream memset is not ordered against it
+  hipMemsetAsync(d->A, 0, (size_t)d->mpad * d->npad * 8, d->stream);
+  hipStreamSynchronize(d->stream);
+  // the potrf + inverse kernel keeps a 128 x 129 (+ 128) fp64 block in dynamic LDS
+  hipFuncSetAttribute((const void*)k_potrf_inv128, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (kDB * (kDB + 1) + kDB) * 8);
+  d->info.n = n;
+  d->info.m = m;
+  *out = d;
+  return FPSQ_OK;
+}
+
+int fpsq_dense_destroy(fpsq_dense d) {
+  if (!d) return FPSQ_ERR_ARG;
+  hipSetDevice(d->device);
+  if (d->stream) hipStreamSynchronize(d->stream);
+  for (void* p : d->allocs) hipFree(p);
+  if (d->e0) hipEventDestroy(d->e0);
+  if (d->e1) hipEventDestroy(d->e1);
+  if (d->e2) hipEventDestroy(d->e2);
+  if (d->stream) hipStreamDestroy(d->stream);
+  delete d;
+  return FPSQ_OK;
+}
+
+int fpsq_dense_set_jacobian(fpsq_dense d, const double* a_rowmajor) {
+  if (!d || !a_rowmajor) return FPSQ_ERR_ARG;
+  hipSetDevice(d->device);
+  DCHK(d, hipMemcpy2DAsync(d->A, (size_t)d->npad * 8, a_rowmajor, (size_t)d->n * 8, (size_t)d->n * 8, (size_t)d->m,
+                           hipMemcpyDefault, d->stream));
+  DCHK(d, hipStreamSynchronize(d->stream));
+  d->have_jac = true;
+  d->factored = false;
+  return FPSQ_OK;
+}
+
+int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
+  if (!d || !(delta >= 0.0)) return FPSQ_ERR_ARG;
+  if (!d->have_jac) {
+    d->err = "dense_factorize: Jacobian not set";
+    return FPSQ_ERR_STATE;
+  }
+  hipSetDevice(d->device);
+  hipStream_t s = d->stream;
+  const int nb = (int)d->nb, ld = (int)d->mpad;
+  DCHK(d, hipMemsetAsync(d->info_dev, 0, 4, s));
+  hipEventRecord(d->e0, s);
+  // M = A A' (lower tiles) on the fp64 matrix cores, then + delta I
+  hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->A, (int)d->npad, d->A, (int)d->npad,
+                     (int)d->npad, 1.0, 0.0);
+  hipLaunchKernelGGL(k_dense_diag, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->M, ld, (int)d->m,
+                     (int)d->mpad, delta);
+  hipEventRecord(d->e1, s);
+  // right-looking blocked Cholesky, block 128: potrf + inverse of the diagonal block (one workgroup), panel
+  // L_ik = M_ik Linv_kk' and trailing update M_ij -= L_ik L_jk' on the matrix cores
+  for (int k = 0; k < nb; ++k) {
+    double* Mkk = d->M + (size_t)k * kDB * ld + (size_t)k * kDB;
+    double* inv = d->invs + (size_t)k * kDB * kDB;
+    hipLaunchKernelGGL(k_potrf_inv128, dim3(1), dim3(kPotrfThreads), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
+                       d->info_dev);
+    const int rem = nb - k - 1;
+    if (rem > 0) {
+      double* panel = d->M + (size_t)(k + 1) * kDB * ld + (size_t)k * kDB;
+      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), 0, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0);
+      double* trail = d->M + (size_t)(k + 1) * kDB * ld + (size_t)(k + 1) * kDB;
+      hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(rem, rem), dim3(256), 0, s, trail, ld, panel, ld, panel, ld, kDB, -1.0,
+                         1.0);
+    }
+  }
+  hipEventRecord(d->e2, s);
+  int32_t hinfo = 0;
+  DCHK(d, hipMemcpyAsync(&hinfo, d->info_dev, 4, hipMemcpyDeviceToHost, s));
+  DCHK(d, hipStreamSynchronize(s));
+  float a = 0.f, b = 0.f;
+  hipEventElapsedTime(&a, d->e0, d->e1);
+  hipEventElapsedTime(&b, d->e1, d->e2);
+  d->info.last_syrk_ms = a;
+  d->info.last_chol_ms = b;
+  if (info) *info = hinfo;
+  d->factored = hinfo == 0;
+  return hinfo == 0 ? FPSQ_OK : 1;  // soft failure: M not positive definite (the reference warns and goes on, :244-246)
+}
+
+int fpsq_dense_solve_two_mixed(fpsq_dense d, const double* rhs1, const double* rhs2, double* p1, double* q1, double* p2,
+                               double* q2) {
+  if (!d || !rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2) return FPSQ_ERR_ARG;
+  if (!d->factored) {
+    d->err = "dense_solve: no valid factorisation";
+    return FPSQ_ERR_STATE;
+  }
+  hipSetDevice(d->device);
+  hipStream_t s = d->stream;
+  DCHK(d, hipMemcpyAsync(d->in_a, rhs1, (size_t)d->n * 8, hipMemcpyDefault, s));
+  DCHK(d, hipMemcpyAsync(d->in_b, rhs2, (size_t)d->m * 8, hipMemcpyDefault, s));
+  hipEventRecord(d->e0, s);
+  // r = [A g, -c]:  q1 = M^-1 A g,  q2 = -M^-1 c   
+  hipLaunchKernelGGL(k_dense_pack2, dim3((unsigned)((d->npad + 255) / 256)), dim3(256), 0, s, d->in_a, 1.0,
+                     (const double*)nullptr, 0.0, d->x2, (int)d->n, (int)d->npad);
+  hipLaunchKernelGGL(k_dense_gemv<2>, dim3((unsigned)((d->mpad + 3) / 4)), dim3(256), 0, s, d->A, (int)d->npad,
+                     (int)d->mpad, (int)d->npad, d->x2, 1.0, (const double*)nullptr, 0.0, d->y2);
+  hipLaunchKernelGGL(k_dense_unpack2, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->y2, d->o_q1, d->o_q2,
+                     (int)d->mpad);
+  hipLaunchKernelGGL(k_dense_pack2, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->o_q1, 1.0, d->in_b, -1.0,
+                     d->r2, (int)d->m, (int)d->mpad);
+  solve_two_rhs(d);
+  return finish(d, d->in_a, nullptr, p1, q1, p2, q2);
+}
+
+int fpsq_dense_solve_two_least_squares(fpsq_dense d, const double* rhs1, const double* rhs2, double* p1, double* q1,
+                                       double* p2, double* q2) {
+  if (!d || !rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2) return FPSQ_ERR_ARG;
+  if (!d->factored) {
+    d->err = "dense_solve: no valid factorisation";
+    return FPSQ_ERR_STATE;
+  }
+  hipSetDevice(d->device);
+  hipStream_t s = d->stream;
+  DCHK(d, hipMemcpyAsync(d->in_a, rhs1, (size_t)d->n * 8, hipMemcpyDefault, s));
+  DCHK(d, hipMemcpyAsync(d->in_b, rhs2, (size_t)d->n * 8, hipMemcpyDefault, s));
+  hipEventRecord(d->e0, s);
+  hipLaunchKernelGGL(k_dense_pack2, dim3((unsigned)((d->npad + 255) / 256)), dim3(256), 0, s, d->in_a, 1.0, d->in_b, 1.0,
+                     d->x2, (int)d->n, (int)d->npad);
+  hipLaunchKernelGGL(k_dense_gemv<2>, dim3((unsigned)((d->mpad + 3) / 4)), dim3(256), 0, s, d->A, (int)d->npad,
+                     (int)d->mpad, (int)d->npad, d->x2, 1.0, (const double*)nullptr, 0.0, d->r2);
+  solve_two_rhs(d);
+  return finish(d, d->in_a, d->in_b, p1, q1, p2, q2);
+}
+
+int fpsq_dense_get_factor(fpsq_dense d, double* l_out) {
+  if (!d || !l_out) return FPSQ_ERR_ARG;
+  hipSetDevice(d->device);
+  DCHK(d, hipMemcpy2D(l_out, (size_t)d->m * 8, d->M, (size_t)d->mpad * 8, (size_t)d->m * 8, (size_t)d->m, hipMemcpyDefault));
+  return FPSQ_OK;
+}
+
+int fpsq_dense_get_info(fpsq_dense d, fpsq_dense_info* info) {
+  if (!d || !info) return FPSQ_ERR_ARG;
+  *info = d->info;
+  return FPSQ_OK;
+}
+
+}  // extern "C"

@@ -142,3 +142,79 @@ class HIPQDSolver(QDSolver):
 
 # src/parameters.jl:197 -- the registry fps_solve(...; qds_solver = :sym) looks back-ends up in
 qdsolver_correspondence = {"hip": HIPQDSolver}
+
+
+class HIPDirectQDSolver(QDSolver):
+    """`HIPDirectQDSolver(nlp, T(0))`: the DIRECT back-end on the MI355X for small / dense Jacobians -- the role
+    `LDLtSolver` plays in the reference (src/solve_two_systems_struct.jl:299-353; it is the reference's default,
+    src/parameters.jl:290).  Instead of an LDL' of K it factorises the normal equations M = A A' + delta I (fp64 MFMA
+    SYRK + blocked Cholesky) and solves both systems with two right-hand sides; like `ldl_factorize!` it refactorises
+    on every `solve_two_mixed` (src/solve_linear_system.jl:233-234) and re-uses the factors in
+    `solve_two_least_squares` (:194-195).  A non positive definite M only warns (:244-246)."""
+
+    def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, **kwargs):
+        if explicit_linear_constraints:
+            raise NotImplementedError("explicit_linear_constraints=True is outside this build's hot-path scope")
+        self._lib = _lib.load()
+        self.nvar, self.ncon = int(nlp.meta.nvar), int(nlp.meta.ncon)
+        d = C.c_void_p()
+        if self._lib.fpsq_dense_create(C.byref(d), self.nvar, self.ncon, int(kwargs.get("device", 0))) != 0:
+            raise FpsqError(self._lib.fpsq_dense_last_error(None).decode())
+        self._d = d
+        rows, cols = nlp.jac_structure()
+        self._rows = np.asarray(rows, dtype=np.int64) - 1
+        self._cols = np.asarray(cols, dtype=np.int64) - 1
+        self._A = np.zeros((self.ncon, self.nvar))
+        self.factorized = False
+
+    def _check(self, rc):
+        if rc < 0:
+            raise FpsqError(self._lib.fpsq_dense_last_error(self._d).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_d", None):
+            self._lib.fpsq_dense_destroy(self._d)
+            self._d = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _factorize(self, nlp, x):
+        self._A[:] = 0.0
+        np.add.at(self._A, (self._rows, self._cols), np.asarray(nlp.nlp.jac_coord(x), dtype=np.float64))
+        self._check(self._lib.fpsq_dense_set_jacobian(self._d, self._A.ctypes.data))
+        info = C.c_int32()
+        rc = self._check(self._lib.fpsq_dense_factorize(self._d, float(nlp.delta), C.byref(info)))
+        self.factorized = rc == 0
+        return rc
+
+    def _solve(self, fn, rhs1, rhs2):
+        n, m = self.nvar, self.ncon
+        rhs1 = np.ascontiguousarray(rhs1, dtype=np.float64)
+        rhs2 = np.ascontiguousarray(rhs2, dtype=np.float64)
+        p1, q1, p2, q2 = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+        if not self.factorized:
+            warnings.warn("_solve_ldlt_factorization: failed _factorization")
+            return p1, q1, p2, q2
+        self._check(fn(self._d, rhs1.ctypes.data, rhs2.ctypes.data, p1.ctypes.data, q1.ctypes.data, p2.ctypes.data,
+                       q2.ctypes.data))
+        return p1, q1, p2, q2
+
+    def solve_two_mixed(self, nlp, x, rhs1, rhs2):
+        self._factorize(nlp, x)
+        return self._solve(self._lib.fpsq_dense_solve_two_mixed, rhs1, rhs2)
+
+    def solve_two_least_squares(self, nlp, x, rhs1, rhs2):
+        return self._solve(self._lib.fpsq_dense_solve_two_least_squares, rhs1, rhs2)
+
+    def info(self):
+        i = _lib.DenseInfo()
+        self._check(self._lib.fpsq_dense_get_info(self._d, C.byref(i)))
+        return i.as_dict()
+
+
+qdsolver_correspondence["hip_direct"] = HIPDirectQDSolver

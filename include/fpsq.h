@@ -167,6 +167,35 @@ int fpsq_local_group_create(int32_t nshards, void **group);
 int fpsq_local_group_destroy(void *group);
 int fpsq_comm_init_local(fpsq_handle h, void *group, int32_t shard);
 
+
+/* ---- dense-block Jacobian variant (BASELINE configs[2]; the DIRECT back-end of the seam for small / dense problems).
+ * Replaces the reference's factorisation path: LDLtSolver (src/solve_two_systems_struct.jl:308-353),
+ * solve_two_mixed / solve_two_least_squares with `ldl_factorize!` + `ldiv!` (src/solve_linear_system.jl:161-252) and
+ * the dense A A' + tau I contraction of src/model-Fletcherpenaltynlp.jl:478-484.  Here: M = A A' + delta I on the fp64
+ * matrix cores (v_mfma_f64_16x16x4_f64), blocked Cholesky M = L L', two right-hand sides per solve:
+ *   q1 = M^-1 A rhs1, p1 = rhs1 - A'q1;   mixed: q2 = -M^-1 rhs2, p2 = -A'q2;   least squares: q2 = M^-1 A rhs2, p2 = rhs2 - A'q2.
+ * fpsq_dense_factorize returns 1 (soft) with *info = first non-positive pivot row (1-based) when M is not positive
+ * definite -- the counterpart of `factorized(str) == false` (src/solve_linear_system.jl:242-246). */
+typedef struct fpsq_dense_s *fpsq_dense;
+typedef struct {
+  int64_t n, m;
+  double last_syrk_ms; /* device time of M = A A' + delta I */
+  double last_chol_ms; /* device time of the blocked Cholesky */
+  double last_solve_ms;
+} fpsq_dense_info;
+int fpsq_dense_create(fpsq_dense *out, int64_t n, int64_t m, int32_t device);
+int fpsq_dense_destroy(fpsq_dense d);
+const char *fpsq_dense_last_error(fpsq_dense d);
+int fpsq_dense_set_jacobian(fpsq_dense d, const double *a_rowmajor); /* m x n, the Jacobian at the current x */
+int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t *info);
+int fpsq_dense_solve_two_mixed(fpsq_dense d, const double *rhs1, const double *rhs2, double *p1, double *q1, double *p2,
+                               double *q2);
+int fpsq_dense_solve_two_least_squares(fpsq_dense d, const double *rhs1, const double *rhs2, double *p1, double *q1,
+                                       double *p2, double *q2);
+/* m x m row-major copy of the factor storage: lower triangle = L with M = L L' (upper triangle unspecified) */
+int fpsq_dense_get_factor(fpsq_dense d, double *l_out);
+int fpsq_dense_get_info(fpsq_dense d, fpsq_dense_info *info);
+
 /* ---- introspection for benchmarks / profiling */
 typedef struct {
   int64_t n, m, nnz;
