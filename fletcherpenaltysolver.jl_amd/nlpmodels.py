@@ -21,6 +21,16 @@ class _Model:
         np.add.at(out, cols - 1, self.jac_coord(x) * np.asarray(v)[rows - 1])
         return out
 
+    def jprod(self, x, v):
+        rows, cols = self.jac_structure()
+        out = np.zeros(self.meta.ncon)
+        np.add.at(out, rows - 1, self.jac_coord(x) * np.asarray(v)[cols - 1])
+        return out
+
+    def ghjvprod(self, x, g, v):
+        """(g' Hess c_i v)_i; zero unless a model overrides it (linear constraints)."""
+        return np.zeros(self.meta.ncon)
+
 
 class SumSquares(_Model):
     """f = x'x, c = sum(x) - 1   (test/unit-test.jl:18, test/test-2.jl:30)"""
@@ -51,6 +61,9 @@ class RosenbrockCircle(_Model):
     def hprod(self, x, y, v, obj_weight=1.0):
         H = np.array([[2 - 400 * (x[1] - x[0] ** 2) + 800 * x[0] ** 2, -400 * x[0]], [-400 * x[0], 200.0]])
         return obj_weight * (H @ v) + y[0] * 2.0 * np.asarray(v)
+
+    def ghjvprod(self, x, g, v):
+        return np.array([2.0 * float(np.dot(g, v))])
 
 
 class HS6(_Model):
@@ -85,4 +98,5 @@ class EqQPModel(_Model):
     def jac_structure(self): return self._struct
     def jac_coord(self, x): return self.qp.vals
     def jtprod(self, x, v): return self._A.T @ v
+    def jprod(self, x, v): return self._A @ v
     def hprod(self, x, y, v, obj_weight=1.0): return obj_weight * self.qp.qdiag * np.asarray(v)

@@ -1,6 +1,7 @@
-"""Host-side mirror of `FletcherPenaltyNLP` (src/model-Fletcherpenaltynlp.jl:58-103) -- the hot part only:
-`_compute_ys_gs!` (:234-252), `obj` (:352-370), `grad!` (:372-401), `objgrad!` (:403-437).  The Hessian part
-(hprod!/hess_coord!) is the next row of SURVEY.md §8f and is not built yet.
+"""Host-side mirror of `FletcherPenaltyNLP` (src/model-Fletcherpenaltynlp.jl:58-103): the hot part
+`_compute_ys_gs!` (:234-252), `obj` (:352-370), `grad!` (:372-401), `objgrad!` (:403-437), and the matrix-free
+Hessian products `hprod!` Val(2) (:521-570) and Val(1) (:572-634) -- SURVEY.md §8f rows 1-2 -- which reach the
+back-end through `solve_two_least_squares` / `solve_two_extras`.  `hess_coord!` (dense O(n^2) Hessian) is not built.
 """
 from __future__ import annotations
 
@@ -99,3 +100,36 @@ class FletcherPenaltyNLP:
 
     def objgrad(self, x):
         return self.objgrad_(x, np.empty(self.meta.nvar))
+
+    # :521-570 (Val(2)) and :572-634 (Val(1))   (hprod!)
+    def hprod_(self, x, v, Hv, obj_weight=1.0):
+        x, v = np.asarray(x, float), np.asarray(v, float)
+        assert x.size == self.meta.nvar and v.size == self.meta.nvar and Hv.size == self.meta.nvar
+        self.counters["neval_hprod"] = self.counters.get("neval_hprod", 0) + 1
+        sigma, rho = self.sigma, self.rho
+        gs, ys, _, _ = self._compute_ys_gs(x)
+        c = self.cx
+        Jv = -ys                                                             # :536 / :590
+        Hsv = self.nlp.hprod(x, Jv, v, obj_weight=1.0)                       # :537 / :591
+        p1, _, p2, _ = self.qdsolver.solve_two_least_squares(self, x, v, Hsv)  # :542 / :593
+        Ptv = v - p1                                                         # :543 / :594
+        HsPtv = self.nlp.hprod(x, Jv, Ptv, obj_weight=1.0)                   # :545 / :598
+        if self.hessian_approx == 2:
+            Hv[:] = p2 - HsPtv + 2 * sigma * Ptv                             # :550
+        else:
+            Ssv = self.nlp.ghjvprod(x, gs, v)                                # :600
+            invJtJJv, invJtJSsv = self.qdsolver.solve_two_extras(self, x, v, Ssv)  # :602
+            JtinvJtJSsv = self.nlp.jtprod(x, invJtJSsv)                      # :606
+            Hv[:] = p2 - HsPtv + 2 * sigma * Ptv - JtinvJtJSsv               # :612
+            Hv -= self.nlp.hprod(x, invJtJJv, gs, obj_weight=0.0)            # :613-614
+        if rho > 0.0:
+            JtJv = self.nlp.jtprod(x, self.nlp.jprod(x, v))                  # :557-558 / :621-622
+            Hcv = self.nlp.hprod(x, c, v, obj_weight=0.0)                    # :560 / :624
+            Hv += Hcv + rho * JtJv if self.hessian_approx == 2 else rho * (Hcv + JtJv)  # :562 / :626
+        if self.eta > 0.0:
+            Hv += self.eta * v
+        Hv *= obj_weight
+        return Hv
+
+    def hprod(self, x, v, obj_weight=1.0):
+        return self.hprod_(x, v, np.empty(self.meta.nvar), obj_weight)

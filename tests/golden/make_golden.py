@@ -38,6 +38,13 @@ cases.append(dict(
                 grad=[2 * v - Ys * cx - ys(xr) for v in xr]),     # unit-test.jl:58-59
     atol=dict(obj=1e-13, ys=1e-13, cx=0.0, grad=1e-13)))
 
+# hprod known answer of the same model (unit-test.jl:190-191 at xfeas, atol 1e-13; :201-202 at xr, atol 1e-12):
+#   hprod(fpnlp, x, v) = 2 v - 2 ones(n) Ys' v   for ANY v (the reference draws v = rand(n)); fixed v here.
+vfix = [((7 * i + 3) % 11) / 11.0 for i in range(n)]
+hv = [2 * vi - 2 * Ys * sum(vfix) for vi in vfix]
+cases[0]["hprod"] = dict(v=vfix, expect=hv, atol=1e-13, cite="test/unit-test.jl:190-191")
+cases[1]["hprod"] = dict(v=vfix, expect=hv, atol=1e-12, cite="test/unit-test.jl:201-202")
+
 # --- test/unit-test.jl:78-152 (and :216-287): Rosenbrock + unit circle,
 #     FletcherPenaltyNLP(nlp, 0.5, 0.1, 0.25, Val(k)) => sigma = .5, rho = .1, delta = .25
 sigma, rho, delta = 0.5, 0.1, 0.25

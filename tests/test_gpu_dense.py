@@ -99,6 +99,10 @@ def test_reference_known_answers_through_direct_backend(case):
     for key, want in case["expect"].items():
         np.testing.assert_allclose(got[key], want, rtol=0, atol=max(case["atol"][key], 1e-15),
                                    err_msg=f"{case['name']}:{key}")
+    if "hprod" in case:  # unit-test.jl:190-191, 201-202 (Val(2); solve_two_least_squares re-uses the factorisation)
+        fp2 = FletcherPenaltyNLP(nlp, case["sigma"], case["rho"], case["delta"], 2, qds=qds)
+        hv = fp2.hprod(x, np.array(case["hprod"]["v"]))
+        np.testing.assert_allclose(hv, case["hprod"]["expect"], rtol=0, atol=case["hprod"]["atol"])
     qds.close()
 
 

@@ -167,7 +167,33 @@ def test_reference_known_answers_through_hip_backend(case):
         atol = max(case["atol"][key], 1e-15) * 4
         np.testing.assert_allclose(got[key], want, rtol=0, atol=atol, err_msg=f"{case['name']}:{key}")
     assert qds.stats[0].solved and qds.stats[1].solved
+    if "hprod" in case:  # unit-test.jl:190-191, 201-202: both Hessian approximations share this closed form here
+        for approx in (2, 1):
+            fp2 = FletcherPenaltyNLP(nlp, case["sigma"], case["rho"], case["delta"], approx, qds=qds)
+            hv = fp2.hprod(x, np.array(case["hprod"]["v"]))
+            np.testing.assert_allclose(hv, case["hprod"]["expect"], rtol=0, atol=case["hprod"]["atol"] * 4,
+                                       err_msg=f"{case['name']}:hprod Val({approx})")
     qds.close()
+
+
+def test_hprod_both_backends_agree_on_nonlinear_constraints():
+    """hprod! Val(1)/Val(2) (model-Fletcherpenaltynlp.jl:521-634) on Rosenbrock + circle (nonlinear constraint, so
+    ghjvprod and solve_two_extras are exercised): the iterative and the direct MI355X back-ends agree."""
+    from fps_amd.qdsolver import HIPDirectQDSolver
+
+    nlp = nlpmodels.RosenbrockCircle()
+    x = np.array([0.7, -0.4])
+    v = np.array([0.3, 1.1])
+    out = {}
+    tight = {**TIGHT, "ne_atol": 1e-15, "ne_rtol": 1e-15, "ne_etol": 1e-15}
+    for approx in (1, 2):
+        it = FletcherPenaltyNLP(nlp, 0.5, 0.1, 0.25, approx, qds=HIPQDSolver(nlp, 0.0, **tight))
+        out[("it", approx)] = it.hprod(x, v)
+        it.qdsolver.close()
+    d2 = FletcherPenaltyNLP(nlp, 0.5, 0.1, 0.25, 2, qds=HIPDirectQDSolver(nlp, 0.0))
+    np.testing.assert_allclose(out[("it", 2)], d2.hprod(x, v), rtol=1e-10)
+    d2.qdsolver.close()
+    assert np.all(np.isfinite(out[("it", 1)])) and not np.allclose(out[("it", 1)], out[("it", 2)])
 
 
 def test_hs6_plumbing_kkt_3x3(oracle):
@@ -417,3 +443,37 @@ def test_rccl_single_rank_communicator():
     assert _rel(gb, ga) < 1e-9 and abs(fa - fb) <= 1e-9 * abs(fa)
     a.close()
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE configs
+
+def test_config_aug2dc_like_full_size(oracle):
+    """BASELINE configs[3] stand-in (AUG2DC-like, N = 100: n = 20200, m = 10000; NOT SIF-verified, parity unpinned
+    against CUTEst): hundreds of Krylov iterations on an ill-conditioned incidence matrix; same iteration counts as
+    the C restatement, grad(phi) equal to 1e-7 (rounding differences accumulate over ~10^3 iterations)."""
+    qp = problems.aug2dc_like(N=100)
+    assert (qp.n, qp.m) == (20200, 10000)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=SE)
+    gx, ys = np.empty(qp.n), np.empty(qp.m)
+    fx, rc = dev.objgrad(qp.x, gx=gx, ys=ys)
+    o = oracle.qp_objgrad(qp, qp.x, 1e3, 1.0, SE)
+    assert rc == o["rc"]
+    its = (dev.stats[0].niter, dev.stats[1].niter)
+    its_o = (o["stats"][0].niter, o["stats"][1].niter)
+    assert abs(its[0] - its_o[0]) <= 2 and abs(its[1] - its_o[1]) <= 2 and its[0] > 50
+    assert _rel(gx, o["gx"]) < 1e-6 and _rel(ys, o["ys"]) < 1e-6
+    dev.close()
+
+
+def test_config_random_eqqp_cfg2_size(oracle):
+    """BASELINE configs[1]: random sparse eq-QP n = 1e5, m = 1e4, nnz = 1e6 (columns spread over all of n)."""
+    qp = problems.random_eqqp()
+    assert (qp.n, qp.m, qp.nnz) == (100_000, 10_000, 1_000_000)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+    gx = np.empty(qp.n)
+    fx, rc = dev.objgrad(qp.x, gx=gx)
+    o = oracle.qp_objgrad(qp, qp.x, 1e3, 1.0, 0.0)
+    assert rc == o["rc"] == 0
+    assert (dev.stats[0].niter, dev.stats[1].niter) == (o["stats"][0].niter, o["stats"][1].niter)
+    assert _rel(gx, o["gx"]) < 1e-8 and abs(fx - o["fx"]) <= 1e-8 * abs(o["fx"])
+    dev.close()
