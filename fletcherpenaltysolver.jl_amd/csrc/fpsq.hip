@@ -42,6 +42,14 @@ struct EventPair {
   hipEvent_t a, b;
 };
 
+struct DevRgcs {
+  bool ok = false;
+  RgcsView view{};
+  double* vals = nullptr;
+  int32_t* vperm = nullptr;  // vals[t] = A.vals[vperm[t]]
+  int64_t nnz = 0;
+};
+
 // ------------------------------------------------------------------ communicators (row-sharded A)
 // Collectives are enqueued on the solver's stream; every rank issues the same sequence (the Krylov loop takes
 // its exit decision from replicated, bitwise-identical device state at fixed iteration boundaries).
@@ -156,6 +164,7 @@ struct fpsq_solver_s {
   std::string err;
 
   DevCsr A, AT;
+  DevRgcs RA;                   // column-sorted row-group copy of A used by the A product when eligible
   int32_t* permT = nullptr;     // AT.vals[t] = A.vals[permT[t]]
   int64_t nnz_in = 0;           // length of the caller's value array (COO entries or CSR nnz)
   int32_t* in_perm = nullptr;   // COO path: sorted position -> caller index
@@ -292,6 +301,93 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
   return 0;
 }
 
+// Row-group column-sorted copy of A (see k_spmv_rgcs).  Not built (ok = false) when a group spans >= 2^21 columns.
+int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
+  const int64_t nnz = (int64_t)H.colind.size();
+  D.ok = false;
+  if (nnz == 0 || h->opt.jac_format == 1) return 0;
+  std::vector<int32_t> grow{0}, gent{0}, gcmin, gtp{0};
+  std::vector<uint32_t> pidx(nnz);
+  std::vector<int32_t> vperm(nnz);
+  std::vector<uint16_t> tptr;
+  std::vector<int32_t> ord, lrow, cntr, nxt;
+  int64_t r = 0;
+  while (r < H.nrows) {
+    int64_t r1 = r, nz = 0;
+    while (r1 < H.nrows && r1 - r < kRgcsMaxRows) {
+      const int64_t len = H.rowptr[r1 + 1] - H.rowptr[r1];
+      if (nz + len > kRgcsGroupNnz && r1 > r) break;
+      nz += len;
+      ++r1;
+    }
+    const int R = (int)(r1 - r);
+    const int e0 = H.rowptr[r], e1 = H.rowptr[r1], cnt = e1 - e0;
+    int cmin = INT32_MAX, cmax = -1;
+    for (int k = e0; k < e1; ++k) {
+      cmin = std::min(cmin, H.colind[k]);
+      cmax = std::max(cmax, H.colind[k]);
+    }
+    if (cnt == 0) cmin = cmax = 0;
+    if ((int64_t)cmax - cmin >= (1ll << kRgcsColBits)) return 0;  // not representable: keep CSR-stream
+    lrow.resize(cnt);
+    for (int rr = 0; rr < R; ++rr)
+      for (int k = H.rowptr[r + rr]; k < H.rowptr[r + rr + 1]; ++k) lrow[k - e0] = rr;
+    ord.resize(cnt);
+    for (int k = 0; k < cnt; ++k) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return H.colind[e0 + a] < H.colind[e0 + b]; });
+    const int ntile = (cnt + kRgcsTile - 1) / kRgcsTile;
+    for (int t = 0; t < ntile; ++t) {
+      const int a = t * kRgcsTile, b = std::min(cnt, a + kRgcsTile);
+      cntr.assign(R + 1, 0);
+      for (int k = a; k < b; ++k) cntr[lrow[ord[k]] + 1]++;
+      for (int rr = 0; rr < R; ++rr) cntr[rr + 1] += cntr[rr];
+      for (int rr = 0; rr <= R; ++rr) tptr.push_back((uint16_t)cntr[rr]);
+      nxt.assign(cntr.begin(), cntr.end() - 1);
+      for (int k = a; k < b; ++k) {
+        const int src = ord[k];
+        const int slot = nxt[lrow[src]]++;
+        pidx[e0 + k] = ((uint32_t)slot << kRgcsColBits) | (uint32_t)(H.colind[e0 + src] - cmin);
+        vperm[e0 + k] = e0 + src;
+      }
+    }
+    if (ntile == 0)
+      for (int rr = 0; rr <= R; ++rr) tptr.push_back(0);
+    grow.push_back((int32_t)r1);
+    gent.push_back(e1);
+    gcmin.push_back(cmin);
+    gtp.push_back((int32_t)tptr.size());
+    r = r1;
+  }
+  tptr.push_back(0);
+  tptr.push_back(0);  // the kernel reads two uint16 at once
+  uint32_t* dp;
+  int32_t *d1, *d2, *d3, *d4;
+  uint16_t* d5;
+  if (int rc = dalloc(h, &dp, (size_t)nnz + 1)) return rc;
+  if (int rc = dalloc(h, &D.vals, (size_t)nnz + 1)) return rc;
+  if (int rc = dalloc(h, &D.vperm, (size_t)nnz)) return rc;
+  if (int rc = dalloc(h, &d1, grow.size())) return rc;
+  if (int rc = dalloc(h, &d2, gent.size())) return rc;
+  if (int rc = dalloc(h, &d3, gcmin.size())) return rc;
+  if (int rc = dalloc(h, &d4, gtp.size())) return rc;
+  if (int rc = dalloc(h, &d5, tptr.size() + 2)) return rc;
+  HIPCHK(h, hipMemcpy(dp, pidx.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemset(dp + nnz, 0, 4));
+  HIPCHK(h, hipMemset(D.vals + nnz, 0, 8));
+  HIPCHK(h, hipMemcpy(D.vperm, vperm.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(d1, grow.data(), grow.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(d2, gent.data(), gent.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(d3, gcmin.data(), gcmin.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(d4, gtp.data(), gtp.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(d5, tptr.data(), tptr.size() * 2, hipMemcpyHostToDevice));
+  D.view = RgcsView{dp, D.vals, d1, d2, d3, d4, d5, (int32_t)gcmin.size(), (int32_t)H.nrows};
+  D.nnz = nnz;
+  D.ok = true;
+  return 0;
+}
+
+inline int npart_A(fpsq_handle h) { return h->RA.ok ? h->RA.view.ng : h->A.nblk; }
+
 int alloc_workspaces(fpsq_handle h) {
   const size_t n = (size_t)h->n, m = (size_t)h->m;
   if (int rc = dalloc(h, &h->LP, 2 * n)) return rc;
@@ -305,7 +401,7 @@ int alloc_workspaces(fpsq_handle h) {
                    &h->Mr[0], &h->Mr[1], &h->Mw[0], &h->Mw[1], &h->Mx};
   for (auto p : mv)
     if (int rc = dalloc(h, p, m)) return rc;
-  h->npS = std::max(std::max(h->A.nblk, h->AT.nblk), kEwBlocksMax);
+  h->npS = std::max(std::max(std::max(h->A.nblk, h->AT.nblk), kEwBlocksMax), npart_A(h));
   if (int rc = dalloc(h, &h->pS, (size_t)h->npS * 2)) return rc;
   if (int rc = dalloc(h, &h->pS2, (size_t)h->npS * 2)) return rc;
   double** ev[] = {&h->pW[0], &h->pW[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1]};
@@ -321,6 +417,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   transpose_structure(HA, HT, perm);
   if (int rc = upload_csr(h, HA, h->A)) return rc;
   if (int rc = upload_csr(h, HT, h->AT)) return rc;
+  if (int rc = build_rgcs(h, HA, h->RA)) return rc;
   if (int rc = dalloc(h, &h->permT, perm.size())) return rc;
   if (!perm.empty()) HIPCHK(h, hipMemcpy(h->permT, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
   h->nnz = h->A.nnz;
@@ -331,7 +428,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   h->info.n = h->n;
   h->info.m = h->m;
   h->info.nnz = h->nnz;
-  h->info.spmv_a_blocks = h->A.nblk;
+  h->info.spmv_a_blocks = npart_A(h);
   h->info.spmv_at_blocks = h->AT.nblk;
   return 0;
 }
@@ -359,15 +456,22 @@ void prof_end(fpsq_handle h) {
 template <int NL>
 void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, double* yout, const LaneCtl* c0,
                  const LaneCtl* c1, double* partials) {
-  const DevCsr& M = tag == TAG_A ? h->A : h->AT;
-  const int per_xcd = (M.nblk + 7) / 8;
-  const dim3 grid(per_xcd * 8), block(kBlock);
+  const dim3 block(kBlock);
   prof_begin(h);
-  if (tag == TAG_A)
-    hipLaunchKernelGGL((k_spmv<NL, TAG_A>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials, per_xcd);
-  else
-    hipLaunchKernelGGL((k_spmv<NL, TAG_AT>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
+  if (tag == TAG_A && h->RA.ok) {
+    const int per_xcd = (h->RA.view.ng + 7) / 8;
+    hipLaunchKernelGGL((k_spmv_rgcs<NL>), dim3(per_xcd * 8), block, 0, h->stream, h->RA.view, x, yin, yout, c0, c1, partials,
                        per_xcd);
+  } else {
+    const DevCsr& M = tag == TAG_A ? h->A : h->AT;
+    const int per_xcd = (M.nblk + 7) / 8;
+    const dim3 grid(per_xcd * 8);
+    if (tag == TAG_A)
+      hipLaunchKernelGGL((k_spmv<NL, TAG_A>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials, per_xcd);
+    else
+      hipLaunchKernelGGL((k_spmv<NL, TAG_AT>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
+                         per_xcd);
+  }
   prof_end(h);
   h->launches++;
   h->spmv_launches++;
@@ -598,7 +702,7 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   const fpsq_options& o = h->opt;
   hipStream_t s = h->stream;
   const int gn = ew_grid(n), gm = ew_grid(m);
-  const int nbA = h->A.nblk, nbT = h->AT.nblk;
+  const int nbA = npart_A(h);
   double* LP = h->LP;
   double* SP = h->SP;
   bool any_lsqr = false;
@@ -1200,6 +1304,8 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
       HIPCHK(h, hipMemcpyAsync(h->A.vals, vals, (size_t)h->nnz * 8, hipMemcpyDefault, s));
     }
     hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->A.vals, h->permT, h->AT.vals, h->nnz);
+    if (h->RA.ok)
+      hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->A.vals, h->RA.vperm, h->RA.vals, h->nnz);
   }
   HIPCHK(h, hipStreamSynchronize(s));
   h->have_values = true;

@@ -230,6 +230,158 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------ RGCS product
+//
+// RGCS = Row Groups, Column-Sorted.  The CSR-stream kernel gathers x in ROW order: for a wide matrix whose rows spread
+// over thousands of columns (the constraint Jacobian: 100 nonzeros in an 8192-column window) the 64 gathers of one
+// wave instruction land in 64 different 128-byte lines and the L2->L1 line traffic, not HBM, bounds the product
+// (rocSPARSE's csrmv hits the same wall: tools/spmv_bench.hip).  Here the entries of a group of consecutive rows
+// (<= kRgcsGroupNnz nonzeros, <= kRgcsMaxRows rows) are stored sorted by COLUMN and cut into tiles of kRgcsTile
+// entries, so consecutive lanes gather neighbouring columns (~10 lines per wave instruction).  Each entry carries, packed
+// with its group-relative column in one 32-bit word (12 B/nnz like CSR), its slot in the tile's ROW-major order:
+// products are scattered to LDS by slot and every row's segment is reduced exactly as in the CSR-stream kernel;
+// the per-row sums accumulate in registers across the tiles of the group.  Deterministic, no atomics.
+constexpr int kRgcsTile = 2048;
+constexpr int kRgcsColBits = 21;     // group-relative column < 2^21, slot < 2^11
+constexpr int kRgcsMaxPass = 4;      // rows per group <= kRgcsMaxPass * kBlock
+constexpr int kRgcsGroupNnz = 12800;
+constexpr int kRgcsMaxRows = 128;
+
+struct RgcsView {
+  const uint32_t* pidx;   // (slot << kRgcsColBits) | (col - gcmin[g])
+  const double* vals;     // same (column-sorted) order
+  const int32_t* grow;    // ng + 1 first rows
+  const int32_t* gent;    // ng + 1 first entries
+  const int32_t* gcmin;   // ng smallest column of the group
+  const int32_t* gtp;     // ng offsets into tptr
+  const uint16_t* tptr;   // per tile: R + 1 row-segment boundaries in slot space
+  int32_t ng;
+  int32_t nrows;
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
+                                                      double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
+                                                      double* partials, int grp_per_xcd) {
+  const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
+  if (g >= M.ng) return;
+  const LaneCtl* c[2] = {ctl0, ctl1};
+  double ca[NL], cb[NL];
+  bool act[NL];
+  bool any = false;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    act[l] = !(c[l]->done | c[l]->skip);
+    ca[l] = c[l]->ca;
+    cb[l] = c[l]->cb;
+    any |= act[l];
+  }
+  if (!any) return;
+  __shared__ double prod[kRgcsTile * NL];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int r0 = M.grow[g], R = M.grow[g + 1] - r0;
+  const int e0 = M.gent[g], e1 = M.gent[g + 1];
+  const int cmin = M.gcmin[g];
+  const uint16_t* tp = M.tptr + M.gtp[g];
+  int G = 1;
+  while (G < 64 && G * 2 * R <= kBlock) G <<= 1;
+  const int rpp = kBlock / G, gid = tid / G, gl = tid % G;
+  double acc[kRgcsMaxPass][NL];
+#pragma unroll
+  for (int p = 0; p < kRgcsMaxPass; ++p)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[p][l] = 0.0;
+  constexpr int kPer = kRgcsTile / kBlock;
+  uint32_t pk[kPer];
+  double v[kPer];
+  uint32_t traw[kRgcsMaxPass];  // this tile's LDS segment [a, b) of each of my rows: two uint16 in one raw dword
+  // everything the next tile needs from global memory, issued together and left untouched until it is consumed
+  auto fetch = [&](int base, int tile) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = base + tid + k * kBlock;
+      const int ii = i < e1 ? i : e0;
+      pk[k] = M.pidx[ii];
+      v[k] = M.vals[ii];
+    }
+    const uint16_t* tpt = tp + (size_t)tile * (R + 1);
+#pragma unroll
+    for (int p = 0; p < kRgcsMaxPass; ++p) {
+      const int rr = p * rpp + gid;
+      const int rq = rr < R ? rr : 0;
+      __builtin_memcpy(&traw[p], tpt + rq, 4);
+    }
+  };
+  fetch(e0, 0);
+  int tile = 0;
+  for (int base = e0; base < e1; base += kRgcsTile, ++tile) {
+    int sa[kRgcsMaxPass], sb[kRgcsMaxPass];
+    {
+      double2 xv[kPer];
+      uint32_t pq[kPer];
+      double vq[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const bool ok = base + tid + k * kBlock < e1;  // out-of-range lanes park a zero in an unused slot
+        pq[k] = ok ? pk[k] : ((uint32_t)(tid + k * kBlock) << kRgcsColBits);
+        vq[k] = ok ? v[k] : 0.0;
+        const int col = cmin + (int)(pq[k] & ((1u << kRgcsColBits) - 1));
+        if (NL == 1) xv[k].x = x[col];
+        else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
+      }
+#pragma unroll
+      for (int p = 0; p < kRgcsMaxPass; ++p) {
+        const bool valid = p * rpp + gid < R;
+        sa[p] = (int)(traw[p] & 0xffffu);
+        sb[p] = valid ? (int)(traw[p] >> 16) : sa[p];
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const int slot = (int)(pq[k] >> kRgcsColBits);
+        if (NL == 1) prod[slot] = vq[k] * xv[k].x;
+        else *reinterpret_cast<double2*>(prod + 2 * slot) = make_double2(vq[k] * xv[k].x, vq[k] * xv[k].y);
+      }
+    }
+    if (base + kRgcsTile < e1) fetch(base + kRgcsTile, tile + 1);
+    lds_barrier();
+#pragma unroll
+    for (int p = 0; p < kRgcsMaxPass; ++p) row_segment_sum<NL>(prod, sa[p] + gl, sb[p], G, acc[p]);
+    lds_barrier();
+  }
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+#pragma unroll
+  for (int p = 0; p < kRgcsMaxPass; ++p) {
+    for (int off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[p][l] += __shfl_down(acc[p][l], off, 64);
+    }
+    const int rr = p * rpp + gid;
+    if (rr < R && gl == 0) {
+      const size_t row = (size_t)(r0 + rr);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        if (act[l]) {
+          const double o = ca[l] * acc[p][l] + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0);
+          yout[row * NL + l] = o;
+          sq[l] += o * o;
+        }
+      }
+    }
+  }
+  if (partials != nullptr) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double t = block_sum(sq[l], red);
+      if (tid == 0) partials[(size_t)l * M.ng + g] = t;
+    }
+  }
+}
+
 // vals_out[t] = vals_in[perm[t]]  (refresh of the A' copy when the Jacobian values change)
 __global__ __launch_bounds__(kBlock) void k_gather(const double* __restrict__ in, const int32_t* __restrict__ perm,
                                                    double* __restrict__ out, int64_t n) {

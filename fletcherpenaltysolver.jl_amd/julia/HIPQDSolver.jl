@@ -20,7 +20,7 @@ mutable struct FpsqOptions  # fpsq_options (same field order as include/fpsq.h)
   ln_atol::Float64; ln_rtol::Float64; ln_btol::Float64; ln_conlim::Float64; ln_itmax::Int64
   ne_atol::Float64; ne_rtol::Float64; ne_etol::Float64; ne_itmax::Int64; ne_conlim::Float64
   ls_axtol::Float64; ls_btol::Float64; ls_etol::Float64; ls_conlim::Float64
-  fuse_two_rhs::Int32; lookahead::Int32; device::Int32; reserved::Int32
+  fuse_two_rhs::Int32; lookahead::Int32; device::Int32; jac_format::Int32
   FpsqOptions() = new()
 end
 

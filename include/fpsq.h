@@ -83,7 +83,8 @@ typedef struct {
                             product instead of two SpMVs; results per system are identical to the unfused run */
   int32_t lookahead;     /* Krylov iterations the host may enqueue ahead of the device's progress word */
   int32_t device;        /* HIP device ordinal */
-  int32_t reserved;
+  int32_t jac_format;    /* storage of A for the A product: 0 = auto (column-sorted row groups when every group spans
+                            < 2^21 columns, else CSR), 1 = CSR only */
 } fpsq_options;
 
 /* defaults of src/solve_two_systems_struct.jl:99-115 for an (n, m) problem; fuse_two_rhs = 1 */
