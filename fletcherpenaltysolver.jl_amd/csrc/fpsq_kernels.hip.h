@@ -99,6 +99,46 @@ __device__ __forceinline__ void row_segment_sum(const double* prod, int first, i
   }
 }
 
+// Row epilogue shared by the product kernels: out = ca * acc + cb * yin for the active lanes, squared-norm
+// accumulation.  The yin values of both lanes are fetched with one (16-byte when NL = 2) load before any arithmetic
+// and written back with one store when both lanes are active -- a per-lane load/use/store chain costs two dependent
+// memory round trips per row.
+template <int NL>
+__device__ __forceinline__ void row_epilogue(size_t row, const double* acc, const double* ca, const double* cb,
+                                             const bool* act, const double* yin, double* yout, double* sq) {
+  double yv[NL];
+  bool need = false;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    yv[l] = 0.0;
+    need |= act[l] && cb[l] != 0.0;
+  }
+  if (need) {
+    if (NL == 2) {
+      const double2 t = *reinterpret_cast<const double2*>(yin + row * 2);
+      yv[0] = t.x;
+      yv[NL - 1] = t.y;
+    } else {
+      yv[0] = yin[row];
+    }
+  }
+  double o[NL];
+  bool all = true;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    o[l] = ca[l] * acc[l] + (cb[l] != 0.0 ? cb[l] * yv[l] : 0.0);
+    all &= act[l];
+    if (act[l]) sq[l] += o[l] * o[l];
+  }
+  if (NL == 2 && all) {
+    *reinterpret_cast<double2*>(yout + row * 2) = make_double2(o[0], o[NL - 1]);
+  } else {
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+      if (act[l]) yout[row * NL + l] = o[l];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ SpMV / SpMM
 //
 // out[r][l] = ca_l * sum_k vals[k] * x[colind[k]][l] + cb_l * yin[r][l],  partial[l][blk] = sum_r out[r][l]^2
@@ -163,6 +203,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     // phase 1: coalesced stream of the block's nonzeros -> products in LDS.  Every lane issues all of its loads and
     // all of its gathers unconditionally (out-of-range lanes use column 0 with value 0 and park a zero in an unused
     // slot): a per-element branch would make hipcc wait for each gather before issuing the next one.
+    // (the row-segment boundaries of phase 2 are loaded here too, ahead of the barrier that would expose their latency)
+    int G = 1;
+    while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
+    const int rows_per_pass = kBlock / G;
+    const int g = tid / G, gl = tid % G;
+    const int rq0 = g < nr ? g : 0;
+    const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
     double v[kPer];
@@ -190,10 +237,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     }
     __syncthreads();
     // phase 2: G lanes per row
-    int G = 1;
-    while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
-    const int rows_per_pass = kBlock / G;
-    const int g = tid / G, gl = tid % G;
     for (int base = 0; base < nr; base += rows_per_pass) {
       const int rr = base + g;
       const bool valid = rr < nr;
@@ -201,24 +244,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] = 0.0;
       if (valid) {
-        const int a = A.rowptr[r0 + rr] - s, b = A.rowptr[r0 + rr + 1] - s;
+        const int a = (base == 0 ? seg_a0 : A.rowptr[r0 + rr]) - s, b = (base == 0 ? seg_b0 : A.rowptr[r0 + rr + 1]) - s;
         row_segment_sum<NL>(prod, a + gl, b, G, acc);
       }
       for (int off = G >> 1; off > 0; off >>= 1) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] += __shfl_down(acc[l], off, 64);
       }
-      if (valid && gl == 0) {
-        const size_t row = (size_t)(r0 + rr);
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-          if (act[l]) {
-            const double o = ca[l] * acc[l] + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0);
-            yout[row * NL + l] = o;
-            sq[l] += o * o;
-          }
-        }
-      }
+      if (valid && gl == 0) row_epilogue<NL>((size_t)(r0 + rr), acc, ca, cb, act, yin, yout, sq);
     }
   }
   if (partials != nullptr) {
@@ -361,17 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       for (int l = 0; l < NL; ++l) acc[p][l] += __shfl_down(acc[p][l], off, 64);
     }
     const int rr = p * rpp + gid;
-    if (rr < R && gl == 0) {
-      const size_t row = (size_t)(r0 + rr);
-#pragma unroll
-      for (int l = 0; l < NL; ++l) {
-        if (act[l]) {
-          const double o = ca[l] * acc[p][l] + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0);
-          yout[row * NL + l] = o;
-          sq[l] += o * o;
-        }
-      }
-    }
+    if (rr < R && gl == 0) row_epilogue<NL>((size_t)(r0 + rr), acc[p], ca, cb, act, yin, yout, sq);
   }
   if (partials != nullptr) {
 #pragma unroll

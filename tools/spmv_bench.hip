@@ -291,11 +291,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_ntgather(CsrView A, const doubl
 // Entries of a row group are stored sorted by COLUMN (so the 64 gathers of a wave instruction fall in a handful
 // of cache lines) and carry, packed with the group-relative column, their slot in the tile's ROW-major order, so
 // the products land in LDS grouped by row and are reduced exactly like in the CSR-stream kernel.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void p_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int kTile = 2048;
 constexpr int kColBits = 21;
 constexpr int kMaxPass = 4;
-struct RgcsView {
+struct PRgcsView {
   const uint32_t* pidx; const double* vals;
   const int32_t* grow; const int32_t* gent; const int32_t* gcmin; const int32_t* gtp; const uint16_t* tptr;
   int ng; int nrows;
@@ -308,7 +308,7 @@ struct TileRegs {   // everything one tile needs from global memory, kept raw un
 };
 
 template <int NL, int ABL = 0>
-__global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin, double* yout,
+__global__ __launch_bounds__(kBlock) void k_spmv_rgcs_proto(PRgcsView M, const double* __restrict__ x, const double* yin, double* yout,
                                                       const LaneCtl* ctl0, const LaneCtl* ctl1, double* partials, int grp_per_xcd) {
   const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
   if (g >= M.ng) return;
@@ -371,13 +371,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       if (NL == 1) prod[slot] = vq[k] * xv[k].x;
       else *reinterpret_cast<double2*>(prod + 2 * slot) = make_double2(vq[k] * xv[k].x, vq[k] * xv[k].y);
     }
-    lds_barrier();
+    p_lds_barrier();
 #pragma unroll
     for (int p = 0; p < kMaxPass; ++p) {
       const int a = (ABL & 4) ? tid : sa[p], b = (ABL & 4) ? tid + (p == 0) : sb[p];
       row_segment_sum<NL>(prod, a + gl, b, G, acc[p]);
     }
-    lds_barrier();
+    p_lds_barrier();
   };
   TileRegs<NL> RA, RB;
   fetch(RA, e0, 0);
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   for (int l = 0; l < NL; ++l) { const double t = block_sum(sq[l], red); if (tid == 0) partials[(size_t)l * M.ng + g] = t; }
 }
 
-struct RgcsDev { RgcsView view; };
-static RgcsDev build_rgcs(const Host& H, int group_nnz, int max_rows) {
+struct PRgcsDev { PRgcsView view; };
+static PRgcsDev build_rgcs(const Host& H, int group_nnz, int max_rows) {
   std::vector<int32_t> grow{0}, gent{0}, gcmin, gtp{0};
   std::vector<uint32_t> pidx(H.ci.size()); std::vector<double> vals(H.ci.size()); std::vector<uint16_t> tptr;
   int64_t r = 0;
@@ -440,7 +440,7 @@ static RgcsDev build_rgcs(const Host& H, int group_nnz, int max_rows) {
     grow.push_back((int32_t)r1); gent.push_back(e1); gcmin.push_back(cmin); gtp.push_back((int32_t)tptr.size());
     r = r1;
   }
-  RgcsDev D; RgcsView& V = D.view; V.ng = gcmin.size(); V.nrows = H.nr;
+  PRgcsDev D; PRgcsView& V = D.view; V.ng = gcmin.size(); V.nrows = H.nr;
   uint32_t* dp; double* dv; int32_t *d1, *d2, *d3, *d4; uint16_t* d5;
   CK(hipMalloc(&dp, pidx.size() * 4)); CK(hipMalloc(&dv, vals.size() * 8)); CK(hipMalloc(&d1, grow.size() * 4)); CK(hipMalloc(&d2, gent.size() * 4));
   CK(hipMalloc(&d3, gcmin.size() * 4)); CK(hipMalloc(&d4, gtp.size() * 4)); CK(hipMalloc(&d5, tptr.size() * 2 + 16));
@@ -473,9 +473,9 @@ __global__ __launch_bounds__(kBlock) void k_probe(const uint32_t* __restrict__ p
     if (FEAT & 1) {
 #pragma unroll
       for (int k = 0; k < kPer; ++k) *reinterpret_cast<double2*>(prod + 2 * (tid + k * kBlock)) = make_double2(v[k] * (double)pk[k], v[k]);
-      lds_barrier();
+      p_lds_barrier();
       acc += prod[2 * ((tid * 7) & (kTile - 1))];
-      lds_barrier();
+      p_lds_barrier();
     } else {
 #pragma unroll
       for (int k = 0; k < kPer; ++k) acc += v[k] * (double)pk[k];
@@ -596,20 +596,20 @@ int main(int argc, char** argv) {
   }
 
 #define ADD_RGCS(NLv, GNA, RA, GNT, RT)                                                                                   \
-  { RgcsDev ra = build_rgcs(A, GNA, RA), rt = build_rgcs(T, GNT, RT);                                                     \
+  { PRgcsDev ra = build_rgcs(A, GNA, RA), rt = build_rgcs(T, GNT, RT);                                                     \
     Variant v; v.name = "rgcs NL=" #NLv " A(" #GNA "," #RA ") AT(" #GNT "," #RT ")"; v.nl = NLv;                         \
     int pa = (ra.view.ng + 7) / 8, pt = (rt.view.ng + 7) / 8;                                                             \
-    v.launchA = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv>), dim3(pa * 8), dim3(kBlock), 0, 0, ra.view, xn, ym, ym, ctl, ctl, part, pa); }; \
-    v.launchT = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv>), dim3(pt * 8), dim3(kBlock), 0, 0, rt.view, xm, yn, yn, ctl, ctl, part, pt); }; \
+    v.launchA = [=]() { hipLaunchKernelGGL((k_spmv_rgcs_proto<NLv>), dim3(pa * 8), dim3(kBlock), 0, 0, ra.view, xn, ym, ym, ctl, ctl, part, pa); }; \
+    v.launchT = [=]() { hipLaunchKernelGGL((k_spmv_rgcs_proto<NLv>), dim3(pt * 8), dim3(kBlock), 0, 0, rt.view, xm, yn, yn, ctl, ctl, part, pt); }; \
     vs.push_back(v); }
   ADD_RGCS(1, 6400, 64, 8192, 1024) ADD_RGCS(2, 6400, 64, 8192, 1024) ADD_RGCS(2, 12800, 128, 4096, 512) ADD_RGCS(2, 3200, 32, 2048, 256)
   ADD_RGCS(2, 25600, 256, 16384, 1024)
 
 #define ADD_RGCS_ABL(NLv, ABLv, GNA, RA)                                                                                  \
-  { RgcsDev ra = build_rgcs(A, GNA, RA);                                                                                  \
+  { PRgcsDev ra = build_rgcs(A, GNA, RA);                                                                                  \
     Variant v; v.name = "rgcs ABL=" #ABLv " NL=" #NLv " A(" #GNA "," #RA ")"; v.nl = NLv;                                 \
     int pa = (ra.view.ng + 7) / 8, pt = (dT.nblk + 7) / 8;                                                                \
-    v.launchA = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv, ABLv>), dim3(pa * 8), dim3(kBlock), 0, 0, ra.view, xn, ym, ym, ctl, ctl, part, pa); }; \
+    v.launchA = [=]() { hipLaunchKernelGGL((k_spmv_rgcs_proto<NLv, ABLv>), dim3(pa * 8), dim3(kBlock), 0, 0, ra.view, xn, ym, ym, ctl, ctl, part, pa); }; \
     v.launchT = [=]() { hipLaunchKernelGGL((k_spmv<NLv, 1>), dim3(pt * 8), dim3(kBlock), 0, 0, dT.view, xm, yn, yn, ctl, ctl, part, pt); }; \
     vs.push_back(v); }
   ADD_RGCS_ABL(2, 31, 12800, 128) ADD_RGCS_ABL(2, 63, 12800, 128) ADD_RGCS_ABL(2, 47, 12800, 128) ADD_RGCS_ABL(2, 63, 3200, 32) ADD_RGCS_ABL(2, 63, 51200, 512)
@@ -625,11 +625,11 @@ int main(int argc, char** argv) {
   ADD_PROBE(0, 1) ADD_PROBE(0, 4) ADD_PROBE(1, 1) ADD_PROBE(1, 4) ADD_PROBE(2, 1) ADD_PROBE(2, 4) ADD_PROBE(3, 4) ADD_PROBE(3, 1) ADD_PROBE(0, 19) ADD_PROBE(1, 19)
 
 #define ADD_RGCS_ABL_T(NLv, ABLv, GNT, RT)                                                                                \
-  { RgcsDev rt = build_rgcs(T, GNT, RT);                                                                                  \
+  { PRgcsDev rt = build_rgcs(T, GNT, RT);                                                                                  \
     Variant v; v.name = "rgcsT ABL=" #ABLv " NL=" #NLv " AT(" #GNT "," #RT ")"; v.nl = NLv;                               \
     int pa = (dA.nblk + 7) / 8, pt = (rt.view.ng + 7) / 8;                                                                \
     v.launchA = [=]() { hipLaunchKernelGGL((k_spmv<NLv, 0>), dim3(pa * 8), dim3(kBlock), 0, 0, dA.view, xn, ym, ym, ctl, ctl, part, pa); }; \
-    v.launchT = [=]() { hipLaunchKernelGGL((k_spmv_rgcs<NLv, ABLv>), dim3(pt * 8), dim3(kBlock), 0, 0, rt.view, xm, yn, yn, ctl, ctl, part, pt); }; \
+    v.launchT = [=]() { hipLaunchKernelGGL((k_spmv_rgcs_proto<NLv, ABLv>), dim3(pt * 8), dim3(kBlock), 0, 0, rt.view, xm, yn, yn, ctl, ctl, part, pt); }; \
     vs.push_back(v); }
   ADD_RGCS_ABL_T(2, 8, 2048, 256) ADD_RGCS_ABL_T(2, 9, 2048, 256) ADD_RGCS_ABL_T(2, 10, 2048, 256) ADD_RGCS_ABL_T(2, 12, 2048, 256) ADD_RGCS_ABL_T(2, 15, 2048, 256)
   ADD_RGCS_ABL_T(2, 8, 8192, 1024) ADD_RGCS_ABL_T(2, 12, 8192, 1024) ADD_RGCS_ABL_T(2, 15, 8192, 1024) ADD_RGCS_ABL_T(1, 8, 8192, 1024)
