@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--workload", default="pde-control-like n=1e6 m=1e5 nnz=1e7", choices=list(WORKLOADS))
     ap.add_argument("--delta", type=float, default=0.0, help="regularisation; 0 = first outer iteration (algo.jl:46)")
     ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--lookahead", type=int, default=0, help="override fpsq_options.lookahead (0 = library default)")
     ap.add_argument("--cpu-evals", type=int, default=6, help="evaluations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--parallel", default="auto", choices=["auto", "shard", "replicas"],
                     help="N > 1: 'shard' = rows of A sharded over the ranks, RCCL all-reduce per Krylov iteration "
@@ -95,7 +96,8 @@ def main():
         model = DeviceEqQP(local, sigma=sigma, rho=rho, delta=args.delta, device=local_rank,
                            fuse_two_rhs=args.fuse, comm=("rccl", world, rank, bytes(ident.cpu().numpy())))
     else:
-        model = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=args.delta, device=local_rank, fuse_two_rhs=args.fuse)
+        extra = {"lookahead": args.lookahead} if args.lookahead > 0 else {}
+        model = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=args.delta, device=local_rank, fuse_two_rhs=args.fuse, **extra)
 
     # distinct evaluation points, resident in HBM (sharded: the same replicated x on every rank; replicas: each
     # rank evaluates its own sequence)
@@ -163,12 +165,21 @@ def main():
     achieved = nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "fpsq::k_spmv (CSR-stream SpMV/SpMM + fused axpby + norm partials)",
+                "kernel": "fpsq::k_spmv_rgcs (A) + fpsq::k_spmv (A'): SpMV/SpMM with fused axpby + norm partials",
                 "productive_launches_per_eval": productive / K, "launches_per_eval": launches / K,
                 "avg_launch_us": round(1e3 * t_ms / max(launches, 1), 2),
                 "avg_productive_launch_us": round(1e3 * t_ms / max(productive, 1), 2),
                 "algorithmic_bytes_per_productive_launch": round(nbytes / max(productive, 1)),
                 "spmv_share_of_eval_time": round(t_ms / tot_ms, 3) if tot_ms > 0 else None}
+
+    # HBM traffic per productive launch from the committed PMC passes (profiles/: bench.py cannot run rocprofv3 on itself)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1:
+            roofline["traffic"] = pmc["traffic_bytes_per_productive_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    except (OSError, KeyError, ValueError):
+        pass
 
     out = {
         "metric": "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "evals/s",
