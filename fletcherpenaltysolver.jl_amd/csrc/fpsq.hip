@@ -35,7 +35,9 @@ struct DevCsr {
   double* vals = nullptr;
   int32_t* rowblk = nullptr;
   int32_t nblk = 0;
-  CsrView view() const { return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows}; }
+  uint16_t* col16 = nullptr;   // compressed columns (see CsrView), null when not representable
+  int32_t* colbase = nullptr;
+  CsrView view() const { return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows, col16, colbase}; }
 };
 
 struct EventPair {
@@ -298,6 +300,30 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
   if (!H.colind.empty())
     HIPCHK(h, hipMemcpy(D.colind, H.colind.data(), H.colind.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(D.rowblk, rb.data(), rb.size() * 4, hipMemcpyHostToDevice));
+  // 16-bit block-relative columns when every row block spans < 65536 columns
+  if (h->opt.jac_format != 1 && D.nnz > 0) {
+    std::vector<int32_t> base(D.nblk, 0);
+    std::vector<uint16_t> c16(D.nnz + 1, 0);
+    bool ok = true;
+    for (int b = 0; b < D.nblk && ok; ++b) {
+      const int s = H.rowptr[rb[b]], e = H.rowptr[rb[b + 1]];
+      int lo = INT32_MAX, hi = -1;
+      for (int k = s; k < e; ++k) {
+        lo = std::min(lo, H.colind[k]);
+        hi = std::max(hi, H.colind[k]);
+      }
+      if (e == s) lo = hi = 0;
+      if (hi - lo > 65535) ok = false;
+      base[b] = lo;
+      for (int k = s; k < e && ok; ++k) c16[k] = (uint16_t)(H.colind[k] - lo);
+    }
+    if (ok) {
+      if (int rc = dalloc(h, &D.col16, c16.size())) return rc;
+      if (int rc = dalloc(h, &D.colbase, base.size())) return rc;
+      HIPCHK(h, hipMemcpy(D.col16, c16.data(), c16.size() * 2, hipMemcpyHostToDevice));
+      HIPCHK(h, hipMemcpy(D.colbase, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
   return 0;
 }
 
@@ -466,8 +492,14 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
     const dim3 grid(per_xcd * 8);
-    if (tag == TAG_A)
+    if (tag == TAG_A && M.col16)
+      hipLaunchKernelGGL((k_spmv<NL, TAG_A, true>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
+                         per_xcd);
+    else if (tag == TAG_A)
       hipLaunchKernelGGL((k_spmv<NL, TAG_A>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials, per_xcd);
+    else if (M.col16)
+      hipLaunchKernelGGL((k_spmv<NL, TAG_AT, true>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
+                         per_xcd);
     else
       hipLaunchKernelGGL((k_spmv<NL, TAG_AT>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
                          per_xcd);

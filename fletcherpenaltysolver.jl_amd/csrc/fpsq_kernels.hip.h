@@ -34,6 +34,10 @@ struct CsrView {
   const int32_t* rowblk;  // nblk + 1 row boundaries; a block has <= kSpmvNnz nonzeros unless it is ONE long row
   int32_t nblk;
   int32_t nrows;
+  // optional compressed column indices: col = colbase[block] + col16[k] (built when every row block spans < 65536
+  // columns -- always the case for A' of a banded Jacobian); halves the index stream of the product
+  const uint16_t* col16;
+  const int32_t* colbase;
 };
 
 // ------------------------------------------------------------------------------------------------ reductions
@@ -52,6 +56,28 @@ __device__ __forceinline__ double block_sum(double v, double* red /* >= 4 double
   if (lane == 0) red[w] = v;
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// hold every wave until its outstanding global loads/stores (prefetched tiles, the epilogue's stores) are acknowledged.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Workgroup sums of NL per-thread values with ONE LDS-only barrier; totals valid in thread 0 (fixed order).
+// `red` holds 4 * NL doubles and must not be in use by other waves when this is entered.
+template <int NL>
+__device__ __forceinline__ void block_sum_lanes(double* v, double* red) {
+#pragma unroll
+  for (int l = 0; l < NL; ++l) v[l] = wave_sum(v[l]);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) red[w * NL + l] = v[l];
+  }
+  lds_barrier();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) v[l] = (red[l] + red[NL + l]) + (red[2 * NL + l] + red[3 * NL + l]);
+  }
 }
 
 // Deterministic sum of a partials array by ONE workgroup (used by the scalar kernels). Valid in thread 0.
@@ -149,7 +175,7 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
 // chosen from the block's row count: ~100-nnz rows of A get 8 lanes each, ~10-nnz rows of A' one lane each).
 // blockIdx is remapped so that each XCD walks a contiguous eighth of the matrix: its private L2 then caches one
 // slice of x instead of all of it.  Summation order is a pure function of the sparsity => reproducible.
-template <int NL, int TAG>
+template <int NL, int TAG, bool IDX16 = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                  double* partials, int blk_per_xcd) {
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     if (!any) return;
   }
   __shared__ double prod[kSpmvNnz * NL];
-  __shared__ double red[4];
+  __shared__ double red[4 * NL];
   const int tid = threadIdx.x;
   const int r0 = A.rowblk[L], r1 = A.rowblk[L + 1];
   const int s = A.rowptr[r0], e = A.rowptr[r1];
@@ -184,8 +210,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    const int cbase = IDX16 ? A.colbase[L] : 0;
     for (int i = s + tid; i < e; i += kBlock) {
-      const int c = A.colind[i];
+      const int c = IDX16 ? cbase + (int)A.col16[i] : A.colind[i];
       const double v = A.vals[i];
 #pragma unroll
       for (int l = 0; l < NL; ++l) acc[l] += v * x[(size_t)c * NL + l];
@@ -213,12 +240,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
     double v[kPer];
+    const int cbase = IDX16 ? A.colbase[L] : 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int i = s + tid + k * kBlock;
       const bool ok = i < e;
       const int ii = ok ? i : s;
-      cidx[k] = A.colind[ii];
+      cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
       v[k] = ok ? A.vals[ii] : 0.0;
     }
     if (NL == 1) {
@@ -235,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
       for (int k = 0; k < kPer; ++k)
         *reinterpret_cast<double2*>(prod + 2 * (tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
     }
-    __syncthreads();
+    lds_barrier();
     // phase 2: G lanes per row
     for (int base = 0; base < nr; base += rows_per_pass) {
       const int rr = base + g;
@@ -255,10 +283,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     }
   }
   if (partials != nullptr) {
+    block_sum_lanes<NL>(sq, red);
+    if (tid == 0) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      const double t = block_sum(sq[l], red);
-      if (tid == 0) partials[(size_t)l * A.nblk + L] = t;
+      for (int l = 0; l < NL; ++l) partials[(size_t)l * A.nblk + L] = sq[l];
     }
   }
 }
@@ -292,8 +320,6 @@ struct RgcsView {
   int32_t nrows;
 };
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <int NL>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   }
   if (!any) return;
   __shared__ double prod[kRgcsTile * NL];
-  __shared__ double red[4];
+  __shared__ double red[4 * NL];
   const int tid = threadIdx.x;
   const int r0 = M.grow[g], R = M.grow[g + 1] - r0;
   const int e0 = M.gent[g], e1 = M.gent[g + 1];
@@ -397,10 +423,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     if (rr < R && gl == 0) row_epilogue<NL>((size_t)(r0 + rr), acc[p], ca, cb, act, yin, yout, sq);
   }
   if (partials != nullptr) {
+    block_sum_lanes<NL>(sq, red);
+    if (tid == 0) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      const double t = block_sum(sq[l], red);
-      if (tid == 0) partials[(size_t)l * M.ng + g] = t;
+      for (int l = 0; l < NL; ++l) partials[(size_t)l * M.ng + g] = sq[l];
     }
   }
 }
