@@ -37,7 +37,8 @@ struct DevCsr {
   int32_t nblk = 0;
   uint16_t* col16 = nullptr;   // compressed columns (see CsrView), null when not representable
   int32_t* colbase = nullptr;
-  CsrView view() const { return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows, col16, colbase}; }
+  int4* blkdesc = nullptr;
+  CsrView view() const { return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows, col16, colbase, blkdesc}; }
 };
 
 struct EventPair {
@@ -300,6 +301,12 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
   if (!H.colind.empty())
     HIPCHK(h, hipMemcpy(D.colind, H.colind.data(), H.colind.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(D.rowblk, rb.data(), rb.size() * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<int4> bd(std::max(D.nblk, 1));
+    for (int b = 0; b < D.nblk; ++b) bd[b] = int4{rb[b], rb[b + 1] - rb[b], H.rowptr[rb[b]], H.rowptr[rb[b + 1]]};
+    if (int rc = dalloc(h, &D.blkdesc, bd.size())) return rc;
+    HIPCHK(h, hipMemcpy(D.blkdesc, bd.data(), bd.size() * sizeof(int4), hipMemcpyHostToDevice));
+  }
   // 16-bit block-relative columns when every row block spans < 65536 columns
   if (h->opt.jac_format != 1 && D.nnz > 0) {
     std::vector<int32_t> base(D.nblk, 0);
@@ -332,7 +339,7 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
   const int64_t nnz = (int64_t)H.colind.size();
   D.ok = false;
   if (nnz == 0 || h->opt.jac_format == 1) return 0;
-  std::vector<int32_t> grow{0}, gent{0}, gcmin, gtp{0};
+  std::vector<RgcsGroup> groups;
   std::vector<uint32_t> pidx(nnz);
   std::vector<int32_t> vperm(nnz);
   std::vector<uint16_t> tptr;
@@ -362,6 +369,7 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
     for (int k = 0; k < cnt; ++k) ord[k] = k;
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return H.colind[e0 + a] < H.colind[e0 + b]; });
     const int ntile = (cnt + kRgcsTile - 1) / kRgcsTile;
+    const int32_t tp_start = (int32_t)tptr.size();
     for (int t = 0; t < ntile; ++t) {
       const int a = t * kRgcsTile, b = std::min(cnt, a + kRgcsTile);
       cntr.assign(R + 1, 0);
@@ -376,37 +384,35 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
         vperm[e0 + k] = e0 + src;
       }
     }
+    RgcsGroup gd{};
+    gd.r0 = (int32_t)r;
+    gd.R = R;
+    gd.e0 = e0;
+    gd.e1 = e1;
+    gd.cmin = cmin;
+    gd.tp = tp_start;
+    groups.push_back(gd);
     if (ntile == 0)
       for (int rr = 0; rr <= R; ++rr) tptr.push_back(0);
-    grow.push_back((int32_t)r1);
-    gent.push_back(e1);
-    gcmin.push_back(cmin);
-    gtp.push_back((int32_t)tptr.size());
     r = r1;
   }
   tptr.push_back(0);
   tptr.push_back(0);  // the kernel reads two uint16 at once
   uint32_t* dp;
-  int32_t *d1, *d2, *d3, *d4;
+  RgcsGroup* dg;
   uint16_t* d5;
   if (int rc = dalloc(h, &dp, (size_t)nnz + 1)) return rc;
   if (int rc = dalloc(h, &D.vals, (size_t)nnz + 1)) return rc;
   if (int rc = dalloc(h, &D.vperm, (size_t)nnz)) return rc;
-  if (int rc = dalloc(h, &d1, grow.size())) return rc;
-  if (int rc = dalloc(h, &d2, gent.size())) return rc;
-  if (int rc = dalloc(h, &d3, gcmin.size())) return rc;
-  if (int rc = dalloc(h, &d4, gtp.size())) return rc;
+  if (int rc = dalloc(h, &dg, groups.size())) return rc;
   if (int rc = dalloc(h, &d5, tptr.size() + 2)) return rc;
   HIPCHK(h, hipMemcpy(dp, pidx.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(dp + nnz, 0, 4));
   HIPCHK(h, hipMemset(D.vals + nnz, 0, 8));
   HIPCHK(h, hipMemcpy(D.vperm, vperm.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(d1, grow.data(), grow.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(d2, gent.data(), gent.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(d3, gcmin.data(), gcmin.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(d4, gtp.data(), gtp.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dg, groups.data(), groups.size() * sizeof(RgcsGroup), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d5, tptr.data(), tptr.size() * 2, hipMemcpyHostToDevice));
-  D.view = RgcsView{dp, D.vals, d1, d2, d3, d4, d5, (int32_t)gcmin.size(), (int32_t)H.nrows};
+  D.view = RgcsView{dp, D.vals, dg, d5, (int32_t)groups.size(), (int32_t)H.nrows};
   D.nnz = nnz;
   D.ok = true;
   return 0;

@@ -38,6 +38,9 @@ struct CsrView {
   // columns -- always the case for A' of a banded Jacobian); halves the index stream of the product
   const uint16_t* col16;
   const int32_t* colbase;
+  // per row block {first row, #rows, first nonzero, end nonzero}: ONE 16-byte load instead of the dependent chain
+  // rowblk[L] -> rowptr[r0] at the head of every workgroup
+  const int4* blkdesc;
 };
 
 // ------------------------------------------------------------------------------------------------ reductions
@@ -181,6 +184,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
                                                  double* partials, int blk_per_xcd) {
   const int L = (blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3);
   if (L >= A.nblk) return;
+  // issued before the (dependent) done-check below: one memory round trip at the head of the workgroup, not two
+  const int4 bd = A.blkdesc[L];
+  const int cbase = IDX16 ? A.colbase[L] : 0;
   bool act[NL];
   double ca[NL], cb[NL];
   {
@@ -198,9 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   __shared__ double prod[kSpmvNnz * NL];
   __shared__ double red[4 * NL];
   const int tid = threadIdx.x;
-  const int r0 = A.rowblk[L], r1 = A.rowblk[L + 1];
-  const int s = A.rowptr[r0], e = A.rowptr[r1];
-  const int nr = r1 - r0;
+  const int r0 = bd.x, nr = bd.y, s = bd.z, e = bd.w;
   double sq[NL];
 #pragma unroll
   for (int l = 0; l < NL; ++l) sq[l] = 0.0;
@@ -210,7 +214,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
-    const int cbase = IDX16 ? A.colbase[L] : 0;
     for (int i = s + tid; i < e; i += kBlock) {
       const int c = IDX16 ? cbase + (int)A.col16[i] : A.colind[i];
       const double v = A.vals[i];
@@ -240,7 +243,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
     double v[kPer];
-    const int cbase = IDX16 ? A.colbase[L] : 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       const int i = s + tid + k * kBlock;
@@ -308,13 +310,18 @@ constexpr int kRgcsMaxPass = 4;      // rows per group <= kRgcsMaxPass * kBlock
 constexpr int kRgcsGroupNnz = 12800;
 constexpr int kRgcsMaxRows = 128;
 
+struct RgcsGroup {        // 32 bytes, fetched with two independent 16-byte loads at the head of the workgroup
+  int32_t r0, R;          // first row, #rows
+  int32_t e0, e1;         // entry range
+  int32_t cmin;           // smallest column of the group
+  int32_t tp;             // offset into tptr
+  int32_t pad[2];
+};
+
 struct RgcsView {
-  const uint32_t* pidx;   // (slot << kRgcsColBits) | (col - gcmin[g])
+  const uint32_t* pidx;   // (slot << kRgcsColBits) | (col - cmin)
   const double* vals;     // same (column-sorted) order
-  const int32_t* grow;    // ng + 1 first rows
-  const int32_t* gent;    // ng + 1 first entries
-  const int32_t* gcmin;   // ng smallest column of the group
-  const int32_t* gtp;     // ng offsets into tptr
+  const RgcsGroup* grp;   // ng group descriptors
   const uint16_t* tptr;   // per tile: R + 1 row-segment boundaries in slot space
   int32_t ng;
   int32_t nrows;
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
                                                       double* partials, int grp_per_xcd) {
   const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
   if (g >= M.ng) return;
+  const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
   const LaneCtl* c[2] = {ctl0, ctl1};
   double ca[NL], cb[NL];
   bool act[NL];
@@ -341,10 +349,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   __shared__ double prod[kRgcsTile * NL];
   __shared__ double red[4 * NL];
   const int tid = threadIdx.x;
-  const int r0 = M.grow[g], R = M.grow[g + 1] - r0;
-  const int e0 = M.gent[g], e1 = M.gent[g + 1];
-  const int cmin = M.gcmin[g];
-  const uint16_t* tp = M.tptr + M.gtp[g];
+  const int r0 = gd.r0, R = gd.R, e0 = gd.e0, e1 = gd.e1, cmin = gd.cmin;
+  const uint16_t* tp = M.tptr + gd.tp;
   int G = 1;
   while (G < 64 && G * 2 * R <= kBlock) G <<= 1;
   const int rpp = kBlock / G, gid = tid / G, gl = tid % G;

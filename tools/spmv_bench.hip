@@ -34,7 +34,9 @@ static Dev upload(const Host& H) {
   CK(hipMalloc(&D.rp, H.rp.size()*4)); CK(hipMalloc(&D.ci, H.ci.size()*4)); CK(hipMalloc(&D.v, H.v.size()*8)); CK(hipMalloc(&D.rb, rb.size()*4));
   CK(hipMemcpy(D.rp, H.rp.data(), H.rp.size()*4, hipMemcpyHostToDevice)); CK(hipMemcpy(D.ci, H.ci.data(), H.ci.size()*4, hipMemcpyHostToDevice));
   CK(hipMemcpy(D.v, H.v.data(), H.v.size()*8, hipMemcpyHostToDevice)); CK(hipMemcpy(D.rb, rb.data(), rb.size()*4, hipMemcpyHostToDevice));
-  D.view = CsrView{D.rp, D.ci, D.v, D.rb, D.nblk, (int32_t)D.nr, nullptr, nullptr};
+  std::vector<int4> bd(D.nblk); for (int b = 0; b < D.nblk; ++b) bd[b] = int4{rb[b], rb[b+1]-rb[b], H.rp[rb[b]], H.rp[rb[b+1]]};
+  int4* dbd; CK(hipMalloc(&dbd, bd.size()*16)); CK(hipMemcpy(dbd, bd.data(), bd.size()*16, hipMemcpyHostToDevice));
+  D.view = CsrView{D.rp, D.ci, D.v, D.rb, D.nblk, (int32_t)D.nr, nullptr, nullptr, dbd};
   return D;
 }
 static Host transpose(const Host& A) {
