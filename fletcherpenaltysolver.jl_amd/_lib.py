@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfpsq.so")
+# FPSQ_LIB_PATH: developer A/B runs against another BUILD of the same HIP library (never a CPU implementation)
+LIB_PATH = os.environ.get("FPSQ_LIB_PATH") or os.path.join(_HERE, "lib", "libfpsq.so")
 
 
 class Stats(C.Structure):

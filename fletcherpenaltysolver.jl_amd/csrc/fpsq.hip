@@ -189,6 +189,8 @@ struct fpsq_solver_s {
   MinresState* minres;
   LaneCtl* ctl_tmp;
   LaneCtl* ctl_raw;             // constant {ca = 1, cb = 0, done = 0}: raw partial products before an all-reduce
+  LaneCtl* ctl_pm;              // constant {1, -1}
+  LaneCtl* ctl_mp;              // constant {-1, 1}
   Comm* comm = nullptr;         // null: single GPU
   double* comm_vec = nullptr;   // [n][2] all-reduce payload (partial A' products)
   double* comm_scal = nullptr;  // 8 doubles: scalar all-reduce payload
@@ -526,9 +528,16 @@ __global__ void k_set_ctl(LaneCtl* c, double ca, double cb) {
 
 // out = ca * op(A) x + cb * yin with host-given constants
 void spmv_const(fpsq_handle h, int tag, double ca, const double* x, double cb, const double* yin, double* yout) {
-  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, h->stream, h->ctl_tmp, ca, cb);
-  h->launches++;
-  launch_spmv<1>(h, tag, x, yin, yout, h->ctl_tmp, h->ctl_tmp, nullptr);
+  const LaneCtl* c = nullptr;  // the coefficient pairs of the hot path are resident constants: no set-up launch
+  if (ca == 1.0 && cb == 0.0) c = h->ctl_raw;
+  else if (ca == 1.0 && cb == -1.0) c = h->ctl_pm;
+  else if (ca == -1.0 && cb == 1.0) c = h->ctl_mp;
+  if (!c) {
+    hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, h->stream, h->ctl_tmp, ca, cb);
+    h->launches++;
+    c = h->ctl_tmp;
+  }
+  launch_spmv<1>(h, tag, x, yin, yout, c, c, nullptr);
 }
 
 int comm_allreduce(fpsq_handle h, double* buf, size_t count) {
@@ -611,7 +620,7 @@ struct LsqrParams {
   int64_t itmax;
 };
 
-__global__ void k_lsqr_params(LsqrState* S, LsqrParams P) {
+__device__ __forceinline__ void lsqr_set_params(LsqrState* S, const LsqrParams& P) {
   S->lambda = P.lambda;
   S->atol = P.atol;
   S->rtol = P.rtol;
@@ -631,7 +640,7 @@ struct CraigParams {
   int32_t start_skipped;
 };
 
-__global__ void k_craig_params(CraigState* S, CraigParams P) {
+__device__ __forceinline__ void craig_set_params(CraigState* S, const CraigParams& P) {
   S->mu = P.mu;
   S->lambda = P.lambda;
   S->atol = P.atol;
@@ -643,6 +652,13 @@ __global__ void k_craig_params(CraigState* S, CraigParams P) {
   S->ctl.done = 0;
   S->ctl.skip = P.start_skipped;  // stays out of the LSQR lane's start-up product; craig_begin clears it
   S->ctl.upd_iter = -1;
+}
+
+// Parameters of every lane of a run in one launch (null state = lane kind not present).
+__global__ void k_lane_params(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrParams P1, CraigState* C, CraigParams PC) {
+  if (S0) lsqr_set_params(S0, P0);
+  if (S1) lsqr_set_params(S1, P1);
+  if (C) craig_set_params(C, PC);
 }
 
 enum { LANE_LSQR = 1, LANE_CRAIG = 2 };
@@ -747,6 +763,10 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   int64_t itmax_all = 0;
   Progress* prog[2];
   int nlsqr = 0;
+  LsqrState* lsS[2] = {nullptr, nullptr};
+  LsqrParams lsP[2] = {};
+  CraigState* crS = nullptr;
+  CraigParams crP{};
   for (int l = 0; l < NL; ++l) {
     Lane& L = lanes[l];
     prog[l] = &h->prog_dev[l];
@@ -758,21 +778,22 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       L.state = S;
       L.ctl = &S->ctl;
       L.itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
-      LsqrParams P{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax};
-      hipLaunchKernelGGL(k_lsqr_params, dim3(1), dim3(1), 0, s, S, P);
+      lsP[nlsqr - 1] = LsqrParams{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax};
+      lsS[nlsqr - 1] = S;
     } else {
       CraigState* S = h->craig;
       L.state = S;
       L.ctl = &S->ctl;
       L.itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
       const bool reg = L.delta != 0.0;
-      CraigParams P{reg ? 1.0 / L.delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim,
-                    L.xsign, L.itmax, NL == 2 ? 1 : 0};
-      hipLaunchKernelGGL(k_craig_params, dim3(1), dim3(1), 0, s, S, P);
+      crP = CraigParams{reg ? 1.0 / L.delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim,
+                        L.xsign, L.itmax, NL == 2 ? 1 : 0};
+      crS = S;
     }
-    h->launches++;
     itmax_all = std::max(itmax_all, L.itmax);
   }
+  hipLaunchKernelGGL(k_lane_params, dim3(1), dim3(1), 0, s, lsS[0], lsP[0], lsS[1], lsP[1], crS, crP);
+  h->launches++;
   const LaneCtl* c0 = lanes[0].ctl;
   const LaneCtl* c1 = lanes[NL - 1].ctl;
 
@@ -784,14 +805,22 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     Lane& L = lanes[l];
     double* pe = l == 0 ? h->pE : h->pE2;
     if (L.kind == LANE_LSQR) {
-      HIPCHK(h, hipMemsetAsync(L.x, 0, (size_t)m * 8, s));
+      // x = 0 is written by the w_1 start-up kernel (also when the recurrence ends at start-up)
       hipLaunchKernelGGL(k_load_lane<NL>, dim3(gn), dim3(kBlock), 0, s, L.rhs, L.rhs_scale, LP, l, n, pe);
       (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
     } else {
-      HIPCHK(h, hipMemsetAsync(L.x, 0, (size_t)n * 8, s));
-      HIPCHK(h, hipMemsetAsync(L.y, 0, (size_t)m * 8, s));
-      HIPCHK(h, hipMemsetAsync(h->Cw, 0, (size_t)m * 8, s));
-      if (L.delta != 0.0) HIPCHK(h, hipMemsetAsync(h->Cw2, 0, (size_t)n * 8, s));
+      ZeroArgs z{};
+      z.p[0] = L.x;
+      z.n[0] = n;
+      z.p[1] = L.y;
+      z.n[1] = m;
+      z.p[2] = h->Cw;
+      z.n[2] = m;
+      if (L.delta != 0.0) {
+        z.p[3] = h->Cw2;
+        z.n[3] = n;
+      }
+      hipLaunchKernelGGL(k_zero_multi, dim3(gn), dim3(kBlock), 0, s, z);
       hipLaunchKernelGGL(k_load_lane<NL>, dim3(gm), dim3(kBlock), 0, s, L.rhs, L.rhs_scale, SP, l, m, pe);
     }
     h->launches++;
@@ -1177,10 +1206,10 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 2 * sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
+  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 4 * sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
     return fail("hipMalloc", e);
   h->allocs.push_back(p);
-  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 2 * sizeof(LaneCtl) + 64 * sizeof(double));
+  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 4 * sizeof(LaneCtl) + 64 * sizeof(double));
   char* cp = (char*)p;
   h->lsqr[0] = (LsqrState*)cp;
   h->lsqr[1] = h->lsqr[0] + 1;
@@ -1193,6 +1222,10 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   cp += sizeof(LaneCtl);
   h->ctl_raw = (LaneCtl*)cp;
   cp += sizeof(LaneCtl);
+  h->ctl_pm = (LaneCtl*)cp;
+  cp += sizeof(LaneCtl);
+  h->ctl_mp = (LaneCtl*)cp;
+  cp += sizeof(LaneCtl);
   h->dscal = (double*)cp;
   h->comm_scal = h->dscal + 32;
   {
@@ -1201,6 +1234,12 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     raw.cb = 0.0;
     raw.upd_iter = -1;
     hipMemcpy(h->ctl_raw, &raw, sizeof raw, hipMemcpyHostToDevice);
+    raw.ca = 1.0;
+    raw.cb = -1.0;
+    hipMemcpy(h->ctl_pm, &raw, sizeof raw, hipMemcpyHostToDevice);
+    raw.ca = -1.0;
+    raw.cb = 1.0;
+    hipMemcpy(h->ctl_mp, &raw, sizeof raw, hipMemcpyHostToDevice);
   }
   hipDeviceSynchronize();
   *out = h;

@@ -437,6 +437,19 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   }
 }
 
+// zero up to four vectors in one launch
+struct ZeroArgs {
+  double* p[4];
+  int64_t n[4];
+};
+__global__ __launch_bounds__(kBlock) void k_zero_multi(ZeroArgs z) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!z.p[k]) continue;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < z.n[k]; i += (int64_t)gridDim.x * kBlock) z.p[k][i] = 0.0;
+  }
+}
+
 // vals_out[t] = vals_in[perm[t]]  (refresh of the A' copy when the Jacobian values change)
 __global__ __launch_bounds__(kBlock) void k_gather(const double* __restrict__ in, const int32_t* __restrict__ perm,
                                                    double* __restrict__ out, int64_t n) {
@@ -504,13 +517,18 @@ struct UpdSeg {
 template <int NL, bool WINIT>
 __device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red) {
   const LaneCtl* ctl = s.ctl;
-  if (WINIT ? (ctl->done != 0) : (ctl->done && ctl->upd_iter != s.it)) return;
+  if (WINIT && ctl->done) {  // the recurrence ended at start-up (b = 0 or B'b = 0): the solution is x = 0
+    for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) s.a[i] = 0.0;
+    return;
+  }
+  if (!WINIT && ctl->done && ctl->upd_iter != s.it) return;
   const double sg = ctl->e[0], tr = ctl->e[1], ia = ctl->e[2];
   double sq = 0.0;
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
     double wn;
     if (WINIT) {
       wn = s.src[i * NL + s.lane] * ia;
+      s.a[i] = 0.0;  // x_0 = 0
     } else {
       const double wi = s.b[i];
       s.a[i] += sg * wi;

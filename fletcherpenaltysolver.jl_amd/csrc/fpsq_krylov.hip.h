@@ -704,27 +704,51 @@ __device__ __forceinline__ bool lane_done(const StepArgs& a) {
          reinterpret_cast<const LaneCtl*>(a.state)->done;
 }
 
+__device__ __forceinline__ int state_bytes(int kind) {
+  switch (kind) {
+    case STEP_LSQR_BEGIN: case STEP_LSQR_BEGIN2: case STEP_LSQR_SA: case STEP_LSQR_SB: return (int)sizeof(LsqrState);
+    case STEP_CRAIG_BEGIN: case STEP_CRAIG_SA: case STEP_CRAIG_SB: return (int)sizeof(CraigState);
+    default: return (int)sizeof(MinresState);
+  }
+}
+
 __global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1) {
   const StepArgs& a = blockIdx.x == 0 ? a0 : a1;
   if (a.kind == STEP_NONE || lane_done(a)) return;
   __shared__ double red[32];
+  // The recurrence state (<= 0.5 KB) is staged in LDS with one coalesced read issued together with the partial-sum
+  // loads, advanced there by thread 0, and written back with one coalesced store: the ~40 dependent scalar accesses of
+  // a step then cost LDS latency instead of a global round trip each.
+  __shared__ __attribute__((aligned(16))) unsigned long long st[80];
+  const int nq = state_bytes(a.kind) / 8;
+  const unsigned long long* gsrc = reinterpret_cast<const unsigned long long*>(a.state);
+  if ((int)threadIdx.x < nq) st[threadIdx.x] = gsrc[threadIdx.x];
   double s0 = 0.0, s1 = 0.0;
-  reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);
-  if (threadIdx.x != 0) return;
-  switch (a.kind) {
-    case STEP_LSQR_BEGIN: lsqr_begin_step((LsqrState*)a.state, s0, a.prog); break;
-    case STEP_LSQR_BEGIN2: lsqr_begin2_step((LsqrState*)a.state, s0, a.prog); break;
-    case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)a.state, s0); break;
-    case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)a.state, s0, s1, a.it, a.prog); break;
-    case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)a.state, s0, a.prog); break;
-    case STEP_CRAIG_SA: craig_sa_step((CraigState*)a.state, s0, a.it, a.prog); break;
-    case STEP_CRAIG_SB: craig_sb_step((CraigState*)a.state, s0, s1, a.it, a.prog); break;
-    case STEP_MINRES_BEGIN: minres_begin_step((MinresState*)a.state, s0, a.prog); break;
-    case STEP_MINRES_A: minres_a_step((MinresState*)a.state, s0); break;
-    case STEP_MINRES_B: minres_b_step((MinresState*)a.state, s0, a.it); break;
-    case STEP_MINRES_C: minres_c_step((MinresState*)a.state, s0, a.it, a.prog); break;
-    default: break;
+  reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);  // contains the workgroup barrier that publishes `st`
+  if (threadIdx.x == 0) {
+    void* S = st;
+    switch (a.kind) {
+      case STEP_LSQR_BEGIN: lsqr_begin_step((LsqrState*)S, s0, a.prog); break;
+      case STEP_LSQR_BEGIN2: lsqr_begin2_step((LsqrState*)S, s0, a.prog); break;
+      case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)S, s0); break;
+      case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)S, s0, s1, a.it, a.prog); break;
+      case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)S, s0, a.prog); break;
+      case STEP_CRAIG_SA: craig_sa_step((CraigState*)S, s0, a.it, a.prog); break;
+      case STEP_CRAIG_SB: craig_sb_step((CraigState*)S, s0, s1, a.it, a.prog); break;
+      case STEP_MINRES_BEGIN: minres_begin_step((MinresState*)S, s0, a.prog); break;
+      case STEP_MINRES_A: minres_a_step((MinresState*)S, s0); break;
+      case STEP_MINRES_B: minres_b_step((MinresState*)S, s0, a.it); break;
+      case STEP_MINRES_C: minres_c_step((MinresState*)S, s0, a.it, a.prog); break;
+      default: break;
+    }
   }
+  __syncthreads();
+  unsigned long long* gdst = reinterpret_cast<unsigned long long*>(a.state);
+  if ((int)threadIdx.x < nq) gdst[threadIdx.x] = st[threadIdx.x];
 }
+
+static_assert(sizeof(LsqrState) % 8 == 0 && sizeof(LsqrState) <= 640, "state staging");
+static_assert(sizeof(CraigState) % 8 == 0 && sizeof(CraigState) <= 640, "state staging");
+static_assert(sizeof(MinresState) % 8 == 0 && sizeof(MinresState) <= 640, "state staging");
 
 }  // namespace fpsq
