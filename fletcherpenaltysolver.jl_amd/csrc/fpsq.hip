@@ -177,6 +177,7 @@ struct fpsq_solver_s {
   std::vector<void*> allocs;
   // Golub-Kahan vectors, [len][2] interleaved: LP = "long" (n) pair, SP = "short" (m) pair
   double *LP, *SP;
+  double* SP2;                  // alternate short pair: the A product ping-pongs SP so fused updates may read the old one
   // n-vectors
   double *Cx, *Cw2, *in_n1, *in_n2, *p1, *p2b, *gs, *gx, *jc, *g, *xin, *xk;
   // m-vectors
@@ -426,6 +427,7 @@ int alloc_workspaces(fpsq_handle h) {
   const size_t n = (size_t)h->n, m = (size_t)h->m;
   if (int rc = dalloc(h, &h->LP, 2 * n)) return rc;
   if (int rc = dalloc(h, &h->SP, 2 * m)) return rc;
+  if (int rc = dalloc(h, &h->SP2, 2 * m)) return rc;
   if (int rc = dalloc(h, &h->comm_vec, 2 * n)) return rc;
   double** nv[] = {&h->Cx, &h->Cw2, &h->in_n1, &h->in_n2, &h->p1, &h->p2b,
                    &h->gs, &h->gx, &h->jc, &h->g, &h->xin, &h->xk};
@@ -487,30 +489,41 @@ void prof_end(fpsq_handle h) {
   h->ev_used++;
 }
 
+UpdSeg seg_none() {
+  UpdSeg s{};
+  s.kind = UPD_NONE;
+  s.nblk = 0;
+  return s;
+}
+
+// u0/u1: vector-update segments that ride in the product launch (run_fused_updates); they may only read what the
+// product reads.
 template <int NL>
 void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, double* yout, const LaneCtl* c0,
-                 const LaneCtl* c1, double* partials) {
+                 const LaneCtl* c1, double* partials, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none()) {
   const dim3 block(kBlock);
+  const int nupd = u0.nblk + u1.nblk;
   prof_begin(h);
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
-    hipLaunchKernelGGL((k_spmv_rgcs<NL>), dim3(per_xcd * 8), block, 0, h->stream, h->RA.view, x, yin, yout, c0, c1, partials,
-                       per_xcd);
+    hipLaunchKernelGGL((k_spmv_rgcs<NL>), dim3(per_xcd * 8 + nupd), block, 0, h->stream, h->RA.view, x, yin, yout, c0, c1,
+                       partials, per_xcd, u0, u1);
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
-    const dim3 grid(per_xcd * 8);
+    const dim3 grid(per_xcd * 8 + nupd);
     if (tag == TAG_A && M.col16)
       hipLaunchKernelGGL((k_spmv<NL, TAG_A, true>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
-                         per_xcd);
+                         per_xcd, u0, u1);
     else if (tag == TAG_A)
-      hipLaunchKernelGGL((k_spmv<NL, TAG_A>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials, per_xcd);
+      hipLaunchKernelGGL((k_spmv<NL, TAG_A>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials, per_xcd,
+                         u0, u1);
     else if (M.col16)
       hipLaunchKernelGGL((k_spmv<NL, TAG_AT, true>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
-                         per_xcd);
+                         per_xcd, u0, u1);
     else
       hipLaunchKernelGGL((k_spmv<NL, TAG_AT>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
-                         per_xcd);
+                         per_xcd, u0, u1);
   }
   prof_end(h);
   h->launches++;
@@ -552,9 +565,9 @@ int comm_allreduce(fpsq_handle h, double* buf, size_t count) {
 // A'x = sum_r A_r' x_r: raw partial product -> all-reduce -> fused axpby + norm on the replicated result.
 template <int NL>
 int at_product(fpsq_handle h, const double* x, double* y, const LaneCtl* c0, const LaneCtl* c1, double* partials,
-               int* np) {
+               int* np, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none()) {
   if (!h->comm) {
-    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials);
+    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials, u0, u1);
     *np = h->AT.nblk;
     return 0;
   }
@@ -738,12 +751,6 @@ void launch_updates(fpsq_handle h, const UpdSeg& s0, const UpdSeg& s1, const Upd
   h->launches++;
 }
 
-UpdSeg seg_none() {
-  UpdSeg s{};
-  s.kind = UPD_NONE;
-  s.nblk = 0;
-  return s;
-}
 
 // Runs 1 or 2 recurrences in lock-step on the interleaved Golub-Kahan pairs LP (n) / SP (m):
 //   A' product: LP <- ca A' SP + cb LP      (LSQR: u~ <- B v - alpha u;     CRAIG: v~ <- B'u - beta v)
@@ -858,6 +865,13 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
         return rc;
 
   // ---- main loop
+  // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
+  // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
+  // iteration it; CRAIG's updates of iteration it (read the long pair and the OLD short pair) go with the A product,
+  // which therefore writes the alternate short pair (ping-pong).  Sharded: separate update launch, in place.
+  const bool fuse_upd = h->comm == nullptr;
+  double* SPcur = SP;
+  double* SPalt = h->SP2;
   const int look = std::max(1, o.lookahead);
   int64_t it = 0;
   auto lsqr_upd_seg = [&](int l, int64_t it_of_update) {
@@ -865,7 +879,7 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     u.kind = UPD_LSQR;
     u.it = (int)it_of_update;
     u.ctl = lanes[l].ctl;
-    u.src = SP;
+    u.src = SPcur;
     u.lane = l;
     u.nblk = gm;
     u.a = lanes[l].x;
@@ -881,50 +895,63 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   };
   while (it < itmax_all) {
     ++it;
+    // LSQR's x/w update of the PREVIOUS iteration
+    UpdSeg lu[2] = {seg_none(), seg_none()};
+    int nlu = 0;
+    if (it > 1)
+      for (int l = 0; l < NL; ++l)
+        if (lanes[l].kind == LANE_LSQR) lu[nlu++] = lsqr_upd_seg(l, it - 1);
     // first half-step of every lane: one A' product
     int npT = 0;
-    if (int rc = at_product<NL>(h, SP, LP, c0, c1, h->pS, &npT)) return rc;
+    if (fuse_upd) {
+      if (int rc = at_product<NL>(h, SPcur, LP, c0, c1, h->pS, &npT, lu[0], lu[1])) return rc;
+    } else {
+      if (int rc = at_product<NL>(h, SPcur, LP, c0, c1, h->pS, &npT)) return rc;
+    }
     StepArgs sa[2] = {none, none};
     for (int l = 0; l < NL; ++l)
       sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : STEP_CRAIG_SA, lanes[l], (int)it,
                         h->pS + (size_t)l * npT, npT, nullptr, 0, prog[l]);
     launch_step(h, sa[0], sa[1]);  // sums over replicated n-vectors: no all-reduce
-    // vector updates: LSQR's x/w update of the PREVIOUS iteration, CRAIG's updates of this one
-    UpdSeg seg[3] = {seg_none(), seg_none(), seg_none()};
-    int ns = 0;
+    // CRAIG's updates of this iteration
+    UpdSeg cu[2] = {seg_none(), seg_none()};
     for (int l = 0; l < NL; ++l) {
       const Lane& L = lanes[l];
-      if (L.kind == LANE_LSQR) {
-        if (it > 1) seg[ns++] = lsqr_upd_seg(l, it - 1);
-      } else {
-        UpdSeg u{};
-        u.kind = L.delta != 0.0 ? UPD_CRAIG_LONG_REG : UPD_CRAIG_LONG;
-        u.it = (int)it;
-        u.ctl = L.ctl;
-        u.src = LP;
-        u.lane = l;
-        u.nblk = gn;
-        u.a = L.x;
-        u.b = h->Cw2;
-        u.len = n;
-        seg[ns++] = u;
-        UpdSeg v{};
-        v.kind = UPD_CRAIG_SHORT;
-        v.it = (int)it;
-        v.ctl = L.ctl;
-        v.src = SP;
-        v.lane = l;
-        v.nblk = gm;
-        v.a = h->Cw;
-        v.b = L.y;
-        v.len = m;
-        v.partials = h->pW[l];
-        seg[ns++] = v;
-      }
+      if (L.kind != LANE_CRAIG) continue;
+      UpdSeg u{};
+      u.kind = L.delta != 0.0 ? UPD_CRAIG_LONG_REG : UPD_CRAIG_LONG;
+      u.it = (int)it;
+      u.ctl = L.ctl;
+      u.src = LP;
+      u.lane = l;
+      u.nblk = gn;
+      u.a = L.x;
+      u.b = h->Cw2;
+      u.len = n;
+      cu[0] = u;
+      UpdSeg v{};
+      v.kind = UPD_CRAIG_SHORT;
+      v.it = (int)it;
+      v.ctl = L.ctl;
+      v.src = SPcur;
+      v.lane = l;
+      v.nblk = gm;
+      v.a = h->Cw;
+      v.b = L.y;
+      v.len = m;
+      v.partials = h->pW[l];
+      cu[1] = v;
     }
-    launch_updates<NL>(h, seg[0], seg[1], seg[2]);
     // second half-step: one A product
-    launch_spmv<NL>(h, TAG_A, LP, SP, SP, c0, c1, h->pS2);
+    if (fuse_upd) {
+      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPalt, c0, c1, h->pS2, cu[0], cu[1]);
+      std::swap(SPcur, SPalt);
+    } else {
+      // (at most three segments: lanes <= 2 and only one of them can be CRAIG)
+      if (nlu == 2) launch_updates<NL>(h, lu[0], lu[1], seg_none());
+      else launch_updates<NL>(h, lu[0], cu[0], cu[1]);
+      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPcur, c0, c1, h->pS2);
+    }
     StepArgs sb[2] = {none, none};
     for (int l = 0; l < NL; ++l)
       sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : STEP_CRAIG_SB, lanes[l], (int)it,

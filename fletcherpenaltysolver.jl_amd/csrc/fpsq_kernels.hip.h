@@ -168,6 +168,120 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
   }
 }
 
+// ---- Krylov vector updates.  Several independent updates (the LSQR x/w update of the previous iteration, the CRAIG
+// long and short updates of this one) are merged into ONE launch: consecutive workgroup ranges run different bodies.
+
+enum UpdKind : int32_t { UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT };
+
+struct UpdSeg {
+  int32_t kind;
+  int32_t it;        // iteration this update belongs to (see LaneCtl::upd_iter)
+  const LaneCtl* ctl;
+  const double* src; // interleaved Golub-Kahan vector [len][NL]
+  int32_t lane;      // which interleaved lane of src
+  int32_t nblk;      // workgroups assigned to this segment
+  double* a;         // LSQR: x      CRAIG long: xs      CRAIG short: w
+  double* b;         // LSQR: w      CRAIG long: w2s     CRAIG short: y
+  int64_t len;
+  double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
+};
+
+// LSQR (Krylov.jl lsqr!): x += (phi/rho) w; w = v - (theta/rho) w, with v = vt / alpha deferred.
+//   e[0] = phi/rho, e[1] = theta/rho, e[2] = 1/alpha.   WINIT: w = vt / alpha only (w_1 = v_1).
+template <int NL, bool WINIT>
+__device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red) {
+  const LaneCtl* ctl = s.ctl;
+  if (WINIT && ctl->done) {  // the recurrence ended at start-up (b = 0 or B'b = 0): the solution is x = 0
+    for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) s.a[i] = 0.0;
+    return;
+  }
+  if (!WINIT && ctl->done && ctl->upd_iter != s.it) return;
+  const double sg = ctl->e[0], tr = ctl->e[1], ia = ctl->e[2];
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    double wn;
+    if (WINIT) {
+      wn = s.src[i * NL + s.lane] * ia;
+      s.a[i] = 0.0;  // x_0 = 0
+    } else {
+      const double wi = s.b[i];
+      s.a[i] += sg * wi;
+      wn = s.src[i * NL + s.lane] * ia - tr * wi;
+    }
+    s.b[i] = wn;
+    sq += wn * wn;
+  }
+  const double t = block_sum(sq, red);
+  if (threadIdx.x == 0) s.partials[blk] = t;
+}
+
+// CRAIG (Krylov.jl craig!), long (n) part.  `xs` accumulates sgn * x (sgn = -1 gives p2 = -x directly,
+// src/solve_linear_system.jl:133).  With v = vt / alpha and the true w2 = omega * w2s (the scaling by s2 is deferred):
+//   lambda > 0:  xs += e0 * vt + e1 * w2s;   w2s = e2 * vt + e3 * w2s
+//       e0 = sgn xi c1 / alpha, e1 = sgn xi s1 omega, e2 = s1 / alpha, e3 = -c1 omega
+//   lambda = 0:  xs += e0 * vt                      (e0 = sgn xi / alpha)
+template <int NL, bool REG>
+__device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk) {
+  const LaneCtl* ctl = s.ctl;
+  if (ctl->done && ctl->upd_iter != s.it) return;
+  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3];
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    const double v = s.src[i * NL + s.lane];
+    if (REG) {
+      const double w2 = s.b[i];
+      s.a[i] += e0 * v + e1 * w2;
+      s.b[i] = e2 * v + e3 * w2;
+    } else {
+      s.a[i] += e0 * v;
+    }
+  }
+}
+
+// CRAIG short (m) part:  w = u - (theta/rho_prev) w with u = e4 * mut (= mu Mu~ / beta);  y += e6 * w.
+//   e4 = mu/beta, e5 = theta/rho_prev, e6 = xi/rho
+template <int NL>
+__device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double* red) {
+  const LaneCtl* ctl = s.ctl;
+  if (ctl->done && ctl->upd_iter != s.it) return;
+  const double e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6];
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    const double wn = e4 * s.src[i * NL + s.lane] - e5 * s.a[i];
+    s.a[i] = wn;
+    s.b[i] += e6 * wn;
+    sq += wn * wn;
+  }
+  const double t = block_sum(sq, red);
+  if (threadIdx.x == 0) s.partials[blk] = t;
+}
+
+template <int NL>
+__device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
+  switch (s.kind) {
+    case UPD_LSQR: upd_lsqr<NL, false>(s, blk, red); break;
+    case UPD_LSQR_WINIT: upd_lsqr<NL, true>(s, blk, red); break;
+    case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true>(s, blk); break;
+    case UPD_CRAIG_LONG: upd_craig_long<NL, false>(s, blk); break;
+    case UPD_CRAIG_SHORT: upd_craig_short<NL>(s, blk, red); break;
+    default: break;
+  }
+}
+
+// Update segments riding in a product launch ("horizontal fusion"): the workgroups past the product's own grid
+// (they are dispatched last and fill the product's tail) run vector updates that only READ what the product reads, so one launch replaces two and the streaming updates
+// overlap the gather-bound product.  Returns true when this workgroup was an update workgroup.
+template <int NL>
+__device__ __forceinline__ bool run_fused_updates(const UpdSeg& u0, const UpdSeg& u1, int nprod, double* red) {
+  const int blk = (int)blockIdx.x - nprod;
+  if (blk < 0) return false;
+  if (blk < u0.nblk) {
+    upd_run<NL>(u0, blk, red);
+  } else {
+    upd_run<NL>(u1, blk - u0.nblk, red);
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------ SpMV / SpMM
 //
 // out[r][l] = ca_l * sum_k vals[k] * x[colind[k]][l] + cb_l * yin[r][l],  partial[l][blk] = sum_r out[r][l]^2
@@ -181,7 +295,9 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
 template <int NL, int TAG, bool IDX16 = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
-                                                 double* partials, int blk_per_xcd) {
+                                                 double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1) {
+  __shared__ double red[4 * NL];
+  if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   const int L = (blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3);
   if (L >= A.nblk) return;
   // issued before the (dependent) done-check below: one memory round trip at the head of the workgroup, not two
@@ -202,7 +318,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     if (!any) return;
   }
   __shared__ double prod[kSpmvNnz * NL];
-  __shared__ double red[4 * NL];
   const int tid = threadIdx.x;
   const int r0 = bd.x, nr = bd.y, s = bd.z, e = bd.w;
   double sq[NL];
@@ -330,7 +445,10 @@ struct RgcsView {
 template <int NL>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
-                                                      double* partials, int grp_per_xcd) {
+                                                      double* partials, int grp_per_xcd, const UpdSeg u0,
+                                                      const UpdSeg u1) {
+  __shared__ double red[4 * NL];
+  if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
   const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
   if (g >= M.ng) return;
   const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
@@ -347,7 +465,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   }
   if (!any) return;
   __shared__ double prod[kRgcsTile * NL];
-  __shared__ double red[4 * NL];
   const int tid = threadIdx.x;
   const int r0 = gd.r0, R = gd.R, e0 = gd.e0, e1 = gd.e1, cmin = gd.cmin;
   const uint16_t* tp = M.tptr + gd.tp;
@@ -492,105 +609,6 @@ __global__ __launch_bounds__(kBlock) void k_store_lane(const double* __restrict_
                                                        const double* y, double b, double* out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
     out[i] = a * x[i * NL + lane] + (b != 0.0 ? b * y[i] : 0.0);
-}
-
-// ---- Krylov vector updates.  Several independent updates (the LSQR x/w update of the previous iteration, the CRAIG
-// long and short updates of this one) are merged into ONE launch: consecutive workgroup ranges run different bodies.
-
-enum UpdKind : int32_t { UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT };
-
-struct UpdSeg {
-  int32_t kind;
-  int32_t it;        // iteration this update belongs to (see LaneCtl::upd_iter)
-  const LaneCtl* ctl;
-  const double* src; // interleaved Golub-Kahan vector [len][NL]
-  int32_t lane;      // which interleaved lane of src
-  int32_t nblk;      // workgroups assigned to this segment
-  double* a;         // LSQR: x      CRAIG long: xs      CRAIG short: w
-  double* b;         // LSQR: w      CRAIG long: w2s     CRAIG short: y
-  int64_t len;
-  double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
-};
-
-// LSQR (Krylov.jl lsqr!): x += (phi/rho) w; w = v - (theta/rho) w, with v = vt / alpha deferred.
-//   e[0] = phi/rho, e[1] = theta/rho, e[2] = 1/alpha.   WINIT: w = vt / alpha only (w_1 = v_1).
-template <int NL, bool WINIT>
-__device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red) {
-  const LaneCtl* ctl = s.ctl;
-  if (WINIT && ctl->done) {  // the recurrence ended at start-up (b = 0 or B'b = 0): the solution is x = 0
-    for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) s.a[i] = 0.0;
-    return;
-  }
-  if (!WINIT && ctl->done && ctl->upd_iter != s.it) return;
-  const double sg = ctl->e[0], tr = ctl->e[1], ia = ctl->e[2];
-  double sq = 0.0;
-  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    double wn;
-    if (WINIT) {
-      wn = s.src[i * NL + s.lane] * ia;
-      s.a[i] = 0.0;  // x_0 = 0
-    } else {
-      const double wi = s.b[i];
-      s.a[i] += sg * wi;
-      wn = s.src[i * NL + s.lane] * ia - tr * wi;
-    }
-    s.b[i] = wn;
-    sq += wn * wn;
-  }
-  const double t = block_sum(sq, red);
-  if (threadIdx.x == 0) s.partials[blk] = t;
-}
-
-// CRAIG (Krylov.jl craig!), long (n) part.  `xs` accumulates sgn * x (sgn = -1 gives p2 = -x directly,
-// src/solve_linear_system.jl:133).  With v = vt / alpha and the true w2 = omega * w2s (the scaling by s2 is deferred):
-//   lambda > 0:  xs += e0 * vt + e1 * w2s;   w2s = e2 * vt + e3 * w2s
-//       e0 = sgn xi c1 / alpha, e1 = sgn xi s1 omega, e2 = s1 / alpha, e3 = -c1 omega
-//   lambda = 0:  xs += e0 * vt                      (e0 = sgn xi / alpha)
-template <int NL, bool REG>
-__device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk) {
-  const LaneCtl* ctl = s.ctl;
-  if (ctl->done && ctl->upd_iter != s.it) return;
-  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3];
-  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    const double v = s.src[i * NL + s.lane];
-    if (REG) {
-      const double w2 = s.b[i];
-      s.a[i] += e0 * v + e1 * w2;
-      s.b[i] = e2 * v + e3 * w2;
-    } else {
-      s.a[i] += e0 * v;
-    }
-  }
-}
-
-// CRAIG short (m) part:  w = u - (theta/rho_prev) w with u = e4 * mut (= mu Mu~ / beta);  y += e6 * w.
-//   e4 = mu/beta, e5 = theta/rho_prev, e6 = xi/rho
-template <int NL>
-__device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double* red) {
-  const LaneCtl* ctl = s.ctl;
-  if (ctl->done && ctl->upd_iter != s.it) return;
-  const double e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6];
-  double sq = 0.0;
-  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    const double wn = e4 * s.src[i * NL + s.lane] - e5 * s.a[i];
-    s.a[i] = wn;
-    s.b[i] += e6 * wn;
-    sq += wn * wn;
-  }
-  const double t = block_sum(sq, red);
-  if (threadIdx.x == 0) s.partials[blk] = t;
-}
-
-template <int NL>
-__device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
-  switch (s.kind) {
-    case UPD_LSQR: upd_lsqr<NL, false>(s, blk, red); break;
-    case UPD_LSQR_WINIT: upd_lsqr<NL, true>(s, blk, red); break;
-    case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true>(s, blk); break;
-    case UPD_CRAIG_LONG: upd_craig_long<NL, false>(s, blk); break;
-    case UPD_CRAIG_SHORT: upd_craig_short<NL>(s, blk, red); break;
-    default: break;
-  }
 }
 
 // (the segments are kernel arguments: select by branch, never through a pointer, or they are spilled to scratch)
