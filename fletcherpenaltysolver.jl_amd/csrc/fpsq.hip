@@ -7,6 +7,7 @@
 #include "fpsq_krylov.hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>  // types only; the library is dlopen'ed on first use
 
 #include <dlfcn.h>
@@ -473,20 +474,23 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
 
 enum { TAG_A = 0, TAG_AT = 1 };
 
-void prof_begin(fpsq_handle h) {
-  if (!h->profile) return;
+// Profiled product launches attach the event pair to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time
+// is the kernel's own start-to-end time, as rocprofv3 reports it.  Two hipEventRecord markers around the launch add
+// ~5 us of marker processing to every sample.
+template <typename K, typename... Args>
+void launch_product(fpsq_handle h, K kernel, dim3 grid, Args... args) {
+  if (!h->profile) {
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, h->stream, args...);
+    return;
+  }
   if (h->ev_used == h->ev_pool.size()) {
     EventPair p;
     hipEventCreate(&p.a);
     hipEventCreate(&p.b);
     h->ev_pool.push_back(p);
   }
-  hipEventRecord(h->ev_pool[h->ev_used].a, h->stream);
-}
-void prof_end(fpsq_handle h) {
-  if (!h->profile) return;
-  hipEventRecord(h->ev_pool[h->ev_used].b, h->stream);
-  h->ev_used++;
+  EventPair& e = h->ev_pool[h->ev_used++];
+  hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, h->stream, e.a, e.b, 0, args...);
 }
 
 UpdSeg seg_none() {
@@ -501,31 +505,23 @@ UpdSeg seg_none() {
 template <int NL>
 void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, double* yout, const LaneCtl* c0,
                  const LaneCtl* c1, double* partials, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none()) {
-  const dim3 block(kBlock);
   const int nupd = u0.nblk + u1.nblk;
-  prof_begin(h);
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
-    hipLaunchKernelGGL((k_spmv_rgcs<NL>), dim3(per_xcd * 8 + nupd), block, 0, h->stream, h->RA.view, x, yin, yout, c0, c1,
-                       partials, per_xcd, u0, u1);
+    launch_product(h, k_spmv_rgcs<NL>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
     const dim3 grid(per_xcd * 8 + nupd);
     if (tag == TAG_A && M.col16)
-      hipLaunchKernelGGL((k_spmv<NL, TAG_A, true>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
-                         per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_A, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
     else if (tag == TAG_A)
-      hipLaunchKernelGGL((k_spmv<NL, TAG_A>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials, per_xcd,
-                         u0, u1);
+      launch_product(h, k_spmv<NL, TAG_A, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
     else if (M.col16)
-      hipLaunchKernelGGL((k_spmv<NL, TAG_AT, true>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
-                         per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_AT, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
     else
-      hipLaunchKernelGGL((k_spmv<NL, TAG_AT>), grid, block, 0, h->stream, M.view(), x, yin, yout, c0, c1, partials,
-                         per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_AT, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
   }
-  prof_end(h);
   h->launches++;
   h->spmv_launches++;
   (tag == TAG_A ? h->prod_a : h->prod_at)[NL - 1]++;
