@@ -199,8 +199,10 @@ struct fpsq_solver_s {
   double* dscal;               // small device scalar scratch
   Progress* prog_host = nullptr;  // host-mapped
   Progress* prog_dev = nullptr;
-  fpsq_stats* hstats = nullptr;   // pinned
-  double* hscal = nullptr;        // pinned
+  fpsq_stats* hstats = nullptr;   // host-mapped: written by the step kernel that ends a recurrence
+  fpsq_stats* hstats_dev = nullptr;
+  double* hscal = nullptr;        // host-mapped: scalar results (phi, f, c'c) written by the kernel that computes them
+  double* hscal_dev = nullptr;
 
   // instrumentation
   bool profile = false;
@@ -682,7 +684,8 @@ struct Lane {
   double xsign = 1.0;           // CRAIG: xs accumulates xsign * x
   double* x = nullptr;          // LSQR: solution (m).  CRAIG: xs (n)
   double* y = nullptr;          // CRAIG: y (m)
-  fpsq_stats* st = nullptr;     // pinned host destination of the final stats
+  fpsq_stats* st = nullptr;     // destination of the final stats: an element of the host-mapped h->hstats
+  fpsq_stats* st_dev = nullptr; // its device alias (filled by run_krylov / run_minres)
   // filled by run_krylov
   void* state = nullptr;
   LaneCtl* ctl = nullptr;
@@ -699,6 +702,7 @@ StepArgs step_args(int kind, const Lane& L, int it, const double* p0, int n0, co
   a.n0 = n0;
   a.n1 = n1;
   a.prog = prog;
+  a.host_stats = L.st_dev;
   return a;
 }
 
@@ -775,6 +779,8 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     prog[l] = &h->prog_dev[l];
     h->prog_host[l].iter = 0;
     h->prog_host[l].done = 0;
+    L.st_dev = h->hstats_dev + (L.st - h->hstats);
+    *L.st = fpsq_stats{};
     if (L.kind == LANE_LSQR) {
       any_lsqr = true;
       LsqrState* S = h->lsqr[nlsqr++];
@@ -986,12 +992,7 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       if (lanes[l].kind == LANE_LSQR && it >= 1) seg[ns++] = lsqr_upd_seg(l, it);
     launch_updates<NL>(h, seg[0], seg[1], seg_none());
   }
-  for (int l = 0; l < NL; ++l) {
-    const fpsq_stats* src = lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->stats
-                                                       : &((CraigState*)lanes[l].state)->stats;
-    HIPCHK(h, hipMemcpyAsync(lanes[l].st, src, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
-  }
-  return 0;
+  return 0;  // the final stats were left in lanes[l].st by the step that ended each recurrence
 }
 
 struct MinresParams {
@@ -1038,6 +1039,9 @@ int run_minres(fpsq_handle h, const double* b, double lambda, fpsq_stats* st_out
   hipLaunchKernelGGL(k_load_lane<1>, dim3(gm), dim3(kBlock), 0, s, b, 1.0, h->SP, 0, m, h->pE);
   Lane L;
   L.state = S;
+  L.st = st_out;
+  L.st_dev = h->hstats_dev + (st_out - h->hstats);
+  *st_out = fpsq_stats{};
   StepArgs none{};
   none.kind = STEP_NONE;
   launch_step(h, step_args(STEP_MINRES_BEGIN, L, 0, h->pE, gm, nullptr, 0, prog), none);
@@ -1066,7 +1070,6 @@ int run_minres(fpsq_handle h, const double* b, double lambda, fpsq_stats* st_out
       if (h->prog_host[0].done) break;
     }
   }
-  HIPCHK(h, hipMemcpyAsync(st_out, &S->stats, sizeof(fpsq_stats), hipMemcpyDeviceToHost, s));
   return 0;
 }
 
@@ -1114,6 +1117,16 @@ int call_end(fpsq_handle h) {
   }
   h->info.last_spmv_ms = sp;
   return 0;
+}
+
+// true when p is device memory of the handle's GPU (kernels may then use it in place)
+bool on_this_device(fpsq_handle h, const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory: not an error
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice && a.device == h->opt.device;
 }
 
 int soft_rc(const fpsq_stats st[2]) { return (st[0].solved ? 0 : 1) | (st[1].solved ? 0 : 2); }
@@ -1224,8 +1237,18 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   std::memset(h->prog_host, 0, 4 * sizeof(Progress));
   if ((e = hipHostGetDevicePointer((void**)&h->prog_dev, h->prog_host, 0)) != hipSuccess)
     return fail("hipHostGetDevicePointer", e);
-  if ((e = hipHostMalloc((void**)&h->hstats, 4 * sizeof(fpsq_stats), 0)) != hipSuccess) return fail("hipHostMalloc", e);
-  if ((e = hipHostMalloc((void**)&h->hscal, 16 * sizeof(double), 0)) != hipSuccess) return fail("hipHostMalloc", e);
+  if ((e = hipHostMalloc((void**)&h->hstats, 4 * sizeof(fpsq_stats), hipHostMallocMapped | hipHostMallocCoherent)) !=
+      hipSuccess)
+    return fail("hipHostMalloc", e);
+  if ((e = hipHostMalloc((void**)&h->hscal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
+      hipSuccess)
+    return fail("hipHostMalloc", e);
+  std::memset(h->hstats, 0, 4 * sizeof(fpsq_stats));
+  std::memset(h->hscal, 0, 16 * sizeof(double));
+  if ((e = hipHostGetDevicePointer((void**)&h->hstats_dev, h->hstats, 0)) != hipSuccess)
+    return fail("hipHostGetDevicePointer", e);
+  if ((e = hipHostGetDevicePointer((void**)&h->hscal_dev, h->hscal, 0)) != hipSuccess)
+    return fail("hipHostGetDevicePointer", e);
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
@@ -1617,7 +1640,13 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   const int64_t n = h->n, m = h->m;
   const size_t nb = (size_t)n * 8, mb = (size_t)m * 8;
   const int gn = ew_grid(n), gm = ew_grid(m);
-  HIPCHK(h, hipMemcpyAsync(h->xin, x, nb, hipMemcpyDefault, s));
+  // x and gx resident on this GPU are used in place (no staging copy); host buffers go through h->xin / h->gx
+  const double* dx = x;
+  if (!on_this_device(h, x)) {
+    HIPCHK(h, hipMemcpyAsync(h->xin, x, nb, hipMemcpyDefault, s));
+    dx = h->xin;
+  }
+  double* dgx = gx && on_this_device(h, gx) ? gx : h->gx;
   const double* dxk = nullptr;
   if (eta > 0.0) {
     HIPCHK(h, hipMemcpyAsync(h->xk, xk, nb, hipMemcpyDefault, s));
@@ -1625,17 +1654,17 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   }
   call_begin(h);
   // user-model evaluations of _compute_ys_gs!  (src/model-Fletcherpenaltynlp.jl:238-240)
-  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, h->xin, dxk, h->g, n, h->pQ[0], h->pQ[1]);
+  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1]);
   h->launches++;
-  spmv_const(h, TAG_A, 1.0, h->xin, -1.0, qp->b, h->c);  // c = A x - b
+  spmv_const(h, TAG_A, 1.0, dx, -1.0, qp->b, h->c);  // c = A x - b
   if (int rc = two_mixed_device(h, h->g, h->c)) return rc;
   // ys = q1 + sigma q2 and the dots of objgrad!
   hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax);
   h->launches++;
   if (rho > 0.0)
     if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
-  hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn), dim3(kBlock), 0, s, h->p1, h->Cx, qp->q, h->jc, h->xin, dxk, sigma,
-                     rho, eta, h->gs, h->gx, n);
+  hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn), dim3(kBlock), 0, s, h->p1, h->Cx, qp->q, h->jc, dx, dxk, sigma,
+                     rho, eta, h->gs, dgx, n);
   const double *pcy = h->pE, *pcc = h->pE + kEwBlocksMax;
   int npm = gm;
   if (h->comm) {  // c'ys and c'c are sums over the rank's rows only
@@ -1650,10 +1679,9 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
     pcc = h->comm_scal + 1;
     npm = 1;
   }
-  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pQ[0], h->pQ[1], gn, pcy, pcc, npm, rho, eta, h->dscal);
+  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pQ[0], h->pQ[1], gn, pcy, pcc, npm, rho, eta, h->hscal_dev);
   h->launches += 2;
-  HIPCHK(h, hipMemcpyAsync(h->hscal, h->dscal, 3 * 8, hipMemcpyDeviceToHost, s));
-  if (gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
+  if (gx && dgx != gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
   if (ys) HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
   if (gs) HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;

@@ -650,6 +650,7 @@ struct StepArgs {
   const double* p1;  // second partial array (||w||^2 of the last update), may be null
   int32_t n0, n1;
   Progress* prog;
+  fpsq_stats* host_stats;  // host-mapped: the step that ends the recurrence leaves the final stats there (no copy)
 };
 
 constexpr int kStepThreads = 1024;
@@ -740,6 +741,12 @@ __global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1)
       case STEP_MINRES_B: minres_b_step((MinresState*)S, s0, a.it); break;
       case STEP_MINRES_C: minres_c_step((MinresState*)S, s0, a.it, a.prog); break;
       default: break;
+    }
+    if (a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
+      const fpsq_stats* fin = a.kind >= STEP_MINRES_BEGIN ? &((MinresState*)S)->stats
+                              : a.kind >= STEP_CRAIG_BEGIN ? &((CraigState*)S)->stats
+                                                           : &((LsqrState*)S)->stats;
+      *a.host_stats = *fin;
     }
   }
   __syncthreads();
