@@ -672,6 +672,54 @@ __global__ void k_lane_params(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrP
   if (C) craig_set_params(C, PC);
 }
 
+// Start-up of a run in ONE launch: lane parameters (workgroup 0), the right-hand sides loaded into their interleaved
+// lanes with the squared-norm partials, and the vectors that start at zero.
+struct LoadSeg {
+  const double* src;
+  double scale;
+  double* dst;
+  int32_t lane, nblk;
+  int64_t len;
+  double* partials;
+};
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrParams P1, CraigState* C,
+                                                    CraigParams PC, LoadSeg l0, LoadSeg l1, ZeroArgs z, int nzblk) {
+  __shared__ double red[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (S0) lsqr_set_params(S0, P0);
+    if (S1) lsqr_set_params(S1, P1);
+    if (C) craig_set_params(C, PC);
+  }
+  int blk = blockIdx.x;
+  if (blk < l0.nblk + l1.nblk) {
+    const bool first = blk < l0.nblk;
+    if (!first) blk -= l0.nblk;
+    const double* src = first ? l0.src : l1.src;
+    double* dst = first ? l0.dst : l1.dst;
+    const double scale = first ? l0.scale : l1.scale;
+    const int lane = first ? l0.lane : l1.lane;
+    const int nb = first ? l0.nblk : l1.nblk;
+    const int64_t len = first ? l0.len : l1.len;
+    double* partials = first ? l0.partials : l1.partials;
+    double sq = 0.0;
+    for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < len; i += (int64_t)nb * kBlock) {
+      const double v = scale * src[i];
+      dst[i * NL + lane] = v;
+      sq += v * v;
+    }
+    const double t = block_sum(sq, red);
+    if (threadIdx.x == 0) partials[blk] = t;
+    return;
+  }
+  blk -= l0.nblk + l1.nblk;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!z.p[k]) continue;
+    for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < z.n[k]; i += (int64_t)nzblk * kBlock) z.p[k][i] = 0.0;
+  }
+}
+
 enum { LANE_LSQR = 1, LANE_CRAIG = 2 };
 
 // One Krylov recurrence of a (possibly fused) run.
@@ -801,24 +849,34 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     }
     itmax_all = std::max(itmax_all, L.itmax);
   }
-  hipLaunchKernelGGL(k_lane_params, dim3(1), dim3(1), 0, s, lsS[0], lsP[0], lsS[1], lsP[1], crS, crP);
-  h->launches++;
   const LaneCtl* c0 = lanes[0].ctl;
   const LaneCtl* c1 = lanes[NL - 1].ctl;
 
-  // ---- start-up: load right-hand sides, beta_1, (LSQR) alpha_1 and w_1
+  // ---- start-up: parameters, right-hand sides, beta_1 (one launch), then (LSQR) alpha_1 and w_1
   StepArgs none{};
   none.kind = STEP_NONE;
   StepArgs b0 = none, b1 = none;
+  LoadSeg ld[2] = {};
+  ZeroArgs z{};
+  int nzblk = 0;
   for (int l = 0; l < NL; ++l) {
     Lane& L = lanes[l];
     double* pe = l == 0 ? h->pE : h->pE2;
+    LoadSeg& g = ld[l];
+    g.src = L.rhs;
+    g.scale = L.rhs_scale;
+    g.lane = l;
+    g.partials = pe;
     if (L.kind == LANE_LSQR) {
-      // x = 0 is written by the w_1 start-up kernel (also when the recurrence ends at start-up)
-      hipLaunchKernelGGL(k_load_lane<NL>, dim3(gn), dim3(kBlock), 0, s, L.rhs, L.rhs_scale, LP, l, n, pe);
+      // x = 0 is written by the w_1 start-up update (also when the recurrence ends at start-up)
+      g.dst = LP;
+      g.len = n;
+      g.nblk = gn;
       (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
     } else {
-      ZeroArgs z{};
+      g.dst = SP;
+      g.len = m;
+      g.nblk = gm;
       z.p[0] = L.x;
       z.n[0] = n;
       z.p[1] = L.y;
@@ -829,11 +887,19 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
         z.p[3] = h->Cw2;
         z.n[3] = n;
       }
-      hipLaunchKernelGGL(k_zero_multi, dim3(gn), dim3(kBlock), 0, s, z);
-      hipLaunchKernelGGL(k_load_lane<NL>, dim3(gm), dim3(kBlock), 0, s, L.rhs, L.rhs_scale, SP, l, m, pe);
+      nzblk = gn;
     }
-    h->launches++;
   }
+  hipLaunchKernelGGL(k_startup<NL>, dim3(ld[0].nblk + ld[1].nblk + nzblk), dim3(kBlock), 0, s, lsS[0], lsP[0], lsS[1], lsP[1],
+                     crS, crP, ld[0], ld[1], z, nzblk);
+  h->launches++;
+  // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
+  // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
+  // iteration it; CRAIG's updates of iteration it (read the long pair and the OLD short pair) go with the A product,
+  // which therefore writes the alternate short pair (ping-pong).  Sharded: separate update launch, in place.
+  const bool fuse_upd = h->comm == nullptr;
+  UpdSeg winit[2] = {seg_none(), seg_none()};
+  bool craig_begun = false;
   if (any_lsqr) {
     launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none);
     // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes (CRAIG lane parked by ctl.skip)
@@ -857,21 +923,29 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       u.partials = h->pW[l];
       (w0.nblk ? w1 : w0) = u;
     }
+    if (fuse_upd && !s1.kind) {
+      // the CRAIG lane's beta_1 step shares the launch (it un-parks the lane: must follow the start-up product)
+      for (int l = 0; l < NL; ++l)
+        if (lanes[l].kind == LANE_CRAIG) {
+          s1 = step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]);
+          craig_begun = true;
+        }
+    }
     if (int rc = launch_step(h, s0, s1, /*sharded=*/true)) return rc;
-    launch_updates<NL>(h, w0, w1, seg_none());
+    if (fuse_upd) {  // w_1 rides in the first A' product
+      winit[0] = w0;
+      winit[1] = w1;
+    } else {
+      launch_updates<NL>(h, w0, w1, seg_none());
+    }
   }
   for (int l = 0; l < NL; ++l)
-    if (lanes[l].kind == LANE_CRAIG)
+    if (lanes[l].kind == LANE_CRAIG && !craig_begun)
       if (int rc = launch_step(h, step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]),
                                none, /*sharded=*/true))
         return rc;
 
   // ---- main loop
-  // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
-  // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
-  // iteration it; CRAIG's updates of iteration it (read the long pair and the OLD short pair) go with the A product,
-  // which therefore writes the alternate short pair (ping-pong).  Sharded: separate update launch, in place.
-  const bool fuse_upd = h->comm == nullptr;
   double* SPcur = SP;
   double* SPalt = h->SP2;
   const int look = std::max(1, o.lookahead);
@@ -900,9 +974,13 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     // LSQR's x/w update of the PREVIOUS iteration
     UpdSeg lu[2] = {seg_none(), seg_none()};
     int nlu = 0;
-    if (it > 1)
+    if (it > 1) {
       for (int l = 0; l < NL; ++l)
         if (lanes[l].kind == LANE_LSQR) lu[nlu++] = lsqr_upd_seg(l, it - 1);
+    } else {
+      lu[0] = winit[0];  // fused runs: w_1 = v_1 (empty segments otherwise)
+      lu[1] = winit[1];
+    }
     // first half-step of every lane: one A' product
     int npT = 0;
     if (fuse_upd) {
@@ -990,6 +1068,10 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     int ns = 0;
     for (int l = 0; l < NL; ++l)
       if (lanes[l].kind == LANE_LSQR && it >= 1) seg[ns++] = lsqr_upd_seg(l, it);
+    if (it == 0) {  // no iteration ran (itmax = 0): the pending w_1 / x = 0 start-up still has to happen
+      seg[0] = winit[0];
+      seg[1] = winit[1];
+    }
     launch_updates<NL>(h, seg[0], seg[1], seg_none());
   }
   return 0;  // the final stats were left in lanes[l].st by the step that ended each recurrence
