@@ -296,7 +296,10 @@ template <int NL, int TAG, bool IDX16 = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1) {
-  __shared__ double red[4 * NL];
+  // exactly 32 KB of LDS for two right-hand sides (five workgroups fit the CU's 160 KB): the reduction scratch
+  // aliases the head of the product buffer
+  __shared__ double prod[kSpmvNnz * NL];
+  double* red = prod;
   if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   const int L = (blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3);
   if (L >= A.nblk) return;
@@ -317,7 +320,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     }
     if (!any) return;
   }
-  __shared__ double prod[kSpmvNnz * NL];
   const int tid = threadIdx.x;
   const int r0 = bd.x, nr = bd.y, s = bd.z, e = bd.w;
   double sq[NL];
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     }
   }
   if (partials != nullptr) {
+    lds_barrier();  // `red` aliases `prod`: every wave must be past its phase-2 reads
     block_sum_lanes<NL>(sq, red);
     if (tid == 0) {
 #pragma unroll
@@ -419,11 +422,22 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 // with its group-relative column in one 32-bit word (12 B/nnz like CSR), its slot in the tile's ROW-major order:
 // products are scattered to LDS by slot and every row's segment is reduced exactly as in the CSR-stream kernel;
 // the per-row sums accumulate in registers across the tiles of the group.  Deterministic, no atomics.
-constexpr int kRgcsTile = 2048;
+#ifndef FPSQ_RGCS_TILE
+#define FPSQ_RGCS_TILE 2048
+#endif
+#ifndef FPSQ_RGCS_GROUP_NNZ
+#define FPSQ_RGCS_GROUP_NNZ 12800
+#endif
+#ifndef FPSQ_RGCS_MAX_ROWS
+#define FPSQ_RGCS_MAX_ROWS 128
+#endif
+constexpr int kRgcsTile = FPSQ_RGCS_TILE;
 constexpr int kRgcsColBits = 21;     // group-relative column < 2^21, slot < 2^11
-constexpr int kRgcsMaxPass = 4;      // rows per group <= kRgcsMaxPass * kBlock
-constexpr int kRgcsGroupNnz = 12800;
-constexpr int kRgcsMaxRows = 128;
+constexpr int kRgcsGroupNnz = FPSQ_RGCS_GROUP_NNZ;
+constexpr int kRgcsMaxRows = FPSQ_RGCS_MAX_ROWS;
+// row passes of the segment reduction: G lanes per row with G * R <= kBlock, so rows <= kBlock need a single pass
+constexpr int kRgcsMaxPass = (kRgcsMaxRows + kBlock - 1) / kBlock;
+static_assert(kRgcsTile <= 2048 && kRgcsTile % kBlock == 0, "slot field is 11 bits");
 
 struct RgcsGroup {        // 32 bytes, fetched with two independent 16-byte loads at the head of the workgroup
   int32_t r0, R;          // first row, #rows
@@ -447,7 +461,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                       double* partials, int grp_per_xcd, const UpdSeg u0,
                                                       const UpdSeg u1) {
-  __shared__ double red[4 * NL];
+  __shared__ double prod[kRgcsTile * NL];
+  double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
   if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
   const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
   if (g >= M.ng) return;
@@ -464,7 +479,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     any |= act[l];
   }
   if (!any) return;
-  __shared__ double prod[kRgcsTile * NL];
   const int tid = threadIdx.x;
   const int r0 = gd.r0, R = gd.R, e0 = gd.e0, e1 = gd.e1, cmin = gd.cmin;
   const uint16_t* tp = M.tptr + gd.tp;
