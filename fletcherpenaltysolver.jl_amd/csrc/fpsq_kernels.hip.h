@@ -134,7 +134,8 @@ __device__ __forceinline__ void row_segment_sum(const double* prod, int first, i
 // memory round trips per row.
 template <int NL>
 __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, const double* ca, const double* cb,
-                                             const bool* act, const double* yin, double* yout, double* sq) {
+                                             const bool* act, const double* yin, double* yout, double* sq,
+                                             const double* ypre = nullptr) {
   double yv[NL];
   bool need = false;
 #pragma unroll
@@ -142,7 +143,10 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
     yv[l] = 0.0;
     need |= act[l] && cb[l] != 0.0;
   }
-  if (need) {
+  if (ypre) {  // fetched at the head of the workgroup, one memory round trip ahead of this point
+#pragma unroll
+    for (int l = 0; l < NL; ++l) yv[l] = ypre[l];
+  } else if (need) {
     if (NL == 2) {
       const double2 t = *reinterpret_cast<const double2*>(yin + row * 2);
       yv[0] = t.x;
@@ -357,6 +361,20 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     const int g = tid / G, gl = tid % G;
     const int rq0 = g < nr ? g : 0;
     const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
+    // the yin values of the first row pass, requested now: the epilogue would otherwise expose their latency (a
+    // workgroup's life is a chain of ~4 memory round trips; measured +4 % evaluations/s at the headline size)
+    double ypre[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ypre[l] = 0.0;
+    if (yin != nullptr) {
+      if (NL == 2) {
+        const double2 t = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
+        ypre[0] = t.x;
+        ypre[NL - 1] = t.y;
+      } else {
+        ypre[0] = yin[r0 + rq0];
+      }
+    }
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
     double v[kPer];
@@ -398,7 +416,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] += __shfl_down(acc[l], off, 64);
       }
-      if (valid && gl == 0) row_epilogue<NL>((size_t)(r0 + rr), acc, ca, cb, act, yin, yout, sq);
+      if (valid && gl == 0)
+        row_epilogue<NL>((size_t)(r0 + rr), acc, ca, cb, act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
     }
   }
   if (partials != nullptr) {
