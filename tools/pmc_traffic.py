@@ -1,0 +1,64 @@
+"""Post-process the two rocprofv3 PMC passes into profiles/rNN_pmc_traffic.json.
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --cpu-evals 0
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --cpu-evals 0
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv J > profiles/r01_pmc_traffic.json
+
+J = joint Krylov iterations per evaluation (max of the LSQR / CRAIG counts bench.py prints).  Corrections per
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KB and reports half of the bytes of coalesced streaming reads on
+gfx950 (hbm_read = 2 * 1024 * FETCH_SIZE); WRITE_SIZE is exact (hbm_write = 1024 * WRITE_SIZE)."""
+import collections, csv, json, sys
+
+fetch_csv, write_csv, J = sys.argv[1], sys.argv[2], int(sys.argv[3])
+n, m, nnz = 1_000_000, 100_000, 10_000_000
+
+
+def load(path, floor):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        v = float(r["Counter_Value"])
+        if v > floor:  # launches past convergence move nothing
+            d[r["Kernel_Name"]].append(v)
+    return d
+
+
+f, w = load(fetch_csv, 1000.0), load(write_csv, 100.0)
+
+
+def pb(nrhs):
+    a = 12 * nnz + 4 * (m + 1) + 8 * nrhs * (n + 2 * m)
+    at = 12 * nnz + 4 * (n + 1) + 8 * nrhs * (m + 2 * n)
+    return a, at
+
+
+a1, at1 = pb(1)
+a2, at2 = pb(2)
+upd_at, upd_a = 8 * 5 * m, 8 * (3 * n + 5 * m)
+alg = {  # average algorithmic bytes of a productive launch (products + the vector updates riding in them)
+    "k_spmv_rgcs<2>": (J * (a2 + upd_a) + a2) / (J + 1),
+    "k_spmv<2, 1": at2 + upd_at * (J - 1) / J,
+    "k_spmv_rgcs<1>": a1,
+    "k_spmv<1, 1": at1,
+}
+mix = {"k_spmv_rgcs<2>": J + 1, "k_spmv<2, 1": J, "k_spmv_rgcs<1>": 1, "k_spmv<1, 1": 2}
+out = {"_how": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "workload": "pde-control-like n=1e6 m=1e5 nnz=1e7",
+       "joint_iterations": J, "kernels": {}}
+tb = ab = 0.0
+for key in alg:
+    kn = [k for k in f if key in k]
+    assert len(kn) == 1, (key, kn)
+    fv, wv = f[kn[0]], w[kn[0]]
+    hbm = 2 * 1024 * sum(fv) / len(fv) + 1024 * sum(wv) / len(wv)
+    out["kernels"][key] = {"productive_launches": len(fv), "FETCH_SIZE_KB": round(sum(fv) / len(fv), 1),
+                           "WRITE_SIZE_KB": round(sum(wv) / len(wv), 1), "hbm_bytes": round(hbm),
+                           "algorithmic_bytes": round(alg[key]), "hbm_over_algorithmic": round(hbm / alg[key], 3)}
+    tb += mix[key] * hbm
+    ab += mix[key] * alg[key]
+tot = sum(mix.values())
+out["per_evaluation_mix"] = mix
+out["traffic_bytes_per_productive_launch"] = round(tb / tot)
+out["algorithmic_bytes_per_productive_launch"] = round(ab / tot)
+out["traffic_over_algorithmic"] = round(tb / ab, 3)
+out["note"] = ("A' is stored with 16-bit block-relative columns (10 B/nnz against the 12 B/nnz of the algorithmic count), so its "
+               "HBM traffic is BELOW the algorithmic bytes; the column-sorted A product re-reads part of its x window through L2.")
+print(json.dumps(out, indent=1))
