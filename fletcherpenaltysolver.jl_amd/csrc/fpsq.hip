@@ -39,6 +39,8 @@ struct DevCsr {
   uint16_t* col16 = nullptr;   // compressed columns (see CsrView), null when not representable
   int32_t* colbase = nullptr;
   int4* blkdesc = nullptr;
+  bool padded = false;         // vals / col16 / colind hold nblk blocks of kSpmvNnz slots (see k_spmv<.., PAD>)
+  int64_t nstore = 0;          // stored value slots: nnz, or nblk * kSpmvNnz when padded
   CsrView view() const { return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows, col16, colbase, blkdesc}; }
 };
 
@@ -239,6 +241,15 @@ int dalloc(fpsq_handle h, T** p, size_t count) {
   return 0;
 }
 
+// release one dalloc'ed buffer before the handle dies
+template <class T>
+void dfree(fpsq_handle h, T** p) {
+  auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)*p);
+  if (it != h->allocs.end()) h->allocs.erase(it);
+  hipFree(*p);
+  *p = nullptr;
+}
+
 inline int ew_grid(int64_t n) {
   int64_t g = (n + kBlock - 1) / kBlock;
   return (int)std::max<int64_t>(1, std::min<int64_t>(g, kEwBlocksMax));
@@ -294,6 +305,7 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
   D.nrows = H.nrows;
   D.ncols = H.ncols;
   D.nnz = (int64_t)H.colind.size();
+  D.nstore = D.nnz;
   std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows);
   D.nblk = (int32_t)rb.size() - 1;
   if (int rc = dalloc(h, &D.rowptr, H.rowptr.size())) return rc;
@@ -337,6 +349,55 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
       HIPCHK(h, hipMemcpy(D.colbase, base.data(), base.size() * 4, hipMemcpyHostToDevice));
     }
   }
+  return 0;
+}
+
+// Re-store an uploaded CSR in the padded block layout of k_spmv<.., PAD>.  `perm` (value source of every compact entry)
+// is rewritten to the padded numbering with -1 in the padding slots.  No-op when some block is one long row.
+int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevCsr& D) {
+  if (D.nnz == 0 || h->opt.jac_format == 1) return 0;
+  std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows);
+  const int nblk = (int)rb.size() - 1;
+  for (int b = 0; b < nblk; ++b)
+    if (H.rowptr[rb[b + 1]] - H.rowptr[rb[b]] > kSpmvNnz) return 0;
+  const size_t slots = (size_t)nblk * kSpmvNnz;
+  if (slots >= (size_t)INT32_MAX) return 0;
+  std::vector<int32_t> pperm(slots, -1), pcol;
+  std::vector<uint16_t> pc16;
+  std::vector<int32_t> base;
+  const bool idx16 = D.col16 != nullptr;
+  if (idx16) {
+    pc16.assign(slots, 0);
+    base.resize(nblk);
+    HIPCHK(h, hipMemcpy(base.data(), D.colbase, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+  } else {
+    pcol.assign(slots, 0);
+  }
+  for (int b = 0; b < nblk; ++b) {
+    const int s = H.rowptr[rb[b]], e = H.rowptr[rb[b + 1]];
+    for (int k = s; k < e; ++k) {
+      const size_t q = (size_t)b * kSpmvNnz + (k - s);
+      pperm[q] = perm[k];
+      if (idx16) pc16[q] = (uint16_t)(H.colind[k] - base[b]);
+      else pcol[q] = H.colind[k];
+    }
+  }
+  dfree(h, &D.vals);
+  if (int rc = dalloc(h, &D.vals, slots)) return rc;
+  HIPCHK(h, hipMemset(D.vals, 0, slots * 8));
+  if (idx16) {
+    dfree(h, &D.col16);
+    dfree(h, &D.colind);  // the 16-bit form is the only one the padded kernel reads
+    if (int rc = dalloc(h, &D.col16, slots)) return rc;
+    HIPCHK(h, hipMemcpy(D.col16, pc16.data(), slots * 2, hipMemcpyHostToDevice));
+  } else {
+    dfree(h, &D.colind);
+    if (int rc = dalloc(h, &D.colind, slots)) return rc;
+    HIPCHK(h, hipMemcpy(D.colind, pcol.data(), slots * 4, hipMemcpyHostToDevice));
+  }
+  D.padded = true;
+  D.nstore = (int64_t)slots;
+  perm.swap(pperm);
   return 0;
 }
 
@@ -471,6 +532,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   transpose_structure(HA, HT, perm);
   if (int rc = upload_csr(h, HA, h->A)) return rc;
   if (int rc = upload_csr(h, HT, h->AT)) return rc;
+  if (int rc = pad_blocks(h, HT, perm, h->AT)) return rc;
   if (int rc = build_rgcs(h, HA, h->RA)) return rc;
   if (int rc = dalloc(h, &h->permT, perm.size())) return rc;
   if (!perm.empty()) HIPCHK(h, hipMemcpy(h->permT, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
@@ -534,8 +596,12 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
       launch_product(h, k_spmv<NL, TAG_A, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
     else if (tag == TAG_A)
       launch_product(h, k_spmv<NL, TAG_A, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+    else if (M.col16 && M.padded)
+      launch_product(h, k_spmv<NL, TAG_AT, true, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
     else if (M.col16)
       launch_product(h, k_spmv<NL, TAG_AT, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+    else if (M.padded)
+      launch_product(h, k_spmv<NL, TAG_AT, false, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
     else
       launch_product(h, k_spmv<NL, TAG_AT, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
   }
@@ -1523,7 +1589,8 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
     } else {
       HIPCHK(h, hipMemcpyAsync(h->A.vals, vals, (size_t)h->nnz * 8, hipMemcpyDefault, s));
     }
-    hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->A.vals, h->permT, h->AT.vals, h->nnz);
+    hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->AT.nstore)), dim3(kBlock), 0, s, h->A.vals, h->permT, h->AT.vals,
+                       h->AT.nstore);
     if (h->RA.ok)
       hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->A.vals, h->RA.vperm, h->RA.vals, h->nnz);
   }

@@ -296,7 +296,11 @@ __device__ __forceinline__ bool run_fused_updates(const UpdSeg& u0, const UpdSeg
 // chosen from the block's row count: ~100-nnz rows of A get 8 lanes each, ~10-nnz rows of A' one lane each).
 // blockIdx is remapped so that each XCD walks a contiguous eighth of the matrix: its private L2 then caches one
 // slice of x instead of all of it.  Summation order is a pure function of the sparsity => reproducible.
-template <int NL, int TAG, bool IDX16 = false>
+// PAD: every row block's entries are stored at [L * kSpmvNnz, ...) and zero-padded to kSpmvNnz (CsrView::vals /
+// col16 / colind then point to the padded arrays): the matrix stream needs neither the block descriptor (one link
+// less in the workgroup's chain of dependent memory round trips) nor bounds checks.  Requires that no block is a
+// long row.
+template <int NL, int TAG, bool IDX16 = false, bool PAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1) {
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 #pragma unroll
   for (int l = 0; l < NL; ++l) sq[l] = 0.0;
 
-  if (e - s > kSpmvNnz) {
+  if (!PAD && e - s > kSpmvNnz) {
     // one long row (nr == 1): every thread strides over it, no LDS staging
     double acc[NL];
 #pragma unroll
@@ -380,11 +384,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     double v[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      const int i = s + tid + k * kBlock;
-      const bool ok = i < e;
-      const int ii = ok ? i : s;
-      cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
-      v[k] = ok ? A.vals[ii] : 0.0;
+      if (PAD) {
+        const size_t ii = (size_t)L * kSpmvNnz + tid + k * kBlock;
+        cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
+        v[k] = A.vals[ii];
+      } else {
+        const int i = s + tid + k * kBlock;
+        const bool ok = i < e;
+        const int ii = ok ? i : s;
+        cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
+        v[k] = ok ? A.vals[ii] : 0.0;
+      }
     }
     if (NL == 1) {
       double xv[kPer];
@@ -603,8 +613,10 @@ __global__ __launch_bounds__(kBlock) void k_zero_multi(ZeroArgs z) {
 // vals_out[t] = vals_in[perm[t]]  (refresh of the A' copy when the Jacobian values change)
 __global__ __launch_bounds__(kBlock) void k_gather(const double* __restrict__ in, const int32_t* __restrict__ perm,
                                                    double* __restrict__ out, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    out[i] = in[perm[i]];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t p = perm[i];
+    out[i] = p >= 0 ? in[p] : 0.0;  // (< 0: padding slot of a padded block layout)
+  }
 }
 
 // CSR slot value = sum of the COO entries that map to it, in sorted (fixed) order: duplicates are summed like
