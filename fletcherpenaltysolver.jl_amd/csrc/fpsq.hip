@@ -54,6 +54,7 @@ struct DevRgcs {
   double* vals = nullptr;
   int32_t* vperm = nullptr;  // vals[t] = A.vals[vperm[t]]
   int64_t nnz = 0;
+  int64_t nstore = 0;        // stored value slots (> nnz in the padded layout)
 };
 
 // ------------------------------------------------------------------ communicators (row-sharded A)
@@ -480,21 +481,44 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
   }
   tptr.push_back(0);
   tptr.push_back(0);  // the kernel reads two uint16 at once
+  // Padded layout (k_spmv_rgcs<.., PAD>): group g at [g * budget, ...), zero entries up to the end of its last tile.
+  bool padded = (int64_t)groups.size() * budget < (int64_t)INT32_MAX;
+  for (const RgcsGroup& gd : groups) padded = padded && gd.e1 - gd.e0 <= budget;
+  int64_t nstore = nnz;
+  if (padded) {
+    nstore = (int64_t)groups.size() * budget;
+    std::vector<uint32_t> pp((size_t)nstore, 0u);
+    std::vector<int32_t> vp((size_t)nstore, -1);
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      RgcsGroup& gd = groups[gi];
+      const int cnt = gd.e1 - gd.e0;
+      const size_t dst = gi * (size_t)budget;
+      for (int k = 0; k < cnt; ++k) {
+        pp[dst + k] = pidx[gd.e0 + k];
+        vp[dst + k] = vperm[gd.e0 + k];
+      }
+      const int full = (cnt + kRgcsTile - 1) / kRgcsTile * kRgcsTile;
+      for (int k = cnt; k < full; ++k) pp[dst + k] = (uint32_t)(k % kRgcsTile) << kRgcsColBits;  // unused slot, value 0
+    }
+    pidx.swap(pp);
+    vperm.swap(vp);
+  }
   uint32_t* dp;
   RgcsGroup* dg;
   uint16_t* d5;
-  if (int rc = dalloc(h, &dp, (size_t)nnz + 1)) return rc;
-  if (int rc = dalloc(h, &D.vals, (size_t)nnz + 1)) return rc;
-  if (int rc = dalloc(h, &D.vperm, (size_t)nnz)) return rc;
+  if (int rc = dalloc(h, &dp, (size_t)nstore + 1)) return rc;
+  if (int rc = dalloc(h, &D.vals, (size_t)nstore + 1)) return rc;
+  if (int rc = dalloc(h, &D.vperm, (size_t)nstore)) return rc;
   if (int rc = dalloc(h, &dg, groups.size())) return rc;
   if (int rc = dalloc(h, &d5, tptr.size() + 2)) return rc;
-  HIPCHK(h, hipMemcpy(dp, pidx.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemset(dp + nnz, 0, 4));
-  HIPCHK(h, hipMemset(D.vals + nnz, 0, 8));
-  HIPCHK(h, hipMemcpy(D.vperm, vperm.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dp, pidx.data(), (size_t)nstore * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemset(dp + nstore, 0, 4));
+  HIPCHK(h, hipMemset(D.vals, 0, ((size_t)nstore + 1) * 8));
+  HIPCHK(h, hipMemcpy(D.vperm, vperm.data(), (size_t)nstore * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dg, groups.data(), groups.size() * sizeof(RgcsGroup), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d5, tptr.data(), tptr.size() * 2, hipMemcpyHostToDevice));
-  D.view = RgcsView{dp, D.vals, dg, d5, (int32_t)groups.size(), (int32_t)H.nrows};
+  D.view = RgcsView{dp, D.vals, dg, d5, (int32_t)groups.size(), (int32_t)H.nrows, padded ? budget : 0};
+  D.nstore = nstore;
   D.nnz = nnz;
   D.ok = true;
   return 0;
@@ -587,7 +611,12 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
   const int nupd = u0.nblk + u1.nblk;
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
-    launch_product(h, k_spmv_rgcs<NL>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+    if (h->RA.view.stride)
+      launch_product(h, k_spmv_rgcs<NL, true>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd,
+                     u0, u1);
+    else
+      launch_product(h, k_spmv_rgcs<NL, false>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials,
+                     per_xcd, u0, u1);
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
@@ -1592,7 +1621,8 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
     hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->AT.nstore)), dim3(kBlock), 0, s, h->A.vals, h->permT, h->AT.vals,
                        h->AT.nstore);
     if (h->RA.ok)
-      hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, h->A.vals, h->RA.vperm, h->RA.vals, h->nnz);
+      hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->RA.nstore)), dim3(kBlock), 0, s, h->A.vals, h->RA.vperm, h->RA.vals,
+                         h->RA.nstore);
   }
   HIPCHK(h, hipStreamSynchronize(s));
   h->have_values = true;

@@ -483,9 +483,12 @@ struct RgcsView {
   const uint16_t* tptr;   // per tile: R + 1 row-segment boundaries in slot space
   int32_t ng;
   int32_t nrows;
+  int32_t stride;         // padded layout: group g's entries start at g * stride (0: compact, start = grp[g].e0)
 };
 
-template <int NL>
+// PAD: the groups' entries are stored at a fixed stride and zero-padded to whole tiles, so the first tile's stream
+// does not wait for the group descriptor and no load needs a bounds check.
+template <int NL, bool PAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                       double* partials, int grp_per_xcd, const UpdSeg u0,
@@ -495,6 +498,21 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
   const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
   if (g >= M.ng) return;
+  constexpr int kPer = kRgcsTile / kBlock;
+  const int tid = threadIdx.x;
+  uint32_t pk[kPer];
+  double v[kPer];
+  // everything the next tile needs from global memory, issued together and left untouched until it is consumed
+  auto fetch_stream = [&](int base, int lo, int hi) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = base + tid + k * kBlock;
+      const int ii = PAD ? i : (i < hi ? i : lo);
+      pk[k] = M.pidx[ii];
+      v[k] = M.vals[ii];
+    }
+  };
+  if (PAD) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
   const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
   const LaneCtl* c[2] = {ctl0, ctl1};
   double ca[NL], cb[NL];
@@ -508,8 +526,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     any |= act[l];
   }
   if (!any) return;
-  const int tid = threadIdx.x;
-  const int r0 = gd.r0, R = gd.R, e0 = gd.e0, e1 = gd.e1, cmin = gd.cmin;
+  const int r0 = gd.r0, R = gd.R, e0 = PAD ? g * M.stride : gd.e0, e1 = PAD ? g * M.stride + (gd.e1 - gd.e0) : gd.e1;
+  const int cmin = gd.cmin;
   const uint16_t* tp = M.tptr + gd.tp;
   int G = 1;
   while (G < 64 && G * 2 * R <= kBlock) G <<= 1;
@@ -519,19 +537,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   for (int p = 0; p < kRgcsMaxPass; ++p)
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[p][l] = 0.0;
-  constexpr int kPer = kRgcsTile / kBlock;
-  uint32_t pk[kPer];
-  double v[kPer];
   uint32_t traw[kRgcsMaxPass];  // this tile's LDS segment [a, b) of each of my rows: two uint16 in one raw dword
-  // everything the next tile needs from global memory, issued together and left untouched until it is consumed
-  auto fetch = [&](int base, int tile) {
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int i = base + tid + k * kBlock;
-      const int ii = i < e1 ? i : e0;
-      pk[k] = M.pidx[ii];
-      v[k] = M.vals[ii];
-    }
+  auto fetch_segs = [&](int tile) {
     const uint16_t* tpt = tp + (size_t)tile * (R + 1);
 #pragma unroll
     for (int p = 0; p < kRgcsMaxPass; ++p) {
@@ -540,7 +547,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       __builtin_memcpy(&traw[p], tpt + rq, 4);
     }
   };
-  fetch(e0, 0);
+  auto fetch = [&](int base, int tile) {
+    fetch_stream(base, e0, e1);
+    fetch_segs(tile);
+  };
+  if (PAD) fetch_segs(0);
+  else fetch(e0, 0);
   int tile = 0;
   for (int base = e0; base < e1; base += kRgcsTile, ++tile) {
     int sa[kRgcsMaxPass], sb[kRgcsMaxPass];
@@ -550,7 +562,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       double vq[kPer];
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
-        const bool ok = base + tid + k * kBlock < e1;  // out-of-range lanes park a zero in an unused slot
+        // out-of-range lanes park a zero in an unused slot (PAD: the stored padding entries already say so)
+        const bool ok = PAD || base + tid + k * kBlock < e1;
         pq[k] = ok ? pk[k] : ((uint32_t)(tid + k * kBlock) << kRgcsColBits);
         vq[k] = ok ? v[k] : 0.0;
         const int col = cmin + (int)(pq[k] & ((1u << kRgcsColBits) - 1));
