@@ -426,6 +426,8 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
     const int64_t kmax = std::max<int64_t>(1, (int64_t)(std::min<double>(kRgcsMaxRows * avg, kRgcsGroupNnz) / kRgcsTile));
     const int64_t k = std::min(kmax, std::max<int64_t>(1, (nnz + slots * kRgcsTile - 1) / (slots * kRgcsTile)));
     budget = (int)(k * kRgcsTile);
+    if (const char* ev = std::getenv("FPSQ_RGCS_TILES"))  // tuning override: tiles per group
+      budget = (int)(std::max<int64_t>(1, std::min<int64_t>(kmax, std::atoi(ev))) * kRgcsTile);
   }
   int64_t r = 0;
   while (r < H.nrows) {
