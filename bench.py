@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pde-control-like n=1e6 m=1e5 nnz=1e7", choices=list(WORKLOADS))
+    ap.add_argument("--op", default="objgrad", choices=["objgrad", "hprod-solves"],
+                    help="objgrad = the headline metric; hprod-solves = solve_two_least_squares (the two solves of every "
+                         "hprod!, solve_linear_system.jl:79-105) on distinct right-hand-side pairs: SURVEY 8(f) rank 1")
     ap.add_argument("--delta", type=float, default=0.0, help="regularisation; 0 = first outer iteration (algo.jl:46)")
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--lookahead", type=int, default=0, help="override fpsq_options.lookahead (0 = library default)")
@@ -107,7 +110,18 @@ def main():
     for t in range(K + W):
         xs[t].copy_(torch.from_numpy(qp.point(1 + t + (0 if sharded else rank) * (K + W))))
     gx = torch.empty(n, dtype=torch.float64, device=dev)
+    hp = args.op == "hprod-solves"
+    if hp:  # the points double as right-hand sides: (xs[t], xs[t] reversed) are the two n-vectors of step t
+        if sharded:
+            raise SystemExit("--op hprod-solves: single GPU or replicas only")
+        xr = torch.flip(xs, dims=[1]).contiguous()
+        hp_out = [torch.empty(k, dtype=torch.float64, device=dev) for k in (n, m, n, m)]
     torch.cuda.synchronize()
+
+    def step(t):
+        if hp:
+            return None, model.solve_two_least_squares(xs[t], xr[t], *hp_out)
+        return model.objgrad(xs[t], gx=gx)
 
     def barrier():
         if world > 1:
@@ -116,12 +130,12 @@ def main():
 
     its = []
     for t in range(W):
-        model.objgrad(xs[t], gx=gx)
+        step(t)
     barrier()
     t0 = time.perf_counter()
     soft = 0
     for t in range(W, W + K):
-        _, rc = model.objgrad(xs[t], gx=gx)
+        _, rc = step(t)
         soft |= rc
         its.append((model.stats[0].niter, model.stats[1].niter))
     barrier()
@@ -137,7 +151,7 @@ def main():
     model.set_profiling(True)
     pa, pat, t_ms, tot_ms = np.zeros(2), np.zeros(2), 0.0, 0.0
     for t in range(W, W + K):
-        model.objgrad(xs[t], gx=gx)
+        step(t)
         info = model.info()
         pa += info["last_prod_a"]
         pat += info["last_prod_at"]
@@ -160,7 +174,11 @@ def main():
     upd_at = 0 if sharded else 8 * 5 * m
     upd_a = 0 if sharded else 8 * ((3 if args.delta == 0.0 else 5) * n + 5 * m)
     for il, ic in its:
-        if args.fuse:
+        if hp:  # two LSQR recurrences: J two-RHS A' products (both x/w updates riding), J + 1 two-RHS A products,
+            J = max(il, ic)  # then p_k = rhs_k - A'q_k with one right-hand side each
+            nbytes += J * at2 + (J + 1) * a2 + 2 * at1 + (max(il - 1, 0) + max(ic - 1, 0)) * upd_at
+            productive += 2 * J + 3
+        elif args.fuse:
             J = max(il, ic)
             nbytes += J * at2 + (J + 1) * a2 + a1 + 2 * at1
             nbytes += max(il - 1, 0) * upd_at + ic * upd_a
@@ -183,20 +201,21 @@ def main():
     # HBM traffic per productive launch from the committed PMC passes (profiles/: bench.py cannot run rocprofv3 on itself)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1:
+        if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1 and not hp:
             roofline["traffic"] = pmc["traffic_bytes_per_productive_launch"]
             roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
     except (OSError, KeyError, ValueError):
         pass
 
     out = {
-        "metric": "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "evals/s",
+        "metric": "solve_two_least_squares calls/sec (the two KKT solves of one hprod!)" if hp
+        else "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "calls/s" if hp else "evals/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4),
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "m": m, "nnz": nnz, "sigma": sigma, "rho": rho,
                    "delta": args.delta, "fuse_two_rhs": args.fuse,
-                   "krylov": "LSQR+CRAIG, atol=rtol=sqrt(eps) (reference defaults)",
+                   "krylov": ("LSQR+LSQR" if hp else "LSQR+CRAIG") + ", atol=rtol=sqrt(eps) (reference defaults)",
                    "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
                    "all_solved": soft == 0,
                    "parallelism": "single GPU" if world == 1 else
@@ -215,12 +234,18 @@ def main():
         t0 = time.perf_counter()
         done = 0
         for t in range(args.cpu_evals):
-            oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, args.delta)
+            if hp:
+                r1 = qp.point(1 + W + t)
+                oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, args.delta, r1,
+                                               np.ascontiguousarray(r1[::-1]))
+            else:
+                oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, args.delta)
             done += 1
             if time.perf_counter() - t0 > 30.0:
                 break
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(done / dt, 4), "unit": "evals/s", "cores": 1, "kind": "port",
+        out["cpu_baseline"] = {"value": round(done / dt, 4), "unit": "calls/s" if hp else "evals/s", "cores": 1,
+                               "kind": "port",
                                "sample": f"{done} evaluations of the same workload (same points as the first timed "
                                          "steps), oracle/fps_oracle.c, gcc -O3 -march=native, single thread "
                                          "(the reference is single-threaded Julia; Julia is not installed)"}

@@ -70,6 +70,23 @@ class DeviceEqQP:
                                                    _lib.ptr(gs), self.stats))
         return fx.value, rc
 
+    # -- the QDSolver seam on the same handle; every argument: numpy array, torch tensor (host or device) or address
+    def solve_two_mixed(self, rhs1, rhs2, p1, q1, p2, q2):
+        """src/solve_linear_system.jl:107-140 on the Jacobian the model holds (outputs are caller-owned buffers)."""
+        return self._check(self._lib.fpsq_solve_two_mixed(self._h, _lib.ptr(rhs1), _lib.ptr(rhs2), _lib.ptr(p1),
+                                                          _lib.ptr(q1), _lib.ptr(p2), _lib.ptr(q2), self.stats))
+
+    def solve_two_least_squares(self, rhs1, rhs2, p1, q1, p2, q2):
+        """src/solve_linear_system.jl:79-105: the two solves of every hprod! (two LSQR recurrences, fused)."""
+        return self._check(self._lib.fpsq_solve_two_least_squares(self._h, _lib.ptr(rhs1), _lib.ptr(rhs2),
+                                                                  _lib.ptr(p1), _lib.ptr(q1), _lib.ptr(p2),
+                                                                  _lib.ptr(q2), self.stats))
+
+    def ys_gs(self, g, c, gs, ys, v, w):
+        """_compute_ys_gs! after the user-model evaluations (src/model-Fletcherpenaltynlp.jl:242-248)."""
+        return self._check(self._lib.fpsq_ys_gs(self._h, _lib.ptr(g), _lib.ptr(c), self.sigma, _lib.ptr(gs),
+                                                _lib.ptr(ys), _lib.ptr(v), _lib.ptr(w), self.stats))
+
     def info(self):
         i = _lib.Info()
         self._check(self._lib.fpsq_get_info(self._h, C.byref(i)))

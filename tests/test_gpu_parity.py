@@ -477,3 +477,55 @@ def test_config_random_eqqp_cfg2_size(oracle):
     assert (dev.stats[0].niter, dev.stats[1].niter) == (o["stats"][0].niter, o["stats"][1].niter)
     assert _rel(gx, o["gx"]) < 1e-8 and abs(fx - o["fx"]) <= 1e-8 * abs(o["fx"])
     dev.close()
+
+
+def test_config_headline_full_size_properties():
+    """BASELINE configs[4] / the bench workload (n = 1e6, m = 1e5, nnz = 1e7): too large for the CPU restatement to
+    finish in seconds, so parity goes through size-independent properties checked with an independent host CSR:
+    the KKT residuals of what the solves return, the closed forms of phi and grad(phi), and linearity of the solves."""
+    import scipy.sparse as sp
+
+    qp = problems.pde_control_like(n=1_000_000, m=100_000)
+    assert (qp.n, qp.m) == (1_000_000, 100_000) and qp.nnz >= 10_000_000
+    A = sp.csr_matrix((qp.vals, qp.colind, qp.rowptr), shape=(qp.m, qp.n))
+    sigma, rho = 1e3, 1.0
+    for delta in (0.0, SE):
+        dev = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=delta)
+        x = qp.point(3)
+        g = qp.qdiag * x + qp.d
+        c = A @ x - qp.b
+        # (1) the two systems of solve_two_mixed: K [p1; q1] = [g; 0],  K [p2; q2] = [0; c]
+        p1, q1, p2, q2 = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)
+        rc_mixed = dev.solve_two_mixed(g, c, p1, q1, p2, q2)
+        # delta = sqrt(eps): CRAIG with M = (1/delta) I reaches the condition-number limit ln_conlim = 1/sqrt(eps) of
+        # the reference's defaults (struct.jl:107) after 12 iterations and stops "ill-conditioned": a soft failure the
+        # reference only warns about (linear_system.jl:136-138); the C restatement stops at the same iteration
+        assert rc_mixed == (0 if delta == 0.0 else 2)
+        it_mixed = (dev.stats[0].niter, dev.stats[1].niter)
+        assert 5 <= it_mixed[0] <= 60 and 5 <= it_mixed[1] <= 60
+        tol = 2e-6  # Krylov stop at sqrt(eps) relative residual estimates; cond(A) ~ 10 on this generator
+        assert np.linalg.norm(p1 + A.T @ q1 - g) <= tol * np.linalg.norm(g)
+        assert np.linalg.norm(A @ p1 - delta * q1) <= tol * np.linalg.norm(g)
+        tol2 = tol if rc_mixed == 0 else 1e-3  # (the early "ill-conditioned" stop leaves a 1e-4 relative residual)
+        assert np.linalg.norm(p2 + A.T @ q2) <= tol2 * np.linalg.norm(c)
+        assert np.linalg.norm(A @ p2 - delta * q2 - c) <= tol2 * np.linalg.norm(c)
+        # (2) objgrad closed forms from (ys, gs, v = p2):  model:244-248, 362-369, 385-397, 424-431
+        gx, ys, gs = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n)
+        fx, rc = dev.objgrad(x, gx=gx, ys=ys, gs=gs)
+        assert rc == rc_mixed and (dev.stats[0].niter, dev.stats[1].niter) == it_mixed
+        assert _rel(ys, q1 + sigma * q2) < 1e-12 and _rel(gs, p1 + sigma * p2) < 1e-12
+        f = 0.5 * np.dot(x, qp.qdiag * x) + np.dot(qp.d, x)
+        assert abs(fx - (f - np.dot(c, ys) + 0.5 * rho * np.dot(c, c))) <= 1e-11 * max(1.0, abs(fx))
+        expect = gs - qp.qdiag * p2 + sigma * p2 + rho * (A.T @ c)
+        assert _rel(gx, expect) < 1e-11
+        # (3) solve_two_least_squares (hprod!): K [p; q] = [rhs; 0] for two right-hand sides at once; linear in rhs
+        r1, r2 = qp.point(11), qp.point(12)
+        a1, b1, a2, b2 = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)
+        assert dev.solve_two_least_squares(r1, r2, a1, b1, a2, b2) == 0
+        for rhs, pp, qq in ((r1, a1, b1), (r2, a2, b2)):
+            assert np.linalg.norm(pp + A.T @ qq - rhs) <= tol * np.linalg.norm(rhs)
+            assert np.linalg.norm(A @ pp - delta * qq) <= tol * np.linalg.norm(rhs)
+        s1, t1, s2, t2 = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)
+        assert dev.solve_two_least_squares(r1 + 2.0 * r2, r2, s1, t1, s2, t2) == 0
+        assert _rel(t1, b1 + 2.0 * b2) < 1e-5 and _rel(t2, b2) < 1e-9
+        dev.close()
