@@ -249,6 +249,25 @@ def main():
                                "sample": f"{done} evaluations of the same workload (same points as the first timed "
                                          "steps), oracle/fps_oracle.c, gcc -O3 -march=native, single thread "
                                          "(the reference is single-threaded Julia; Julia is not installed)"}
+        # the same restatement with OpenMP on every host core (SURVEY.md 8d asks for both); a second number, not `value`
+        try:
+            t0 = time.perf_counter()
+            done2 = 0
+            for t in range(args.cpu_evals):
+                if hp:
+                    r1 = qp.point(1 + W + t)
+                    oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, args.delta, r1,
+                                                   np.ascontiguousarray(r1[::-1]), threaded=True)
+                else:
+                    oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, args.delta, threaded=True)
+                done2 += 1
+                if time.perf_counter() - t0 > 15.0:
+                    break
+            out["cpu_baseline"]["all_cores"] = {"value": round(done2 / (time.perf_counter() - t0), 4),
+                                                "cores": len(os.sched_getaffinity(0)),
+                                                "kind": "port, OpenMP (oracle/libfps_oracle_omp.so)"}
+        except (OSError, AttributeError) as e:  # no libgomp on this host
+            out["cpu_baseline"]["all_cores"] = {"value": None, "error": str(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     model.close()

@@ -102,7 +102,17 @@ void fpo_default_options(int64_t n, int64_t m, fpo_options *o) {
 /* ------------------------------------------------------------------ basic linear algebra */
 
 /* y = A x   (the body of jprod! for a linear-constraint model) */
+/* FPO_OMP (libfps_oracle_omp.so, the all-cores CPU baseline of bench.py only): the loops below run under OpenMP.  The
+ * parity oracle is the serial build -- the threaded sums associate differently. */
+#ifdef FPO_OMP
+#include <omp.h>
+#define FPO_PRAGMA(x) _Pragma(#x)
+#else
+#define FPO_PRAGMA(x)
+#endif
+
 static void csr_mul(const fpo_csr *A, const double *x, double *y) {
+  FPO_PRAGMA(omp parallel for schedule(static))
   for (int64_t i = 0; i < A->m; ++i) {
     double s = 0.0;
     for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) s += A->vals[k] * x[A->colind[k]];
@@ -111,7 +121,91 @@ static void csr_mul(const fpo_csr *A, const double *x, double *y) {
 }
 
 /* y = A' u  (jtprod!) */
+#ifdef FPO_OMP
+/* Transposed copy for the threaded A'u (row-parallel on A'): built by fpo_omp_prepare for the arrays of the next
+ * calls, dropped by fpo_omp_release.  Only the all-cores baseline uses it. */
+static struct {
+  const int64_t *rowptr;
+  const double *vals;
+  int64_t m, n;
+  int64_t *trp, *tci;
+  double *tv;
+} g_tr = {0, 0, 0, 0, 0, 0, 0};
+
+void fpo_omp_release(void) {
+  free(g_tr.trp);
+  free(g_tr.tci);
+  free(g_tr.tv);
+  memset(&g_tr, 0, sizeof g_tr);
+}
+
+int fpo_omp_prepare(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colind, const double *vals) {
+  fpo_omp_release();
+  const int64_t nnz = rowptr[m];
+  int64_t *trp = (int64_t *)calloc((size_t)n + 2, sizeof(int64_t));
+  int64_t *tci = (int64_t *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int64_t));
+  double *tv = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+  if (!trp || !tci || !tv) {
+    free(trp);
+    free(tci);
+    free(tv);
+    return 1;
+  }
+  for (int64_t k = 0; k < nnz; ++k) trp[colind[k] + 2]++;
+  for (int64_t j = 0; j < n; ++j) trp[j + 2] += trp[j + 1];
+  for (int64_t i = 0; i < m; ++i)
+    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const int64_t q = trp[colind[k] + 1]++;
+      tci[q] = i;
+      tv[q] = vals[k];
+    }
+  g_tr.rowptr = rowptr;
+  g_tr.vals = vals;
+  g_tr.m = m;
+  g_tr.n = n;
+  g_tr.trp = trp;
+  g_tr.tci = tci;
+  g_tr.tv = tv;
+  return 0;
+}
+#endif
+
 static void csr_tmul(const fpo_csr *A, const double *u, double *y) {
+#ifdef FPO_OMP
+  if (g_tr.trp && g_tr.rowptr == A->rowptr && g_tr.vals == A->vals && g_tr.m == A->m && g_tr.n == A->n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < A->n; ++j) {
+      double s = 0.0;
+      for (int64_t k = g_tr.trp[j]; k < g_tr.trp[j + 1]; ++k) s += g_tr.tv[k] * u[g_tr.tci[k]];
+      y[j] = s;
+    }
+    return;
+  }
+  /* row blocks scatter into per-thread copies of y, summed afterwards in thread order */
+  const int T = omp_get_max_threads();
+  double *buf = (double *)calloc((size_t)T * (size_t)A->n, sizeof(double));
+  if (buf) {
+#pragma omp parallel num_threads(T)
+    {
+      const int t = omp_get_thread_num();
+      double *yt = buf + (size_t)t * (size_t)A->n;
+      const int64_t lo = A->m * t / T, hi = A->m * (t + 1) / T;
+      for (int64_t i = lo; i < hi; ++i) {
+        const double ui = u[i];
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) yt[A->colind[k]] += A->vals[k] * ui;
+      }
+#pragma omp barrier
+#pragma omp for schedule(static)
+      for (int64_t j = 0; j < A->n; ++j) {
+        double s = 0.0;
+        for (int q = 0; q < T; ++q) s += buf[(size_t)q * (size_t)A->n + j];
+        y[j] = s;
+      }
+    }
+    free(buf);
+    return;
+  }
+#endif
   memset(y, 0, (size_t)A->n * sizeof(double));
   for (int64_t i = 0; i < A->m; ++i) {
     const double ui = u[i];
@@ -135,14 +229,22 @@ static void op_tmul(const fpo_op *B, const double *u, double *y) {
 
 static double dotp(int64_t n, const double *a, const double *b) {
   double s = 0.0;
+  FPO_PRAGMA(omp parallel for reduction(+ : s) schedule(static))
   for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
 static double nrm2(int64_t n, const double *a) { return sqrt(dotp(n, a, a)); }
-static void scal(int64_t n, double s, double *a) { for (int64_t i = 0; i < n; ++i) a[i] *= s; }
-static void axpy(int64_t n, double s, const double *x, double *y) { for (int64_t i = 0; i < n; ++i) y[i] += s * x[i]; }
+static void scal(int64_t n, double s, double *a) {
+  FPO_PRAGMA(omp parallel for schedule(static))
+  for (int64_t i = 0; i < n; ++i) a[i] *= s;
+}
+static void axpy(int64_t n, double s, const double *x, double *y) {
+  FPO_PRAGMA(omp parallel for schedule(static))
+  for (int64_t i = 0; i < n; ++i) y[i] += s * x[i];
+}
 /* y = a x + b y */
 static void axpby(int64_t n, double a, const double *x, double b, double *y) {
+  FPO_PRAGMA(omp parallel for schedule(static))
   for (int64_t i = 0; i < n; ++i) y[i] = a * x[i] + b * y[i];
 }
 static double sgn(double a) { return (a > 0.0) - (a < 0.0); }

@@ -21,6 +21,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_OMP = None
 
 
 class Stats(C.Structure):
@@ -43,14 +44,22 @@ class Options(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libfps_oracle.so")
+    so2 = os.path.join(_HERE, "libfps_oracle_omp.so")
     src = os.path.join(_HERE, "fps_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if (force or not os.path.exists(so) or not os.path.exists(so2)
+            or min(os.path.getmtime(so), os.path.getmtime(so2)) < os.path.getmtime(src)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
 
-def lib():
-    global _LIB
+def lib(threaded: bool = False):
+    """threaded=True: the OpenMP build (bench.py's all-cores CPU baseline only; the parity oracle is the serial one)."""
+    global _LIB, _LIB_OMP
+    if threaded:
+        if _LIB_OMP is None:
+            build()
+            _LIB_OMP = C.CDLL(os.path.join(_HERE, "libfps_oracle_omp.so"))
+        return _LIB_OMP
     if _LIB is None:
         _LIB = C.CDLL(build())
     return _LIB
@@ -133,8 +142,10 @@ def minres_aat(m, n, rowptr, colind, vals, b, lam=0.0, atol=None, rtol=None, eto
     return x, st
 
 
-def _two(fn, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, outs):
+def _two(fn, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, outs, threaded=False):
     rp, ci, va = _csr64(rowptr, colind, vals)
+    if threaded:
+        lib(True).fpo_omp_prepare(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va))
     rhs1 = np.ascontiguousarray(rhs1, dtype=np.float64)
     rhs2 = np.ascontiguousarray(rhs2, dtype=np.float64)
     opts = opts or default_options(n, m)
@@ -142,6 +153,8 @@ def _two(fn, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, outs):
     bufs = [np.empty(k) for k in outs]
     rc = fn(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va), C.c_double(delta),
             C.byref(opts), _p(rhs1), _p(rhs2), *[_p(b) for b in bufs], st)
+    if threaded:
+        lib(True).fpo_omp_release()
     return (*bufs, [st[0], st[1]], rc)
 
 
@@ -150,9 +163,10 @@ def solve_two_mixed(m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts=None):
     return _two(lib().fpo_solve_two_mixed, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, (n, m, n, m))
 
 
-def solve_two_least_squares(m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts=None):
+def solve_two_least_squares(m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts=None, threaded=False):
     """C restatement of solve_linear_system.jl:79-105."""
-    return _two(lib().fpo_solve_two_least_squares, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, (n, m, n, m))
+    return _two(lib(threaded).fpo_solve_two_least_squares, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, (n, m, n, m),
+                threaded)
 
 
 def solve_two_extras(m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts=None):
@@ -160,7 +174,7 @@ def solve_two_extras(m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts=None):
     return _two(lib().fpo_solve_two_extras, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, (m, m))
 
 
-def qp_objgrad(qp, x, sigma, rho, delta, eta=0.0, xk=None, opts=None):
+def qp_objgrad(qp, x, sigma, rho, delta, eta=0.0, xk=None, opts=None, threaded=False):
     """C restatement of objgrad! (model-Fletcherpenaltynlp.jl:403-437) on the eq-QP user model.
     Returns dict(fx, gx, ys, gs, stats, rc)."""
     rp, ci, va = _csr64(qp.rowptr, qp.colind, qp.vals)
@@ -171,10 +185,14 @@ def qp_objgrad(qp, x, sigma, rho, delta, eta=0.0, xk=None, opts=None):
     gx, ys, gs = np.empty(n), np.empty(m), np.empty(n)
     fx = C.c_double()
     st = (Stats * 2)()
-    rc = lib().fpo_qp_objgrad(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va),
+    if threaded:
+        lib(True).fpo_omp_prepare(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va))
+    rc = lib(threaded).fpo_qp_objgrad(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va),
                               _p(qp.qdiag), _p(qp.d), _p(qp.b), _p(x), C.c_double(sigma), C.c_double(rho),
                               C.c_double(delta), C.c_double(eta), _p(xk), C.byref(opts), _p(gx), C.byref(fx),
                               _p(ys), _p(gs), st)
+    if threaded:
+        lib(True).fpo_omp_release()
     return dict(fx=fx.value, gx=gx, ys=ys, gs=gs, stats=[st[0], st[1]], rc=rc)
 
 
