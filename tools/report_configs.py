@@ -1,0 +1,91 @@
+"""All five BASELINE.json configurations through the HIP path on one MI355X, one row each ("also report
+configs 1-4").  Writes a markdown table to stdout:   python tools/report_configs.py > profiles/r01_configs.md
+The headline row repeats bench.py's measurement; the others are parity-test cases (tests/), timed here for the record."""
+import os, sys, time
+import numpy as np
+import torch  # noqa: F401  (first: one HIP runtime per process)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fps_amd  # noqa: E402,F401
+from fps_amd import nlpmodels, problems  # noqa: E402
+from fps_amd.device_qp import DeviceEqQP  # noqa: E402
+from fps_amd.penalty_nlp import FletcherPenaltyNLP  # noqa: E402
+from fps_amd.qdsolver import HIPDirectQDSolver, HIPQDSolver  # noqa: E402
+
+SE = float(np.sqrt(np.finfo(float).eps))
+rows = []
+
+
+def eqqp_rate(qp, delta, steps, warm=2):
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    t = torch.device("cuda", 0)
+    xs = [torch.from_numpy(qp.point(1 + k)).to(t) for k in range(steps + warm)]
+    gx = torch.empty(qp.n, dtype=torch.float64, device=t)
+    for k in range(warm):
+        dev.objgrad(xs[k], gx=gx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its = []
+    rcs = 0
+    for k in range(warm, warm + steps):
+        _, rc = dev.objgrad(xs[k], gx=gx)
+        rcs |= rc
+        its.append((dev.stats[0].niter, dev.stats[1].niter))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dev.close()
+    return dt, (int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))), rcs
+
+
+# cfg1: HS6 (test/test-2.jl:54-72): plumbing, K is 3 x 3
+nlp = nlpmodels.HS6()
+for name, qds in (("iterative (HIPQDSolver)", HIPQDSolver(nlp, 0.0)), ("direct (HIPDirectQDSolver)", HIPDirectQDSolver(nlp, 0.0))):
+    fp = FletcherPenaltyNLP(nlp, sigma=1e3, rho=1.0, delta=0.0, qds=qds)
+    x = np.array([-1.2, 1.0])
+    fp.objgrad(x + 1e-3)
+    t0 = time.perf_counter()
+    for k in range(20):
+        fp.objgrad(x + 1e-4 * k)
+    rows.append(("cfg1 HS6 n=2 m=1", name, f"{(time.perf_counter() - t0) / 20 * 1e3:.3f} ms / objgrad (host round trips; no roofline)", ""))
+    qds.close()
+
+# cfg2: random sparse eq-QP
+qp = problems.random_eqqp()
+dt, its, rc = eqqp_rate(qp, 0.0, 50)
+rows.append((f"cfg2 random eq-QP n={qp.n} m={qp.m} nnz={qp.nnz}", "LSQR+CRAIG fused, delta=0", f"{1 / dt:.0f} evals/s ({dt * 1e3:.3f} ms)", f"iterations {its}, rc {rc}"))
+
+# cfg3: dense block, direct back-end (fp64 MFMA SYRK + blocked Cholesky)
+qd = problems.dense_block()
+model = nlpmodels.EqQPModel(qd)
+qds = HIPDirectQDSolver(model, 0.0)
+fp = FletcherPenaltyNLP(model, sigma=1e3, rho=1.0, delta=1e-3, qds=qds)
+fp.objgrad(qd.point(1))
+t0 = time.perf_counter()
+for k in range(5):
+    fp.objgrad(qd.point(2 + k))
+dt = (time.perf_counter() - t0) / 5
+i = qds.info()
+flops = 1.0 * qd.m * qd.m * qd.n + 128 * qd.m * qd.n
+rows.append((f"cfg3 dense block n={qd.n} m={qd.m}", "direct: M = AA'+delta I (MFMA f64), Cholesky, 2 RHS",
+             f"syrk {i['last_syrk_ms']:.3f} ms ({flops / i['last_syrk_ms'] / 1e9:.1f} TFLOP/s), cholesky {i['last_chol_ms']:.3f} ms, "
+             f"solves {i['last_solve_ms']:.3f} ms", f"objgrad wall {dt * 1e3:.1f} ms incl. host model + 64 MB Jacobian upload"))
+qds.close()
+
+# cfg4: AUG2DC-like (not SIF-verified)
+qa = problems.aug2dc_like(N=100)
+dt, its, rc = eqqp_rate(qa, SE, 5, warm=1)
+rows.append((f"cfg4 AUG2DC-like n={qa.n} m={qa.m} nnz={qa.nnz}", "LSQR+CRAIG fused, delta=sqrt(eps)", f"{1 / dt:.1f} evals/s ({dt * 1e3:.2f} ms)",
+             f"iterations {its}, rc {rc} (ill-conditioned incidence matrix: launch-latency bound)"))
+
+# cfg5: headline
+qh = problems.pde_control_like(n=1_000_000, m=100_000)
+for delta in (0.0, SE):
+    dt, its, rc = eqqp_rate(qh, delta, 20, warm=3)
+    rows.append((f"cfg5 PDE-control-like n={qh.n} m={qh.m} nnz={qh.nnz}", f"LSQR+CRAIG fused, delta={delta:.3g}", f"{1 / dt:.0f} evals/s ({dt * 1e3:.3f} ms)",
+                 f"iterations {its}, rc {rc}"))
+
+print("| configuration | path | measured on one MI355X | notes |")
+print("|---|---|---|---|")
+for r in rows:
+    print("| " + " | ".join(r) + " |")
