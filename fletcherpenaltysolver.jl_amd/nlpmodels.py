@@ -81,6 +81,32 @@ class HS6(_Model):
     def hprod(self, x, y, v, obj_weight=1.0):
         return np.array([obj_weight * 2 * v[0] + y[0] * (-20.0) * v[0], 0.0])
 
+    def ghjvprod(self, x, g, v):
+        return np.array([-20.0 * g[0] * v[0]])
+
+
+class HS7(_Model):
+    """f = log(1 + x1^2) - x2, c = (1 + x1^2)^2 + x2^2 - 4, x0 = (2, 2); x* = (0, sqrt 3)   (test/test-2.jl:76-83)"""
+
+    def __init__(self):
+        super().__init__(2, 1, 2, np.array([2.0, 2.0]), name="HS7")
+
+    def obj(self, x): return float(np.log(1 + x[0] ** 2) - x[1])
+    def grad(self, x): return np.array([2 * x[0] / (1 + x[0] ** 2), -1.0])
+    def cons(self, x): return np.array([(1 + x[0] ** 2) ** 2 + x[1] ** 2 - 4.0])
+    def jac_structure(self): return np.array([1, 1]), np.array([1, 2])
+    def jac_coord(self, x): return np.array([4 * x[0] * (1 + x[0] ** 2), 2 * x[1]])
+
+    def _hc(self, x):  # Hessian of c (diagonal)
+        return np.array([4 + 12 * x[0] ** 2, 2.0])
+
+    def hprod(self, x, y, v, obj_weight=1.0):
+        hf = np.array([(2 - 2 * x[0] ** 2) / (1 + x[0] ** 2) ** 2, 0.0])
+        return (obj_weight * hf + y[0] * self._hc(x)) * np.asarray(v)
+
+    def ghjvprod(self, x, g, v):
+        return np.array([np.sum(np.asarray(g) * self._hc(x) * np.asarray(v))])
+
 
 class EqQPModel(_Model):
     """Host view of problems.EqQP: f = 1/2 x'diag(q)x + d'x, c = Ax - b."""

@@ -211,6 +211,14 @@ class HIPDirectQDSolver(QDSolver):
     def solve_two_least_squares(self, nlp, x, rhs1, rhs2):
         return self._solve(self._lib.fpsq_dense_solve_two_least_squares, rhs1, rhs2)
 
+    def solve_two_extras(self, nlp, x, rhs1, rhs2):
+        """invJtJJv = (AA' + tau I)^-1 A rhs1, invJtJSsv = (AA' + tau I)^-1 rhs2 (src/solve_linear_system.jl:142-159).
+        The reference's LDL' back-end runs `cgls` / `minres` on the operator with tau = max(delta, 1e-14); here both
+        come out of the cached Cholesky factor of AA' + delta I (q1 and -q2 of a mixed solve) -- identical for
+        delta >= 1e-14 and within 1e-14 * cond(AA') relative otherwise."""
+        _, q1, _, q2 = self._solve(self._lib.fpsq_dense_solve_two_mixed, rhs1, rhs2)
+        return q1, -q2
+
     def info(self):
         i = _lib.DenseInfo()
         self._check(self._lib.fpsq_dense_get_info(self._d, C.byref(i)))
