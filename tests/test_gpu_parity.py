@@ -93,16 +93,20 @@ def _spmv_cases():
     cases["ragged"] = sp.vstack([sp.random(1, 3000, density=d, random_state=rng, format="csr")
                                  for d in (0.0, 0.001, 0.9, 0.0, 0.3, 0.001, 0.7, 0.0)]).tocsr()
     cases["tall"] = sp.random(5000, 40, density=0.1, random_state=rng, format="csr")
+    B = sp.random(3000, 50, density=0.05, random_state=rng, format="lil")
+    B[:, 7] = rng.standard_normal((3000, 1))  # a dense column: A' gets a row longer than the LDS stage (unpadded A')
+    cases["dense_column"] = B.tocsr()
     return cases
 
 
+@pytest.mark.parametrize("fmt", [0, 1])  # 0: RGCS / padded / 16-bit-column layouts where representable, 1: plain CSR
 @pytest.mark.parametrize("name", list(_spmv_cases()))
-def test_spmv_matches_oracle(oracle, name):
+def test_spmv_matches_oracle(oracle, name, fmt):
     A = sp.csr_matrix(_spmv_cases()[name])
     A.sort_indices()
     m, n = A.shape
     rng = np.random.default_rng(1)
-    H = _Handle(A)
+    H = _Handle(A, jac_format=fmt)
     x, u = rng.standard_normal(n), rng.standard_normal(m)
     y0, z0 = rng.standard_normal(m), rng.standard_normal(n)
     want = 1.5 * oracle.spmv(m, n, A.indptr, A.indices, A.data, x) - 0.5 * y0
@@ -216,16 +220,17 @@ def _small_pde(seed=7, n=4000, m=400):
     return problems.pde_control_like(n=n, m=m, per_row=20, window=512, seed=seed)
 
 
+@pytest.mark.parametrize("fmt", [0, 1])  # every storage layout of the products must give the same recurrences
 @pytest.mark.parametrize("delta", [0.0, SE, 0.25])
 @pytest.mark.parametrize("fuse", [0, 1])
-def test_solve_two_mixed_iteration_parity_with_c_restatement(oracle, delta, fuse):
+def test_solve_two_mixed_iteration_parity_with_c_restatement(oracle, delta, fuse, fmt):
     """Default reference tolerances: same iteration counts / statuses as the CPU restatement, vectors equal to
     1e-9 (relative inf-norm: only the summation order differs), and within 1e-6 of the exact solve."""
     qp = _small_pde()
     A = qp.scipy_csr()
     g = qp.qdiag * qp.x + qp.d
     c = A @ qp.x - qp.b
-    H = _Handle(A, delta=delta, fuse_two_rhs=fuse)
+    H = _Handle(A, delta=delta, fuse_two_rhs=fuse, jac_format=fmt)
     p1, q1, p2, q2, rc = H.solve_two_mixed(g, c)
     o = oracle.solve_two_mixed(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, c)
     assert rc == o[5]
