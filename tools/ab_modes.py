@@ -18,6 +18,10 @@ envname, envvals = None, [None]
 if os.environ.get("AB_ENV"):
     envname, vals = os.environ["AB_ENV"].split("=")
     envvals = vals.split(",")
+optname, optvals = None, [None]
+if os.environ.get("AB_OPT"):  # an fpsq_options field, e.g. AB_OPT="lookahead=2,4,8"
+    optname, vals = os.environ["AB_OPT"].split("=")
+    optvals = [int(v) for v in vals.split(",")]
 workload = os.environ.get("AB_WORKLOAD", "headline")
 qp = problems.pde_control_like(n=1_000_000, m=100_000) if workload == "headline" else problems.random_eqqp(n=100_000, m=10_000)
 dev = torch.device("cuda", 0)
@@ -28,7 +32,10 @@ for lp in libs:
     for ev in envvals:
         if envname:
             os.environ[envname] = ev
-        models[(os.path.basename(lp), ev)] = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, device=0, fuse_two_rhs=1)
+        for ov in optvals:
+            extra = {optname: ov} if optname else {}
+            models[(os.path.basename(lp), f"{ev}/{optname}={ov}#{len(models)}" if optname else ev)] = DeviceEqQP(
+                qp, sigma=1e3, rho=1.0, delta=0.0, device=0, fuse_two_rhs=1, **extra)
 xs = torch.empty((batch, qp.n), dtype=torch.float64, device=dev)
 for t in range(batch):
     xs[t].copy_(torch.from_numpy(qp.point(1 + t)))
