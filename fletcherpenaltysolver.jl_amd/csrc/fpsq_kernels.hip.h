@@ -10,6 +10,7 @@
 namespace fpsq {
 
 constexpr int kBlock = 256;        // threads per workgroup (4 waves)
+static_assert(kBlock == 256, "block_sum / block_sum_lanes and the tile-per-thread constants assume 4 waves");
 #ifndef FPSQ_SPMV_NNZ
 #define FPSQ_SPMV_NNZ 2048
 #endif
