@@ -251,6 +251,8 @@ def main():
                                          "(the reference is single-threaded Julia; Julia is not installed)"}
         # the same restatement with OpenMP on every host core (SURVEY.md 8d asks for both); a second number, not `value`
         try:
+            # (a one-GPU box exposes every host core in the affinity mask but grants a 16-core share)
+            nthreads = oracle.lib(True).fpo_omp_threads(min(len(os.sched_getaffinity(0)), 16))
             t0 = time.perf_counter()
             done2 = 0
             for t in range(args.cpu_evals):
@@ -264,7 +266,7 @@ def main():
                 if time.perf_counter() - t0 > 15.0:
                     break
             out["cpu_baseline"]["all_cores"] = {"value": round(done2 / (time.perf_counter() - t0), 4),
-                                                "cores": len(os.sched_getaffinity(0)),
+                                                "cores": int(nthreads),
                                                 "kind": "port, OpenMP (oracle/libfps_oracle_omp.so)"}
         except (OSError, AttributeError) as e:  # no libgomp on this host
             out["cpu_baseline"]["all_cores"] = {"value": None, "error": str(e)}

@@ -132,6 +132,12 @@ static struct {
   double *tv;
 } g_tr = {0, 0, 0, 0, 0, 0, 0};
 
+/* n > 0: use n threads from now on; returns the thread count in effect */
+int fpo_omp_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
+
 void fpo_omp_release(void) {
   free(g_tr.trp);
   free(g_tr.tci);
