@@ -206,6 +206,8 @@ struct fpsq_solver_s {
   fpsq_stats* hstats_dev = nullptr;
   double* hscal = nullptr;        // host-mapped: scalar results (phi, f, c'c) written by the kernel that computes them
   double* hscal_dev = nullptr;
+  int64_t expect_iters[3][3] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
+  bool adaptive_runahead = true;    // FPSQ_ADAPTIVE_RUNAHEAD=0 disables (A/B)
 
   // instrumentation
   bool profile = false;
@@ -1061,6 +1063,9 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   double* SPcur = SP;
   double* SPalt = h->SP2;
   const int look = std::max(1, o.lookahead);
+  // iteration count of the previous run with the same pair of recurrences (0: unknown)
+  int64_t* expect_slot = &h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
+  const int64_t expect = h->adaptive_runahead ? *expect_slot : 0;
   int64_t it = 0;
   auto lsqr_upd_seg = [&](int l, int64_t it_of_update) {
     UpdSeg u{};
@@ -1173,6 +1178,25 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       }
       if (all_done()) break;
     }
+    // Consecutive calls of one kind (the evaluations of a line search, the CG steps of a Newton iteration) mostly take
+    // the same number of iterations: do not enqueue iteration expect + 1 before the device has finished iteration
+    // `expect`.  When the count repeats, no launch is enqueued past convergence (each costs ~3.5 us of GPU time even
+    // though it exits at once: ~50 us per evaluation at lookahead 4); when it does not, this is one short bubble.
+    if (expect > 0 && it == expect) {
+      for (int l = 0; l < NL; ++l) {
+        if (h->prog_host[l].done) continue;
+        const int32_t* ddone = &lanes[l].ctl->done;
+        const int32_t* diter = lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->iter
+                                                          : &((CraigState*)lanes[l].state)->iter;
+        if (int rc = wait_progress(h, l, (int)it, ddone, diter)) return rc;
+      }
+      if (all_done()) break;
+    }
+  }
+  if (all_done()) {  // the iteration at which the last recurrence finished (its progress word says so)
+    int64_t e = 0;
+    for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter);
+    *expect_slot = e;
   }
   // the last LSQR update (iteration `it`) has not been enqueued yet
   {
@@ -1437,6 +1461,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if ((e = hipHostMalloc((void**)&h->hscal, 16 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
       hipSuccess)
     return fail("hipHostMalloc", e);
+  if (const char* ev = std::getenv("FPSQ_ADAPTIVE_RUNAHEAD")) h->adaptive_runahead = std::atoi(ev) != 0;
   std::memset(h->hstats, 0, 4 * sizeof(fpsq_stats));
   std::memset(h->hscal, 0, 16 * sizeof(double));
   if ((e = hipHostGetDevicePointer((void**)&h->hstats_dev, h->hstats, 0)) != hipSuccess)
