@@ -159,8 +159,8 @@ def main():
         tot_ms += info["last_solve_ms"]
     model.set_profiling(False)
     # Algorithmic bytes of the PRODUCTIVE product launches only: with J = max(LSQR, CRAIG iterations)
-    # an evaluation runs J two-RHS A' products, J + 1 two-RHS A products (the +1 is LSQR's start-up B'u), and with one
-    # right-hand side c = Ax - b (A), p1 = g - A'q1 and rho A'c (A').  Launches enqueued past convergence (host
+    # an evaluation runs J two-RHS A' products, J + 1 two-RHS A products (the +1 is LSQR's start-up B'u), c = Ax - b
+    # with one right-hand side (A), and p1 = g - A'q1 with rho A'c (A': one raw two-RHS product on a single GPU).  Launches enqueued past convergence (host
     # run-ahead) exit at once: they count in the time, not in the bytes.  Unfused runs: 2 single-RHS products per
     # iteration of each solver.
     m_loc, nnz_loc = (local.m, local.nnz) if sharded else (m, nnz)
@@ -180,9 +180,13 @@ def main():
             productive += 2 * J + 3
         elif args.fuse:
             J = max(il, ic)
-            nbytes += J * at2 + (J + 1) * a2 + a1 + 2 * at1
+            if sharded:  # c = Ax - b, then p1 = g - A'q1 and rho A'c as two single-RHS products
+                nbytes += J * at2 + (J + 1) * a2 + a1 + 2 * at1
+                productive += 2 * J + 4
+            else:        # single GPU: the last two share one raw two-RHS product A'[q1, c] (no yin read)
+                nbytes += J * at2 + (J + 1) * a2 + a1 + (at2 - 8 * 2 * n)
+                productive += 2 * J + 3
             nbytes += max(il - 1, 0) * upd_at + ic * upd_a
-            productive += 2 * J + 4
         else:
             nbytes += (il + ic) * (a1 + at1) + a1 + a1 + 2 * at1
             productive += 2 * (il + ic) + 4

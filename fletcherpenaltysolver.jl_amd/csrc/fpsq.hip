@@ -1350,7 +1350,8 @@ bool on_this_device(fpsq_handle h, const void* p) {
 int soft_rc(const fpsq_stats st[2]) { return (st[0].solved ? 0 : 1) | (st[1].solved ? 0 : 2); }
 
 // device-side solve_two_mixed: g (n), c (m) device pointers; results left in h->p1, h->Lx[0] (q1), h->Cx (p2), h->Cy (q2)
-int two_mixed_device(fpsq_handle h, const double* g, const double* c) {
+// defer_p1: the caller forms p1 = g - A'q1 itself (qp_objgrad pairs that product with A'c in one two-RHS launch)
+int two_mixed_device(fpsq_handle h, const double* g, const double* c, bool defer_p1 = false) {
   Lane lanes[2];
   // (q1, stats1) = solve_least_square(qds, Aop', rhs1, sqrt(delta))      src/solve_linear_system.jl:123
   lanes[0].kind = LANE_LSQR;
@@ -1369,7 +1370,8 @@ int two_mixed_device(fpsq_handle h, const double* g, const double* c) {
   lanes[1].st = &h->hstats[1];
   if (int rc = run_lanes(h, lanes, 2)) return rc;
   // p1 = rhs1 - Aop' q1                                                   :126-127
-  if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, g, h->p1)) return rc;
+  if (!defer_p1)
+    if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, g, h->p1)) return rc;
   return 0;
 }
 
@@ -1766,7 +1768,7 @@ int fpsq_ys_gs(fpsq_handle h, const double* g, const double* c, double sigma, do
   // src/model-Fletcherpenaltynlp.jl:244-248
   hipLaunchKernelGGL(k_gs, dim3(ew_grid(h->n)), dim3(kBlock), 0, s, h->p1, h->Cx, sigma, h->gs, h->n);
   hipLaunchKernelGGL(k_ys, dim3(ew_grid(h->m)), dim3(kBlock), 0, s, h->Lx[0], h->Cy, (const double*)nullptr, sigma, h->ys,
-                     h->m, (double*)nullptr, (double*)nullptr);
+                     h->m, (double*)nullptr, (double*)nullptr, (double*)nullptr);
   h->launches += 2;
   HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
@@ -1828,22 +1830,10 @@ int fpsq_qp_destroy(fpsq_qp qp) {
 }  // extern "C"
 
 namespace {
-// fx = f - c'ys + rho/2 c'c + eta/2 ||x - xk||^2 from the partial sums   (src/model-Fletcherpenaltynlp.jl:419-433)
-__global__ __launch_bounds__(kBlock) void k_qp_fx(const double* pf, const double* pdx, int np_n, const double* pcy,
-                                                  const double* pcc, int np_m, double rho, double eta, double* out) {
+// stand-alone form of qp_fx (sharded runs: the m-vector sums pass through an all-reduce first)
+__global__ __launch_bounds__(kBlock) void k_qp_fx(const FxArgs a) {
   __shared__ double red[4];
-  const double f = reduce_partials(pf, np_n, red);
-  const double dx = reduce_partials(pdx, np_n, red);
-  const double cy = reduce_partials(pcy, np_m, red);
-  const double cc = reduce_partials(pcc, np_m, red);
-  if (threadIdx.x == 0) {
-    double fx = f - cy;
-    if (rho > 0.0) fx += rho / 2 * cc;
-    if (eta > 0.0) fx += eta / 2 * dx;
-    out[0] = fx;
-    out[1] = f;
-    out[2] = cc;
-  }
+  qp_fx(a, red);
 }
 }  // namespace
 
@@ -1878,30 +1868,53 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1]);
   h->launches++;
   spmv_const(h, TAG_A, 1.0, dx, -1.0, qp->b, h->c);  // c = A x - b
-  if (int rc = two_mixed_device(h, h->g, h->c)) return rc;
+  // Single GPU with rho > 0: p1 = g - A'q1 and J'c (:424-428) share ONE two-right-hand-side product A'[q1, c], and
+  // phi is reduced by an extra workgroup of the gradient kernel: 2 launches fewer at the end of every evaluation.
+  const bool paired = !h->comm && rho > 0.0;
+  if (int rc = two_mixed_device(h, h->g, h->c, paired)) return rc;
   // ys = q1 + sigma q2 and the dots of objgrad!
-  hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax);
+  hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax,
+                     paired ? h->SP : (double*)nullptr);
   h->launches++;
-  if (rho > 0.0)
-    if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
-  hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn), dim3(kBlock), 0, s, h->p1, h->Cx, qp->q, h->jc, dx, dxk, sigma,
-                     rho, eta, h->gs, dgx, n);
-  const double *pcy = h->pE, *pcc = h->pE + kEwBlocksMax;
-  int npm = gm;
-  if (h->comm) {  // c'ys and c'c are sums over the rank's rows only
-    PresumArgs P{};
-    P.p[0] = pcy;
-    P.n[0] = gm;
-    P.p[1] = pcc;
-    P.n[1] = gm;
-    hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
-    if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
-    pcy = h->comm_scal;
-    pcc = h->comm_scal + 1;
-    npm = 1;
+  FxArgs fa{};
+  fa.pf = h->pQ[0];
+  fa.pdx = h->pQ[1];
+  fa.np_n = gn;
+  fa.pcy = h->pE;
+  fa.pcc = h->pE + kEwBlocksMax;
+  fa.np_m = gm;
+  fa.rho = rho;
+  fa.eta = eta;
+  fa.out = h->hscal_dev;
+  if (paired) {
+    launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr);
+    hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn + 1), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP, h->Cx, qp->q,
+                       (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, fa);
+    h->launches++;
+  } else {
+    if (rho > 0.0)
+      if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
+    FxArgs none = fa;
+    none.out = nullptr;
+    hipLaunchKernelGGL(k_qp_penalty_grad, dim3(h->comm ? gn : gn + 1), dim3(kBlock), 0, s, h->p1, h->g,
+                       (const double*)nullptr, h->Cx, qp->q, h->jc, dx, dxk, sigma, rho, eta, h->gs, dgx, n,
+                       h->comm ? none : fa);
+    if (h->comm) {  // c'ys and c'c are sums over the rank's rows only
+      PresumArgs P{};
+      P.p[0] = fa.pcy;
+      P.n[0] = gm;
+      P.p[1] = fa.pcc;
+      P.n[1] = gm;
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
+      if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
+      fa.pcy = h->comm_scal;
+      fa.pcc = h->comm_scal + 1;
+      fa.np_m = 1;
+      hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa);
+      h->launches += 2;
+    }
+    h->launches++;
   }
-  hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, h->pQ[0], h->pQ[1], gn, pcy, pcc, npm, rho, eta, h->hscal_dev);
-  h->launches += 2;
   if (gx && dgx != gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
   if (ys) HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
   if (gs) HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));

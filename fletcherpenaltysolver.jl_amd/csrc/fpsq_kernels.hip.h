@@ -786,12 +786,13 @@ __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q
 // ys = q1 + sigma q2 ; partials of c'ys and c'c            (m-vectors)
 __global__ __launch_bounds__(kBlock) void k_ys(const double* __restrict__ q1, const double* __restrict__ q2,
                                                const double* __restrict__ c, double sigma, double* ys, int64_t m,
-                                               double* pcy, double* pcc) {
+                                               double* pcy, double* pcc, double* pack) {
   __shared__ double red[4];
   double cy = 0.0, cc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
     const double y = q1[i] + sigma * q2[i];
     ys[i] = y;
+    if (pack) *reinterpret_cast<double2*>(pack + 2 * i) = make_double2(q1[i], c[i]);  // input pair of the A'[q1, c] product
     if (c) {
       const double ci = c[i];
       cy += ci * y;
@@ -813,20 +814,64 @@ __global__ __launch_bounds__(kBlock) void k_gs(const double* __restrict__ p1, co
     gs[i] = p1[i] + sigma * p2[i];
 }
 
-// QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2
-__global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __restrict__ p1, const double* __restrict__ v,
+// phi from the partial sums of the evaluation (src/model-Fletcherpenaltynlp.jl:419-433); out = {phi, f, c'c}
+struct FxArgs {
+  const double *pf, *pdx, *pcy, *pcc;
+  int32_t np_n, np_m;
+  double rho, eta;
+  double* out;  // null: not computed by this launch
+};
+__device__ __forceinline__ void qp_fx(const FxArgs& a, double* red) {
+  const double f = reduce_partials(a.pf, a.np_n, red);
+  const double dx = reduce_partials(a.pdx, a.np_n, red);
+  const double cy = reduce_partials(a.pcy, a.np_m, red);
+  const double cc = reduce_partials(a.pcc, a.np_m, red);
+  if (threadIdx.x == 0) {
+    double fx = f - cy;
+    if (a.rho > 0.0) fx += a.rho / 2 * cc;
+    if (a.eta > 0.0) fx += a.eta / 2 * dx;
+    a.out[0] = fx;
+    a.out[1] = f;
+    a.out[2] = cc;
+  }
+}
+
+// QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2.
+// pj != null: p1 and Jc come from ONE two-right-hand-side raw product pj[i] = {(A'q1)_i, (A'c)_i}: p1 = g - pj[.][0].
+// The last workgroup of the grid does no streaming: it reduces the evaluation's partial sums to phi (fx.out != null),
+// concurrently with the others -- one launch less at the end of every evaluation.
+__global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __restrict__ p1, const double* __restrict__ g,
+                                                            const double* __restrict__ pj, const double* __restrict__ v,
                                                             const double* __restrict__ q, const double* jc,
                                                             const double* x, const double* xk, double sigma,
                                                             double rho, double eta, double* gs, double* gx,
-                                                            int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+                                                            int64_t n, const FxArgs fx) {
+  int nb = gridDim.x;
+  if (fx.out) {
+    --nb;
+    if ((int)blockIdx.x == nb) {
+      __shared__ double red[4];
+      qp_fx(fx, red);
+      return;
+    }
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)nb * kBlock) {
     const double vi = v[i];
-    const double gsi = p1[i] + sigma * vi;
+    double p1i, jci = 0.0;
+    if (pj) {
+      const double2 t = *reinterpret_cast<const double2*>(pj + 2 * i);
+      p1i = g[i] - t.x;
+      jci = t.y;
+    } else {
+      p1i = p1[i];
+      if (rho > 0.0) jci = jc[i];
+    }
+    const double gsi = p1i + sigma * vi;
     gs[i] = gsi;
-    double g = gsi - q[i] * vi + sigma * vi;
-    if (rho > 0.0) g += jc[i] * rho;
-    if (eta > 0.0) g += eta * (x[i] - xk[i]);
-    gx[i] = g;
+    double gg = gsi - q[i] * vi + sigma * vi;
+    if (rho > 0.0) gg += jci * rho;
+    if (eta > 0.0) gg += eta * (x[i] - xk[i]);
+    gx[i] = gg;
   }
 }
 
