@@ -395,6 +395,30 @@ def test_repeat_calls_are_bitwise_reproducible():
     dev.close()
 
 
+def test_run_ahead_history_does_not_change_results(oracle):
+    """The host holds its run-ahead at the iteration count of the previous call of the same kind; a wrong guess in
+    either direction (easy problem after a hard one and back) must give exactly what a fresh handle gives."""
+    qp = _small_pde(seed=23, n=4000, m=400)
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    easy = 1e-3 * g  # stops after fewer iterations under the absolute tolerance
+    H = _Handle(A, delta=0.0)
+    seq = [(g, c), (easy, 1e-3 * c), (g, c), (g, 0.0 * c), (g, c)]
+    its = []
+    for r1, r2 in seq:
+        got = H.solve_two_mixed(r1, r2)
+        its.append((H.st[0].niter, H.st[1].niter))
+        F = _Handle(A, delta=0.0)
+        want = F.solve_two_mixed(r1, r2)
+        assert (F.st[0].niter, F.st[1].niter) == its[-1]
+        for a, b in zip(got[:4], want[:4]):
+            assert np.array_equal(a, b)
+        F.close()
+    assert len(set(its)) >= 2, its  # the sequence really changes the iteration counts
+    H.close()
+
+
 # ---------------------------------------------------------------------------------------------- row sharding
 
 @pytest.mark.parametrize("nshards", [2, 3])
