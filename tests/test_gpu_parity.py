@@ -123,6 +123,60 @@ def test_spmv_matches_oracle(oracle, name, fmt):
     H.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_spmv_random_structures_layouts_agree(seed):
+    """Randomised structures (row lengths from 0 to several LDS stages, banded and scattered columns, sizes that are
+    not multiples of any tile): the tuned layouts (RGCS groups, padded blocks, 16-bit columns) and plain CSR must give
+    the same products to rounding, and a two-system solve the same iteration counts."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(1, 700))
+    n = int(rng.integers(max(2, m // 4), 6000))
+    kind = seed % 4
+    rows, cols = [], []
+    for i in range(m):
+        if kind == 0:    # short scattered rows, many empty
+            k = int(rng.integers(0, 6))
+            c = rng.choice(n, size=min(k, n), replace=False)
+        elif kind == 1:  # banded, ~100 per row (the headline shape in small)
+            w = min(n, 900)
+            lo = int(rng.integers(0, n - w + 1))
+            c = lo + rng.choice(w, size=min(100, w), replace=False)
+        elif kind == 2:  # wildly different row lengths including rows longer than one LDS stage
+            k = int(rng.choice([0, 1, 3, 50, 400, 2500, 5000]))
+            c = rng.choice(n, size=min(k, n), replace=False)
+        else:            # dense-ish narrow matrix: long rows of A' (dense columns)
+            c = rng.choice(n, size=max(1, n // 3), replace=False)
+        rows += [i] * len(c)
+        cols += list(c)
+    A = sp.csr_matrix((rng.standard_normal(len(rows)), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    if A.nnz == 0:
+        A = sp.csr_matrix(([1.0], ([0], [0])), shape=(m, n))
+    x, u = rng.standard_normal(n), rng.standard_normal(m)
+    y0, z0 = rng.standard_normal(m), rng.standard_normal(n)
+    H0, H1 = _Handle(A, jac_format=0), _Handle(A, jac_format=1)
+    for trans, vec, add in ((0, x, y0), (1, u, z0)):
+        a = H0.jac_mul(trans, 0.75, vec, -1.25, add)
+        b = H1.jac_mul(trans, 0.75, vec, -1.25, add)
+        ref = 0.75 * ((A.T if trans else A) @ vec) - 1.25 * add
+        scale = np.abs(A.T if trans else A) @ np.abs(vec) + np.abs(add) + 1e-300
+        assert np.max(np.abs(a - ref) / scale) < 1e-13 and np.max(np.abs(b - ref) / scale) < 1e-13
+    if m <= n:  # a full-row-rank-ish system: both layouts run the same recurrences
+        g, c = rng.standard_normal(n), rng.standard_normal(m)
+        r0 = H0.solve_two_mixed(g, c)
+        it0 = (H0.st[0].niter, H0.st[1].niter)
+        r1 = H1.solve_two_mixed(g, c)
+        # (ill-conditioned draws run thousands of iterations: rounding differences may shift the stop by a few)
+        for k in range(2):
+            assert abs(H1.st[k].niter - it0[k]) <= max(1, it0[k] // 50)
+        if r0[4] == 0 and r1[4] == 0 and (H1.st[0].niter, H1.st[1].niter) == it0:
+            for a, b in zip(r0[:4], r1[:4]):
+                assert _rel(a, b) < 1e-7
+    H0.close()
+    H1.close()
+
+
 def test_coo_structure_with_duplicates_matches_sparse_sum():
     """jac_structure! may repeat (i, j); SparseArrays.sparse sums duplicates (src/solve_linear_system.jl:233)."""
     rng = np.random.default_rng(3)
