@@ -53,9 +53,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pde-control-like n=1e6 m=1e5 nnz=1e7", choices=list(WORKLOADS))
-    ap.add_argument("--op", default="objgrad", choices=["objgrad", "hprod-solves"],
+    ap.add_argument("--op", default="objgrad", choices=["objgrad", "hprod-solves", "hprod"],
                     help="objgrad = the headline metric; hprod-solves = solve_two_least_squares (the two solves of every "
-                         "hprod!, solve_linear_system.jl:79-105) on distinct right-hand-side pairs: SURVEY 8(f) rank 1")
+                         "hprod!, solve_linear_system.jl:79-105) on distinct right-hand-side pairs; hprod = the whole "
+                         "device-resident hprod! Val(2) (model-Fletcherpenaltynlp.jl:521-570): SURVEY 8(f) rank 1")
     ap.add_argument("--delta", type=float, default=0.0, help="regularisation; 0 = first outer iteration (algo.jl:46)")
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--lookahead", type=int, default=0, help="override fpsq_options.lookahead (0 = library default)")
@@ -110,7 +111,8 @@ def main():
     for t in range(K + W):
         xs[t].copy_(torch.from_numpy(qp.point(1 + t + (0 if sharded else rank) * (K + W))))
     gx = torch.empty(n, dtype=torch.float64, device=dev)
-    hp = args.op == "hprod-solves"
+    hp = args.op in ("hprod-solves", "hprod")
+    hfull = args.op == "hprod"
     if hp:  # the points double as right-hand sides: (xs[t], xs[t] reversed) are the two n-vectors of step t
         if sharded:
             raise SystemExit("--op hprod-solves: single GPU or replicas only")
@@ -119,6 +121,8 @@ def main():
     torch.cuda.synchronize()
 
     def step(t):
+        if hfull:
+            return None, model.hprod(xs[t], hp_out[0])
         if hp:
             return None, model.solve_two_least_squares(xs[t], xr[t], *hp_out)
         return model.objgrad(xs[t], gx=gx)
@@ -178,6 +182,9 @@ def main():
             J = max(il, ic)  # then p_k = rhs_k - A'q_k with one right-hand side each
             nbytes += J * at2 + (J + 1) * a2 + 2 * at1 + (max(il - 1, 0) + max(ic - 1, 0)) * upd_at
             productive += 2 * J + 3
+            if hfull and rho > 0.0:  # rho A'(A v): one more single-RHS product of each kind
+                nbytes += a1 + at1
+                productive += 2
         elif args.fuse:
             J = max(il, ic)
             if sharded:  # c = Ax - b, then p1 = g - A'q1 and rho A'c as two single-RHS products
@@ -212,7 +219,8 @@ def main():
         pass
 
     out = {
-        "metric": "solve_two_least_squares calls/sec (the two KKT solves of one hprod!)" if hp
+        "metric": "penalty hprod! (Val(2)) evals/sec" if hfull
+        else "solve_two_least_squares calls/sec (the two KKT solves of one hprod!)" if hp
         else "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "calls/s" if hp else "evals/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4),
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
@@ -238,10 +246,10 @@ def main():
         t0 = time.perf_counter()
         done = 0
         for t in range(args.cpu_evals):
-            if hp:
+            if hp:  # (hprod: the solves are all of its CPU cost but two products and three vector passes)
                 r1 = qp.point(1 + W + t)
                 oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, args.delta, r1,
-                                               np.ascontiguousarray(r1[::-1]))
+                                               np.ascontiguousarray(r1[::-1]) if not hfull else qp.qdiag * r1)
             else:
                 oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, args.delta)
             done += 1

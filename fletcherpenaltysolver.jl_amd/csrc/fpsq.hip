@@ -1925,6 +1925,51 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   return soft_rc(st);
 }
 
+static int fpsq_qp_hprod_once(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta,
+                              double* Hv, fpsq_stats st[2]) {
+  if (int rc = check_ready(h)) return rc;
+  if (!qp || qp->h != h || !v || !Hv || !st) {
+    h->err = "qp_hprod: bad argument";
+    return FPSQ_ERR_ARG;
+  }
+  if (h->comm) {
+    h->err = "qp_hprod: not available on a sharded handle";
+    return FPSQ_ERR_STATE;
+  }
+  hipSetDevice(h->opt.device);
+  hipStream_t s = h->stream;
+  const int64_t n = h->n;
+  const size_t nb = (size_t)n * 8;
+  const int gn = ew_grid(n);
+  const double* dv = v;
+  if (!on_this_device(h, v)) {
+    HIPCHK(h, hipMemcpyAsync(h->in_n1, v, nb, hipMemcpyDefault, s));
+    dv = h->in_n1;
+  }
+  double* dhv = on_this_device(h, Hv) ? Hv : h->gx;
+  call_begin(h);
+  hipLaunchKernelGGL(k_qp_hsv, dim3(gn), dim3(kBlock), 0, s, qp->q, dv, h->in_n2, n);                    // :537
+  if (int rc = two_least_squares_device(h, dv, h->in_n2)) return rc;                                      // :542
+  if (rho > 0.0) {                                                                                        // :557-558
+    spmv_const(h, TAG_A, 1.0, dv, 0.0, nullptr, h->in_m);
+    if (int rc = at_product_const(h, 1.0, h->in_m, 0.0, nullptr, h->jc)) return rc;
+  }
+  hipLaunchKernelGGL(k_qp_hprod_fin, dim3(gn), dim3(kBlock), 0, s, h->p1, h->p2b, qp->q, dv, h->jc, sigma, rho, eta, dhv,
+                     n);                                                                                  // :543-562
+  h->launches += 2;
+  if (dhv != Hv) HIPCHK(h, hipMemcpyAsync(Hv, dhv, nb, hipMemcpyDefault, s));
+  if (int rc = call_end(h)) return rc;
+  st[0] = h->hstats[0];
+  st[1] = h->hstats[1];
+  return soft_rc(st);
+}
+
+int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta, double* Hv,
+                  fpsq_stats st[2]) {
+  int rc = fpsq_qp_hprod_once(h, qp, v, sigma, rho, eta, Hv, st);
+  return rc;
+}
+
 int fpsq_comm_unique_id(uint8_t id[128]) {
   std::string err;
   if (!id || !g_rccl.load(err)) {

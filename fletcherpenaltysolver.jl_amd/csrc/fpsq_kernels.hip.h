@@ -875,4 +875,24 @@ __global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __rest
   }
 }
 
+// hprod! Val(2) on the eq-QP model, the two element-wise ends:  Hsv = q .* v   and
+//   Hv = p2 - q .* (v - p1) + 2 sigma (v - p1) (+ rho JtJv) (+ eta v)
+__global__ __launch_bounds__(kBlock) void k_qp_hsv(const double* __restrict__ q, const double* __restrict__ v, double* hsv,
+                                                   int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) hsv[i] = q[i] * v[i];
+}
+__global__ __launch_bounds__(kBlock) void k_qp_hprod_fin(const double* __restrict__ p1, const double* __restrict__ p2,
+                                                         const double* __restrict__ q, const double* __restrict__ v,
+                                                         const double* jtjv, double sigma, double rho, double eta,
+                                                         double* hv, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double vi = v[i];
+    const double pt = vi - p1[i];
+    double r = p2[i] - q[i] * pt + 2.0 * sigma * pt;
+    if (rho > 0.0) r += rho * jtjv[i];
+    if (eta > 0.0) r += eta * vi;
+    hv[i] = r;
+  }
+}
+
 }  // namespace fpsq

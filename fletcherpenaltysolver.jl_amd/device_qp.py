@@ -87,6 +87,12 @@ class DeviceEqQP:
         return self._check(self._lib.fpsq_ys_gs(self._h, _lib.ptr(g), _lib.ptr(c), self.sigma, _lib.ptr(gs),
                                                 _lib.ptr(ys), _lib.ptr(v), _lib.ptr(w), self.stats))
 
+    def hprod(self, v, Hv):
+        """hprod!(::FletcherPenaltyNLP, x, v, Hv), hessian_approx = Val(2) (model-Fletcherpenaltynlp.jl:521-570), on the
+        device; the model is quadratic with linear constraints, so the product does not depend on x.  Returns rc."""
+        return self._check(self._lib.fpsq_qp_hprod(self._h, self._q, _lib.ptr(v), self.sigma, self.rho, self.eta,
+                                                   _lib.ptr(Hv), self.stats))
+
     def info(self):
         i = _lib.Info()
         self._check(self._lib.fpsq_get_info(self._h, C.byref(i)))

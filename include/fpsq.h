@@ -152,6 +152,13 @@ int fpsq_qp_create(fpsq_handle h, const double *qdiag, const double *d, const do
 int fpsq_qp_destroy(fpsq_qp qp);
 int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double *x, double sigma, double rho, double eta,
                     const double *xk, double *fx, double *gx, double *ys, double *gs, fpsq_stats st[2]);
+/* One `hprod!(::FletcherPenaltyNLP, x, v, Hv)` with hessian_approx = Val(2)
+ * (src/model-Fletcherpenaltynlp.jl:521-570) on the same model, entirely on the device:
+ *   Hsv = q .* v;  (p1, _, p2, _) = solve_two_least_squares(v, Hsv);  Ptv = v - p1;
+ *   Hv = p2 - q .* Ptv + 2 sigma Ptv (+ rho A'(A v)) (+ eta v)      (the constraint Hessians vanish: c is linear).
+ * The Hessian-free sub-solvers call this once per inner CG iteration. */
+int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double *v, double sigma, double rho, double eta, double *Hv,
+                  fpsq_stats st[2]);
 
 /* ---- multi-GPU: 1-D row sharding of A across ranks.  Each rank creates its handle with
  * the GLOBAL n and its LOCAL m (its block of constraints), passes its local rows to set_jacobian_*, and

@@ -423,6 +423,27 @@ def test_device_qp_matches_host_mirror(oracle):
     fp.qdsolver.close()
 
 
+@pytest.mark.parametrize("delta,rho,eta", [(0.0, 1.0, 0.0), (SE, 0.0, 0.0), (1e-2, 2.0, 0.5)])
+def test_device_qp_hprod_matches_host_mirror(delta, rho, eta):
+    """fpsq_qp_hprod (device-resident hprod! Val(2)) against the host mirror of src/model-Fletcherpenaltynlp.jl:521-570
+    driven through the same back-end; the penalty Hessian approximation is symmetric to the Krylov tolerance."""
+    qp = _small_pde(seed=31, n=3000, m=300)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=rho, delta=delta, eta=eta, **TIGHT)
+    model = nlpmodels.EqQPModel(qp)
+    qds = HIPQDSolver(model, 0.0, **TIGHT)
+    fp = FletcherPenaltyNLP(model, sigma=1e3, rho=rho, delta=delta, hessian_approx=2, qds=qds)
+    fp.eta = eta
+    rng = np.random.default_rng(5)
+    v, w = rng.standard_normal(qp.n), rng.standard_normal(qp.n)
+    Hv, Hw = np.empty(qp.n), np.empty(qp.n)
+    assert dev.hprod(v, Hv) == 0 and dev.hprod(w, Hw) == 0
+    want = fp.hprod(qp.x, v)
+    assert _rel(Hv, want) < 1e-9
+    assert abs(w @ Hv - v @ Hw) <= 1e-7 * (np.linalg.norm(w) * np.linalg.norm(Hv))
+    dev.close()
+    qds.close()
+
+
 def test_torch_device_pointers_accepted():
     import torch
 
