@@ -190,9 +190,10 @@ def main():
             if sharded:  # c = Ax - b, then p1 = g - A'q1 and rho A'c as two single-RHS products
                 nbytes += J * at2 + (J + 1) * a2 + a1 + 2 * at1
                 productive += 2 * J + 4
-            else:        # single GPU: the last two share one raw two-RHS product A'[q1, c] (no yin read)
-                nbytes += J * at2 + (J + 1) * a2 + a1 + (at2 - 8 * 2 * n)
-                productive += 2 * J + 3
+            else:        # single GPU: c = Ax - b rides in the CRAIG lane of LSQR's start-up A product, and the last
+                         # two share one raw two-RHS product A'[q1, c] (no yin read)
+                nbytes += J * at2 + (J + 1) * a2 + (at2 - 8 * 2 * n)
+                productive += 2 * J + 2
             nbytes += max(il - 1, 0) * upd_at + ic * upd_a
         else:
             nbytes += (il + ic) * (a1 + at1) + a1 + a1 + 2 * at1

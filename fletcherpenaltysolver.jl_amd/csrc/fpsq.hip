@@ -848,6 +848,10 @@ struct Lane {
   double* y = nullptr;          // CRAIG: y (m)
   fpsq_stats* st = nullptr;     // destination of the final stats: an element of the host-mapped h->hstats
   fpsq_stats* st_dev = nullptr; // its device alias (filled by run_krylov / run_minres)
+  // fast start (qp_objgrad, fused single-GPU runs):
+  bool preloaded = false;               // LSQR: the caller already wrote rhs into the long pair's lane and ||rhs||^2 partials to pE
+  const double* affine_shift = nullptr; // CRAIG: rhs = -(A z - shift) with z already in the long pair's lane: formed by the
+  double* affine_out = nullptr;         //        LSQR start-up product (the lane is otherwise parked there); A z - shift -> affine_out
   // filled by run_krylov
   void* state = nullptr;
   LaneCtl* ctl = nullptr;
@@ -965,6 +969,9 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   }
   const LaneCtl* c0 = lanes[0].ctl;
   const LaneCtl* c1 = lanes[NL - 1].ctl;
+  int affine_lane = -1;  // fast start: the CRAIG lane whose right-hand side the LSQR start-up product forms
+  for (int l = 0; l < NL; ++l)
+    if (lanes[l].kind == LANE_CRAIG && lanes[l].affine_shift && any_lsqr && NL == 2 && !h->comm) affine_lane = l;
 
   // ---- start-up: parameters, right-hand sides, beta_1 (one launch), then (LSQR) alpha_1 and w_1
   StepArgs none{};
@@ -985,9 +992,13 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       // x = 0 is written by the w_1 start-up update (also when the recurrence ends at start-up)
       g.dst = LP;
       g.len = n;
-      g.nblk = gn;
+      g.nblk = L.preloaded ? 0 : gn;  // fast start: the caller wrote the lane and the ||rhs||^2 partials already
       (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
     } else {
+      if (L.affine_shift) {  // fast start: the lane receives `shift`; the start-up product turns it into -(A z - shift)
+        g.src = L.affine_shift;
+        g.scale = 1.0;
+      }
       g.dst = SP;
       g.len = m;
       g.nblk = gm;
@@ -1016,8 +1027,16 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   bool craig_begun = false;
   if (any_lsqr) {
     launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none);
-    // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes (CRAIG lane parked by ctl.skip)
-    launch_spmv<NL>(h, TAG_A, LP, SP, SP, c0, c1, h->pS2);
+    // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes.  The CRAIG lane is parked by ctl.skip -- unless its
+    // right-hand side is still to be formed (fast start): then it rides along with the constant pair (-1, +1):
+    // SP[.][l] <- -A z + shift, and the norm partials of the launch are those of its right-hand side.
+    {
+      const LaneCtl* s0c = c0;
+      const LaneCtl* s1c = c1;
+      if (affine_lane == 0) s0c = h->ctl_mp;
+      if (affine_lane == NL - 1 && affine_lane >= 0) s1c = h->ctl_mp;
+      launch_spmv<NL>(h, TAG_A, LP, SP, SP, s0c, s1c, h->pS2);
+    }
     StepArgs s0 = none, s1 = none;
     UpdSeg w0 = seg_none(), w1 = seg_none();
     for (int l = 0; l < NL; ++l) {
@@ -1041,9 +1060,22 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       // the CRAIG lane's beta_1 step shares the launch (it un-parks the lane: must follow the start-up product)
       for (int l = 0; l < NL; ++l)
         if (lanes[l].kind == LANE_CRAIG) {
-          s1 = step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]);
+          if (l == affine_lane)  // ||rhs||^2 came out of the start-up product
+            s1 = step_args(STEP_CRAIG_BEGIN, lanes[l], 0, h->pS2 + (size_t)l * nbA, nbA, nullptr, 0, prog[l]);
+          else
+            s1 = step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]);
           craig_begun = true;
         }
+    }
+    if (affine_lane >= 0) {  // keep A z - shift = -rhs before the first A product overwrites the lane
+      UpdSeg u = seg_none();
+      u.kind = UPD_NEG_COPY;
+      u.src = SP;
+      u.lane = affine_lane;
+      u.nblk = gm;
+      u.a = lanes[affine_lane].affine_out;
+      u.len = m;
+      (w0.nblk ? w1 : w0) = u;
     }
     if (int rc = launch_step(h, s0, s1, /*sharded=*/true)) return rc;
     if (fuse_upd) {  // w_1 rides in the first A' product
@@ -1351,7 +1383,10 @@ int soft_rc(const fpsq_stats st[2]) { return (st[0].solved ? 0 : 1) | (st[1].sol
 
 // device-side solve_two_mixed: g (n), c (m) device pointers; results left in h->p1, h->Lx[0] (q1), h->Cx (p2), h->Cy (q2)
 // defer_p1: the caller forms p1 = g - A'q1 itself (qp_objgrad pairs that product with A'c in one two-RHS launch)
-int two_mixed_device(fpsq_handle h, const double* g, const double* c, bool defer_p1 = false) {
+// affine_shift != null (fast start): c is NOT formed yet; CRAIG's right-hand side -(A z - shift), z in the long pair's
+// CRAIG lane, comes out of the LSQR start-up product and A z - shift is left in `c` (see run_krylov)
+int two_mixed_device(fpsq_handle h, const double* g, double* c, bool defer_p1 = false,
+                     const double* affine_shift = nullptr) {
   Lane lanes[2];
   // (q1, stats1) = solve_least_square(qds, Aop', rhs1, sqrt(delta))      src/solve_linear_system.jl:123
   lanes[0].kind = LANE_LSQR;
@@ -1363,6 +1398,11 @@ int two_mixed_device(fpsq_handle h, const double* g, const double* c, bool defer
   lanes[1].kind = LANE_CRAIG;
   lanes[1].rhs = c;
   lanes[1].rhs_scale = -1.0;
+  if (affine_shift) {
+    lanes[0].preloaded = true;
+    lanes[1].affine_shift = affine_shift;
+    lanes[1].affine_out = c;
+  }
   lanes[1].delta = h->delta;
   lanes[1].xsign = -1.0;
   lanes[1].x = h->Cx;
@@ -1865,13 +1905,18 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   }
   call_begin(h);
   // user-model evaluations of _compute_ys_gs!  (src/model-Fletcherpenaltynlp.jl:238-240)
-  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1]);
+  // Fast start (single GPU, fused recurrences): the gradient kernel writes the long pair {g, x} itself and the LSQR
+  // start-up product A u~_1, in which the CRAIG lane is otherwise parked, forms c = A x - b on the side: the separate
+  // c = A x - b product and the right-hand-side loads of the start-up are not launched.
+  const bool fast = !h->comm && h->opt.fuse_two_rhs != 0;
+  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1],
+                     fast ? h->LP : (double*)nullptr, fast ? h->pE : (double*)nullptr);
   h->launches++;
-  spmv_const(h, TAG_A, 1.0, dx, -1.0, qp->b, h->c);  // c = A x - b
+  if (!fast) spmv_const(h, TAG_A, 1.0, dx, -1.0, qp->b, h->c);  // c = A x - b
   // Single GPU with rho > 0: p1 = g - A'q1 and J'c (:424-428) share ONE two-right-hand-side product A'[q1, c], and
   // phi is reduced by an extra workgroup of the gradient kernel: 2 launches fewer at the end of every evaluation.
   const bool paired = !h->comm && rho > 0.0;
-  if (int rc = two_mixed_device(h, h->g, h->c, paired)) return rc;
+  if (int rc = two_mixed_device(h, h->g, h->c, paired, fast ? qp->b : nullptr)) return rc;
   // ys = q1 + sigma q2 and the dots of objgrad!
   hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax,
                      paired ? h->SP : (double*)nullptr);

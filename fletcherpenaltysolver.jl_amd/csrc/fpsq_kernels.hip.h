@@ -176,7 +176,10 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
 // ---- Krylov vector updates.  Several independent updates (the LSQR x/w update of the previous iteration, the CRAIG
 // long and short updates of this one) are merged into ONE launch: consecutive workgroup ranges run different bodies.
 
-enum UpdKind : int32_t { UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT };
+enum UpdKind : int32_t {
+  UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT,
+  UPD_NEG_COPY  // a[i] = -src[i][lane]: keeps c = -(CRAIG's right-hand side) when the start-up product formed it
+};
 
 struct UpdSeg {
   int32_t kind;
@@ -268,6 +271,10 @@ __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
     case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true>(s, blk); break;
     case UPD_CRAIG_LONG: upd_craig_long<NL, false>(s, blk); break;
     case UPD_CRAIG_SHORT: upd_craig_short<NL>(s, blk, red); break;
+    case UPD_NEG_COPY:
+      for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock)
+        s.a[i] = -s.src[i * NL + s.lane];
+      break;
     default: break;
   }
 }
@@ -762,15 +769,23 @@ __global__ __launch_bounds__(kBlock) void k_local_allreduce(ShardBufs B, int64_t
 
 // ---- equality-QP user model + penalty epilogues (src/model-Fletcherpenaltynlp.jl:238-248, 385-397, 419-433)
 
-// g = q .* x + d ;  partial of f = sum x (q x / 2 + d) ;  partial of ||x - xk||^2 when xk != null
+// g = q .* x + d ;  partial of f = sum x (q x / 2 + d) ;  partial of ||x - xk||^2 when xk != null.
+// lp != null (fast start of qp_objgrad): also lp[i] = {g_i, x_i} -- the long Golub-Kahan pair with LSQR's u~_1 = g in lane 0
+// and, in the still unused CRAIG lane, the point whose constraint values the start-up product will form -- and the
+// partials of ||g||^2 in pg.
 __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q, const double* __restrict__ d,
                                                     const double* __restrict__ x, const double* xk, double* g,
-                                                    int64_t n, double* pf, double* pdx) {
+                                                    int64_t n, double* pf, double* pdx, double* lp, double* pg) {
   __shared__ double red[4];
-  double f = 0.0, dx2 = 0.0;
+  double f = 0.0, dx2 = 0.0, gg = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const double xi = x[i], qi = q[i], di = d[i];
-    g[i] = qi * xi + di;
+    const double gi = qi * xi + di;
+    g[i] = gi;
+    if (lp) {
+      *reinterpret_cast<double2*>(lp + 2 * i) = make_double2(gi, xi);
+      gg += gi * gi;
+    }
     f += xi * (0.5 * qi * xi + di);
     if (xk) {
       const double t = xi - xk[i];
@@ -781,6 +796,10 @@ __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q
   if (threadIdx.x == 0) pf[blockIdx.x] = tf;
   const double td = block_sum(dx2, red);
   if (threadIdx.x == 0) pdx[blockIdx.x] = td;
+  if (lp) {
+    const double tg = block_sum(gg, red);
+    if (threadIdx.x == 0) pg[blockIdx.x] = tg;
+  }
 }
 
 // ys = q1 + sigma q2 ; partials of c'ys and c'c            (m-vectors)
