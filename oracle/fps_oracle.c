@@ -784,7 +784,7 @@ int fpo_qp_objgrad(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *c
                    double rho, double delta, double eta, const double *xk, const fpo_options *o, double *gx,
                    double *fx_out, double *ys, double *gs, fpo_stats st[2]) {
   fpo_csr A = {m, n, rowptr, colind, vals};
-  double *g = malloc((size_t)n * 8), *c = malloc((size_t)m * 8);
+  double *g = malloc((size_t)n * 8), *c = calloc((size_t)(m > 0 ? m : 1), 8);
   double *p1 = malloc((size_t)n * 8), *q1 = malloc((size_t)m * 8);
   double *p2 = malloc((size_t)n * 8), *q2 = malloc((size_t)m * 8);
   double *Jc = malloc((size_t)n * 8);
