@@ -34,13 +34,13 @@ def pb(nrhs):
 a1, at1 = pb(1)
 a2, at2 = pb(2)
 upd_at, upd_a = 8 * 5 * m, 8 * (3 * n + 5 * m)
+# One evaluation (fast start + paired epilogue product, bench.py default): J + 1 two-RHS A products (the start-up one
+# without riding updates), J two-RHS A' products with the LSQR update riding + ONE raw two-RHS A' product (no yin read).
 alg = {  # average algorithmic bytes of a productive launch (products + the vector updates riding in them)
     "k_spmv_rgcs<2": (J * (a2 + upd_a) + a2) / (J + 1),
-    "k_spmv<2, 1": at2 + upd_at * (J - 1) / J,
-    "k_spmv_rgcs<1": a1,
-    "k_spmv<1, 1": at1,
+    "k_spmv<2, 1": (J * at2 + upd_at * (J - 1) + (at2 - 8 * 2 * n)) / (J + 1),
 }
-mix = {"k_spmv_rgcs<2": J + 1, "k_spmv<2, 1": J, "k_spmv_rgcs<1": 1, "k_spmv<1, 1": 2}
+mix = {"k_spmv_rgcs<2": J + 1, "k_spmv<2, 1": J + 1}
 out = {"_how": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "workload": "pde-control-like n=1e6 m=1e5 nnz=1e7",
        "joint_iterations": J, "kernels": {}}
 tb = ab = 0.0
