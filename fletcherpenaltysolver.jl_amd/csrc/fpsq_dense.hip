@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,6 +25,7 @@ struct fpsq_dense_s {
   double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
   int* info_dev = nullptr;
   int nchunk = 16;
+  int potrf_gen = 2;  // diagonal-block kernel: 2 = wave-level (k_potrf_inv128w), 1 = unblocked (FPSQ_DENSE_POTRF=1)
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   fpsq_dense_info info{};
   std::vector<void*> allocs;
@@ -142,6 +144,9 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   // the potrf + inverse kernel keeps a 128 x 129 (+ 128) fp64 block in dynamic LDS
   hipFuncSetAttribute((const void*)k_potrf_inv128, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (kDB * (kDB + 1) + kDB) * 8);
+  hipFuncSetAttribute((const void*)k_potrf_inv128w, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (kDB * (kDB + 1) + kDB) * 8);
+  if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) d->potrf_gen = std::atoi(ev);
   d->info.n = n;
   d->info.m = m;
   *out = d;
@@ -194,8 +199,12 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
   for (int k = 0; k < nb; ++k) {
     double* Mkk = d->M + (size_t)k * kDB * ld + (size_t)k * kDB;
     double* inv = d->invs + (size_t)k * kDB * kDB;
-    hipLaunchKernelGGL(k_potrf_inv128, dim3(1), dim3(kPotrfThreads), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
-                       d->info_dev);
+    if (d->potrf_gen == 1)
+      hipLaunchKernelGGL(k_potrf_inv128, dim3(1), dim3(kPotrfThreads), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
+                         d->info_dev);
+    else
+      hipLaunchKernelGGL(k_potrf_inv128w, dim3(1), dim3(256), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
+                         d->info_dev);
     const int rem = nb - k - 1;
     if (rem > 0) {
       double* panel = d->M + (size_t)(k + 1) * kDB * ld + (size_t)k * kDB;

@@ -186,6 +186,154 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv128(double* Mkk, int
   }
 }
 
+// ---- the same diagonal-block job, second generation: 64 x 64 sub-blocks factored and inverted by ONE WAVE with the
+// rows in registers (lane i = row i; broadcasts are v_readlane, no LDS traffic and no workgroup barrier in the 64
+// column steps), glued by 4 x 4 register-tiled 64^3 products on the LDS copy:
+//   A = [A11 0; A21 A22]:  L11 = chol(A11), X11 = L11^-1, L21 = A21 X11', A22 -= L21 L21', L22 = chol(A22), X22 = L22^-1,
+//   X21 = -X22 (L21 X11).
+// The unblocked kernel above costs ~1.07 us per column step (three 16-wave barriers each): 274 us per block.
+__device__ __forceinline__ double rdlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Cholesky of the 64 x 64 block at (o, o) of the LDS matrix, by the calling wave; the factor replaces the block's lower
+// triangle in LDS.  a[] (the lane's row of the factor) stays live for the caller.
+__device__ __forceinline__ void wave_potrf64(double* L, int LD, int o, int row0, int* info, double* a) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) a[c] = L[(o + lane) * LD + o + c];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const double d = rdlane(a[j], j);
+    const bool bad = !(d > 0.0);
+    if (bad && lane == 0) atomicCAS(info, 0, row0 + o + j + 1);
+    const double piv = bad ? 1.0 : sqrt(d);  // a unit pivot keeps the kernel finite; the caller reports `info`
+    const double rp = 1.0 / piv;              // (uniform: one division per column, not one per row)
+    const double l = lane > j ? a[j] * rp : (lane == j ? piv : 0.0);
+    a[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < 64; ++c) a[c] -= l * rdlane(l, c);  // (meaningful for lanes >= c; the rest is never read)
+  }
+#pragma unroll
+  for (int c = 0; c < 64; ++c) L[(o + lane) * LD + o + c] = c <= lane ? a[c] : 0.0;
+}
+
+// X = L^-1 for the 64 x 64 lower-triangular block whose rows are in a[] (wave_potrf64); X replaces the block in LDS.
+// acc_i = e_i - sum_{k<i} L[i][k] X[k][.] is built by sweeping k; row k of X = acc_k / L[k][k] is broadcast on the fly.
+__device__ __forceinline__ void wave_trtri64(double* L, int LD, int o, const double* a) {
+  const int lane = threadIdx.x & 63;
+  double acc[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = c == lane ? 1.0 : 0.0;
+  double dsel = 1.0;  // this lane's diagonal entry (a[lane]), selected without dynamic register indexing
+#pragma unroll
+  for (int c = 0; c < 64; ++c) dsel = c == lane ? a[c] : dsel;
+  const double dinv = 1.0 / dsel;
+#pragma unroll
+  for (int k = 0; k < 63; ++k) {
+    const double dk = rdlane(dinv, k);
+    const double lik = lane > k ? a[k] : 0.0;
+#pragma unroll
+    for (int c = 0; c <= k; ++c) acc[c] -= lik * (rdlane(acc[c], k) * dk);
+  }
+#pragma unroll
+  for (int c = 0; c < 64; ++c) L[(o + lane) * LD + o + c] = c <= lane ? acc[c] * dinv : 0.0;
+}
+
+// C (64 x 64 at LDS (cr, cc)) = alpha * A B^T or alpha * A B (+ C) with A at (ar, ac), B at (br, bc); 256 threads, 4 x 4
+// outputs each.  TB: 0 -> sum_k A[i][k] B[j][k], 1 -> sum_k A[i][k] B[k][j].  The result is RETURNED in registers: the caller
+// synchronises before storing (outputs may overlay inputs).
+template <int TB>
+__device__ __forceinline__ void tile64(const double* L, int LD, int ar, int ac, int br, int bc, double out[4][4]) {
+  const int ti = (threadIdx.x >> 4) * 4, tj = (threadIdx.x & 15) * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[r][c] = 0.0;
+  for (int k = 0; k < 64; ++k) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) av[r] = L[(ar + ti + r) * LD + ac + k];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bv[c] = TB == 0 ? L[(br + tj + c) * LD + bc + k] : L[(br + k) * LD + bc + tj + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[r][c] += av[r] * bv[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_potrf_inv128w(double* Mkk, int ld, double* inv, int row0, int* info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* L = sm;
+  constexpr int LD = kDB + 1;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    L[r * LD + c] = (c <= r) ? Mkk[(size_t)r * ld + c] : 0.0;
+  }
+  __syncthreads();
+  double t[4][4];
+  // L11, then X11 in its place (L11 goes to global first)
+  if (wave == 0) {
+    double a[64];
+    wave_potrf64(L, LD, 0, row0, info, a);
+    const int lane = tid;
+    for (int c = 0; c <= lane; ++c) Mkk[(size_t)lane * ld + c] = L[lane * LD + c];
+    wave_trtri64(L, LD, 0, a);
+  }
+  __syncthreads();
+  // L21 = A21 X11'   (X11 lower: terms with k > column vanish because X11's upper part is stored as zeros)
+  tile64<0>(L, LD, 64, 0, 0, 0, t);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      L[(64 + ti + r) * LD + tj + c] = t[r][c];
+      Mkk[(size_t)(64 + ti + r) * ld + tj + c] = t[r][c];
+    }
+  __syncthreads();
+  // A22 -= L21 L21'
+  tile64<0>(L, LD, 64, 0, 64, 0, t);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L[(64 + ti + r) * LD + 64 + tj + c] -= t[r][c];
+  __syncthreads();
+  // L22, X22
+  if (wave == 0) {
+    double a[64];
+    wave_potrf64(L, LD, 64, row0, info, a);
+    const int lane = tid;
+    for (int c = 0; c <= lane; ++c) Mkk[(size_t)(64 + lane) * ld + 64 + c] = L[(64 + lane) * LD + 64 + c];
+    wave_trtri64(L, LD, 64, a);
+  }
+  __syncthreads();
+  // X21 = -X22 (L21 X11)
+  tile64<1>(L, LD, 64, 0, 0, 0, t);   // T = L21 X11
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L[(64 + ti + r) * LD + tj + c] = t[r][c];
+  __syncthreads();
+  tile64<1>(L, LD, 64, 64, 64, 0, t);  // X22 T
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L[(64 + ti + r) * LD + tj + c] = -t[r][c];
+  __syncthreads();
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    inv[(size_t)r * kDB + c] = (c <= r) ? L[r * LD + c] : 0.0;
+  }
+}
+
 // y (len rows) = A (rows x cols, lda) x, for NR right-hand sides interleaved [..][NR]; one wave per row.
 template <int NR>
 __global__ __launch_bounds__(256) void k_dense_gemv(const double* __restrict__ A, int lda, int rows, int cols,
