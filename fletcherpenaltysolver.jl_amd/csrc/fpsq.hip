@@ -1970,8 +1970,8 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   return soft_rc(st);
 }
 
-static int fpsq_qp_hprod_once(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta,
-                              double* Hv, fpsq_stats st[2]) {
+int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta, double* Hv,
+                  fpsq_stats st[2]) {
   if (int rc = check_ready(h)) return rc;
   if (!qp || qp->h != h || !v || !Hv || !st) {
     h->err = "qp_hprod: bad argument";
@@ -2007,12 +2007,6 @@ static int fpsq_qp_hprod_once(fpsq_handle h, fpsq_qp qp, const double* v, double
   st[0] = h->hstats[0];
   st[1] = h->hstats[1];
   return soft_rc(st);
-}
-
-int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta, double* Hv,
-                  fpsq_stats st[2]) {
-  int rc = fpsq_qp_hprod_once(h, qp, v, sigma, rho, eta, Hv, st);
-  return rc;
 }
 
 int fpsq_comm_unique_id(uint8_t id[128]) {
