@@ -633,3 +633,48 @@ def test_config_headline_full_size_properties():
         assert dev.solve_two_least_squares(r1 + 2.0 * r2, r2, s1, t1, s2, t2) == 0
         assert _rel(t1, b1 + 2.0 * b2) < 1e-5 and _rel(t2, b2) < 1e-9
         dev.close()
+
+
+def test_error_codes_of_the_c_abi():
+    """Hard errors are negative codes with a message, never exceptions or crashes: calls out of order,
+    null arguments, a model that belongs to another handle, unsupported combinations."""
+    lib = _lib.load()
+    o = _lib.Options()
+    lib.fpsq_default_options(50, 5, C.byref(o))
+    h = C.c_void_p()
+    assert lib.fpsq_create(C.byref(h), 50, 5, C.byref(o)) == 0
+    st = (_lib.Stats * 2)()
+    z = np.zeros(50)
+    zm = np.zeros(5)
+    # solve before the Jacobian structure / values exist
+    rc = lib.fpsq_solve_two_mixed(h, z.ctypes.data, zm.ctypes.data, z.ctypes.data, zm.ctypes.data, z.ctypes.data,
+                                  zm.ctypes.data, st)
+    assert rc == -3 and lib.fpsq_last_error(h)
+    A = sp.random(5, 50, density=0.3, random_state=np.random.default_rng(3), format="csr")
+    A.sort_indices()
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    assert lib.fpsq_set_jacobian_structure_csr(h, rp.ctypes.data, ci.ctypes.data) == 0
+    rc = lib.fpsq_solve_two_mixed(h, z.ctypes.data, zm.ctypes.data, z.ctypes.data, zm.ctypes.data, z.ctypes.data,
+                                  zm.ctypes.data, st)
+    assert rc == -3  # structure but no values yet
+    assert lib.fpsq_set_jacobian_values(h, A.data.ctypes.data) == 0
+    assert lib.fpsq_set_delta(h, -1.0) < 0  # delta must be >= 0
+    assert lib.fpsq_solve_two_mixed(h, None, zm.ctypes.data, z.ctypes.data, zm.ctypes.data, z.ctypes.data,
+                                    zm.ctypes.data, st) == -1
+    assert lib.fpsq_jac_mul(h, 0, 1.0, None, 0.0, zm.ctypes.data) == -1
+    # a QP model created on another handle is rejected
+    h2 = C.c_void_p()
+    assert lib.fpsq_create(C.byref(h2), 50, 5, C.byref(o)) == 0
+    assert lib.fpsq_set_jacobian_structure_csr(h2, rp.ctypes.data, ci.ctypes.data) == 0
+    assert lib.fpsq_set_jacobian_values(h2, A.data.ctypes.data) == 0
+    q = C.c_void_p()
+    ones = np.ones(50)
+    assert lib.fpsq_qp_create(h2, ones.ctypes.data, z.ctypes.data, zm.ctypes.data, C.byref(q)) == 0
+    fx = C.c_double()
+    assert lib.fpsq_qp_objgrad(h, q, z.ctypes.data, 1.0, 1.0, 0.0, None, C.byref(fx), None, None, None, st) == -1
+    assert lib.fpsq_qp_hprod(h, q, z.ctypes.data, 1.0, 1.0, 0.0, z.ctypes.data, st) == -1
+    # and the right pairing works
+    assert lib.fpsq_qp_objgrad(h2, q, z.ctypes.data, 1.0, 1.0, 0.0, None, C.byref(fx), None, None, None, st) >= 0
+    lib.fpsq_qp_destroy(q)
+    lib.fpsq_destroy(h2)
+    lib.fpsq_destroy(h)
