@@ -11,9 +11,12 @@ import numpy as np
 
 
 class _Model:
-    def __init__(self, nvar, ncon, nnzj, x0, lcon=None, name="model"):
+    def __init__(self, nvar, ncon, nnzj, x0, lcon=None, name="model", lin=()):
+        lin = np.asarray(sorted(lin), dtype=np.int64)          # 0-based indices of the linear constraints
+        nln = np.setdiff1d(np.arange(ncon, dtype=np.int64), lin)
         self.meta = SimpleNamespace(nvar=nvar, ncon=ncon, nnzj=nnzj, x0=np.asarray(x0, float),
-                                    lcon=np.zeros(ncon) if lcon is None else np.asarray(lcon, float), name=name)
+                                    lcon=np.zeros(ncon) if lcon is None else np.asarray(lcon, float), name=name,
+                                    lin=lin, nln=nln, nlin=int(lin.size), nnln=int(nln.size))
 
     def jtprod(self, x, v):
         rows, cols = self.jac_structure()
@@ -30,6 +33,72 @@ class _Model:
     def ghjvprod(self, x, g, v):
         """(g' Hess c_i v)_i; zero unless a model overrides it (linear constraints)."""
         return np.zeros(self.meta.ncon)
+
+
+class NonlinearConstraintsView(_Model):
+    """The model seen by the penalty function when `explicit_linear_constraints = true`: same objective, only the
+    NONLINEAR constraints (NLPModels' cons_nln!, jac_nln_structure!, jac_nln_coord!, jtprod_nln!, and the `lag_mul`
+    scatter of hprod_nln! / ghjvprod_nln!, src/model-Fletcherpenaltynlp.jl:282-350)."""
+
+    def __init__(self, nlp):
+        self.base = nlp
+        rows, cols = nlp.jac_structure()
+        rows = np.asarray(rows, dtype=np.int64) - 1
+        keep = np.isin(rows, nlp.meta.nln)
+        renum = -np.ones(nlp.meta.ncon, dtype=np.int64)
+        renum[nlp.meta.nln] = np.arange(nlp.meta.nnln)
+        self._keep = keep
+        self._struct = (renum[rows[keep]] + 1, np.asarray(cols, dtype=np.int64)[keep])
+        super().__init__(nlp.meta.nvar, nlp.meta.nnln, int(keep.sum()), nlp.meta.x0, lcon=nlp.meta.lcon[nlp.meta.nln],
+                         name=nlp.meta.name + " (nonlinear constraints)")
+
+    def obj(self, x): return self.base.obj(x)
+    def grad(self, x): return self.base.grad(x)
+    def cons(self, x): return np.asarray(self.base.cons(x))[self.base.meta.nln]
+    def jac_structure(self): return self._struct
+    def jac_coord(self, x): return np.asarray(self.base.jac_coord(x))[self._keep]
+
+    def _lag(self, y):
+        full = np.zeros(self.base.meta.ncon)
+        full[self.base.meta.nln] = y
+        return full
+
+    def hprod(self, x, y, v, obj_weight=1.0): return self.base.hprod(x, self._lag(y), v, obj_weight=obj_weight)
+    def ghjvprod(self, x, g, v): return np.asarray(self.base.ghjvprod(x, g, v))[self.base.meta.nln]
+
+
+class LinearPlusCircle(_Model):
+    """f = x'x, c1 = x1 + x2 + x3 - 1 (linear), c2 = x1^2 + x2^2 - 1/2 (nonlinear): a small model with both kinds of
+    equality constraints for `explicit_linear_constraints` (the reference's option, src/parameters.jl:84)."""
+
+    def __init__(self, with_linear=True):
+        self.with_linear = with_linear
+        super().__init__(3, 2 if with_linear else 1, 5 if with_linear else 2, np.array([0.3, 0.8, -0.2]),
+                         name="linear+circle", lin=(0,) if with_linear else ())
+
+    def obj(self, x): return float(x @ x)
+    def grad(self, x): return 2.0 * np.asarray(x, float)
+
+    def cons(self, x):
+        nl = x[0] ** 2 + x[1] ** 2 - 0.5
+        return np.array([x.sum() - 1.0, nl]) if self.with_linear else np.array([nl])
+
+    def jac_structure(self):
+        if self.with_linear:
+            return np.array([1, 1, 1, 2, 2]), np.array([1, 2, 3, 1, 2])
+        return np.array([1, 1]), np.array([1, 2])
+
+    def jac_coord(self, x):
+        nl = np.array([2 * x[0], 2 * x[1]])
+        return np.concatenate([np.ones(3), nl]) if self.with_linear else nl
+
+    def hprod(self, x, y, v, obj_weight=1.0):
+        ynl = y[1] if self.with_linear else y[0]
+        return obj_weight * 2.0 * np.asarray(v, float) + ynl * np.array([2 * v[0], 2 * v[1], 0.0])
+
+    def ghjvprod(self, x, g, v):
+        val = 2 * g[0] * v[0] + 2 * g[1] * v[1]
+        return np.array([0.0, val]) if self.with_linear else np.array([val])
 
 
 class SumSquares(_Model):

@@ -16,14 +16,27 @@ class FletcherPenaltyNLP:
     Defaults follow the keyword constructor at :194-204 (sigma_0 = 1, rho_0 = delta_0 = 0, Val(2)); the
     reference's default `qds` is the CPU LDLtSolver (:113), here it is the MI355X back-end."""
 
-    def __init__(self, nlp, sigma=1.0, rho=0.0, delta=0.0, hessian_approx=2, x0=None, *, qds: QDSolver | None = None):
+    def __init__(self, nlp, sigma=1.0, rho=0.0, delta=0.0, hessian_approx=2, x0=None, *, qds: QDSolver | None = None,
+                 explicit_linear_constraints=False):
         self.nlp = nlp
         self.sigma, self.rho, self.delta, self.eta = sigma, rho, delta, 0.0
         self.hessian_approx = hessian_approx
-        n, m = nlp.meta.nvar, nlp.meta.ncon
-        self.meta = type(nlp.meta)(nvar=n, ncon=0, x0=np.asarray(nlp.meta.x0 if x0 is None else x0, float),
+        # explicit_linear_constraints (:112-141): only the NONLINEAR constraints are penalised -- `pen` is the model the
+        # penalty function and the back-end see -- and the linear ones stay constraints of this model (meta.ncon = nlin,
+        # cons / jprod / jtprod below), left to a sub-solver that handles linear constraints
+        self.explicit_linear_constraints = bool(explicit_linear_constraints)
+        if self.explicit_linear_constraints:
+            from .nlpmodels import NonlinearConstraintsView
+            self.pen = NonlinearConstraintsView(nlp)
+        else:
+            self.pen = nlp
+        n, m = nlp.meta.nvar, self.pen.meta.ncon
+        nlin = nlp.meta.nlin if self.explicit_linear_constraints else 0
+        self.meta = type(nlp.meta)(nvar=n, ncon=nlin, x0=np.asarray(nlp.meta.x0 if x0 is None else x0, float),
+                                   lcon=nlp.meta.lcon[nlp.meta.lin] if nlin else np.zeros(0),
                                    name=f"Fletcher penalization of {nlp.meta.name}")
-        self.qdsolver = qds if qds is not None else HIPQDSolver(nlp, 0.0)
+        self.qdsolver = qds if qds is not None else HIPQDSolver(
+            nlp, 0.0, explicit_linear_constraints=self.explicit_linear_constraints)
         self.shahx = None
         self.fx = float("nan")
         self.cx, self.gx = np.empty(m), np.empty(n)
@@ -34,7 +47,7 @@ class FletcherPenaltyNLP:
 
     # :260-269
     def cons_norhs(self, x):
-        return self.nlp.cons(x) - self.nlp.meta.lcon
+        return self.pen.cons(x) - self.pen.meta.lcon  # (cons_nln! and lcon[nln] when the linear ones are explicit)
 
     # :215-227
     def linear_system2(self, x):
@@ -73,11 +86,11 @@ class FletcherPenaltyNLP:
         assert x.size == self.meta.nvar and gx.size == self.meta.nvar
         self.counters["neval_grad"] += 1
         gs, ys, v, w = self._compute_ys_gs(x)
-        Hsv = self.nlp.hprod(x, ys, v, obj_weight=1.0)
-        Sstw = self.nlp.hprod(x, w, gs, obj_weight=0.0)
+        Hsv = self.pen.hprod(x, ys, v, obj_weight=1.0)
+        Sstw = self.pen.hprod(x, w, gs, obj_weight=0.0)
         gx[:] = gs - Hsv + self.sigma * v + Sstw
         if self.rho > 0.0:
-            gx += self.nlp.jtprod(x, self.cx) * self.rho
+            gx += self.pen.jtprod(x, self.cx) * self.rho
         if self.eta > 0.0:
             gx += self.eta * (x - self.xk)
         return gx
@@ -110,21 +123,21 @@ class FletcherPenaltyNLP:
         gs, ys, _, _ = self._compute_ys_gs(x)
         c = self.cx
         Jv = -ys                                                             # :536 / :590
-        Hsv = self.nlp.hprod(x, Jv, v, obj_weight=1.0)                       # :537 / :591
+        Hsv = self.pen.hprod(x, Jv, v, obj_weight=1.0)                       # :537 / :591
         p1, _, p2, _ = self.qdsolver.solve_two_least_squares(self, x, v, Hsv)  # :542 / :593
         Ptv = v - p1                                                         # :543 / :594
-        HsPtv = self.nlp.hprod(x, Jv, Ptv, obj_weight=1.0)                   # :545 / :598
+        HsPtv = self.pen.hprod(x, Jv, Ptv, obj_weight=1.0)                   # :545 / :598
         if self.hessian_approx == 2:
             Hv[:] = p2 - HsPtv + 2 * sigma * Ptv                             # :550
         else:
-            Ssv = self.nlp.ghjvprod(x, gs, v)                                # :600
+            Ssv = self.pen.ghjvprod(x, gs, v)                                # :600
             invJtJJv, invJtJSsv = self.qdsolver.solve_two_extras(self, x, v, Ssv)  # :602
-            JtinvJtJSsv = self.nlp.jtprod(x, invJtJSsv)                      # :606
+            JtinvJtJSsv = self.pen.jtprod(x, invJtJSsv)                      # :606
             Hv[:] = p2 - HsPtv + 2 * sigma * Ptv - JtinvJtJSsv               # :612
-            Hv -= self.nlp.hprod(x, invJtJJv, gs, obj_weight=0.0)            # :613-614
+            Hv -= self.pen.hprod(x, invJtJJv, gs, obj_weight=0.0)            # :613-614
         if rho > 0.0:
-            JtJv = self.nlp.jtprod(x, self.nlp.jprod(x, v))                  # :557-558 / :621-622
-            Hcv = self.nlp.hprod(x, c, v, obj_weight=0.0)                    # :560 / :624
+            JtJv = self.pen.jtprod(x, self.pen.jprod(x, v))                  # :557-558 / :621-622
+            Hcv = self.pen.hprod(x, c, v, obj_weight=0.0)                    # :560 / :624
             Hv += Hcv + rho * JtJv if self.hessian_approx == 2 else rho * (Hcv + JtJv)  # :562 / :626
         if self.eta > 0.0:
             Hv += self.eta * v
@@ -133,3 +146,31 @@ class FletcherPenaltyNLP:
 
     def hprod(self, x, v, obj_weight=1.0):
         return self.hprod_(x, v, np.empty(self.meta.nvar), obj_weight)
+
+    # :636-726 -- the linear constraints kept explicit (cons_lin!, jprod_lin!, jtprod_lin! of the wrapped model)
+    def _lin_rows(self):
+        rows, cols = self.nlp.jac_structure()
+        rows = np.asarray(rows, dtype=np.int64) - 1
+        keep = np.isin(rows, self.nlp.meta.lin)
+        renum = -np.ones(self.nlp.meta.ncon, dtype=np.int64)
+        renum[self.nlp.meta.lin] = np.arange(self.nlp.meta.nlin)
+        return keep, renum[rows[keep]], np.asarray(cols, dtype=np.int64)[keep] - 1
+
+    def cons(self, x):
+        if not self.explicit_linear_constraints:
+            return np.zeros(0)
+        return np.asarray(self.nlp.cons(np.asarray(x, float)))[self.nlp.meta.lin]
+
+    def jprod(self, x, v):
+        out = np.zeros(self.meta.ncon)
+        if self.meta.ncon:
+            keep, r, c = self._lin_rows()
+            np.add.at(out, r, np.asarray(self.nlp.jac_coord(x))[keep] * np.asarray(v, float)[c])
+        return out
+
+    def jtprod(self, x, v):
+        out = np.zeros(self.meta.nvar)
+        if self.meta.ncon:
+            keep, r, c = self._lin_rows()
+            np.add.at(out, c, np.asarray(self.nlp.jac_coord(x))[keep] * np.asarray(v, float)[r])
+        return out

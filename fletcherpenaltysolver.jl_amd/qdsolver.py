@@ -38,8 +38,10 @@ class HIPQDSolver(QDSolver):
     ne_etol, ne_itmax, ne_conlim; unknown keywords are swallowed like the reference's `kwargs...`."""
 
     def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, **kwargs):
-        if explicit_linear_constraints:
-            raise NotImplementedError("explicit_linear_constraints=True is outside this build's hot-path scope")
+        if explicit_linear_constraints:  # the systems then involve the NONLINEAR constraints only (struct.jl:101-103,333)
+            from .nlpmodels import NonlinearConstraintsView
+            nlp = NonlinearConstraintsView(nlp)
+        self.explicit_linear_constraints = bool(explicit_linear_constraints)
         self._lib = _lib.load()
         self.nvar, self.ncon = int(nlp.meta.nvar), int(nlp.meta.ncon)
         opts = _lib.Options()
@@ -81,7 +83,7 @@ class HIPQDSolver(QDSolver):
 
     def _refresh(self, nlp, x, values=True):
         if values:
-            vals = np.ascontiguousarray(nlp.nlp.jac_coord(x), dtype=np.float64)
+            vals = np.ascontiguousarray(nlp.pen.jac_coord(x), dtype=np.float64)  # jac_coord! / jac_nln_coord! (:223-228)
             self._check(self._lib.fpsq_set_jacobian_values(self._h, vals.ctypes.data))
         if self._delta != nlp.delta:
             self._check(self._lib.fpsq_set_delta(self._h, float(nlp.delta)))
@@ -154,7 +156,9 @@ class HIPDirectQDSolver(QDSolver):
 
     def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, **kwargs):
         if explicit_linear_constraints:
-            raise NotImplementedError("explicit_linear_constraints=True is outside this build's hot-path scope")
+            from .nlpmodels import NonlinearConstraintsView
+            nlp = NonlinearConstraintsView(nlp)
+        self.explicit_linear_constraints = bool(explicit_linear_constraints)
         self._lib = _lib.load()
         self.nvar, self.ncon = int(nlp.meta.nvar), int(nlp.meta.ncon)
         d = C.c_void_p()
@@ -185,7 +189,7 @@ class HIPDirectQDSolver(QDSolver):
 
     def _factorize(self, nlp, x):
         self._A[:] = 0.0
-        np.add.at(self._A, (self._rows, self._cols), np.asarray(nlp.nlp.jac_coord(x), dtype=np.float64))
+        np.add.at(self._A, (self._rows, self._cols), np.asarray(nlp.pen.jac_coord(x), dtype=np.float64))
         self._check(self._lib.fpsq_dense_set_jacobian(self._d, self._A.ctypes.data))
         info = C.c_int32()
         rc = self._check(self._lib.fpsq_dense_factorize(self._d, float(nlp.delta), C.byref(info)))

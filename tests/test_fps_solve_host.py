@@ -41,3 +41,23 @@ def test_parameter_schedule_defaults_and_updates():
     assert (fp.sigma, fp.rho, fp.shahx) == (2e3, 1.0, None)
     F._update_parameters(fp, meta, feas=False)
     assert (fp.sigma, fp.rho) == (4e3, 2.0)
+
+
+def test_nonlinear_constraints_view_is_the_model_without_its_linear_rows():
+    """explicit_linear_constraints: the penalty function sees cons_nln! / jac_nln_* / the lag_mul scatter of hprod_nln!
+    (src/model-Fletcherpenaltynlp.jl:260-350).  The view of a model with one linear and one nonlinear constraint must
+    coincide with the same model written without the linear constraint."""
+    from fps_amd import nlpmodels
+
+    full, nl = nlpmodels.LinearPlusCircle(True), nlpmodels.LinearPlusCircle(False)
+    assert (full.meta.nlin, full.meta.nnln, list(full.meta.lin), list(full.meta.nln)) == (1, 1, [0], [1])
+    view = nlpmodels.NonlinearConstraintsView(full)
+    rng = np.random.default_rng(2)
+    x, v, g = rng.standard_normal(3), rng.standard_normal(3), rng.standard_normal(3)
+    y = rng.standard_normal(1)
+    assert view.meta.ncon == 1 and np.allclose(view.cons(x), nl.cons(x))
+    for a, b in zip(view.jac_structure(), nl.jac_structure()):
+        assert np.array_equal(a, b)
+    assert np.allclose(view.jac_coord(x), nl.jac_coord(x))
+    assert np.allclose(view.jtprod(x, y), nl.jtprod(x, y)) and np.allclose(view.jprod(x, v), nl.jprod(x, v))
+    assert np.allclose(view.hprod(x, y, v), nl.hprod(x, y, v)) and np.allclose(view.ghjvprod(x, g, v), nl.ghjvprod(x, g, v))

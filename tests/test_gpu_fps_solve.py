@@ -43,3 +43,33 @@ def test_hs7(sub, ha):
     stats = fps_solve(nlp, nlp.meta.x0, qds_solver="hip_direct", subproblem_solver=sub, hessian_approx=ha)
     _accept(stats, nlp.meta.x0)
     assert abs(stats.objective + np.sqrt(3.0)) < 1e-6 and abs(stats.solution[0]) < 1e-4
+
+
+@pytest.mark.parametrize("backend", ["hip", "hip_direct"])
+@pytest.mark.parametrize("ha", [1, 2])
+def test_explicit_linear_constraints_penalise_only_the_nonlinear_ones(backend, ha):
+    """`explicit_linear_constraints = true` (src/model-Fletcherpenaltynlp.jl:112-141): phi, grad phi and the Hessian
+    products are those of the model WITHOUT its linear constraint, which stays a constraint of the penalised model."""
+    from fps_amd.penalty_nlp import FletcherPenaltyNLP
+    from fps_amd.qdsolver import qdsolver_correspondence
+
+    Q = qdsolver_correspondence[backend]
+    full, nl = nlpmodels.LinearPlusCircle(True), nlpmodels.LinearPlusCircle(False)
+    tight = dict(ls_atol=1e-15, ls_rtol=1e-15, ln_atol=1e-15, ln_rtol=1e-15, ln_btol=1e-15, ln_conlim=0.0,
+                 ls_axtol=1e-15, ls_btol=1e-15, ls_etol=1e-15, ne_atol=1e-15, ne_rtol=1e-15, ne_etol=1e-15)
+    qe = Q(full, 0.0, explicit_linear_constraints=True, **tight)
+    qn = Q(nl, 0.0, **tight)
+    fe = FletcherPenaltyNLP(full, 10.0, 0.5, 1e-3, ha, explicit_linear_constraints=True, qds=qe)
+    fn = FletcherPenaltyNLP(nl, 10.0, 0.5, 1e-3, ha, qds=qn)
+    assert fe.meta.ncon == 1 and fn.meta.ncon == 0
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        x, v = rng.standard_normal(3), rng.standard_normal(3)
+        f1, g1 = fe.objgrad(x)
+        f2, g2 = fn.objgrad(x)
+        assert abs(f1 - f2) <= 1e-10 * max(1.0, abs(f2)) and np.allclose(g1, g2, rtol=1e-9, atol=1e-10)
+        assert np.allclose(fe.hprod(x, v), fn.hprod(x, v), rtol=1e-7, atol=1e-8)
+        assert np.allclose(fe.cons(x), [x.sum() - 1.0])
+        assert np.allclose(fe.jprod(x, v), [v.sum()]) and np.allclose(fe.jtprod(x, np.array([2.0])), 2.0 * np.ones(3))
+    qe.close()
+    qn.close()
