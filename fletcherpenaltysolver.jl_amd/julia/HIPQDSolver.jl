@@ -38,12 +38,14 @@ mutable struct HIPQDSolver{T, S} <: QDSolver
   p1::S; q1::S; p2::S; q2::S
   stats::Vector{FpsqStats}
   δ::T
+  explicit_linear_constraints::Bool   # only the nonlinear rows of the Jacobian enter the systems (struct.jl:101-103)
 end
 
 function HIPQDSolver(nlp::AbstractNLPModel{T, S}, ::T; explicit_linear_constraints = false, kwargs...) where {T, S}
   T == Float64 || error("HIPQDSolver is fp64 only")
-  explicit_linear_constraints && error("HIPQDSolver: explicit_linear_constraints is not supported yet")
-  nvar, ncon, nnzj = nlp.meta.nvar, nlp.meta.ncon, nlp.meta.nnzj
+  nvar = nlp.meta.nvar
+  ncon = explicit_linear_constraints ? nlp.meta.nnln : nlp.meta.ncon
+  nnzj = explicit_linear_constraints ? nlp.meta.nln_nnzj : nlp.meta.nnzj
   opts = FpsqOptions()
   ccall((:fpsq_default_options, libfpsq), Cvoid, (Int64, Int64, Ref{FpsqOptions}), nvar, ncon, opts)
   for (k, v) in kwargs
@@ -52,19 +54,19 @@ function HIPQDSolver(nlp::AbstractNLPModel{T, S}, ::T; explicit_linear_constrain
   h = Ref{Ptr{Cvoid}}(C_NULL)
   rc = ccall((:fpsq_create, libfpsq), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Ref{FpsqOptions}), h, nvar, ncon, opts)
   rc == 0 || error(unsafe_string(ccall((:fpsq_last_error, libfpsq), Cstring, (Ptr{Cvoid},), C_NULL)))
-  rows, cols = jac_structure(nlp)                       # replaces struct.jl:331-337
+  rows, cols = explicit_linear_constraints ? jac_nln_structure(nlp) : jac_structure(nlp)   # replaces struct.jl:331-337
   rc = ccall((:fpsq_set_jacobian_structure_coo, libfpsq), Cint,
              (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnzj, Int64.(rows), Int64.(cols), 1)
   rc == 0 || error(unsafe_string(ccall((:fpsq_last_error, libfpsq), Cstring, (Ptr{Cvoid},), h[])))
   qds = HIPQDSolver{T, S}(h[], nvar, ncon, S(undef, nnzj), S(undef, nvar), S(undef, ncon), S(undef, nvar),
-                          S(undef, ncon), Vector{FpsqStats}(undef, 2), T(NaN))
+                          S(undef, ncon), Vector{FpsqStats}(undef, 2), T(NaN), explicit_linear_constraints)
   finalizer(q -> ccall((:fpsq_destroy, libfpsq), Cint, (Ptr{Cvoid},), q.handle), qds)
   return qds
 end
 
 function _refresh!(qds::HIPQDSolver, nlp, x; values = true)
   if values                                             # replaces linear_system.jl:118-122 / :223-228
-    jac_coord!(nlp.nlp, x, qds.vals)
+    qds.explicit_linear_constraints ? jac_nln_coord!(nlp.nlp, x, qds.vals) : jac_coord!(nlp.nlp, x, qds.vals)
     ccall((:fpsq_set_jacobian_values, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}), qds.handle, qds.vals)
   end
   if qds.δ != nlp.δ
