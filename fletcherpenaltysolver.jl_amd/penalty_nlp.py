@@ -1,7 +1,7 @@
 """Host-side mirror of `FletcherPenaltyNLP` (src/model-Fletcherpenaltynlp.jl:58-103): the hot part
 `_compute_ys_gs!` (:234-252), `obj` (:352-370), `grad!` (:372-401), `objgrad!` (:403-437), and the matrix-free
 Hessian products `hprod!` Val(2) (:521-570) and Val(1) (:572-634) -- SURVEY.md §8f rows 1-2 -- which reach the
-back-end through `solve_two_least_squares` / `solve_two_extras`.  `hess_coord!` (dense O(n^2) Hessian) is not built.
+back-end through `solve_two_least_squares` / `solve_two_extras`, and the dense `hess_coord!` (:439-519, small problems).
 """
 from __future__ import annotations
 
@@ -146,6 +146,44 @@ class FletcherPenaltyNLP:
 
     def hprod(self, x, v, obj_weight=1.0):
         return self.hprod_(x, v, np.empty(self.meta.nvar), obj_weight)
+
+    # :439-519  (hess_structure! / hess_coord!): DENSE lower triangle, column by column -- small problems only.  Like the
+    # reference it does not go through the QDSolver: (A A' + tau I)^-1 is formed explicitly (`pinv` there).
+    def hess_structure(self):
+        n = self.meta.nvar
+        ij = [(i + 1, j + 1) for j in range(n) for i in range(j, n)]
+        return np.array([a for a, _ in ij]), np.array([b for _, b in ij])
+
+    def hess_coord(self, x, obj_weight=1.0):
+        x = np.asarray(x, float)
+        n, m = self.meta.nvar, self.pen.meta.ncon
+        self.counters["neval_hess"] = self.counters.get("neval_hess", 0) + 1
+        gs, ys, _, _ = self._compute_ys_gs(x)
+        c = self.cx
+        rows, cols = self.pen.jac_structure()
+        A = np.zeros((m, n))
+        np.add.at(A, (np.asarray(rows) - 1, np.asarray(cols) - 1), np.asarray(self.pen.jac_coord(x), float))
+        eye = np.eye(n)
+        dense = lambda y, w: np.column_stack([self.pen.hprod(x, y, eye[:, j], obj_weight=w) for j in range(n)])
+        Hs = dense(-ys, 1.0)                                                 # :477
+        tau = max(self.delta, 1e-14)
+        invAtA = np.linalg.pinv(A @ A.T + tau * np.eye(m))                   # :480
+        AinvAtA = A.T @ invAtA
+        Pt = AinvAtA @ A
+        Hx = Hs - Pt @ Hs - Hs @ Pt + 2.0 * self.sigma * Pt                  # :484
+        if self.rho > 0.0:
+            Hx += dense(c * self.rho, 0.0) + self.rho * (A.T @ A)            # :486-489
+        if self.hessian_approx == 1:                                         # :491-498
+            Ss = np.zeros((m, n))
+            for k in range(m):
+                ek = np.zeros(m)
+                ek[k] = 1.0
+                Ss[k, :] = np.column_stack([self.pen.hprod(x, ek, eye[:, j], obj_weight=0.0) for j in range(n)]).T @ gs
+            Hx += -AinvAtA @ Ss - Ss.T @ invAtA @ A
+        vals = np.array([Hx[i, j] for j in range(n) for i in range(j, n)]) * obj_weight
+        if self.eta > 0.0:
+            vals[[k for k, (i, j) in enumerate((i, j) for j in range(n) for i in range(j, n)) if i == j]] += obj_weight * self.eta
+        return vals
 
     # :636-726 -- the linear constraints kept explicit (cons_lin!, jprod_lin!, jtprod_lin! of the wrapped model)
     def _lin_rows(self):

@@ -1,0 +1,81 @@
+"""The host mirror of the reference interface on the CPU suite: FletcherPenaltyNLP (obj / grad! / hprod! / hess_coord!),
+explicit_linear_constraints and fps_solve, driven through a QDSolver backed by the exact KKT oracle
+(tests/oracle_qdsolver.py).  The same cases run through the HIP back-ends in the -m gpu suite."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import fps_amd  # noqa: E402,F401
+from fps_amd import nlpmodels  # noqa: E402
+from fps_amd.fps_solve import fps_solve  # noqa: E402
+from fps_amd.penalty_nlp import FletcherPenaltyNLP  # noqa: E402
+from oracle_qdsolver import OracleQDSolver  # noqa: E402
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", GOLD, ids=[c["name"] for c in GOLD])
+def test_reference_known_answers_through_the_host_mirror(oracle, case):
+    """test/unit-test.jl:16-152 through FletcherPenaltyNLP itself (the GPU suite does the same with the HIP back-ends)."""
+    nlp = nlpmodels.SumSquares(case["n"]) if case["model"] == "sumsq" else nlpmodels.RosenbrockCircle()
+    fp = FletcherPenaltyNLP(nlp, case["sigma"], case["rho"], case["delta"], 2, qds=OracleQDSolver(nlp, 0.0))
+    x = np.array(case["x"])
+    fx, gx = fp.objgrad(x)
+    exp, tol = case["expect"], case["atol"]
+    got = dict(obj=fx, grad=gx, ys=fp.ys, fx=fp.fx, gx=fp.gx, cx=fp.cx)
+    for key, want in exp.items():  # whatever the reference test asserts for this case
+        np.testing.assert_allclose(got[key], want, rtol=0, atol=max(tol[key], 1e-15), err_msg=key)
+
+
+@pytest.mark.parametrize("ha", [1, 2])
+@pytest.mark.parametrize("model", ["hs6", "circle"])
+def test_hess_coord_is_the_matrix_of_hprod(oracle, model, ha):
+    """hess_coord! (:439-519) and hprod! (:521-634) are the same Hessian approximation: H v == hprod(v).
+    Reference quirk kept by the mirror: hprod! Val(2) adds `Hcv + rho JtJv` (:562) where hess_coord! and hprod! Val(1)
+    add `rho (Hcv + JtJv)` (:486-489, :626) -- the two only agree for rho in {0, 1}, so Val(2) is checked at rho = 1."""
+    nlp = nlpmodels.HS6() if model == "hs6" else nlpmodels.LinearPlusCircle(False)
+    fp = FletcherPenaltyNLP(nlp, 10.0, 1.0 if ha == 2 else 0.5, 1e-3, ha, qds=OracleQDSolver(nlp, 0.0))
+    n = nlp.meta.nvar
+    rng = np.random.default_rng(0)
+    x = nlp.meta.x0 + 0.1 * rng.standard_normal(n)
+    vals = fp.hess_coord(x)
+    rows, cols = fp.hess_structure()
+    H = np.zeros((n, n))
+    H[rows - 1, cols - 1] = vals
+    H = H + np.tril(H, -1).T
+    for _ in range(3):
+        v = rng.standard_normal(n)
+        np.testing.assert_allclose(H @ v, fp.hprod(x, v), rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("sub,ha", [("lbfgs", 2), ("trunk", 2), ("trunk", 1)])
+@pytest.mark.parametrize("model", ["sumsq", "hs6", "hs7"])
+def test_fps_solve_end_to_end_on_the_exact_backend(oracle, model, sub, ha):
+    """test/test-2.jl:28-97 acceptance: :first_order with residuals < 1e-6 max(||x0||, 1)."""
+    nlp = {"sumsq": lambda: nlpmodels.SumSquares(10), "hs6": nlpmodels.HS6, "hs7": nlpmodels.HS7}[model]()
+    stats = fps_solve(nlp, nlp.meta.x0, subproblem_solver=sub, hessian_approx=ha, qds=OracleQDSolver(nlp, 0.0))
+    bound = 1e-6 * max(np.linalg.norm(nlp.meta.x0), 1.0)
+    assert stats.status == "first_order" and stats.dual_feas < bound and stats.primal_feas < bound
+    if model == "sumsq":
+        assert np.linalg.norm(10 * stats.solution - 1.0) < 1e-6
+    if model == "hs7":
+        assert abs(stats.objective + np.sqrt(3.0)) < 1e-6
+
+
+@pytest.mark.parametrize("ha", [1, 2])
+def test_explicit_linear_constraints_on_the_exact_backend(oracle, ha):
+    full, nl = nlpmodels.LinearPlusCircle(True), nlpmodels.LinearPlusCircle(False)
+    fe = FletcherPenaltyNLP(full, 10.0, 0.5, 1e-3, ha, explicit_linear_constraints=True,
+                            qds=OracleQDSolver(full, 0.0, explicit_linear_constraints=True))
+    fn = FletcherPenaltyNLP(nl, 10.0, 0.5, 1e-3, ha, qds=OracleQDSolver(nl, 0.0))
+    rng = np.random.default_rng(4)
+    x, v = rng.standard_normal(3), rng.standard_normal(3)
+    f1, g1 = fe.objgrad(x)
+    f2, g2 = fn.objgrad(x)
+    assert abs(f1 - f2) <= 1e-12 * max(1.0, abs(f2)) and np.allclose(g1, g2, rtol=1e-12, atol=1e-12)
+    assert np.allclose(fe.hprod(x, v), fn.hprod(x, v), rtol=1e-10, atol=1e-12)
+    assert fe.meta.ncon == 1 and np.allclose(fe.cons(x), [x.sum() - 1.0])
