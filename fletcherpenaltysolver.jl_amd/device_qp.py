@@ -87,6 +87,10 @@ class DeviceEqQP:
         return self._check(self._lib.fpsq_ys_gs(self._h, _lib.ptr(g), _lib.ptr(c), self.sigma, _lib.ptr(gs),
                                                 _lib.ptr(ys), _lib.ptr(v), _lib.ptr(w), self.stats))
 
+    def jac_mul(self, trans, alpha, x, beta, y):
+        """y = alpha op(A) x + beta y with the model's Jacobian (fpsq_jac_mul; trans = 0: A, 1: A')."""
+        return self._check(self._lib.fpsq_jac_mul(self._h, int(trans), float(alpha), _lib.ptr(x), float(beta), _lib.ptr(y)))
+
     def hprod(self, v, Hv):
         """hprod!(::FletcherPenaltyNLP, x, v, Hv), hessian_approx = Val(2) (model-Fletcherpenaltynlp.jl:521-570), on the
         device; the model is quadratic with linear constraints, so the product does not depend on x.  Returns rc."""

@@ -60,38 +60,71 @@ class ExecutionStats:
     solver_specific: dict = field(default_factory=dict)
 
 
+# ------------------------------------------------------------------ vectors: numpy arrays or torch tensors (host or device)
+
+def _is_torch(a):
+    return type(a).__module__.split(".")[0] == "torch"
+
+
+def _copy(a):
+    return a.clone() if _is_torch(a) else a.copy()
+
+
+def _empty_like(a):
+    return a.new_empty(a.shape) if _is_torch(a) else np.empty_like(a)
+
+
+def _zeros_like(a):
+    return a.new_zeros(a.shape) if _is_torch(a) else np.zeros_like(a)
+
+
+def _dot(a, b):
+    return float(a @ b)
+
+
+def _nrm2(a):
+    return float(a.norm()) if _is_torch(a) else float(np.linalg.norm(a))
+
+
+def _nrminf(a):
+    return float(a.abs().max()) if _is_torch(a) else float(np.linalg.norm(a, np.inf))
+
+
+def _same(a, b):
+    return bool((a == b).all())
+
+
 # ------------------------------------------------------------------ sub-problem solvers (unconstrained min of phi)
 
 def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
     """Limited-memory BFGS with an Armijo backtracking line search.  Returns (x, status, g)."""
-    n = x.size
-    g = np.empty(n)
+    g = _empty_like(x)
     f, _ = fp.objgrad_(x, g)
-    tol = atol + rtol * np.linalg.norm(g, np.inf)
+    tol = atol + rtol * _nrminf(g)
     S, Y = [], []
     for it in range(max_iter):
-        if np.linalg.norm(g, np.inf) <= tol:
+        if _nrminf(g) <= tol:
             return x, "optimal", g
         if f < -unbounded_below:
             return x, "unbounded", g
-        q = g.copy()
+        q = _copy(g)
         al = []
         for s, y in zip(reversed(S), reversed(Y)):
-            a = (s @ q) / (y @ s)
+            a = _dot(s, q) / _dot(y, s)
             al.append(a)
             q -= a * y
         if S:
-            q *= (S[-1] @ Y[-1]) / (Y[-1] @ Y[-1])
+            q *= _dot(S[-1], Y[-1]) / _dot(Y[-1], Y[-1])
         for (s, y), a in zip(zip(S, Y), reversed(al)):
-            b = (y @ q) / (y @ s)
+            b = _dot(y, q) / _dot(y, s)
             q += (a - b) * s
         d = -q
-        slope = g @ d
+        slope = _dot(g, d)
         if slope >= 0.0:  # not a descent direction: restart from steepest descent
             S, Y = [], []
-            d, slope = -g, -(g @ g)
-        t = 1.0 if S else min(1.0, 1.0 / max(np.linalg.norm(g), 1e-16))
-        gn = np.empty(n)
+            d, slope = -g, -_dot(g, g)
+        t = 1.0 if S else min(1.0, 1.0 / max(_nrm2(g), 1e-16))
+        gn = _empty_like(x)
         for _ in range(60):
             xn = x + t * d
             fn, _ = fp.objgrad_(xn, gn)
@@ -101,7 +134,7 @@ def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
         else:
             return x, "stalled", g
         s, y = xn - x, gn - g
-        if s @ y > 1e-12 * np.linalg.norm(s) * np.linalg.norm(y):
+        if _dot(s, y) > 1e-12 * _nrm2(s) * _nrm2(y):
             S.append(s)
             Y.append(y)
             if len(S) > mem:
@@ -113,51 +146,51 @@ def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
 
 def _trunk(fp, x, atol, rtol, max_iter, unbounded_below):
     """Trust-region Newton-CG (Steihaug-Toint) on hprod!.  Returns (x, status, g)."""
-    n = x.size
-    g = np.empty(n)
+    n = x.shape[0]
+    g = _empty_like(x)
     f, _ = fp.objgrad_(x, g)
-    tol = atol + rtol * np.linalg.norm(g, np.inf)
-    radius = max(1.0, 0.1 * np.linalg.norm(g))
-    Hd = np.empty(n)
+    tol = atol + rtol * _nrminf(g)
+    radius = max(1.0, 0.1 * _nrm2(g))
+    Hd = _empty_like(x)
     for it in range(max_iter):
-        gnorm = np.linalg.norm(g)
-        if np.linalg.norm(g, np.inf) <= tol:
+        gnorm = _nrm2(g)
+        if _nrminf(g) <= tol:
             return x, "optimal", g
         if f < -unbounded_below:
             return x, "unbounded", g
         # Steihaug CG on  min g's + s'Hs/2,  ||s|| <= radius
-        s, r, d = np.zeros(n), g.copy(), -g.copy()
+        s, r, d = _zeros_like(x), _copy(g), -g
         cg_tol = min(0.1, np.sqrt(gnorm)) * gnorm
-        for _ in range(2 * n + 10):
+        for _ in range(min(2 * n + 10, 500)):
             fp.hprod_(x, d, Hd)
-            dHd = d @ Hd
-            rr = r @ r
-            if dHd <= 1e-14 * (d @ d):  # negative curvature: to the boundary
+            dHd = _dot(d, Hd)
+            rr = _dot(r, r)
+            if dHd <= 1e-14 * _dot(d, d):  # negative curvature: to the boundary
                 s = s + _to_boundary(s, d, radius) * d
                 break
             a = rr / dHd
-            if np.linalg.norm(s + a * d) >= radius:
+            if _nrm2(s + a * d) >= radius:
                 s = s + _to_boundary(s, d, radius) * d
                 break
             s = s + a * d
             r = r + a * Hd
-            if np.linalg.norm(r) <= cg_tol:
+            if _nrm2(r) <= cg_tol:
                 break
-            d = -r + (r @ r) / rr * d
+            d = -r + (_dot(r, r) / rr) * d
         fp.hprod_(x, s, Hd)
-        pred = -(g @ s + 0.5 * (s @ Hd))
-        gn = np.empty(n)
+        pred = -(_dot(g, s) + 0.5 * _dot(s, Hd))
+        gn = _empty_like(x)
         fn, _ = fp.objgrad_(x + s, gn)
         rho_tr = (f - fn) / pred if pred > 0 else -1.0
         if not np.isfinite(fn):
             rho_tr = -1.0
         if rho_tr >= 1e-4:
             x, f, g = x + s, fn, gn
-            if rho_tr > 0.75 and np.linalg.norm(s) > 0.9 * radius:
+            if rho_tr > 0.75 and _nrm2(s) > 0.9 * radius:
                 radius *= 2.0
         else:
-            radius = 0.25 * max(np.linalg.norm(s), 1e-16)
-            if radius < 1e-14 * max(1.0, np.linalg.norm(x)):
+            radius = 0.25 * max(_nrm2(s), 1e-16)
+            if radius < 1e-14 * max(1.0, _nrm2(x)):
                 return x, "stalled", g
         if rho_tr < 0.25 and rho_tr >= 1e-4:
             radius *= 0.5
@@ -165,7 +198,7 @@ def _trunk(fp, x, atol, rtol, max_iter, unbounded_below):
 
 
 def _to_boundary(s, d, radius):
-    a, b, c = d @ d, 2.0 * (s @ d), s @ s - radius * radius
+    a, b, c = _dot(d, d), 2.0 * _dot(s, d), _dot(s, s) - radius * radius
     return (-b + np.sqrt(max(b * b - 4.0 * a * c, 0.0))) / (2.0 * a)
 
 
@@ -173,6 +206,39 @@ _SUBSOLVERS = {"lbfgs": _lbfgs, "trunk": _trunk}
 
 
 # ------------------------------------------------------------------ outer loop
+
+class _HostPenalty:
+    """What the outer loop needs from a penalty model, for the host mirror FletcherPenaltyNLP."""
+
+    def __init__(self, fp, nlp):
+        self.fp, self.nlp = fp, nlp
+        self.objgrad_, self.hprod_ = fp.objgrad_, fp.hprod_
+
+    sigma = property(lambda s: s.fp.sigma, lambda s, v: setattr(s.fp, "sigma", v))
+    rho = property(lambda s: s.fp.rho, lambda s, v: setattr(s.fp, "rho", v))
+    delta = property(lambda s: s.fp.delta, lambda s, v: setattr(s.fp, "delta", v))
+    eta = property(lambda s: s.fp.eta, lambda s, v: setattr(s.fp, "eta", v))
+
+    def set_xk(self, x):
+        self.fp.xk = _copy(x)
+
+    def invalidate(self):
+        self.fp.shahx = None  # phi changed: the memo of _compute_ys_gs! is stale
+
+    def state(self, x):
+        """(f(x), ||c(x)||_2, ys(x)) -- memoised: no new solve when x was the last point evaluated."""
+        self.fp._compute_ys_gs(x)
+        return self.fp.fx, _nrm2(self.fp.cx), self.fp.ys
+
+    def primal_inf(self, x):
+        return _nrminf(self.nlp.cons(x) - self.nlp.meta.lcon)
+
+    def grad_f(self, x):
+        return self.nlp.grad(x)
+
+    def info(self):
+        return {"counters": dict(self.fp.counters)}
+
 
 def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0, verbose=0, qds=None, **kwargs):
     """stats = fps_solve(nlp, x0; kwargs...)   (src/FletcherPenaltySolver.jl:127-186 -> src/algo.jl:26-288).
@@ -184,19 +250,22 @@ def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0,
     qds = qds if qds is not None else qdsolver_correspondence[meta.qds_solver](nlp, 0.0)
     fp = FletcherPenaltyNLP(nlp, sigma=meta.sigma_0, rho=meta.rho_0, delta=0.0, hessian_approx=meta.hessian_approx,
                             x0=x, qds=qds)                                                     # algo.jl:45-52
+    return _outer_loop(_HostPenalty(fp, nlp), x, meta, atol, rtol, max_iter, max_time, verbose)
+
+
+def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
+    """src/algo.jl:26-288 on a penalty model `pen` (host mirror or device-resident); x: numpy array or torch tensor."""
     sub = _SUBSOLVERS[meta.subproblem_solver]
     t_start = time.perf_counter()
-    stats = ExecutionStats(solution=x.copy(), multipliers=np.zeros(nlp.meta.ncon))
-    lcon = nlp.meta.lcon
+    stats = ExecutionStats(solution=_copy(x))
 
     def score(x, lam, res):
         """Fletcher_penalty_optimality_check (FletcherPenaltySolver.jl:28-50), no bounds."""
-        nxk = max(np.linalg.norm(x), 1.0)
-        nlk = max(np.linalg.norm(lam), 1.0)
-        return np.linalg.norm(nlp.cons(x) - lcon, np.inf) / nxk, np.linalg.norm(res, np.inf) / nlk
+        nxk = max(_nrm2(x), 1.0)
+        nlk = max(_nrm2(lam), 1.0) if lam is not None else 1.0
+        return pen.primal_inf(x) / nxk, _nrminf(res) / nlk
 
-    g0 = nlp.grad(x)
-    p0, d0 = score(x, stats.multipliers, g0)
+    p0, d0 = score(x, None, pen.grad_f(x))
     tol = max(atol, rtol * max(p0, d0))        # Stopping.jl's default tol_check(atol, rtol, optimality0)
     sub_atol, sub_rtol = atol, rtol            # meta.atol_sub / rtol_sub are the identity by default (parameters.jl:88-89)
     feas_tol = atol
@@ -208,18 +277,17 @@ def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0,
     while status == "unknown":
         it += 1
         x_prev = x
-        xs, sub_status, res = sub(fp, x.copy(), sub_atol, sub_rtol, meta.subsolver_max_iter,
+        xs, sub_status, res = sub(pen, _copy(x), sub_atol, sub_rtol, meta.subsolver_max_iter,
                                   meta.subpb_unbounded_threshold)
-        fp._compute_ys_gs(xs)  # phi's caches at the returned point (memoised: no new solve when it was the last one)
-        unb_mult = np.linalg.norm(fp.ys, np.inf) >= meta.lagrange_bound
-        ncx = np.linalg.norm(fp.cx)
+        fx_user, ncx, ys = pen.state(xs)
+        unb_mult = _nrminf(ys) >= meta.lagrange_bound
         feas = ncx < feas_tol
         if sub_status == "optimal" and not unb_mult:                                            # algo.jl:121-151
-            stalling = stalling + 1 if np.array_equal(xs, x_prev) else 0
+            stalling = stalling + 1 if _same(xs, x_prev) else 0
             unsuccessful = unbounded = 0
             x = xs
-            stats.solution, stats.multipliers = x.copy(), -fp.ys.copy()
-            stats.objective = fp.fx
+            stats.solution, stats.multipliers = _copy(x), -ys
+            stats.objective = fx_user
             stats.primal_feas, stats.dual_feas = score(x, stats.multipliers, res)
             if max(stats.primal_feas, stats.dual_feas) <= tol:
                 status = "first_order"
@@ -233,7 +301,7 @@ def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0,
         else:                                                                                   # :161-181
             stalling = unbounded = 0
             unsuccessful += 1
-        if fp.sigma > meta.sigma_max or fp.rho > meta.rho_max or fp.delta > meta.delta_max:     # :189-190
+        if pen.sigma > meta.sigma_max or pen.rho > meta.rho_max or pen.delta > meta.delta_max:  # :189-190
             status = "stalled" if feas else "infeasible"
             break
         if it >= max_iter:
@@ -247,40 +315,118 @@ def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0,
             if feas:                                           # tighten the sub-problem tolerances (:195-199)
                 sub_atol = max(sub_atol / 10.0, np.finfo(float).eps)
                 sub_rtol = max(sub_rtol / 10.0, np.finfo(float).eps)
-                fp.eta = max(meta.eta_1, fp.eta * meta.eta_update)
-                fp.xk = x.copy()
-                fp.shahx = None
+                pen.eta = max(meta.eta_1, pen.eta * meta.eta_update)
+                pen.set_xk(x)
+                pen.invalidate()
             elif stalling >= 3 or sub_atol < np.finfo(float).eps:  # infeasible stationary point (:200-214, no restoration)
                 status = "infeasible"
                 break
             else:
-                _update_parameters(fp, meta, feas)
+                _update_parameters(pen, meta, feas)
         elif sub_status == "unbounded" or unb_mult:
             if unbounded >= 3 and not feas:                   # would enter the feasibility phase (:216-224)
                 status = "infeasible"
                 break
-            fp.delta = meta.delta_0 if fp.delta == 0.0 else fp.delta * meta.delta_update         # :380-390
-            _update_parameters(fp, meta, feas)
+            pen.delta = meta.delta_0 if pen.delta == 0.0 else pen.delta * meta.delta_update     # :380-390
+            _update_parameters(pen, meta, feas)
         else:
             if unsuccessful >= 3:                             # would enter a restoration phase (:236-247)
                 status = "stalled"
                 break
-            _update_parameters(fp, meta, feas)
+            _update_parameters(pen, meta, feas)
         if verbose:
-            print(f"fps_solve it {it:3d} sub={sub_status:9s} f={fp.fx: .6e} |c|={ncx:.2e} sigma={fp.sigma:.1e} "
-                  f"rho={fp.rho:.1e} delta={fp.delta:.1e}")
+            print(f"fps_solve it {it:3d} sub={sub_status:9s} f={fx_user: .6e} |c|={ncx:.2e} sigma={pen.sigma:.1e} "
+                  f"rho={pen.rho:.1e} delta={pen.delta:.1e}")
     stats.status = status
     stats.iter = it
     stats.elapsed_time = time.perf_counter() - t_start
-    if stats.solution is not None and not np.isfinite(stats.primal_feas):
-        stats.primal_feas, stats.dual_feas = score(stats.solution, stats.multipliers, nlp.grad(stats.solution))
-    stats.solver_specific = {"sigma": fp.sigma, "rho": fp.rho, "delta": fp.delta, "counters": dict(fp.counters)}
+    if stats.multipliers is None:
+        stats.multipliers = -pen.state(stats.solution)[2]
+    if not np.isfinite(stats.primal_feas):
+        stats.primal_feas, stats.dual_feas = score(stats.solution, stats.multipliers, pen.grad_f(stats.solution))
+    stats.solver_specific = {"sigma": pen.sigma, "rho": pen.rho, "delta": pen.delta, **pen.info()}
     return stats
 
 
-def _update_parameters(fp, meta, feas):
+def _update_parameters(pen, meta, feas):
     """update_parameters! (src/algo.jl:361-375): sigma always, rho when the iterate is infeasible."""
-    fp.sigma *= meta.sigma_update
+    pen.sigma *= meta.sigma_update
     if not feas:
-        fp.rho *= meta.rho_update
-    fp.shahx = None  # phi changed: the memo of _compute_ys_gs! is stale
+        pen.rho *= meta.rho_update
+    pen.invalidate()
+
+
+# ------------------------------------------------------------------ the same loop on the device-resident eq-QP model
+
+class _DevicePenalty:
+    """The penalty function of a DeviceEqQP (fpsq_qp_objgrad / fpsq_qp_hprod): every vector stays in HBM (torch
+    tensors); the host only sees scalars."""
+
+    def __init__(self, dev, torch):
+        self.dev, self.torch = dev, torch
+        d = torch.device("cuda", int(dev.opts.device))
+        qp = dev.qp
+        self.q = torch.from_numpy(np.ascontiguousarray(qp.qdiag)).to(d)
+        self.d = torch.from_numpy(np.ascontiguousarray(qp.d)).to(d)
+        self.b = torch.from_numpy(np.ascontiguousarray(qp.b)).to(d)
+        self.ys = torch.empty(qp.m, dtype=torch.float64, device=d)
+        self.c = torch.empty(qp.m, dtype=torch.float64, device=d)
+        self.scratch = torch.empty(qp.n, dtype=torch.float64, device=d)
+        self._at = None
+        self.nobjgrad = self.nhprod = 0
+
+    sigma = property(lambda s: s.dev.sigma, lambda s, v: setattr(s.dev, "sigma", v))
+    rho = property(lambda s: s.dev.rho, lambda s, v: setattr(s.dev, "rho", v))
+    eta = property(lambda s: s.dev.eta, lambda s, v: setattr(s.dev, "eta", v))
+    delta = property(lambda s: s.dev.delta, lambda s, v: s.dev.set_delta(v))
+
+    def objgrad_(self, x, g):
+        self.nobjgrad += 1
+        fx, _ = self.dev.objgrad(x, gx=g, ys=self.ys, xk=self._xk if self.dev.eta > 0.0 else None)
+        self._at = x
+        return fx, g
+
+    def hprod_(self, x, v, Hv):
+        self.nhprod += 1
+        self.dev.hprod(v, Hv)
+        return Hv
+
+    _xk = None
+
+    def set_xk(self, x):
+        self._xk = x.clone()
+
+    def invalidate(self):
+        self._at = None
+
+    def _cons(self, x):
+        self.c.copy_(self.b)
+        self.dev.jac_mul(0, 1.0, x, -1.0, self.c)  # c = A x - b
+        return self.c
+
+    def state(self, x):
+        if self._at is None or self._at is not x:
+            self.objgrad_(x, self.scratch)
+        f = float(0.5 * (x @ (self.q * x)) + self.d @ x)
+        return f, _nrm2(self._cons(x)), self.ys
+
+    def primal_inf(self, x):
+        return _nrminf(self._cons(x))
+
+    def grad_f(self, x):
+        return self.q * x + self.d
+
+    def info(self):
+        return {"objgrad_calls": self.nobjgrad, "hprod_calls": self.nhprod}
+
+
+def fps_solve_device(dev, x0, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0, verbose=0, **kwargs):
+    """fps_solve on a device-resident equality QP (`DeviceEqQP`): x0 and every iterate are torch tensors in HBM, each
+    obj/grad! is one fpsq_qp_objgrad, each Hessian product of the `trunk` sub-solver one fpsq_qp_hprod.
+    Returns ExecutionStats whose `solution` / `multipliers` are device tensors."""
+    import torch
+
+    meta = AlgoData(**{k: v for k, v in kwargs.items() if k in AlgoData.__dataclass_fields__})
+    dev.sigma, dev.rho, dev.eta = meta.sigma_0, meta.rho_0, 0.0
+    dev.set_delta(0.0)
+    return _outer_loop(_DevicePenalty(dev, torch), x0, meta, atol, rtol, max_iter, max_time, verbose)

@@ -34,11 +34,14 @@ def test_parameter_schedule_defaults_and_updates():
     assert meta.delta_0 == se and meta.delta_update == 10.0 and meta.sigma_max == 1 / se
 
     class _FP:
-        sigma, rho, delta, shahx = 1e3, 1.0, 0.0, 123
+        sigma, rho, delta, stale = 1e3, 1.0, 0.0, False
+
+        def invalidate(self):
+            self.stale = True
 
     fp = _FP()
     F._update_parameters(fp, meta, feas=True)      # feasible iterate: sigma only (algo.jl:364-367)
-    assert (fp.sigma, fp.rho, fp.shahx) == (2e3, 1.0, None)
+    assert (fp.sigma, fp.rho, fp.stale) == (2e3, 1.0, True)
     F._update_parameters(fp, meta, feas=False)
     assert (fp.sigma, fp.rho) == (4e3, 2.0)
 

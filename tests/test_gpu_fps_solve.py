@@ -73,3 +73,36 @@ def test_explicit_linear_constraints_penalise_only_the_nonlinear_ones(backend, h
         assert np.allclose(fe.jprod(x, v), [v.sum()]) and np.allclose(fe.jtprod(x, np.array([2.0])), 2.0 * np.ones(3))
     qe.close()
     qn.close()
+
+
+@pytest.mark.parametrize("sub", ["trunk", "lbfgs"])
+def test_fps_solve_device_resident_qp_reaches_the_kkt_point(sub):
+    """fps_solve_device: the outer loop on a DeviceEqQP (every iterate a tensor in HBM, obj/grad! = fpsq_qp_objgrad,
+    Hessian products = fpsq_qp_hprod) must reach the solution of the equality QP's KKT system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+
+    from fps_amd import problems
+    from fps_amd.device_qp import DeviceEqQP
+    from fps_amd.fps_solve import fps_solve_device
+
+    qp = problems.pde_control_like(n=3000, m=300, seed=5) if "seed" in problems.pde_control_like.__code__.co_varnames \
+        else problems.pde_control_like(n=3000, m=300)
+    A = qp.scipy_csr()
+    K = sp.bmat([[sp.diags(qp.qdiag), A.T], [A, None]], format="csc")
+    sol = spla.spsolve(K, np.concatenate([-qp.d, qp.b]))
+    xstar, lam = sol[:qp.n], sol[qp.n:]
+    # Krylov tolerances well below the outer tolerance (at the reference's sqrt(eps) defaults grad(phi) carries an error
+    # of ~sigma * sqrt(eps) and the sub-problem cannot be driven to 1e-7)
+    tight = dict(ls_atol=1e-13, ls_rtol=1e-13, ls_axtol=1e-13, ls_btol=1e-13, ls_etol=1e-13, ln_atol=1e-13,
+                 ln_rtol=1e-13, ln_btol=1e-13, ln_conlim=0.0)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, **tight)
+    x0 = torch.from_numpy(qp.x).to(torch.device("cuda", 0))
+    stats = fps_solve_device(dev, x0, subproblem_solver=sub, atol=1e-7, rtol=1e-7)
+    assert stats.status == "first_order", (stats.status, stats.solver_specific)
+    x = stats.solution.cpu().numpy()
+    assert np.linalg.norm(x - xstar) <= 1e-5 * np.linalg.norm(xstar)
+    assert np.linalg.norm(stats.multipliers.cpu().numpy() - lam) <= 1e-4 * max(1.0, np.linalg.norm(lam))
+    assert abs(stats.objective - (0.5 * xstar @ (qp.qdiag * xstar) + qp.d @ xstar)) <= 1e-6 * max(1.0, abs(stats.objective))
+    dev.close()
