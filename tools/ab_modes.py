@@ -36,7 +36,7 @@ for lp in libs:
             extra = {optname: ov} if optname else {}
             if os.environ.get("AB_ITMAX"):  # bound the runs of deliberately wrong experimental kernels
                 extra.update(ls_itmax=int(os.environ["AB_ITMAX"]), ln_itmax=int(os.environ["AB_ITMAX"]))
-            models[(os.path.basename(lp), f"{ev}/{optname}={ov}#{len(models)}" if optname else ev)] = DeviceEqQP(
+            models[(os.path.basename(lp), f"{ev}/{optname}={ov}#{len(models)}")] = DeviceEqQP(
                 qp, sigma=1e3, rho=1.0, delta=0.0, device=0, fuse_two_rhs=1, **extra)
 xs = torch.empty((batch, qp.n), dtype=torch.float64, device=dev)
 for t in range(batch):
