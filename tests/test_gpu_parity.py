@@ -678,3 +678,33 @@ def test_error_codes_of_the_c_abi():
     lib.fpsq_qp_destroy(q)
     lib.fpsq_destroy(h2)
     lib.fpsq_destroy(h)
+
+
+def test_rank_deficient_jacobian_is_handled_softly(oracle):
+    """Two identical constraint rows.  delta > 0: the regularised systems are well posed and must match the exact solve.
+    delta = 0: the reference's two back-ends legitimately differ (hard parts); what is required is a
+    finite result, matching the C restatement's iteration counts and flags -- never a hang or a hard error."""
+    qp = _small_pde(seed=41, n=600, m=40)
+    A = qp.scipy_csr().tolil()
+    A[7, :] = A[3, :]
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    rng = np.random.default_rng(8)
+    g, c = rng.standard_normal(600), rng.standard_normal(40)
+    c[7] = c[3]  # consistent right-hand side
+    for delta in (1e-2, 0.0):
+        H = _Handle(A, delta=delta)
+        p1, q1, p2, q2, rc = H.solve_two_mixed(g, c)
+        o = oracle.solve_two_mixed(40, 600, A.indptr, A.indices, A.data, delta, g, c)
+        assert rc >= 0 and rc == o[5]
+        assert all(np.all(np.isfinite(v)) for v in (p1, q1, p2, q2))
+        for k in range(2):
+            assert abs(H.st[k].niter - o[4][k].niter) <= 1 and H.st[k].solved == o[4][k].solved
+        if delta > 0:
+            e = oracle.exact_two_mixed(A, delta, g, c)
+            for got, want in zip((p1, q1, p2, q2), e):
+                assert _rel(got, want) < 1e-5
+        else:  # the minimum-norm property: p1 = P_null(A) g does not depend on the redundant row
+            assert np.linalg.norm(A @ p1) <= 1e-6 * np.linalg.norm(g)
+            assert np.linalg.norm(A @ p2 - c) <= 1e-5 * np.linalg.norm(c)
+        H.close()
