@@ -822,3 +822,48 @@ int fpo_qp_objgrad(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *c
   free(g); free(c); free(p1); free(q1); free(p2); free(q2); free(Jc);
   return rc;
 }
+
+/* One penalty hprod! on the same equality-QP user model, following model-Fletcherpenaltynlp.jl:521-570 (Val(2),
+ * approx = 2) and :572-634 (Val(1), approx = 1).  The constraints are linear, so
+ *   hprod_nln!(x, -ys, v; obj_weight = 1) = q .* v,   hprod_nln!(x, y, v; obj_weight = 0) = 0,   ghjvprod = 0:
+ *   Hsv = q.*v                                              :537-538 / :588-589
+ *   (p1, _, p2, _) = solve_two_least_squares(v, Hsv)        :542 / :591
+ *   Ptv = v - p1;  HsPtv = q.*Ptv                           :543-545 / :592-596
+ *   Val(1) only: Ssv = 0; (invJtJJv, invJtJSsv) = solve_two_extras(v, Ssv); JtinvJtJSsv = A'invJtJSsv;
+ *                SsinvJtJJv = 0                             :598-612   (their stats land in st[2], st[3])
+ *   Hv = p2 - HsPtv + 2 sigma Ptv (- JtinvJtJSsv - SsinvJtJJv)          :550 / :609-612
+ *   rho > 0: Hv += Hcv (= 0) + rho A'(A v)                  :552-563 / :614-625
+ *   eta > 0: Hv += eta v                                    :564-566 / :626-628
+ * The product does not depend on x for this model (ys only enters through the vanishing constraint Hessians). */
+int fpo_qp_hprod(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colind, const double *vals,
+                 const double *qdiag, const double *v, double sigma, double rho, double delta, double eta,
+                 int approx, const fpo_options *o, double *Hv, fpo_stats st[4]) {
+  fpo_csr A = {m, n, rowptr, colind, vals};
+  double *Hsv = calloc((size_t)(n > 0 ? n : 1), 8), *p1 = malloc((size_t)n * 8), *p2 = malloc((size_t)n * 8);
+  double *q1 = malloc((size_t)m * 8), *q2 = malloc((size_t)m * 8);
+  double *Jv = calloc((size_t)(m > 0 ? m : 1), 8), *JtJv = malloc((size_t)n * 8);
+  memset(st, 0, 4 * sizeof(fpo_stats));
+  for (int64_t i = 0; i < n; ++i) Hsv[i] = qdiag[i] * v[i];
+  int rc = fpo_solve_two_least_squares(m, n, rowptr, colind, vals, delta, o, v, Hsv, p1, q1, p2, q2, st);
+  for (int64_t i = 0; i < n; ++i) {
+    const double Ptv = v[i] - p1[i];
+    Hv[i] = p2[i] - qdiag[i] * Ptv + 2.0 * sigma * Ptv;
+  }
+  if (approx == 1) {
+    double *Ssv = calloc((size_t)(m > 0 ? m : 1), 8);
+    const int rc2 = fpo_solve_two_extras(m, n, rowptr, colind, vals, delta, o, v, Ssv, q1, q2, st + 2);
+    csr_tmul(&A, q2, JtJv); /* JtinvJtJSsv */
+    for (int64_t i = 0; i < n; ++i) Hv[i] -= JtJv[i];
+    rc |= rc2 << 2;
+    free(Ssv);
+  }
+  if (rho > 0.0) {
+    csr_mul(&A, v, Jv);
+    csr_tmul(&A, Jv, JtJv);
+    for (int64_t i = 0; i < n; ++i) Hv[i] += rho * JtJv[i];
+  }
+  if (eta > 0.0)
+    for (int64_t i = 0; i < n; ++i) Hv[i] += eta * v[i];
+  free(Hsv); free(p1); free(p2); free(q1); free(q2); free(Jv); free(JtJv);
+  return rc;
+}

@@ -196,6 +196,21 @@ def qp_objgrad(qp, x, sigma, rho, delta, eta=0.0, xk=None, opts=None, threaded=F
     return dict(fx=fx.value, gx=gx, ys=ys, gs=gs, stats=[st[0], st[1]], rc=rc)
 
 
+def qp_hprod(qp, v, sigma, rho, delta, eta=0.0, approx=2, opts=None):
+    """C restatement of hprod! (model-Fletcherpenaltynlp.jl:521-570 for approx = 2, :572-634 for approx = 1) on the
+    eq-QP user model.  Returns dict(Hv, stats (4: the two LSQR solves, then LSQR + MINRES of solve_two_extras), rc)."""
+    rp, ci, va = _csr64(qp.rowptr, qp.colind, qp.vals)
+    n, m = qp.n, qp.m
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    opts = opts or default_options(n, m)
+    Hv = np.empty(n)
+    st = (Stats * 4)()
+    rc = lib().fpo_qp_hprod(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va), _p(qp.qdiag),
+                            _p(v), C.c_double(sigma), C.c_double(rho), C.c_double(delta), C.c_double(eta),
+                            C.c_int(approx), C.byref(opts), _p(Hv), st)
+    return dict(Hv=Hv, stats=[st[k] for k in range(4)], rc=rc)
+
+
 # ----------------------------------------------------------------------------- exact (direct) oracle
 
 def _kkt_solve(A, delta, rhs):
@@ -243,6 +258,19 @@ def exact_two_extras(A, delta, rhs1, rhs2):
     Ad = A.toarray() if sp.issparse(A) else np.asarray(A)
     M = Ad @ Ad.T + tau * np.eye(Ad.shape[0])
     return np.linalg.solve(M, Ad @ rhs1), np.linalg.solve(M, rhs2)
+
+
+def exact_qp_hprod(qp, v, sigma, rho, delta, eta=0.0):
+    """hprod! Val(2) on the eq-QP model through the exact KKT solve (model-Fletcherpenaltynlp.jl:521-570)."""
+    A = qp.scipy_csr()
+    p1, _, p2, _ = exact_two_least_squares(A, delta, v, qp.qdiag * v)
+    ptv = v - p1
+    Hv = p2 - qp.qdiag * ptv + 2.0 * sigma * ptv
+    if rho > 0:
+        Hv = Hv + rho * (A.T @ (A @ v))
+    if eta > 0:
+        Hv = Hv + eta * v
+    return Hv
 
 
 def exact_qp_objgrad(qp, x, sigma, rho, delta, eta=0.0, xk=None):

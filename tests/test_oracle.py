@@ -191,3 +191,93 @@ def test_lsqr_zero_rhs_and_zero_atb_edge_cases(oracle):
     b -= Ad.T @ np.linalg.lstsq(Ad.T, b, rcond=None)[0]
     x, st = oracle.lsqr(5, 12, A.indptr, A.indices, A.data, b, atol=SE, rtol=SE, transposed=True)
     assert st.solved and np.linalg.norm(x) < 1e-12
+
+
+# ---------------------------------------------------------------- the iterative back-end's known-answer case
+
+_KCASE = os.path.join(os.path.dirname(__file__), "golden", "krylov_case_small_pde.json")
+_KGOLD = os.path.join(os.path.dirname(__file__), "golden", "krylov_golden.json")
+
+
+def _krylov_case():
+    case = json.load(open(_KCASE))
+    A = sp.csr_matrix((case["vals"], (np.array(case["rows"]) - 1, np.array(case["cols"]) - 1)),
+                      shape=(case["m"], case["n"]))
+    A.sort_indices()
+    return case, A, np.array(case["g"]), np.array(case["c"])
+
+
+def test_krylov_case_fixture_is_what_its_generator_writes():
+    """tests/golden/krylov_case_small_pde.json (the input of make_krylov_golden.jl) is reproducible bit for bit from the
+    committed generator, and Krylov iterates well past one step on it (unlike the m = 1 known-answer cases)."""
+    case, A, g, c = _krylov_case()
+    qp = problems.pde_control_like(n=400, m=60, per_row=20, window=128, seed=77)
+    assert (case["n"], case["m"]) == (qp.n, qp.m)
+    B = qp.scipy_csr()
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices) and np.array_equal(A.data, B.data)
+    assert np.array_equal(g, qp.qdiag * qp.x + qp.d) and np.array_equal(c, B @ qp.x - qp.b)
+
+
+@pytest.mark.parametrize("delta", [0.0, SE, 0.25])
+def test_oracle_iterates_on_krylov_case(oracle, delta):
+    """The C restatement on the Krylov known-answer case at the reference's default tolerances: > 10 iterations of each
+    method, and the answers sit where those tolerances put them relative to the exact KKT solve."""
+    case, A, g, c = _krylov_case()
+    m, n = A.shape
+    p1, q1, p2, q2, st, rc = oracle.solve_two_mixed(m, n, A.indptr, A.indices, A.data, delta, g, c)
+    assert st[0].niter > 10 and st[1].niter > 10
+    e = oracle.exact_two_mixed(A, delta, g, c)
+    assert np.linalg.norm(q1 - e[1]) <= 1e-6 * np.linalg.norm(e[1])
+    if st[1].solved:
+        assert np.linalg.norm(q2 - e[3]) <= 1e-6 * np.linalg.norm(e[3])
+
+
+def _status_code(s):
+    """Krylov.jl stats.status string -> FPO_ST_* code (substring match)."""
+    s = s.lower()
+    if s.startswith("x = 0 is a zero-residual") or s.startswith("x is a zero-residual"):
+        return 1
+    if s.startswith("x = 0 is a minimum least-squares"):
+        return 2
+    if "zero-residual" in s:
+        return 4
+    if "forward error" in s:
+        return 5
+    if "condition number" in s:
+        return 6
+    if "maximum number of iterations" in s:
+        return 7
+    if "inconsistent" in s:
+        return 8
+    if "least-squares solution" in s or "good enough" in s or "solution" in s:
+        return 3
+    return 0
+
+
+@pytest.mark.skipif(not os.path.exists(_KGOLD), reason="tests/golden/krylov_golden.json absent: it is written by "
+                    "tests/golden/make_krylov_golden.jl, which needs Julia + Krylov.jl 0.10 (not in this pipeline) -- "
+                    "iteration-level parity with Krylov.jl stays UNPINNED until someone runs it")
+def test_oracle_matches_krylov_jl_golden(oracle):
+    """Pins oracle/fps_oracle.c against the real Krylov.jl: niter, solved, status and the solution vectors of lsqr,
+    craig (sqd for delta != 0) and minres with the reference's keyword arguments."""
+    gold = json.load(open(_KGOLD))
+    case, A, g, c = _krylov_case()
+    m, n = A.shape
+    for run in gold["runs"]:
+        delta = run["delta"]
+        x, st = oracle.lsqr(m, n, A.indptr, A.indices, A.data, g, lam=np.sqrt(delta), atol=SE, rtol=SE,
+                            itmax=5 * (m + n), transposed=True)
+        w = run["lsqr"]
+        assert (st.niter, bool(st.solved)) == (w["stats"]["niter"], w["stats"]["solved"])
+        assert st.status == _status_code(w["stats"]["status"])
+        np.testing.assert_allclose(x, w["x"], rtol=0, atol=1e-12 * np.linalg.norm(w["x"]))
+        xc, yc, st = oracle.craig(m, n, A.indptr, A.indices, A.data, -c, delta=delta, itmax=5 * (m + n))
+        w = run["craig"]
+        assert (st.niter, bool(st.solved)) == (w["stats"]["niter"], w["stats"]["solved"])
+        assert st.status == _status_code(w["stats"]["status"])
+        np.testing.assert_allclose(xc, w["x"], rtol=0, atol=1e-12 * np.linalg.norm(w["x"]))
+        np.testing.assert_allclose(yc, w["y"], rtol=0, atol=1e-12 * np.linalg.norm(w["y"]))
+        xm, st = oracle.minres_aat(m, n, A.indptr, A.indices, A.data, c, lam=max(delta, 1e-14))
+        w = run["minres"]
+        assert (st.niter, bool(st.solved)) == (w["stats"]["niter"], w["stats"]["solved"])
+        np.testing.assert_allclose(xm, w["x"], rtol=0, atol=1e-12 * np.linalg.norm(w["x"]))
