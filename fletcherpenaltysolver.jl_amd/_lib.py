@@ -67,6 +67,7 @@ SYMBOLS = [
     ("fpsq_set_jacobian_structure_coo", C.c_int, [_VP, _I64, _DP, _DP, _I32]),
     ("fpsq_set_jacobian_structure_csr", C.c_int, [_VP, _DP, _DP]),
     ("fpsq_set_jacobian_values", C.c_int, [_VP, _DP]),
+    ("fpsq_set_input_stream", C.c_int, [_VP, _I32, _VP]),
     ("fpsq_set_delta", C.c_int, [_VP, _D]),
     ("fpsq_solve_two_mixed", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP, C.POINTER(Stats)]),
     ("fpsq_solve_two_least_squares", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP, C.POINTER(Stats)]),
@@ -117,6 +118,17 @@ def load():
             fn.argtypes = args
         _LIB = lib
     return _LIB
+
+
+def producer_stream(*args):
+    """The HIP stream on which torch is producing the CUDA tensors among `args` (torch's current stream), or None when
+    no argument is a device tensor.  Passed to fpsq_set_input_stream so the library orders its reads after them."""
+    for a in args:
+        if getattr(a, "is_cuda", False):
+            import torch
+
+            return int(torch.cuda.current_stream(a.device).cuda_stream)
+    return None
 
 
 def ptr(a):

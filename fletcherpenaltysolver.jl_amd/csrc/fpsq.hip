@@ -167,6 +167,9 @@ struct fpsq_solver_s {
   fpsq_options opt{};
   double delta = 0.0;
   hipStream_t stream = nullptr;
+  bool in_stream_on = false;     // fpsq_set_input_stream: producer stream of device-resident arguments
+  hipStream_t in_stream = nullptr;
+  hipEvent_t ev_in = nullptr;
   bool have_structure = false, have_values = false;
   std::string err;
 
@@ -1339,6 +1342,14 @@ int check_ready(fpsq_handle h) {
   return 0;
 }
 
+// Device-resident arguments are produced on the caller's stream: everything queued there so far must be complete
+// before the first kernel / copy of this call touches them (include/fpsq.h, "INPUT READINESS").
+void order_inputs(fpsq_handle h) {
+  if (!h->in_stream_on) return;
+  hipEventRecord(h->ev_in, h->in_stream);
+  hipStreamWaitEvent(h->stream, h->ev_in, 0);
+}
+
 void call_begin(fpsq_handle h) {
   h->launches = 0;
   h->spmv_launches = 0;
@@ -1565,6 +1576,7 @@ int fpsq_destroy(fpsq_handle h) {
   }
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->ev_in) hipEventDestroy(h->ev_in);
   if (h->prog_host) hipHostFree(h->prog_host);
   if (h->hstats) hipHostFree(h->hstats);
   if (h->hscal) hipHostFree(h->hscal);
@@ -1675,6 +1687,7 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   if (h->nnz_in > 0) {
     if (h->in_perm) {
       HIPCHK(h, hipMemcpyAsync(h->in_vals, vals, (size_t)h->nnz_in * 8, hipMemcpyDefault, s));
@@ -1698,6 +1711,15 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
   return FPSQ_OK;
 }
 
+int fpsq_set_input_stream(fpsq_handle h, int32_t enabled, void* hip_stream) {
+  if (!h) return FPSQ_ERR_ARG;
+  hipSetDevice(h->opt.device);
+  if (enabled && !h->ev_in) HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+  h->in_stream_on = enabled != 0;
+  h->in_stream = (hipStream_t)hip_stream;
+  return FPSQ_OK;
+}
+
 int fpsq_set_delta(fpsq_handle h, double delta) {
   if (!h || !(delta >= 0.0)) {
     if (h) h->err = "set_delta: delta must be >= 0";
@@ -1716,6 +1738,7 @@ int fpsq_solve_two_mixed(fpsq_handle h, const double* rhs1, const double* rhs2, 
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
   HIPCHK(h, hipMemcpyAsync(h->in_n1, rhs1, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(h->in_m, rhs2, mb, hipMemcpyDefault, s));
@@ -1740,6 +1763,7 @@ int fpsq_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
   HIPCHK(h, hipMemcpyAsync(h->in_n1, rhs1, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(h->in_n2, rhs2, nb, hipMemcpyDefault, s));
@@ -1768,6 +1792,7 @@ int fpsq_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2,
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
   HIPCHK(h, hipMemcpyAsync(h->in_n1, rhs1, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(h->in_m, rhs2, mb, hipMemcpyDefault, s));
@@ -1800,6 +1825,7 @@ int fpsq_ys_gs(fpsq_handle h, const double* g, const double* c, double sigma, do
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   const size_t nb = (size_t)h->n * 8, mb = (size_t)h->m * 8;
   HIPCHK(h, hipMemcpyAsync(h->in_n1, g, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(h->in_m, c, mb, hipMemcpyDefault, s));
@@ -1828,6 +1854,7 @@ int fpsq_jac_mul(fpsq_handle h, int32_t trans, double alpha, const double* x, do
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   const size_t xb = (size_t)(trans ? h->m : h->n) * 8, yb = (size_t)(trans ? h->n : h->m) * 8;
   double* dx = trans ? h->in_m : h->in_n1;
   double* dy = trans ? h->in_n2 : h->c;
@@ -1888,6 +1915,7 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   const int64_t n = h->n, m = h->m;
   const size_t nb = (size_t)n * 8, mb = (size_t)m * 8;
   const int gn = ew_grid(n), gm = ew_grid(m);
@@ -1983,6 +2011,7 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
+  order_inputs(h);
   const int64_t n = h->n;
   const size_t nb = (size_t)n * 8;
   const int gn = ew_grid(n);

@@ -39,6 +39,7 @@ class DeviceEqQP:
         self._check(self._lib.fpsq_qp_create(h, qp.qdiag.ctypes.data, qp.d.ctypes.data, qp.b.ctypes.data, C.byref(q)))
         self._q = q
         self.stats = (_lib.Stats * 2)()
+        self._in_stream = -1
         if comm is not None:
             if comm[0] == "rccl":
                 _, nranks, rank, ident = comm
@@ -54,6 +55,14 @@ class DeviceEqQP:
             raise FpsqError(self._lib.fpsq_last_error(self._h).decode())
         return rc
 
+    def _order(self, *args):
+        """Device tensors among the arguments are produced on torch's current stream: register it so the library's
+        stream waits for it (fpsq_set_input_stream; include/fpsq.h "INPUT READINESS").  No host synchronisation."""
+        st = _lib.producer_stream(*args)
+        if st is not None and st != self._in_stream:
+            self._check(self._lib.fpsq_set_input_stream(self._h, 1, st))
+            self._in_stream = st
+
     def set_delta(self, delta):
         self.delta = delta
         self._check(self._lib.fpsq_set_delta(self._h, float(delta)))
@@ -65,6 +74,7 @@ class DeviceEqQP:
         """x / gx / ys / gs / xk: numpy arrays, torch tensors (host or device) or raw addresses.
         Returns (fx, rc): rc > 0 flags a Krylov solve that stopped unsolved (the reference warns)."""
         fx = C.c_double()
+        self._order(x, gx, ys, gs, xk)
         rc = self._check(self._lib.fpsq_qp_objgrad(self._h, self._q, _lib.ptr(x), self.sigma, self.rho, self.eta,
                                                    _lib.ptr(xk), C.byref(fx), _lib.ptr(gx), _lib.ptr(ys),
                                                    _lib.ptr(gs), self.stats))
@@ -73,27 +83,32 @@ class DeviceEqQP:
     # -- the QDSolver seam on the same handle; every argument: numpy array, torch tensor (host or device) or address
     def solve_two_mixed(self, rhs1, rhs2, p1, q1, p2, q2):
         """src/solve_linear_system.jl:107-140 on the Jacobian the model holds (outputs are caller-owned buffers)."""
+        self._order(rhs1, rhs2, p1, q1, p2, q2)
         return self._check(self._lib.fpsq_solve_two_mixed(self._h, _lib.ptr(rhs1), _lib.ptr(rhs2), _lib.ptr(p1),
                                                           _lib.ptr(q1), _lib.ptr(p2), _lib.ptr(q2), self.stats))
 
     def solve_two_least_squares(self, rhs1, rhs2, p1, q1, p2, q2):
         """src/solve_linear_system.jl:79-105: the two solves of every hprod! (two LSQR recurrences, fused)."""
+        self._order(rhs1, rhs2, p1, q1, p2, q2)
         return self._check(self._lib.fpsq_solve_two_least_squares(self._h, _lib.ptr(rhs1), _lib.ptr(rhs2),
                                                                   _lib.ptr(p1), _lib.ptr(q1), _lib.ptr(p2),
                                                                   _lib.ptr(q2), self.stats))
 
     def ys_gs(self, g, c, gs, ys, v, w):
         """_compute_ys_gs! after the user-model evaluations (src/model-Fletcherpenaltynlp.jl:242-248)."""
+        self._order(g, c, gs, ys, v, w)
         return self._check(self._lib.fpsq_ys_gs(self._h, _lib.ptr(g), _lib.ptr(c), self.sigma, _lib.ptr(gs),
                                                 _lib.ptr(ys), _lib.ptr(v), _lib.ptr(w), self.stats))
 
     def jac_mul(self, trans, alpha, x, beta, y):
         """y = alpha op(A) x + beta y with the model's Jacobian (fpsq_jac_mul; trans = 0: A, 1: A')."""
+        self._order(x, y)
         return self._check(self._lib.fpsq_jac_mul(self._h, int(trans), float(alpha), _lib.ptr(x), float(beta), _lib.ptr(y)))
 
     def hprod(self, v, Hv):
         """hprod!(::FletcherPenaltyNLP, x, v, Hv), hessian_approx = Val(2) (model-Fletcherpenaltynlp.jl:521-570), on the
         device; the model is quadratic with linear constraints, so the product does not depend on x.  Returns rc."""
+        self._order(v, Hv)
         return self._check(self._lib.fpsq_qp_hprod(self._h, self._q, _lib.ptr(v), self.sigma, self.rho, self.eta,
                                                    _lib.ptr(Hv), self.stats))
 

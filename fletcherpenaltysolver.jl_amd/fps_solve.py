@@ -282,8 +282,9 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
         fx_user, ncx, ys = pen.state(xs)
         unb_mult = _nrminf(ys) >= meta.lagrange_bound
         feas = ncx < feas_tol
-        if sub_status == "optimal" and not unb_mult:                                            # algo.jl:121-151
-            stalling = stalling + 1 if _same(xs, x_prev) else 0
+        if sub_status == "optimal":                      # algo.jl:121-151 (taken whatever the multiplier bound says)
+            if _same(xs, x_prev):                       # :122-124 -- only ever incremented here, reset by the other branches
+                stalling += 1
             unsuccessful = unbounded = 0
             x = xs
             stats.solution, stats.multipliers = _copy(x), -ys
@@ -311,7 +312,7 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
             status = "max_time"
             break
         # ---- not finished: algo.jl:193-251
-        if sub_status == "optimal" and not unb_mult:
+        if sub_status == "optimal":
             if feas:                                           # tighten the sub-problem tolerances (:195-199)
                 sub_atol = max(sub_atol / 10.0, np.finfo(float).eps)
                 sub_rtol = max(sub_rtol / 10.0, np.finfo(float).eps)

@@ -13,6 +13,12 @@
  *   out aliases of solver-owned buffers, src/solve_linear_system.jl:139; callers copy out immediately,
  *   src/model-Fletcherpenaltynlp.jl:244-248, so caller-owned outputs are equivalent and remove the aliasing).
  *   All calls are synchronous: on return the outputs are complete (the solver's stream has been synchronised).
+ *   INPUT READINESS: the library works on its own non-blocking HIP stream and reads DEVICE-resident arguments in place.
+ *   Device data handed to a call must therefore be complete when the call is made -- either the caller has
+ *   synchronised the stream that produced it, or it has registered that stream once with fpsq_set_input_stream(): every
+ *   call then first makes the solver's stream wait (event, no host block) for all work queued on the registered
+ *   stream so far, which orders both the reads of device inputs and the overwriting of device output buffers that
+ *   earlier kernels of that stream may still be reading.  Host-resident arguments need nothing.
  *   One handle is non-re-entrant, exactly like one reference QDSolver (shared mutable workspaces).
  *
  * Return codes
@@ -109,6 +115,10 @@ int fpsq_set_jacobian_structure_csr(fpsq_handle h, const int32_t *rowptr, const 
 /* Jacobian values at the current x, in the order of the structure call.  Replaces `jac_coord!(nlp, x, vals)`
  * at src/solve_linear_system.jl:223-228 and the per-x operator rebuild `jac_op!` at :118-122. */
 int fpsq_set_jacobian_values(fpsq_handle h, const double *vals);
+
+/* Registers (enabled != 0) or clears the caller's producer stream for device-resident arguments, see "INPUT
+ * READINESS" above.  `hip_stream` is a hipStream_t (NULL = the legacy default stream). */
+int fpsq_set_input_stream(fpsq_handle h, int32_t enabled, void *hip_stream);
 
 /* `nlp.delta`, mutated by the outer loop (src/algo.jl:389-393). */
 int fpsq_set_delta(fpsq_handle h, double delta);

@@ -506,6 +506,35 @@ def test_ys_gs_entry_point(oracle, where, delta):
     dev.close()
 
 
+def test_device_inputs_are_ordered_after_the_producer_stream(oracle):
+    """include/fpsq.h "INPUT READINESS": the library runs on its own non-blocking stream and reads device tensors in
+    place, so the evaluation must wait for the torch kernels that are still PRODUCING x when the call is made.  Here x
+    is far from its final value until a queue of ~2 ms of torch work (a large matmul, then 50 in-place updates) has
+    run; objgrad is called right behind it with no host synchronisation and must see the final x (n = 1e6)."""
+    import torch
+
+    qp = problems.pde_control_like(n=1_000_000, m=100_000)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+    x0 = torch.from_numpy(qp.point(5)).cuda()
+    noise = torch.from_numpy(qp.point(6) - qp.xhat).cuda()
+    big = torch.randn(4096, 4096, dtype=torch.float64, device="cuda")
+    gx = torch.empty(qp.n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        x = x0 + 50.0 * noise          # far away (phi differs by orders of magnitude)
+        _ = big @ big                  # ~2 ms of queued work ahead of the updates
+        for _k in range(50):
+            x.sub_(noise)              # ... ends at x0 exactly? no: at x0 + 50 noise - 50 noise up to rounding
+        fx, rc = dev.objgrad(x, gx=gx)  # no torch.cuda.synchronize() in between
+        xh = x.cpu().numpy()           # the final x, read back AFTER the call
+        o = oracle.qp_objgrad(qp, xh, 1e3, 1.0, 0.0)
+        assert rc == o["rc"] == 0
+        assert (dev.stats[0].niter, dev.stats[1].niter) == (o["stats"][0].niter, o["stats"][1].niter)
+        assert abs(fx - o["fx"]) <= 1e-8 * abs(o["fx"])
+        assert _rel(gx.cpu().numpy(), o["gx"]) < 1e-8
+    dev.close()
+
+
 def test_torch_device_pointers_accepted():
     import torch
 
