@@ -81,6 +81,7 @@ SYMBOLS = [
     ("fpsq_qp_hprod", C.c_int, [_VP, _VP, _DP, _D, _D, _D, _DP, C.POINTER(Stats)]),
     ("fpsq_comm_unique_id", C.c_int, [_DP]),
     ("fpsq_comm_init", C.c_int, [_VP, _I32, _I32, _DP]),
+    ("fpsq_comm_set_halo", C.c_int, [_VP, _I64, _I64]),
     ("fpsq_local_group_create", C.c_int, [_I32, C.POINTER(_VP)]),
     ("fpsq_local_group_destroy", C.c_int, [_VP]),
     ("fpsq_comm_init_local", C.c_int, [_VP, _VP, _I32]),

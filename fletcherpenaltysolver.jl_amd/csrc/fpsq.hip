@@ -64,6 +64,11 @@ struct Comm {
   int nranks = 1, rank = 0;
   std::string err;
   virtual int allreduce_sum(double* buf, size_t count, hipStream_t s) = 0;
+  // Halo mode: vec is this rank's [n_loc][NL] window of raw partial products.  Its first tl rows are the same global
+  // columns as the last tl rows of rank - 1's window, its last tr rows the first tr rows of rank + 1's.  On return
+  // (stream order) recvL / recvR hold the neighbours' partials on those regions; vec itself is untouched.
+  virtual int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL,
+                            double* recvR, hipStream_t s) = 0;
   virtual ~Comm() {}
 };
 
@@ -73,6 +78,10 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool load(std::string& err) {
     if (lib) return true;
@@ -89,7 +98,12 @@ struct RcclApi {
     AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+    Send = (decltype(Send))dlsym(lib, "ncclSend");
+    Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
+    GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString || !Send || !Recv || !GroupStart ||
+        !GroupEnd) {
       err = "librccl is missing a required symbol";
       return false;
     }
@@ -108,6 +122,26 @@ struct RcclComm : Comm {
     }
     return 0;
   }
+  // neighbour-to-neighbour exchange over xGMI: one grouped send/recv pair per neighbour (<= 2 x window x NL doubles)
+  int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL, double* recvR,
+                    hipStream_t s) override {
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r == ncclSuccess && rank > 0 && tl > 0) {
+      r = g_rccl.Send(vec, (size_t)tl * NL, ncclDouble, rank - 1, c, s);
+      if (r == ncclSuccess) r = g_rccl.Recv(recvL, (size_t)tl * NL, ncclDouble, rank - 1, c, s);
+    }
+    if (r == ncclSuccess && rank < nranks - 1 && tr > 0) {
+      r = g_rccl.Send(vec + (size_t)(n_loc - tr) * NL, (size_t)tr * NL, ncclDouble, rank + 1, c, s);
+      if (r == ncclSuccess) r = g_rccl.Recv(recvR, (size_t)tr * NL, ncclDouble, rank + 1, c, s);
+    }
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) {
+      err = std::string("halo exchange (ncclSend/ncclRecv): ") + g_rccl.GetErrorString(r);
+      return FPSQ_ERR_COMM;
+    }
+    return 0;
+  }
   ~RcclComm() override {
     if (c) g_rccl.CommDestroy(c);
   }
@@ -121,7 +155,10 @@ struct LocalGroup {
   int arrived = 0;
   long generation = 0;
   double* bufs[8] = {};
+  const double* vecs[8] = {};  // halo exchange: every shard's window of partial products and its length
+  int64_t nloc[8] = {};
   hipEvent_t ready[8] = {};
+  hipEvent_t copied[8] = {};
   hipEvent_t done = nullptr;
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
@@ -156,6 +193,29 @@ struct LocalComm : Comm {
     g->barrier();
     hipStreamWaitEvent(s, g->done, 0);
     g->barrier();  // nobody may start the next collective (and overwrite bufs[] / re-record events) before all queued the wait
+    return 0;
+  }
+  int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL, double* recvR,
+                    hipStream_t s) override {
+    g->vecs[rank] = vec;
+    g->nloc[rank] = n_loc;
+    hipEventRecord(g->ready[rank], s);
+    g->barrier();  // every shard's pointer and `ready` event are published
+    if (rank > 0 && tl > 0) {
+      hipStreamWaitEvent(s, g->ready[rank - 1], 0);
+      hipMemcpyAsync(recvL, g->vecs[rank - 1] + (size_t)(g->nloc[rank - 1] - tl) * NL, (size_t)tl * NL * 8,
+                     hipMemcpyDeviceToDevice, s);
+    }
+    if (rank < nranks - 1 && tr > 0) {
+      hipStreamWaitEvent(s, g->ready[rank + 1], 0);
+      hipMemcpyAsync(recvR, g->vecs[rank + 1], (size_t)tr * NL * 8, hipMemcpyDeviceToDevice, s);
+    }
+    hipEventRecord(g->copied[rank], s);
+    g->barrier();  // every `copied` event is recorded
+    // the caller's next kernel modifies vec: both neighbours must have taken their copies of it first
+    if (rank > 0) hipStreamWaitEvent(s, g->copied[rank - 1], 0);
+    if (rank < nranks - 1) hipStreamWaitEvent(s, g->copied[rank + 1], 0);
+    g->barrier();  // the events may be re-recorded by the next collective only after everyone queued its waits
     return 0;
   }
 };
@@ -200,6 +260,12 @@ struct fpsq_solver_s {
   LaneCtl* ctl_pm;              // constant {1, -1}
   LaneCtl* ctl_mp;              // constant {-1, 1}
   Comm* comm = nullptr;         // null: single GPU
+  // Halo mode of the sharded handle (fpsq_comm_set_halo): n is the length of this rank's COLUMN WINDOW; its first
+  // `ovl` entries are shared with rank - 1, its last `ovr` with rank + 1; sums over n-vectors run over the owned prefix
+  // [0, n - ovr) and are all-reduced like the sums over the (row-sharded) m-vectors.
+  bool halo = false;
+  int64_t ovl = 0, ovr = 0;
+  double* halo_recv = nullptr;  // [(ovl + ovr)][2]
   double* comm_vec = nullptr;   // [n][2] all-reduce payload (partial A' products)
   double* comm_scal = nullptr;  // 8 doubles: scalar all-reduce payload
   double* dscal;               // small device scalar scratch
@@ -532,6 +598,7 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
 }
 
 inline int npart_A(fpsq_handle h) { return h->RA.ok ? h->RA.view.ng : h->A.nblk; }
+inline int64_t n_owned(fpsq_handle h) { return h->halo ? h->n - h->ovr : h->n; }
 
 int alloc_workspaces(fpsq_handle h) {
   const size_t n = (size_t)h->n, m = (size_t)h->m;
@@ -676,6 +743,25 @@ int comm_allreduce(fpsq_handle h, double* buf, size_t count) {
   return 0;
 }
 
+// Sum over the ranks of the raw partial A' products in buf ([n][NL]): all-reduce of the replicated n-vector, or, in
+// halo mode, the neighbour exchange of the two overlap regions of the rank's column window.
+int comm_reduce_long(fpsq_handle h, double* buf, int NL) {
+  if (!h->halo) return comm_allreduce(h, buf, (size_t)h->n * NL);
+  double* rl = h->halo_recv;
+  double* rr = h->halo_recv + (size_t)h->ovl * NL;
+  if (int rc = h->comm->halo_exchange(buf, h->n, NL, h->ovl, h->ovr, rl, rr, h->stream)) {
+    h->err = h->comm->err;
+    return rc;
+  }
+  const int64_t cnt = (h->ovl + h->ovr) * NL;
+  if (cnt > 0) {
+    hipLaunchKernelGGL(k_halo_add, dim3(ew_grid(cnt)), dim3(kBlock), 0, h->stream, buf, rl, h->ovl * NL, rr, h->ovr * NL,
+                       (h->n - h->ovr) * NL);
+    h->launches++;
+  }
+  return 0;
+}
+
 // LP <- ca A' SP + cb LP with norm partials (count returned in *np).  Sharded: every rank holds a row block A_r, so
 // A'x = sum_r A_r' x_r: raw partial product -> all-reduce -> fused axpby + norm on the replicated result.
 template <int NL>
@@ -687,9 +773,10 @@ int at_product(fpsq_handle h, const double* x, double* y, const LaneCtl* c0, con
     return 0;
   }
   launch_spmv<NL>(h, TAG_AT, x, nullptr, h->comm_vec, h->ctl_raw, h->ctl_raw, nullptr);
-  if (int rc = comm_allreduce(h, h->comm_vec, (size_t)h->n * NL)) return rc;
+  if (int rc = comm_reduce_long(h, h->comm_vec, NL)) return rc;
   const int g = ew_grid(h->n);
-  hipLaunchKernelGGL(k_axpby_norm<NL>, dim3(g), dim3(kBlock), 0, h->stream, h->comm_vec, y, c0, c1, h->n, partials);
+  hipLaunchKernelGGL(k_axpby_norm<NL>, dim3(g), dim3(kBlock), 0, h->stream, h->comm_vec, y, c0, c1, h->n, n_owned(h),
+                     partials);
   h->launches++;
   *np = g;
   return 0;
@@ -702,7 +789,7 @@ int at_product_const(fpsq_handle h, double ca, const double* x, double cb, const
     return 0;
   }
   launch_spmv<1>(h, TAG_AT, x, nullptr, h->comm_vec, h->ctl_raw, h->ctl_raw, nullptr);
-  if (int rc = comm_allreduce(h, h->comm_vec, (size_t)h->n)) return rc;
+  if (int rc = comm_reduce_long(h, h->comm_vec, 1)) return rc;
   hipLaunchKernelGGL(k_axpby_plain, dim3(ew_grid(h->n)), dim3(kBlock), 0, h->stream, h->comm_vec, ca, yin, cb, yout, h->n);
   h->launches++;
   return 0;
@@ -797,6 +884,7 @@ struct LoadSeg {
   double* dst;
   int32_t lane, nblk;
   int64_t len;
+  int64_t sum_len;  // the squared-norm partials run over [0, sum_len) (halo mode: the owned prefix of an n-vector)
   double* partials;
 };
 template <int NL>
@@ -818,12 +906,13 @@ __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0
     const int lane = first ? l0.lane : l1.lane;
     const int nb = first ? l0.nblk : l1.nblk;
     const int64_t len = first ? l0.len : l1.len;
+    const int64_t sum_len = first ? l0.sum_len : l1.sum_len;
     double* partials = first ? l0.partials : l1.partials;
     double sq = 0.0;
     for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < len; i += (int64_t)nb * kBlock) {
       const double v = scale * src[i];
       dst[i * NL + lane] = v;
-      sq += v * v;
+      if (i < sum_len) sq += v * v;
     }
     const double t = block_sum(sq, red);
     if (threadIdx.x == 0) partials[blk] = t;
@@ -995,6 +1084,7 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       // x = 0 is written by the w_1 start-up update (also when the recurrence ends at start-up)
       g.dst = LP;
       g.len = n;
+      g.sum_len = n_owned(h);
       g.nblk = L.preloaded ? 0 : gn;  // fast start: the caller wrote the lane and the ||rhs||^2 partials already
       (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
     } else {
@@ -1004,6 +1094,7 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       }
       g.dst = SP;
       g.len = m;
+      g.sum_len = m;
       g.nblk = gm;
       z.p[0] = L.x;
       z.n[0] = n;
@@ -1029,7 +1120,7 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   UpdSeg winit[2] = {seg_none(), seg_none()};
   bool craig_begun = false;
   if (any_lsqr) {
-    launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none);
+    if (int rc = launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none, /*sharded=*/h->halo)) return rc;
     // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes.  The CRAIG lane is parked by ctl.skip -- unless its
     // right-hand side is still to be formed (fast start): then it rides along with the constant pair (-1, +1):
     // SP[.][l] <- -A z + shift, and the norm partials of the launch are those of its right-hand side.
@@ -1144,7 +1235,8 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     for (int l = 0; l < NL; ++l)
       sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : STEP_CRAIG_SA, lanes[l], (int)it,
                         h->pS + (size_t)l * npT, npT, nullptr, 0, prog[l]);
-    launch_step(h, sa[0], sa[1]);  // sums over replicated n-vectors: no all-reduce
+    // sums over n-vectors: replicated (no all-reduce) unless the n-vectors are column windows (halo mode)
+    if (int rc = launch_step(h, sa[0], sa[1], /*sharded=*/h->halo)) return rc;
     // CRAIG's updates of this iteration
     UpdSeg cu[2] = {seg_none(), seg_none()};
     for (int l = 0; l < NL; ++l) {
@@ -1289,7 +1381,7 @@ int run_minres(fpsq_handle h, const double* b, double lambda, fpsq_stats* st_out
   HIPCHK(h, hipMemsetAsync(h->Mr[0], 0, (size_t)m * 8, s));
   // r1 = r2 = b: r2 sits in Mr[1] (iteration 1 reads r2 from Mr[it % 2]) and in the short pair SP (lane 0)
   HIPCHK(h, hipMemcpyAsync(h->Mr[1], b, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_load_lane<1>, dim3(gm), dim3(kBlock), 0, s, b, 1.0, h->SP, 0, m, h->pE);
+  hipLaunchKernelGGL(k_load_lane<1>, dim3(gm), dim3(kBlock), 0, s, b, 1.0, h->SP, 0, m, h->pE, m);
   Lane L;
   L.state = S;
   L.st = st_out;
@@ -1938,7 +2030,7 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   // c = A x - b product and the right-hand-side loads of the start-up are not launched.
   const bool fast = !h->comm && h->opt.fuse_two_rhs != 0;
   hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1],
-                     fast ? h->LP : (double*)nullptr, fast ? h->pE : (double*)nullptr);
+                     fast ? h->LP : (double*)nullptr, fast ? h->pE : (double*)nullptr, n_owned(h));
   h->launches++;
   if (!fast) spmv_const(h, TAG_A, 1.0, dx, -1.0, qp->b, h->c);  // c = A x - b
   // Single GPU with rho > 0: p1 = g - A'q1 and J'c (:424-428) share ONE two-right-hand-side product A'[q1, c], and
@@ -1978,11 +2070,22 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
       P.n[0] = gm;
       P.p[1] = fa.pcc;
       P.n[1] = gm;
+      if (h->halo) {  // f and ||x - xk||^2 are sums over the owned part of the rank's column window
+        P.p[2] = fa.pf;
+        P.n[2] = gn;
+        P.p[3] = fa.pdx;
+        P.n[3] = gn;
+      }
       hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
       if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
       fa.pcy = h->comm_scal;
       fa.pcc = h->comm_scal + 1;
       fa.np_m = 1;
+      if (h->halo) {
+        fa.pf = h->comm_scal + 2;
+        fa.pdx = h->comm_scal + 3;
+        fa.np_n = 1;
+      }
       hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa);
       h->launches += 2;
     }
@@ -2004,10 +2107,6 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
   if (!qp || qp->h != h || !v || !Hv || !st) {
     h->err = "qp_hprod: bad argument";
     return FPSQ_ERR_ARG;
-  }
-  if (h->comm) {
-    h->err = "qp_hprod: not available on a sharded handle";
-    return FPSQ_ERR_STATE;
   }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
@@ -2082,7 +2181,10 @@ int fpsq_local_group_create(int32_t nshards, void** out) {
   if (!out || nshards < 1 || nshards > 8) return FPSQ_ERR_ARG;
   LocalGroup* g = new LocalGroup();
   g->n = nshards;
-  for (int r = 0; r < nshards; ++r) hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming);
+  for (int r = 0; r < nshards; ++r) {
+    hipEventCreateWithFlags(&g->ready[r], hipEventDisableTiming);
+    hipEventCreateWithFlags(&g->copied[r], hipEventDisableTiming);
+  }
   hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
   *out = g;
   return FPSQ_OK;
@@ -2091,7 +2193,10 @@ int fpsq_local_group_create(int32_t nshards, void** out) {
 int fpsq_local_group_destroy(void* group) {
   LocalGroup* g = (LocalGroup*)group;
   if (!g) return FPSQ_ERR_ARG;
-  for (int r = 0; r < g->n; ++r) hipEventDestroy(g->ready[r]);
+  for (int r = 0; r < g->n; ++r) {
+    hipEventDestroy(g->ready[r]);
+    hipEventDestroy(g->copied[r]);
+  }
   hipEventDestroy(g->done);
   delete g;
   return FPSQ_OK;
@@ -2108,6 +2213,21 @@ int fpsq_comm_init_local(fpsq_handle h, void* group, int32_t shard) {
   c->rank = shard;
   c->g = g;
   h->comm = c;
+  return FPSQ_OK;
+}
+
+int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_right) {
+  if (!h || !h->comm || overlap_left < 0 || overlap_right < 0 || overlap_left + overlap_right > h->n ||
+      (h->comm->rank == 0 && overlap_left != 0) || (h->comm->rank == h->comm->nranks - 1 && overlap_right != 0)) {
+    if (h) h->err = "comm_set_halo: needs a communicator; overlaps must fit the window and vanish at the outer ends";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(h->opt.device);
+  if (h->halo_recv) dfree(h, &h->halo_recv);
+  if (int rc = dalloc(h, &h->halo_recv, (size_t)(overlap_left + overlap_right) * 2)) return rc;
+  h->halo = true;
+  h->ovl = overlap_left;
+  h->ovr = overlap_right;
   return FPSQ_OK;
 }
 

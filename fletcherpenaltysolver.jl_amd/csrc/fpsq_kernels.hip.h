@@ -660,13 +660,13 @@ __global__ __launch_bounds__(kBlock) void k_gather_sum(const double* __restrict_
 // dst[i][lane] = src[i] (plain -> interleaved lane), with the squared-norm partial of what was stored
 template <int NL>
 __global__ __launch_bounds__(kBlock) void k_load_lane(const double* __restrict__ src, double scale, double* dst,
-                                                      int lane, int64_t n, double* partials) {
+                                                      int lane, int64_t n, double* partials, int64_t sum_len) {
   __shared__ double red[4];
   double sq = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const double v = scale * src[i];
     dst[i * NL + lane] = v;
-    sq += v * v;
+    if (i < sum_len) sq += v * v;
   }
   const double t = block_sum(sq, red);
   if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
@@ -698,9 +698,12 @@ __global__ __launch_bounds__(kBlock) void k_updates(const UpdSeg s0, const UpdSe
 
 // After the all-reduce of the raw partial products P = sum_r A_r' x_r:  y = ca * P + cb * y with the squared-norm
 // partials -- the epilogue the single-GPU product kernel fuses.  Runs on replicated n-vectors.
+// sum_len <= len: the norm is taken over the rank's OWNED prefix only (halo mode: the tail of the window is owned by the
+// right neighbour and counted there).
 template <int NL>
 __global__ __launch_bounds__(kBlock) void k_axpby_norm(const double* __restrict__ P, double* y, const LaneCtl* ctl0,
-                                                       const LaneCtl* ctl1, int64_t len, double* partials) {
+                                                       const LaneCtl* ctl1, int64_t len, int64_t sum_len,
+                                                       double* partials) {
   const LaneCtl* c[2] = {ctl0, ctl1};
   bool act[NL];
   double ca[NL], cb[NL];
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(kBlock) void k_axpby_norm(const double* __restrict_
       if (act[l]) {
         const double o = ca[l] * P[i * NL + l] + (cb[l] != 0.0 ? cb[l] * y[i * NL + l] : 0.0);
         y[i * NL + l] = o;
-        sq[l] += o * o;
+        if (i < sum_len) sq[l] += o * o;
       }
     }
   }
@@ -731,6 +734,17 @@ __global__ __launch_bounds__(kBlock) void k_axpby_norm(const double* __restrict_
   for (int l = 0; l < NL; ++l) {
     const double t = block_sum(sq[l], red);
     if (threadIdx.x == 0) partials[(size_t)l * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// Halo mode of the row-sharded A' product: the raw partial products on the two overlap regions of the rank's column
+// window receive the neighbour's partials of the same global columns (a + b on one side, b + a on the other: the
+// overlap ends up bitwise identical on both ranks).  vec: [n_loc][NL]; recvL: [TL][NL] (head), recvR: [TR][NL] (tail).
+__global__ __launch_bounds__(kBlock) void k_halo_add(double* vec, const double* __restrict__ recvL, int64_t nl,
+                                                     const double* __restrict__ recvR, int64_t nr, int64_t tail0) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nl + nr; i += (int64_t)gridDim.x * kBlock) {
+    if (i < nl) vec[i] += recvL[i];
+    else vec[tail0 + (i - nl)] += recvR[i - nl];
   }
 }
 
@@ -778,7 +792,8 @@ __global__ __launch_bounds__(kBlock) void k_local_allreduce(ShardBufs B, int64_t
 // partials of ||g||^2 in pg.
 __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q, const double* __restrict__ d,
                                                     const double* __restrict__ x, const double* xk, double* g,
-                                                    int64_t n, double* pf, double* pdx, double* lp, double* pg) {
+                                                    int64_t n, double* pf, double* pdx, double* lp, double* pg,
+                                                    int64_t n_sum) {
   __shared__ double red[4];
   double f = 0.0, dx2 = 0.0, gg = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
@@ -789,10 +804,12 @@ __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q
       *reinterpret_cast<double2*>(lp + 2 * i) = make_double2(gi, xi);
       gg += gi * gi;
     }
-    f += xi * (0.5 * qi * xi + di);
-    if (xk) {
-      const double t = xi - xk[i];
-      dx2 += t * t;
+    if (i < n_sum) {  // (halo mode: sums over the rank's owned prefix of its column window)
+      f += xi * (0.5 * qi * xi + di);
+      if (xk) {
+        const double t = xi - xk[i];
+        dx2 += t * t;
+      }
     }
   }
   const double tf = block_sum(f, red);

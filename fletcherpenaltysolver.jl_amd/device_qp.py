@@ -15,9 +15,10 @@ from .qdsolver import FpsqError
 
 class DeviceEqQP:
     """`comm`: None (single GPU), ("rccl", nranks, rank, id_bytes) or ("local", group_ptr, shard) for a row-sharded
-    model; `qp` is then the rank's row block (distributed.shard_qp)."""
+    model; `qp` is then the rank's row block (distributed.shard_qp).  `halo` = (overlap_left, overlap_right): the
+    n-vectors are column windows (distributed.shard_qp_halo / HaloPlan.overlaps) instead of replicated."""
 
-    def __init__(self, qp, sigma=1e3, rho=1.0, delta=0.0, eta=0.0, device=0, comm=None, **opt_overrides):
+    def __init__(self, qp, sigma=1e3, rho=1.0, delta=0.0, eta=0.0, device=0, comm=None, halo=None, **opt_overrides):
         self._lib = _lib.load()
         self.qp, self.sigma, self.rho, self.delta, self.eta = qp, sigma, rho, delta, eta
         opts = _lib.Options()
@@ -40,6 +41,14 @@ class DeviceEqQP:
         self._q = q
         self.stats = (_lib.Stats * 2)()
         self._in_stream = -1
+        try:
+            self._attach_comm(comm, halo)
+        except Exception:
+            self.close()
+            raise
+
+    def _attach_comm(self, comm, halo):
+        h = self._h
         if comm is not None:
             if comm[0] == "rccl":
                 _, nranks, rank, ident = comm
@@ -49,6 +58,8 @@ class DeviceEqQP:
                 self._check(self._lib.fpsq_comm_init_local(h, comm[1], comm[2]))
             else:
                 raise ValueError(comm[0])
+            if halo is not None:
+                self._check(self._lib.fpsq_comm_set_halo(h, int(halo[0]), int(halo[1])))
 
     def _check(self, rc):
         if rc < 0:

@@ -178,6 +178,16 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double *v, double sigma, doub
  * fpsq_comm_init.  Without fpsq_comm_init the handle is single-GPU. */
 int fpsq_comm_unique_id(uint8_t id[128]);
 int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id[128]);
+/* HALO MODE (banded Jacobians; SURVEY.md 8e "contract path").  When the rows of a rank touch only a column window
+ * [w_lo(r), w_hi(r)) of the n columns, windows tile [0, n) and only overlap between neighbouring ranks, the n-vectors
+ * need not be replicated: the rank's handle is created with n = its WINDOW length (column indices relative to
+ * w_lo(r)), every n-vector argument is the rank's window of the global vector (identical on overlaps), and per
+ * Krylov iteration the ranks exchange the partial A'u products of the overlap regions with their neighbours
+ * (overlap_left = w_hi(r-1) - w_lo(r) entries at the head of the window, overlap_right = w_hi(r) - w_lo(r+1) at its
+ * tail; <= 2 x 8192 x 2 doubles at the headline size) instead of all-reducing an n x 2 vector, plus one 4-double
+ * all-reduce per reduction (sums over n-vectors run over the owned prefix [0, n - overlap_right)).  Call after
+ * fpsq_comm_init / fpsq_comm_init_local; overlaps must be 0 at the outer ends (rank 0 left, last rank right). */
+int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_right);
 /* In-process stand-in for RCCL: `nshards` (<= 8) row-shard handles living in ONE process on ONE GPU, each driven
  * by its own host thread; the all-reduce is a summation kernel.  Lets the sharded numerics be parity-tested on a
  * one-GPU box.  Create the group, attach every shard handle, run the same call on all shards concurrently. */

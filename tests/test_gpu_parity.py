@@ -624,6 +624,92 @@ def test_row_sharded_objgrad_matches_single_gpu(oracle, nshards, delta):
     group.close()
 
 
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, delta):
+    """HALO mode (include/fpsq.h fpsq_comm_set_halo; the SURVEY 8e contract path): every shard holds only its column
+    window of the n-vectors and exchanges the partial A'u products of its two overlap regions with its neighbours
+    (in-process communicator: copy kernels instead of ncclSend/ncclRecv) plus 4-double all-reduces.  objgrad and hprod
+    on 2 / 3 / 8 shards reproduce the unsharded handle (iteration counts identical, values to 1e-9: only the order of
+    the reductions differs); overlaps are bitwise identical on the two ranks that share them; phi is bitwise
+    identical on all shards (replicated scalars)."""
+    from fps_amd.device_qp import LocalGroup
+    from fps_amd.distributed import halo_plan, row_partition, shard_qp_halo
+
+    qp = problems.pde_control_like(n=24000, m=2400, per_row=24, window=512, seed=29)
+    sigma, rho = 1e3, 1.0
+    ref = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=delta)
+    g_ref, ys_ref, gs_ref = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n)
+    f_ref, rc_ref = ref.objgrad(qp.x, gx=g_ref, ys=ys_ref, gs=gs_ref)
+    it_ref = (ref.stats[0].niter, ref.stats[1].niter)
+    v = np.random.default_rng(3).standard_normal(qp.n)
+    hv_ref = np.empty(qp.n)
+    assert ref.hprod(v, hv_ref) == 0
+    ith_ref = (ref.stats[0].niter, ref.stats[1].niter)
+    ref.close()
+
+    bounds = row_partition(qp.rowptr, nshards)
+    plan = halo_plan(qp.rowptr, qp.colind, qp.n, bounds)
+    assert plan is not None and plan.max_exchange_doubles() <= 2 * 2 * 512
+    group = LocalGroup(nshards)
+    locs = [shard_qp_halo(qp, plan, r) for r in range(nshards)]
+    shards = [DeviceEqQP(locs[r], sigma=sigma, rho=rho, delta=delta, comm=("local", group.ptr, r),
+                         halo=plan.overlaps(r)) for r in range(nshards)]
+    gx = [np.empty(l.n) for l in locs]
+    gs = [np.empty(l.n) for l in locs]
+    ys = [np.empty(l.m) for l in locs]
+    res = group.run([lambda r=r: shards[r].objgrad(locs[r].x, gx=gx[r], ys=ys[r], gs=gs[r]) for r in range(nshards)])
+    for r in range(nshards):
+        f, rc = res[r]
+        assert rc == rc_ref == 0
+        assert (shards[r].stats[0].niter, shards[r].stats[1].niter) == it_ref
+        assert f == res[0][0] and abs(f - f_ref) <= 1e-9 * abs(f_ref)
+        if r + 1 < nshards:  # the overlap with the right neighbour: same global columns, bitwise equal
+            t = plan.overlaps(r)[1]
+            assert t > 0 and np.array_equal(gx[r][-t:], gx[r + 1][:t]) and np.array_equal(gs[r][-t:], gs[r + 1][:t])
+    assert _rel(plan.assemble(gx), g_ref) < 1e-9 and _rel(plan.assemble(gs), gs_ref) < 1e-9
+    assert _rel(np.concatenate(ys), ys_ref) < 1e-9
+    # hprod! Val(2) on the sharded handles (two LSQR lanes + rho A'(A v))
+    hv = [np.empty(l.n) for l in locs]
+    rcs = group.run([lambda r=r: shards[r].hprod(v[plan.window(r)], hv[r]) for r in range(nshards)])
+    assert all(rc == 0 for rc in rcs)
+    assert all((sh.stats[0].niter, sh.stats[1].niter) == ith_ref for sh in shards)
+    assert _rel(plan.assemble(hv), hv_ref) < 1e-9
+    # the seam itself: solve_two_mixed / solve_two_least_squares with window right-hand sides
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    outs = [[np.empty(l.n), np.empty(l.m), np.empty(l.n), np.empty(l.m)] for l in locs]
+    group.run([lambda r=r: shards[r].solve_two_mixed(g[plan.window(r)], c[bounds[r]:bounds[r + 1]], *outs[r])
+               for r in range(nshards)])
+    o = oracle.solve_two_mixed(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, c)
+    assert all((sh.stats[0].niter, sh.stats[1].niter) == (o[4][0].niter, o[4][1].niter) for sh in shards)
+    assert _rel(plan.assemble([x[0] for x in outs]), o[0]) < 1e-8 and _rel(np.concatenate([x[1] for x in outs]), o[1]) < 1e-8
+    assert _rel(plan.assemble([x[2] for x in outs]), o[2]) < 1e-8 and _rel(np.concatenate([x[3] for x in outs]), o[3]) < 1e-8
+    for sh in shards:
+        sh.close()
+    group.close()
+
+
+def test_halo_mode_argument_checks():
+    """fpsq_comm_set_halo: needs a communicator; overlaps must fit the window and vanish at the outer ends."""
+    from fps_amd.device_qp import LocalGroup
+    from fps_amd.qdsolver import FpsqError
+
+    qp = _small_pde(seed=23, n=3000, m=300)
+    single = DeviceEqQP(qp)
+    assert single._lib.fpsq_comm_set_halo(single._h, 0, 0) == -1  # no communicator
+    single.close()
+    group = LocalGroup(2)
+    with pytest.raises(FpsqError):
+        DeviceEqQP(qp, comm=("local", group.ptr, 0), halo=(5, 0))   # rank 0 has no left neighbour
+    with pytest.raises(FpsqError):
+        DeviceEqQP(qp, comm=("local", group.ptr, 1), halo=(2000, 2000))  # overlaps larger than the window
+    ok = DeviceEqQP(qp, comm=("local", group.ptr, 1), halo=(100, 0))
+    ok.close()
+    group.close()
+
+
 def test_rccl_single_rank_communicator():
     """world_size = 1 through the real RCCL path (the only RCCL configuration a one-GPU box can run)."""
     from fps_amd.device_qp import rccl_unique_id
