@@ -6,36 +6,82 @@ on the synthetic PDE-control-like equality QP  n = 1e6, m = 1e5, nnz(A) = 1e7, f
 user-model f, g, c  +  solve_two_mixed (the two KKT solves)  +  the ys/gs epilogue  +  Hsv  +  rho A'c.
 Inputs (A, q, d, b and all evaluation points) are resident in HBM before the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel = the CSR-stream
-SpMV/SpMM, algorithmic bytes / HIP-event time) and `cpu_baseline` (the single-threaded C restatement of the
-reference's iterative path, oracle/fps_oracle.c, on a bounded sample of the same workload).
+N > 1 without a torch.distributed environment: bench.py starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything touches the GPU) and relays rank 0's
+line; under the driver's own torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  The K-step timed pass
+(barrier + synchronize on both sides, max over ranks) is repeated R times (>= 1 s in total); `ms_per_step` / `value`
+are the MEDIAN pass, min / max are reported next to them.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel = the SpMV/SpMM product
+kernels, algorithmic bytes / per-launch HIP-event time, measured live in a second pass) and `cpu_baseline` (the
+single-threaded C restatement of the reference's iterative path, oracle/fps_oracle.c, on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch  # first: one HIP runtime per process (see fps_amd/_lib.py)
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-import fps_amd  # noqa: E402,F401
-from fps_amd import problems  # noqa: E402
-from fps_amd.device_qp import DeviceEqQP  # noqa: E402
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0    # same guide: measured copy ceiling
+F64_MFMA_PEAK_TF = 78.6  # dense fp64 matrix peak (vendor figure; SURVEY.md 8d)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-HBM_COPY_GBS = 6290.0  # same guide: measured copy ceiling
+WORKLOADS = ["pde-control-like n=1e6 m=1e5 nnz=1e7", "random-eqqp n=1e5 m=1e4 nnz=1e6", "aug2dc-like N=100",
+             "dense-block n=4096 m=2048"]
 
-WORKLOADS = {
-    # name: (generator, kwargs)
-    "pde-control-like n=1e6 m=1e5 nnz=1e7": (problems.pde_control_like, dict(n=1_000_000, m=100_000)),
-    "random-eqqp n=1e5 m=1e4 nnz=1e6": (problems.random_eqqp, dict(n=100_000, m=10_000)),
-}
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed K-step passes (0 = as many as make >= 1 s of timed work, 3..50); median reported")
+    ap.add_argument("--workload", default=WORKLOADS[0], choices=WORKLOADS)
+    ap.add_argument("--op", default="objgrad", choices=["objgrad", "hprod-solves", "hprod"],
+                    help="objgrad = the headline metric; hprod-solves = solve_two_least_squares (the two solves of every "
+                         "hprod!, solve_linear_system.jl:79-105) on distinct right-hand-side pairs; hprod = the whole "
+                         "device-resident hprod! Val(2) (model-Fletcherpenaltynlp.jl:521-570): SURVEY 8(f) rank 1")
+    ap.add_argument("--delta", type=float, default=None, help="regularisation; default 0 = first outer iteration "
+                    "(algo.jl:46); 1e-3 for the dense-block workload")
+    ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--lookahead", type=int, default=0, help="override fpsq_options.lookahead (0 = library default)")
+    ap.add_argument("--cpu-evals", type=int, default=6, help="evaluations timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--pointers", default="device", choices=["device", "host", "host+jac"],
+                    help="device: x / gx resident in HBM (the `value` of the contract).  host: x and gx are host arrays "
+                         "(PCIe inside the timed region: what a Julia caller holding host vectors gets).  host+jac: "
+                         "additionally hands over new Jacobian values (fpsq_set_jacobian_values, 8 nnz bytes) before "
+                         "every evaluation, like a host-resident NONLINEAR model (solve_linear_system.jl:223-228)")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "shard", "shard-allreduce", "replicas"],
+                    help="N > 1: 'shard' = rows of A sharded over the ranks in HALO layout (column-window n-vectors, "
+                         "neighbour exchange + 4-double all-reduces per Krylov iteration; falls back to replicated "
+                         "n-vectors + n x 2 all-reduce when the Jacobian is not banded); 'shard-allreduce' forces that "
+                         "fallback; 'replicas' = every rank evaluates its own points, no collective; 'auto' = halo "
+                         "sharding when it applies, else replicas")
+    ap.add_argument("--force-shard", action="store_true", default=False,
+                    help="rehearsal on one GPU: run the sharded code path (RCCL communicator of size 1)")
+    ap.add_argument("--no-roofline-pass", action="store_true", default=False,
+                    help="skip the second (per-launch HIP event) pass -- for runs under rocprofv3")
+    return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no rendezvous environment: start the ranks as a fresh child (never exec from a
+    process that may touch the GPU) and relay its output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def product_bytes(n, m, nnz, nrhs):
@@ -47,33 +93,181 @@ def product_bytes(n, m, nnz, nrhs):
     return a, at
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="pde-control-like n=1e6 m=1e5 nnz=1e7", choices=list(WORKLOADS))
-    ap.add_argument("--op", default="objgrad", choices=["objgrad", "hprod-solves", "hprod"],
-                    help="objgrad = the headline metric; hprod-solves = solve_two_least_squares (the two solves of every "
-                         "hprod!, solve_linear_system.jl:79-105) on distinct right-hand-side pairs; hprod = the whole "
-                         "device-resident hprod! Val(2) (model-Fletcherpenaltynlp.jl:521-570): SURVEY 8(f) rank 1")
-    ap.add_argument("--delta", type=float, default=0.0, help="regularisation; 0 = first outer iteration (algo.jl:46)")
-    ap.add_argument("--fuse", type=int, default=1)
-    ap.add_argument("--lookahead", type=int, default=0, help="override fpsq_options.lookahead (0 = library default)")
-    ap.add_argument("--cpu-evals", type=int, default=6, help="evaluations timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "shard", "replicas"],
-                    help="N > 1: 'shard' = rows of A sharded over the ranks, RCCL all-reduce per Krylov iteration "
-                         "(fixed total work: strong scaling); 'replicas' = every rank evaluates its own points; "
-                         "'auto' = shard only when the local product outweighs the all-reduce (DESIGN.md, Multi-GPU)")
-    ap.add_argument("--force-shard", action="store_true", default=False,
-                    help="rehearsal on one GPU: run the sharded code path (RCCL communicator of size 1)")
-    args = ap.parse_args()
+def make_workload(name):
+    from fps_amd import problems
 
+    if name.startswith("pde-control-like"):
+        return problems.pde_control_like(n=1_000_000, m=100_000)
+    if name.startswith("random-eqqp"):
+        return problems.random_eqqp(n=100_000, m=10_000)
+    if name.startswith("aug2dc-like"):
+        return problems.aug2dc_like(N=100)
+    return problems.dense_block(n=4096, m=2048)
+
+
+class Timer:
+    """K-step passes bracketed by barrier + torch.cuda.synchronize(); max over ranks; median over R repeats."""
+
+    def __init__(self, world, rehearse, dev):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.world, self.rehearse, self.dev = torch, dist, world, rehearse, dev
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def maxreduce(self, v):
+        if self.world > 1:
+            t = self.torch.tensor([v], dtype=self.torch.float64, device="cpu" if self.rehearse else self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
+
+    def run(self, step, W, K, repeats, collect=None):
+        for t in range(W):
+            step(t)
+        times = []
+        R = repeats if repeats > 0 else 1
+        r = 0
+        while r < R:
+            self.barrier()
+            t0 = time.perf_counter()
+            for t in range(W, W + K):
+                out = step(t)
+                if collect is not None and r == 0:
+                    collect(out)
+            self.barrier()
+            times.append(self.maxreduce(time.perf_counter() - t0))
+            if r == 0 and repeats <= 0:  # as many passes as make >= 1 s of timed work (same count on every rank)
+                R = int(min(50, max(3, np.ceil(1.0 / max(times[0], 1e-6)))))
+            r += 1
+        return np.array(times)
+
+
+def bench_dense(args, rank, world, local_rank, timer, dev):
+    """BASELINE configs[2]: dense-block Jacobian through the direct back-end (fp64 MFMA SYRK + blocked Cholesky + two
+    right-hand sides).  One step = new Jacobian values (resident in HBM) -> M = AA' + delta I -> factorisation ->
+    solve_two_mixed(g_t, c_t), the reference's LDLt `solve_two_mixed` (solve_linear_system.jl:206-252)."""
+    import ctypes as C
+
+    import torch
+    from fps_amd import _lib
+
+    qp = make_workload(args.workload)
+    n, m = qp.n, qp.m
+    delta = 1e-3 if args.delta is None else args.delta
+    lib = _lib.load()
+    d = C.c_void_p()
+    if lib.fpsq_dense_create(C.byref(d), n, m, local_rank) != 0:
+        raise SystemExit(lib.fpsq_dense_last_error(None).decode())
+    A = torch.from_numpy(qp.scipy_csr().toarray()).to(dev)
+    K, W = args.steps, args.warmup
+    As = qp.scipy_csr()
+    gs = torch.empty((K + W, n), dtype=torch.float64, device=dev)
+    cs = torch.empty((K + W, m), dtype=torch.float64, device=dev)
+    for t in range(K + W):
+        x = qp.point(1 + t + rank * (K + W))
+        gs[t].copy_(torch.from_numpy(qp.qdiag * x + qp.d))
+        cs[t].copy_(torch.from_numpy(As @ x - qp.b))
+    outs = [torch.empty(k, dtype=torch.float64, device=dev) for k in (n, m, n, m)]
+    info_i = C.c_int32()
+    tsum = np.zeros(3)
+
+    def step(t):
+        assert lib.fpsq_dense_set_jacobian(d, A.data_ptr()) == 0
+        rc = lib.fpsq_dense_factorize(d, delta, C.byref(info_i))
+        assert rc == 0, (rc, info_i.value)
+        assert lib.fpsq_dense_solve_two_mixed(d, gs[t].data_ptr(), cs[t].data_ptr(), *[o.data_ptr() for o in outs]) == 0
+        i = _lib.DenseInfo()
+        lib.fpsq_dense_get_info(d, C.byref(i))
+        return np.array([i.last_syrk_ms, i.last_chol_ms, i.last_solve_ms])
+
+    def collect(v):
+        tsum.__iadd__(v)
+
+    torch.cuda.synchronize()
+    times = timer.run(step, W, K, args.repeats, collect)
+    med = float(np.median(times))
+    # algorithmic flops of one step: SYRK m^2 n (lower triangle of the Gram matrix, 2 flops per multiply-add pair
+    # counted on half the entries), Cholesky m^3 / 3, two triangular solves x two right-hand sides 4 m^2,
+    # A g, A' q1, A' q2: 6 m n
+    flops = 1.0 * m * m * n + m ** 3 / 3.0 + 4.0 * m * m + 6.0 * m * n
+    dev_ms = tsum / K
+    tf = flops / (dev_ms.sum() * 1e-3) / 1e12
+    out = {"metric": "penalty grad-phi evals/sec", "value": round(K * world / med, 3), "unit": "evals/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * med / K, 4),
+           "ms_per_step_min": round(1e3 * times.min() / K, 4), "ms_per_step_max": round(1e3 * times.max() / K, 4),
+           "repeats": int(times.size), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": args.workload, "n": n, "m": m, "delta": delta,
+                      "path": "direct back-end: M = AA' + delta I (v_mfma_f64_16x16x4_f64), blocked Cholesky, 2 RHS; one "
+                              "step = Jacobian values + factorisation + solve_two_mixed (no user-model f/g/c)",
+                      "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(tf / F64_MFMA_PEAK_TF, 4), "traffic": None,
+                        "kernel": "fpsq dense SYRK + blocked Cholesky + triangular solves (device time of the three "
+                                  "phases, HIP events on the solver's stream)",
+                        "flops_per_step": flops,
+                        "device_ms": {"syrk": round(dev_ms[0], 4), "cholesky": round(dev_ms[1], 4),
+                                      "solve": round(dev_ms[2], 4)},
+                        "syrk_tflops": round(1.0 * m * m * n / (dev_ms[0] * 1e-3) / 1e12, 2),
+                        "cholesky_tflops": round(m ** 3 / 3.0 / (dev_ms[1] * 1e-3) / 1e12, 2)}}
+    if rank == 0 and world == 1 and args.cpu_evals > 0:
+        import scipy.linalg as sla
+
+        Ad = qp.scipy_csr().toarray()
+        t0 = time.perf_counter()
+        done = 0
+        for t in range(args.cpu_evals):
+            M = Ad @ Ad.T + delta * np.eye(m)
+            cf = sla.cho_factor(M, lower=True)
+            x = qp.point(1 + t)
+            g, c = qp.qdiag * x + qp.d, Ad @ x - qp.b
+            q1 = sla.cho_solve(cf, Ad @ g)
+            q2 = -sla.cho_solve(cf, c)
+            _ = (g - Ad.T @ q1, -Ad.T @ q2)
+            done += 1
+            if time.perf_counter() - t0 > 20.0:
+                break
+        dt = time.perf_counter() - t0
+        try:
+            from threadpoolctl import threadpool_info
+            nth = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:  # noqa: BLE001
+            nth = len(os.sched_getaffinity(0))
+        out["cpu_baseline"] = {"value": round(done / dt, 4), "unit": "evals/s", "cores": int(nth), "kind": "port",
+                               "sample": f"{done} steps of the same dense normal-equations path with numpy/scipy "
+                                         "(LAPACK dpotrf/dpotrs, BLAS dgemm) on the host: a stand-in for the "
+                                         "reference's LDLFactorizations.jl path, which cannot run here (no Julia)"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    lib.fpsq_dense_destroy(d)
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(self_launch(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 "(or without a torch.distributed environment, bench.py then starts its own ranks)")
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch  # first: one HIP runtime per process (see fps_amd/_lib.py)
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    import fps_amd  # noqa: F401
+    from fps_amd.device_qp import DeviceEqQP
+
     # FPSQ_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a one-GPU box (every rank on device 0, gloo for the
-    # barrier / max-over-ranks; only the replicas mode, which has no data-path collective)
+    # barrier / max-over-ranks; only the replicas mode: RCCL refuses two ranks on one device)
     rehearse = os.environ.get("FPSQ_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -84,168 +278,224 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    timer = Timer(world, rehearse, dev)
 
-    gen, kw = WORKLOADS[args.workload]
-    qp = gen(**kw)
+    if args.workload.startswith("dense-block"):
+        bench_dense(args, rank, world, local_rank, timer, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    qp = make_workload(args.workload)
     n, m, nnz = qp.n, qp.m, qp.nnz
     sigma, rho = 1e3, 1.0  # parameters.jl:71,75 (first outer iteration)
-    # Row sharding exchanges an n x 2 fp64 all-reduce per Krylov iteration (ring: 2 (P-1)/P * 16 n bytes over one
-    # ~50 GB/s xGMI link direction) against a local product of 12 nnz / P bytes at ~5 TB/s: it pays only when
-    # nnz / n >~ 130 P.  The headline (nnz / n = 10) is far below that at every P, so 'auto' runs replicas.
-    shard_pays = (12.0 * nnz / max(world, 1)) / 5e12 > (2.0 * 16.0 * n) / 50e9
-    want_shard = args.parallel == "shard" or (args.parallel == "auto" and shard_pays)
-    sharded = (world > 1 or args.force_shard) and want_shard
-    if sharded:
-        from fps_amd.device_qp import rccl_unique_id
-        from fps_amd.distributed import row_partition, shard_qp
+    delta = 0.0 if args.delta is None else args.delta
+    extra = {"lookahead": args.lookahead} if args.lookahead > 0 else {}
+
+    # ---- how the N ranks share the work
+    plan = None
+    layout = "single"
+    if world > 1 or args.force_shard:
+        from fps_amd.distributed import halo_plan, row_partition, shard_qp, shard_qp_halo
 
         bounds = row_partition(qp.rowptr, world)
-        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            ident.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
-        if world > 1:
-            dist.broadcast(ident, src=0)
-        local = shard_qp(qp, int(bounds[rank]), int(bounds[rank + 1]))
-        model = DeviceEqQP(local, sigma=sigma, rho=rho, delta=args.delta, device=local_rank,
-                           fuse_two_rhs=args.fuse, comm=("rccl", world, rank, bytes(ident.cpu().numpy())))
-    else:
-        extra = {"lookahead": args.lookahead} if args.lookahead > 0 else {}
-        model = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=args.delta, device=local_rank, fuse_two_rhs=args.fuse, **extra)
+        if args.parallel in ("auto", "shard"):
+            plan = halo_plan(qp.rowptr, qp.colind, n, bounds)
+        if plan is not None:
+            layout = "halo"
+        elif args.parallel in ("shard", "shard-allreduce") or args.force_shard:
+            layout = "allreduce"
+        else:
+            layout = "replicas"  # auto without a banded Jacobian, or asked for
+        if args.parallel == "replicas" and not args.force_shard:
+            layout = "replicas"
+    sharded = layout in ("halo", "allreduce")
+    if sharded and rehearse:
+        sys.exit("bench.py: FPSQ_BENCH_REHEARSE runs every rank on one device; RCCL needs one device per rank -- use "
+                 "--parallel replicas (or tests/test_gpu_parity.py's in-process loopback shards)")
+    if sharded and args.pointers != "device":
+        sys.exit("bench.py: --pointers host: single GPU or replicas only")
 
-    # distinct evaluation points, resident in HBM (sharded: the same replicated x on every rank; replicas: each
-    # rank evaluates its own sequence)
+    def build_model(kind):
+        if kind in ("halo", "allreduce"):
+            from fps_amd.device_qp import rccl_unique_id
+
+            ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                ident.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(ident, src=0)
+            comm = ("rccl", world, rank, bytes(ident.cpu().numpy()))
+            if kind == "halo":
+                loc = shard_qp_halo(qp, plan, rank)
+                return loc, DeviceEqQP(loc, sigma=sigma, rho=rho, delta=delta, device=local_rank,
+                                       fuse_two_rhs=args.fuse, comm=comm, halo=plan.overlaps(rank), **extra)
+            loc = shard_qp(qp, int(bounds[rank]), int(bounds[rank + 1]))
+            return loc, DeviceEqQP(loc, sigma=sigma, rho=rho, delta=delta, device=local_rank, fuse_two_rhs=args.fuse,
+                                   comm=comm, **extra)
+        return qp, DeviceEqQP(qp, sigma=sigma, rho=rho, delta=delta, device=local_rank, fuse_two_rhs=args.fuse, **extra)
+
+    local, model = build_model(layout)
+    n_loc = local.n  # window length in halo layout, n otherwise
+
+    # distinct evaluation points, resident in HBM (sharded: every rank holds its window of the SAME points; replicas:
+    # each rank evaluates its own sequence)
     K, W = args.steps, args.warmup
-    xs = torch.empty((K + W, n), dtype=torch.float64, device=dev)
-    for t in range(K + W):
-        xs[t].copy_(torch.from_numpy(qp.point(1 + t + (0 if sharded else rank) * (K + W))))
-    gx = torch.empty(n, dtype=torch.float64, device=dev)
+    host_ptr = args.pointers != "device"
+    win = plan.window(rank) if layout == "halo" else slice(0, n)
+
+    def points(off, length=None):
+        arr = np.empty((K + W, n_loc if length is None else length))
+        for t in range(K + W):
+            arr[t] = qp.point(1 + t + off)[win if length is None else slice(0, length)]
+        return arr
+
+    xs_h = points(0 if sharded else rank * (K + W))
+    xs = xs_h if host_ptr else torch.from_numpy(xs_h).to(dev)
+    gx = np.empty(n_loc) if host_ptr else torch.empty(n_loc, dtype=torch.float64, device=dev)
     hp = args.op in ("hprod-solves", "hprod")
     hfull = args.op == "hprod"
     if hp:  # the points double as right-hand sides: (xs[t], xs[t] reversed) are the two n-vectors of step t
-        if sharded:
-            raise SystemExit("--op hprod-solves: single GPU or replicas only")
+        if sharded or host_ptr:
+            raise SystemExit("--op hprod-solves / hprod: device pointers, single GPU or replicas only")
         xr = torch.flip(xs, dims=[1]).contiguous()
         hp_out = [torch.empty(k, dtype=torch.float64, device=dev) for k in (n, m, n, m)]
+    jac_vals = np.ascontiguousarray(qp.vals) if args.pointers == "host+jac" else None
     torch.cuda.synchronize()
 
-    def step(t):
-        if hfull:
-            return None, model.hprod(xs[t], hp_out[0])
-        if hp:
-            return None, model.solve_two_least_squares(xs[t], xr[t], *hp_out)
-        return model.objgrad(xs[t], gx=gx)
+    def make_step(mdl, pts, out):
+        def step(t):
+            if hfull:
+                return None, mdl.hprod(pts[t], hp_out[0])
+            if hp:
+                return None, mdl.solve_two_least_squares(pts[t], xr[t], *hp_out)
+            if jac_vals is not None:
+                mdl._check(mdl._lib.fpsq_set_jacobian_values(mdl._h, jac_vals.ctypes.data))
+            return mdl.objgrad(pts[t], gx=out)
+        return step
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    step = make_step(model, xs, gx)
+    its, soft = [], [0]
 
-    its = []
-    for t in range(W):
-        step(t)
-    barrier()
-    t0 = time.perf_counter()
-    soft = 0
-    for t in range(W, W + K):
-        _, rc = step(t)
-        soft |= rc
+    def collect(out):
+        soft[0] |= out[1]
         its.append((model.stats[0].niter, model.stats[1].niter))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+
+    times = timer.run(step, W, K, args.repeats, collect)
+    med = float(np.median(times))
     evals = K if sharded else K * world  # sharded: all ranks work on the same K evaluations
-    value = evals / elapsed
+    value = evals / med
 
     # ---- roofline of the dominant kernel: a second pass over the same K points with per-launch HIP events
-    model.set_profiling(True)
-    pa, pat, t_ms, tot_ms = np.zeros(2), np.zeros(2), 0.0, 0.0
-    for t in range(W, W + K):
-        step(t)
-        info = model.info()
-        pa += info["last_prod_a"]
-        pat += info["last_prod_at"]
-        t_ms += info["last_spmv_ms"]
-        tot_ms += info["last_solve_ms"]
-    model.set_profiling(False)
-    # Algorithmic bytes of the PRODUCTIVE product launches only: with J = max(LSQR, CRAIG iterations)
-    # an evaluation runs J two-RHS A' products, J + 1 two-RHS A products (the +1 is LSQR's start-up B'u), c = Ax - b
-    # with one right-hand side (A), and p1 = g - A'q1 with rho A'c (A': one raw two-RHS product on a single GPU).  Launches enqueued past convergence (host
-    # run-ahead) exit at once: they count in the time, not in the bytes.  Unfused runs: 2 single-RHS products per
-    # iteration of each solver.
-    m_loc, nnz_loc = (local.m, local.nnz) if sharded else (m, nnz)
-    a1, at1 = product_bytes(n, m_loc, nnz_loc, 1)
-    a2, at2 = product_bytes(n, m_loc, nnz_loc, 2)
-    nbytes = 0.0
-    productive = 0
-    # Vector updates riding in the product launches (single GPU, fused run): LSQR's x/w update of the previous
-    # iteration in the A' launch (read v, w, x; write w, x: 5 m-passes), CRAIG's in the A launch (read v, x; write x:
-    # 3 n-passes, +2 for w2 when delta != 0; read u, w, y; write w, y: 5 m-passes).
-    upd_at = 0 if sharded else 8 * 5 * m
-    upd_a = 0 if sharded else 8 * ((3 if args.delta == 0.0 else 5) * n + 5 * m)
-    for il, ic in its:
-        if hp:  # two LSQR recurrences: J two-RHS A' products (both x/w updates riding), J + 1 two-RHS A products,
-            J = max(il, ic)  # then p_k = rhs_k - A'q_k with one right-hand side each
-            nbytes += J * at2 + (J + 1) * a2 + 2 * at1 + (max(il - 1, 0) + max(ic - 1, 0)) * upd_at
-            productive += 2 * J + 3
-            if hfull and rho > 0.0:  # rho A'(A v): one more single-RHS product of each kind
-                nbytes += a1 + at1
-                productive += 2
-        elif args.fuse:
-            J = max(il, ic)
-            if sharded:  # c = Ax - b, then p1 = g - A'q1 and rho A'c as two single-RHS products
-                nbytes += J * at2 + (J + 1) * a2 + a1 + 2 * at1
-                productive += 2 * J + 4
-            else:        # single GPU: c = Ax - b rides in the CRAIG lane of LSQR's start-up A product, and the last
-                         # two share one raw two-RHS product A'[q1, c] (no yin read)
-                nbytes += J * at2 + (J + 1) * a2 + (at2 - 8 * 2 * n)
-                productive += 2 * J + 2
-            nbytes += max(il - 1, 0) * upd_at + ic * upd_a
-        else:
-            nbytes += (il + ic) * (a1 + at1) + a1 + a1 + 2 * at1
-            productive += 2 * (il + ic) + 4
-    launches = int(pa.sum() + pat.sum())
-    achieved = nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "fpsq::k_spmv_rgcs (A) + fpsq::k_spmv (A'): SpMV/SpMM with fused axpby + norm partials + riding vector updates",
-                "productive_launches_per_eval": productive / K, "launches_per_eval": launches / K,
-                "avg_launch_us": round(1e3 * t_ms / max(launches, 1), 2),
-                "avg_productive_launch_us": round(1e3 * t_ms / max(productive, 1), 2),
-                "algorithmic_bytes_per_productive_launch": round(nbytes / max(productive, 1)),
-                "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
-                "spmv_share_of_eval_time": round(t_ms / tot_ms, 3) if tot_ms > 0 else None}
+    roofline = None
+    if not args.no_roofline_pass:
+        model.set_profiling(True)
+        pa, pat, t_ms, tot_ms = np.zeros(2), np.zeros(2), 0.0, 0.0
+        for t in range(W, W + K):
+            step(t)
+            info = model.info()
+            pa += info["last_prod_a"]
+            pat += info["last_prod_at"]
+            t_ms += info["last_spmv_ms"]
+            tot_ms += info["last_solve_ms"]
+        model.set_profiling(False)
+        # Algorithmic bytes of the PRODUCTIVE product launches only: with J = max(LSQR, CRAIG
+        # iterations) an evaluation runs J two-RHS A' products, J + 1 two-RHS A products (the +1 is LSQR's start-up B'u),
+        # c = Ax - b with one right-hand side (A), and p1 = g - A'q1 with rho A'c (A': one raw two-RHS product on a single
+        # GPU).  Launches enqueued past convergence (host run-ahead) exit at once: they count in the time, not in the
+        # bytes.  Unfused runs: 2 single-RHS products per iteration of each solver.
+        m_loc, nnz_loc = local.m, local.nnz
+        a1, at1 = product_bytes(n_loc, m_loc, nnz_loc, 1)
+        a2, at2 = product_bytes(n_loc, m_loc, nnz_loc, 2)
+        nbytes, productive = 0.0, 0
+        # Vector updates riding in the product launches (single GPU, fused run): LSQR's x/w update of the previous
+        # iteration in the A' launch (read v, w, x; write w, x: 5 m-passes), CRAIG's in the A launch (read v, x; write x:
+        # 3 n-passes, +2 for w2 when delta != 0; read u, w, y; write w, y: 5 m-passes).
+        upd_at = 0 if sharded else 8 * 5 * m
+        upd_a = 0 if sharded else 8 * ((3 if delta == 0.0 else 5) * n + 5 * m)
+        for il, ic in its:
+            if hp:  # two LSQR recurrences: J two-RHS A' products (both x/w updates riding), J + 1 two-RHS A products,
+                J = max(il, ic)  # then p_k = rhs_k - A'q_k with one right-hand side each
+                nbytes += J * at2 + (J + 1) * a2 + 2 * at1 + (max(il - 1, 0) + max(ic - 1, 0)) * upd_at
+                productive += 2 * J + 3
+                if hfull and rho > 0.0:  # rho A'(A v): one more single-RHS product of each kind
+                    nbytes += a1 + at1
+                    productive += 2
+            elif args.fuse:
+                J = max(il, ic)
+                if sharded:  # c = Ax - b, then p1 = g - A'q1 and rho A'c as two single-RHS products
+                    nbytes += J * at2 + (J + 1) * a2 + a1 + 2 * at1
+                    productive += 2 * J + 4
+                else:        # single GPU: c = Ax - b rides in the CRAIG lane of LSQR's start-up A product, and the
+                             # last two share one raw two-RHS product A'[q1, c] (no yin read)
+                    nbytes += J * at2 + (J + 1) * a2 + (at2 - 8 * 2 * n)
+                    productive += 2 * J + 2
+                nbytes += max(il - 1, 0) * upd_at + ic * upd_a
+            else:
+                nbytes += (il + ic) * (a1 + at1) + a1 + a1 + 2 * at1
+                productive += 2 * (il + ic) + 4
+        launches = int(pa.sum() + pat.sum())
+        achieved = nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "fpsq::k_spmv_rgcs (A) + fpsq::k_spmv (A'): SpMV/SpMM with fused axpby + norm partials + "
+                              "riding vector updates",
+                    "productive_launches_per_eval": productive / K, "launches_per_eval": launches / K,
+                    "avg_launch_us": round(1e3 * t_ms / max(launches, 1), 2),
+                    "avg_productive_launch_us": round(1e3 * t_ms / max(productive, 1), 2),
+                    "algorithmic_bytes_per_productive_launch": round(nbytes / max(productive, 1)),
+                    "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+                    "spmv_share_of_eval_time": round(t_ms / tot_ms, 3) if tot_ms > 0 else None,
+                    "whole_eval_frac_of_peak": round(nbytes / K / (med / K) / 1e9 / HBM_PEAK_GBS, 4) if not sharded else None}
+        # HBM traffic per productive launch: PMC counters cannot be read from inside the run (rocprofv3 writes them when
+        # the process ends); the number below is from the COMMITTED profile of this same command, labelled as such
+        for prof in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1 and not hp \
+                        and not host_ptr:
+                    roofline["traffic"] = pmc["traffic_bytes_per_productive_launch"]
+                    roofline["traffic_source"] = (f"committed profile profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / "
+                                                  "WRITE_SIZE passes of this command; not measured in this run)")
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
 
-    # HBM traffic per productive launch from the committed PMC passes (profiles/: bench.py cannot run rocprofv3 on itself)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1 and not hp:
-            roofline["traffic"] = pmc["traffic_bytes_per_productive_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-    except (OSError, KeyError, ValueError):
-        pass
-
+    par = {"single": "single GPU",
+           "halo": f"rows of A sharded over {world} GPUs, HALO layout: each rank holds its column window of the n-vectors, "
+                   f"RCCL send/recv of the A'u overlap regions with its neighbours (<= {plan.max_exchange_doubles() if plan else 0} "
+                   "doubles per rank and iteration) + two 4-double all-reduces per Krylov iteration",
+           "allreduce": f"rows of A sharded over {world} GPUs, replicated n-vectors: RCCL all-reduce of the partial A'u "
+                        "products (n x 2 fp64) and of the m-vector norm partials every Krylov iteration",
+           "replicas": f"{world} independent replicas (each rank evaluates its own points), no data-path collective"}[layout]
     out = {
         "metric": "penalty hprod! (Val(2)) evals/sec" if hfull
         else "solve_two_least_squares calls/sec (the two KKT solves of one hprod!)" if hp
         else "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "calls/s" if hp else "evals/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 4),
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * med / K, 4),
+        "ms_per_step_min": round(1e3 * times.min() / K, 4), "ms_per_step_max": round(1e3 * times.max() / K, 4),
+        "repeats": int(times.size),
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "m": m, "nnz": nnz, "sigma": sigma, "rho": rho,
-                   "delta": args.delta, "fuse_two_rhs": args.fuse,
+                   "delta": delta, "fuse_two_rhs": args.fuse, "pointers": args.pointers,
                    "krylov": ("LSQR+LSQR" if hp else "LSQR+CRAIG") + ", atol=rtol=sqrt(eps) (reference defaults)",
                    "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
-                   "all_solved": soft == 0,
-                   "parallelism": "single GPU" if world == 1 else
-                   (f"rows of A sharded over {world} GPUs, RCCL all-reduce of the partial A'u products (n x 2 fp64) and "
-                    "of the m-vector norm partials every Krylov iteration" if sharded else
-                    f"{world} independent replicas (each rank evaluates its own points), no data-path collective; row "
-                    "sharding (--parallel shard) is implemented but communication-bound at nnz/n = 10")},
+                   "all_solved": soft[0] == 0, "parallelism": par},
         "roofline": roofline,
     }
+
+    # ---- N > 1, sharded: the same ranks as independent replicas, for the record (a second number, not `value`)
+    if sharded and world > 1 and not hp:
+        model.close()
+        _, rep = build_model("replicas")
+        xs2 = torch.from_numpy(points(rank * (K + W), n)).to(dev)
+        gx2 = torch.empty(n, dtype=torch.float64, device=dev)
+        t2 = timer.run(make_step(rep, xs2, gx2), W, K, 3)
+        out["replicas_alternative"] = {"value": round(K * world / float(np.median(t2)), 3), "unit": "evals/s",
+                                       "scaling": "weak", "note": "same ranks, each evaluating its own points with the "
+                                       "whole Jacobian, no collective"}
+        model = rep
 
     # ---- CPU baseline: the C restatement of the reference's iterative path, one thread, bounded sample
     if rank == 0 and world == 1 and args.cpu_evals > 0:
@@ -257,10 +507,10 @@ def main():
         for t in range(args.cpu_evals):
             if hp:  # (hprod: the solves are all of its CPU cost but two products and three vector passes)
                 r1 = qp.point(1 + W + t)
-                oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, args.delta, r1,
+                oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, delta, r1,
                                                np.ascontiguousarray(r1[::-1]) if not hfull else qp.qdiag * r1)
             else:
-                oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, args.delta)
+                oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, delta)
             done += 1
             if time.perf_counter() - t0 > 30.0:
                 break
@@ -279,10 +529,10 @@ def main():
             for t in range(args.cpu_evals):
                 if hp:
                     r1 = qp.point(1 + W + t)
-                    oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, args.delta, r1,
+                    oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, delta, r1,
                                                    np.ascontiguousarray(r1[::-1]), threaded=True)
                 else:
-                    oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, args.delta, threaded=True)
+                    oracle.qp_objgrad(qp, qp.point(1 + W + t), sigma, rho, delta, threaded=True)
                 done2 += 1
                 if time.perf_counter() - t0 > 15.0:
                     break
