@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -275,6 +276,10 @@ struct fpsq_solver_s {
   fpsq_stats* hstats_dev = nullptr;
   double* hscal = nullptr;        // host-mapped: scalar results (phi, f, c'c) written by the kernel that computes them
   double* hscal_dev = nullptr;
+  // Speculative epilogue (run_krylov): kernels launched while gate0 is set only act once BOTH lane controls say `done`.
+  const LaneCtl* gate0 = nullptr;
+  const LaneCtl* gate1 = nullptr;
+  bool tail_was_run = false;   // the caller's epilogue was enqueued (gated) inside run_krylov and the gates were open
   int64_t expect_iters[3][3] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
   bool adaptive_runahead = true;    // FPSQ_ADAPTIVE_RUNAHEAD=0 disables (A/B)
 
@@ -283,6 +288,7 @@ struct fpsq_solver_s {
   std::vector<EventPair> ev_pool;
   size_t ev_used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::chrono::steady_clock::time_point t_call;
   fpsq_info info{};
   int64_t launches = 0, spmv_launches = 0;
   int64_t prod_a[2] = {0, 0}, prod_at[2] = {0, 0};
@@ -687,26 +693,26 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     const int per_xcd = (h->RA.view.ng + 7) / 8;
     if (h->RA.view.stride)
       launch_product(h, k_spmv_rgcs<NL, true>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd,
-                     u0, u1);
+                     u0, u1, h->gate0, h->gate1);
     else
       launch_product(h, k_spmv_rgcs<NL, false>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials,
-                     per_xcd, u0, u1);
+                     per_xcd, u0, u1, h->gate0, h->gate1);
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
     const dim3 grid(per_xcd * 8 + nupd);
     if (tag == TAG_A && M.col16)
-      launch_product(h, k_spmv<NL, TAG_A, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_A, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
     else if (tag == TAG_A)
-      launch_product(h, k_spmv<NL, TAG_A, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_A, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
     else if (M.col16 && M.padded)
-      launch_product(h, k_spmv<NL, TAG_AT, true, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_AT, true, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
     else if (M.col16)
-      launch_product(h, k_spmv<NL, TAG_AT, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_AT, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
     else if (M.padded)
-      launch_product(h, k_spmv<NL, TAG_AT, false, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_AT, false, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
     else
-      launch_product(h, k_spmv<NL, TAG_AT, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1);
+      launch_product(h, k_spmv<NL, TAG_AT, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
   }
   h->launches++;
   h->spmv_launches++;
@@ -833,6 +839,7 @@ int wait_progress(fpsq_handle h, int lane, int target, const int32_t* dev_done, 
 struct LsqrParams {
   double lambda, atol, rtol, axtol, btol, etol, conlim;
   int64_t itmax;
+  int32_t pub_from;
 };
 
 __device__ __forceinline__ void lsqr_set_params(LsqrState* S, const LsqrParams& P) {
@@ -844,6 +851,7 @@ __device__ __forceinline__ void lsqr_set_params(LsqrState* S, const LsqrParams& 
   S->etol = P.etol;
   S->ctol = P.conlim > 0.0 ? 1.0 / P.conlim : 0.0;
   S->itmax = P.itmax;
+  S->pub_from = P.pub_from;
   S->ctl.done = 0;
   S->ctl.skip = 0;
   S->ctl.upd_iter = -1;
@@ -853,6 +861,7 @@ struct CraigParams {
   double mu, lambda, atol, rtol, btol, conlim, xsign;
   int64_t itmax;
   int32_t start_skipped;
+  int32_t pub_from;
 };
 
 __device__ __forceinline__ void craig_set_params(CraigState* S, const CraigParams& P) {
@@ -864,6 +873,7 @@ __device__ __forceinline__ void craig_set_params(CraigState* S, const CraigParam
   S->ctol = P.conlim > 0.0 ? 1.0 / P.conlim : 0.0;
   S->xsign = P.xsign;
   S->itmax = P.itmax;
+  S->pub_from = P.pub_from;
   S->ctl.done = 0;
   S->ctl.skip = P.start_skipped;  // stays out of the LSQR lane's start-up product; craig_begin clears it
   S->ctl.upd_iter = -1;
@@ -1015,9 +1025,17 @@ void launch_updates(fpsq_handle h, const UpdSeg& s0, const UpdSeg& s1, const Upd
 //   A  product: SP <- ca A  LP + cb SP      (LSQR: v~ <- B'u - beta v;      CRAIG: Mu~ <- B v - alpha Mu)
 // Each lane is exactly Krylov.jl's lsqr! / craig! on its own right-hand side (its results do not depend on the
 // other lane); running them side by side turns two SpMVs into one SpMM with k = 2.
+// `tail` (optional, single GPU): enqueues the caller's epilogue kernels.  When the iteration count of the previous call
+// of the same kind is known, the final LSQR flush and the tail are enqueued SPECULATIVELY right behind iteration
+// `expect`, gated on the lanes' `done` flags (h->gate0/1): if the recurrences do end there -- consecutive evaluations of
+// a line search mostly repeat their counts -- the epilogue runs without the host first having to see `done` and only
+// then launching it (a ~30 us bubble per evaluation); if not, the gated kernels exit at once and the loop goes on.
+// h->tail_was_run tells the caller whether its epilogue has been taken care of.
+using TailFn = std::function<int()>;
 template <int NL>
-int run_krylov(fpsq_handle h, Lane* lanes) {
+int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   const int64_t n = h->n, m = h->m;
+  h->tail_was_run = false;
   const fpsq_options& o = h->opt;
   hipStream_t s = h->stream;
   const int gn = ew_grid(n), gm = ew_grid(m);
@@ -1028,6 +1046,11 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   int64_t itmax_all = 0;
   Progress* prog[2];
   int nlsqr = 0;
+  // iteration count of the previous run with the same pair of recurrences (0: unknown).  The scalar steps publish their
+  // progress to the host only from that iteration on (and when a recurrence ends): see publish().
+  int64_t* expect_slot = &h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
+  const int64_t expect = (h->adaptive_runahead && !h->comm) ? *expect_slot : 0;
+  const int32_t pub_from = (int32_t)std::min<int64_t>(expect, INT32_MAX);
   LsqrState* lsS[2] = {nullptr, nullptr};
   LsqrParams lsP[2] = {};
   CraigState* crS = nullptr;
@@ -1045,7 +1068,8 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       L.state = S;
       L.ctl = &S->ctl;
       L.itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
-      lsP[nlsqr - 1] = LsqrParams{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax};
+      lsP[nlsqr - 1] = LsqrParams{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax,
+                                  pub_from};
       lsS[nlsqr - 1] = S;
     } else {
       CraigState* S = h->craig;
@@ -1054,7 +1078,7 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       L.itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
       const bool reg = L.delta != 0.0;
       crP = CraigParams{reg ? 1.0 / L.delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim,
-                        L.xsign, L.itmax, NL == 2 ? 1 : 0};
+                        L.xsign, L.itmax, NL == 2 ? 1 : 0, pub_from};
       crS = S;
     }
     itmax_all = std::max(itmax_all, L.itmax);
@@ -1189,10 +1213,8 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
   double* SPcur = SP;
   double* SPalt = h->SP2;
   const int look = std::max(1, o.lookahead);
-  // iteration count of the previous run with the same pair of recurrences (0: unknown)
-  int64_t* expect_slot = &h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
-  const int64_t expect = h->adaptive_runahead ? *expect_slot : 0;
   int64_t it = 0;
+  int64_t spec_it = -1;  // iteration behind which the gated flush + tail were enqueued
   auto lsqr_upd_seg = [&](int l, int64_t it_of_update) {
     UpdSeg u{};
     u.kind = UPD_LSQR;
@@ -1291,11 +1313,13 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
       continue;
     }
     if (all_done()) break;
+    // before the expected count the steps publish nothing (but the end of a recurrence): enqueue on
+    if (it < expect) continue;
     // bound the run-ahead of the host on the slowest unfinished lane
     int slow = INT32_MAX;
     for (int l = 0; l < NL; ++l)
       if (!h->prog_host[l].done) slow = std::min(slow, (int)h->prog_host[l].iter);
-    if (it - slow >= look) {
+    if (it > expect && it - slow >= look) {
       for (int l = 0; l < NL; ++l) {
         if (h->prog_host[l].done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
@@ -1310,6 +1334,22 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     // `expect`.  When the count repeats, no launch is enqueued past convergence (each costs ~3.5 us of GPU time even
     // though it exits at once: ~50 us per evaluation at lookahead 4); when it does not, this is one short bubble.
     if (expect > 0 && it == expect) {
+      if (tail != nullptr && fuse_upd) {
+        UpdSeg seg[2] = {seg_none(), seg_none()};
+        int ns = 0;
+        for (int l = 0; l < NL; ++l)
+          if (lanes[l].kind == LANE_LSQR) {
+            seg[ns] = lsqr_upd_seg(l, it);
+            seg[ns++].gate = lanes[NL - 1 - l].ctl;  // the other lane of the call (NL = 1: itself)
+          }
+        launch_updates<NL>(h, seg[0], seg[1], seg_none());
+        h->gate0 = lanes[0].ctl;
+        h->gate1 = lanes[NL - 1].ctl;
+        const int rc = (*tail)();
+        h->gate0 = h->gate1 = nullptr;
+        if (rc) return rc;
+        spec_it = it;
+      }
       for (int l = 0; l < NL; ++l) {
         if (h->prog_host[l].done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
@@ -1324,6 +1364,12 @@ int run_krylov(fpsq_handle h, Lane* lanes) {
     int64_t e = 0;
     for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter);
     *expect_slot = e;
+  }
+  if (spec_it >= 0 && spec_it == it && all_done()) {
+    // every recurrence ended at or before the iteration the speculative flush + tail were enqueued behind: their gates
+    // were open, the call's epilogue is already in the stream
+    h->tail_was_run = true;
+    return 0;
   }
   // the last LSQR update (iteration `it`) has not been enqueued yet
   {
@@ -1418,8 +1464,9 @@ int run_minres(fpsq_handle h, const double* b, double lambda, fpsq_stats* st_out
   return 0;
 }
 
-int run_lanes(fpsq_handle h, Lane* lanes, int nlanes) {
-  if (nlanes == 2 && h->opt.fuse_two_rhs) return run_krylov<2>(h, lanes);
+int run_lanes(fpsq_handle h, Lane* lanes, int nlanes, const TailFn* tail = nullptr) {
+  h->tail_was_run = false;
+  if (nlanes == 2 && h->opt.fuse_two_rhs) return run_krylov<2>(h, lanes, h->comm ? nullptr : tail);
   for (int l = 0; l < nlanes; ++l)
     if (int rc = run_krylov<1>(h, lanes + l)) return rc;
   return 0;
@@ -1447,14 +1494,18 @@ void call_begin(fpsq_handle h) {
   h->spmv_launches = 0;
   h->prod_a[0] = h->prod_a[1] = h->prod_at[0] = h->prod_at[1] = 0;
   h->ev_used = 0;
-  hipEventRecord(h->ev0, h->stream);
+  // device-side timing of the whole call only when profiling is on: an event record is a marker packet the GPU has to
+  // process (a few us each); otherwise last_solve_ms is the host's wall time of the call
+  if (h->profile) hipEventRecord(h->ev0, h->stream);
+  h->t_call = std::chrono::steady_clock::now();
 }
 
 int call_end(fpsq_handle h) {
-  hipEventRecord(h->ev1, h->stream);
+  if (h->profile) hipEventRecord(h->ev1, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0.f;
-  hipEventElapsedTime(&ms, h->ev0, h->ev1);
+  if (h->profile) hipEventElapsedTime(&ms, h->ev0, h->ev1);
+  else ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->t_call).count();
   h->info.last_solve_ms = ms;
   h->info.last_kernel_launches = h->launches;
   h->info.last_spmv_launches = h->spmv_launches;
@@ -1489,7 +1540,7 @@ int soft_rc(const fpsq_stats st[2]) { return (st[0].solved ? 0 : 1) | (st[1].sol
 // affine_shift != null (fast start): c is NOT formed yet; CRAIG's right-hand side -(A z - shift), z in the long pair's
 // CRAIG lane, comes out of the LSQR start-up product and A z - shift is left in `c` (see run_krylov)
 int two_mixed_device(fpsq_handle h, const double* g, double* c, bool defer_p1 = false,
-                     const double* affine_shift = nullptr) {
+                     const double* affine_shift = nullptr, const TailFn* tail = nullptr) {
   Lane lanes[2];
   // (q1, stats1) = solve_least_square(qds, Aop', rhs1, sqrt(delta))      src/solve_linear_system.jl:123
   lanes[0].kind = LANE_LSQR;
@@ -1511,15 +1562,20 @@ int two_mixed_device(fpsq_handle h, const double* g, double* c, bool defer_p1 = 
   lanes[1].x = h->Cx;
   lanes[1].y = h->Cy;
   lanes[1].st = &h->hstats[1];
-  if (int rc = run_lanes(h, lanes, 2)) return rc;
   // p1 = rhs1 - Aop' q1                                                   :126-127
-  if (!defer_p1)
-    if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, g, h->p1)) return rc;
+  TailFn full = [&]() -> int {
+    if (!defer_p1)
+      if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, g, h->p1)) return rc;
+    return tail ? (*tail)() : 0;
+  };
+  if (int rc = run_lanes(h, lanes, 2, tail ? &full : nullptr)) return rc;
+  if (!h->tail_was_run)
+    if (int rc = full()) return rc;
   return 0;
 }
 
 // device-side solve_two_least_squares: results in h->p1, h->Lx[0], h->p2b, h->Lx[1]
-int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2) {
+int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2, const TailFn* tail = nullptr) {
   Lane lanes[2];
   const double* rhs[2] = {r1, r2};
   for (int l = 0; l < 2; ++l) {
@@ -1529,10 +1585,15 @@ int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2) 
     lanes[l].x = h->Lx[l];
     lanes[l].st = &h->hstats[l];
   }
-  if (int rc = run_lanes(h, lanes, 2)) return rc;
   // src/solve_linear_system.jl:90-91 and :99-100
-  if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, r1, h->p1)) return rc;
-  if (int rc = at_product_const(h, -1.0, h->Lx[1], 1.0, r2, h->p2b)) return rc;
+  TailFn full = [&]() -> int {
+    if (int rc = at_product_const(h, -1.0, h->Lx[0], 1.0, r1, h->p1)) return rc;
+    if (int rc = at_product_const(h, -1.0, h->Lx[1], 1.0, r2, h->p2b)) return rc;
+    return tail ? (*tail)() : 0;
+  };
+  if (int rc = run_lanes(h, lanes, 2, tail ? &full : nullptr)) return rc;
+  if (!h->tail_was_run)
+    if (int rc = full()) return rc;
   return 0;
 }
 
@@ -1926,7 +1987,8 @@ int fpsq_ys_gs(fpsq_handle h, const double* g, const double* c, double sigma, do
   // src/model-Fletcherpenaltynlp.jl:244-248
   hipLaunchKernelGGL(k_gs, dim3(ew_grid(h->n)), dim3(kBlock), 0, s, h->p1, h->Cx, sigma, h->gs, h->n);
   hipLaunchKernelGGL(k_ys, dim3(ew_grid(h->m)), dim3(kBlock), 0, s, h->Lx[0], h->Cy, (const double*)nullptr, sigma, h->ys,
-                     h->m, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+                     h->m, (double*)nullptr, (double*)nullptr, (double*)nullptr, (const LaneCtl*)nullptr,
+                     (const LaneCtl*)nullptr);
   h->launches += 2;
   HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
@@ -2036,61 +2098,69 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   // Single GPU with rho > 0: p1 = g - A'q1 and J'c (:424-428) share ONE two-right-hand-side product A'[q1, c], and
   // phi is reduced by an extra workgroup of the gradient kernel: 2 launches fewer at the end of every evaluation.
   const bool paired = !h->comm && rho > 0.0;
-  if (int rc = two_mixed_device(h, h->g, h->c, paired, fast ? qp->b : nullptr)) return rc;
-  // ys = q1 + sigma q2 and the dots of objgrad!
-  hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax,
-                     paired ? h->SP : (double*)nullptr);
-  h->launches++;
-  FxArgs fa{};
-  fa.pf = h->pQ[0];
-  fa.pdx = h->pQ[1];
-  fa.np_n = gn;
-  fa.pcy = h->pE;
-  fa.pcc = h->pE + kEwBlocksMax;
-  fa.np_m = gm;
-  fa.rho = rho;
-  fa.eta = eta;
-  fa.out = h->hscal_dev;
-  if (paired) {
-    launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr);
-    hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn + 1), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP, h->Cx, qp->q,
-                       (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, fa);
+  // everything behind the two solves: enqueued speculatively (gated on the recurrences' `done` flags) by run_krylov when
+  // the iteration count of the previous evaluation is known, else here
+  TailFn epi = [&]() -> int {
+    // ys = q1 + sigma q2 and the dots of objgrad!
+    hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax,
+                       paired ? h->SP : (double*)nullptr, h->gate0, h->gate1);
     h->launches++;
-  } else {
-    if (rho > 0.0)
-      if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
-    FxArgs none = fa;
-    none.out = nullptr;
-    hipLaunchKernelGGL(k_qp_penalty_grad, dim3(h->comm ? gn : gn + 1), dim3(kBlock), 0, s, h->p1, h->g,
-                       (const double*)nullptr, h->Cx, qp->q, h->jc, dx, dxk, sigma, rho, eta, h->gs, dgx, n,
-                       h->comm ? none : fa);
-    if (h->comm) {  // c'ys and c'c are sums over the rank's rows only
-      PresumArgs P{};
-      P.p[0] = fa.pcy;
-      P.n[0] = gm;
-      P.p[1] = fa.pcc;
-      P.n[1] = gm;
-      if (h->halo) {  // f and ||x - xk||^2 are sums over the owned part of the rank's column window
-        P.p[2] = fa.pf;
-        P.n[2] = gn;
-        P.p[3] = fa.pdx;
-        P.n[3] = gn;
+    FxArgs fa{};
+    fa.pf = h->pQ[0];
+    fa.pdx = h->pQ[1];
+    fa.np_n = gn;
+    fa.pcy = h->pE;
+    fa.pcc = h->pE + kEwBlocksMax;
+    fa.np_m = gm;
+    fa.rho = rho;
+    fa.eta = eta;
+    fa.out = h->hscal_dev;
+    if (paired) {
+      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr);
+      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn + 1), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP, h->Cx, qp->q,
+                         (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, fa, h->gate0,
+                         h->gate1);
+      h->launches++;
+    } else {
+      if (rho > 0.0)
+        if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
+      FxArgs none = fa;
+      none.out = nullptr;
+      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(h->comm ? gn : gn + 1), dim3(kBlock), 0, s, h->p1, h->g,
+                         (const double*)nullptr, h->Cx, qp->q, h->jc, dx, dxk, sigma, rho, eta, h->gs, dgx, n,
+                         h->comm ? none : fa, h->gate0, h->gate1);
+      if (h->comm) {  // c'ys and c'c are sums over the rank's rows only
+        PresumArgs P{};
+        P.p[0] = fa.pcy;
+        P.n[0] = gm;
+        P.p[1] = fa.pcc;
+        P.n[1] = gm;
+        if (h->halo) {  // f and ||x - xk||^2 are sums over the owned part of the rank's column window
+          P.p[2] = fa.pf;
+          P.n[2] = gn;
+          P.p[3] = fa.pdx;
+          P.n[3] = gn;
+        }
+        hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
+        if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
+        fa.pcy = h->comm_scal;
+        fa.pcc = h->comm_scal + 1;
+        fa.np_m = 1;
+        if (h->halo) {
+          fa.pf = h->comm_scal + 2;
+          fa.pdx = h->comm_scal + 3;
+          fa.np_n = 1;
+        }
+        hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa);
+        h->launches += 2;
       }
-      hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
-      if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
-      fa.pcy = h->comm_scal;
-      fa.pcc = h->comm_scal + 1;
-      fa.np_m = 1;
-      if (h->halo) {
-        fa.pf = h->comm_scal + 2;
-        fa.pdx = h->comm_scal + 3;
-        fa.np_n = 1;
-      }
-      hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa);
-      h->launches += 2;
+      h->launches++;
     }
-    h->launches++;
-  }
+    return 0;
+  };
+  if (int rc = two_mixed_device(h, h->g, h->c, paired, fast ? qp->b : nullptr, h->comm ? nullptr : &epi)) return rc;
+  if (h->comm)
+    if (int rc = epi()) return rc;
   if (gx && dgx != gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
   if (ys) HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
   if (gs) HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
@@ -2122,14 +2192,19 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
   double* dhv = on_this_device(h, Hv) ? Hv : h->gx;
   call_begin(h);
   hipLaunchKernelGGL(k_qp_hsv, dim3(gn), dim3(kBlock), 0, s, qp->q, dv, h->in_n2, n);                    // :537
-  if (int rc = two_least_squares_device(h, dv, h->in_n2)) return rc;                                      // :542
-  if (rho > 0.0) {                                                                                        // :557-558
-    spmv_const(h, TAG_A, 1.0, dv, 0.0, nullptr, h->in_m);
-    if (int rc = at_product_const(h, 1.0, h->in_m, 0.0, nullptr, h->jc)) return rc;
-  }
-  hipLaunchKernelGGL(k_qp_hprod_fin, dim3(gn), dim3(kBlock), 0, s, h->p1, h->p2b, qp->q, dv, h->jc, sigma, rho, eta, dhv,
-                     n);                                                                                  // :543-562
-  h->launches += 2;
+  TailFn epi = [&]() -> int {
+    if (rho > 0.0) {                                                                                      // :557-558
+      spmv_const(h, TAG_A, 1.0, dv, 0.0, nullptr, h->in_m);
+      if (int rc = at_product_const(h, 1.0, h->in_m, 0.0, nullptr, h->jc)) return rc;
+    }
+    hipLaunchKernelGGL(k_qp_hprod_fin, dim3(gn), dim3(kBlock), 0, s, h->p1, h->p2b, qp->q, dv, h->jc, sigma, rho, eta, dhv,
+                       n, h->gate0, h->gate1);                                                            // :543-562
+    h->launches += 2;
+    return 0;
+  };
+  if (int rc = two_least_squares_device(h, dv, h->in_n2, h->comm ? nullptr : &epi)) return rc;           // :542
+  if (h->comm)
+    if (int rc = epi()) return rc;
   if (dhv != Hv) HIPCHK(h, hipMemcpyAsync(Hv, dhv, nb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;
   st[0] = h->hstats[0];

@@ -188,6 +188,11 @@ struct UpdSeg {
   const double* src; // interleaved Golub-Kahan vector [len][NL]
   int32_t lane;      // which interleaved lane of src
   int32_t nblk;      // workgroups assigned to this segment
+  int32_t pad_[2];
+  // Speculatively enqueued final flush: runs only if this recurrence AND the one behind `gate` have ended (null:
+  // ungated).  While any lane of the call still iterates the loop goes on and the next product launch carries this
+  // update -- it must not be applied twice.
+  const LaneCtl* gate;
   double* a;         // LSQR: x      CRAIG long: xs      CRAIG short: w
   double* b;         // LSQR: w      CRAIG long: w2s     CRAIG short: y
   int64_t len;
@@ -204,6 +209,7 @@ __device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red) 
     return;
   }
   if (!WINIT && ctl->done && ctl->upd_iter != s.it) return;
+  if (!WINIT && s.gate != nullptr && !(ctl->done && s.gate->done)) return;  // the call still iterates
   const double sg = ctl->e[0], tr = ctl->e[1], ia = ctl->e[2];
   double sq = 0.0;
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
@@ -311,11 +317,14 @@ __device__ __forceinline__ bool run_fused_updates(const UpdSeg& u0, const UpdSeg
 template <int NL, int TAG, bool IDX16 = false, bool PAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
-                                                 double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1) {
+                                                 double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
+                                                 const LaneCtl* gate0, const LaneCtl* gate1) {
   // exactly 32 KB of LDS for two right-hand sides (five workgroups fit the CU's 160 KB): the reduction scratch
   // aliases the head of the product buffer
   __shared__ double prod[kSpmvNnz * NL];
   double* red = prod;
+  // speculatively enqueued epilogue product: runs only once both recurrences of the call have ended
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   // A (TAG 0): XCD-contiguous eighths, so an XCD's L2 holds one slice of the long gathered vector.  A' (TAG 1): the gathered
   // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
@@ -502,9 +511,10 @@ template <int NL, bool PAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                       double* partials, int grp_per_xcd, const UpdSeg u0,
-                                                      const UpdSeg u1) {
+                                                      const UpdSeg u1, const LaneCtl* gate0, const LaneCtl* gate1) {
   __shared__ double prod[kRgcsTile * NL];
   double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
   // (XCD-contiguous eighths: essential here -- with the identity map the product takes 43 us instead of 29 us)
   const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
@@ -825,7 +835,9 @@ __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q
 // ys = q1 + sigma q2 ; partials of c'ys and c'c            (m-vectors)
 __global__ __launch_bounds__(kBlock) void k_ys(const double* __restrict__ q1, const double* __restrict__ q2,
                                                const double* __restrict__ c, double sigma, double* ys, int64_t m,
-                                               double* pcy, double* pcc, double* pack) {
+                                               double* pcy, double* pcc, double* pack, const LaneCtl* gate0,
+                                               const LaneCtl* gate1) {
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   __shared__ double red[4];
   double cy = 0.0, cc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
@@ -884,7 +896,9 @@ __global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __rest
                                                             const double* __restrict__ q, const double* jc,
                                                             const double* x, const double* xk, double sigma,
                                                             double rho, double eta, double* gs, double* gx,
-                                                            int64_t n, const FxArgs fx) {
+                                                            int64_t n, const FxArgs fx, const LaneCtl* gate0,
+                                                            const LaneCtl* gate1) {
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   int nb = gridDim.x;
   if (fx.out) {
     --nb;
@@ -923,7 +937,9 @@ __global__ __launch_bounds__(kBlock) void k_qp_hsv(const double* __restrict__ q,
 __global__ __launch_bounds__(kBlock) void k_qp_hprod_fin(const double* __restrict__ p1, const double* __restrict__ p2,
                                                          const double* __restrict__ q, const double* __restrict__ v,
                                                          const double* jtjv, double sigma, double rho, double eta,
-                                                         double* hv, int64_t n) {
+                                                         double* hv, int64_t n, const LaneCtl* gate0,
+                                                         const LaneCtl* gate1) {
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const double vi = v[i];
     const double pt = vi - p1[i];

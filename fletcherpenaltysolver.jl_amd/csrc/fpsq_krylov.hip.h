@@ -26,7 +26,9 @@ struct Progress {  // host-mapped, written by the device, polled by the host
 __device__ __forceinline__ void publish(Progress* p, int iter, int done) {
   // relaxed system-scope stores, no fence: the host only needs to see them eventually (it bounds its run-ahead with
   // them and re-reads the device state itself if the stream drains first); a fence here would hold the kernel for a
-  // PCIe round trip on every step
+  // PCIe round trip on every step.  Even so the END of the kernel waits for these stores to be acknowledged over the
+  // host link (measured: the next kernel starts ~3.6 us later than after a step that published nothing), so the steps
+  // only publish when the host is going to look: at the end of a recurrence and from iteration `pub_from` on.
   __hip_atomic_store(&p->iter, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&p->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -67,7 +69,7 @@ struct LsqrState {
   double alpha, beta, beta1, Anorm2, dNorm2, xNorm2, c2, s2, z, xENorm2, phibar, rhobar, res2, ArNorm0;
   double err_vec[5];
   int32_t iter;
-  int32_t pad;
+  int32_t pub_from;  // progress is published to the host from this iteration on (and whenever the recurrence ends)
   fpsq_stats stats;
 };
 
@@ -95,7 +97,7 @@ __device__ __forceinline__ void lsqr_begin_step(LsqrState* S, double bb, Progres
   S->ctl.done = 0;
   S->ctl.ca = 1.0 / beta1;  // v~_1 = B' u~_1 / beta1
   S->ctl.cb = 0.0;
-  publish(prog, 0, 0);
+  // (nothing to publish: the host zeroed its progress word before the launch)
 }
 
 // after v~_1 = B'u_1: alpha_1 = ||v~_1||; start-up tests of lsqr!
@@ -248,7 +250,7 @@ __device__ __forceinline__ void lsqr_sb_step(LsqrState* S, double aa, double ww,
     S->stats.inconsistent = !zero_resid;
     lane_finish(S->ctl, it);
     publish(prog, it, 1);
-  } else {
+  } else if (it >= S->pub_from) {
     publish(prog, it, 0);
   }
 }
@@ -264,7 +266,7 @@ struct CraigState {
   double alpha, beta, beta1, theta, xi, deltag, rho_prev, omega, c1, s1, rho;
   double Anorm2, Dnorm2, xNorm2, eps_c;
   int32_t iter;
-  int32_t pad;
+  int32_t pub_from;
   fpsq_stats stats;
 };
 
@@ -308,7 +310,6 @@ __device__ __forceinline__ void craig_begin_step(CraigState* S, double bb, Progr
   S->ctl.done = 0;
   S->ctl.ca = S->mu / beta1;  // v~_1 = B'u_1 = (mu / beta1) B' Mu~
   S->ctl.cb = 0.0;            // Nv_0 = 0
-  publish(prog, 0, 0);
 }
 
 // after v~ <- B'u - beta v: alpha = ||v~||, first Givens, xi; coefficients of the x / w2 / w / y updates
@@ -406,12 +407,10 @@ __device__ __forceinline__ void craig_sb_step(CraigState* S, double bb, double w
     S->stats.inconsistent = 0;
     S->ctl.done = 1;
     publish(prog, it, 1);
-  } else {
+  } else if (it >= S->pub_from) {
     publish(prog, it, 0);
   }
 }
-
-
 
 // =============================================================================================== MINRES
 // (A A' + lambda I) x = b, all vectors in R^m; Krylov.jl minres! with M = I (src/solve_linear_system.jl:58-70).
@@ -659,30 +658,49 @@ struct StepArgs {
 constexpr int kStepThreads = 256;
 
 // sums of two partial arrays at once; results valid in thread 0
+// U loads per thread issued back to back and UNCONDITIONALLY (clamped index, value masked afterwards): a predicated
+// load makes hipcc wait for each one, and a loop over batches costs one global round trip (~1.5 us) per batch.
+template <int U>
+__device__ __forceinline__ double partial_batch(const double* p, int base, int n, int t) {
+  double v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = base + u * kStepThreads + t;
+    v[u] = p[i < n ? i : n - 1];
+  }
+  double a = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) a += (base + u * kStepThreads + t < n) ? v[u] : 0.0;
+  return a;
+}
+
 __device__ __forceinline__ void reduce_two(const double* p0, int n0, const double* p1, int n1, double* red,
                                            double& s0, double& s1) {
   double a = 0.0, b = 0.0;
   const int t = threadIdx.x;
-  constexpr int U = 8;
-  for (int base = 0; base < n0; base += kStepThreads * U) {
-    double v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + u * kStepThreads + t;
-      v[u] = (i < n0) ? p0[i] : 0.0;
+  // the whole of both arrays in ONE batch of loads whenever they fit (<= 24 x 256 = 6144 and <= 4 x 256 entries:
+  // 4883 + 391 at the headline size), in a fixed order
+  constexpr int U0 = 24, U1 = 4;
+  if (n0 > 0 && n0 <= kStepThreads * U0 && n1 <= kStepThreads * U1) {
+    if (n0 <= kStepThreads * 4) {
+      const double x = partial_batch<4>(p0, 0, n0, t);
+      const double y = n1 > 0 ? partial_batch<U1>(p1, 0, n1, t) : 0.0;
+      a = x;
+      b = y;
+    } else if (n0 <= kStepThreads * 8) {
+      const double x = partial_batch<8>(p0, 0, n0, t);
+      const double y = n1 > 0 ? partial_batch<U1>(p1, 0, n1, t) : 0.0;
+      a = x;
+      b = y;
+    } else {
+      const double x = partial_batch<U0>(p0, 0, n0, t);
+      const double y = n1 > 0 ? partial_batch<U1>(p1, 0, n1, t) : 0.0;
+      a = x;
+      b = y;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) a += v[u];
-  }
-  for (int base = 0; base < n1; base += kStepThreads * U) {
-    double v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + u * kStepThreads + t;
-      v[u] = (i < n1) ? p1[i] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) b += v[u];
+  } else {
+    for (int base = 0; base < n0; base += kStepThreads * 8) a += partial_batch<8>(p0, base, n0, t);
+    for (int base = 0; base < n1; base += kStepThreads * 8) b += partial_batch<8>(p1, base, n1, t);
   }
   a = wave_sum(a);
   b = wave_sum(b);

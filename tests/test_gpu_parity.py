@@ -585,6 +585,47 @@ def test_run_ahead_history_does_not_change_results(oracle):
     H.close()
 
 
+def test_speculative_epilogue_is_bitwise_neutral(monkeypatch):
+    """objgrad / hprod enqueue their epilogue speculatively behind the iteration count of the PREVIOUS call (gated on the
+    recurrences' `done` flags).  Over a sequence of points whose Krylov counts go up and down (misses in both
+    directions, one lane ending before the other), results must be bitwise those of a handle with the adaptive
+    run-ahead switched off -- in particular the final LSQR update is applied exactly once."""
+    import torch
+
+    tight = dict(TIGHT)
+    qp = _small_pde(seed=5, n=3000, m=300)
+    monkeypatch.setenv("FPSQ_ADAPTIVE_RUNAHEAD", "0")
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, **tight)
+    monkeypatch.setenv("FPSQ_ADAPTIVE_RUNAHEAD", "1")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, **tight)
+    rng = np.random.default_rng(0)
+    counts = set()
+    for k in range(40):
+        scale = 0.5 ** (k % 14) * (1.0 if k % 3 else 1e-3)
+        x = qp.xhat + scale * rng.standard_normal(qp.n)
+        g1, g2, y1, y2 = np.empty(qp.n), np.empty(qp.n), np.empty(qp.m), np.empty(qp.m)
+        f1, rc1 = ref.objgrad(x, gx=g1, ys=y1)
+        i1 = (ref.stats[0].niter, ref.stats[1].niter)
+        if k % 2:  # device-resident arguments take the in-place path
+            xt = torch.from_numpy(x).cuda()
+            t2 = torch.empty(qp.n, dtype=torch.float64, device="cuda")
+            f2, rc2 = dev.objgrad(xt, gx=t2, ys=y2)
+            g2 = t2.cpu().numpy()
+        else:
+            f2, rc2 = dev.objgrad(x, gx=g2, ys=y2)
+        assert (dev.stats[0].niter, dev.stats[1].niter) == i1 and rc1 == rc2
+        assert f1 == f2 and np.array_equal(g1, g2) and np.array_equal(y1, y2), (k, i1)
+        counts.add(i1)
+        if k % 5 == 0:
+            v = scale * rng.standard_normal(qp.n)
+            h1, h2 = np.empty(qp.n), np.empty(qp.n)
+            assert ref.hprod(v, h1) == dev.hprod(v, h2)
+            assert np.array_equal(h1, h2)
+    assert len(counts) >= 4, counts  # the sequence really moves the iteration counts around
+    ref.close()
+    dev.close()
+
+
 # ---------------------------------------------------------------------------------------------- row sharding
 
 @pytest.mark.parametrize("nshards", [2, 3])
