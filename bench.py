@@ -45,10 +45,12 @@ def parse_args():
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed K-step passes (0 = as many as make >= 1 s of timed work, 3..50); median reported")
     ap.add_argument("--workload", default=WORKLOADS[0], choices=WORKLOADS)
-    ap.add_argument("--op", default="objgrad", choices=["objgrad", "hprod-solves", "hprod"],
+    ap.add_argument("--op", default="objgrad", choices=["objgrad", "hprod-solves", "hprod", "extras"],
                     help="objgrad = the headline metric; hprod-solves = solve_two_least_squares (the two solves of every "
                          "hprod!, solve_linear_system.jl:79-105) on distinct right-hand-side pairs; hprod = the whole "
-                         "device-resident hprod! Val(2) (model-Fletcherpenaltynlp.jl:521-570): SURVEY 8(f) rank 1")
+                         "device-resident hprod! Val(2) (model-Fletcherpenaltynlp.jl:521-570): SURVEY 8(f) rank 1; extras = "
+                         "solve_two_extras (LSQR + MINRES on AA' + tau I, solve_linear_system.jl:45-77: the extra solves "
+                         "of hprod! Val(1)) -- timing only, no roofline accounting")
     ap.add_argument("--delta", type=float, default=None, help="regularisation; default 0 = first outer iteration "
                     "(algo.jl:46); 1e-3 for the dense-block workload")
     ap.add_argument("--fuse", type=int, default=1)
@@ -353,13 +355,16 @@ def main():
     xs_h = points(0 if sharded else rank * (K + W))
     xs = xs_h if host_ptr else torch.from_numpy(xs_h).to(dev)
     gx = np.empty(n_loc) if host_ptr else torch.empty(n_loc, dtype=torch.float64, device=dev)
-    hp = args.op in ("hprod-solves", "hprod")
+    hp = args.op in ("hprod-solves", "hprod", "extras")
     hfull = args.op == "hprod"
+    extras = args.op == "extras"
     if hp:  # the points double as right-hand sides: (xs[t], xs[t] reversed) are the two n-vectors of step t
         if sharded or host_ptr:
             raise SystemExit("--op hprod-solves / hprod: device pointers, single GPU or replicas only")
         xr = torch.flip(xs, dims=[1]).contiguous()
         hp_out = [torch.empty(k, dtype=torch.float64, device=dev) for k in (n, m, n, m)]
+        if extras:  # rhs2 of step t: the first m entries of the reversed point
+            xm = xr[:, :m].contiguous()
     jac_vals = np.ascontiguousarray(qp.vals) if args.pointers == "host+jac" else None
     torch.cuda.synchronize()
 
@@ -367,6 +372,11 @@ def main():
         def step(t):
             if hfull:
                 return None, mdl.hprod(pts[t], hp_out[0])
+            if extras:
+                mdl._order(pts[t], xm[t], hp_out[1], hp_out[3])
+                return None, mdl._check(mdl._lib.fpsq_solve_two_extras(mdl._h, pts[t].data_ptr(), xm[t].data_ptr(),
+                                                                      hp_out[1].data_ptr(), hp_out[3].data_ptr(),
+                                                                      mdl.stats))
             if hp:
                 return None, mdl.solve_two_least_squares(pts[t], xr[t], *hp_out)
             if jac_vals is not None:
@@ -388,7 +398,7 @@ def main():
 
     # ---- roofline of the dominant kernel: a second pass over the same K points with per-launch HIP events
     roofline = None
-    if not args.no_roofline_pass:
+    if not args.no_roofline_pass and not extras:
         model.set_profiling(True)
         pa, pat, t_ms, tot_ms = np.zeros(2), np.zeros(2), 0.0, 0.0
         for t in range(W, W + K):
@@ -470,6 +480,7 @@ def main():
            "replicas": f"{world} independent replicas (each rank evaluates its own points), no data-path collective"}[layout]
     out = {
         "metric": "penalty hprod! (Val(2)) evals/sec" if hfull
+        else "solve_two_extras calls/sec (LSQR + MINRES lanes, the extra solves of hprod! Val(1))" if extras
         else "solve_two_least_squares calls/sec (the two KKT solves of one hprod!)" if hp
         else "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "calls/s" if hp else "evals/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * med / K, 4),
@@ -479,7 +490,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "m": m, "nnz": nnz, "sigma": sigma, "rho": rho,
                    "delta": delta, "fuse_two_rhs": args.fuse, "pointers": args.pointers,
-                   "krylov": ("LSQR+LSQR" if hp else "LSQR+CRAIG") + ", atol=rtol=sqrt(eps) (reference defaults)",
+                   "krylov": ("LSQR+MINRES" if extras else "LSQR+LSQR" if hp else "LSQR+CRAIG") +
+                             ", atol=rtol=sqrt(eps) (reference defaults)",
                    "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
                    "all_solved": soft[0] == 0, "parallelism": par},
         "roofline": roofline,
@@ -505,7 +517,10 @@ def main():
         t0 = time.perf_counter()
         done = 0
         for t in range(args.cpu_evals):
-            if hp:  # (hprod: the solves are all of its CPU cost but two products and three vector passes)
+            if extras:
+                r1 = qp.point(1 + W + t)
+                oracle.solve_two_extras(m, n, qp.rowptr, qp.colind, qp.vals, delta, r1, np.ascontiguousarray(r1[::-1][:m]))
+            elif hp:  # (hprod: the solves are all of its CPU cost but two products and three vector passes)
                 r1 = qp.point(1 + W + t)
                 oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, delta, r1,
                                                np.ascontiguousarray(r1[::-1]) if not hfull else qp.qdiag * r1)
@@ -527,6 +542,8 @@ def main():
             t0 = time.perf_counter()
             done2 = 0
             for t in range(args.cpu_evals):
+                if extras:
+                    break
                 if hp:
                     r1 = qp.point(1 + W + t)
                     oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, delta, r1,
@@ -536,6 +553,8 @@ def main():
                 done2 += 1
                 if time.perf_counter() - t0 > 15.0:
                     break
+            if done2 == 0:
+                raise AttributeError("no OpenMP leg for this op")
             out["cpu_baseline"]["all_cores"] = {"value": round(done2 / (time.perf_counter() - t0), 4),
                                                 "cores": int(nthreads),
                                                 "kind": "port, OpenMP (oracle/libfps_oracle_omp.so)"}

@@ -280,7 +280,7 @@ struct fpsq_solver_s {
   const LaneCtl* gate0 = nullptr;
   const LaneCtl* gate1 = nullptr;
   bool tail_was_run = false;   // the caller's epilogue was enqueued (gated) inside run_krylov and the gates were open
-  int64_t expect_iters[3][3] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
+  int64_t expect_iters[4][4] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
   bool adaptive_runahead = true;    // FPSQ_ADAPTIVE_RUNAHEAD=0 disables (A/B)
 
   // instrumentation
@@ -879,6 +879,30 @@ __device__ __forceinline__ void craig_set_params(CraigState* S, const CraigParam
   S->ctl.upd_iter = -1;
 }
 
+struct MinresParams {
+  double lambda, atol, rtol, etol, conlim;
+  int64_t itmax;
+  int32_t pub_from;
+};
+
+__device__ __forceinline__ void minres_set_params(MinresState* S, const MinresParams& P) {
+  S->lambda = P.lambda;
+  S->atol = P.atol;
+  S->rtol = P.rtol;
+  S->etol = P.etol;
+  S->ctol = P.conlim > 0.0 ? 1.0 / P.conlim : 0.0;
+  S->itmax = P.itmax;
+  S->pub_from = P.pub_from;
+  S->ctl.done = 0;
+  S->ctl.skip = 1;  // stays out of the LSQR lane's start-up product; minres_begin_step clears it
+  S->ctl.upd_iter = -1;
+  S->ctlT.done = 0;
+  S->ctlT.skip = 0;
+  S->ctlT.upd_iter = -1;
+  S->ctlT.ca = 1.0;  // tmp = A' r2, raw
+  S->ctlT.cb = 0.0;
+}
+
 // Parameters of every lane of a run in one launch (null state = lane kind not present).
 __global__ void k_lane_params(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrParams P1, CraigState* C, CraigParams PC) {
   if (S0) lsqr_set_params(S0, P0);
@@ -892,6 +916,7 @@ struct LoadSeg {
   const double* src;
   double scale;
   double* dst;
+  double* dst2;  // optional plain copy of the scaled vector (MINRES keeps r2 = b next to the pair's lane)
   int32_t lane, nblk;
   int64_t len;
   int64_t sum_len;  // the squared-norm partials run over [0, sum_len) (halo mode: the owned prefix of an n-vector)
@@ -899,12 +924,14 @@ struct LoadSeg {
 };
 template <int NL>
 __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrParams P1, CraigState* C,
-                                                    CraigParams PC, LoadSeg l0, LoadSeg l1, ZeroArgs z, int nzblk) {
+                                                    CraigParams PC, MinresState* M, MinresParams PM, LoadSeg l0, LoadSeg l1,
+                                                    ZeroArgs z, int nzblk) {
   __shared__ double red[4];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (S0) lsqr_set_params(S0, P0);
     if (S1) lsqr_set_params(S1, P1);
     if (C) craig_set_params(C, PC);
+    if (M) minres_set_params(M, PM);
   }
   int blk = blockIdx.x;
   if (blk < l0.nblk + l1.nblk) {
@@ -912,6 +939,7 @@ __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0
     if (!first) blk -= l0.nblk;
     const double* src = first ? l0.src : l1.src;
     double* dst = first ? l0.dst : l1.dst;
+    double* dst2 = first ? l0.dst2 : l1.dst2;
     const double scale = first ? l0.scale : l1.scale;
     const int lane = first ? l0.lane : l1.lane;
     const int nb = first ? l0.nblk : l1.nblk;
@@ -922,6 +950,7 @@ __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0
     for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < len; i += (int64_t)nb * kBlock) {
       const double v = scale * src[i];
       dst[i * NL + lane] = v;
+      if (dst2) dst2[i] = v;
       if (i < sum_len) sq += v * v;
     }
     const double t = block_sum(sq, red);
@@ -936,17 +965,17 @@ __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0
   }
 }
 
-enum { LANE_LSQR = 1, LANE_CRAIG = 2 };
+enum { LANE_LSQR = 1, LANE_CRAIG = 2, LANE_MINRES = 3 };
 
 // One Krylov recurrence of a (possibly fused) run.
 struct Lane {
   int kind = 0;
-  const double* rhs = nullptr;  // LSQR: n-vector b;  CRAIG: m-vector b
+  const double* rhs = nullptr;  // LSQR: n-vector b;  CRAIG, MINRES: m-vector b
   double rhs_scale = 1.0;
-  double lambda = 0.0;          // LSQR regularisation
+  double lambda = 0.0;          // LSQR regularisation; MINRES: shift of A A' + lambda I
   double delta = 0.0;           // CRAIG: M = (1/delta) I, sqd when != 0
   double xsign = 1.0;           // CRAIG: xs accumulates xsign * x
-  double* x = nullptr;          // LSQR: solution (m).  CRAIG: xs (n)
+  double* x = nullptr;          // LSQR, MINRES: solution (m).  CRAIG: xs (n)
   double* y = nullptr;          // CRAIG: y (m)
   fpsq_stats* st = nullptr;     // destination of the final stats: an element of the host-mapped h->hstats
   fpsq_stats* st_dev = nullptr; // its device alias (filled by run_krylov / run_minres)
@@ -956,7 +985,8 @@ struct Lane {
   double* affine_out = nullptr;         //        LSQR start-up product (the lane is otherwise parked there); A z - shift -> affine_out
   // filled by run_krylov
   void* state = nullptr;
-  LaneCtl* ctl = nullptr;
+  LaneCtl* ctl = nullptr;       // coefficients of the A product (and of the A' product for LSQR / CRAIG)
+  LaneCtl* ctlT = nullptr;      // coefficients of the A' product (MINRES: the raw tmp = A' r2)
   int64_t itmax = 0;
 };
 
@@ -982,12 +1012,13 @@ void launch_step_raw(fpsq_handle h, const StepArgs& a0, const StepArgs& a1) {
 
 // `sharded`: the partial arrays of these steps are sums over m-vectors, of which a rank only holds its rows:
 // local sums -> one scalar all-reduce (4 doubles) -> the step kernel reads the global sums.
-int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false) {
-  if (h->comm && sharded) {
+int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, int sharded1 = -1) {
+  const bool sh[2] = {sharded, sharded1 < 0 ? sharded : sharded1 != 0};  // per step: its partials are per-rank sums
+  if (h->comm && (sh[0] || sh[1])) {
     PresumArgs P{};
     const StepArgs* a[2] = {&a0, &a1};
     for (int k = 0; k < 2; ++k) {
-      if (a[k]->kind == STEP_NONE) continue;
+      if (a[k]->kind == STEP_NONE || !sh[k]) continue;
       P.p[2 * k] = a[k]->p0;
       P.n[2 * k] = a[k]->n0;
       P.p[2 * k + 1] = a[k]->p1;
@@ -998,7 +1029,7 @@ int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false) {
     if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
     StepArgs* w[2] = {&a0, &a1};
     for (int k = 0; k < 2; ++k) {
-      if (w[k]->kind == STEP_NONE) continue;
+      if (w[k]->kind == STEP_NONE || !sh[k]) continue;
       w[k]->p0 = h->comm_scal + 2 * k;
       w[k]->n0 = 1;
       if (w[k]->p1) {
@@ -1055,6 +1086,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   LsqrParams lsP[2] = {};
   CraigState* crS = nullptr;
   CraigParams crP{};
+  MinresState* mrS = nullptr;
+  MinresParams mrP{};
+  int minres_lane = -1;
   for (int l = 0; l < NL; ++l) {
     Lane& L = lanes[l];
     prog[l] = &h->prog_dev[l];
@@ -1071,6 +1105,16 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       lsP[nlsqr - 1] = LsqrParams{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax,
                                   pub_from};
       lsS[nlsqr - 1] = S;
+    } else if (L.kind == LANE_MINRES) {
+      MinresState* S = h->minres;
+      L.state = S;
+      L.ctl = &S->ctl;
+      L.ctlT = &S->ctlT;
+      L.itmax = o.ne_itmax == 0 ? 2 * m : o.ne_itmax;
+      // (its stopping tests of iteration k run one product later than the other recurrences': see the main loop)
+      mrP = MinresParams{L.lambda, o.ne_atol, o.ne_rtol, o.ne_etol, o.ne_conlim, L.itmax, std::max(pub_from - 1, 0)};
+      mrS = S;
+      minres_lane = l;
     } else {
       CraigState* S = h->craig;
       L.state = S;
@@ -1081,10 +1125,13 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
                         L.xsign, L.itmax, NL == 2 ? 1 : 0, pub_from};
       crS = S;
     }
+    if (!L.ctlT) L.ctlT = L.ctl;
     itmax_all = std::max(itmax_all, L.itmax);
   }
-  const LaneCtl* c0 = lanes[0].ctl;
+  const LaneCtl* c0 = lanes[0].ctl;  // A product
   const LaneCtl* c1 = lanes[NL - 1].ctl;
+  const LaneCtl* t0 = lanes[0].ctlT;  // A' product
+  const LaneCtl* t1 = lanes[NL - 1].ctlT;
   int affine_lane = -1;  // fast start: the CRAIG lane whose right-hand side the LSQR start-up product forms
   for (int l = 0; l < NL; ++l)
     if (lanes[l].kind == LANE_CRAIG && lanes[l].affine_shift && any_lsqr && NL == 2 && !h->comm) affine_lane = l;
@@ -1111,6 +1158,19 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       g.sum_len = n_owned(h);
       g.nblk = L.preloaded ? 0 : gn;  // fast start: the caller wrote the lane and the ||rhs||^2 partials already
       (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
+    } else if (L.kind == LANE_MINRES) {
+      // r1 = r2 = b: r2 sits in Mr[1] (iteration 1 reads r2 from Mr[it % 2]) and in the short pair's lane
+      g.dst = SP;
+      g.dst2 = h->Mr[1];
+      g.len = m;
+      g.sum_len = m;
+      g.nblk = gm;
+      z.p[0] = L.x;
+      z.p[1] = h->Mw[0];
+      z.p[2] = h->Mw[1];
+      z.p[3] = h->Mr[0];
+      z.n[0] = z.n[1] = z.n[2] = z.n[3] = m;
+      nzblk = gm;
     } else {
       if (L.affine_shift) {  // fast start: the lane receives `shift`; the start-up product turns it into -(A z - shift)
         g.src = L.affine_shift;
@@ -1134,7 +1194,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     }
   }
   hipLaunchKernelGGL(k_startup<NL>, dim3(ld[0].nblk + ld[1].nblk + nzblk), dim3(kBlock), 0, s, lsS[0], lsP[0], lsS[1], lsP[1],
-                     crS, crP, ld[0], ld[1], z, nzblk);
+                     crS, crP, mrS, mrP, ld[0], ld[1], z, nzblk);
   h->launches++;
   // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
   // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
@@ -1209,7 +1269,18 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
                                none, /*sharded=*/true))
         return rc;
 
+  if (minres_lane >= 0)  // (un-parks the lane: must follow the LSQR lane's start-up product)
+    if (int rc = launch_step(h, step_args(STEP_MINRES_BEGIN, lanes[minres_lane], 0, minres_lane == 0 ? h->pE : h->pE2, gm,
+                                          nullptr, 0, prog[minres_lane]),
+                             none, /*sharded=*/true))
+      return rc;
+
   // ---- main loop
+  // A MINRES lane (solve_two_extras) shares the two products of an iteration with the other recurrence: tmp = A' r2
+  // rides in the A' product, q = (A tmp + lambda r2) / beta in the A product; then its element-wise stages E1 -> scalar
+  // step A -> E2 -> step B.  Stage E3 (w, x) only needs the scalars of step B: it rides in the A' product of the NEXT
+  // iteration and its stopping tests (step C) share the step launch that follows that product -- one short
+  // element-wise launch and one scalar launch more per iteration than the other recurrence alone.
   double* SPcur = SP;
   double* SPalt = h->SP2;
   const int look = std::max(1, o.lookahead);
@@ -1234,6 +1305,46 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       if (!h->prog_host[l].done) return false;
     return true;
   };
+  // MINRES stage segments of iteration `k` (the Lanczos vector under construction sits in lane l of `pair`)
+  auto minres_seg = [&](int stage, int64_t k, double* pair) {
+    const int l = minres_lane;
+    UpdSeg u{};
+    u.kind = stage == 1 ? UPD_MINRES_E1 : stage == 2 ? UPD_MINRES_E2 : UPD_MINRES_E3;
+    u.it = (int)k;
+    u.ctl = lanes[l].ctl;
+    u.src = pair;
+    u.lane = l;
+    u.nblk = gm;
+    u.len = m;
+    double* r2 = h->Mr[k % 2];
+    double* r1 = h->Mr[(k + 1) % 2];  // also receives the new r2
+    double* w1 = h->Mw[k % 2];        // w_{k-2}, overwritten by w_k
+    double* w2 = h->Mw[(k + 1) % 2];
+    if (stage == 1) {
+      u.a = r1;
+      u.b = r2;
+      u.partials = h->pE3;
+    } else if (stage == 2) {
+      u.a = r2;
+      u.b = r1;
+      u.c = w2;
+      u.d = w1;
+      u.partials = h->pW[l];
+    } else {
+      u.a = w1;
+      u.b = lanes[l].x;
+      u.partials = h->pW[l];
+    }
+    return u;
+  };
+  auto iter_ptr = [&](int l) -> const int32_t* {
+    return lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->iter
+           : lanes[l].kind == LANE_CRAIG ? &((CraigState*)lanes[l].state)->iter
+                                         : &((MinresState*)lanes[l].state)->iter;
+  };
+  // a MINRES lane reports iteration k (its step C) while the host is enqueueing iteration k + 1
+  auto lag = [&](int l) { return lanes[l].kind == LANE_MINRES ? 1 : 0; };
+  const bool split_steps = h->comm && !h->halo;  // replicated n-sums and per-rank m-sums cannot share a presum launch
   while (it < itmax_all) {
     ++it;
     // LSQR's x/w update of the PREVIOUS iteration
@@ -1246,19 +1357,45 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       lu[0] = winit[0];  // fused runs: w_1 = v_1 (empty segments otherwise)
       lu[1] = winit[1];
     }
+    // MINRES: stage E3 of the PREVIOUS iteration (w, x and ||x||^2 for its stopping tests)
+    UpdSeg e3 = seg_none();
+    if (minres_lane >= 0 && it > 1) {
+      e3 = minres_seg(3, it - 1, SPcur);
+      if (fuse_upd) lu[nlu < 2 ? nlu : 1] = e3;
+      else launch_updates<NL>(h, e3, seg_none(), seg_none());
+    }
     // first half-step of every lane: one A' product
     int npT = 0;
     if (fuse_upd) {
-      if (int rc = at_product<NL>(h, SPcur, LP, c0, c1, h->pS, &npT, lu[0], lu[1])) return rc;
+      if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT, lu[0], lu[1])) return rc;
     } else {
-      if (int rc = at_product<NL>(h, SPcur, LP, c0, c1, h->pS, &npT)) return rc;
+      if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT)) return rc;
     }
     StepArgs sa[2] = {none, none};
-    for (int l = 0; l < NL; ++l)
+    for (int l = 0; l < NL; ++l) {
+      if (lanes[l].kind == LANE_MINRES) {  // the stopping tests of iteration it - 1
+        if (it > 1) sa[l] = step_args(STEP_MINRES_C, lanes[l], (int)it - 1, h->pW[l], gm, nullptr, 0, prog[l]);
+        continue;
+      }
       sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : STEP_CRAIG_SA, lanes[l], (int)it,
                         h->pS + (size_t)l * npT, npT, nullptr, 0, prog[l]);
-    // sums over n-vectors: replicated (no all-reduce) unless the n-vectors are column windows (halo mode)
-    if (int rc = launch_step(h, sa[0], sa[1], /*sharded=*/h->halo)) return rc;
+    }
+    // sums over n-vectors: replicated (no all-reduce) unless the n-vectors are column windows (halo mode); MINRES' sums
+    // run over (row-sharded) m-vectors
+    {
+      const bool sh0 = lanes[0].kind == LANE_MINRES ? true : h->halo;
+      const bool sh1 = lanes[NL - 1].kind == LANE_MINRES ? true : h->halo;
+      if (NL == 2 && split_steps && sh0 != sh1) {
+        if (int rc = launch_step(h, sa[0], none, sh0)) return rc;
+        if (int rc = launch_step(h, sa[1], none, sh1)) return rc;
+      } else if (NL == 2) {
+        if (int rc = launch_step(h, sa[0].kind ? sa[0] : sa[1], sa[0].kind ? sa[1] : none, sa[0].kind ? sh0 : sh1,
+                                 sa[0].kind ? sh1 : 0))
+          return rc;
+      } else if (sa[0].kind) {
+        if (int rc = launch_step(h, sa[0], none, sh0)) return rc;
+      }
+    }
     // CRAIG's updates of this iteration
     UpdSeg cu[2] = {seg_none(), seg_none()};
     for (int l = 0; l < NL; ++l) {
@@ -1298,11 +1435,24 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       else launch_updates<NL>(h, lu[0], cu[0], cu[1]);
       launch_spmv<NL>(h, TAG_A, LP, SPcur, SPcur, c0, c1, h->pS2);
     }
+    // MINRES: E1 on q (now in the current pair's lane) before its scalar step A
+    if (minres_lane >= 0) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
     StepArgs sb[2] = {none, none};
-    for (int l = 0; l < NL; ++l)
-      sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : STEP_CRAIG_SB, lanes[l], (int)it,
-                        h->pS2 + (size_t)l * nbA, nbA, h->pW[l], gm, prog[l]);
+    for (int l = 0; l < NL; ++l) {
+      if (lanes[l].kind == LANE_MINRES)
+        sb[l] = step_args(STEP_MINRES_A, lanes[l], (int)it, h->pE3, gm, nullptr, 0, prog[l]);
+      else
+        sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : STEP_CRAIG_SB, lanes[l], (int)it,
+                          h->pS2 + (size_t)l * nbA, nbA, h->pW[l], gm, prog[l]);
+    }
     if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
+    if (minres_lane >= 0) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
+      launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
+      if (int rc = launch_step(h, step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
+                                            prog[minres_lane]),
+                               none, /*sharded=*/true))
+        return rc;
+    }
     if (h->comm) {
       // every rank must enqueue the same collectives: decide at fixed iteration boundaries from the (replicated,
       // bitwise identical) device state, never from the timing of the progress word
@@ -1318,14 +1468,12 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     // bound the run-ahead of the host on the slowest unfinished lane
     int slow = INT32_MAX;
     for (int l = 0; l < NL; ++l)
-      if (!h->prog_host[l].done) slow = std::min(slow, (int)h->prog_host[l].iter);
+      if (!h->prog_host[l].done) slow = std::min(slow, (int)h->prog_host[l].iter + lag(l));
     if (it > expect && it - slow >= look) {
       for (int l = 0; l < NL; ++l) {
         if (h->prog_host[l].done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
-        const int32_t* diter = lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->iter
-                                                          : &((CraigState*)lanes[l].state)->iter;
-        if (int rc = wait_progress(h, l, (int)(it - look + 1), ddone, diter)) return rc;
+        if (int rc = wait_progress(h, l, (int)(it - look + 1) - lag(l), ddone, iter_ptr(l))) return rc;
       }
       if (all_done()) break;
     }
@@ -1353,16 +1501,14 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       for (int l = 0; l < NL; ++l) {
         if (h->prog_host[l].done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
-        const int32_t* diter = lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->iter
-                                                          : &((CraigState*)lanes[l].state)->iter;
-        if (int rc = wait_progress(h, l, (int)it, ddone, diter)) return rc;
+        if (int rc = wait_progress(h, l, (int)it - lag(l), ddone, iter_ptr(l))) return rc;
       }
       if (all_done()) break;
     }
   }
   if (all_done()) {  // the iteration at which the last recurrence finished (its progress word says so)
     int64_t e = 0;
-    for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter);
+    for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter + lag(l));
     *expect_slot = e;
   }
   if (spec_it >= 0 && spec_it == it && all_done()) {
@@ -1381,87 +1527,15 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       seg[0] = winit[0];
       seg[1] = winit[1];
     }
-    launch_updates<NL>(h, seg[0], seg[1], seg_none());
+    // MINRES: stage E3 and the stopping tests of the last enqueued iteration (no-ops when it ended earlier)
+    launch_updates<NL>(h, seg[0], seg[1], minres_lane >= 0 && it >= 1 ? minres_seg(3, it, SPcur) : seg_none());
+    if (minres_lane >= 0 && it >= 1)
+      if (int rc = launch_step(h, step_args(STEP_MINRES_C, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
+                                            prog[minres_lane]),
+                               none, /*sharded=*/true))
+        return rc;
   }
   return 0;  // the final stats were left in lanes[l].st by the step that ended each recurrence
-}
-
-struct MinresParams {
-  double lambda, atol, rtol, etol, conlim;
-  int64_t itmax;
-};
-
-__global__ void k_minres_params(MinresState* S, MinresParams P) {
-  S->lambda = P.lambda;
-  S->atol = P.atol;
-  S->rtol = P.rtol;
-  S->etol = P.etol;
-  S->ctol = P.conlim > 0.0 ? 1.0 / P.conlim : 0.0;
-  S->itmax = P.itmax;
-  S->ctl.done = 0;
-  S->ctl.skip = 0;
-  S->ctl.upd_iter = -1;
-  S->ctlT.done = 0;
-  S->ctlT.skip = 0;
-  S->ctlT.ca = 1.0;
-  S->ctlT.cb = 0.0;
-}
-
-// MINRES on (A A' + lambda I) x = b: src/solve_linear_system.jl:58-72.  b (m, device) -> h->Mx.
-int run_minres(fpsq_handle h, const double* b, double lambda, fpsq_stats* st_out) {
-  const int64_t m = h->m;
-  const fpsq_options& o = h->opt;
-  hipStream_t s = h->stream;
-  MinresState* S = h->minres;
-  const LaneCtl* ctl = &S->ctl;
-  Progress* prog = &h->prog_dev[0];
-  h->prog_host[0].iter = 0;
-  h->prog_host[0].done = 0;
-  const int gm = ew_grid(m);
-  const int64_t itmax = o.ne_itmax == 0 ? 2 * m : o.ne_itmax;
-  MinresParams P{lambda, o.ne_atol, o.ne_rtol, o.ne_etol, o.ne_conlim, itmax};
-  hipLaunchKernelGGL(k_minres_params, dim3(1), dim3(1), 0, s, S, P);
-  HIPCHK(h, hipMemsetAsync(h->Mx, 0, (size_t)m * 8, s));
-  HIPCHK(h, hipMemsetAsync(h->Mw[0], 0, (size_t)m * 8, s));
-  HIPCHK(h, hipMemsetAsync(h->Mw[1], 0, (size_t)m * 8, s));
-  HIPCHK(h, hipMemsetAsync(h->Mr[0], 0, (size_t)m * 8, s));
-  // r1 = r2 = b: r2 sits in Mr[1] (iteration 1 reads r2 from Mr[it % 2]) and in the short pair SP (lane 0)
-  HIPCHK(h, hipMemcpyAsync(h->Mr[1], b, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_load_lane<1>, dim3(gm), dim3(kBlock), 0, s, b, 1.0, h->SP, 0, m, h->pE, m);
-  Lane L;
-  L.state = S;
-  L.st = st_out;
-  L.st_dev = h->hstats_dev + (st_out - h->hstats);
-  *st_out = fpsq_stats{};
-  StepArgs none{};
-  none.kind = STEP_NONE;
-  launch_step(h, step_args(STEP_MINRES_BEGIN, L, 0, h->pE, gm, nullptr, 0, prog), none);
-  h->launches += 3;
-  const int look = std::max(1, o.lookahead);
-  for (int64_t it = 1; it <= itmax; ++it) {
-    double* r2 = h->Mr[it % 2];
-    double* r1 = h->Mr[(it + 1) % 2];  // also receives the new r2
-    double* w1 = h->Mw[it % 2];        // w_{k-2}, overwritten by w_k
-    double* w2 = h->Mw[(it + 1) % 2];
-    launch_spmv<1>(h, TAG_AT, h->SP, nullptr, h->LP, &S->ctlT, &S->ctlT, nullptr);  // tmp = A' r2
-    launch_spmv<1>(h, TAG_A, h->LP, h->SP, h->SP, ctl, ctl, nullptr);     // q = ca A tmp + cb r2
-    hipLaunchKernelGGL((k_minres_ew<1, 1>), dim3(gm), dim3(kBlock), 0, s, ctl, h->SP, 0, r1, r2, r1, w1, w2, w1, h->Mx, m,
-                       h->pW[0]);
-    launch_step(h, step_args(STEP_MINRES_A, L, (int)it, h->pW[0], gm, nullptr, 0, prog), none);
-    hipLaunchKernelGGL((k_minres_ew<1, 2>), dim3(gm), dim3(kBlock), 0, s, ctl, h->SP, 0, r1, r2, r1, w1, w2, w1, h->Mx, m,
-                       h->pW[1]);
-    launch_step(h, step_args(STEP_MINRES_B, L, (int)it, h->pW[1], gm, nullptr, 0, prog), none);
-    hipLaunchKernelGGL((k_minres_ew<1, 3>), dim3(gm), dim3(kBlock), 0, s, ctl, h->SP, 0, r1, r2, r1, w1, w2, w1, h->Mx, m,
-                       h->pW[0]);
-    launch_step(h, step_args(STEP_MINRES_C, L, (int)it, h->pW[0], gm, nullptr, 0, prog), none);
-    h->launches += 3;
-    if (h->prog_host[0].done) break;
-    if (it - h->prog_host[0].iter >= look) {
-      if (int rc = wait_progress(h, 0, (int)(it - look + 1), &S->ctl.done, &S->iter)) return rc;
-      if (h->prog_host[0].done) break;
-    }
-  }
-  return 0;
 }
 
 int run_lanes(fpsq_handle h, Lane* lanes, int nlanes, const TailFn* tail = nullptr) {
@@ -1939,10 +2013,6 @@ int fpsq_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2,
     h->err = "solve_two_extras: null argument";
     return FPSQ_ERR_ARG;
   }
-  if (h->comm) {
-    h->err = "solve_two_extras: not available on a row-sharded handle yet";
-    return FPSQ_ERR_STATE;
-  }
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
   order_inputs(h);
@@ -1952,15 +2022,20 @@ int fpsq_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2,
   call_begin(h);
   const double tau = std::max(h->delta, 1e-14);  // src/solve_linear_system.jl:51
   // (invJtJJv, stats) = solve_least_square(qds, Aop', rhs1, sqrt(tau))          :53
-  Lane L;
-  L.kind = LANE_LSQR;
-  L.rhs = h->in_n1;
-  L.lambda = std::sqrt(tau);
-  L.x = h->Lx[0];
-  L.st = &h->hstats[0];
-  if (int rc = run_krylov<1>(h, &L)) return rc;
+  Lane lanes[2];
+  lanes[0].kind = LANE_LSQR;
+  lanes[0].rhs = h->in_n1;
+  lanes[0].lambda = std::sqrt(tau);
+  lanes[0].x = h->Lx[0];
+  lanes[0].st = &h->hstats[0];
   // minres(JtJ, rhs2, lambda = tau)                                              :58-72
-  if (int rc = run_minres(h, h->in_m, tau, &h->hstats[1])) return rc;
+  // (fused: the MINRES recurrence shares the two products of every LSQR iteration, see run_krylov)
+  lanes[1].kind = LANE_MINRES;
+  lanes[1].rhs = h->in_m;
+  lanes[1].lambda = tau;
+  lanes[1].x = h->Mx;
+  lanes[1].st = &h->hstats[1];
+  if (int rc = run_lanes(h, lanes, 2)) return rc;
   HIPCHK(h, hipMemcpyAsync(out1, h->Lx[0], mb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(out2, h->Mx, mb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;

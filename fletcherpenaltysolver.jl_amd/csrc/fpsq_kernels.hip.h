@@ -178,7 +178,8 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
 
 enum UpdKind : int32_t {
   UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT,
-  UPD_NEG_COPY  // a[i] = -src[i][lane]: keeps c = -(CRAIG's right-hand side) when the start-up product formed it
+  UPD_NEG_COPY,  // a[i] = -src[i][lane]: keeps c = -(CRAIG's right-hand side) when the start-up product formed it
+  UPD_MINRES_E1, UPD_MINRES_E2, UPD_MINRES_E3  // the three element-wise stages of a MINRES iteration (upd_minres)
 };
 
 struct UpdSeg {
@@ -193,8 +194,10 @@ struct UpdSeg {
   // ungated).  While any lane of the call still iterates the loop goes on and the next product launch carries this
   // update -- it must not be applied twice.
   const LaneCtl* gate;
-  double* a;         // LSQR: x      CRAIG long: xs      CRAIG short: w
-  double* b;         // LSQR: w      CRAIG long: w2s     CRAIG short: y
+  double* a;         // LSQR: x      CRAIG long: xs      CRAIG short: w      MINRES: r1 (E1), r2 (E2), w (E3)
+  double* b;         // LSQR: w      CRAIG long: w2s     CRAIG short: y      MINRES: r2 (E1), r_new (E2), x (E3)
+  double* c;         // MINRES E2: w2 (read)
+  double* d;         // MINRES E2: w1 (read, overwritten by the new w~)
   int64_t len;
   double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
 };
@@ -269,9 +272,55 @@ __device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double
   if (threadIdx.x == 0) s.partials[blk] = t;
 }
 
+// MINRES (Krylov.jl minres!, M = I) on (A A' + lambda I): the three element-wise stages of an iteration on m-vectors.
+// The Lanczos vector under construction lives in lane `lane` of the short pair `src` (q after the A product).
+//   E1: y0 = q - (beta/oldbeta) r1                              partial <r2, y0>   -> alpha          (e0)
+//   E2: y = y0 - (alpha/beta) r2;  r_new = y (also back into the pair);
+//       w~ = r2/beta - delta w2 - eps w1  (stored over w1)      partial ||y||^2    -> beta_new       (e1..e4)
+//   E3: w = w~ / gamma; x += phi w                              partial ||x||^2    -> stopping tests (e5, e6)
+template <int NL, int STAGE>
+__device__ __forceinline__ void upd_minres(const UpdSeg& s, int blk, double* red) {
+  const LaneCtl* ctl = s.ctl;
+  if (STAGE == 3) {
+    if (ctl->done && ctl->upd_iter != s.it) return;
+    if (ctl->upd_iter != s.it) return;  // (stage B of this iteration did not run: nothing to apply)
+  } else if (ctl->done) {
+    return;
+  }
+  double* sp = const_cast<double*>(s.src);
+  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3], e4 = ctl->e[4], e5 = ctl->e[5],
+               e6 = ctl->e[6];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    if (STAGE == 1) {
+      const double y0 = sp[i * NL + s.lane] - (e0 != 0.0 ? e0 * s.a[i] : 0.0);
+      sp[i * NL + s.lane] = y0;
+      acc += s.b[i] * y0;
+    } else if (STAGE == 2) {
+      const double r = s.a[i];
+      const double y = sp[i * NL + s.lane] - e1 * r;
+      sp[i * NL + s.lane] = y;
+      s.b[i] = y;
+      s.d[i] = e2 * r - e3 * s.c[i] - e4 * s.d[i];
+      acc += y * y;
+    } else {
+      const double w = s.a[i] * e5;
+      s.a[i] = w;
+      const double xn = s.b[i] + e6 * w;
+      s.b[i] = xn;
+      acc += xn * xn;
+    }
+  }
+  const double t = block_sum(acc, red);
+  if (threadIdx.x == 0) s.partials[blk] = t;
+}
+
 template <int NL>
 __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
   switch (s.kind) {
+    case UPD_MINRES_E1: upd_minres<NL, 1>(s, blk, red); break;
+    case UPD_MINRES_E2: upd_minres<NL, 2>(s, blk, red); break;
+    case UPD_MINRES_E3: upd_minres<NL, 3>(s, blk, red); break;
     case UPD_LSQR: upd_lsqr<NL, false>(s, blk, red); break;
     case UPD_LSQR_WINIT: upd_lsqr<NL, true>(s, blk, red); break;
     case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true>(s, blk); break;

@@ -427,7 +427,7 @@ struct MinresState {
   double ANorm2, xENorm2, root, gammabar, phi, gamma;
   double err_vec[5];
   int32_t iter;
-  int32_t pad;
+  int32_t pub_from;
   fpsq_stats stats;
 };
 
@@ -481,7 +481,6 @@ __device__ __forceinline__ void minres_begin_step(MinresState* S, double bb, Pro
   S->ctl.ca = 1.0 / beta1;         // q = (A tmp + lambda r2) / beta
   S->ctl.cb = S->lambda / beta1;
   S->ctl.e[0] = 0.0;               // E1: beta/oldbeta (no r1 term at iteration 1)
-  publish(prog, 0, 0);
 }
 
 // after E1: alpha = <r2, y0> / beta
@@ -524,6 +523,11 @@ __device__ __forceinline__ void minres_b_step(MinresState* S, double yy, int it)
   S->ctl.e[5] = 1.0 / gamma;  // E3: w = e5 w~; x += e6 w
   S->ctl.e[6] = phi;
   S->ctl.upd_iter = it;
+  // The next iteration's product coefficients only depend on beta: set here, so the next A' product (in which E3 of
+  // THIS iteration rides) and A product need not wait for the stopping tests of stage C.
+  S->ctl.ca = (beta != 0.0) ? 1.0 / beta : 0.0;
+  S->ctl.cb = (beta != 0.0) ? S->lambda / beta : 0.0;
+  S->ctl.e[0] = (S->oldbeta != 0.0) ? beta / S->oldbeta : 0.0;
 }
 
 // after E3: ||x||, estimates and the stopping tests of minres!
@@ -575,10 +579,6 @@ __device__ __forceinline__ void minres_c_step(MinresState* S, double xx, int it,
   const bool resid_decrease = resid_decrease_mach | resid_decrease_lim;
   const bool ill_cond = ill_cond_mach | ill_cond_lim;
   const bool solved = solved_mach | solved_lim | zero_resid | fwd_err | resid_decrease;
-  // next iteration's coefficients
-  S->ctl.ca = (beta != 0.0) ? 1.0 / beta : 0.0;
-  S->ctl.cb = (beta != 0.0) ? S->lambda / beta : 0.0;
-  S->ctl.e[0] = (S->oldbeta != 0.0) ? beta / S->oldbeta : 0.0;
   if (solved | tired | ill_cond) {
     int status = FPSQ_ST_UNKNOWN;
     if (tired) status = FPSQ_ST_MAXITER;
@@ -592,43 +592,9 @@ __device__ __forceinline__ void minres_c_step(MinresState* S, double xx, int it,
     S->ctl.done = 1;
     S->ctlT.done = 1;
     publish(prog, it, 1);
-  } else {
+  } else if (it >= S->pub_from) {
     publish(prog, it, 0);
   }
-}
-
-// MINRES element-wise stages (m-vectors).  q lives in the short Golub-Kahan pair (lane `lane` of `sp`).
-template <int NL, int STAGE>
-__global__ __launch_bounds__(kBlock) void k_minres_ew(const LaneCtl* ctl, double* sp, int lane, const double* r1,
-                                                      double* r2, double* rnew, const double* w1old, const double* w2,
-                                                      double* wnew, double* x, int64_t m, double* partials) {
-  if (ctl->done) return;
-  __shared__ double red[4];
-  double acc = 0.0;
-  const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3], e4 = ctl->e[4], e5 = ctl->e[5],
-               e6 = ctl->e[6];
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-    if (STAGE == 1) {  // y0 = q - (beta/oldbeta) r1 ; <r2, y0>
-      const double y0 = sp[i * NL + lane] - (e0 != 0.0 ? e0 * r1[i] : 0.0);
-      sp[i * NL + lane] = y0;
-      acc += r2[i] * y0;
-    } else if (STAGE == 2) {  // y = y0 - (alpha/beta) r2 ; w~ ; the new r2 goes to rnew AND back into the pair
-      const double r = r2[i];
-      const double y = sp[i * NL + lane] - e1 * r;
-      sp[i * NL + lane] = y;
-      rnew[i] = y;
-      wnew[i] = e2 * r - e3 * w2[i] - e4 * w1old[i];
-      acc += y * y;
-    } else {  // w = w~ / gamma ; x += phi w ; ||x||^2
-      const double w = wnew[i] * e5;
-      wnew[i] = w;
-      const double xn = x[i] + e6 * w;
-      x[i] = xn;
-      acc += xn * xn;
-    }
-  }
-  const double t = block_sum(acc, red);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
 // =============================================================================================== step kernel

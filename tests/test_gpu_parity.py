@@ -338,24 +338,36 @@ def test_solve_two_least_squares_parity(oracle, fuse):
     H.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("delta", [0.0, 0.01])
-def test_solve_two_extras_parity(oracle, delta):
+def test_solve_two_extras_parity(oracle, delta, fuse):
     """LSQR + MINRES on A A' + tau I (src/solve_linear_system.jl:45-77): iteration parity with the C restatement at
-    the reference's default tolerances, and agreement with the exact solve."""
+    the reference's default tolerances, and agreement with the exact solve.  fuse = 1: the MINRES recurrence runs as
+    the second lane of the lock-step loop (its products share the LSQR lane's SpMMs); fuse = 0: one after the other.
+    Repeated calls (the run-ahead history) and a zero second right-hand side give the same answers."""
     qp = problems.random_eqqp(n=3000, m=300, per_row=24, seed=5)
     A = qp.scipy_csr()
     rng = np.random.default_rng(1)
     r1, r2 = rng.standard_normal(qp.n), rng.standard_normal(qp.m)
-    H = _Handle(A, delta=delta)
+    H = _Handle(A, delta=delta, fuse_two_rhs=fuse)
     a, b, rc = H.solve_two_extras(r1, r2)
     o = oracle.solve_two_extras(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, r1, r2)
     assert rc == o[3]
     for k in range(2):
         assert H.st[k].niter == o[2][k].niter and H.st[k].status == o[2][k].status
         assert H.st[k].solved == o[2][k].solved
+    assert H.st[0].niter > 5 and H.st[1].niter > 5
     ea, eb = oracle.exact_two_extras(A, delta, r1, r2)
     assert _rel(a, o[0]) < 1e-9 and _rel(b, o[1]) < 1e-9
     assert _rel(a, ea) < 1e-6 and _rel(b, eb) < 1e-6
+    a2, b2, rc2 = H.solve_two_extras(r1, r2)  # second call: the host paces itself on the first call's counts
+    assert rc2 == rc and np.array_equal(a, a2) and np.array_equal(b, b2)
+    a3, b3, _ = H.solve_two_extras(1e-3 * r1, 0.0 * r2)  # hprod! Val(1) on a model with linear constraints: Ssv = 0
+    o3 = oracle.solve_two_extras(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, 1e-3 * r1, 0.0 * r2)
+    assert np.all(b3 == 0.0) and H.st[1].niter == 0 and H.st[1].solved == o3[2][1].solved == 1
+    assert H.st[0].niter == o3[2][0].niter and _rel(a3, o3[0]) < 1e-9
+    a4, b4, _ = H.solve_two_extras(r1, r2)
+    assert np.array_equal(a, a4) and np.array_equal(b, b4)
     # tight tolerances: 1e-10 of the exact solution
     Ht = _Handle(A, delta=delta, ls_atol=1e-14, ls_rtol=1e-14, ls_axtol=1e-14, ls_btol=1e-14, ls_etol=1e-14,
                  ne_atol=1e-14, ne_rtol=1e-14, ne_etol=1e-14)
@@ -727,6 +739,22 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, delta):
     assert all((sh.stats[0].niter, sh.stats[1].niter) == (o[4][0].niter, o[4][1].niter) for sh in shards)
     assert _rel(plan.assemble([x[0] for x in outs]), o[0]) < 1e-8 and _rel(np.concatenate([x[1] for x in outs]), o[1]) < 1e-8
     assert _rel(plan.assemble([x[2] for x in outs]), o[2]) < 1e-8 and _rel(np.concatenate([x[3] for x in outs]), o[3]) < 1e-8
+    # solve_two_extras (LSQR + MINRES lanes) on the sharded handles
+    r2 = np.random.default_rng(4).standard_normal(qp.m)
+    ex = [[np.empty(l.m), np.empty(l.m)] for l in locs]
+    lib = shards[0]._lib
+
+    def extras(r):
+        sh = shards[r]
+        gw = np.ascontiguousarray(g[plan.window(r)])
+        rw = np.ascontiguousarray(r2[bounds[r]:bounds[r + 1]])
+        return sh._check(lib.fpsq_solve_two_extras(sh._h, gw.ctypes.data, rw.ctypes.data, ex[r][0].ctypes.data,
+                                                   ex[r][1].ctypes.data, sh.stats))
+
+    group.run([lambda r=r: extras(r) for r in range(nshards)])
+    oe = oracle.solve_two_extras(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, r2)
+    assert all((sh.stats[0].niter, sh.stats[1].niter) == (oe[2][0].niter, oe[2][1].niter) for sh in shards)
+    assert _rel(np.concatenate([x[0] for x in ex]), oe[0]) < 1e-8 and _rel(np.concatenate([x[1] for x in ex]), oe[1]) < 1e-8
     for sh in shards:
         sh.close()
     group.close()
