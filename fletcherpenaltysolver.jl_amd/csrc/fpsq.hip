@@ -256,6 +256,7 @@ struct fpsq_solver_s {
   LsqrState* lsqr[2];
   CraigState* craig;
   MinresState* minres;
+  LnlqState* lnlq;
   LaneCtl* ctl_tmp;
   LaneCtl* ctl_raw;             // constant {ca = 1, cb = 0, done = 0}: raw partial products before an all-reduce
   LaneCtl* ctl_pm;              // constant {1, -1}
@@ -280,7 +281,7 @@ struct fpsq_solver_s {
   const LaneCtl* gate0 = nullptr;
   const LaneCtl* gate1 = nullptr;
   bool tail_was_run = false;   // the caller's epilogue was enqueued (gated) inside run_krylov and the gates were open
-  int64_t expect_iters[4][4] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
+  int64_t expect_iters[5][5] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
   bool adaptive_runahead = true;    // FPSQ_ADAPTIVE_RUNAHEAD=0 disables (A/B)
 
   // instrumentation
@@ -879,6 +880,24 @@ __device__ __forceinline__ void craig_set_params(CraigState* S, const CraigParam
   S->ctl.upd_iter = -1;
 }
 
+struct LnlqParams {
+  double mu, atol, rtol, xsign;
+  int64_t itmax;
+  int32_t start_skipped, pub_from;
+};
+
+__device__ __forceinline__ void lnlq_set_params(LnlqState* S, const LnlqParams& P) {
+  S->mu = P.mu;
+  S->atol = P.atol;
+  S->rtol = P.rtol;
+  S->xsign = P.xsign;
+  S->itmax = P.itmax;
+  S->pub_from = P.pub_from;
+  S->ctl.done = 0;
+  S->ctl.skip = P.start_skipped;  // stays out of the LSQR lane's start-up product; lnlq_begin_step clears it
+  S->ctl.upd_iter = -1;
+}
+
 struct MinresParams {
   double lambda, atol, rtol, etol, conlim;
   int64_t itmax;
@@ -924,14 +943,15 @@ struct LoadSeg {
 };
 template <int NL>
 __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrParams P1, CraigState* C,
-                                                    CraigParams PC, MinresState* M, MinresParams PM, LoadSeg l0, LoadSeg l1,
-                                                    ZeroArgs z, int nzblk) {
+                                                    CraigParams PC, MinresState* M, MinresParams PM, LnlqState* Q,
+                                                    LnlqParams PQ, LoadSeg l0, LoadSeg l1, ZeroArgs z, int nzblk) {
   __shared__ double red[4];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (S0) lsqr_set_params(S0, P0);
     if (S1) lsqr_set_params(S1, P1);
     if (C) craig_set_params(C, PC);
     if (M) minres_set_params(M, PM);
+    if (Q) lnlq_set_params(Q, PQ);
   }
   int blk = blockIdx.x;
   if (blk < l0.nblk + l1.nblk) {
@@ -965,7 +985,9 @@ __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0
   }
 }
 
-enum { LANE_LSQR = 1, LANE_CRAIG = 2, LANE_MINRES = 3 };
+enum { LANE_LSQR = 1, LANE_CRAIG = 2, LANE_MINRES = 3, LANE_LNLQ = 4 };
+// the two least-norm recurrences share their vector plumbing (short Mu~, w, y; long v~, x)
+inline bool is_ln(int kind) { return kind == LANE_CRAIG || kind == LANE_LNLQ; }
 
 // One Krylov recurrence of a (possibly fused) run.
 struct Lane {
@@ -1088,6 +1110,8 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   CraigParams crP{};
   MinresState* mrS = nullptr;
   MinresParams mrP{};
+  LnlqState* lqS = nullptr;
+  LnlqParams lqP{};
   int minres_lane = -1;
   for (int l = 0; l < NL; ++l) {
     Lane& L = lanes[l];
@@ -1115,6 +1139,15 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       mrP = MinresParams{L.lambda, o.ne_atol, o.ne_rtol, o.ne_etol, o.ne_conlim, L.itmax, std::max(pub_from - 1, 0)};
       mrS = S;
       minres_lane = l;
+    } else if (L.kind == LANE_LNLQ) {
+      LnlqState* S = h->lnlq;
+      L.state = S;
+      L.ctl = &S->ctl;
+      // pass k of lnlq!'s loop is completed (and tested) by the step after the A' product of iteration k + 1
+      L.itmax = (o.ln_itmax == 0 ? n + m : o.ln_itmax) + 1;
+      lqP = LnlqParams{L.delta != 0.0 ? 1.0 / L.delta : 1.0, o.ln_atol, o.ln_rtol, L.xsign, L.itmax - 1, NL == 2 ? 1 : 0,
+                       std::max(pub_from - 1, 0)};
+      lqS = S;
     } else {
       CraigState* S = h->craig;
       L.state = S;
@@ -1134,7 +1167,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   const LaneCtl* t1 = lanes[NL - 1].ctlT;
   int affine_lane = -1;  // fast start: the CRAIG lane whose right-hand side the LSQR start-up product forms
   for (int l = 0; l < NL; ++l)
-    if (lanes[l].kind == LANE_CRAIG && lanes[l].affine_shift && any_lsqr && NL == 2 && !h->comm) affine_lane = l;
+    if (is_ln(lanes[l].kind) && lanes[l].affine_shift && any_lsqr && NL == 2 && !h->comm) affine_lane = l;
 
   // ---- start-up: parameters, right-hand sides, beta_1 (one launch), then (LSQR) alpha_1 and w_1
   StepArgs none{};
@@ -1194,7 +1227,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     }
   }
   hipLaunchKernelGGL(k_startup<NL>, dim3(ld[0].nblk + ld[1].nblk + nzblk), dim3(kBlock), 0, s, lsS[0], lsP[0], lsS[1], lsP[1],
-                     crS, crP, mrS, mrP, ld[0], ld[1], z, nzblk);
+                     crS, crP, mrS, mrP, lqS, lqP, ld[0], ld[1], z, nzblk);
   h->launches++;
   // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
   // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
@@ -1237,11 +1270,12 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (fuse_upd && !s1.kind) {
       // the CRAIG lane's beta_1 step shares the launch (it un-parks the lane: must follow the start-up product)
       for (int l = 0; l < NL; ++l)
-        if (lanes[l].kind == LANE_CRAIG) {
+        if (is_ln(lanes[l].kind)) {
+          const int kind = lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_BEGIN : STEP_LNLQ_BEGIN;
           if (l == affine_lane)  // ||rhs||^2 came out of the start-up product
-            s1 = step_args(STEP_CRAIG_BEGIN, lanes[l], 0, h->pS2 + (size_t)l * nbA, nbA, nullptr, 0, prog[l]);
+            s1 = step_args(kind, lanes[l], 0, h->pS2 + (size_t)l * nbA, nbA, nullptr, 0, prog[l]);
           else
-            s1 = step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]);
+            s1 = step_args(kind, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]);
           craig_begun = true;
         }
     }
@@ -1264,8 +1298,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     }
   }
   for (int l = 0; l < NL; ++l)
-    if (lanes[l].kind == LANE_CRAIG && !craig_begun)
-      if (int rc = launch_step(h, step_args(STEP_CRAIG_BEGIN, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]),
+    if (is_ln(lanes[l].kind) && !craig_begun)
+      if (int rc = launch_step(h, step_args(lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_BEGIN : STEP_LNLQ_BEGIN, lanes[l], 0,
+                                            l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]),
                                none, /*sharded=*/true))
         return rc;
 
@@ -1340,10 +1375,11 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   auto iter_ptr = [&](int l) -> const int32_t* {
     return lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->iter
            : lanes[l].kind == LANE_CRAIG ? &((CraigState*)lanes[l].state)->iter
+           : lanes[l].kind == LANE_LNLQ  ? &((LnlqState*)lanes[l].state)->iter
                                          : &((MinresState*)lanes[l].state)->iter;
   };
-  // a MINRES lane reports iteration k (its step C) while the host is enqueueing iteration k + 1
-  auto lag = [&](int l) { return lanes[l].kind == LANE_MINRES ? 1 : 0; };
+  // a MINRES / LNLQ lane reports iteration k (step C; pass k) while the host is enqueueing iteration k + 1
+  auto lag = [&](int l) { return lanes[l].kind == LANE_MINRES || lanes[l].kind == LANE_LNLQ ? 1 : 0; };
   const bool split_steps = h->comm && !h->halo;  // replicated n-sums and per-rank m-sums cannot share a presum launch
   while (it < itmax_all) {
     ++it;
@@ -1377,8 +1413,8 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         if (it > 1) sa[l] = step_args(STEP_MINRES_C, lanes[l], (int)it - 1, h->pW[l], gm, nullptr, 0, prog[l]);
         continue;
       }
-      sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : STEP_CRAIG_SA, lanes[l], (int)it,
-                        h->pS + (size_t)l * npT, npT, nullptr, 0, prog[l]);
+      sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SA : STEP_LNLQ_SA,
+                        lanes[l], (int)it, h->pS + (size_t)l * npT, npT, nullptr, 0, prog[l]);
     }
     // sums over n-vectors: replicated (no all-reduce) unless the n-vectors are column windows (halo mode); MINRES' sums
     // run over (row-sharded) m-vectors
@@ -1400,9 +1436,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     UpdSeg cu[2] = {seg_none(), seg_none()};
     for (int l = 0; l < NL; ++l) {
       const Lane& L = lanes[l];
-      if (L.kind != LANE_CRAIG) continue;
+      if (!is_ln(L.kind)) continue;
       UpdSeg u{};
-      u.kind = L.delta != 0.0 ? UPD_CRAIG_LONG_REG : UPD_CRAIG_LONG;
+      u.kind = L.kind == LANE_LNLQ ? UPD_LNLQ_LONG : L.delta != 0.0 ? UPD_CRAIG_LONG_REG : UPD_CRAIG_LONG;
       u.it = (int)it;
       u.ctl = L.ctl;
       u.src = LP;
@@ -1413,7 +1449,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       u.len = n;
       cu[0] = u;
       UpdSeg v{};
-      v.kind = UPD_CRAIG_SHORT;
+      v.kind = L.kind == LANE_LNLQ ? UPD_LNLQ_SHORT : UPD_CRAIG_SHORT;
       v.it = (int)it;
       v.ctl = L.ctl;
       v.src = SPcur;
@@ -1442,8 +1478,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       if (lanes[l].kind == LANE_MINRES)
         sb[l] = step_args(STEP_MINRES_A, lanes[l], (int)it, h->pE3, gm, nullptr, 0, prog[l]);
       else
-        sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : STEP_CRAIG_SB, lanes[l], (int)it,
-                          h->pS2 + (size_t)l * nbA, nbA, h->pW[l], gm, prog[l]);
+        sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SB : STEP_LNLQ_SB,
+                          lanes[l], (int)it, h->pS2 + (size_t)l * nbA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : h->pW[l],
+                          gm, prog[l]);
     }
     if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
     if (minres_lane >= 0) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
@@ -1623,7 +1660,7 @@ int two_mixed_device(fpsq_handle h, const double* g, double* c, bool defer_p1 = 
   lanes[0].x = h->Lx[0];
   lanes[0].st = &h->hstats[0];
   // (p2, q2, stats2) = solve_least_norm(qds, Aop, -rhs2, delta); p2 = -p2 :132-133
-  lanes[1].kind = LANE_CRAIG;
+  lanes[1].kind = h->opt.ln_method == FPSQ_LN_LNLQ ? LANE_LNLQ : LANE_CRAIG;
   lanes[1].rhs = c;
   lanes[1].rhs_scale = -1.0;
   if (affine_shift) {
@@ -1751,10 +1788,11 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  if ((e = hipMalloc(&p, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 4 * sizeof(LaneCtl) + 64 * sizeof(double))) != hipSuccess)
-    return fail("hipMalloc", e);
+  const size_t state_bytes = sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + sizeof(LnlqState) +
+                             4 * sizeof(LaneCtl) + 64 * sizeof(double);
+  if ((e = hipMalloc(&p, state_bytes)) != hipSuccess) return fail("hipMalloc", e);
   h->allocs.push_back(p);
-  hipMemset(p, 0, sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + 4 * sizeof(LaneCtl) + 64 * sizeof(double));
+  hipMemset(p, 0, state_bytes);
   char* cp = (char*)p;
   h->lsqr[0] = (LsqrState*)cp;
   h->lsqr[1] = h->lsqr[0] + 1;
@@ -1763,6 +1801,8 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   cp += sizeof(CraigState);
   h->minres = (MinresState*)cp;
   cp += sizeof(MinresState);
+  h->lnlq = (LnlqState*)cp;
+  cp += sizeof(LnlqState);
   h->ctl_tmp = (LaneCtl*)cp;
   cp += sizeof(LaneCtl);
   h->ctl_raw = (LaneCtl*)cp;

@@ -179,7 +179,8 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
 enum UpdKind : int32_t {
   UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT,
   UPD_NEG_COPY,  // a[i] = -src[i][lane]: keeps c = -(CRAIG's right-hand side) when the start-up product formed it
-  UPD_MINRES_E1, UPD_MINRES_E2, UPD_MINRES_E3  // the three element-wise stages of a MINRES iteration (upd_minres)
+  UPD_MINRES_E1, UPD_MINRES_E2, UPD_MINRES_E3,  // the three element-wise stages of a MINRES iteration (upd_minres)
+  UPD_LNLQ_LONG, UPD_LNLQ_SHORT                 // LNLQ: x and (y, wbar) updates (upd_lnlq_*)
 };
 
 struct UpdSeg {
@@ -315,9 +316,41 @@ __device__ __forceinline__ void upd_minres(const UpdSeg& s, int blk, double* red
   if (threadIdx.x == 0) s.partials[blk] = t;
 }
 
+// LNLQ (Krylov.jl lnlq!, lambda = 0), long (n) part: xs += e0 * vt  with vt = alpha v the stored Golub-Kahan vector
+//   e0 = sgn tau_k / alpha_k while iterating; at the end the transfer step sgn tau / alpha (CRAIG point) or
+//   sgn eta zeta / alpha (LQ point).
+template <int NL>
+__device__ __forceinline__ void upd_lnlq_long(const UpdSeg& s, int blk) {
+  const LaneCtl* ctl = s.ctl;
+  if (ctl->done && ctl->upd_iter != s.it) return;
+  const double e0 = ctl->e[0];
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock)
+    s.a[i] += e0 * s.src[i * NL + s.lane];
+}
+
+// LNLQ short (m) part, with u = e4 * mut (= mu Mu~ / beta):
+//   y += e5 * wbar + e6 * u            (= zeta_k w_k,  w_k = c wbar + s u)
+//   wbar <- e2 * wbar + e3 * u         (= s wbar - c u)
+//   y += e7 * wbar_new                 (transfer to the CRAIG point when the recurrence ends there, else e7 = 0)
+template <int NL>
+__device__ __forceinline__ void upd_lnlq_short(const UpdSeg& s, int blk) {
+  const LaneCtl* ctl = s.ctl;
+  if (ctl->done && ctl->upd_iter != s.it) return;
+  const double e2 = ctl->e[2], e3 = ctl->e[3], e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6], e7 = ctl->e[7];
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
+    const double u = e4 * s.src[i * NL + s.lane];
+    const double wb = s.a[i];
+    const double wn = e2 * wb + e3 * u;
+    s.a[i] = wn;
+    s.b[i] += (e5 * wb + e6 * u) + (e7 != 0.0 ? e7 * wn : 0.0);
+  }
+}
+
 template <int NL>
 __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
   switch (s.kind) {
+    case UPD_LNLQ_LONG: upd_lnlq_long<NL>(s, blk); break;
+    case UPD_LNLQ_SHORT: upd_lnlq_short<NL>(s, blk); break;
     case UPD_MINRES_E1: upd_minres<NL, 1>(s, blk, red); break;
     case UPD_MINRES_E2: upd_minres<NL, 2>(s, blk, red); break;
     case UPD_MINRES_E3: upd_minres<NL, 3>(s, blk, red); break;

@@ -412,6 +412,142 @@ __device__ __forceinline__ void craig_sb_step(CraigState* S, double bb, double w
   }
 }
 
+// =============================================================================================== LNLQ
+// Estrin, Orban & Saunders (2019); Krylov.jl lnlq! with N = I, lambda = 0, sigma = 0, transfer_to_craig = true, as
+// the reference's GENERIC solve_least_norm calls it (src/solve_two_systems_struct.jl:251-281; the commented default
+// workspace of :121): M = (1/delta) I when delta != 0 -- WITHOUT sqd, so M only preconditions (mu = 1/delta or 1).
+// Same Golub-Kahan vectors as CRAIG ("short" Mu~, wbar, y in R^m, "long" v~, x in R^n); pass k of lnlq!'s loop needs
+// beta_{k+1} (A product of iteration k) AND alpha_{k+1} (A' product of iteration k + 1), so its scalars, its stopping
+// tests and the coefficients of its vector updates are computed by the step that follows the A' product of iteration
+// k + 1, together with the x update that opens pass k + 1 (or the transfer to the final point).
+struct LnlqState {
+  LaneCtl ctl;
+  double mu, atol, rtol, xsign;
+  int64_t itmax;
+  double alpha, beta, bNorm, eps_l, ahat, epsbar, tau, zetabar, zeta_km1, eta, ck, sk;
+  int32_t iter;      // passes of lnlq!'s loop completed
+  int32_t pub_from;
+  fpsq_stats stats;
+};
+
+// after Mu~ = b: beta_1 = sqrt(mu) ||b||, ||b||_2 for the tolerance
+__device__ __forceinline__ void lnlq_begin_step(LnlqState* S, double bb, Progress* prog) {
+  const double bNorm = sqrt(bb);
+  S->bNorm = bNorm;
+  S->iter = 0;
+  S->ctl.skip = 0;
+  S->ctl.upd_iter = -1;
+  S->stats = fpsq_stats{0, 0, 0, FPSQ_ST_UNKNOWN, bNorm, 0.0};
+  if (bNorm == 0.0) {
+    S->stats.solved = 1;
+    S->stats.status = FPSQ_ST_ZERO_RHS;
+    S->ctl.done = 1;
+    publish(prog, 0, 1);
+    return;
+  }
+  S->eps_l = S->atol + S->rtol * bNorm;
+  const double beta1 = sqrt(S->mu * bb);
+  S->beta = beta1;
+  S->ctl.done = 0;
+  S->ctl.ca = S->mu / beta1;  // v~_1 = B'u_1 = (mu / beta1) B' Mu~
+  S->ctl.cb = 0.0;
+}
+
+// after v~ <- B'u - beta v (A' product of iteration it): alpha_it; it = 1: the initialisation of lnlq!; it >= 2:
+// pass k = it - 1 of its loop (scalars, stopping tests), then the coefficients of the updates riding in the A product.
+__device__ __forceinline__ void lnlq_sa_step(LnlqState* S, double aa, int it, Progress* prog) {
+  const double alpha_n = sqrt(aa);
+  const double sx = S->xsign;
+  S->ctl.upd_iter = it;  // the updates of this iteration always run (they carry the transfer to the final point)
+  S->ctl.e[4] = (S->beta != 0.0) ? S->mu / S->beta : 0.0;  // u = mu Mu~ / beta
+  if (it == 1) {
+    S->alpha = alpha_n;
+    S->ahat = alpha_n;
+    S->epsbar = alpha_n;
+    S->tau = S->beta / alpha_n;
+    S->zetabar = S->tau / S->epsbar;
+    S->zeta_km1 = 0.0;
+    S->eta = 0.0;
+    S->ck = 0.0;
+    S->sk = 0.0;
+    // wbar_1 = u_1 (wbar starts at 0: s = 0, c = -1), nothing for y yet; x_aux += tau_1 v_1
+    S->ctl.e[2] = 0.0;
+    S->ctl.e[3] = 1.0;
+    S->ctl.e[5] = 0.0;
+    S->ctl.e[6] = 0.0;
+    S->ctl.e[7] = 0.0;
+    S->ctl.e[0] = (alpha_n != 0.0) ? sx * S->tau / alpha_n : 0.0;
+    S->ctl.ca = (alpha_n != 0.0) ? 1.0 / alpha_n : 0.0;  // Mu~ <- B v~ / alpha - (alpha / beta) Mu~
+    S->ctl.cb = -alpha_n / S->beta;
+    return;
+  }
+  const int k = it - 1;  // `iter` of lnlq! during this pass
+  const double beta_n = S->beta, bhat_n = beta_n, ahat_n = alpha_n;
+  double c_n, s_n, eps_k;
+  sym_givens(S->epsbar, bhat_n, c_n, s_n, eps_k);
+  const double eta_n = ahat_n * s_n;
+  const double epsbar_n = -ahat_n * c_n;
+  const double tau_n = -bhat_n * S->tau / ahat_n;
+  const double zeta_k = c_n * S->zetabar;
+  const double zetabar_n = (tau_n - eta_n * zeta_k) / epsbar_n;
+  double rNorm_lq = S->bNorm;
+  if (k != 1) {
+    const double t1 = S->epsbar * S->zetabar, t2 = bhat_n * S->sk * S->zeta_km1;
+    rNorm_lq = fabs(S->ahat) * sqrt(t1 * t1 + t2 * t2);
+  }
+  const double rNorm_cg = fabs(bhat_n * S->tau);
+  S->ck = c_n;
+  S->sk = s_n;
+  S->alpha = alpha_n;
+  S->ahat = ahat_n;
+  S->eta = eta_n;
+  S->epsbar = epsbar_n;
+  S->tau = tau_n;
+  S->zeta_km1 = zeta_k;
+  S->zetabar = zetabar_n;
+  const bool tired = k >= S->itmax;
+  const bool solved_lq = rNorm_lq <= S->eps_l;
+  const bool solved_cg = rNorm_cg <= S->eps_l;
+  S->iter = k;
+  // y += zeta_k (c wbar + s u);  wbar <- s wbar - c u
+  S->ctl.e[2] = s_n;
+  S->ctl.e[3] = -c_n;
+  S->ctl.e[5] = zeta_k * c_n;
+  S->ctl.e[6] = zeta_k * s_n;
+  S->ctl.e[7] = 0.0;
+  S->stats.niter = k + 1;  // lnlq! advances its counter at the end of every pass, including the last
+  if (solved_lq | solved_cg | tired) {
+    int status = FPSQ_ST_UNKNOWN;
+    if (tired) status = FPSQ_ST_MAXITER;
+    if (solved_lq) status = FPSQ_ST_SOLVED_LQ;
+    if (solved_cg) status = FPSQ_ST_SOLVED;
+    S->stats.status = status;
+    S->stats.solved = solved_lq | solved_cg;
+    S->stats.inconsistent = 0;
+    S->stats.rnorm = solved_cg ? rNorm_cg : rNorm_lq;
+    // transfer: CRAIG point x += tau v, y += zetabar wbar;  else LQ point x += eta zeta v
+    const double cx = solved_cg ? tau_n : eta_n * zeta_k;
+    S->ctl.e[0] = (alpha_n != 0.0) ? sx * cx / alpha_n : 0.0;
+    S->ctl.e[7] = solved_cg ? zetabar_n : 0.0;
+    S->ctl.done = 1;
+    publish(prog, k, 1);
+    return;
+  }
+  S->stats.rnorm = rNorm_lq;
+  S->ctl.e[0] = (alpha_n != 0.0) ? sx * tau_n / alpha_n : 0.0;  // x_aux += tau_{k+1} v_{k+1}: opens pass k + 1
+  S->ctl.ca = (alpha_n != 0.0) ? 1.0 / alpha_n : 0.0;
+  S->ctl.cb = -alpha_n / beta_n;
+  if (k >= S->pub_from) publish(prog, k, 0);
+}
+
+// after Mu~ <- B v - alpha Mu (A product of iteration it): beta_{it+1}; coefficients of the next A' product
+__device__ __forceinline__ void lnlq_sb_step(LnlqState* S, double bb) {
+  const double beta = sqrt(S->mu * bb);
+  S->beta = beta;
+  S->ctl.ca = (beta != 0.0) ? S->mu / beta : 0.0;  // v~ <- (mu / beta) B' Mu~ - (beta / alpha) v~
+  S->ctl.cb = -beta / S->alpha;
+}
+
 // =============================================================================================== MINRES
 // (A A' + lambda I) x = b, all vectors in R^m; Krylov.jl minres! with M = I (src/solve_linear_system.jl:58-70).
 // Per iteration: tmp = A' r2 (n), q = (A tmp + lambda r2) / beta, then three short element-wise stages:
@@ -604,7 +740,8 @@ enum StepKind : int32_t {
   STEP_NONE = 0,
   STEP_LSQR_BEGIN, STEP_LSQR_BEGIN2, STEP_LSQR_SA, STEP_LSQR_SB,
   STEP_CRAIG_BEGIN, STEP_CRAIG_SA, STEP_CRAIG_SB,
-  STEP_MINRES_BEGIN, STEP_MINRES_A, STEP_MINRES_B, STEP_MINRES_C
+  STEP_MINRES_BEGIN, STEP_MINRES_A, STEP_MINRES_B, STEP_MINRES_C,
+  STEP_LNLQ_BEGIN, STEP_LNLQ_SA, STEP_LNLQ_SB
 };
 
 struct StepArgs {
@@ -689,13 +826,14 @@ __device__ __forceinline__ void reduce_two(const double* p0, int n0, const doubl
 __device__ __forceinline__ bool lane_done(const StepArgs& a) {
   // LaneCtl is the first member of every state struct
   return a.kind != STEP_LSQR_BEGIN && a.kind != STEP_CRAIG_BEGIN && a.kind != STEP_MINRES_BEGIN &&
-         reinterpret_cast<const LaneCtl*>(a.state)->done;
+         a.kind != STEP_LNLQ_BEGIN && reinterpret_cast<const LaneCtl*>(a.state)->done;
 }
 
 __device__ __forceinline__ int state_bytes(int kind) {
   switch (kind) {
     case STEP_LSQR_BEGIN: case STEP_LSQR_BEGIN2: case STEP_LSQR_SA: case STEP_LSQR_SB: return (int)sizeof(LsqrState);
     case STEP_CRAIG_BEGIN: case STEP_CRAIG_SA: case STEP_CRAIG_SB: return (int)sizeof(CraigState);
+    case STEP_LNLQ_BEGIN: case STEP_LNLQ_SA: case STEP_LNLQ_SB: return (int)sizeof(LnlqState);
     default: return (int)sizeof(MinresState);
   }
 }
@@ -727,10 +865,14 @@ __global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1)
       case STEP_MINRES_A: minres_a_step((MinresState*)S, s0); break;
       case STEP_MINRES_B: minres_b_step((MinresState*)S, s0, a.it); break;
       case STEP_MINRES_C: minres_c_step((MinresState*)S, s0, a.it, a.prog); break;
+      case STEP_LNLQ_BEGIN: lnlq_begin_step((LnlqState*)S, s0, a.prog); break;
+      case STEP_LNLQ_SA: lnlq_sa_step((LnlqState*)S, s0, a.it, a.prog); break;
+      case STEP_LNLQ_SB: lnlq_sb_step((LnlqState*)S, s0); break;
       default: break;
     }
     if (a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
-      const fpsq_stats* fin = a.kind >= STEP_MINRES_BEGIN ? &((MinresState*)S)->stats
+      const fpsq_stats* fin = a.kind >= STEP_LNLQ_BEGIN ? &((LnlqState*)S)->stats
+                              : a.kind >= STEP_MINRES_BEGIN ? &((MinresState*)S)->stats
                               : a.kind >= STEP_CRAIG_BEGIN ? &((CraigState*)S)->stats
                                                            : &((LsqrState*)S)->stats;
       *a.host_stats = *fin;
@@ -744,5 +886,6 @@ __global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1)
 static_assert(sizeof(LsqrState) % 8 == 0 && sizeof(LsqrState) <= 640, "state staging");
 static_assert(sizeof(CraigState) % 8 == 0 && sizeof(CraigState) <= 640, "state staging");
 static_assert(sizeof(MinresState) % 8 == 0 && sizeof(MinresState) <= 640, "state staging");
+static_assert(sizeof(LnlqState) % 8 == 0 && sizeof(LnlqState) <= 640, "state staging");
 
 }  // namespace fpsq

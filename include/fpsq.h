@@ -58,7 +58,15 @@ enum {
   FPSQ_ST_FWD_ERR = 5,      /* "truncated forward error small enough" */
   FPSQ_ST_ILL_COND = 6,     /* condition number limit */
   FPSQ_ST_MAXITER = 7,      /* "maximum number of iterations exceeded" */
-  FPSQ_ST_INCONSISTENT = 8  /* "system may be inconsistent" (CRAIG) */
+  FPSQ_ST_INCONSISTENT = 8, /* "system may be inconsistent" (CRAIG) */
+  FPSQ_ST_SOLVED_LQ = 9     /* LNLQ: "solutions xL and yL good enough" (FPSQ_ST_SOLVED: the CRAIG point xC, yC) */
+};
+
+/* least-norm method of solve_two_mixed / ys_gs / qp_objgrad (fpsq_options.ln_method) */
+enum {
+  FPSQ_LN_CRAIG = 0, /* craig! with sqd and M = (1/delta) I: the reference's default workspace (struct.jl:121, :210-244) */
+  FPSQ_LN_LNLQ = 1   /* lnlq! through the generic solve_least_norm (struct.jl:251-281; the commented alternative of
+                        :121): M = (1/delta) I WITHOUT sqd, i.e. the minimum-norm solution of A x = -c for every delta */
 };
 
 /* The fields of Krylov.jl's `stats` that the reference reads
@@ -91,6 +99,9 @@ typedef struct {
   int32_t device;        /* HIP device ordinal */
   int32_t jac_format;    /* storage of A for the A product: 0 = auto (column-sorted row groups when every group spans
                             < 2^21 columns, else CSR), 1 = CSR only */
+  int32_t ln_method;     /* FPSQ_LN_CRAIG (default) or FPSQ_LN_LNLQ: which Krylov.jl workspace `solver_struct_least_norm`
+                            would be (src/solve_two_systems_struct.jl:121) */
+  int32_t reserved;
 } fpsq_options;
 
 /* defaults of src/solve_two_systems_struct.jl:99-115 for an (n, m) problem; fuse_two_rhs = 1 */

@@ -61,7 +61,8 @@ enum {
   FPO_ST_FWD_ERR = 5,     /* truncated forward error small enough */
   FPO_ST_ILL_COND = 6,    /* condition number limit */
   FPO_ST_MAXITER = 7,     /* maximum number of iterations exceeded */
-  FPO_ST_INCONSISTENT = 8 /* system may be inconsistent (craig) */
+  FPO_ST_INCONSISTENT = 8, /* system may be inconsistent (craig) */
+  FPO_ST_SOLVED_LQ = 9     /* lnlq: "solutions xL and yL good enough" (FPO_ST_SOLVED = the CRAIG point xC, yC) */
 };
 
 typedef struct {
@@ -75,6 +76,10 @@ typedef struct {
   /* Krylov.jl lsqr! keyword arguments that the reference leaves at their defaults (sqrt(eps), 1/sqrt(eps));
    * exposed so tests can run the same recurrences to tighter accuracy than the defaults allow */
   double ls_axtol, ls_btol, ls_etol, ls_conlim;
+  /* least-norm method of solve_two_mixed: 0 = craig! (the reference's default workspace, struct.jl:121),
+   * 1 = lnlq! through the generic solve_least_norm (the commented alternative of struct.jl:121; :251-281) */
+  int32_t ln_method;
+  int32_t pad;
 } fpo_options;
 
 /* defaults of IterativeSolver, solve_two_systems_struct.jl:99-115 */
@@ -97,6 +102,8 @@ void fpo_default_options(int64_t n, int64_t m, fpo_options *o) {
   o->ls_btol = se;
   o->ls_etol = se;
   o->ls_conlim = 1.0 / se;
+  o->ln_method = 0;
+  o->pad = 0;
 }
 
 /* ------------------------------------------------------------------ basic linear algebra */
@@ -549,6 +556,106 @@ done:
   return 0;
 }
 
+/* ------------------------------------------------------------------ LNLQ
+ * Estrin, Orban & Saunders, "LNLQ: an iterative method for least-norm problems with an error minimization
+ * property", SIMAX 40(3), 2019; Krylov.jl lnlq! with N = I, lambda = 0, sigma = 0 (no error bounds),
+ * transfer_to_craig = true (the default).  The reference reaches it through the GENERIC solve_least_norm
+ * (solve_two_systems_struct.jl:251-281), which passes M = (1/delta) I for delta != 0 but neither `sqd` nor a
+ * regularisation: M then only preconditions -- the answer is the minimum-norm solution of Bx = b whatever delta is,
+ * reached after a different number of passes because the residual estimates are measured in the M-norm while
+ * eps = atol + rtol ||b||_2 is not.  `mu` = 1/delta (or 1).  iter counts as in lnlq!: it is advanced at the end of
+ * every pass of the loop, including the last one, so niter = passes + 1. */
+int fpo_lnlq_op(const fpo_op *B, const double *b, double delta_reg, double atol, double rtol, int64_t itmax,
+                double *x, double *y, fpo_stats *st) {
+  const int64_t m = op_rows(B), n = op_cols(B);
+  const double mu = delta_reg != 0.0 ? 1.0 / delta_reg : 1.0; /* M = mu I */
+  double *Mu = malloc((size_t)m * 8), *u = malloc((size_t)m * 8), *Nv = malloc((size_t)n * 8);
+  double *wbar = malloc((size_t)m * 8), *Av = malloc((size_t)m * 8), *Atu = malloc((size_t)n * 8);
+  memset(st, 0, sizeof *st);
+  memset(x, 0, (size_t)n * 8);
+  memset(y, 0, (size_t)m * 8);
+  const double bNorm = nrm2(m, b);
+  if (bNorm == 0.0) {
+    st->solved = 1; st->niter = 0; st->status = FPO_ST_ZERO_RHS;
+    goto done;
+  }
+  const double eps_l = atol + rtol * bNorm;
+  int64_t iter = 0;
+  if (itmax == 0) itmax = m + n;
+  iter = iter + 1;
+  /* beta_1 M u_1 = b */
+  memcpy(Mu, b, (size_t)m * 8);
+  for (int64_t i = 0; i < m; ++i) u[i] = mu * Mu[i];
+  double beta = sqrt(dotp(m, u, Mu));
+  if (beta != 0.0) { scal(m, 1.0 / beta, u); scal(m, 1.0 / beta, Mu); }
+  /* alpha_1 N v_1 = B' u_1 */
+  op_tmul(B, u, Atu);
+  memcpy(Nv, Atu, (size_t)n * 8);
+  double alpha = nrm2(n, Nv);
+  if (alpha != 0.0) scal(n, 1.0 / alpha, Nv);
+  memcpy(wbar, u, (size_t)m * 8);
+  double ck = 0.0, sk = 0.0, zeta_km1 = 0.0, eta = 0.0;
+  double ahat = alpha, epsbar = ahat;
+  double tau = beta / ahat, zetabar = tau / epsbar;
+  int solved_lq = 0, solved_cg = 0, tired = 0;
+  double rNorm_lq = bNorm, rNorm_cg = bNorm;
+  while (!(solved_lq || solved_cg || tired)) {
+    /* (x aux)_k = V_k t_k */
+    axpy(n, tau, Nv, x);
+    /* beta_{k+1} M u_{k+1} = B v_k - alpha_k M u_k */
+    op_mul(B, Nv, Av);
+    axpby(m, 1.0, Av, -alpha, Mu);
+    for (int64_t i = 0; i < m; ++i) u[i] = mu * Mu[i];
+    const double beta_n = sqrt(dotp(m, u, Mu));
+    if (beta_n != 0.0) { scal(m, 1.0 / beta_n, u); scal(m, 1.0 / beta_n, Mu); }
+    /* alpha_{k+1} N v_{k+1} = B' u_{k+1} - beta_{k+1} N v_k */
+    op_tmul(B, u, Atu);
+    axpby(n, 1.0, Atu, -beta_n, Nv);
+    const double alpha_n = nrm2(n, Nv);
+    if (alpha_n != 0.0) scal(n, 1.0 / alpha_n, Nv);
+    const double bhat_n = beta_n, ahat_n = alpha_n; /* lambda = 0 */
+    /* continue the LQ factorisation of (L_{k+1})' */
+    double c_n, s_n, eps_k;
+    sym_givens(epsbar, bhat_n, &c_n, &s_n, &eps_k);
+    const double eta_n = ahat_n * s_n;
+    const double epsbar_n = -ahat_n * c_n;
+    const double tau_n = -bhat_n * tau / ahat_n;
+    const double zeta_k = c_n * zetabar;
+    const double zetabar_n = (tau_n - eta_n * zeta_k) / epsbar_n;
+    /* (y^L)_{k+1} = (y^L)_k + zeta_k w_k,  w_k = c wbar_k + s u_{k+1};  wbar_{k+1} = s wbar_k - c u_{k+1} */
+    axpy(m, zeta_k * c_n, wbar, y);
+    axpy(m, zeta_k * s_n, u, y);
+    axpby(m, -c_n, u, s_n, wbar);
+    if (iter == 1) rNorm_lq = bNorm;
+    else rNorm_lq = fabs(ahat) * sqrt((epsbar * zetabar) * (epsbar * zetabar) + (bhat_n * sk * zeta_km1) * (bhat_n * sk * zeta_km1));
+    rNorm_cg = fabs(bhat_n * tau);
+    ck = c_n; sk = s_n; alpha = alpha_n; ahat = ahat_n; beta = beta_n; eta = eta_n; epsbar = epsbar_n; tau = tau_n;
+    zeta_km1 = zeta_k; zetabar = zetabar_n;
+    tired = iter >= itmax;
+    solved_lq = rNorm_lq <= eps_l;
+    solved_cg = rNorm_cg <= eps_l;
+    iter = iter + 1;
+  }
+  (void)ck;
+  if (solved_cg) { /* transfer to the CRAIG point */
+    axpy(n, tau, Nv, x);
+    axpy(m, zetabar, wbar, y);
+  } else {
+    axpy(n, eta * zeta_km1, Nv, x);
+  }
+  st->status = FPO_ST_UNKNOWN;
+  if (tired) st->status = FPO_ST_MAXITER;
+  if (solved_lq) st->status = FPO_ST_SOLVED_LQ;
+  if (solved_cg) st->status = FPO_ST_SOLVED;
+  st->niter = (int32_t)iter;
+  st->solved = solved_lq || solved_cg;
+  st->inconsistent = 0;
+  st->rnorm = solved_cg ? rNorm_cg : rNorm_lq;
+done:
+  free(Mu); free(u); free(Nv); free(wbar); free(Av); free(Atu);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ MINRES on (A A' + lambda I) y = b
  * Krylov.jl minres! with M = I, applied to the product operator `nlp.Aop * nlp.Aop'`
  * (solve_linear_system.jl:58-70). */
@@ -704,6 +811,14 @@ int fpo_craig(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colind
   return fpo_craig_op(&B, b, delta, atol, rtol, btol, conlim, itmax, x, y, st);
 }
 
+int fpo_lnlq(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colind, const double *vals, int transposed,
+             const double *b, double delta, double atol, double rtol, int64_t itmax, double *x, double *y,
+             fpo_stats *st) {
+  fpo_csr A = {m, n, rowptr, colind, vals};
+  fpo_op B = {&A, transposed};
+  return fpo_lnlq_op(&B, b, delta, atol, rtol, itmax, x, y, st);
+}
+
 int fpo_minres(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colind, const double *vals,
                const double *b, double lambda, double atol, double rtol, double etol, double conlim,
                int64_t itmax, double *x, fpo_stats *st) {
@@ -733,7 +848,10 @@ int fpo_solve_two_mixed(int64_t m, int64_t n, const int64_t *rowptr, const int64
   /* (p2, q2, stats2) = solve_least_norm(qds, Aop, -rhs2, delta); p2 = -p2       :132-133 */
   double *nrhs2 = malloc((size_t)m * 8);
   for (int64_t i = 0; i < m; ++i) nrhs2[i] = -rhs2[i];
-  fpo_craig_op(&Aop, nrhs2, delta, o->ln_atol, o->ln_rtol, o->ln_btol, o->ln_conlim, o->ln_itmax, p2, q2, &st[1]);
+  if (o->ln_method == 1) /* the generic solve_least_norm with an LNLQ workspace, struct.jl:251-281 */
+    fpo_lnlq_op(&Aop, nrhs2, delta, o->ln_atol, o->ln_rtol, o->ln_itmax, p2, q2, &st[1]);
+  else
+    fpo_craig_op(&Aop, nrhs2, delta, o->ln_atol, o->ln_rtol, o->ln_btol, o->ln_conlim, o->ln_itmax, p2, q2, &st[1]);
   for (int64_t i = 0; i < n; ++i) p2[i] = -p2[i];
   free(nrhs2);
   return (st[0].solved ? 0 : 1) | (st[1].solved ? 0 : 2);

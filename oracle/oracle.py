@@ -39,7 +39,7 @@ class Options(C.Structure):
                 ("ne_atol", C.c_double), ("ne_rtol", C.c_double), ("ne_etol", C.c_double),
                 ("ne_itmax", C.c_int64), ("ne_conlim", C.c_double),
                 ("ls_axtol", C.c_double), ("ls_btol", C.c_double), ("ls_etol", C.c_double),
-                ("ls_conlim", C.c_double)]
+                ("ls_conlim", C.c_double), ("ln_method", C.c_int32), ("pad", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -123,6 +123,22 @@ def craig(m, n, rowptr, colind, vals, b, delta=0.0, atol=None, rtol=None, btol=N
     lib().fpo_craig(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va), C.c_int(transposed),
                     _p(b), C.c_double(delta), C.c_double(atol), C.c_double(rtol), C.c_double(btol),
                     C.c_double(conlim), C.c_int64(itmax), _p(x), _p(y), C.byref(st))
+    return x, y, st
+
+
+def lnlq(m, n, rowptr, colind, vals, b, delta=0.0, atol=None, rtol=None, itmax=0, transposed=False):
+    """C restatement of Krylov.jl lnlq! as the reference's generic solve_least_norm calls it (struct.jl:251-281)."""
+    se = np.sqrt(np.finfo(float).eps)
+    atol = se if atol is None else atol
+    rtol = se if rtol is None else rtol
+    rp, ci, va = _csr64(rowptr, colind, vals)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.empty(m if transposed else n)
+    y = np.empty(n if transposed else m)
+    st = Stats()
+    lib().fpo_lnlq(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va), C.c_int(transposed),
+                   _p(b), C.c_double(delta), C.c_double(atol), C.c_double(rtol), C.c_int64(itmax), _p(x), _p(y),
+                   C.byref(st))
     return x, y, st
 
 

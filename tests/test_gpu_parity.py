@@ -377,6 +377,50 @@ def test_solve_two_extras_parity(oracle, delta, fuse):
     Ht.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("delta", [0.0, SE, 0.25])
+def test_lnlq_method_parity(oracle, delta, fuse):
+    """fpsq_options.ln_method = FPSQ_LN_LNLQ: the least-norm system through LNLQ as the reference's generic
+    solve_least_norm would run it with an LNLQ workspace (struct.jl:121, :251-281) -- lane for lane against the C
+    restatement (niter, status, solved, vectors 1e-9), the minimum-norm solution of A x = -c for every delta, and the
+    whole objgrad with the selector on."""
+    qp = _small_pde(seed=19, n=4000, m=400)
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    H = _Handle(A, delta=delta, ln_method=1, fuse_two_rhs=fuse)
+    p1, q1, p2, q2, rc = H.solve_two_mixed(g, c)
+    o = oracle.solve_two_mixed(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, c,
+                               oracle.default_options(qp.n, qp.m, ln_method=1))
+    assert rc == o[5] == 0
+    for k in range(2):
+        assert (H.st[k].niter, H.st[k].status, H.st[k].solved) == (o[4][k].niter, o[4][k].status, o[4][k].solved)
+    assert H.st[1].niter > 10 and H.st[1].status in (3, 9)
+    for got, want in zip((p1, q1, p2, q2), o[:4]):
+        assert _rel(got, want) < 1e-9
+    Ad = A.toarray()
+    ye = np.linalg.solve(Ad @ Ad.T, -c)
+    assert _rel(q2, ye) < 1e-6 and _rel(p2, -(Ad.T @ ye)) < 1e-6  # delta only preconditions: unregularised answer
+    p1b, q1b, p2b, q2b, _ = H.solve_two_mixed(g, c)  # run-ahead history
+    assert np.array_equal(p2, p2b) and np.array_equal(q2, q2b) and np.array_equal(q1, q1b)
+    z = H.solve_two_mixed(g, 0.0 * c)
+    assert not z[2].any() and not z[3].any() and H.st[1].niter == 0 and H.st[1].solved == 1
+    H.close()
+    Hc = _Handle(A, delta=delta, ln_method=1, ln_itmax=3)
+    Hc.solve_two_mixed(g, c)
+    oc = oracle.solve_two_mixed(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, c,
+                                oracle.default_options(qp.n, qp.m, ln_method=1, ln_itmax=3))
+    assert (Hc.st[1].niter, Hc.st[1].status, Hc.st[1].solved) == (oc[4][1].niter, oc[4][1].status, oc[4][1].solved) == (4, 7, 0)
+    Hc.close()
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, ln_method=1, fuse_two_rhs=fuse)
+    gx, ys = np.empty(qp.n), np.empty(qp.m)
+    fx, rc = dev.objgrad(qp.x, gx=gx, ys=ys)
+    od = oracle.qp_objgrad(qp, qp.x, 1e3, 1.0, delta, opts=oracle.default_options(qp.n, qp.m, ln_method=1))
+    assert rc == od["rc"] == 0 and (dev.stats[0].niter, dev.stats[1].niter) == (od["stats"][0].niter, od["stats"][1].niter)
+    assert _rel(gx, od["gx"]) < 1e-8 and _rel(ys, od["ys"]) < 1e-8 and abs(fx - od["fx"]) <= 1e-8 * abs(od["fx"])
+    dev.close()
+
+
 def test_zero_right_hand_sides():
     """Edge cases of lsqr!/craig!: b = 0 returns x = 0, solved, 0 iterations."""
     qp = _small_pde(n=600, m=60)

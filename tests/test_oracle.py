@@ -193,6 +193,34 @@ def test_lsqr_zero_rhs_and_zero_atb_edge_cases(oracle):
     assert st.solved and np.linalg.norm(x) < 1e-12
 
 
+@pytest.mark.parametrize("delta", [0.0, SE, 0.25])
+def test_c_lnlq_least_norm_vs_exact(oracle, delta):
+    """LNLQ as the reference's GENERIC solve_least_norm calls it (struct.jl:251-281: M = (1/delta) I without sqd): M
+    only preconditions, so for every delta the answer is the minimum-norm solution of A x = b with x = A'y."""
+    qp = problems.pde_control_like(n=400, m=60, per_row=20, window=128, seed=77)
+    A = qp.scipy_csr()
+    Ad = A.toarray()
+    b = -(A @ qp.x - qp.b)
+    ye = np.linalg.solve(Ad @ Ad.T, b)
+    xe = Ad.T @ ye
+    x, y, st = oracle.lnlq(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, b, delta=delta)
+    assert st.solved and st.niter > 10 and st.status in (3, 9)
+    assert np.linalg.norm(x - xe) <= 1e-7 * np.linalg.norm(xe) and np.linalg.norm(y - ye) <= 1e-7 * np.linalg.norm(ye)
+    x, y, st = oracle.lnlq(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, b, delta=delta, atol=1e-14, rtol=1e-14)
+    assert st.solved
+    assert np.linalg.norm(x - xe) <= 1e-13 * np.linalg.norm(xe) and np.linalg.norm(y - ye) <= 1e-13 * np.linalg.norm(ye)
+    # zero right-hand side and the iteration cap
+    x, y, st = oracle.lnlq(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, 0.0 * b, delta=delta)
+    assert st.solved and st.niter == 0 and st.status == 1 and not x.any() and not y.any()
+    x, y, st = oracle.lnlq(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, b, delta=delta, itmax=3)
+    assert not st.solved and st.status == 7 and st.niter == 4  # lnlq! counts one more than the passes it made
+    # through solve_two_mixed with the method selector
+    o = oracle.default_options(qp.n, qp.m, ln_method=1)
+    g = qp.qdiag * qp.x + qp.d
+    p1, q1, p2, q2, stats, rc = oracle.solve_two_mixed(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, g, -b, o)
+    assert rc == 0 and np.linalg.norm(p2 + xe) <= 1e-7 * np.linalg.norm(xe)  # p2 = -x  (linear_system.jl:133)
+
+
 # ---------------------------------------------------------------- the iterative back-end's known-answer case
 
 _KCASE = os.path.join(os.path.dirname(__file__), "golden", "krylov_case_small_pde.json")
@@ -277,6 +305,12 @@ def test_oracle_matches_krylov_jl_golden(oracle):
         assert st.status == _status_code(w["stats"]["status"])
         np.testing.assert_allclose(xc, w["x"], rtol=0, atol=1e-12 * np.linalg.norm(w["x"]))
         np.testing.assert_allclose(yc, w["y"], rtol=0, atol=1e-12 * np.linalg.norm(w["y"]))
+        if "lnlq" in run:
+            xl, yl, st = oracle.lnlq(m, n, A.indptr, A.indices, A.data, -c, delta=delta, itmax=5 * (m + n))
+            w = run["lnlq"]
+            assert (st.niter, bool(st.solved)) == (w["stats"]["niter"], w["stats"]["solved"])
+            np.testing.assert_allclose(xl, w["x"], rtol=0, atol=1e-12 * np.linalg.norm(w["x"]))
+            np.testing.assert_allclose(yl, w["y"], rtol=0, atol=1e-12 * np.linalg.norm(w["y"]))
         xm, st = oracle.minres_aat(m, n, A.indptr, A.indices, A.data, c, lam=max(delta, 1e-14))
         w = run["minres"]
         assert (st.niter, bool(st.solved)) == (w["stats"]["niter"], w["stats"]["solved"])
