@@ -50,7 +50,7 @@ class Info(C.Structure):
 
 class DenseInfo(C.Structure):
     _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("last_syrk_ms", C.c_double), ("last_chol_ms", C.c_double),
-                ("last_solve_ms", C.c_double)]
+                ("last_solve_ms", C.c_double), ("regularized_pivots", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -90,6 +90,7 @@ SYMBOLS = [
     ("fpsq_dense_last_error", C.c_char_p, [_VP]),
     ("fpsq_dense_set_jacobian", C.c_int, [_VP, _DP]),
     ("fpsq_dense_factorize", C.c_int, [_VP, _D, C.POINTER(C.c_int32)]),
+    ("fpsq_dense_set_regularization", C.c_int, [_VP, _D, _D]),
     ("fpsq_dense_solve_two_mixed", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
     ("fpsq_dense_solve_two_least_squares", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
     ("fpsq_dense_get_factor", C.c_int, [_VP, _DP]),

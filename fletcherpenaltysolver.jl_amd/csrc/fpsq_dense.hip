@@ -21,11 +21,18 @@ struct fpsq_dense_s {
   double* A = nullptr;     // mpad x npad, row-major, zero padded
   double* M = nullptr;     // mpad x mpad: lower triangle holds the Cholesky factor after factorize
   double* invs = nullptr;  // nb inverses of the diagonal 128 x 128 blocks of L
+  double* invsT = nullptr; // ... and their transposes (k_potrf_inv128r / k_trsv_step2)
+  int64_t regularized = 0; // pivots replaced by the dynamic regularisation in the last factorisation
   double *r2 = nullptr, *y2 = nullptr, *x2 = nullptr, *part = nullptr;  // [mpad][2], [mpad][2], [npad][2], gemvt partials
   double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
   int* info_dev = nullptr;
   int nchunk = 16;
-  int potrf_gen = 2;  // diagonal-block kernel: 2 = wave-level (k_potrf_inv128w), 1 = unblocked (FPSQ_DENSE_POTRF=1)
+  int potrf_gen = 4;  // diagonal-block kernel: 4 = compact 16-column panels (k_potrf_inv128p), 3 = 32-column panels
+                      // (k_potrf_inv128r), 2 = wave-level 64 (k_potrf_inv128w), 1 = unblocked (FPSQ_DENSE_POTRF selects;
+                      // 3 and 4 regularise pivots and feed the coalesced triangular solves)
+  int splitk = 1;          // k-slices of the Gram-matrix product (balance of the 128 x 128 tiles over the CUs)
+  double* planes = nullptr;  // splitk partial planes of M
+  double piv_tol = 0.0, piv_reg = 0.0;  // dynamic regularisation (fpsq_dense_set_regularization); reg <= 0: off
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   fpsq_dense_info info{};
   std::vector<void*> allocs;
@@ -56,6 +63,13 @@ int dmalloc(fpsq_dense d, T** p, size_t count) {
 void solve_two_rhs(fpsq_dense d) {
   hipStream_t s = d->stream;
   const int nb = (int)d->nb, ld = (int)d->mpad;
+  if (d->potrf_gen >= 3) {
+    for (int k = 0; k < nb; ++k)
+      hipLaunchKernelGGL(k_trsv_step2<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, k);
+    for (int k = nb - 1; k >= 0; --k)
+      hipLaunchKernelGGL(k_trsv_step2<false>, dim3(k + 1), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->y2, d->r2, k);
+    return;
+  }
   for (int k = 0; k < nb; ++k)
     hipLaunchKernelGGL(k_trsv_step<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->r2, d->y2, k);
   for (int k = nb - 1; k >= 0; --k)
@@ -122,6 +136,7 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   rc |= dmalloc(d, &d->A, (size_t)d->mpad * d->npad);
   rc |= dmalloc(d, &d->M, (size_t)d->mpad * d->mpad);
   rc |= dmalloc(d, &d->invs, (size_t)d->nb * kDB * kDB);
+  rc |= dmalloc(d, &d->invsT, (size_t)d->nb * kDB * kDB);
   rc |= dmalloc(d, &d->r2, (size_t)d->mpad * 2);
   rc |= dmalloc(d, &d->y2, (size_t)d->mpad * 2);
   rc |= dmalloc(d, &d->x2, (size_t)d->npad * 2);
@@ -146,7 +161,23 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
                       (kDB * (kDB + 1) + kDB) * 8);
   hipFuncSetAttribute((const void*)k_potrf_inv128w, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (kDB * (kDB + 1) + kDB) * 8);
+  hipFuncSetAttribute((const void*)k_potrf_inv128r, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
+  hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) d->potrf_gen = std::atoi(ev);
+  {
+    // k-slices of the Gram product (FPSQ_DENSE_SPLITK, default 1 = off).  Measured at n = 4096, m = 2048 on the MI355X:
+    // 0.76 / 0.94 / 1.09 / 1.18 ms for 1 / 8 / 12 / 15 slices -- the product kernel itself takes the same ~0.77 ms however
+    // its 136 tiles are cut (it is bound by its operand staging, not by the 136-of-256 CU occupancy), and the reduction of
+    // the planes comes on top.
+    int64_t S = 1;
+    if (const char* ev = std::getenv("FPSQ_DENSE_SPLITK")) S = std::max(1, std::atoi(ev));
+    d->splitk = (int)S;
+    if (S > 1 && dmalloc(d, &d->planes, (size_t)S * d->mpad * d->mpad)) {
+      g_dense_create_error = d->err;
+      fpsq_dense_destroy(d);
+      return FPSQ_ERR_HIP;
+    }
+  }
   d->info.n = n;
   d->info.m = m;
   *out = d;
@@ -186,20 +217,35 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
   hipSetDevice(d->device);
   hipStream_t s = d->stream;
   const int nb = (int)d->nb, ld = (int)d->mpad;
-  DCHK(d, hipMemsetAsync(d->info_dev, 0, 4, s));
+  DCHK(d, hipMemsetAsync(d->info_dev, 0, 8, s));
   hipEventRecord(d->e0, s);
   // M = A A' (lower tiles) on the fp64 matrix cores, then + delta I
-  hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->A, (int)d->npad, d->A, (int)d->npad,
-                     (int)d->npad, 1.0, 0.0);
-  hipLaunchKernelGGL(k_dense_diag, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->M, ld, (int)d->m,
-                     (int)d->mpad, delta);
+  if (d->splitk > 1) {
+    const int ksteps = (int)(d->npad / kDK);
+    const int kchunk = (ksteps + d->splitk - 1) / d->splitk * kDK;
+    const size_t zs = (size_t)d->mpad * d->mpad;
+    hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb, d->splitk), dim3(256), 0, s, d->planes, ld, d->A, (int)d->npad, d->A,
+                       (int)d->npad, (int)d->npad, 1.0, 0.0, kchunk, zs);
+    hipLaunchKernelGGL(k_syrk_reduce, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->planes, zs, d->splitk, (int)d->m, delta);
+  } else {
+    hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->A, (int)d->npad, d->A, (int)d->npad,
+                       (int)d->npad, 1.0, 0.0, 0, (size_t)0);
+    hipLaunchKernelGGL(k_dense_diag, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->M, ld, (int)d->m,
+                       (int)d->mpad, delta);
+  }
   hipEventRecord(d->e1, s);
   // right-looking blocked Cholesky, block 128: potrf + inverse of the diagonal block (one workgroup), panel
   // L_ik = M_ik Linv_kk' and trailing update M_ij -= L_ik L_jk' on the matrix cores
   for (int k = 0; k < nb; ++k) {
     double* Mkk = d->M + (size_t)k * kDB * ld + (size_t)k * kDB;
     double* inv = d->invs + (size_t)k * kDB * kDB;
-    if (d->potrf_gen == 1)
+    if (d->potrf_gen == 4)
+      hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, ld, inv,
+                         d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
+    else if (d->potrf_gen == 3)
+      hipLaunchKernelGGL(k_potrf_inv128r, dim3(1), dim3(256), kPotrfLds, s, Mkk, ld, inv,
+                         d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
+    else if (d->potrf_gen == 1)
       hipLaunchKernelGGL(k_potrf_inv128, dim3(1), dim3(kPotrfThreads), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
                          d->info_dev);
     else
@@ -208,24 +254,39 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
     const int rem = nb - k - 1;
     if (rem > 0) {
       double* panel = d->M + (size_t)(k + 1) * kDB * ld + (size_t)k * kDB;
-      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), 0, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0);
+      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), 0, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0, 0,
+                         (size_t)0);
       double* trail = d->M + (size_t)(k + 1) * kDB * ld + (size_t)(k + 1) * kDB;
       hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(rem, rem), dim3(256), 0, s, trail, ld, panel, ld, panel, ld, kDB, -1.0,
-                         1.0);
+                         1.0, 0, (size_t)0);
     }
   }
   hipEventRecord(d->e2, s);
-  int32_t hinfo = 0;
-  DCHK(d, hipMemcpyAsync(&hinfo, d->info_dev, 4, hipMemcpyDeviceToHost, s));
+  int32_t hinfo2[2] = {0, 0};
+  DCHK(d, hipMemcpyAsync(hinfo2, d->info_dev, 8, hipMemcpyDeviceToHost, s));
   DCHK(d, hipStreamSynchronize(s));
   float a = 0.f, b = 0.f;
   hipEventElapsedTime(&a, d->e0, d->e1);
   hipEventElapsedTime(&b, d->e1, d->e2);
   d->info.last_syrk_ms = a;
   d->info.last_chol_ms = b;
+  const int32_t hinfo = hinfo2[0];
+  d->regularized = hinfo2[1];
+  d->info.regularized_pivots = hinfo2[1];
   if (info) *info = hinfo;
   d->factored = hinfo == 0;
   return hinfo == 0 ? FPSQ_OK : 1;  // soft failure: M not positive definite (the reference warns and goes on, :244-246)
+}
+
+int fpsq_dense_set_regularization(fpsq_dense d, double tol, double reg) {
+  if (!d || !(tol >= 0.0)) return FPSQ_ERR_ARG;
+  if (reg > 0.0 && d->potrf_gen < 3) {
+    d->err = "dense_set_regularization: the diagonal-block kernels 1 and 2 (FPSQ_DENSE_POTRF) do not regularise pivots";
+    return FPSQ_ERR_STATE;
+  }
+  d->piv_tol = tol;
+  d->piv_reg = reg;
+  return FPSQ_OK;
 }
 
 int fpsq_dense_solve_two_mixed(fpsq_dense d, const double* rhs1, const double* rhs2, double* p1, double* q1, double* p2,

@@ -13,6 +13,7 @@ namespace fpsq {
 
 constexpr int kDB = 128;      // block size of the Cholesky / GEMM tiles
 constexpr int kDK = 16;       // k-depth of one LDS stage
+constexpr int kPotrfLds = (kDB * (kDB + 1) + 3 * 32 * 33 + kDB) * 8;  // k_potrf_inv128r / 128p: block + scratch + 1/diag
 constexpr int kDLd = 144;     // LDS leading dimension (doubles) of a [k][row] tile: 128 + 16 so that the four k-planes a
                               // wave reads with one ds_read_b64 fall in disjoint bank halves
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -22,12 +23,27 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 // LOWER: only tiles with blockIdx.y >= blockIdx.x are computed (symmetric rank-k update of the lower triangle).
 // Fragment maps of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md section 3): lane l holds A[i = l & 15][k = l >> 4],
 // B[k = l >> 4][j = l & 15]; D register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
+// SPLIT-K (gridDim.z > 1): slice z handles k in [z * kchunk, min(K, (z + 1) * kchunk)) and writes its partial tile to
+// the plane C + z * zstride (beta must be 0); k_syrk_reduce sums the planes in a fixed order.  A 128 x 128 x 4096 tile
+// keeps one CU's matrix cores busy for >= 0.44 ms (v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD on gfx950), so the
+// 136 lower tiles of the m = 2048 Gram matrix leave half the chip idle however fast the kernel is; slices restore the
+// balance.
 template <bool LOWER>
 __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const double* __restrict__ A, int lda,
                                                      const double* __restrict__ B, int ldb, int K, double alpha,
-                                                     double beta) {
+                                                     double beta, int kchunk = 0, size_t zstride = 0) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (LOWER && bi < bj) return;
+  int kbeg = 0;
+  if (kchunk > 0) {
+    kbeg = (int)blockIdx.z * kchunk;
+    K = min(K, kbeg + kchunk);
+    C += (size_t)blockIdx.z * zstride;
+    A += kbeg;
+    B += kbeg;
+    K -= kbeg;
+    if (K < 0) K = 0;
+  }
   __shared__ double sA[2][kDK * kDLd];
   __shared__ double sB[2][kDK * kDLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -62,11 +78,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
       sB[buf][(sk + q) * kDLd + srow] = rb[q];
     }
   };
-  gload(0);
-  lstore(0);
-  __syncthreads();
   const int fr = lane & 15, fk = lane >> 4;
   int buf = 0;
+  if (K > 0) {  // (an empty k-slice still stores its zero tile)
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
   for (int k0 = 0; k0 < K; k0 += kDK) {
     const bool more = k0 + kDK < K;
     if (more) gload(k0 + kDK);
@@ -97,6 +115,21 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
         const double v = alpha * acc[i][j][r];
         *p = (beta != 0.0) ? v + beta * *p : v;
       }
+}
+
+// M (lower 128 x 128 tiles) = sum of the S split-K planes, in plane order; + delta on the diagonal, 1 on the padded diagonal
+__global__ __launch_bounds__(256) void k_syrk_reduce(double* M, int ld, const double* __restrict__ P, size_t zstride, int S,
+                                                     int m, double delta) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bi < bj) return;
+  for (int e = threadIdx.x; e < kDB * kDB; e += 256) {
+    const int r = bi * kDB + (e >> 7), c = bj * kDB + (e & 127);
+    const size_t off = (size_t)r * ld + c;
+    double s = 0.0;
+    for (int z = 0; z < S; ++z) s += P[(size_t)z * zstride + off];
+    if (r == c) s = r < m ? s + delta : 1.0;
+    M[off] = s;
+  }
 }
 
 // M[i][i] += delta for i < m; M[i][i] = 1 on the padding
@@ -334,6 +367,362 @@ __global__ __launch_bounds__(256) void k_potrf_inv128w(double* Mkk, int ld, doub
   }
 }
 
+// ---- third generation of the diagonal-block job: left-looking over 32-column panels inside the 128 x 128 block.
+// Per panel: (a) all 256 threads apply the previous panels to it (4 x 4 register tiles on the LDS copy), (b) ONE wave
+// factors the 32 x 32 diagonal block with its rows in registers (v_readlane broadcasts: the only serial part, ~1/4 of the
+// 64-wide routine's dependent chain per call), (c) one thread per row below solves its 32 entries by forward
+// substitution against the (broadcast-read) diagonal block.  The inverse X = L^-1 -- the panel of the outer
+// factorisation and the triangular solves apply diagonal blocks through it -- is then built blockwise in the UPPER
+// triangle of the same LDS matrix (X' there, its diagonal kept implicitly as 1 / L_ii): the four diagonal 32 x 32
+// inverses column by column (128 threads, substitution in registers), the off-diagonal blocks level by level,
+// X_ij = -X_ii (sum_k L_ik X_kj).
+// PIVOTS: `reg` > 0 switches on the dynamic regularisation of LDLFactorizations.jl as the reference configures it
+// (src/solve_two_systems_struct.jl:345-348: tol = r1 = sqrt(eps), r2 = -sqrt(eps)): a pivot of M = A A' + delta I that
+// does not exceed `tol` -- minus that pivot is the pivot of the (2,2) block of K = [I A'; A -delta I] once the identity
+// block has been eliminated -- is replaced by `reg` (= -r2) and counted in info[1]; with reg <= 0 a non-positive pivot is
+// reported in info[0] (first offending row, 1-based) like before.
+__device__ __forceinline__ void wave_potrf32(double* L, int LD, int o, int row0, int* info, double tol, double reg,
+                                             double* dinv) {
+  const int lane = threadIdx.x & 63;
+  const int rl = lane & 31;  // (lanes 32..63 mirror 0..31: their results are never stored)
+  double a[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) a[c] = L[(o + rl) * LD + o + c];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    double d = rdlane(a[j], j);
+    if (reg > 0.0) {
+      if (!(d > tol)) {
+        d = reg;
+        if (lane == 0) atomicAdd(info + 1, 1);
+      }
+    } else if (!(d > 0.0)) {
+      if (lane == 0) atomicCAS(info, 0, row0 + o + j + 1);
+      d = 1.0;  // a unit pivot keeps the kernel finite; the caller reports `info`
+    }
+    const double piv = sqrt(d);
+    const double rp = 1.0 / piv;
+    if (lane == j) dinv[o + j] = rp;  // reciprocals of the diagonal, for the substitutions and the inverse
+    const double l = rl > j ? a[j] * rp : (rl == j ? piv : 0.0);
+    a[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < 32; ++c) a[c] -= l * rdlane(l, c);
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c <= lane) L[(o + lane) * LD + o + c] = a[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_potrf_inv128r(double* Mkk, int ld, double* inv, double* invT, int row0,
+                                                       int* info, double tol, double reg) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* L = sm;
+  constexpr int LD = kDB + 1;
+  double* T = sm + kDB * LD;  // 3 scratch blocks of 32 x 33
+  constexpr int TLD = 33;
+  double* dinv = T + 3 * 32 * TLD;  // 128 reciprocals of the diagonal of L
+  const int tid = threadIdx.x, wave = tid >> 6;
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    L[r * LD + c] = (c <= r) ? Mkk[(size_t)r * ld + c] : 0.0;
+  }
+  __syncthreads();
+  const int tr = tid >> 3, tc = (tid & 7) * 4;  // 32 x 8 thread grid: rows tr + 32 i, columns tc .. tc + 3 of a panel
+  for (int kb = 0; kb < 4; ++kb) {
+    const int c0 = kb * 32;
+    if (kb > 0) {  // (a) A[c0:, c0:c0+32] -= L[c0:, 0:c0] L[c0:c0+32, 0:c0]'
+      double acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+      for (int p = 0; p < c0; ++p) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = c0 + tr + 32 * i;
+          av[i] = r < kDB ? L[r * LD + p] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = L[(c0 + tc + j) * LD + p];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = c0 + tr + 32 * i;
+        if (r < kDB) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + tc + j <= r) L[r * LD + c0 + tc + j] -= acc[i][j];
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) wave_potrf32(L, LD, c0, row0, info, tol, reg, dinv);  // (b)
+    __syncthreads();
+    {  // (c) rows below the diagonal block: x L_kk' = a, one thread per row
+      const int r = c0 + 32 + tid;
+      if (r < kDB) {
+        double x[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) x[c] = L[r * LD + c0 + c];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          double s = x[c];
+#pragma unroll
+          for (int p = 0; p < c; ++p) s -= x[p] * L[(c0 + c) * LD + c0 + p];
+          x[c] = s * dinv[c0 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) L[r * LD + c0 + c] = x[c];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (c <= r) Mkk[(size_t)r * ld + c] = L[r * LD + c];
+  }
+  // ---- X = L^-1 into the upper triangle (X(r, c), r > c, at L[c * LD + r])
+  if (tid < kDB) {  // diagonal blocks: column c of block b by substitution, L_bb x = e_c
+    const int b0 = (tid >> 5) * 32, c = tid & 31;
+    double x[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      double s = r == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int p = 0; p < r; ++p) s -= L[(b0 + r) * LD + b0 + p] * x[p];  // (x[p] = 0 for p < c)
+      x[r] = r >= c ? s * dinv[b0 + r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r)
+      if (r > c) L[(b0 + c) * LD + b0 + r] = x[r];
+  }
+  __syncthreads();
+  auto Xe = [&](int r, int c) -> double {  // X(r, c) for r >= c
+    return r == c ? dinv[r] : L[c * LD + r];
+  };
+  for (int dlev = 1; dlev < 4; ++dlev) {
+    const int nblk = 4 - dlev;  // blocks (i, i - dlev)
+    // T_b = sum_{k = j}^{i - 1} L_ik X_kj
+    for (int b = 0; b < nblk; ++b) {
+      const int i0 = (b + dlev) * 32, j0 = b * 32;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      const int r = tr;  // 32 rows x 8 column groups of 4: one 32 x 32 block per pass
+      for (int k = j0; k < i0; ++k) {
+        const double lv = L[(i0 + r) * LD + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = j0 + tc + j;
+          acc[j] += k >= c ? lv * Xe(k, c) : 0.0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T[b * 32 * TLD + r * TLD + tc + j] = acc[j];
+    }
+    __syncthreads();
+    // X_ij = -X_ii T_b
+    for (int b = 0; b < nblk; ++b) {
+      const int i0 = (b + dlev) * 32, j0 = b * 32;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      const int r = tr;
+      for (int k = 0; k <= r; ++k) {
+        const double xv = Xe(i0 + r, i0 + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += xv * T[b * 32 * TLD + k * TLD + tc + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L[(j0 + tc + j) * LD + i0 + r] = -acc[j];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    inv[(size_t)r * kDB + c] = c < r ? L[c * LD + r] : (c == r ? dinv[r] : 0.0);
+    invT[(size_t)r * kDB + c] = c > r ? L[r * LD + c] : (c == r ? dinv[r] : 0.0);  // X' (upper), for coalesced X r products
+  }
+}
+
+// ---- fourth generation (the default): the same left-looking scheme over 16-column panels with COMPACT code.
+// The 64- and 32-wide register routines above are thousands of straight-line instructions executed once per call: the
+// wave spends its time waiting for instruction fetches (both run at ~220 us per block whatever their arithmetic).  Here
+// the only unrolled part is a 16 x 16 factor-and-invert routine (~1000 instructions) that is the body of a ROLLED loop
+// over the eight panels, so it is fetched once and reused; everything else is rolled loops over the LDS copy:
+//   per panel  (a) all threads: panel -= L[:, previous] L[panel rows, previous]'      (4 x 2 register tiles)
+//              (b) wave 0: L16 = chol(A16), X16 = L16^-1 in registers (v_readlane broadcasts)
+//              (c) one thread per row below: row <- row X16'
+//   then X = L^-1 by doubling: X(2h) = [X11 0; -X22 (L21 X11) X22] for h = 16, 32, 64, all pairs of a level together,
+//   stored transposed in the upper triangle of the LDS matrix (diagonal kept as 1 / L_ii in `dinv`).
+__device__ __forceinline__ void wave_diag16(double* L, int LD, int o, int row0, int* info, double tol, double reg,
+                                            double* dinv) {
+  const int lane = threadIdx.x & 63;
+  const int rl = lane & 15;  // lanes 16..63 mirror 0..15
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = L[(o + rl) * LD + o + c];
+  double rdiag = 1.0;  // this lane's 1 / L[rl][rl]
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double d = rdlane(a[j], j);
+    if (reg > 0.0) {
+      if (!(d > tol)) {
+        d = reg;
+        if (lane == 0) atomicAdd(info + 1, 1);
+      }
+    } else if (!(d > 0.0)) {
+      if (lane == 0) atomicCAS(info, 0, row0 + o + j + 1);
+      d = 1.0;  // a unit pivot keeps the kernel finite; the caller reports `info`
+    }
+    const double piv = sqrt(d);
+    const double rp = 1.0 / piv;
+    rdiag = rl == j ? rp : rdiag;
+    const double l = rl > j ? a[j] * rp : (rl == j ? piv : 0.0);
+    a[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) a[c] -= l * rdlane(l, c);
+  }
+  // X16 = L16^-1: acc_i = e_i - sum_{k<i} L[i][k] X[k][.], row k of X broadcast as soon as it is complete
+  double acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = c == rl ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    const double dk = rdlane(rdiag, k);
+    const double lik = rl > k ? a[k] : 0.0;
+#pragma unroll
+    for (int c = 0; c <= k; ++c) acc[c] -= lik * (rdlane(acc[c], k) * dk);
+  }
+  if (lane < 16) {
+    dinv[o + lane] = rdiag;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c <= lane) L[(o + lane) * LD + o + c] = a[c];                 // L16, lower
+      if (c < lane) L[(o + c) * LD + o + lane] = acc[c] * rdiag;        // X16(lane, c), kept transposed above it
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, double* inv, double* invT, int row0,
+                                                       int* info, double tol, double reg) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* L = sm;
+  constexpr int LD = kDB + 1;
+  double* T = sm + kDB * LD;  // 64 x 33 scratch of the doubling steps
+  constexpr int TLD = 33;
+  double* dinv = T + 64 * TLD;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    L[r * LD + c] = (c <= r) ? Mkk[(size_t)r * ld + c] : 0.0;
+  }
+  __syncthreads();
+  auto Xe = [&](int r, int c) -> double { return r == c ? dinv[r] : L[c * LD + r]; };  // X(r, c), r >= c
+  const int tr = tid >> 3, tc = (tid & 7) * 2;  // 32 x 8 thread grid: rows tr + 32 i, columns tc, tc + 1 of a panel
+#pragma unroll 1
+  for (int pb = 0; pb < 8; ++pb) {
+    const int o = pb * 16;
+    if (pb > 0) {  // (a)
+      double acc[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = 0.0;
+#pragma unroll 4
+      for (int p = 0; p < o; ++p) {
+        const double b0 = L[(o + tc) * LD + p], b1 = L[(o + tc + 1) * LD + p];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = o + tr + 32 * i;
+          const double av = r < kDB ? L[r * LD + p] : 0.0;
+          acc[i][0] += av * b0;
+          acc[i][1] += av * b1;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = o + tr + 32 * i;
+        if (r < kDB) {
+          if (o + tc <= r) L[r * LD + o + tc] -= acc[i][0];
+          if (o + tc + 1 <= r) L[r * LD + o + tc + 1] -= acc[i][1];
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) wave_diag16(L, LD, o, row0, info, tol, reg, dinv);  // (b)
+    __syncthreads();
+    {  // (c)
+      const int r = o + 16 + tid;
+      if (r < kDB) {
+        double a[16], out[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = L[r * LD + o + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double s = a[c] * dinv[o + c];
+#pragma unroll
+          for (int p = 0; p < c; ++p) s += a[p] * L[(o + p) * LD + o + c];  // X16(c, p)
+          out[c] = s;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) L[r * LD + o + c] = out[c];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    if (c <= r) Mkk[(size_t)r * ld + c] = L[r * LD + c];
+  }
+  // ---- X = L^-1 by doubling
+#pragma unroll 1
+  for (int h = 16; h < kDB; h *= 2) {
+    const int w = h < 32 ? h : 32;  // column chunk; all 128 / (2h) pairs of the level together: 64 x w outputs per chunk
+    const int tpr = w / 4;          // threads per output row (4 columns each)
+#pragma unroll 1
+    for (int cc = 0; cc < h; cc += w) {
+      // T[q h + r][c] = sum_{p >= c} L21[r][p] X11(p, c)
+      for (int t = tid; t < 64 * tpr; t += 256) {
+        const int gr = t / tpr, c4 = (t % tpr) * 4;
+        const int q = gr / h, r = gr % h, b0 = q * 2 * h;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int p = cc + c4; p < h; ++p) {
+          const double lv = L[(b0 + h + r) * LD + b0 + p];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = cc + c4 + j;
+            acc[j] += p >= c ? lv * Xe(b0 + p, b0 + c) : 0.0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) T[gr * TLD + c4 + j] = acc[j];
+      }
+      __syncthreads();
+      // X21[r][c] = - sum_{p <= r} X22(r, p) T[p][c]
+      for (int t = tid; t < 64 * tpr; t += 256) {
+        const int gr = t / tpr, c4 = (t % tpr) * 4;
+        const int q = gr / h, r = gr % h, b0 = q * 2 * h;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int p = 0; p <= r; ++p) {
+          const double xv = Xe(b0 + h + r, b0 + h + p);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += xv * T[(q * h + p) * TLD + c4 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L[(b0 + cc + c4 + j) * LD + b0 + h + r] = -acc[j];
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < kDB * kDB; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    inv[(size_t)r * kDB + c] = c < r ? L[c * LD + r] : (c == r ? dinv[r] : 0.0);
+    invT[(size_t)r * kDB + c] = c > r ? L[r * LD + c] : (c == r ? dinv[r] : 0.0);  // X' (upper), for coalesced X r products
+  }
+}
+
 // y (len rows) = A (rows x cols, lda) x, for NR right-hand sides interleaved [..][NR]; one wave per row.
 template <int NR>
 __global__ __launch_bounds__(256) void k_dense_gemv(const double* __restrict__ A, int lda, int rows, int cols,
@@ -449,6 +838,76 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ Lm
     for (int p = 0; p < kDB; ++p) s += Lb[(size_t)p * ld] * yk[p * 2 + rr];
   }
   r[(size_t)(blk * kDB + i) * 2 + rr] -= s;
+}
+
+// Second generation of the triangular-solve step: every global access is coalesced.  The diagonal solve reads the
+// inverse in the layout whose rows run along the threads (X' for the forward sweep, X for the backward one: 128
+// independent loads per thread instead of a chain of 128 strided ones), the forward update streams each row of the L
+// block with one wave (2 x 64 lanes x 8 B) and reduces with shuffles; the backward update already reads along rows.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ Lm, int ld, const double* __restrict__ inv,
+                                                    const double* __restrict__ invT, double* r, double* out, int k) {
+  __shared__ double rk[kDB * 2];
+  __shared__ double yk[kDB * 2];
+  const int tid = threadIdx.x;
+  const int blk = FORWARD ? k + (int)blockIdx.x : (int)blockIdx.x;  // forward: blocks k..nb-1, backward: blocks 0..k
+  rk[tid] = r[(size_t)(k * kDB) * 2 + tid];
+  __syncthreads();
+  const int i = tid >> 1, rr = tid & 1;
+  {
+    // forward: y_i = sum_{p <= i} X[i][p] r_p = sum_p X'[p][i] r_p;   backward: q_i = sum_{p >= i} X[p][i] y_p
+    const double* Xc = (FORWARD ? invT : inv) + (size_t)k * kDB * kDB + i;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 8
+    for (int p = 0; p < kDB; p += 4) {
+      s0 += Xc[(size_t)p * kDB] * rk[p * 2 + rr];
+      s1 += Xc[(size_t)(p + 1) * kDB] * rk[(p + 1) * 2 + rr];
+      s2 += Xc[(size_t)(p + 2) * kDB] * rk[(p + 2) * 2 + rr];
+      s3 += Xc[(size_t)(p + 3) * kDB] * rk[(p + 3) * 2 + rr];
+    }
+    yk[i * 2 + rr] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (blk == k) {
+    out[(size_t)(k * kDB) * 2 + tid] = yk[tid];
+    return;
+  }
+  if (FORWARD) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const double y00 = yk[lane * 2], y01 = yk[lane * 2 + 1], y10 = yk[(lane + 64) * 2], y11 = yk[(lane + 64) * 2 + 1];
+    for (int q = 0; q < 32; q += 4) {  // 4 rows in flight per wave
+      double a[4][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* Lb = Lm + (size_t)(blk * kDB + wave * 32 + q + u) * ld + k * kDB;
+        a[u][0] = Lb[lane];
+        a[u][1] = Lb[lane + 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        double t0 = a[u][0] * y00 + a[u][1] * y10, t1 = a[u][0] * y01 + a[u][1] * y11;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          t0 += __shfl_down(t0, off, 64);
+          t1 += __shfl_down(t1, off, 64);
+        }
+        if (lane == 0) {
+          double* rp = r + (size_t)(blk * kDB + wave * 32 + q + u) * 2;
+          rp[0] -= t0;
+          rp[1] -= t1;
+        }
+      }
+    }
+  } else {
+    const double* Lb = Lm + (size_t)(k * kDB) * ld + blk * kDB + i;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int p = 0; p < kDB; p += 2) {
+      s0 += Lb[(size_t)p * ld] * yk[p * 2 + rr];
+      s1 += Lb[(size_t)(p + 1) * ld] * yk[(p + 1) * 2 + rr];
+    }
+    r[(size_t)(blk * kDB + i) * 2 + rr] -= s0 + s1;
+  }
 }
 
 }  // namespace fpsq

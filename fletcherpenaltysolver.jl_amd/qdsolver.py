@@ -152,9 +152,13 @@ class HIPDirectQDSolver(QDSolver):
     src/parameters.jl:290).  Instead of an LDL' of K it factorises the normal equations M = A A' + delta I (fp64 MFMA
     SYRK + blocked Cholesky) and solves both systems with two right-hand sides; like `ldl_factorize!` it refactorises
     on every `solve_two_mixed` (src/solve_linear_system.jl:233-234) and re-uses the factors in
-    `solve_two_least_squares` (:194-195).  A non positive definite M only warns (:244-246)."""
+    `solve_two_least_squares` (:194-195).  A non positive definite M only warns (:244-246).
+    Keywords of `LDLtSolver` (struct.jl:308-316): ldlt_tol = sqrt(eps), ldlt_r2 = -sqrt(eps) drive the DYNAMIC
+    REGULARISATION of the factorisation (a vanishing pivot of M is replaced by -ldlt_r2; ldlt_r1 concerns the identity
+    block of K, whose pivots are 1 and never regularised).  Dense storage: m <= 65536."""
 
-    def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, **kwargs):
+    def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, ldlt_tol=None, ldlt_r1=None, ldlt_r2=None,
+                 **kwargs):
         if explicit_linear_constraints:
             from .nlpmodels import NonlinearConstraintsView
             nlp = NonlinearConstraintsView(nlp)
@@ -170,6 +174,11 @@ class HIPDirectQDSolver(QDSolver):
         self._cols = np.asarray(cols, dtype=np.int64) - 1
         self._A = np.zeros((self.ncon, self.nvar))
         self.factorized = False
+        se = float(np.sqrt(np.finfo(float).eps))
+        self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)        # struct.jl:312
+        self.ldlt_r2 = -se if ldlt_r2 is None else float(ldlt_r2)          # struct.jl:314
+        self._check(self._lib.fpsq_dense_set_regularization(self._d, self.ldlt_tol, -self.ldlt_r2))
+        self._fact_key = None
 
     def _check(self, rc):
         if rc < 0:
@@ -187,13 +196,15 @@ class HIPDirectQDSolver(QDSolver):
         except Exception:
             pass
 
-    def _factorize(self, nlp, x):
+    def _factorize(self, nlp, x, delta=None):
+        delta = float(nlp.delta if delta is None else delta)
         self._A[:] = 0.0
         np.add.at(self._A, (self._rows, self._cols), np.asarray(nlp.pen.jac_coord(x), dtype=np.float64))
         self._check(self._lib.fpsq_dense_set_jacobian(self._d, self._A.ctypes.data))
         info = C.c_int32()
-        rc = self._check(self._lib.fpsq_dense_factorize(self._d, float(nlp.delta), C.byref(info)))
+        rc = self._check(self._lib.fpsq_dense_factorize(self._d, delta, C.byref(info)))
         self.factorized = rc == 0
+        self._fact_key = (np.asarray(x, dtype=np.float64).tobytes(), delta) if rc == 0 else None
         return rc
 
     def _solve(self, fn, rhs1, rhs2):
@@ -218,8 +229,12 @@ class HIPDirectQDSolver(QDSolver):
     def solve_two_extras(self, nlp, x, rhs1, rhs2):
         """invJtJJv = (AA' + tau I)^-1 A rhs1, invJtJSsv = (AA' + tau I)^-1 rhs2 (src/solve_linear_system.jl:142-159).
         The reference's LDL' back-end runs `cgls` / `minres` on the operator with tau = max(delta, 1e-14); here both
-        come out of the cached Cholesky factor of AA' + delta I (q1 and -q2 of a mixed solve) -- identical for
-        delta >= 1e-14 and within 1e-14 * cond(AA') relative otherwise."""
+        come out of a Cholesky factor of AA' + tau I at x (q1 and -q2 of a mixed solve): like the reference this
+        variant looks at the Jacobian at x itself (:148-152), so the factor is rebuilt unless the cached one belongs to
+        exactly this x and tau."""
+        tau = max(float(nlp.delta), 1e-14)                                            # :148
+        if self._fact_key != (np.asarray(x, dtype=np.float64).tobytes(), tau):
+            self._factorize(nlp, x, tau)
         _, q1, _, q2 = self._solve(self._lib.fpsq_dense_solve_two_mixed, rhs1, rhs2)
         return q1, -q2
 

@@ -221,12 +221,20 @@ typedef struct {
   double last_syrk_ms; /* device time of M = A A' + delta I */
   double last_chol_ms; /* device time of the blocked Cholesky */
   double last_solve_ms;
+  int64_t regularized_pivots; /* pivots replaced by the dynamic regularisation in the last factorisation */
 } fpsq_dense_info;
 int fpsq_dense_create(fpsq_dense *out, int64_t n, int64_t m, int32_t device);
 int fpsq_dense_destroy(fpsq_dense d);
 const char *fpsq_dense_last_error(fpsq_dense d);
 int fpsq_dense_set_jacobian(fpsq_dense d, const double *a_rowmajor); /* m x n, the Jacobian at the current x */
 int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t *info);
+/* Dynamic regularisation of LDLFactorizations.jl as the reference's LDLtSolver configures it
+ * (src/solve_two_systems_struct.jl:345-348: tol = r1 = sqrt(eps), r2 = -sqrt(eps)).  A pivot d of M = A A' + delta I with
+ * d <= tol -- minus d is the pivot of the (2,2) block of K = [I A'; A -delta I] once the identity block is eliminated
+ * (its pivots are 1: r1 never fires) -- is replaced by `reg` = -r2 and counted (fpsq_dense_info.regularized_pivots); the
+ * factorisation then succeeds on rank-deficient Jacobians (test/rank-deficient.jl) instead of reporting a non-positive
+ * pivot.  reg <= 0 switches it off (the default).  `tol` is absolute, like the scaled threshold the reference uses. */
+int fpsq_dense_set_regularization(fpsq_dense d, double tol, double reg);
 int fpsq_dense_solve_two_mixed(fpsq_dense d, const double *rhs1, const double *rhs2, double *p1, double *q1, double *p2,
                                double *q2);
 int fpsq_dense_solve_two_least_squares(fpsq_dense d, const double *rhs1, const double *rhs2, double *p1, double *q1,

@@ -83,6 +83,42 @@ def test_dense_not_positive_definite_is_a_soft_failure():
     D.close()
 
 
+def test_dynamic_regularisation_factorises_rank_deficient_jacobians(oracle):
+    """fpsq_dense_set_regularization(tol, reg) = the reference's LDLtSolver settings (struct.jl:345-348: tol = sqrt(eps),
+    r2 = -sqrt(eps)): with delta = 0 and a rank-deficient Jacobian (two equal rows, test/rank-deficient.jl's situation)
+    the factorisation goes through with the vanishing pivot replaced, the count is reported, and the solves return the
+    solution of the slightly regularised system: finite, tiny residual on the consistent right-hand side."""
+    se = float(np.sqrt(np.finfo(float).eps))
+    rng = np.random.default_rng(3)
+    A = rng.uniform(-1, 1, (150, 400)) / 20.0
+    A[77] = A[12]   # rank 149, the vanishing pivot sits in the second 128-block / third 32-panel
+    A[140] = A[3]
+    g, c = rng.standard_normal(400), rng.standard_normal(150)
+    c[77], c[140] = c[12], c[3]  # consistent
+    D = _Dense(A)
+    rc, info = D.factorize(0.0)
+    assert rc == 1 and info in (78, 141)  # without it: first non-positive pivot reported, like factorized(str) == false
+    assert D.lib.fpsq_dense_set_regularization(D.d, se, se) == 0
+    rc, info = D.factorize(0.0)
+    assert rc == 0 and info == 0 and D.info()["regularized_pivots"] == 2
+    p1, q1, p2, q2 = D.solve(D.lib.fpsq_dense_solve_two_mixed, g, c)
+    assert all(np.all(np.isfinite(v)) for v in (p1, q1, p2, q2))
+    assert np.linalg.norm(A @ p1) <= 1e-6 * np.linalg.norm(g)            # p1 = projection of g on null(A)
+    assert np.linalg.norm(A @ p2 - c) <= 1e-6 * np.linalg.norm(c)        # A p2 = c (consistent system)
+    assert np.linalg.norm(p2 + A.T @ q2) <= 1e-9 * np.linalg.norm(p2)    # p2 = -A'q2
+    # a well-conditioned matrix is untouched by the option
+    B = rng.uniform(-1, 1, (150, 400)) / 20.0
+    E = _Dense(B)
+    assert E.lib.fpsq_dense_set_regularization(E.d, se, se) == 0
+    rc, info = E.factorize(0.0)
+    assert rc == 0 and E.info()["regularized_pivots"] == 0
+    got = E.solve(E.lib.fpsq_dense_solve_two_mixed, g, c)
+    for a, b in zip(got, oracle.exact_two_mixed(B, 0.0, g, c)):
+        assert _rel(a, b) < 1e-11
+    D.close()
+    E.close()
+
+
 _MODELS = {"sumsq": lambda: nlpmodels.SumSquares(10), "rosenbrock_circle": nlpmodels.RosenbrockCircle}
 
 
