@@ -5,9 +5,11 @@ problems WITHOUT bounds (the case whose every obj / grad! / hprod! goes through 
 mirrored: the parameter schedule of `AlgoData` (src/parameters.jl:69-94), the sub-problem / outer stopping logic
 (`Fletcher_penalty_optimality_check`, src/FletcherPenaltySolver.jl:28-50), `update_parameters!` and
 `update_parameters_unbdd!` (src/algo.jl:361-390), the tolerance tightening of a feasible-but-not-optimal iterate
-(:192-199).  What is NOT built (out of this build's scope): bounds / slack models, the feasibility and random
-restoration phases (src/feasibility.jl, src/algo.jl:200-251) -- an iterate that would enter them ends with status
-"infeasible" / "stalled" instead -- and the third-party sub-solvers (ipopt, knitro, tron, trunk).  The unconstrained
+(:192-199), and -- for host models -- the feasibility and random restoration phases (src/algo.jl:200-251, :295-359;
+`feasibility_step`, src/feasibility.jl:21-189, with small dense solves where the reference runs lsmr / cg on operators).
+What is NOT built (out of this build's scope): bounds / slack models and the third-party sub-solvers (ipopt,
+knitro, tron, trunk); the device-resident loop (`fps_solve_device`) has no restoration phases -- an iterate that would
+enter them ends with status "infeasible" / "stalled" there.  The unconstrained
 sub-problem is solved by one of two small built-in methods: `lbfgs` (objgrad! only) or `trunk` (trust-region
 Newton-CG on hprod!, i.e. two more KKT solves per CG iteration: the caller SURVEY ranks next after grad!).
 """
@@ -239,6 +241,79 @@ class _HostPenalty:
     def info(self):
         return {"counters": dict(self.fp.counters)}
 
+    # -- restoration phases (host models only)
+    def random_restoration(self, x, atol, rng):
+        """random_restoration! (src/algo.jl:340-359): x += radius * rand(n), radius = min(max(atol, 1/sigma, 1e-3), 1)."""
+        radius = min(max(atol, 1.0 / self.sigma, 1e-3), 1.0)
+        return x + radius * rng.random(x.size)
+
+    def restoration_feasibility(self, x, feas_tol, atol, rng):
+        """restoration_feasibility! (src/algo.jl:295-333): a feasibility step; if it fails, a random perturbation."""
+        nlp = self.nlp
+        c = nlp.cons(x) - nlp.meta.lcon
+        z, ok = feasibility_step(nlp, x, c, feas_tol, feas_tol)
+        return z if ok else self.random_restoration(x, atol, rng)
+
+
+def _tr_step(J, c, radius):
+    """TR_lsmr (src/feasibility.jl:208-235): min ||c + J d|| s.t. ||d|| <= radius.  The reference runs lsmr with a
+    radius on the Jacobian operator; for the small host models of this mirror: the minimum-norm Gauss-Newton step, cut
+    back to the trust-region boundary."""
+    d = -np.linalg.lstsq(J, c, rcond=None)[0]
+    nd = np.linalg.norm(d)
+    if nd > radius:
+        d *= radius / nd
+    return d
+
+
+def feasibility_step(nlp, x, cx, rho, ctol, *, eta1=1e-3, eta2=0.66, sigma1=0.25, sigma2=2.0, delta0=1.0,
+                     bad_steps_lim=3, expected_decrease=0.95, max_feas_iter=1000):
+    """feasibility_step (src/feasibility.jl:21-189; defaults of GNSolver, src/parameters.jl:160-170): trust-region
+    Gauss-Newton on min ||c(x) - lcon|| with the aggressive second-order step (Hz + Jz'Jz) d = Jz'cz after
+    `bad_steps_lim` poor steps.  Returns (z, success)."""
+    m, n = nlp.meta.ncon, nlp.meta.nvar
+    rows, cols = nlp.jac_structure()
+
+    def jac(z):
+        J = np.zeros((m, n))
+        np.add.at(J, (np.asarray(rows) - 1, np.asarray(cols) - 1), nlp.jac_coord(z))
+        return J
+
+    z, cz, Jz = np.array(x, float), np.array(cx, float), jac(x)
+    normcz = np.linalg.norm(cz)
+    radius, it, bad, failed, infeasible = delta0, 0, 0, False, False
+    while not (normcz <= rho or it > max_feas_iter or infeasible):
+        d = _tr_step(Jz, cz, radius)
+        infeasible = np.linalg.norm(d) < ctol * min(normcz, 1.0)                    # :226
+        if infeasible:
+            failed = True                                                            # :67-69
+        else:
+            zp = z + d
+            czp = nlp.cons(zp) - nlp.meta.lcon
+            normczp = np.linalg.norm(czp)
+            pred = 0.5 * (normcz ** 2 - np.linalg.norm(Jz @ d + cz) ** 2)            # :75-76
+            ared = 0.5 * (normcz ** 2 - normczp ** 2)
+            if not (pred > 0) or ared / pred < eta1:
+                radius = max(1e-8, radius * sigma1)                                   # :78-80
+            else:
+                bad = bad + 1 if normczp / normcz > expected_decrease else 0          # :85-89
+                if ared / pred > eta2 and np.linalg.norm(d) >= 0.99 * radius:
+                    radius *= sigma2
+                z, cz, normcz, Jz = zp, czp, normczp, jac(zp)
+        if normcz > rho and (bad >= bad_steps_lim or failed):                        # :117-140: aggressive normal step
+            H = np.column_stack([nlp.hprod(z, cz, e, obj_weight=0.0) for e in np.eye(n)])
+            d = np.linalg.lstsq(H + Jz.T @ Jz, Jz.T @ cz, rcond=None)[0]
+            zp = z - d
+            czp = nlp.cons(zp) - nlp.meta.lcon
+            nczp = np.linalg.norm(czp)
+            if nczp < normcz:
+                infeasible, failed = False, False
+                z, cz, normcz, Jz = zp, czp, nczp, jac(zp)
+            elif np.linalg.norm(d) < ctol * min(nczp, 1.0):
+                infeasible = True
+        it += 1
+    return z, bool(normcz <= rho)
+
 
 def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0, verbose=0, qds=None, **kwargs):
     """stats = fps_solve(nlp, x0; kwargs...)   (src/FletcherPenaltySolver.jl:127-186 -> src/algo.jl:26-288).
@@ -270,6 +345,9 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
     sub_atol, sub_rtol = atol, rtol            # meta.atol_sub / rtol_sub are the identity by default (parameters.jl:88-89)
     feas_tol = atol
     stalling = unsuccessful = unbounded = 0
+    feasibility_phase = restoration_phase = False   # each restoration is entered at most once (algo.jl:58-59, :201, :225)
+    can_restore = hasattr(pen, "restoration_feasibility")
+    rng = np.random.default_rng(1234)               # (the reference's tests seed the global generator, runtests.jl:6)
     status = "unknown"
     it = 0
     if max(p0, d0) <= tol:
@@ -319,22 +397,53 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
                 pen.eta = max(meta.eta_1, pen.eta * meta.eta_update)
                 pen.set_xk(x)
                 pen.invalidate()
-            elif stalling >= 3 or sub_atol < np.finfo(float).eps:  # infeasible stationary point (:200-214, no restoration)
+            elif can_restore and not feasibility_phase and (stalling >= 3 or sub_atol < np.finfo(float).eps):
+                # most likely stuck at an infeasible stationary point, or an undetected unbounded problem (:201-209)
+                feasibility_phase = True
+                unbounded = 0
+                x = pen.restoration_feasibility(x, feas_tol, atol, rng)
+                stalling = unsuccessful = 0
+                pen.invalidate()
+            elif stalling >= 3 or sub_atol < np.finfo(float).eps:  # infeasible stationary point (:210-213)
                 status = "infeasible"
                 break
             else:
                 _update_parameters(pen, meta, feas)
         elif sub_status == "unbounded" or unb_mult:
-            if unbounded >= 3 and not feas:                   # would enter the feasibility phase (:216-224)
+            if can_restore and not feasibility_phase and unbounded >= 3 and not feas:          # :217-226
+                feasibility_phase = True
+                unbounded = 0
+                x = pen.restoration_feasibility(x, feas_tol, atol, rng)
+                stalling = unsuccessful = 0
+                pen.invalidate()
+            elif can_restore and not restoration_phase and unbounded >= 3:                       # :227-231
+                restoration_phase = True
+                unbounded = 0
+                x = pen.random_restoration(x, atol, rng)
+                pen.invalidate()
+            elif not can_restore and unbounded >= 3 and not feas:
                 status = "infeasible"
                 break
-            pen.delta = meta.delta_0 if pen.delta == 0.0 else pen.delta * meta.delta_update     # :380-390
-            _update_parameters(pen, meta, feas)
+            else:
+                pen.delta = meta.delta_0 if pen.delta == 0.0 else pen.delta * meta.delta_update     # :380-390
+                _update_parameters(pen, meta, feas)
         else:
-            if unsuccessful >= 3:                             # would enter a restoration phase (:236-247)
+            if can_restore and not restoration_phase and unsuccessful >= 3 and feas:             # :241-245
+                restoration_phase = True
+                unsuccessful = 0
+                x = pen.random_restoration(x, atol, rng)
+                pen.invalidate()
+            elif can_restore and not feasibility_phase and unsuccessful >= 3 and not feas:       # :246-255
+                feasibility_phase = True
+                unsuccessful = 0
+                x = pen.restoration_feasibility(x, feas_tol, atol, rng)
+                stalling = unsuccessful = 0
+                pen.invalidate()
+            elif not can_restore and unsuccessful >= 3:
                 status = "stalled"
                 break
-            _update_parameters(pen, meta, feas)
+            else:
+                _update_parameters(pen, meta, feas)
         if verbose:
             print(f"fps_solve it {it:3d} sub={sub_status:9s} f={fx_user: .6e} |c|={ncx:.2e} sigma={pen.sigma:.1e} "
                   f"rho={pen.rho:.1e} delta={pen.delta:.1e}")

@@ -195,3 +195,103 @@ class EqQPModel(_Model):
     def jtprod(self, x, v): return self._A.T @ v
     def jprod(self, x, v): return self._A @ v
     def hprod(self, x, y, v, obj_weight=1.0): return obj_weight * self.qp.qdiag * np.asarray(v)
+
+
+class ADModel(_Model):
+    """`ADNLPModel(f, x0, c, lcon, ucon)` of the reference's tests: a host user model whose derivatives come from
+    automatic differentiation (here torch.autograd on the CPU in fp64, where the reference uses ForwardDiff through
+    ADNLPModels.jl).  `f` and `c` take a 1-D torch tensor and return a scalar / a 1-D tensor (or a list of scalars).
+    Dense Jacobian structure, like ADNLPModel's default."""
+
+    def __init__(self, f, x0, c, lcon, name="admodel", lin=()):
+        import torch
+
+        x0 = np.asarray(x0, float)
+        lcon = np.asarray(lcon, float)
+        n, m = x0.size, lcon.size
+        super().__init__(n, m, n * m, x0, lcon=lcon, name=name, lin=lin)
+        self._t = torch
+        self._f = f
+        self._c = lambda x: (lambda v: torch.stack(list(v)) if isinstance(v, (list, tuple)) else v)(c(x))
+        self._rows = np.repeat(np.arange(1, m + 1), n)
+        self._cols = np.tile(np.arange(1, n + 1), m)
+
+    def _x(self, x, grad=False):
+        t = self._t.tensor(np.asarray(x, float), dtype=self._t.float64)
+        return t.requires_grad_(True) if grad else t
+
+    def obj(self, x):
+        return float(self._f(self._x(x)))
+
+    def grad(self, x):
+        t = self._x(x, True)
+        v = self._f(t)
+        if not getattr(v, "requires_grad", False):  # constant objective
+            return np.zeros(self.meta.nvar)
+        (g,) = self._t.autograd.grad(v, t, allow_unused=True)
+        return np.zeros(self.meta.nvar) if g is None else g.numpy()
+
+    def cons(self, x):
+        return self._c(self._x(x)).detach().numpy().astype(float)
+
+    def jac_structure(self):
+        return self._rows, self._cols
+
+    def _jac(self, x):
+        J = self._t.autograd.functional.jacobian(self._c, self._x(x))
+        return J.numpy().reshape(self.meta.ncon, self.meta.nvar)
+
+    def jac_coord(self, x):
+        return self._jac(x).ravel()
+
+    def hprod(self, x, y, v, obj_weight=1.0):
+        """(obj_weight Hess f + sum_i y_i Hess c_i) v"""
+        torch = self._t
+        t = self._x(x, True)
+        yv = torch.tensor(np.asarray(y, float), dtype=torch.float64)
+        lag = obj_weight * self._f(t) + (yv * self._c(t)).sum()
+        if not getattr(lag, "requires_grad", False):
+            return np.zeros(self.meta.nvar)
+        (g,) = torch.autograd.grad(lag, t, create_graph=True, allow_unused=True)
+        if g is None or not g.requires_grad:
+            return np.zeros(self.meta.nvar)
+        (hv,) = torch.autograd.grad(g, t, grad_outputs=torch.tensor(np.asarray(v, float), dtype=torch.float64),
+                                    allow_unused=True)
+        return np.zeros(self.meta.nvar) if hv is None else hv.numpy()
+
+    def ghjvprod(self, x, g, v):
+        """(g' Hess c_i v)_i"""
+        out = np.zeros(self.meta.ncon)
+        for i in range(self.meta.ncon):
+            e = np.zeros(self.meta.ncon)
+            e[i] = 1.0
+            out[i] = float(np.dot(g, self.hprod(x, e, v, obj_weight=0.0)))
+        return out
+
+
+def reference_test_problems():
+    """The equality-constrained problems of the reference's integration tests (test/test-2.jl:1-287,
+    test/rank-deficient.jl:22-36), as ADModels: name -> (model, checks)."""
+    import torch
+
+    P = {}
+    P["rosenbrock_sum"] = ADModel(lambda x: (x[0] - 1.0) ** 2 + 100 * (x[1] - x[0] ** 2) ** 2, [-1.2, 1.0],
+                                  lambda x: [x.sum()], [1.0], name="Rosenbrock with sum x = 1")       # test-2.jl:1-9
+    P["hs8"] = ADModel(lambda x: 0.0 * x[0] - 1.0, [2.0, 1.0],
+                       lambda x: [x[0] ** 2 + x[1] ** 2 - 25, x[0] * x[1] - 9], [0.0, 0.0], name="HS8")  # :99-106
+    P["hs9"] = ADModel(lambda x: torch.sin(np.pi * x[0] / 12) * torch.cos(np.pi * x[1] / 16), [0.0, 0.0],
+                       lambda x: [4 * x[0] - 3 * x[1]], [0.0], name="HS9")                              # :125-132
+    P["hs26"] = ADModel(lambda x: (x[0] - x[1]) ** 2 + (x[1] - x[2]) ** 4, [-2.6, 2.0, 2.0],
+                        lambda x: [(1 + x[1] ** 2) * x[0] + x[2] ** 4 - 3], [0.0], name="HS26")         # :151-158
+    P["hs27"] = ADModel(lambda x: 0.01 * (x[0] - 1) ** 2 + (x[1] - x[0] ** 2) ** 2, [2.0, 2.0, 2.0],
+                        lambda x: [x[0] + x[2] ** 2 + 1.0], [0.0], name="HS27")                         # :177-184
+    P["huyer_neumaier"] = ADModel(lambda x: x[0] ** 3 * x[1] ** 3, [0.0, 0.0],
+                                  lambda x: [x[0] ** 2 + x[1] ** 2 - 1], [0.0], name="Huyer-Neumaier")  # :208-209
+    P["estrin_a1"] = ADModel(lambda x: 0.0 * x[0], [0.0], lambda x: [x[0] ** 3 + x[0] - 2.0], [0.0],
+                             name="Estrin et al. A.1")                                                 # :238
+    P["flt"] = ADModel(lambda x: (x[1] - 1) ** 2, [1.0, 0.0], lambda x: [x[0] ** 2, x[0] ** 3], [0.0, 0.0],
+                       name="FLT")                                                                     # :264-271
+    P["hs61"] = ADModel(lambda x: 4 * x[0] ** 2 + 2 * x[1] ** 2 + 2 * x[2] ** 2 - 33 * x[0] + 16 * x[1] - 24 * x[2],
+                        [0.0, 0.0, 0.0], lambda x: [3 * x[0] - 2 * x[1] ** 2 - 7, 4 * x[0] - x[2] ** 2 - 11],
+                        [0.0, 0.0], name="HS61")                                           # rank-deficient.jl:23-29
+    return P

@@ -79,3 +79,57 @@ def test_explicit_linear_constraints_on_the_exact_backend(oracle, ha):
     assert abs(f1 - f2) <= 1e-12 * max(1.0, abs(f2)) and np.allclose(g1, g2, rtol=1e-12, atol=1e-12)
     assert np.allclose(fe.hprod(x, v), fn.hprod(x, v), rtol=1e-10, atol=1e-12)
     assert fe.meta.ncon == 1 and np.allclose(fe.cons(x), [x.sum() - 1.0])
+
+
+_REF_PROBLEMS = ["rosenbrock_sum", "hs8", "hs9", "hs26", "hs27", "huyer_neumaier", "estrin_a1", "flt", "hs61"]
+
+
+@pytest.mark.parametrize("sub,ha", [("lbfgs", 2), ("trunk", 2), ("trunk", 1)])
+@pytest.mark.parametrize("name", _REF_PROBLEMS)
+def test_fps_solve_reference_integration_problems(oracle, name, sub, ha):
+    """The remaining equality-constrained problems of test/test-2.jl:1-287 and test/rank-deficient.jl:22-36 (HS61) with
+    the reference's acceptance: :first_order, primal and dual residuals < 1e-6 max(||x0||, 1).  Huyer-Neumaier starts at
+    an infeasible stationary point and only passes through the feasibility restoration (algo.jl:200-209); HS27 / HS61
+    with the Newton-CG sub-solver go through it too."""
+    nlp = nlpmodels.reference_test_problems()[name]
+    stats = fps_solve(nlp, nlp.meta.x0, subproblem_solver=sub, hessian_approx=ha, qds=OracleQDSolver(nlp, 0.0), max_time=60)
+    bound = 1e-6 * max(np.linalg.norm(nlp.meta.x0), 1.0)
+    assert stats.status == "first_order", (stats.status, stats.solver_specific)
+    assert stats.primal_feas < bound and stats.dual_feas < bound
+    if name == "rosenbrock_sum":
+        assert np.linalg.norm(stats.solution - np.array([-1.612771347383541, 2.612771347383541])) < 1e-5  # test-2.jl:9
+    if name == "estrin_a1":
+        assert abs(stats.solution[0] - 1.0) < 1e-6  # the desirable solution, not the spurious minimum at -1.56
+
+
+def test_admodel_derivatives_match_hand_written_models():
+    """ADModel (torch.autograd) against the hand-derived HS6 / HS7 models: the stand-in for ADNLPModels.jl."""
+    import torch
+
+    hand = nlpmodels.HS7()
+    ad = nlpmodels.ADModel(lambda x: torch.log(1 + x[0] ** 2) - x[1], [2.0, 2.0],
+                           lambda x: [(1 + x[0] ** 2) ** 2 + x[1] ** 2 - 4.0], [0.0])
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        x, v, g, y = rng.standard_normal(2), rng.standard_normal(2), rng.standard_normal(2), rng.standard_normal(1)
+        assert abs(ad.obj(x) - hand.obj(x)) < 1e-14 and np.allclose(ad.grad(x), hand.grad(x), atol=1e-13)
+        assert np.allclose(ad.cons(x), hand.cons(x), atol=1e-13) and np.allclose(ad.jac_coord(x), hand.jac_coord(x), atol=1e-12)
+        assert np.allclose(ad.hprod(x, y, v), hand.hprod(x, y, v), atol=1e-12)
+        assert np.allclose(ad.hprod(x, y, v, obj_weight=0.0), hand.hprod(x, y, v, obj_weight=0.0), atol=1e-12)
+        assert np.allclose(ad.ghjvprod(x, g, v), hand.ghjvprod(x, g, v), atol=1e-12)
+
+
+def test_feasibility_step_reaches_the_constraint_manifold():
+    """feasibility_step (src/feasibility.jl:21-189) from the infeasible stationary point of the Huyer-Neumaier problem
+    (c = x1^2 + x2^2 - 1 at x = 0: the Jacobian vanishes, only the aggressive second-order step can move) and from a
+    generic point of HS61."""
+    from fps_amd.fps_solve import feasibility_step
+
+    P = nlpmodels.reference_test_problems()
+    for name, x in (("hs61", np.array([1.0, 1.0, 1.0])), ("hs8", np.array([2.0, 1.0])), ("hs26", np.array([-2.6, 2.0, 2.0]))):
+        nlp = P[name]
+        z, ok = feasibility_step(nlp, x, nlp.cons(x) - nlp.meta.lcon, 1e-8, 1e-8)
+        assert ok and np.linalg.norm(nlp.cons(z) - nlp.meta.lcon) <= 1e-8
+    nlp = P["huyer_neumaier"]
+    z, ok = feasibility_step(nlp, nlp.meta.x0, nlp.cons(nlp.meta.x0), 1e-8, 1e-8)
+    assert not ok and np.allclose(z, 0.0)  # J = 0 and H = 2 c I = -2 I, J'c = 0: no direction -- the caller perturbs x
