@@ -56,6 +56,15 @@ class DenseInfo(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class BandInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("nnz", C.c_int64), ("nblocks", C.c_int64),
+                ("bandwidth_blocks", C.c_int64), ("factor_bytes", C.c_int64), ("last_form_ms", C.c_double),
+                ("last_chol_ms", C.c_double), ("last_solve_ms", C.c_double), ("regularized_pivots", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 # every symbol include/fpsq.h declares: (name, restype, argtypes)
 _VP, _DP, _I32, _I64, _D = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_double
 SYMBOLS = [
@@ -95,6 +104,14 @@ SYMBOLS = [
     ("fpsq_dense_solve_two_least_squares", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
     ("fpsq_dense_get_factor", C.c_int, [_VP, _DP]),
     ("fpsq_dense_get_info", C.c_int, [_VP, C.POINTER(DenseInfo)]),
+    ("fpsq_band_create", C.c_int, [C.POINTER(_VP), _I64, _I64, _DP, _DP, _I32]),
+    ("fpsq_band_destroy", C.c_int, [_VP]),
+    ("fpsq_band_last_error", C.c_char_p, [_VP]),
+    ("fpsq_band_set_regularization", C.c_int, [_VP, _D, _D]),
+    ("fpsq_band_factorize", C.c_int, [_VP, _DP, _D, C.POINTER(C.c_int32)]),
+    ("fpsq_band_solve_two_mixed", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
+    ("fpsq_band_solve_two_least_squares", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
+    ("fpsq_band_get_info", C.c_int, [_VP, C.POINTER(BandInfo)]),
     ("fpsq_get_info", C.c_int, [_VP, C.POINTER(Info)]),
     ("fpsq_set_profiling", C.c_int, [_VP, _I32]),
 ]

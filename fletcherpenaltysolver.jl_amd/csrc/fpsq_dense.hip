@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -338,6 +339,357 @@ int fpsq_dense_get_factor(fpsq_dense d, double* l_out) {
   if (!d || !l_out) return FPSQ_ERR_ARG;
   hipSetDevice(d->device);
   DCHK(d, hipMemcpy2D(l_out, (size_t)d->m * 8, d->M, (size_t)d->mpad * 8, (size_t)d->m * 8, (size_t)d->m, hipMemcpyDefault));
+  return FPSQ_OK;
+}
+
+// ===================================================================================== sparse direct path (block band)
+
+}  // extern "C"
+
+struct fpsq_band_s {
+  int64_t n = 0, m = 0, nnz = 0, mpad = 0, nb = 0;
+  int band_w = 1;  // blocks per block row of the band storage = half bandwidth (in blocks) + 1
+  int span = 0;    // widest column span of a row (LDS window of k_band_form)
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool factored = false;
+  int32_t *rowptr = nullptr, *colind = nullptr, *t_rowptr = nullptr, *t_colind = nullptr, *t_perm = nullptr;
+  int2* rowspan = nullptr;
+  double *vals = nullptr, *t_vals = nullptr;
+  double* Mb = nullptr;    // nb x band_w blocks of 128 x 128
+  double *invs = nullptr, *invsT = nullptr;
+  double *xn = nullptr, *ym = nullptr, *r2 = nullptr, *y2 = nullptr, *atq = nullptr;  // [n][2], [mpad][2] x 3, [n][2]
+  double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
+  int* info_dev = nullptr;
+  double piv_tol = 0.0, piv_reg = 0.0;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  fpsq_band_info info{};
+  std::vector<void*> allocs;
+};
+
+namespace {
+thread_local std::string g_band_create_error;
+
+#define BCHK(b, call)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      (b)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+      return FPSQ_ERR_HIP;                                                     \
+    }                                                                          \
+  } while (0)
+
+template <class T>
+int bmalloc(fpsq_band b, T** p, size_t count) {
+  void* q = nullptr;
+  BCHK(b, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  b->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+inline size_t blk_off(const fpsq_band b, int64_t i, int64_t j) {  // block (i, j), i - (band_w - 1) <= j <= i
+  return ((size_t)i * b->band_w + (size_t)(j - i + b->band_w - 1)) * kDB * kDB;
+}
+
+// q (in b->r2, [mpad][2]) <- M^-1 r2 with the banded factor; result in b->r2
+void band_solve(fpsq_band b) {
+  hipStream_t s = b->stream;
+  const int nb = (int)b->nb, bw = b->band_w - 1;
+  for (int k = 0; k < nb; ++k)
+    hipLaunchKernelGGL(k_trsv_step2<true>, dim3(std::min(bw, nb - 1 - k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT,
+                       b->r2, b->y2, k, b->band_w);
+  for (int k = nb - 1; k >= 0; --k)
+    hipLaunchKernelGGL(k_trsv_step2<false>, dim3(std::min(bw, k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT, b->y2,
+                       b->r2, k, b->band_w);
+}
+
+// shared tail of the two solve entry points: right-hand sides of the M-solves are in b->r2
+int band_finish(fpsq_band b, const double* a1, double* p1, double* q1, double* p2, double* q2) {
+  hipStream_t s = b->stream;
+  band_solve(b);
+  // P = [a0, a1] - A' Q
+  hipLaunchKernelGGL(k_csr_mv2, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, s, b->t_rowptr, b->t_colind, b->t_vals,
+                     b->r2, b->atq, (int)b->n);
+  hipLaunchKernelGGL(k_band_finish, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, s, b->atq, b->in_a, a1, b->o_p1,
+                     b->o_p2, (int)b->n);
+  hipLaunchKernelGGL(k_dense_unpack2, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->r2, b->o_q1, b->o_q2,
+                     (int)b->m);
+  hipEventRecord(b->e1, s);
+  BCHK(b, hipMemcpyAsync(p1, b->o_p1, (size_t)b->n * 8, hipMemcpyDefault, s));
+  BCHK(b, hipMemcpyAsync(p2, b->o_p2, (size_t)b->n * 8, hipMemcpyDefault, s));
+  BCHK(b, hipMemcpyAsync(q1, b->o_q1, (size_t)b->m * 8, hipMemcpyDefault, s));
+  BCHK(b, hipMemcpyAsync(q2, b->o_q2, (size_t)b->m * 8, hipMemcpyDefault, s));
+  BCHK(b, hipStreamSynchronize(s));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, b->e0, b->e1);
+  b->info.last_solve_ms = ms;
+  return FPSQ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* fpsq_band_last_error(fpsq_band b) { return b ? b->err.c_str() : g_band_create_error.c_str(); }
+
+int fpsq_band_destroy(fpsq_band b) {
+  if (!b) return FPSQ_ERR_ARG;
+  hipSetDevice(b->device);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  for (void* p : b->allocs) hipFree(p);
+  if (b->e0) hipEventDestroy(b->e0);
+  if (b->e1) hipEventDestroy(b->e1);
+  if (b->e2) hipEventDestroy(b->e2);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+  return FPSQ_OK;
+}
+
+int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr, const int32_t* colind, int32_t device) {
+  if (!out || n <= 0 || m <= 0 || !rowptr || n >= INT32_MAX || m >= INT32_MAX - 256) {
+    g_band_create_error = "fpsq_band_create: bad arguments";
+    return FPSQ_ERR_ARG;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    g_band_create_error = std::string("fpsq_band_create: no HIP device (") + hipGetErrorString(e) +
+                          "); libfpsq has no CPU fallback";
+    return FPSQ_ERR_HIP;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_band_create_error = "fpsq_band_create: cannot select the device";
+    return FPSQ_ERR_HIP;
+  }
+  // ---- symbolic analysis on the host (the role of ldl_analyze, src/solve_two_systems_struct.jl:344): the structure of
+  // A A' + delta I is a band whose half width is the largest row distance of two entries of one column of A
+  std::vector<int32_t> rp(m + 1);
+  if (hipMemcpy(rp.data(), rowptr, (size_t)(m + 1) * 4, hipMemcpyDefault) != hipSuccess || rp[0] != 0) {
+    g_band_create_error = "fpsq_band_create: cannot read rowptr (0-based CSR expected)";
+    return FPSQ_ERR_ARG;
+  }
+  const int64_t nnz = rp[m];
+  std::vector<int32_t> ci(std::max<int64_t>(nnz, 1));
+  if (nnz > 0 && (!colind || hipMemcpy(ci.data(), colind, (size_t)nnz * 4, hipMemcpyDefault) != hipSuccess)) {
+    g_band_create_error = "fpsq_band_create: cannot read colind";
+    return FPSQ_ERR_ARG;
+  }
+  std::vector<int32_t> cfirst(n, INT32_MAX), clast(n, -1), tcnt(n + 1, 0);
+  std::vector<int2> span(m);
+  int maxspan = 1;
+  for (int64_t i = 0; i < m; ++i) {
+    if (rp[i + 1] < rp[i]) {
+      g_band_create_error = "fpsq_band_create: rowptr not monotone";
+      return FPSQ_ERR_ARG;
+    }
+    int lo = INT32_MAX, hi = -1;
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+      const int32_t c = ci[k];
+      if (c < 0 || c >= n) {
+        g_band_create_error = "fpsq_band_create: column index out of range";
+        return FPSQ_ERR_ARG;
+      }
+      lo = std::min(lo, c);
+      hi = std::max(hi, c);
+      cfirst[c] = std::min<int32_t>(cfirst[c], (int32_t)i);
+      clast[c] = std::max<int32_t>(clast[c], (int32_t)i);
+      tcnt[c + 1]++;
+    }
+    if (hi < 0) lo = hi = 0;
+    span[i] = int2{lo, hi};
+    maxspan = std::max(maxspan, hi - lo + 1);
+  }
+  int64_t bwb = 0;
+  for (int64_t c = 0; c < n; ++c)
+    if (clast[c] >= 0) bwb = std::max<int64_t>(bwb, clast[c] / kDB - cfirst[c] / kDB);
+  fpsq_band b = new fpsq_band_s();
+  b->n = n;
+  b->m = m;
+  b->nnz = nnz;
+  b->device = device;
+  b->mpad = (m + kDB - 1) / kDB * kDB;
+  b->nb = b->mpad / kDB;
+  b->band_w = (int)std::min<int64_t>(bwb, b->nb - 1) + 1;
+  b->span = maxspan;
+  const size_t fbytes = (size_t)b->nb * b->band_w * kDB * kDB * 8;
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  if ((size_t)maxspan * 8 > 120 * 1024 || fbytes + 3 * ((size_t)b->nb * kDB * kDB * 8) > free_b / 10 * 9) {
+    char msg[256];
+    snprintf(msg, sizeof msg, "fpsq_band_create: the banded direct path does not fit this Jacobian (row span %d columns "
+             "> 15360, or factor storage %.1f GB of %.1f GB free): use the iterative back-end", maxspan, fbytes / 1e9,
+             free_b / 1e9);
+    g_band_create_error = msg;
+    delete b;
+    return FPSQ_ERR_STATE;
+  }
+  // transposed structure (for P = rhs - A' Q) with the value permutation
+  for (int64_t c = 0; c < n; ++c) tcnt[c + 1] += tcnt[c];
+  std::vector<int32_t> trow(std::max<int64_t>(nnz, 1)), tperm(std::max<int64_t>(nnz, 1)), nxt(tcnt.begin(), tcnt.end() - 1);
+  for (int64_t i = 0; i < m; ++i)
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+      const int32_t t = nxt[ci[k]]++;
+      trow[t] = (int32_t)i;
+      tperm[t] = k;
+    }
+  if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_band_create_error = "fpsq_band_create: cannot create a stream";
+    delete b;
+    return FPSQ_ERR_HIP;
+  }
+  hipEventCreate(&b->e0);
+  hipEventCreate(&b->e1);
+  hipEventCreate(&b->e2);
+  int rc = 0;
+  const size_t nz = (size_t)std::max<int64_t>(nnz, 1);
+  rc |= bmalloc(b, &b->rowptr, (size_t)m + 1) | bmalloc(b, &b->colind, nz) | bmalloc(b, &b->vals, nz);
+  rc |= bmalloc(b, &b->t_rowptr, (size_t)n + 1) | bmalloc(b, &b->t_colind, nz) | bmalloc(b, &b->t_vals, nz);
+  rc |= bmalloc(b, &b->t_perm, nz) | bmalloc(b, &b->rowspan, (size_t)m);
+  rc |= bmalloc(b, &b->Mb, (size_t)b->nb * b->band_w * kDB * kDB);
+  rc |= bmalloc(b, &b->invs, (size_t)b->nb * kDB * kDB) | bmalloc(b, &b->invsT, (size_t)b->nb * kDB * kDB);
+  rc |= bmalloc(b, &b->xn, (size_t)n * 2) | bmalloc(b, &b->atq, (size_t)n * 2);
+  rc |= bmalloc(b, &b->ym, (size_t)b->mpad * 2) | bmalloc(b, &b->r2, (size_t)b->mpad * 2) | bmalloc(b, &b->y2, (size_t)b->mpad * 2);
+  rc |= bmalloc(b, &b->in_a, (size_t)n) | bmalloc(b, &b->in_b, (size_t)std::max(n, b->mpad));
+  rc |= bmalloc(b, &b->o_p1, (size_t)n) | bmalloc(b, &b->o_p2, (size_t)n);
+  rc |= bmalloc(b, &b->o_q1, (size_t)b->mpad) | bmalloc(b, &b->o_q2, (size_t)b->mpad) | bmalloc(b, &b->info_dev, 4);
+  if (rc) {
+    g_band_create_error = b->err;
+    fpsq_band_destroy(b);
+    return FPSQ_ERR_HIP;
+  }
+  hipMemcpy(b->rowptr, rp.data(), (size_t)(m + 1) * 4, hipMemcpyHostToDevice);
+  hipMemcpy(b->t_rowptr, tcnt.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
+  hipMemcpy(b->rowspan, span.data(), (size_t)m * sizeof(int2), hipMemcpyHostToDevice);
+  if (nnz > 0) {
+    hipMemcpy(b->colind, ci.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
+    hipMemcpy(b->t_colind, trow.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
+    hipMemcpy(b->t_perm, tperm.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
+  }
+  hipDeviceSynchronize();
+  hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
+  hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 8);
+  b->info.n = n;
+  b->info.m = m;
+  b->info.nnz = nnz;
+  b->info.nblocks = b->nb;
+  b->info.bandwidth_blocks = b->band_w - 1;
+  b->info.factor_bytes = (int64_t)fbytes;
+  *out = b;
+  return FPSQ_OK;
+}
+
+int fpsq_band_set_regularization(fpsq_band b, double tol, double reg) {
+  if (!b || !(tol >= 0.0)) return FPSQ_ERR_ARG;
+  b->piv_tol = tol;
+  b->piv_reg = reg;
+  return FPSQ_OK;
+}
+
+int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* info) {
+  if (!b || (!vals && b->nnz > 0) || !(delta >= 0.0)) return FPSQ_ERR_ARG;
+  hipSetDevice(b->device);
+  hipStream_t s = b->stream;
+  const int nb = (int)b->nb, W = b->band_w, bw = W - 1;
+  b->factored = false;
+  if (b->nnz > 0) {
+    BCHK(b, hipMemcpyAsync(b->vals, vals, (size_t)b->nnz * 8, hipMemcpyDefault, s));
+    hipLaunchKernelGGL(k_gather_d, dim3((unsigned)std::min<int64_t>((b->nnz + 255) / 256, 4096)), dim3(256), 0, s, b->vals,
+                       b->t_perm, b->t_vals, b->nnz);
+  }
+  BCHK(b, hipMemsetAsync(b->info_dev, 0, 8, s));
+  BCHK(b, hipMemsetAsync(b->Mb, 0, (size_t)nb * W * kDB * kDB * 8, s));
+  hipEventRecord(b->e0, s);
+  // numeric phase 1: M = A A' + delta I into the band (jac_coord! + sparse(...) of src/solve_linear_system.jl:223-233)
+  hipLaunchKernelGGL(k_band_form, dim3(nb), dim3(256), (size_t)b->span * 8, s, b->rowptr, b->colind, b->vals, b->rowspan,
+                     (int)b->m, (int)b->mpad, W, delta, b->Mb, b->span);
+  hipEventRecord(b->e1, s);
+  // numeric phase 2: right-looking block-banded Cholesky (ldl_factorize!, :234), the dense back-end's block kernels
+  for (int k = 0; k < nb; ++k) {
+    double* Mkk = b->Mb + blk_off(b, k, k);
+    double* inv = b->invs + (size_t)k * kDB * kDB;
+    hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
+                       k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
+    const int rem = std::min(bw, nb - 1 - k);
+    if (rem > 0) {
+      BlockStrides ps;
+      ps.on = 1;
+      ps.a = ps.ci = (size_t)bw * kDB * kDB;  // block (k + 1 + bi, k): one block row down, one column of the band left
+      ps.b = 0;
+      ps.cj = 0;
+      double* panel = b->Mb + blk_off(b, k + 1, k);
+      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), 0, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0, 0.0,
+                         0, (size_t)0, ps);
+      BlockStrides ts;
+      ts.on = 1;
+      ts.a = ts.b = ts.ci = (size_t)bw * kDB * kDB;
+      ts.cj = (size_t)kDB * kDB;
+      double* trail = b->Mb + blk_off(b, k + 1, k + 1);
+      hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(rem, rem), dim3(256), 0, s, trail, kDB, panel, kDB, panel, kDB, kDB, -1.0,
+                         1.0, 0, (size_t)0, ts);
+    }
+  }
+  hipEventRecord(b->e2, s);
+  int32_t hinfo[2] = {0, 0};
+  BCHK(b, hipMemcpyAsync(hinfo, b->info_dev, 8, hipMemcpyDeviceToHost, s));
+  BCHK(b, hipStreamSynchronize(s));
+  float t0 = 0.f, t1 = 0.f;
+  hipEventElapsedTime(&t0, b->e0, b->e1);
+  hipEventElapsedTime(&t1, b->e1, b->e2);
+  b->info.last_form_ms = t0;
+  b->info.last_chol_ms = t1;
+  b->info.regularized_pivots = hinfo[1];
+  if (info) *info = hinfo[0];
+  b->factored = hinfo[0] == 0;
+  return hinfo[0] == 0 ? FPSQ_OK : 1;  // soft: not positive definite (factorized(str) == false, :242-246)
+}
+
+int fpsq_band_solve_two_mixed(fpsq_band b, const double* rhs1, const double* rhs2, double* p1, double* q1, double* p2,
+                              double* q2) {
+  if (!b || !rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2) return FPSQ_ERR_ARG;
+  if (!b->factored) {
+    b->err = "band_solve: no valid factorisation";
+    return FPSQ_ERR_STATE;
+  }
+  hipSetDevice(b->device);
+  hipStream_t s = b->stream;
+  BCHK(b, hipMemcpyAsync(b->in_a, rhs1, (size_t)b->n * 8, hipMemcpyDefault, s));
+  BCHK(b, hipMemcpyAsync(b->in_b, rhs2, (size_t)b->m * 8, hipMemcpyDefault, s));
+  hipEventRecord(b->e0, s);
+  // r = [A g, -c]:  q1 = M^-1 A g,  q2 = -M^-1 c;  then p1 = g - A'q1, p2 = -A'q2   
+  hipLaunchKernelGGL(k_dense_pack2, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, s, b->in_a, 1.0,
+                     (const double*)nullptr, 0.0, b->xn, (int)b->n, (int)b->n);
+  hipLaunchKernelGGL(k_csr_mv2, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->rowptr, b->colind, b->vals, b->xn,
+                     b->ym, (int)b->m);
+  hipLaunchKernelGGL(k_band_rhs, dim3((unsigned)((b->mpad + 255) / 256)), dim3(256), 0, s, b->ym, 0, b->in_b, -1.0, b->r2,
+                     (int)b->m, (int)b->mpad, 0);
+  return band_finish(b, nullptr, p1, q1, p2, q2);
+}
+
+int fpsq_band_solve_two_least_squares(fpsq_band b, const double* rhs1, const double* rhs2, double* p1, double* q1,
+                                      double* p2, double* q2) {
+  if (!b || !rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2) return FPSQ_ERR_ARG;
+  if (!b->factored) {
+    b->err = "band_solve: no valid factorisation";
+    return FPSQ_ERR_STATE;
+  }
+  hipSetDevice(b->device);
+  hipStream_t s = b->stream;
+  BCHK(b, hipMemcpyAsync(b->in_a, rhs1, (size_t)b->n * 8, hipMemcpyDefault, s));
+  BCHK(b, hipMemcpyAsync(b->in_b, rhs2, (size_t)b->n * 8, hipMemcpyDefault, s));
+  hipEventRecord(b->e0, s);
+  hipLaunchKernelGGL(k_dense_pack2, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, s, b->in_a, 1.0, b->in_b, 1.0, b->xn,
+                     (int)b->n, (int)b->n);
+  hipLaunchKernelGGL(k_csr_mv2, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->rowptr, b->colind, b->vals, b->xn,
+                     b->ym, (int)b->m);
+  hipLaunchKernelGGL(k_band_rhs, dim3((unsigned)((b->mpad + 255) / 256)), dim3(256), 0, s, b->ym, 0, (const double*)nullptr,
+                     0.0, b->r2, (int)b->m, (int)b->mpad, 1);
+  return band_finish(b, b->in_b, p1, q1, p2, q2);
+}
+
+int fpsq_band_get_info(fpsq_band b, fpsq_band_info* info) {
+  if (!b || !info) return FPSQ_ERR_ARG;
+  *info = b->info;
   return FPSQ_OK;
 }
 

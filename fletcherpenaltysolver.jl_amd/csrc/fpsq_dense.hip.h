@@ -18,6 +18,13 @@ constexpr int kDLd = 144;     // LDS leading dimension (doubles) of a [k][row] t
                               // wave reads with one ds_read_b64 fall in disjoint bank halves
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
+// Tile addressing of k_gemm_nt_f64 on a BLOCK-BANDED matrix (fpsq_band): 128 x 128 blocks stored contiguously (row
+// stride 128), tile (bi, bj) of C at C + bi * ci + bj * cj, tile bi of A at A + bi * a, tile bj of B at B + bj * b.
+struct BlockStrides {
+  int on = 0;
+  size_t a = 0, b = 0, ci = 0, cj = 0;
+};
+
 // C (M x N, ldc) = alpha * A (M x K, lda) * B (N x K, ldb)' + beta * C.   M, N multiples of 128, K multiple of 16.
 // One workgroup = one 128 x 128 tile of C, 4 waves in a 2 x 2 grid, each wave 64 x 64 = 4 x 4 MFMA tiles of 16 x 16.
 // LOWER: only tiles with blockIdx.y >= blockIdx.x are computed (symmetric rank-k update of the lower triangle).
@@ -31,7 +38,7 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 template <bool LOWER>
 __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const double* __restrict__ A, int lda,
                                                      const double* __restrict__ B, int ldb, int K, double alpha,
-                                                     double beta, int kchunk = 0, size_t zstride = 0) {
+                                                     double beta, int kchunk = 0, size_t zstride = 0, BlockStrides bs = {}) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (LOWER && bi < bj) return;
   int kbeg = 0;
@@ -48,8 +55,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
   __shared__ double sB[2][kDK * kDLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;  // this wave's 64 x 64 sub-tile
-  const double* Ab = A + (size_t)bi * kDB * lda;
-  const double* Bb = B + (size_t)bj * kDB * ldb;
+  // operand / result tiles: rows of a dense matrix, or (bs.on) blocks of a block-banded storage at affine offsets
+  const double* Ab = A + (bs.on ? (size_t)bi * bs.a : (size_t)bi * kDB * lda);
+  const double* Bb = B + (bs.on ? (size_t)bj * bs.b : (size_t)bj * kDB * ldb);
   // staging: thread t copies 8 consecutive k of row (t >> 1) for both operands
   const int srow = tid >> 1, sk = (tid & 1) * 8;
   f64x4 acc[4][4];
@@ -104,7 +112,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
     __syncthreads();
     buf ^= 1;
   }
-  double* Cb = C + (size_t)(bi * kDB + wr) * ldc + bj * kDB + wc;
+  double* Cb = C + (bs.on ? (size_t)bi * bs.ci + (size_t)bj * bs.cj + (size_t)wr * ldc + wc
+                          : (size_t)(bi * kDB + wr) * ldc + bj * kDB + wc);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -844,13 +853,18 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ Lm
 // inverse in the layout whose rows run along the threads (X' for the forward sweep, X for the backward one: 128
 // independent loads per thread instead of a chain of 128 strided ones), the forward update streams each row of the L
 // block with one wave (2 x 64 lanes x 8 B) and reduces with shuffles; the backward update already reads along rows.
+// band_w > 0: Lm is the block-banded storage of fpsq_band (band_w = blocks per block row, half bandwidth band_w - 1):
+// block (i, j) at Lm + (i * band_w + (j - i + band_w - 1)) * 128 * 128, row stride 128; the grid then only spans the
+// blocks inside the band (forward: k .. k + rem, backward: k - rem .. k, block = k -/+ blockIdx.x).
 template <bool FORWARD>
 __global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ Lm, int ld, const double* __restrict__ inv,
-                                                    const double* __restrict__ invT, double* r, double* out, int k) {
+                                                    const double* __restrict__ invT, double* r, double* out, int k,
+                                                    int band_w = 0) {
   __shared__ double rk[kDB * 2];
   __shared__ double yk[kDB * 2];
   const int tid = threadIdx.x;
-  const int blk = FORWARD ? k + (int)blockIdx.x : (int)blockIdx.x;  // forward: blocks k..nb-1, backward: blocks 0..k
+  // dense: forward blocks k..nb-1, backward blocks 0..k
+  const int blk = FORWARD ? k + (int)blockIdx.x : (band_w > 0 ? k - (int)blockIdx.x : (int)blockIdx.x);
   rk[tid] = r[(size_t)(k * kDB) * 2 + tid];
   __syncthreads();
   const int i = tid >> 1, rr = tid & 1;
@@ -879,7 +893,9 @@ __global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ L
       double a[4][2];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const double* Lb = Lm + (size_t)(blk * kDB + wave * 32 + q + u) * ld + k * kDB;
+        const double* Lb = band_w > 0 ? Lm + ((size_t)blk * band_w + (k - blk + band_w - 1)) * kDB * kDB +
+                                            (size_t)(wave * 32 + q + u) * kDB
+                                      : Lm + (size_t)(blk * kDB + wave * 32 + q + u) * ld + k * kDB;
         a[u][0] = Lb[lane];
         a[u][1] = Lb[lane + 64];
       }
@@ -899,15 +915,103 @@ __global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ L
       }
     }
   } else {
-    const double* Lb = Lm + (size_t)(k * kDB) * ld + blk * kDB + i;
+    const double* Lb = band_w > 0 ? Lm + ((size_t)k * band_w + (blk - k + band_w - 1)) * kDB * kDB + i
+                                  : Lm + (size_t)(k * kDB) * ld + blk * kDB + i;
+    const size_t lds = band_w > 0 ? (size_t)kDB : (size_t)ld;
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
     for (int p = 0; p < kDB; p += 2) {
-      s0 += Lb[(size_t)p * ld] * yk[p * 2 + rr];
-      s1 += Lb[(size_t)(p + 1) * ld] * yk[(p + 1) * 2 + rr];
+      s0 += Lb[(size_t)p * lds] * yk[p * 2 + rr];
+      s1 += Lb[(size_t)(p + 1) * lds] * yk[(p + 1) * 2 + rr];
     }
     r[(size_t)(blk * kDB + i) * 2 + rr] -= s0 + s1;
   }
+}
+
+// ---- sparse direct path (fpsq_band): M = A A' + delta I of a BANDED sparse Jacobian as a block band
+// One workgroup per 128-row block I.  For each of its rows i in turn: scatter the row into a dense LDS window over its
+// column span, then every thread takes rows j <= i of the band (blocks I - bw .. I) and gathers its dot product with
+// row i from the window (columns outside the window contribute nothing); M(i, j) goes to block (I, j / 128).
+// Deterministic (fixed summation order, no atomics).  rowspan[i] = {first column, last column} of row i.
+__global__ __launch_bounds__(256) void k_band_form(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                   const double* __restrict__ vals, const int2* __restrict__ rowspan,
+                                                   int m, int mpad, int band_w, double delta, double* Mb, int span) {
+  extern __shared__ __attribute__((aligned(16))) double win[];
+  const int I = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < span; k += 256) win[k] = 0.0;
+  __syncthreads();
+  const int i0 = I * kDB;
+  const int bw = band_w - 1;
+  const int jlo = max(0, I - bw) * kDB;
+  for (int ii = 0; ii < kDB; ++ii) {
+    const int i = i0 + ii;
+    double* Mrow = Mb + ((size_t)I * band_w) * kDB * kDB + (size_t)ii * kDB;  // row ii of block (I, I - bw)
+    if (i >= m) {  // padding: identity
+      if (tid == 0 && i < mpad) Mrow[(size_t)bw * kDB * kDB + ii] = 1.0;
+      continue;
+    }
+    const int s = rowptr[i], e = rowptr[i + 1];
+    const int2 sp = rowspan[i];
+    for (int k = s + tid; k < e; k += 256) win[colind[k] - sp.x] = vals[k];
+    __syncthreads();
+    for (int j = jlo + tid; j <= i; j += 256) {
+      const int js = rowptr[j], je = rowptr[j + 1];
+      double acc = 0.0;
+      for (int k = js; k < je; ++k) {
+        const int c = colind[k];
+        if (c >= sp.x && c <= sp.y) acc += vals[k] * win[c - sp.x];
+      }
+      if (j == i) acc += delta;
+      const int J = j >> 7;
+      Mrow[(size_t)(J - I + bw) * kDB * kDB + (j & 127)] = acc;
+    }
+    __syncthreads();
+    for (int k = s + tid; k < e; k += 256) win[colind[k] - sp.x] = 0.0;
+    __syncthreads();
+  }
+}
+
+// y[r][0..1] = sum_k vals[k] x[colind[k]][0..1] over row r of a CSR matrix (two interleaved right-hand sides); one
+// thread per row
+__global__ __launch_bounds__(256) void k_csr_mv2(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                 const double* __restrict__ vals, const double* __restrict__ x, double* y,
+                                                 int rows) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  double a0 = 0.0, a1 = 0.0;
+  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+    const double v = vals[k];
+    const double2 xv = *reinterpret_cast<const double2*>(x + (size_t)colind[k] * 2);
+    a0 += v * xv.x;
+    a1 += v * xv.y;
+  }
+  y[(size_t)r * 2] = a0;
+  y[(size_t)r * 2 + 1] = a1;
+}
+
+__global__ __launch_bounds__(256) void k_gather_d(const double* __restrict__ in, const int32_t* __restrict__ perm,
+                                                  double* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[perm[i]];
+}
+
+// r[i] = {ag[i][0], sb * b[i]} on rows < m, zero on the padding (the right-hand sides of the two M-solves)
+__global__ __launch_bounds__(256) void k_band_rhs(const double* __restrict__ ag, int col, const double* b, double sb,
+                                                  double* r, int m, int mpad, int both) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= mpad) return;
+  const bool in = i < m;
+  r[(size_t)i * 2] = in ? ag[(size_t)i * 2] : 0.0;
+  r[(size_t)i * 2 + 1] = in ? (both ? ag[(size_t)i * 2 + 1] : sb * b[i]) : 0.0;
+  (void)col;
+}
+
+// p1 = a0 - atq[.][0];  p2 = (a1 ? a1 : 0) - atq[.][1]
+__global__ __launch_bounds__(256) void k_band_finish(const double* __restrict__ atq, const double* a0, const double* a1,
+                                                     double* p1, double* p2, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  p1[i] = a0[i] - atq[(size_t)i * 2];
+  p2[i] = (a1 ? a1[i] : 0.0) - atq[(size_t)i * 2 + 1];
 }
 
 }  // namespace fpsq

@@ -245,3 +245,105 @@ class HIPDirectQDSolver(QDSolver):
 
 
 qdsolver_correspondence["hip_direct"] = HIPDirectQDSolver
+
+
+class HIPBandedDirectQDSolver(QDSolver):
+    """`HIPBandedDirectQDSolver(nlp, T(0))`: the DIRECT back-end for SPARSE Jacobians whose normal-equations matrix is
+    banded (PDE-like models) -- `LDLtSolver`'s role at sizes where a dense M does not fit (include/fpsq.h, fpsq_band_*).
+    The constructor is the symbolic phase (struct.jl:326-344), `solve_two_mixed` refactorises at x
+    (solve_linear_system.jl:223-234), `solve_two_least_squares` re-uses the factor (:194-195); ldlt_tol / ldlt_r2 as in
+    HIPDirectQDSolver."""
+
+    def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, ldlt_tol=None, ldlt_r1=None, ldlt_r2=None,
+                 **kwargs):
+        import scipy.sparse as sp
+
+        if explicit_linear_constraints:
+            from .nlpmodels import NonlinearConstraintsView
+            nlp = NonlinearConstraintsView(nlp)
+        self.explicit_linear_constraints = bool(explicit_linear_constraints)
+        self._lib = _lib.load()
+        self.nvar, self.ncon = int(nlp.meta.nvar), int(nlp.meta.ncon)
+        rows, cols = nlp.jac_structure()
+        rows, cols = np.asarray(rows, dtype=np.int64) - 1, np.asarray(cols, dtype=np.int64) - 1
+        # COO (model order, duplicates allowed) -> CSR slots; `_slot[k]` = CSR position of COO entry k
+        pat = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(self.ncon, self.nvar))
+        pat.sum_duplicates()
+        pat.sort_indices()
+        self._rp, self._ci = pat.indptr.astype(np.int32), pat.indices.astype(np.int32)
+        key = rows * self.nvar + cols
+        csr_key = np.repeat(np.arange(self.ncon, dtype=np.int64), np.diff(pat.indptr)) * self.nvar + pat.indices
+        self._slot = np.searchsorted(csr_key, key)
+        self._nnz = int(pat.nnz)
+        b = C.c_void_p()
+        rc = self._lib.fpsq_band_create(C.byref(b), self.nvar, self.ncon, self._rp.ctypes.data, self._ci.ctypes.data,
+                                        int(kwargs.get("device", 0)))
+        if rc != 0:
+            raise FpsqError(self._lib.fpsq_band_last_error(None).decode())
+        self._b = b
+        se = float(np.sqrt(np.finfo(float).eps))
+        self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)
+        self.ldlt_r2 = -se if ldlt_r2 is None else float(ldlt_r2)
+        self._check(self._lib.fpsq_band_set_regularization(b, self.ldlt_tol, -self.ldlt_r2))
+        self.factorized = False
+        self._fact_key = None
+
+    def _check(self, rc):
+        if rc < 0:
+            raise FpsqError(self._lib.fpsq_band_last_error(self._b).decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self._lib.fpsq_band_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _factorize(self, nlp, x, delta=None):
+        delta = float(nlp.delta if delta is None else delta)
+        vals = np.zeros(self._nnz)
+        np.add.at(vals, self._slot, np.asarray(nlp.pen.jac_coord(x), dtype=np.float64))
+        info = C.c_int32()
+        rc = self._check(self._lib.fpsq_band_factorize(self._b, vals.ctypes.data, delta, C.byref(info)))
+        self.factorized = rc == 0
+        self._fact_key = (np.asarray(x, dtype=np.float64).tobytes(), delta) if rc == 0 else None
+        return rc
+
+    def _solve(self, fn, rhs1, rhs2):
+        n, m = self.nvar, self.ncon
+        rhs1 = np.ascontiguousarray(rhs1, dtype=np.float64)
+        rhs2 = np.ascontiguousarray(rhs2, dtype=np.float64)
+        p1, q1, p2, q2 = np.zeros(n), np.zeros(m), np.zeros(n), np.zeros(m)
+        if not self.factorized:
+            warnings.warn("_solve_ldlt_factorization: failed _factorization")
+            return p1, q1, p2, q2
+        self._check(fn(self._b, rhs1.ctypes.data, rhs2.ctypes.data, p1.ctypes.data, q1.ctypes.data, p2.ctypes.data,
+                       q2.ctypes.data))
+        return p1, q1, p2, q2
+
+    def solve_two_mixed(self, nlp, x, rhs1, rhs2):
+        self._factorize(nlp, x)
+        return self._solve(self._lib.fpsq_band_solve_two_mixed, rhs1, rhs2)
+
+    def solve_two_least_squares(self, nlp, x, rhs1, rhs2):
+        return self._solve(self._lib.fpsq_band_solve_two_least_squares, rhs1, rhs2)
+
+    def solve_two_extras(self, nlp, x, rhs1, rhs2):
+        tau = max(float(nlp.delta), 1e-14)                                            # solve_linear_system.jl:148
+        if self._fact_key != (np.asarray(x, dtype=np.float64).tobytes(), tau):
+            self._factorize(nlp, x, tau)
+        _, q1, _, q2 = self._solve(self._lib.fpsq_band_solve_two_mixed, rhs1, rhs2)
+        return q1, -q2
+
+    def info(self):
+        i = _lib.BandInfo()
+        self._check(self._lib.fpsq_band_get_info(self._b, C.byref(i)))
+        return i.as_dict()
+
+
+qdsolver_correspondence["hip_ldlt"] = HIPBandedDirectQDSolver

@@ -243,6 +243,40 @@ int fpsq_dense_solve_two_least_squares(fpsq_dense d, const double *rhs1, const d
 int fpsq_dense_get_factor(fpsq_dense d, double *l_out);
 int fpsq_dense_get_info(fpsq_dense d, fpsq_dense_info *info);
 
+/* ---- sparse direct back-end: the reference's LDLtSolver path for SPARSE Jacobians whose
+ * normal-equations matrix is banded (PDE-like Jacobians: row i only touches a column window that moves with i).
+ *   fpsq_band_create      = the constructor's symbolic work (src/solve_two_systems_struct.jl:326-344: the COO pattern of
+ *                           triu(K) and `ldl_analyze`): here the block band structure of M = A A' + delta I -- the Schur
+ *                           complement of the identity block of K = [I A'; A -delta I] -- from the CSR pattern of A
+ *                           (half bandwidth = the largest row distance of two entries of one column).
+ *   fpsq_band_factorize   = `jac_coord!` + `sparse(...)` + `ldl_factorize!` (src/solve_linear_system.jl:223-234): forms M
+ *                           into 128 x 128 blocks of the band on the device and factors it with a right-looking
+ *                           block-banded Cholesky (the dense back-end's MFMA block kernels); returns 1 (soft) with *info
+ *                           = first non-positive pivot row when M is not positive definite and no regularisation is set.
+ *   fpsq_band_set_regularization = the dynamic regularisation of :345-348, as for the dense back-end.
+ *   fpsq_band_solve_two_*  = `ldiv!` with two right-hand sides (:189-203, :236-251) on the cached factor.
+ * Storage is (m / 128) x (half bandwidth in blocks + 1) blocks; create fails with FPSQ_ERR_STATE when that does not fit
+ * the device or a row spans more than 15360 columns.  Arguments may be host or device pointers; calls are synchronous. */
+typedef struct fpsq_band_s *fpsq_band;
+typedef struct {
+  int64_t n, m, nnz;
+  int64_t nblocks;           /* 128-row blocks of M */
+  int64_t bandwidth_blocks;  /* half bandwidth of M in blocks */
+  int64_t factor_bytes;      /* storage of the banded factor */
+  double last_form_ms, last_chol_ms, last_solve_ms;
+  int64_t regularized_pivots;
+} fpsq_band_info;
+int fpsq_band_create(fpsq_band *out, int64_t n, int64_t m, const int32_t *rowptr, const int32_t *colind, int32_t device);
+int fpsq_band_destroy(fpsq_band b);
+const char *fpsq_band_last_error(fpsq_band b);
+int fpsq_band_set_regularization(fpsq_band b, double tol, double reg);
+int fpsq_band_factorize(fpsq_band b, const double *vals, double delta, int32_t *info);
+int fpsq_band_solve_two_mixed(fpsq_band b, const double *rhs1, const double *rhs2, double *p1, double *q1, double *p2,
+                              double *q2);
+int fpsq_band_solve_two_least_squares(fpsq_band b, const double *rhs1, const double *rhs2, double *p1, double *q1,
+                                      double *p2, double *q2);
+int fpsq_band_get_info(fpsq_band b, fpsq_band_info *info);
+
 /* ---- introspection for benchmarks / profiling */
 typedef struct {
   int64_t n, m, nnz;
