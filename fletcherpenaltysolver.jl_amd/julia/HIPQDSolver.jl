@@ -21,6 +21,8 @@ mutable struct FpsqOptions  # fpsq_options (same field order as include/fpsq.h)
   ne_atol::Float64; ne_rtol::Float64; ne_etol::Float64; ne_itmax::Int64; ne_conlim::Float64
   ls_axtol::Float64; ls_btol::Float64; ls_etol::Float64; ls_conlim::Float64
   fuse_two_rhs::Int32; lookahead::Int32; device::Int32; jac_format::Int32
+  ln_method::Int32   # 0 = craig! (the default workspace, struct.jl:121), 1 = lnlq! through the generic solve_least_norm
+  reserved::Int32
   FpsqOptions() = new()
 end
 
@@ -29,6 +31,7 @@ end
 
 MI355X back-end for the systems `[I A'; A -δI]`; same constructor contract as `IterativeSolver`
 (src/solve_two_systems_struct.jl:94-131): the `ls_*`, `ln_*`, `ne_*` keywords are honoured, others are swallowed.
+`ln_method = 1` plays the role of passing `solver_struct_least_norm = LnlqWorkspace(...)` (struct.jl:121).
 """
 mutable struct HIPQDSolver{T, S} <: QDSolver
   handle::Ptr{Cvoid}
@@ -109,4 +112,92 @@ function solve_two_extras(nlp::FletcherPenaltyNLP{T, S, A, P, HIPQDSolver{T, S}}
   (rc & 1) != 0 && @warn "Failed solving 1st linear system lsqr in extra."
   (rc & 2) != 0 && @warn "Failed solving 2nd linear system minres in extra."
   return qds.q1, qds.q2
+end
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Direct back-end for sparse banded Jacobians: the role of LDLtSolver (src/solve_two_systems_struct.jl:299-353,
+# src/solve_linear_system.jl:142-252) on the MI355X -- include/fpsq.h, fpsq_band_*.  Same seam, same keyword names
+# (ldlt_tol, ldlt_r1, ldlt_r2).     FletcherPenaltySolver.qdsolver_correspondence[:hip_ldlt] = HIPLDLtSolver
+
+struct FpsqBandInfo
+  n::Int64; m::Int64; nnz::Int64; nblocks::Int64; bandwidth_blocks::Int64; factor_bytes::Int64
+  last_form_ms::Float64; last_chol_ms::Float64; last_solve_ms::Float64; regularized_pivots::Int64
+end
+
+mutable struct HIPLDLtSolver{T, S} <: QDSolver
+  handle::Ptr{Cvoid}
+  nvar::Int
+  ncon::Int
+  coo_vals::S          # jac_coord! output (model order)
+  csr_vals::S          # the same values in the CSR order handed to fpsq_band_create
+  slot::Vector{Int}    # CSR position of COO entry k (duplicates accumulate)
+  p1::S; q1::S; p2::S; q2::S
+  factorized::Bool
+  explicit_linear_constraints::Bool
+end
+
+function HIPLDLtSolver(nlp::AbstractNLPModel{T, S}, ::T; explicit_linear_constraints = false,
+                       ldlt_tol = √eps(T), ldlt_r1 = √eps(T), ldlt_r2 = -√eps(T), kwargs...) where {T, S}
+  T == Float64 || error("HIPLDLtSolver is fp64 only")
+  nvar = nlp.meta.nvar
+  ncon = explicit_linear_constraints ? nlp.meta.nnln : nlp.meta.ncon
+  rows, cols = explicit_linear_constraints ? jac_nln_structure(nlp) : jac_structure(nlp)       # struct.jl:331-337
+  pat = sparse(cols, rows, collect(1.0:length(rows)), nvar, ncon)   # CSC of A' = CSR of A; values = (summed) COO indices, unused
+  rowptr = Int32.(pat.colptr .- 1); colind = Int32.(pat.rowval .- 1)
+  key(r, c) = (r - 1) * nvar + c
+  csrkeys = [key(j, pat.rowval[k]) for j in 1:ncon for k in pat.colptr[j]:(pat.colptr[j + 1] - 1)]
+  slot = [searchsortedfirst(csrkeys, key(rows[k], cols[k])) for k in eachindex(rows)]
+  h = Ref{Ptr{Cvoid}}(C_NULL)
+  rc = ccall((:fpsq_band_create, libfpsq), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Int32),
+             h, nvar, ncon, rowptr, colind, 0)                       # symbolic phase = ldl_analyze, struct.jl:344
+  rc == 0 || error(unsafe_string(ccall((:fpsq_band_last_error, libfpsq), Cstring, (Ptr{Cvoid},), C_NULL)))
+  ccall((:fpsq_band_set_regularization, libfpsq), Cint, (Ptr{Cvoid}, Float64, Float64), h[], ldlt_tol, -ldlt_r2)  # :345-348
+  qds = HIPLDLtSolver{T, S}(h[], nvar, ncon, S(undef, length(rows)), S(undef, length(csrkeys)), slot, S(undef, nvar),
+                            S(undef, ncon), S(undef, nvar), S(undef, ncon), false, explicit_linear_constraints)
+  finalizer(q -> ccall((:fpsq_band_destroy, libfpsq), Cint, (Ptr{Cvoid},), q.handle), qds)
+  return qds
+end
+
+function _factorize!(qds::HIPLDLtSolver, nlp, x, δ)
+  qds.explicit_linear_constraints ? jac_nln_coord!(nlp.nlp, x, qds.coo_vals) : jac_coord!(nlp.nlp, x, qds.coo_vals)  # :223-228
+  fill!(qds.csr_vals, 0)
+  for k in eachindex(qds.slot)
+    qds.csr_vals[qds.slot[k]] += qds.coo_vals[k]
+  end
+  info = Ref{Int32}(0)
+  rc = ccall((:fpsq_band_factorize, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Float64, Ref{Int32}),
+             qds.handle, qds.csr_vals, δ, info)                       # sparse(...) + ldl_factorize!, :233-234
+  rc < 0 && error(unsafe_string(ccall((:fpsq_band_last_error, libfpsq), Cstring, (Ptr{Cvoid},), qds.handle)))
+  qds.factorized = rc == 0
+end
+
+function _band_solve!(qds::HIPLDLtSolver, fn::Symbol, rhs1, rhs2)
+  if !qds.factorized
+    @warn "_solve_ldlt_factorization: failed _factorization"                        # linear_system.jl:196-198, :244-246
+    return qds.p1, qds.q1, qds.p2, qds.q2
+  end
+  f = fn == :mixed ? :fpsq_band_solve_two_mixed : :fpsq_band_solve_two_least_squares
+  rc = fn == :mixed ?
+    ccall((:fpsq_band_solve_two_mixed, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+          qds.handle, rhs1, rhs2, qds.p1, qds.q1, qds.p2, qds.q2) :
+    ccall((:fpsq_band_solve_two_least_squares, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+          qds.handle, rhs1, rhs2, qds.p1, qds.q1, qds.p2, qds.q2)
+  rc < 0 && error(unsafe_string(ccall((:fpsq_band_last_error, libfpsq), Cstring, (Ptr{Cvoid},), qds.handle)))
+  return qds.p1, qds.q1, qds.p2, qds.q2
+end
+
+function solve_two_mixed(nlp::FletcherPenaltyNLP{T, S, A, P, HIPLDLtSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
+  _factorize!(nlp.qdsolver, nlp, x, nlp.δ)                                                       # :206-252
+  return _band_solve!(nlp.qdsolver, :mixed, rhs1, rhs2)
+end
+
+function solve_two_least_squares(nlp::FletcherPenaltyNLP{T, S, A, P, HIPLDLtSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
+  return _band_solve!(nlp.qdsolver, :least_squares, rhs1, rhs2)                                  # :161-204 (cached factor)
+end
+
+function solve_two_extras(nlp::FletcherPenaltyNLP{T, S, A, P, HIPLDLtSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
+  _factorize!(nlp.qdsolver, nlp, x, max(nlp.δ, 1e-14))                                           # :148: tau, Jacobian at x
+  _, q1, _, q2 = _band_solve!(nlp.qdsolver, :mixed, rhs1, rhs2)
+  return q1, -q2                                          # (A A' + tau I)^-1 A rhs1,  (A A' + tau I)^-1 rhs2
 end

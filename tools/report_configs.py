@@ -85,6 +85,46 @@ for delta in (0.0, SE):
     rows.append((f"cfg5 PDE-control-like n={qh.n} m={qh.m} nnz={qh.nnz}", f"LSQR+CRAIG fused, delta={delta:.3g}", f"{1 / dt:.0f} evals/s ({dt * 1e3:.3f} ms)",
                  f"iterations {its}, rc {rc}"))
 
+# B3 of BASELINE.md: the direct path's CPU stand-in -- scipy.sparse.linalg.splu (SuperLU, NOT LDL') on K = [I A'; A -delta I]
+# with two right-hand sides, for configs 1, 2 and 4; each in a child process with a 60 s cap (cfg2's K fills in heavily)
+import multiprocessing as mp
+
+
+def _splu_job(kind, q):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    if kind == "cfg1":
+        A = sp.csr_matrix(np.array([[24.0, 10.0]]))  # HS6 Jacobian at x0
+        delta = 0.0
+    else:
+        qq = problems.random_eqqp() if kind == "cfg2" else problems.aug2dc_like(N=100)
+        A = qq.scipy_csr()
+        delta = 0.0 if kind == "cfg2" else SE
+    m_, n_ = A.shape
+    K = sp.bmat([[sp.identity(n_), A.T], [A, -delta * sp.identity(m_)]], format="csc")
+    rhs = np.zeros((n_ + m_, 2))
+    rhs[:n_, 0] = 1.0
+    rhs[n_:, 1] = 1.0
+    t0 = time.perf_counter()
+    lu = spla.splu(K)
+    t1 = time.perf_counter()
+    lu.solve(rhs)
+    q.put((t1 - t0, time.perf_counter() - t1, int(lu.L.nnz + lu.U.nnz)))
+
+
+for kind, label in (("cfg1", "cfg1 HS6 n=2 m=1"), ("cfg2", "cfg2 random eq-QP"), ("cfg4", "cfg4 AUG2DC-like")):
+    q = mp.Queue()
+    pr = mp.Process(target=_splu_job, args=(kind, q))
+    pr.start()
+    pr.join(60.0)
+    if pr.is_alive():
+        pr.terminate()
+        rows.append((label, "B3: CPU direct stand-in, scipy splu(K) (SuperLU, 1 core)", "did not finish within 60 s", "fill-in of the random Jacobian"))
+    else:
+        tf, ts, nz = q.get()
+        rows.append((label, "B3: CPU direct stand-in, scipy splu(K) (SuperLU, 1 core)", f"factorise {tf * 1e3:.2f} ms + 2-RHS solve {ts * 1e3:.2f} ms = {1 / (tf + ts):.1f} evals/s", f"nnz(L+U) = {nz}"))
+
 print("| configuration | path | measured on one MI355X | notes |")
 print("|---|---|---|---|")
 for r in rows:
