@@ -560,12 +560,14 @@ __global__ __launch_bounds__(256) void k_potrf_inv128r(double* Mkk, int ld, doub
 // ---- fourth generation (the default): the same left-looking scheme over 16-column panels with COMPACT code.
 // The 64- and 32-wide register routines above are thousands of straight-line instructions executed once per call: the
 // wave spends its time waiting for instruction fetches (both run at ~220 us per block whatever their arithmetic).  Here
-// the only unrolled part is a 16 x 16 factor-and-invert routine (~1000 instructions) that is the body of a ROLLED loop
-// over the eight panels, so it is fetched once and reused; everything else is rolled loops over the LDS copy:
-//   per panel  (a) all threads: panel -= L[:, previous] L[panel rows, previous]'      (4 x 2 register tiles)
-//              (b) wave 0: L16 = chol(A16), X16 = L16^-1 in registers (v_readlane broadcasts)
-//              (c) one thread per row below: row <- row X16'
-//   then X = L^-1 by doubling: X(2h) = [X11 0; -X22 (L21 X11) X22] for h = 16, 32, 64, all pairs of a level together,
+// the only unrolled part is a 16 x 16 factor routine (~500 instructions) that is the body of a ROLLED loop over the eight
+// panels, so it is fetched once and reused; everything else is rolled / lightly unrolled loops over the LDS copy whose
+// LDS reads are issued in batches ahead of the arithmetic (one workgroup has no other wave to hide a round trip behind):
+//   per panel  (a) all threads: panel -= L[:, previous] L[panel rows, previous]'      (4 x 2 register tiles, 8 columns a step)
+//              (b) wave 0: L16 = chol(A16) in registers (v_readlane broadcasts; one rsqrt per column)
+//              (c) one thread per row below: row <- row L16^-T by forward substitution
+//   then the eight diagonal inverses X16 = L16^-1 (128 threads, one column each) and
+//   X = L^-1 by doubling: X(2h) = [X11 0; -X22 (L21 X11) X22] for h = 16, 32, 64, all pairs of a level together,
 //   stored transposed in the upper triangle of the LDS matrix (diagonal kept as 1 / L_ii in `dinv`).
 __device__ __forceinline__ void wave_diag16(double* L, int LD, int o, int row0, int* info, double tol, double reg,
                                             double* dinv) {
@@ -587,37 +589,35 @@ __device__ __forceinline__ void wave_diag16(double* L, int LD, int o, int row0, 
       if (lane == 0) atomicCAS(info, 0, row0 + o + j + 1);
       d = 1.0;  // a unit pivot keeps the kernel finite; the caller reports `info`
     }
-    const double piv = sqrt(d);
-    const double rp = 1.0 / piv;
+    const double rp = rsqrt(d);  // one reciprocal square root per column instead of a square root and a division
+    const double piv = d * rp;
     rdiag = rl == j ? rp : rdiag;
     const double l = rl > j ? a[j] * rp : (rl == j ? piv : 0.0);
     a[j] = l;
 #pragma unroll
     for (int c = j + 1; c < 16; ++c) a[c] -= l * rdlane(l, c);
   }
-  // X16 = L16^-1: acc_i = e_i - sum_{k<i} L[i][k] X[k][.], row k of X broadcast as soon as it is complete
-  double acc[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = c == rl ? 1.0 : 0.0;
-#pragma unroll
-  for (int k = 0; k < 15; ++k) {
-    const double dk = rdlane(rdiag, k);
-    const double lik = rl > k ? a[k] : 0.0;
-#pragma unroll
-    for (int c = 0; c <= k; ++c) acc[c] -= lik * (rdlane(acc[c], k) * dk);
-  }
   if (lane < 16) {
     dinv[o + lane] = rdiag;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      if (c <= lane) L[(o + lane) * LD + o + c] = a[c];                 // L16, lower
-      if (c < lane) L[(o + c) * LD + o + lane] = acc[c] * rdiag;        // X16(lane, c), kept transposed above it
-    }
+    for (int c = 0; c < 16; ++c)
+      if (c <= lane) L[(o + lane) * LD + o + c] = a[c];  // L16, lower
   }
 }
 
+#ifdef FPSQ_POTRF_TIMING  // tools/potrf_probe.hip: s_memtime stamps of thread 0 after every phase
+#define POTRF_STAMP() do { if (threadIdx.x == 0 && stamps) stamps[nst++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define POTRF_TIMING_ARG , long long* stamps
+#else
+#define POTRF_STAMP() do {} while (0)
+#define POTRF_TIMING_ARG
+#endif
 __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, double* inv, double* invT, int row0,
-                                                       int* info, double tol, double reg) {
+                                                       int* info, double tol, double reg POTRF_TIMING_ARG) {
+#ifdef FPSQ_POTRF_TIMING
+  int nst = 0;
+#endif
+  POTRF_STAMP();
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* L = sm;
   constexpr int LD = kDB + 1;
@@ -625,11 +625,25 @@ __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, doub
   constexpr int TLD = 33;
   double* dinv = T + 64 * TLD;
   const int tid = threadIdx.x, wave = tid >> 6;
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    L[r * LD + c] = (c <= r) ? Mkk[(size_t)r * ld + c] : 0.0;
+  // (16 unconditional loads in flight per thread and pass: a predicated load per element serialises on its latency --
+  // the straightforward loop took 24 us of the kernel's 178)
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = (pass * 16 + u) * 256 + tid;
+      v[u] = Mkk[(size_t)(e >> 7) * ld + (e & 127)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = (pass * 16 + u) * 256 + tid;
+      const int r = e >> 7, c = e & 127;
+      L[r * LD + c] = (c <= r) ? v[u] : 0.0;
+    }
   }
   __syncthreads();
+  POTRF_STAMP();
   auto Xe = [&](int r, int c) -> double { return r == c ? dinv[r] : L[c * LD + r]; };  // X(r, c), r >= c
   const int tr = tid >> 3, tc = (tid & 7) * 2;  // 32 x 8 thread grid: rows tr + 32 i, columns tc, tc + 1 of a panel
 #pragma unroll 1
@@ -639,16 +653,28 @@ __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, doub
       double acc[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = 0.0;
-#pragma unroll 4
-      for (int p = 0; p < o; ++p) {
-        const double b0 = L[(o + tc) * LD + p], b1 = L[(o + tc + 1) * LD + p];
+      // o is a multiple of 16: eight columns per step, all 48 LDS reads of a step issued before its 64 FMAs (one read
+      // round trip per step instead of one per column)
+      int rr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = o + tr + 32 * i;
-          const double av = r < kDB ? L[r * LD + p] : 0.0;
-          acc[i][0] += av * b0;
-          acc[i][1] += av * b1;
+      for (int i = 0; i < 4; ++i) rr[i] = min(o + tr + 32 * i, kDB - 1);  // (clamped rows are never stored)
+#pragma unroll 1
+      for (int p0 = 0; p0 < o; p0 += 8) {
+        double b0[8], b1[8], av[4][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          b0[q] = L[(o + tc) * LD + p0 + q];
+          b1[q] = L[(o + tc + 1) * LD + p0 + q];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) av[i][q] = L[rr[i] * LD + p0 + q];
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[i][0] += av[i][q] * b0[q];
+            acc[i][1] += av[i][q] * b1[q];
+          }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -659,33 +685,56 @@ __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, doub
         }
       }
       __syncthreads();
+  POTRF_STAMP();
     }
     if (wave == 0) wave_diag16(L, LD, o, row0, info, tol, reg, dinv);  // (b)
     __syncthreads();
+  POTRF_STAMP();
     {  // (c)
       const int r = o + 16 + tid;
       if (r < kDB) {
-        double a[16], out[16];
+        // x L16' = a by forward substitution (L16 read as LDS broadcasts; a 120-term dependent chain per row, but the
+        // rows run in parallel -- cheaper than inverting L16 inside the single-wave routine)
+        double x[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = L[r * LD + o + c];
+        for (int c = 0; c < 16; ++c) x[c] = L[r * LD + o + c];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          double s = a[c] * dinv[o + c];
+          double s = x[c];
 #pragma unroll
-          for (int p = 0; p < c; ++p) s += a[p] * L[(o + p) * LD + o + c];  // X16(c, p)
-          out[c] = s;
+          for (int p = 0; p < c; ++p) s -= x[p] * L[(o + c) * LD + o + p];
+          x[c] = s * dinv[o + c];
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) L[r * LD + o + c] = out[c];
+        for (int c = 0; c < 16; ++c) L[r * LD + o + c] = x[c];
       }
     }
     __syncthreads();
+  POTRF_STAMP();
   }
   for (int e = tid; e < kDB * kDB; e += 256) {
     const int r = e >> 7, c = e & 127;
     if (c <= r) Mkk[(size_t)r * ld + c] = L[r * LD + c];
   }
-  // ---- X = L^-1 by doubling
+  POTRF_STAMP();
+  // ---- X = L^-1: the eight diagonal 16 x 16 inverses (column c of block b: L16 x = e_c by substitution, 128 threads),
+  // then by doubling
+  if (tid < kDB) {
+    const int b0 = (tid >> 4) * 16, c = tid & 15;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double sacc = r == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int p = 0; p < r; ++p) sacc -= L[(b0 + r) * LD + b0 + p] * x[p];  // (x[p] = 0 for p < c)
+      x[r] = r >= c ? sacc * dinv[b0 + r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r > c) L[(b0 + c) * LD + b0 + r] = x[r];
+  }
+  __syncthreads();
+  POTRF_STAMP();
 #pragma unroll 1
   for (int h = 16; h < kDB; h *= 2) {
     const int w = h < 32 ? h : 32;  // column chunk; all 128 / (2h) pairs of the level together: 64 x w outputs per chunk
@@ -697,32 +746,78 @@ __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, doub
         const int gr = t / tpr, c4 = (t % tpr) * 4;
         const int q = gr / h, r = gr % h, b0 = q * 2 * h;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int p = cc + c4; p < h; ++p) {
+        const int pc = cc + c4;
+        // the four leading columns (diagonal / not-yet-lower entries of X): general form
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p = pc + q;
           const double lv = L[(b0 + h + r) * LD + b0 + p];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = cc + c4 + j;
-            acc[j] += p >= c ? lv * Xe(b0 + p, b0 + c) : 0.0;
+          for (int j = 0; j < 4; ++j) acc[j] += q >= j ? lv * Xe(b0 + p, b0 + pc + j) : 0.0;
+        }
+        // below them X(p, c) is a plain (transposed) LDS entry: no branch, four columns of loads in flight
+        const double* lrow = L + (b0 + h + r) * LD + b0;
+        const double* x0 = L + (b0 + pc) * LD + b0;  // X(p, pc + j) = x0[j * LD + p]
+        int p = pc + 4;
+        for (; p + 3 < h; p += 4) {
+          double lv[4], xv[4][4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            lv[q] = lrow[p + q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[q][j] = x0[j * LD + p + q];
           }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += lv[q] * xv[q][j];
+        }
+        for (; p < h; ++p) {
+          const double lv = lrow[p];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += lv * x0[j * LD + p];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) T[gr * TLD + c4 + j] = acc[j];
       }
       __syncthreads();
+  POTRF_STAMP();
       // X21[r][c] = - sum_{p <= r} X22(r, p) T[p][c]
       for (int t = tid; t < 64 * tpr; t += 256) {
         const int gr = t / tpr, c4 = (t % tpr) * 4;
         const int q = gr / h, r = gr % h, b0 = q * 2 * h;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int p = 0; p <= r; ++p) {
-          const double xv = Xe(b0 + h + r, b0 + h + p);
+        const double* xr = L + (b0 + h) * LD + b0 + h + r;  // X(h + r, h + p) = xr[p * LD] for p < r
+        const double* tq = T + (q * h) * TLD + c4;
+        int p = 0;
+        for (; p + 3 < r; p += 4) {
+          double xv[4], tv[4][4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += xv * T[(q * h + p) * TLD + c4 + j];
+          for (int u = 0; u < 4; ++u) {
+            xv[u] = xr[(p + u) * LD];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[u][j] = tq[(p + u) * TLD + j];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += xv[u] * tv[u][j];
+        }
+        for (; p < r; ++p) {
+          const double xv = xr[p * LD];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += xv * tq[p * TLD + j];
+        }
+        {
+          const double xd = dinv[b0 + h + r];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += xd * tq[r * TLD + j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) L[(b0 + cc + c4 + j) * LD + b0 + h + r] = -acc[j];
       }
       __syncthreads();
+  POTRF_STAMP();
     }
   }
   for (int e = tid; e < kDB * kDB; e += 256) {
@@ -730,6 +825,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, doub
     inv[(size_t)r * kDB + c] = c < r ? L[c * LD + r] : (c == r ? dinv[r] : 0.0);
     invT[(size_t)r * kDB + c] = c > r ? L[r * LD + c] : (c == r ? dinv[r] : 0.0);  // X' (upper), for coalesced X r products
   }
+  POTRF_STAMP();
 }
 
 // y (len rows) = A (rows x cols, lda) x, for NR right-hand sides interleaved [..][NR]; one wave per row.
