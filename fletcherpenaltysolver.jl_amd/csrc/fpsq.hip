@@ -922,13 +922,6 @@ __device__ __forceinline__ void minres_set_params(MinresState* S, const MinresPa
   S->ctlT.cb = 0.0;
 }
 
-// Parameters of every lane of a run in one launch (null state = lane kind not present).
-__global__ void k_lane_params(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrParams P1, CraigState* C, CraigParams PC) {
-  if (S0) lsqr_set_params(S0, P0);
-  if (S1) lsqr_set_params(S1, P1);
-  if (C) craig_set_params(C, PC);
-}
-
 // Start-up of a run in ONE launch: lane parameters (workgroup 0), the right-hand sides loaded into their interleaved
 // lanes with the squared-norm partials, and the vectors that start at zero.
 struct LoadSeg {

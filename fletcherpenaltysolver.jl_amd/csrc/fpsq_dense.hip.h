@@ -38,9 +38,11 @@ struct BlockStrides {
 template <bool LOWER>
 __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const double* __restrict__ A, int lda,
                                                      const double* __restrict__ B, int ldb, int K, double alpha,
-                                                     double beta, int kchunk = 0, size_t zstride = 0, BlockStrides bs = {}) {
+                                                     double beta, int kchunk = 0, size_t zstride = 0, BlockStrides bs = {},
+                                                     int skip00 = 0) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (LOWER && bi < bj) return;
+  if (skip00 && bi == 0 && bj == 0) return;  // look-ahead: tile (0, 0) of the trailing update is done on the critical stream
   int kbeg = 0;
   if (kchunk > 0) {
     kbeg = (int)blockIdx.z * kchunk;
@@ -123,6 +125,96 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
         double* p = Cb + (size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr;
         const double v = alpha * acc[i][j][r];
         *p = (beta != 0.0) ? v + beta * *p : v;
+      }
+}
+
+// The same product on 64 x 64 tiles, for the SHORT-K (K = 128) panel and trailing updates of the blocked Cholesky.  One
+// 128 x 128 x 128 tile keeps a CU's matrix cores busy for >= 13.7 us (a v_mfma_f64_16x16x4_f64 issues every 64 cycles per
+// SIMD on gfx950) and a factorisation step has at most ~120 of them for 256 CUs -- with 64 x 64 tiles four CUs share that
+// work.  4 waves in a 2 x 2 grid, each 32 x 32 = 2 x 2 MFMA tiles.  Tile indices are in units of 64; block addressing
+// (dense rows or BlockStrides) stays in units of 128.
+template <bool LOWER>
+__global__ __launch_bounds__(256) void k_gemm_nt_f64_t64(double* C, int ldc, const double* __restrict__ A, int lda,
+                                                         const double* __restrict__ B, int ldb, int K, double alpha,
+                                                         double beta, BlockStrides bs = {}, int skip00 = 0) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (LOWER && bi < bj) return;
+  if (skip00 && (bi >> 1) == 0 && (bj >> 1) == 0) return;
+  constexpr int T = 64, LDT = T + 16;
+  __shared__ double sA[2][kDK * LDT];
+  __shared__ double sB[2][kDK * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int Ib = bi >> 1, Jb = bj >> 1, si = (bi & 1) * T, sj = (bj & 1) * T;
+  const double* Ab = A + (bs.on ? (size_t)Ib * bs.a : (size_t)Ib * kDB * lda) + (size_t)si * lda;
+  const double* Bb = B + (bs.on ? (size_t)Jb * bs.b : (size_t)Jb * kDB * ldb) + (size_t)sj * ldb;
+  const int srow = tid >> 2, sk = (tid & 3) * 4;  // staging: 4 consecutive k of row (t >> 2) for both operands
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double ra[4], rb[4];
+  auto gload = [&](int k0) {
+    const double2* pa = reinterpret_cast<const double2*>(Ab + (size_t)srow * lda + k0 + sk);
+    const double2* pb = reinterpret_cast<const double2*>(Bb + (size_t)srow * ldb + k0 + sk);
+    const double2 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    ra[0] = a0.x; ra[1] = a0.y; ra[2] = a1.x; ra[3] = a1.y;
+    rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      sA[buf][(sk + q) * LDT + srow] = ra[q];
+      sB[buf][(sk + q) * LDT + srow] = rb[q];
+    }
+  };
+  const int fr = lane & 15, fk = lane >> 4;
+  int buf = 0;
+  if (K > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += kDK) {
+    const bool more = k0 + kDK < K;
+    if (more) gload(k0 + kDK);
+#pragma unroll
+    for (int ks = 0; ks < kDK / 4; ++ks) {
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = sA[buf][(ks * 4 + fk) * LDT + wr + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = sB[buf][(ks * 4 + fk) * LDT + wc + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  double* Cb = C + (bs.on ? (size_t)Ib * bs.ci + (size_t)Jb * bs.cj : (size_t)Ib * kDB * ldc + (size_t)Jb * kDB) +
+               (size_t)(si + wr) * ldc + sj + wc;
+  // beta != 0: all loads of the tile first, then the stores
+  double cold[2][2][4];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cold[i][j][r] = Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = alpha * acc[i][j][r];
+        Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr] = (beta != 0.0) ? v + beta * cold[i][j][r] : v;
       }
 }
 

@@ -713,19 +713,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   }
 }
 
-// zero up to four vectors in one launch
+// up to four vectors zeroed by the start-up launch (k_startup)
 struct ZeroArgs {
   double* p[4];
   int64_t n[4];
 };
-__global__ __launch_bounds__(kBlock) void k_zero_multi(ZeroArgs z) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (!z.p[k]) continue;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < z.n[k]; i += (int64_t)gridDim.x * kBlock) z.p[k][i] = 0.0;
-  }
-}
-
 // vals_out[t] = vals_in[perm[t]]  (refresh of the A' copy when the Jacobian values change)
 __global__ __launch_bounds__(kBlock) void k_gather(const double* __restrict__ in, const int32_t* __restrict__ perm,
                                                    double* __restrict__ out, int64_t n) {
@@ -748,29 +740,6 @@ __global__ __launch_bounds__(kBlock) void k_gather_sum(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ vector kernels
-
-// dst[i][lane] = src[i] (plain -> interleaved lane), with the squared-norm partial of what was stored
-template <int NL>
-__global__ __launch_bounds__(kBlock) void k_load_lane(const double* __restrict__ src, double scale, double* dst,
-                                                      int lane, int64_t n, double* partials, int64_t sum_len) {
-  __shared__ double red[4];
-  double sq = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double v = scale * src[i];
-    dst[i * NL + lane] = v;
-    if (i < sum_len) sq += v * v;
-  }
-  const double t = block_sum(sq, red);
-  if (threadIdx.x == 0 && partials) partials[blockIdx.x] = t;
-}
-
-// out[i] = a * x[i][lane] + b * y[i]   (de-interleave with an affine combination; y may be null when b == 0)
-template <int NL>
-__global__ __launch_bounds__(kBlock) void k_store_lane(const double* __restrict__ x, int lane, double a,
-                                                       const double* y, double b, double* out, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    out[i] = a * x[i * NL + lane] + (b != 0.0 ? b * y[i] : 0.0);
-}
 
 // (the segments are kernel arguments: select by branch, never through a pointer, or they are spilled to scratch)
 template <int NL>
