@@ -570,10 +570,10 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   const size_t fbytes = (size_t)b->nb * b->band_w * kDB * kDB * 8;
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  if ((size_t)maxspan * 8 > 120 * 1024 || fbytes + 3 * ((size_t)b->nb * kDB * kDB * 8) > free_b / 10 * 9) {
+  if ((size_t)maxspan * 16 > 150 * 1024 || fbytes + 3 * ((size_t)b->nb * kDB * kDB * 8) > free_b / 10 * 9) {
     char msg[256];
     snprintf(msg, sizeof msg, "fpsq_band_create: the banded direct path does not fit this Jacobian (row span %d columns "
-             "> 15360, or factor storage %.1f GB of %.1f GB free): use the iterative back-end", maxspan, fbytes / 1e9,
+             "> 9600, or factor storage %.1f GB of %.1f GB free): use the iterative back-end", maxspan, fbytes / 1e9,
              free_b / 1e9);
     g_band_create_error = msg;
     delete b;
@@ -627,7 +627,7 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   }
   hipDeviceSynchronize();
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
-  hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 8);
+  hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 16);
   b->info.n = n;
   b->info.m = m;
   b->info.nnz = nnz;
@@ -660,7 +660,7 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
   BCHK(b, hipMemsetAsync(b->Mb, 0, (size_t)nb * W * kDB * kDB * 8, s));
   hipEventRecord(b->e0, s);
   // numeric phase 1: M = A A' + delta I into the band (jac_coord! + sparse(...) of src/solve_linear_system.jl:223-233)
-  hipLaunchKernelGGL(k_band_form, dim3(nb), dim3(256), (size_t)b->span * 8, s, b->rowptr, b->colind, b->vals, b->rowspan,
+  hipLaunchKernelGGL(k_band_form, dim3(nb), dim3(256), (size_t)b->span * 16, s, b->rowptr, b->colind, b->vals, b->rowspan,
                      (int)b->m, (int)b->mpad, W, delta, b->Mb, b->span);
   hipEventRecord(b->e1, s);
   // numeric phase 2: right-looking block-banded Cholesky (ldl_factorize!, :234), the dense back-end's block kernels

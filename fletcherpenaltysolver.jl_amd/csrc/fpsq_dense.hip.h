@@ -1120,41 +1120,54 @@ __global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ L
 // One workgroup per 128-row block I.  For each of its rows i in turn: scatter the row into a dense LDS window over its
 // column span, then every thread takes rows j <= i of the band (blocks I - bw .. I) and gathers its dot product with
 // row i from the window (columns outside the window contribute nothing); M(i, j) goes to block (I, j / 128).
+// (A wave per band row with unit-stride loads was measured slower -- 114 against 87 ms at the headline size: the loop
+// over the band rows then is a chain of dependent loads, whereas 256 threads walking 256 rows keep 256 streams in flight.)
 // Deterministic (fixed summation order, no atomics).  rowspan[i] = {first column, last column} of row i.
 __global__ __launch_bounds__(256) void k_band_form(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                                                    const double* __restrict__ vals, const int2* __restrict__ rowspan,
                                                    int m, int mpad, int band_w, double delta, double* Mb, int span) {
-  extern __shared__ __attribute__((aligned(16))) double win[];
+  extern __shared__ __attribute__((aligned(16))) double win[];  // two windows of `span` doubles: rows i and i + 1
   const int I = blockIdx.x, tid = threadIdx.x;
-  for (int k = tid; k < span; k += 256) win[k] = 0.0;
+  for (int k = tid; k < 2 * span; k += 256) win[k] = 0.0;
   __syncthreads();
   const int i0 = I * kDB;
   const int bw = band_w - 1;
   const int jlo = max(0, I - bw) * kDB;
-  for (int ii = 0; ii < kDB; ++ii) {
+  // TWO rows of the block per pass: every entry of a band row that is loaded serves both dot products (the band rows
+  // are re-read from L2 once per pass: 64 instead of 128 times)
+  for (int ii = 0; ii < kDB; ii += 2) {
     const int i = i0 + ii;
-    double* Mrow = Mb + ((size_t)I * band_w) * kDB * kDB + (size_t)ii * kDB;  // row ii of block (I, I - bw)
+    double* Mrow0 = Mb + ((size_t)I * band_w) * kDB * kDB + (size_t)ii * kDB;  // row ii of block (I, I - bw)
+    double* Mrow1 = Mrow0 + kDB;
     if (i >= m) {  // padding: identity
-      if (tid == 0 && i < mpad) Mrow[(size_t)bw * kDB * kDB + ii] = 1.0;
+      if (tid == 0 && i < mpad) Mrow0[(size_t)bw * kDB * kDB + ii] = 1.0;
+      if (tid == 0 && i + 1 < mpad) Mrow1[(size_t)bw * kDB * kDB + ii + 1] = 1.0;
       continue;
     }
-    const int s = rowptr[i], e = rowptr[i + 1];
-    const int2 sp = rowspan[i];
-    for (int k = s + tid; k < e; k += 256) win[colind[k] - sp.x] = vals[k];
+    const bool two = i + 1 < m;
+    const int s0 = rowptr[i], e0 = rowptr[i + 1], e1 = two ? rowptr[i + 2] : e0;
+    const int2 sp0 = rowspan[i];
+    const int2 sp1 = two ? rowspan[i + 1] : int2{1, 0};  // (an empty span: nothing matches)
+    for (int k = s0 + tid; k < e0; k += 256) win[colind[k] - sp0.x] = vals[k];
+    for (int k = e0 + tid; k < e1; k += 256) win[span + colind[k] - sp1.x] = vals[k];
     __syncthreads();
-    for (int j = jlo + tid; j <= i; j += 256) {
+    for (int j = jlo + tid; j <= i + 1 && j < m; j += 256) {
       const int js = rowptr[j], je = rowptr[j + 1];
-      double acc = 0.0;
+      double a0 = 0.0, a1 = 0.0;
       for (int k = js; k < je; ++k) {
         const int c = colind[k];
-        if (c >= sp.x && c <= sp.y) acc += vals[k] * win[c - sp.x];
+        const double v = vals[k];
+        if (c >= sp0.x && c <= sp0.y) a0 += v * win[c - sp0.x];
+        if (c >= sp1.x && c <= sp1.y) a1 += v * win[span + c - sp1.x];
       }
-      if (j == i) acc += delta;
-      const int J = j >> 7;
-      Mrow[(size_t)(J - I + bw) * kDB * kDB + (j & 127)] = acc;
+      const size_t off = (size_t)((j >> 7) - I + bw) * kDB * kDB + (j & 127);
+      if (j <= i) Mrow0[off] = j == i ? a0 + delta : a0;
+      if (two) Mrow1[off] = j == i + 1 ? a1 + delta : a1;  // (j <= i + 1 by the loop bound)
     }
+    if (!two && i + 1 < mpad && tid == 0) Mrow1[(size_t)bw * kDB * kDB + ii + 1] = 1.0;  // first padding row
     __syncthreads();
-    for (int k = s + tid; k < e; k += 256) win[colind[k] - sp.x] = 0.0;
+    for (int k = s0 + tid; k < e0; k += 256) win[colind[k] - sp0.x] = 0.0;
+    for (int k = e0 + tid; k < e1; k += 256) win[span + colind[k] - sp1.x] = 0.0;
     __syncthreads();
   }
 }
