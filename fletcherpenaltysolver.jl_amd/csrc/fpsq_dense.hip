@@ -31,6 +31,8 @@ struct fpsq_dense_s {
   int potrf_gen = 4;  // diagonal-block kernel: 4 = compact 16-column panels (k_potrf_inv128p), 3 = 32-column panels
                       // (k_potrf_inv128r), 2 = wave-level 64 (k_potrf_inv128w), 1 = unblocked (FPSQ_DENSE_POTRF selects;
                       // 3 and 4 regularise pivots and feed the coalesced triangular solves)
+  int gram_kd = 16;        // k-depth of an LDS stage of the Gram product (FPSQ_DENSE_GRAM_KD = 16 | 32; 32 measured
+                           // slower, 0.83 against 0.78 ms: the kernel is not waiting for its operand prefetch)
   int splitk = 1;          // k-slices of the Gram-matrix product (balance of the 128 x 128 tiles over the CUs)
   double* planes = nullptr;  // splitk partial planes of M
   double piv_tol = 0.0, piv_reg = 0.0;  // dynamic regularisation (fpsq_dense_set_regularization); reg <= 0: off
@@ -175,6 +177,10 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   hipFuncSetAttribute((const void*)k_potrf_inv128r, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) d->potrf_gen = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_KD")) d->gram_kd = std::atoi(ev);
+  hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds32);
+  hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
+  hipFuncSetAttribute((const void*)k_gemm_nt_f64<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   {
     // k-slices of the Gram product (FPSQ_DENSE_SPLITK, default 1 = off).  Measured at n = 4096, m = 2048 on the MI355X:
     // 0.76 / 0.94 / 1.09 / 1.18 ms for 1 / 8 / 12 / 15 slices -- the product kernel itself takes the same ~0.77 ms however
@@ -241,12 +247,16 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
     const int ksteps = (int)(d->npad / kDK);
     const int kchunk = (ksteps + d->splitk - 1) / d->splitk * kDK;
     const size_t zs = (size_t)d->mpad * d->mpad;
-    hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb, d->splitk), dim3(256), 0, s, d->planes, ld, d->A, (int)d->npad, d->A,
+    hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb, d->splitk), dim3(256), kGemmLds16, s, d->planes, ld, d->A, (int)d->npad, d->A,
                        (int)d->npad, (int)d->npad, 1.0, 0.0, kchunk, zs);
     hipLaunchKernelGGL(k_syrk_reduce, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->planes, zs, d->splitk, (int)d->m, delta);
   } else {
-    hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->A, (int)d->npad, d->A, (int)d->npad,
-                       (int)d->npad, 1.0, 0.0, 0, (size_t)0);
+    if (d->gram_kd == 32 && d->npad % 32 == 0)
+      hipLaunchKernelGGL((k_gemm_nt_f64<true, 32>), dim3(nb, nb), dim3(256), kGemmLds32, s, d->M, ld, d->A, (int)d->npad, d->A,
+                         (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
+    else
+      hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb), dim3(256), kGemmLds16, s, d->M, ld, d->A, (int)d->npad, d->A,
+                         (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
     hipLaunchKernelGGL(k_dense_diag, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->M, ld, (int)d->m,
                        (int)d->mpad, delta);
   }
@@ -273,15 +283,15 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
       double* panel = d->M + (size_t)(k + 1) * kDB * ld + (size_t)k * kDB;
       double* trail = d->M + (size_t)(k + 1) * kDB * ld + (size_t)(k + 1) * kDB;
       if (d->potrf_gen < 3) {  // (the older generations keep the round-1 launch sequence)
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), 0, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0,
+        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0,
                            0, (size_t)0);
-        hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(rem, rem), dim3(256), 0, s, trail, ld, panel, ld, panel, ld, kDB, -1.0,
+        hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(rem, rem), dim3(256), kGemmLds16, s, trail, ld, panel, ld, panel, ld, kDB, -1.0,
                            1.0, 0, (size_t)0);
         continue;
       }
       if (!d->lookahead) {  // 64 x 64 tiles for the K = 128 products (k_gemm_nt_f64_t64)
         // (the panel is updated IN PLACE: its tiles must own whole rows, so it stays on the 128-wide kernel)
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), 0, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0,
+        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0,
                            0, (size_t)0);
         hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s, trail, ld, panel, ld, panel, ld,
                            kDB, -1.0, 1.0, BlockStrides{}, 0);
@@ -292,14 +302,14 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
       // the trailing update runs next to that potrf on the second stream.
       hipStream_t s2 = d->stream2;
       if (k > 0) hipStreamWaitEvent(s, d->evB, 0);  // step k - 1's trailing rest wrote M(k+1, k) and M(k+1, k+1)
-      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, 1), dim3(256), 0, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0, 0,
+      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, 1), dim3(256), kGemmLds16, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0, 0,
                          (size_t)0);
       hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2, 2), dim3(256), 0, s, trail, ld, panel, ld, panel, ld, kDB, -1.0, 1.0,
                          BlockStrides{}, 0);
       hipEventRecord(d->evA, s);
       hipStreamWaitEvent(s2, d->evA, 0);
       if (rem > 1) {
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem - 1), dim3(256), 0, s2, panel + (size_t)kDB * ld, ld,
+        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem - 1), dim3(256), kGemmLds16, s2, panel + (size_t)kDB * ld, ld,
                            panel + (size_t)kDB * ld, ld, inv, kDB, kDB, 1.0, 0.0, 0, (size_t)0);
         hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s2, trail, ld, panel, ld, panel, ld,
                            kDB, -1.0, 1.0, BlockStrides{}, 1);
@@ -628,6 +638,8 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   hipDeviceSynchronize();
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 16);
+  hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
+  hipFuncSetAttribute((const void*)k_gemm_nt_f64<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   b->info.n = n;
   b->info.m = m;
   b->info.nnz = nnz;
@@ -683,7 +695,7 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
       ts.cj = (size_t)kDB * kDB;
       double* trail = b->Mb + blk_off(b, k + 1, k + 1);
       if (!b->lookahead) {
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), 0, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0,
+        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0,
                            0.0, 0, (size_t)0, ps);
         hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s, trail, kDB, panel, kDB, panel,
                            kDB, kDB, -1.0, 1.0, ts, 0);
@@ -692,7 +704,7 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
       // look-ahead as in fpsq_dense_factorize: first panel tile + first trailing tile here, the rest on the second stream
       hipStream_t s2 = b->stream2;
       if (k > 0) hipStreamWaitEvent(s, b->evB, 0);
-      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, 1), dim3(256), 0, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0, 0.0, 0,
+      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, 1), dim3(256), kGemmLds16, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0, 0.0, 0,
                          (size_t)0, ps);
       hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2, 2), dim3(256), 0, s, trail, kDB, panel, kDB, panel, kDB, kDB, -1.0,
                          1.0, ts, 0);
@@ -700,7 +712,7 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
       hipStreamWaitEvent(s2, b->evA, 0);
       if (rem > 1) {
         double* panel2 = b->Mb + blk_off(b, k + 2, k);
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem - 1), dim3(256), 0, s2, panel2, kDB, panel2, kDB, inv, kDB, kDB,
+        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem - 1), dim3(256), kGemmLds16, s2, panel2, kDB, panel2, kDB, inv, kDB, kDB,
                            1.0, 0.0, 0, (size_t)0, ps);
         hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s2, trail, kDB, panel, kDB, panel,
                            kDB, kDB, -1.0, 1.0, ts, 1);

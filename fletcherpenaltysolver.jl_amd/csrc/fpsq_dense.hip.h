@@ -13,6 +13,8 @@ namespace fpsq {
 
 constexpr int kDB = 128;      // block size of the Cholesky / GEMM tiles
 constexpr int kDK = 16;       // k-depth of one LDS stage
+constexpr int kGemmLds16 = 4 * 16 * 144 * 8;  // dynamic LDS of k_gemm_nt_f64<., 16> / <., 32>
+constexpr int kGemmLds32 = 4 * 32 * 144 * 8;
 constexpr int kPotrfLds = (kDB * (kDB + 1) + 3 * 32 * 33 + kDB) * 8;  // k_potrf_inv128r / 128p: block + scratch + 1/diag
 constexpr int kDLd = 144;     // LDS leading dimension (doubles) of a [k][row] tile: 128 + 16 so that the four k-planes a
                               // wave reads with one ds_read_b64 fall in disjoint bank halves
@@ -35,7 +37,9 @@ struct BlockStrides {
 // keeps one CU's matrix cores busy for >= 0.44 ms (v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD on gfx950), so the
 // 136 lower tiles of the m = 2048 Gram matrix leave half the chip idle however fast the kernel is; slices restore the
 // balance.
-template <bool LOWER>
+// KD = k-depth of one LDS stage (16, or 32 as an experiment: a deeper stage gives the next stage's operand loads twice
+// the time to arrive -- measured slower for the Gram product, 0.83 against 0.78 ms, so that latency is not the bound).
+template <bool LOWER, int KD = kDK>
 __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const double* __restrict__ A, int lda,
                                                      const double* __restrict__ B, int ldb, int K, double alpha,
                                                      double beta, int kchunk = 0, size_t zstride = 0, BlockStrides bs = {},
@@ -53,27 +57,29 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
     K -= kbeg;
     if (K < 0) K = 0;
   }
-  __shared__ double sA[2][kDK * kDLd];
-  __shared__ double sB[2][kDK * kDLd];
+  extern __shared__ __attribute__((aligned(16))) double gsm[];
+  double* sA0 = gsm;                 // [2][KD * kDLd]
+  double* sB0 = gsm + 2 * KD * kDLd;  // [2][KD * kDLd]
+  constexpr int KT = KD / 2;         // k per staging thread (two threads per row)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;  // this wave's 64 x 64 sub-tile
   // operand / result tiles: rows of a dense matrix, or (bs.on) blocks of a block-banded storage at affine offsets
   const double* Ab = A + (bs.on ? (size_t)bi * bs.a : (size_t)bi * kDB * lda);
   const double* Bb = B + (bs.on ? (size_t)bj * bs.b : (size_t)bj * kDB * ldb);
   // staging: thread t copies 8 consecutive k of row (t >> 1) for both operands
-  const int srow = tid >> 1, sk = (tid & 1) * 8;
+  const int srow = tid >> 1, sk = (tid & 1) * KT;
   f64x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  double ra[8], rb[8];
+  double ra[KT], rb[KT];
   auto gload = [&](int k0) {
     const double2* pa = reinterpret_cast<const double2*>(Ab + (size_t)srow * lda + k0 + sk);
     const double2* pb = reinterpret_cast<const double2*>(Bb + (size_t)srow * ldb + k0 + sk);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < KT / 2; ++q) {
       const double2 a = pa[q], b = pb[q];
       ra[2 * q] = a.x;
       ra[2 * q + 1] = a.y;
@@ -83,9 +89,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      sA[buf][(sk + q) * kDLd + srow] = ra[q];
-      sB[buf][(sk + q) * kDLd + srow] = rb[q];
+    for (int q = 0; q < KT; ++q) {
+      sA0[buf * KD * kDLd + (sk + q) * kDLd + srow] = ra[q];
+      sB0[buf * KD * kDLd + (sk + q) * kDLd + srow] = rb[q];
     }
   };
   const int fr = lane & 15, fk = lane >> 4;
@@ -95,16 +101,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
     lstore(0);
   }
   __syncthreads();
-  for (int k0 = 0; k0 < K; k0 += kDK) {
-    const bool more = k0 + kDK < K;
-    if (more) gload(k0 + kDK);
+  for (int k0 = 0; k0 < K; k0 += KD) {
+    const bool more = k0 + KD < K;
+    if (more) gload(k0 + KD);
 #pragma unroll
-    for (int ks = 0; ks < kDK / 4; ++ks) {
+    for (int ks = 0; ks < KD / 4; ++ks) {
       double a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = sA[buf][(ks * 4 + fk) * kDLd + wr + i * 16 + fr];
+      for (int i = 0; i < 4; ++i) a[i] = sA0[buf * KD * kDLd + (ks * 4 + fk) * kDLd + wr + i * 16 + fr];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = sB[buf][(ks * 4 + fk) * kDLd + wc + j * 16 + fr];
+      for (int j = 0; j < 4; ++j) b[j] = sB0[buf * KD * kDLd + (ks * 4 + fk) * kDLd + wc + j * 16 + fr];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
