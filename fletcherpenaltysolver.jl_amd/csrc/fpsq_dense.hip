@@ -28,7 +28,8 @@ struct fpsq_dense_s {
   double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
   int* info_dev = nullptr;
   int nchunk = 16;
-  int potrf_gen = 4;  // diagonal-block kernel: 4 = compact 16-column panels (k_potrf_inv128p), 3 = 32-column panels
+  int potrf_gen = 5;  // diagonal-block kernel: 5 = generation 4 with its panel updates and doubling inverse on the matrix
+                      // cores (k_potrf_inv128m), 4 = compact 16-column panels (k_potrf_inv128p), 3 = 32-column panels
                       // (k_potrf_inv128r), 2 = wave-level 64 (k_potrf_inv128w), 1 = unblocked (FPSQ_DENSE_POTRF selects;
                       // 3 and 4 regularise pivots and feed the coalesced triangular solves)
   int gram_kd = 16;        // k-depth of an LDS stage of the Gram product (FPSQ_DENSE_GRAM_KD = 16 | 32; 32 measured
@@ -150,6 +151,10 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   rc |= dmalloc(d, &d->M, (size_t)d->mpad * d->mpad);
   rc |= dmalloc(d, &d->invs, (size_t)d->nb * kDB * kDB);
   rc |= dmalloc(d, &d->invsT, (size_t)d->nb * kDB * kDB);
+  if (!rc) {  // k_potrf_inv128m writes the non-zero triangles only
+    hipMemset(d->invs, 0, (size_t)d->nb * kDB * kDB * 8);
+    hipMemset(d->invsT, 0, (size_t)d->nb * kDB * kDB * 8);
+  }
   rc |= dmalloc(d, &d->r2, (size_t)d->mpad * 2);
   rc |= dmalloc(d, &d->y2, (size_t)d->mpad * 2);
   rc |= dmalloc(d, &d->x2, (size_t)d->npad * 2);
@@ -176,6 +181,7 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
                       (kDB * (kDB + 1) + kDB) * 8);
   hipFuncSetAttribute((const void*)k_potrf_inv128r, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
+  hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5);
   if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) d->potrf_gen = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_KD")) d->gram_kd = std::atoi(ev);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds32);
@@ -266,7 +272,10 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
   for (int k = 0; k < nb; ++k) {
     double* Mkk = d->M + (size_t)k * kDB * ld + (size_t)k * kDB;
     double* inv = d->invs + (size_t)k * kDB * kDB;
-    if (d->potrf_gen == 4)
+    if (d->potrf_gen >= 5)
+      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(256), kPotrfLds5, s, Mkk, ld, inv,
+                         d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
+    else if (d->potrf_gen == 4)
       hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, ld, inv,
                          d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
     else if (d->potrf_gen == 3)
@@ -406,6 +415,7 @@ struct fpsq_band_s {
   int64_t n = 0, m = 0, nnz = 0, mpad = 0, nb = 0;
   int band_w = 1;  // blocks per block row of the band storage = half bandwidth (in blocks) + 1
   int span = 0;    // widest column span of a row (LDS window of k_band_form)
+  int form_gen = 2, form_R = 1;  // 2: k_band_form_t (by columns of A, form_R rows per pass); 1: k_band_form (row pairs)
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -423,6 +433,7 @@ struct fpsq_band_s {
   hipStream_t stream2 = nullptr;  // look-ahead (see fpsq_dense_factorize)
   hipEvent_t evA = nullptr, evB = nullptr;
   int lookahead = 0;
+  int potrf_gen = 5;  // as fpsq_dense_s (4 or 5)
   fpsq_band_info info{};
   std::vector<void*> allocs;
 };
@@ -542,6 +553,8 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   }
   std::vector<int32_t> cfirst(n, INT32_MAX), clast(n, -1), tcnt(n + 1, 0);
   std::vector<int2> span(m);
+  std::vector<int32_t> seen(n, -1);
+  bool has_dup = false;
   int maxspan = 1;
   for (int64_t i = 0; i < m; ++i) {
     if (rp[i + 1] < rp[i]) {
@@ -557,6 +570,8 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
       }
       lo = std::min(lo, c);
       hi = std::max(hi, c);
+      has_dup |= seen[c] == (int32_t)i;
+      seen[c] = (int32_t)i;
       cfirst[c] = std::min<int32_t>(cfirst[c], (int32_t)i);
       clast[c] = std::max<int32_t>(clast[c], (int32_t)i);
       tcnt[c + 1]++;
@@ -577,14 +592,28 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   b->nb = b->mpad / kDB;
   b->band_w = (int)std::min<int64_t>(bwb, b->nb - 1) + 1;
   b->span = maxspan;
+  if (has_dup) {
+    g_band_create_error = "fpsq_band_create: the CSR pattern has duplicate entries (sum them first)";
+    delete b;
+    return FPSQ_ERR_ARG;
+  }
+  // M is formed by columns of A (k_band_form_t) when its accumulator rows fit in LDS; otherwise by row pairs
+  // (k_band_form), which needs the widest row span in LDS twice
+  b->form_R = 16;
+  while (b->form_R > 1 && b->form_R * b->band_w > 144) b->form_R /= 2;
+  b->form_gen = b->band_w > 144 ? 1 : 2;
+  if (const char* ev = std::getenv("FPSQ_BAND_FORM")) {
+    const int want = std::atoi(ev);
+    if (want == 1 || (want == 2 && b->band_w <= 144)) b->form_gen = want;
+  }
   const size_t fbytes = (size_t)b->nb * b->band_w * kDB * kDB * 8;
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  if ((size_t)maxspan * 16 > 150 * 1024 || fbytes + 3 * ((size_t)b->nb * kDB * kDB * 8) > free_b / 10 * 9) {
+  if ((b->form_gen == 1 && (size_t)maxspan * 16 > 150 * 1024) || fbytes + 3 * ((size_t)b->nb * kDB * kDB * 8) > free_b / 10 * 9) {
     char msg[256];
-    snprintf(msg, sizeof msg, "fpsq_band_create: the banded direct path does not fit this Jacobian (row span %d columns "
-             "> 9600, or factor storage %.1f GB of %.1f GB free): use the iterative back-end", maxspan, fbytes / 1e9,
-             free_b / 1e9);
+    snprintf(msg, sizeof msg, "fpsq_band_create: the banded direct path does not fit this Jacobian (half bandwidth %d "
+             "blocks > 143 and a row span of %d columns > 9600, or factor storage %.1f GB of %.1f GB "
+             "free): use the iterative back-end", b->band_w - 1, maxspan, fbytes / 1e9, free_b / 1e9);
     g_band_create_error = msg;
     delete b;
     return FPSQ_ERR_STATE;
@@ -627,6 +656,8 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
     fpsq_band_destroy(b);
     return FPSQ_ERR_HIP;
   }
+  hipMemset(b->invs, 0, (size_t)b->nb * kDB * kDB * 8);  // k_potrf_inv128m writes the non-zero triangles only
+  hipMemset(b->invsT, 0, (size_t)b->nb * kDB * kDB * 8);
   hipMemcpy(b->rowptr, rp.data(), (size_t)(m + 1) * 4, hipMemcpyHostToDevice);
   hipMemcpy(b->t_rowptr, tcnt.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice);
   hipMemcpy(b->rowspan, span.data(), (size_t)m * sizeof(int2), hipMemcpyHostToDevice);
@@ -637,7 +668,13 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   }
   hipDeviceSynchronize();
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
-  hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 16);
+  hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5);
+  if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) b->potrf_gen = std::atoi(ev) >= 5 ? 5 : 4;
+  if (b->form_gen == 1)
+    hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 16);
+  else
+    hipFuncSetAttribute((const void*)k_band_form_t, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        b->form_R * b->band_w * kDB * 8);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   b->info.n = n;
@@ -672,15 +709,23 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
   BCHK(b, hipMemsetAsync(b->Mb, 0, (size_t)nb * W * kDB * kDB * 8, s));
   hipEventRecord(b->e0, s);
   // numeric phase 1: M = A A' + delta I into the band (jac_coord! + sparse(...) of src/solve_linear_system.jl:223-233)
-  hipLaunchKernelGGL(k_band_form, dim3(nb), dim3(256), (size_t)b->span * 16, s, b->rowptr, b->colind, b->vals, b->rowspan,
-                     (int)b->m, (int)b->mpad, W, delta, b->Mb, b->span);
+  if (b->form_gen == 1)
+    hipLaunchKernelGGL(k_band_form, dim3(nb), dim3(256), (size_t)b->span * 16, s, b->rowptr, b->colind, b->vals, b->rowspan,
+                       (int)b->m, (int)b->mpad, W, delta, b->Mb, b->span);
+  else
+    hipLaunchKernelGGL(k_band_form_t, dim3(nb), dim3(256), (size_t)b->form_R * W * kDB * 8, s, b->rowptr, b->colind, b->vals,
+                       b->t_rowptr, b->t_colind, b->t_vals, (int)b->m, (int)b->mpad, W, delta, b->Mb, b->form_R);
   hipEventRecord(b->e1, s);
   // numeric phase 2: right-looking block-banded Cholesky (ldl_factorize!, :234), the dense back-end's block kernels
   for (int k = 0; k < nb; ++k) {
     double* Mkk = b->Mb + blk_off(b, k, k);
     double* inv = b->invs + (size_t)k * kDB * kDB;
-    hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
-                       k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
+    if (b->potrf_gen >= 5)
+      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(256), kPotrfLds5, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
+                         k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
+    else
+      hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
+                         k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
     const int rem = std::min(bw, nb - 1 - k);
     if (rem > 0) {
       BlockStrides ps;

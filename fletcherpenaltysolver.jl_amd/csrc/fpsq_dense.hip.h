@@ -926,6 +926,247 @@ __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, doub
   POTRF_STAMP();
 }
 
+// ---- fifth generation (the default): generation 4 with its two GEMM-shaped parts on the matrix cores.  The phase
+// probe of generation 4 (profiles/r02_potrf_phase_probe.txt, cycles of 276k): left-looking panel updates 55k (LDS
+// bandwidth: 6 reads per 8 FMAs), the 16 x 16 factor routine 8 x 8.1k, row substitutions 8 x 2.8k, doubling inverse 84k,
+// load / stores 44k.  Here
+//   (a) the panel update is v_mfma_f64_16x16x4_f64 on 16 x 16 tiles read straight from the LDS copy (leading dimension
+//       130: the 16 rows x 4 k of an operand fall in distinct banks); wave 0 updates the diagonal tile and goes on to
+//       factor it while waves 1-3 update the tiles below -- their work hides behind the serial 16 x 16 routine;
+//   (d) the doubling steps T = L21 X11 and X21 = -X22 T are MFMA tile products too (T kept transposed, 32 columns at a
+//       time, so both operands of both products are read k-contiguous); entries of the triangular 16 x 16 diagonal
+//       sub-blocks of X are selected on load (strictly lower from the transposed store, diagonal from `dinv`, else 0).
+// Steps (b), (c) and the 16 x 16 inverses are generation 4's.
+#ifndef FPSQ_POTRF_LD5
+#define FPSQ_POTRF_LD5 (kDB + 2)
+#endif
+constexpr int kPotrfLd5 = FPSQ_POTRF_LD5;
+constexpr int kPotrfTld5 = 66;
+constexpr int kPotrfLds5 = (kDB * kPotrfLd5 + 32 * kPotrfTld5 + kDB) * 8;
+
+// the 16 x 16 factor routine of generation 5: wave_diag16 without branches (pivot tests by selects, the counters
+// reported once at the end), so the whole routine is one basic block and the scheduler can run the reciprocal square
+// root of column j + 1 under the updates of column j
+__device__ __forceinline__ void wave_diag16s(double* L, int LD, int o, int row0, int* info, double tol, double reg,
+                                             double* dinv) {
+  const int lane = threadIdx.x & 63;
+  const int rl = lane & 15;  // lanes 16..63 mirror 0..15
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = L[(o + rl) * LD + o + c];
+  double rdiag = 1.0;  // this lane's 1 / L[rl][rl]
+  const bool dyn = reg > 0.0;
+  const double thr = dyn ? tol : 0.0, sub = dyn ? reg : 1.0;  // (a unit pivot keeps the kernel finite when none is set)
+  int nbad = 0, first = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double d = rdlane(a[j], j);
+    const bool bad = !(d > thr);
+    first = (bad && nbad == 0) ? j + 1 : first;
+    nbad += bad ? 1 : 0;
+    d = bad ? sub : d;
+    const double rp = rsqrt(d);
+    const double piv = d * rp;
+    rdiag = rl == j ? rp : rdiag;
+    const double l = rl > j ? a[j] * rp : (rl == j ? piv : 0.0);
+    a[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) a[c] -= l * rdlane(l, c);
+  }
+  if (lane < 16) {
+    dinv[o + lane] = rdiag;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c <= lane) L[(o + lane) * LD + o + c] = a[c];  // L16, lower
+  }
+  if (lane == 0 && nbad) {
+    if (dyn)
+      atomicAdd(info + 1, nbad);
+    else
+      atomicCAS(info, 0, row0 + o + first);
+  }
+}
+
+// inv / invT are written in their non-zero triangles only: the caller zero-fills both buffers ONCE (at allocation).
+__global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, double* inv, double* invT, int row0,
+                                                       int* info, double tol, double reg POTRF_TIMING_ARG) {
+#ifdef FPSQ_POTRF_TIMING
+  int nst = 0;
+#endif
+  POTRF_STAMP();
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* L = sm;
+  constexpr int LD = kPotrfLd5;
+  double* Tt = sm + kDB * LD;  // Tt[c][row]: 32 columns x 64 rows of the doubling steps' T, transposed
+  constexpr int TLD = kPotrfTld5;
+  double* dinv = Tt + 32 * TLD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int tr = tid >> 4, tc = tid & 15;  // element of a 16 x 16 tile
+  // the 36 lower tiles, every load in flight at once (one HBM round trip for the block)
+  {
+    double v[36];
+#pragma unroll
+    for (int t = 0; t < 36; ++t) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      const int tj = t - ti * (ti + 1) / 2;
+      v[t] = Mkk[(size_t)(16 * ti + tr) * ld + 16 * tj + tc];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 36; ++t) {
+      int ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      const int tj = t - ti * (ti + 1) / 2;
+      L[(16 * ti + tr) * LD + 16 * tj + tc] = v[t];
+    }
+  }
+  __syncthreads();
+  POTRF_STAMP();
+  // C(rows of tile t, columns cb) -= L[rows, k0 .. k1) L[cb rows, k0 .. k1)'
+  auto tile_update = [&](int t, int cb, int k0, int k1) {
+    f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double* ar = L + (16 * t + fr) * LD + fk;   // A[i = fr][k = fk]
+    const double* br = L + (16 * cb + fr) * LD + fk;  // B[k = fk][j = fr] = L[16 cb + j][k]
+    for (int k = k0; k < k1; k += 8) {
+      const double a0 = ar[k], b0 = br[k], a1 = ar[k + 4], b1 = br[k + 4];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) L[(16 * t + fk + 4 * r) * LD + 16 * cb + fr] -= acc0[r] + acc1[r];
+  };
+#pragma unroll 1
+  for (int pb = 0; pb < 8; ++pb) {
+    const int o = pb * 16;
+    if (pb > 0) {  // (a)
+      if (wave == 0) {
+        tile_update(pb, pb, o - 16, o);  // the diagonal tile: earlier panels were applied one iteration ago (below)
+      } else {
+        if (wave == 3 && pb < 7) tile_update(pb + 1, pb + 1, 0, o);  // next diagonal tile, the panels before this one
+        for (int t = pb + wave; t < 8; t += 3) tile_update(t, pb, 0, o);
+      }
+    }
+    if (wave == 0) wave_diag16s(L, LD, o, row0, info, tol, reg, dinv);  // (b)
+    __syncthreads();
+    POTRF_STAMP();
+    {  // (c)
+      const int r = o + 16 + tid;
+      if (r < kDB) {
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = L[r * LD + o + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double sacc = x[c];
+#pragma unroll
+          for (int p = 0; p < c; ++p) sacc -= x[p] * L[(o + c) * LD + o + p];
+          x[c] = sacc * dinv[o + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) L[r * LD + o + c] = x[c];
+      }
+    }
+    __syncthreads();
+    POTRF_STAMP();
+  }
+#pragma unroll
+  for (int t = 0; t < 36; ++t) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    if (ti != tj || tc <= tr) Mkk[(size_t)(16 * ti + tr) * ld + 16 * tj + tc] = L[(16 * ti + tr) * LD + 16 * tj + tc];
+  }
+  POTRF_STAMP();
+  if (tid < kDB) {  // the eight 16 x 16 diagonal inverses, stored transposed in the upper triangle
+    const int b0 = (tid >> 4) * 16, c = tid & 15;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double sacc = r == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int p = 0; p < r; ++p) sacc -= L[(b0 + r) * LD + b0 + p] * x[p];
+      x[r] = r >= c ? sacc * dinv[b0 + r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r > c) L[(b0 + c) * LD + b0 + r] = x[r];
+  }
+  __syncthreads();
+  POTRF_STAMP();
+  // (d) X(r, c), r > c, lives at L[c * LD + r]
+#pragma unroll 1
+  for (int h = 16; h < kDB; h *= 2) {
+    const int w = h < 32 ? h : 32;
+    const int ntile = 4 * (w / 16);  // 64 rows (all pairs of the level) x w columns of T in 16 x 16 tiles
+#pragma unroll 1
+    for (int cc = 0; cc < h; cc += w) {
+      for (int tl = wave; tl < ntile; tl += 4) {  // T[q h + r][c] = sum_{p >= c} L21[r][p] X11(p, c)
+        const int gr0 = (tl & 3) * 16, ct = tl >> 2;
+        const int q = gr0 / h, r0 = gr0 % h, b0 = q * 2 * h, c0 = cc + ct * 16;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* arow = L + (b0 + h + r0 + fr) * LD + b0;  // A[i][p] = L21[r0 + i][p]
+        const double* bcol = L + (b0 + c0 + fr) * LD + b0;      // B[p][j] = X11(p, c0 + j)
+        const double dj = dinv[b0 + c0 + fr];
+#pragma unroll
+        for (int p0 = 0; p0 < 16; p0 += 4) {
+          const int p = c0 + p0 + fk, c = c0 + fr;
+          const double a = arow[p];
+          const double xv = bcol[p];
+          const double b = p > c ? xv : (p == c ? dj : 0.0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        for (int p0 = c0 + 16; p0 < h; p0 += 4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[p0 + fk], bcol[p0 + fk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tt[(ct * 16 + fr) * TLD + gr0 + fk + 4 * r] = acc[r];
+      }
+      __syncthreads();
+      POTRF_STAMP();
+      for (int tl = wave; tl < ntile; tl += 4) {  // X21[r][c] = - sum_{p <= r} X22(r, p) T[p][c]
+        const int gr0 = (tl & 3) * 16, ct = tl >> 2;
+        const int q = gr0 / h, r0 = gr0 % h, b0 = q * 2 * h;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* xcol = L + (size_t)(b0 + h) * LD + b0 + h + r0 + fr;  // A[i][p] = X22(r0 + i, p) = xcol[p * LD], p < r0 + i
+        const double* tb = Tt + (ct * 16 + fr) * TLD + q * h;               // B[p][j] = T[q h + p][ct 16 + j]
+        for (int p0 = 0; p0 < r0; p0 += 4)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xcol[(p0 + fk) * LD], tb[p0 + fk], acc, 0, 0, 0);
+#pragma unroll
+        for (int p0 = 0; p0 < 16; p0 += 4) {
+          const int p = r0 + p0 + fk, ri = r0 + fr;
+          const double xv = xcol[p * LD];
+          const double a = ri > p ? xv : (ri == p ? dinv[b0 + h + p] : 0.0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[p], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L[(b0 + cc + ct * 16 + fr) * LD + b0 + h + r0 + fk + 4 * r] = -acc[r];
+      }
+      __syncthreads();
+      POTRF_STAMP();
+    }
+  }
+  // inv = X (lower), invT = X' (upper): tile (ti, tj), tj <= ti, of inv and its mirror image (tj, ti) of invT
+#pragma unroll
+  for (int t = 0; t < 36; ++t) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int r = 16 * ti + tr, c = 16 * tj + tc;  // element (r, c) of inv, r >= c except above a diagonal tile's diagonal
+    const double xl = L[c * LD + r];               // X(r, c) for r > c
+    const int r2 = 16 * tj + tr, c2 = 16 * ti + tc;  // element (r2, c2) of invT, c2 >= r2 except below the diagonal
+    const double xu = L[r2 * LD + c2];               // X(c2, r2) for c2 > r2
+    if (ti != tj) {
+      inv[(size_t)r * kDB + c] = xl;
+      invT[(size_t)r2 * kDB + c2] = xu;
+    } else {
+      inv[(size_t)r * kDB + c] = c < r ? xl : (c == r ? dinv[r] : 0.0);
+      invT[(size_t)r2 * kDB + c2] = c2 > r2 ? xu : (c2 == r2 ? dinv[r2] : 0.0);
+    }
+  }
+  POTRF_STAMP();
+}
+
 // y (len rows) = A (rows x cols, lda) x, for NR right-hand sides interleaved [..][NR]; one wave per row.
 template <int NR>
 __global__ __launch_bounds__(256) void k_dense_gemv(const double* __restrict__ A, int lda, int rows, int cols,
@@ -1174,6 +1415,71 @@ __global__ __launch_bounds__(256) void k_band_form(const int32_t* __restrict__ r
     __syncthreads();
     for (int k = s0 + tid; k < e0; k += 256) win[colind[k] - sp0.x] = 0.0;
     for (int k = e0 + tid; k < e1; k += 256) win[span + colind[k] - sp1.x] = 0.0;
+    __syncthreads();
+  }
+}
+
+// The same band by COLUMNS of A (the default when A has no duplicate entries): M(i, :) = sum over the entries (i, k) of
+// row i of a_ik * A(:, k), the column read from the transposed structure.  Only structurally non-zero products are
+// formed -- nnz(A) * (entries per column) of them, 1e8 at the headline size against the 1.6e10 gather-FMAs of the
+// row-pair scheme above (61 ms there).  One workgroup per 128-row block, R rows of it per pass, one group of G = 256 / R
+// lanes per row with a dense accumulator row of W * 128 doubles in LDS (columns (I - bw) * 128 ...): the lanes of a
+// group take the entries of ONE column of A (distinct rows j: no two lanes touch the same accumulator), the entries
+// (i, k) of the row are taken in CSR order, four columns' loads in flight -- so every M(i, j) is summed in a fixed order,
+// no atomics.  The accumulator rows are then written out whole (zeros included) and cleared.
+__global__ __launch_bounds__(256) void k_band_form_t(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                                                     const double* __restrict__ vals, const int32_t* __restrict__ t_rowptr,
+                                                     const int32_t* __restrict__ t_rowind, const double* __restrict__ t_vals,
+                                                     int m, int mpad, int band_w, double delta, double* Mb, int R) {
+  extern __shared__ __attribute__((aligned(16))) double win[];  // R accumulator rows of band_w * 128
+  const int I = blockIdx.x, tid = threadIdx.x;
+  const int G = 256 / R, g = tid / G, gl = tid % G;
+  const int roww = band_w * kDB;
+  const int base = (I - (band_w - 1)) * kDB;  // global column of accumulator entry 0 (may be negative: never touched)
+  for (int k = tid; k < R * roww; k += 256) win[k] = 0.0;
+  __syncthreads();
+  double* acc = win + (size_t)g * roww - base;  // acc[j], j a global row index of A = column of M
+  for (int pass = 0; pass < kDB; pass += R) {
+    const int i = I * kDB + pass + g;
+    if (i < m) {
+      const int s = rowptr[i], e = rowptr[i + 1];
+      for (int t = s; t < e; t += 4) {
+        int us[4], ue[4], j[4];
+        double a[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = t + q < e;
+          const int k = colind[ok ? t + q : s];
+          a[q] = ok ? vals[t + q] : 0.0;
+          us[q] = t_rowptr[k];
+          ue[q] = ok ? t_rowptr[k + 1] : us[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int u = us[q] + gl;
+          const bool ok = u < ue[q];
+          j[q] = ok ? t_rowind[u] : INT32_MAX;
+          v[q] = ok ? t_vals[u] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (j[q] <= i) acc[j[q]] += a[q] * v[q];
+          for (int u = us[q] + gl + G; u < ue[q]; u += G) {  // columns longer than the group
+            const int jj = t_rowind[u];
+            if (jj <= i) acc[jj] += a[q] * t_vals[u];
+          }
+        }
+      }
+      if (gl == 0) acc[i] += delta;
+    } else if (i < mpad && gl == 0) {
+      acc[i] = 1.0;  // padding: identity
+    }
+    __syncthreads();
+    for (int idx = tid; idx < R * roww; idx += 256) {
+      const int r = idx / roww, e = idx - r * roww;
+      Mb[((size_t)I * band_w + (e >> 7)) * kDB * kDB + (size_t)(pass + r) * kDB + (e & 127)] = win[idx];
+      win[idx] = 0.0;
+    }
     __syncthreads();
   }
 }

@@ -256,7 +256,8 @@ int fpsq_dense_get_info(fpsq_dense d, fpsq_dense_info *info);
  *   fpsq_band_set_regularization = the dynamic regularisation of :345-348, as for the dense back-end.
  *   fpsq_band_solve_two_*  = `ldiv!` with two right-hand sides (:189-203, :236-251) on the cached factor.
  * Storage is (m / 128) x (half bandwidth in blocks + 1) blocks; create fails with FPSQ_ERR_STATE when that does not fit
- * the device or a row spans more than 9600 columns.  Arguments may be host or device pointers; calls are synchronous. */
+ * the device (or the half bandwidth exceeds 143 blocks AND a row spans more than 9600 columns), with FPSQ_ERR_ARG when
+ * the pattern holds duplicate entries.  Arguments may be host or device pointers; calls are synchronous. */
 typedef struct fpsq_band_s *fpsq_band;
 typedef struct {
   int64_t n, m, nnz;

@@ -263,6 +263,36 @@ def test_banded_direct_matches_exact_kkt(oracle, shape, delta):
     B.close()
 
 
+def test_banded_form_kernels_agree_and_duplicates_are_refused(oracle, monkeypatch):
+    """M is formed by columns of A (k_band_form_t, the default) or by row pairs (k_band_form, kept for bands too wide for
+    the column scheme's LDS rows; FPSQ_BAND_FORM=1 selects it): same solves to rounding.  A pattern with a duplicate
+    entry is an argument error (neither kernel sums duplicates)."""
+    from fps_amd import problems
+
+    qp = problems.pde_control_like(n=6000, m=600, per_row=24, window=512, seed=3)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(3)
+    g, c = rng.standard_normal(6000), rng.standard_normal(600)
+    res = []
+    for gen in ("2", "1"):
+        monkeypatch.setenv("FPSQ_BAND_FORM", gen)
+        B = _Band(A)
+        assert B.factorize(1e-3) == (0, 0)
+        res.append(B.solve(B.lib.fpsq_band_solve_two_mixed, g, c))
+        B.close()
+    monkeypatch.delenv("FPSQ_BAND_FORM")
+    for a, b in zip(*res):
+        assert _rel(a, b) < 1e-12
+    for a, b in zip(res[0], oracle.exact_two_mixed(A, 1e-3, g, c)):
+        assert _rel(a, b) < 1e-10
+    lib = _lib.load()
+    rp = np.array([0, 2, 3], dtype=np.int32)
+    ci = np.array([1, 1, 0], dtype=np.int32)
+    h = C.c_void_p()
+    assert lib.fpsq_band_create(C.byref(h), 3, 2, rp.ctypes.data, ci.ctypes.data, 0) == -1
+    assert b"duplicate" in lib.fpsq_band_last_error(None)
+
+
 def test_banded_direct_regularises_rank_deficient_rows(oracle):
     from fps_amd import problems
 
