@@ -73,6 +73,13 @@ int dmalloc(fpsq_dense d, T** p, size_t count) {
 void solve_two_rhs(fpsq_dense d) {
   hipStream_t s = d->stream;
   const int nb = (int)d->nb, ld = (int)d->mpad;
+  if (d->potrf_gen >= 5) {
+    for (int k = 0; k < nb; ++k)
+      hipLaunchKernelGGL(k_trsv_step3<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, k, 0);
+    for (int k = nb - 1; k >= 0; --k)
+      hipLaunchKernelGGL(k_trsv_step3<false>, dim3(k + 1), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->y2, d->r2, k, 0);
+    return;
+  }
   if (d->potrf_gen >= 3) {
     for (int k = 0; k < nb; ++k)
       hipLaunchKernelGGL(k_trsv_step2<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, k);
@@ -467,6 +474,15 @@ inline size_t blk_off(const fpsq_band b, int64_t i, int64_t j) {  // block (i, j
 void band_solve(fpsq_band b) {
   hipStream_t s = b->stream;
   const int nb = (int)b->nb, bw = b->band_w - 1;
+  if (b->potrf_gen >= 5) {
+    for (int k = 0; k < nb; ++k)
+      hipLaunchKernelGGL(k_trsv_step3<true>, dim3(std::min(bw, nb - 1 - k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs,
+                         b->invsT, b->r2, b->y2, k, b->band_w);
+    for (int k = nb - 1; k >= 0; --k)
+      hipLaunchKernelGGL(k_trsv_step3<false>, dim3(std::min(bw, k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT,
+                         b->y2, b->r2, k, b->band_w);
+    return;
+  }
   for (int k = 0; k < nb; ++k)
     hipLaunchKernelGGL(k_trsv_step2<true>, dim3(std::min(bw, nb - 1 - k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT,
                        b->r2, b->y2, k, b->band_w);

@@ -1363,6 +1363,103 @@ __global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ L
   }
 }
 
+// The same step organised for LATENCY (the default): a step is a chain link of the triangular solve -- nb (dense) or
+// 2 m / 128 (band) of them run back to back, each with a handful of workgroups -- so what counts is the number of
+// dependent memory round trips inside it.  Here every global load of the step (the 128 x 128 inverse block AND the
+// workgroup's own off-diagonal block, 64 + 64 values per thread) is issued before the first use: one round trip.  The
+// triangular half of the inverse that is identically zero is skipped by whole waves.  Forward updates reduce their 64
+// (row, right-hand side) partial products per wave with a transposing butterfly (63 shuffles instead of 384; lane l ends
+// with the total of value l, stored coalesced); backward updates read the block by columns and need none.
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_trsv_step3(const double* __restrict__ Lm, int ld, const double* __restrict__ inv,
+                                                    const double* __restrict__ invT, double* r, double* out, int k,
+                                                    int band_w = 0) {
+  __shared__ double rk[kDB * 2];
+  __shared__ double part[2][kDB * 2];
+  __shared__ double yk[kDB * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = FORWARD ? k + (int)blockIdx.x : (band_w > 0 ? k - (int)blockIdx.x : (int)blockIdx.x);
+  const int i = tid & 127, hf = tid >> 7;
+  // forward: y_i = sum_{p <= i} X'[p][i] r_p;   backward: q_i = sum_{p >= i} X[p][i] y_p   (p in this thread's half)
+  const double* Xc = (FORWARD ? invT : inv) + (size_t)k * kDB * kDB + (size_t)(hf * 64) * kDB + i;
+  const bool xskip = FORWARD ? (hf == 1 && i < 64) : (hf == 0 && i >= 64);  // (wave-uniform) all-zero part of the triangle
+  double xs[64], lb[64];
+  if (!xskip) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q) xs[q] = Xc[(size_t)q * kDB];
+  }
+  const size_t lds = band_w > 0 ? (size_t)kDB : (size_t)ld;
+  if (blk != k) {
+    if (FORWARD) {  // block (blk, k), rows 32 wave .. + 31, lanes along the columns
+      const double* Lb = (band_w > 0 ? Lm + ((size_t)blk * band_w + (k - blk + band_w - 1)) * kDB * kDB
+                                     : Lm + (size_t)(blk * kDB) * ld + k * kDB) + (size_t)(wave * 32) * lds + lane;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        lb[2 * u] = Lb[(size_t)u * lds];
+        lb[2 * u + 1] = Lb[(size_t)u * lds + 64];
+      }
+    } else {  // block (k, blk) read by columns: column i, rows of this thread's half
+      const double* Lb = (band_w > 0 ? Lm + ((size_t)k * band_w + (blk - k + band_w - 1)) * kDB * kDB
+                                     : Lm + (size_t)(k * kDB) * ld + blk * kDB) + (size_t)(hf * 64) * lds + i;
+#pragma unroll
+      for (int q = 0; q < 64; ++q) lb[q] = Lb[(size_t)q * lds];
+    }
+  }
+  rk[tid] = r[(size_t)(k * kDB) * 2 + tid];
+  __syncthreads();
+  {
+    double s0 = 0.0, s1 = 0.0;
+    if (!xskip) {
+#pragma unroll
+      for (int q = 0; q < 64; ++q) {
+        s0 += xs[q] * rk[(hf * 64 + q) * 2];
+        s1 += xs[q] * rk[(hf * 64 + q) * 2 + 1];
+      }
+    }
+    part[hf][i * 2] = s0;
+    part[hf][i * 2 + 1] = s1;
+  }
+  __syncthreads();
+  yk[tid] = part[0][tid] + part[1][tid];
+  __syncthreads();
+  if (blk == k) {
+    out[(size_t)(k * kDB) * 2 + tid] = yk[tid];
+    return;
+  }
+  if (FORWARD) {
+    const double y00 = yk[lane * 2], y01 = yk[lane * 2 + 1], y10 = yk[(lane + 64) * 2], y11 = yk[(lane + 64) * 2 + 1];
+    double v[64];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      v[2 * u] = lb[2 * u] * y00 + lb[2 * u + 1] * y10;
+      v[2 * u + 1] = lb[2 * u] * y01 + lb[2 * u + 1] * y11;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const bool hi = (lane & off) != 0;
+#pragma unroll
+      for (int idx = 0; idx < off; ++idx) {
+        const double send = hi ? v[idx] : v[idx + off];
+        const double keep = hi ? v[idx + off] : v[idx];
+        v[idx] = keep + __shfl_xor(send, off, 64);
+      }
+    }
+    r[(size_t)(blk * kDB + wave * 32) * 2 + lane] -= v[0];
+  } else {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+      s0 += lb[q] * yk[(hf * 64 + q) * 2];
+      s1 += lb[q] * yk[(hf * 64 + q) * 2 + 1];
+    }
+    __syncthreads();
+    part[hf][i * 2] = s0;
+    part[hf][i * 2 + 1] = s1;
+    __syncthreads();
+    r[(size_t)(blk * kDB) * 2 + tid] -= part[0][tid] + part[1][tid];
+  }
+}
+
 // ---- sparse direct path (fpsq_band): M = A A' + delta I of a BANDED sparse Jacobian as a block band
 // One workgroup per 128-row block I.  For each of its rows i in turn: scatter the row into a dense LDS window over its
 // column span, then every thread takes rows j <= i of the band (blocks I - bw .. I) and gathers its dot product with
