@@ -28,6 +28,7 @@ struct fpsq_dense_s {
   double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
   int* info_dev = nullptr;
   int nchunk = 16;
+  int direct128 = 1;  // panel / trailing update by k_gemm128_lds (FPSQ_DENSE_GEMM128=0: the staged kernels)
   int potrf_gen = 5;  // diagonal-block kernel: 5 = generation 4 with its panel updates and doubling inverse on the matrix
                       // cores (k_potrf_inv128m), 4 = compact 16-column panels (k_potrf_inv128p), 3 = 32-column panels
                       // (k_potrf_inv128r), 2 = wave-level 64 (k_potrf_inv128w), 1 = unblocked (FPSQ_DENSE_POTRF selects;
@@ -189,7 +190,10 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   hipFuncSetAttribute((const void*)k_potrf_inv128r, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5);
+  hipFuncSetAttribute((const void*)k_gemm128_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds0);
+  hipFuncSetAttribute((const void*)k_gemm128_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds1);
   if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) d->potrf_gen = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_DENSE_GEMM128")) d->direct128 = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_KD")) d->gram_kd = std::atoi(ev);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds32);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
@@ -303,6 +307,13 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
                            0, (size_t)0);
         hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(rem, rem), dim3(256), kGemmLds16, s, trail, ld, panel, ld, panel, ld, kDB, -1.0,
                            1.0, 0, (size_t)0);
+        continue;
+      }
+      if (!d->lookahead && d->direct128) {  // unstaged K = 128 products (k_gemm128_lds)
+        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(256), kG128Lds1, s, panel, ld, panel, ld, inv, kDB,
+                           BlockStrides{});
+        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(256), kG128Lds0, s, trail, ld, panel, ld, panel, ld,
+                           BlockStrides{});
         continue;
       }
       if (!d->lookahead) {  // 64 x 64 tiles for the K = 128 products (k_gemm_nt_f64_t64)
@@ -441,6 +452,7 @@ struct fpsq_band_s {
   hipEvent_t evA = nullptr, evB = nullptr;
   int lookahead = 0;
   int potrf_gen = 5;  // as fpsq_dense_s (4 or 5)
+  int direct128 = 1;  // as fpsq_dense_s
   fpsq_band_info info{};
   std::vector<void*> allocs;
 };
@@ -685,7 +697,10 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   hipDeviceSynchronize();
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5);
+  hipFuncSetAttribute((const void*)k_gemm128_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds0);
+  hipFuncSetAttribute((const void*)k_gemm128_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds1);
   if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) b->potrf_gen = std::atoi(ev) >= 5 ? 5 : 4;
+  if (const char* ev = std::getenv("FPSQ_DENSE_GEMM128")) b->direct128 = std::atoi(ev);
   if (b->form_gen == 1)
     hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 16);
   else
@@ -755,6 +770,12 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
       ts.a = ts.b = ts.ci = (size_t)bw * kDB * kDB;
       ts.cj = (size_t)kDB * kDB;
       double* trail = b->Mb + blk_off(b, k + 1, k + 1);
+      if (!b->lookahead && b->direct128) {
+        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(256), kG128Lds1, s, panel, kDB, panel, kDB, inv, kDB, ps);
+        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(256), kG128Lds0, s, trail, kDB, panel, kDB, panel, kDB,
+                           ts);
+        continue;
+      }
       if (!b->lookahead) {
         hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0,
                            0.0, 0, (size_t)0, ps);
