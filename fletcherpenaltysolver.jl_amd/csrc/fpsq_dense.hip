@@ -28,6 +28,7 @@ struct fpsq_dense_s {
   double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
   int* info_dev = nullptr;
   int nchunk = 16;
+  int gram_waves = 16;  // waves per 128 x 128 tile of the Gram product (FPSQ_DENSE_GRAM_WAVES=4: k_gemm_nt_f64)
   int direct128 = 1;  // panel / trailing update by k_gemm128_lds (FPSQ_DENSE_GEMM128=0: the staged kernels)
   int potrf_gen = 5;  // diagonal-block kernel: 5 = generation 4 with its panel updates and doubling inverse on the matrix
                       // cores (k_potrf_inv128m), 4 = compact 16-column panels (k_potrf_inv128p), 3 = 32-column panels
@@ -194,8 +195,10 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   hipFuncSetAttribute((const void*)k_gemm128_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds1);
   if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) d->potrf_gen = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DENSE_GEMM128")) d->direct128 = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_WAVES")) d->gram_waves = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_KD")) d->gram_kd = std::atoi(ev);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds32);
+  hipFuncSetAttribute((const void*)k_gemm_nt_f64_w16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kW16Lds);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   {
@@ -264,11 +267,18 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
     const int ksteps = (int)(d->npad / kDK);
     const int kchunk = (ksteps + d->splitk - 1) / d->splitk * kDK;
     const size_t zs = (size_t)d->mpad * d->mpad;
-    hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb, d->splitk), dim3(256), kGemmLds16, s, d->planes, ld, d->A, (int)d->npad, d->A,
-                       (int)d->npad, (int)d->npad, 1.0, 0.0, kchunk, zs);
+    if (d->gram_waves == 16 && kchunk % kW16Kd == 0)
+      hipLaunchKernelGGL(k_gemm_nt_f64_w16<true>, dim3(nb, nb, d->splitk), dim3(1024), kW16Lds, s, d->planes, ld, d->A,
+                         (int)d->npad, d->A, (int)d->npad, (int)d->npad, 1.0, 0.0, kchunk, zs);
+    else
+      hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb, d->splitk), dim3(256), kGemmLds16, s, d->planes, ld, d->A, (int)d->npad,
+                         d->A, (int)d->npad, (int)d->npad, 1.0, 0.0, kchunk, zs);
     hipLaunchKernelGGL(k_syrk_reduce, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->planes, zs, d->splitk, (int)d->m, delta);
   } else {
-    if (d->gram_kd == 32 && d->npad % 32 == 0)
+    if (d->gram_waves == 16 && d->npad % kW16Kd == 0)
+      hipLaunchKernelGGL(k_gemm_nt_f64_w16<true>, dim3(nb, nb), dim3(1024), kW16Lds, s, d->M, ld, d->A, (int)d->npad, d->A,
+                         (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
+    else if (d->gram_kd == 32 && d->npad % 32 == 0)
       hipLaunchKernelGGL((k_gemm_nt_f64<true, 32>), dim3(nb, nb), dim3(256), kGemmLds32, s, d->M, ld, d->A, (int)d->npad, d->A,
                          (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
     else

@@ -135,6 +135,103 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const d
       }
 }
 
+// The same 128 x 128 tile with SIXTEEN waves (the default for the Gram product).  tools/mfma_probe.hip: one wave issues a
+// v_mfma_f64_16x16x4_f64 only every ~140 cycles (196 when it depends on the previous one), whatever the number of
+// independent accumulators; a SIMD reaches its rate only with several waves resident (2 per SIMD: 99 cycles per MFMA).
+// The four-wave kernel above has one wave per SIMD and m = 2048 gives 136 tiles for 256 CUs, so its 0.77 ms was
+// 8192 MFMAs per wave x 140 cycles.  Here each wave owns a 32 x 32 sub-tile (2 x 2 MFMA tiles), four waves per SIMD.
+// LDS tiles are [row][k] with leading dimension KD + 1 doubles: the banks are 4 bytes wide and a ds_read_b64 is served 16
+// lanes at a time, so the 16 rows of an MFMA operand must start 2 banks apart (leading dimension = 1 mod 16) to cover the
+// 32 banks once -- KD + 2, two 8-byte banks apart, measured 50 % conflict cycles.  KD = 32 per stage halves the barriers
+// of sixteen waves.  K (or the split-K chunk) must be a multiple of 32.  Split-K as k_gemm_nt_f64.
+constexpr int kW16Kd = 32, kW16Ld = kW16Kd + 1;
+constexpr int kW16Lds = 2 * 2 * kDB * kW16Ld * 8;
+template <bool LOWER>
+__global__ __launch_bounds__(1024) void k_gemm_nt_f64_w16(double* C, int ldc, const double* __restrict__ A, int lda,
+                                                          const double* __restrict__ B, int ldb, int K, double alpha,
+                                                          double beta, int kchunk = 0, size_t zstride = 0) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (LOWER && bi < bj) return;
+  if (kchunk > 0) {
+    const int kbeg = (int)blockIdx.z * kchunk;
+    K = min(K, kbeg + kchunk) - kbeg;
+    if (K < 0) K = 0;
+    C += (size_t)blockIdx.z * zstride;
+    A += kbeg;
+    B += kbeg;
+  }
+  extern __shared__ __attribute__((aligned(16))) double gsm[];
+  constexpr int KD = kW16Kd, LD = kW16Ld;
+  double* sA = gsm;                  // [2][128 * LD]
+  double* sB = gsm + 2 * kDB * LD;   // [2][128 * LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;
+  const double* Ab = A + (size_t)bi * kDB * lda;
+  const double* Bb = B + (size_t)bj * kDB * ldb;
+  const int srow = tid >> 3, sk = (tid & 7) * 4;  // staging: four consecutive k of row (t >> 3) for both operands
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+  f64x2 ra0, ra1, rb0, rb1;
+  auto gload = [&](int k0) {
+    const f64x2* pa = reinterpret_cast<const f64x2*>(Ab + (size_t)srow * lda + k0 + sk);
+    const f64x2* pb = reinterpret_cast<const f64x2*>(Bb + (size_t)srow * ldb + k0 + sk);
+    ra0 = pa[0];
+    ra1 = pa[1];
+    rb0 = pb[0];
+    rb1 = pb[1];
+  };
+  auto lstore = [&](int buf) {
+    double* qa = sA + buf * kDB * LD + srow * LD + sk;
+    double* qb = sB + buf * kDB * LD + srow * LD + sk;
+    qa[0] = ra0[0];
+    qa[1] = ra0[1];
+    qa[2] = ra1[0];
+    qa[3] = ra1[1];
+    qb[0] = rb0[0];
+    qb[1] = rb0[1];
+    qb[2] = rb1[0];
+    qb[3] = rb1[1];
+  };
+  const int fr = lane & 15, fk = lane >> 4;
+  int buf = 0;
+  if (K > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += KD) {
+    const bool more = k0 + KD < K;
+    if (more) gload(k0 + KD);
+    const double* pa = sA + buf * kDB * LD + (wr + fr) * LD + fk;
+    const double* pb = sB + buf * kDB * LD + (wc + fr) * LD + fk;
+#pragma unroll
+    for (int ks = 0; ks < KD / 4; ++ks) {
+      const double a0 = pa[4 * ks], a1 = pa[16 * LD + 4 * ks], b0 = pb[4 * ks], b1 = pb[16 * LD + 4 * ks];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  double* Cb = C + (size_t)(bi * kDB + wr) * ldc + bj * kDB + wc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* p = Cb + (size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr;
+        const double v = alpha * acc[i][j][r];
+        *p = (beta != 0.0) ? v + beta * *p : v;
+      }
+}
+
 // The same product on 64 x 64 tiles, for the SHORT-K (K = 128) panel and trailing updates of the blocked Cholesky.  One
 // 128 x 128 x 128 tile keeps a CU's matrix cores busy for >= 13.7 us (a v_mfma_f64_16x16x4_f64 issues every 64 cycles per
 // SIMD on gfx950) and a factorisation step has at most ~120 of them for 256 CUs -- with 64 x 64 tiles four CUs share that
@@ -1089,7 +1186,10 @@ constexpr int kPotrfLds5 = (kDB * kPotrfLd5 + 32 * kPotrfTld5 + kDB) * 8;
 
 // the 16 x 16 factor routine of generation 5: wave_diag16 without branches (pivot tests by selects, the counters
 // reported once at the end), so the whole routine is one basic block and the scheduler can run the reciprocal square
-// root of column j + 1 under the updates of column j
+// root of column j + 1 under the updates of column j.  (~400 cycles per column remain: the dependent chain pivot ->
+// v_rsq_f64 + refinement -> scale -> broadcast -> update of the next pivot.  Spreading the tile over all 64 lanes, 4
+// columns each with ds_bpermute fetches, halves the instruction count but not that chain: measured 7.0k against 6.6k
+// cycles per tile, not kept.)
 __device__ __forceinline__ void wave_diag16s(double* L, int LD, int o, int row0, int* info, double tol, double reg,
                                              double* dinv) {
   const int lane = threadIdx.x & 63;
@@ -1197,15 +1297,16 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
     {  // (c)
       const int r = o + 16 + tid;
       if (r < kDB) {
+        // x L16' = a, column by column with the later columns updated at once: the dependent chain is 16 x (scale,
+        // update), not the 120 terms of a dot-product form
         double x[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) x[c] = L[r * LD + o + c];
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          double sacc = x[c];
+          x[c] *= dinv[o + c];
 #pragma unroll
-          for (int p = 0; p < c; ++p) sacc -= x[p] * L[(o + c) * LD + o + p];
-          x[c] = sacc * dinv[o + c];
+          for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= x[c] * L[(o + c2) * LD + o + c];
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) L[r * LD + o + c] = x[c];
@@ -1224,13 +1325,14 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
   POTRF_STAMP();
   if (tid < kDB) {  // the eight 16 x 16 diagonal inverses, stored transposed in the upper triangle
     const int b0 = (tid >> 4) * 16, c = tid & 15;
-    double x[16];
+    double x[16];  // L16 x = e_c, rows eliminated one at a time (x[r] = 0 above row c falls out)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = r == c ? 1.0 : 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      double sacc = r == c ? 1.0 : 0.0;
+      x[r] *= dinv[b0 + r];
 #pragma unroll
-      for (int p = 0; p < r; ++p) sacc -= L[(b0 + r) * LD + b0 + p] * x[p];
-      x[r] = r >= c ? sacc * dinv[b0 + r] : 0.0;
+      for (int r2 = r + 1; r2 < 16; ++r2) x[r2] -= L[(b0 + r2) * LD + b0 + r] * x[r];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -1260,10 +1362,21 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
           const double b = p > c ? xv : (p == c ? dj : 0.0);
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
-        for (int p0 = c0 + 16; p0 < h; p0 += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[p0 + fk], bcol[p0 + fk], acc, 0, 0, 0);
+        f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+        for (int p0 = c0 + 16; p0 < h; p0 += 16) {  // (h - c0 is a multiple of 16) operands of four k-steps, then the MFMAs
+          double av[4], bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Tt[(ct * 16 + fr) * TLD + gr0 + fk + 4 * r] = acc[r];
+          for (int u = 0; u < 4; ++u) {
+            av[u] = arow[p0 + 4 * u + fk];
+            bv[u] = bcol[p0 + 4 * u + fk];
+          }
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tt[(ct * 16 + fr) * TLD + gr0 + fk + 4 * r] = acc[r] + acc2[r];
       }
       __syncthreads();
       POTRF_STAMP();
@@ -1273,8 +1386,19 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
         const double* xcol = L + (size_t)(b0 + h) * LD + b0 + h + r0 + fr;  // A[i][p] = X22(r0 + i, p) = xcol[p * LD], p < r0 + i
         const double* tb = Tt + (ct * 16 + fr) * TLD + q * h;               // B[p][j] = T[q h + p][ct 16 + j]
-        for (int p0 = 0; p0 < r0; p0 += 4)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xcol[(p0 + fk) * LD], tb[p0 + fk], acc, 0, 0, 0);
+        f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < r0; p0 += 16) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            av[u] = xcol[(p0 + 4 * u + fk) * LD];
+            bv[u] = tb[p0 + 4 * u + fk];
+          }
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+        }
 #pragma unroll
         for (int p0 = 0; p0 < 16; p0 += 4) {
           const int p = r0 + p0 + fk, ri = r0 + fr;
@@ -1283,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[p], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L[(b0 + cc + ct * 16 + fr) * LD + b0 + h + r0 + fk + 4 * r] = -acc[r];
+        for (int r = 0; r < 4; ++r) L[(b0 + cc + ct * 16 + fr) * LD + b0 + h + r0 + fk + 4 * r] = -(acc[r] + acc2[r]);
       }
       __syncthreads();
       POTRF_STAMP();
