@@ -320,9 +320,9 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
         continue;
       }
       if (!d->lookahead && d->direct128) {  // unstaged K = 128 products (k_gemm128_lds)
-        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(256), kG128Lds1, s, panel, ld, panel, ld, inv, kDB,
+        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(1024), kG128Lds1, s, panel, ld, panel, ld, inv, kDB,
                            BlockStrides{});
-        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(256), kG128Lds0, s, trail, ld, panel, ld, panel, ld,
+        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(1024), kG128Lds0, s, trail, ld, panel, ld, panel, ld,
                            BlockStrides{});
         continue;
       }
@@ -781,8 +781,8 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
       ts.cj = (size_t)kDB * kDB;
       double* trail = b->Mb + blk_off(b, k + 1, k + 1);
       if (!b->lookahead && b->direct128) {
-        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(256), kG128Lds1, s, panel, kDB, panel, kDB, inv, kDB, ps);
-        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(256), kG128Lds0, s, trail, kDB, panel, kDB, panel, kDB,
+        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(1024), kG128Lds1, s, panel, kDB, panel, kDB, inv, kDB, ps);
+        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(1024), kG128Lds0, s, trail, kDB, panel, kDB, panel, kDB,
                            ts);
         continue;
       }

@@ -327,19 +327,21 @@ __global__ __launch_bounds__(256) void k_gemm_nt_f64_t64(double* C, int ldc, con
 // staged kernels above pay eight load -> LDS -> barrier round trips for a 128-deep product (27 us for the panel, ~16 us
 // for the update, against 2-3 us of matrix-core time per workgroup).  Here a workgroup issues every global load of its
 // operand tiles at once -- whole 1 KB rows per wave instruction, 16 bytes per lane --, parks the tiles in LDS row-major
-// with leading dimension = 2 mod 32 (130 / 66 doubles: the 16 rows x 4 k of an MFMA operand fall in distinct banks) and
-// runs the 32 k-steps from there.  (Loading the MFMA fragments straight from global memory, 8 bytes per lane in
-// 32-byte runs, was measured first: 18 / 22 us per launch -- the address unit serialises such loads.)
-//   MODE 0: trailing update, tile (bi, bj) of 64 x 64, bi >= bj:  C -= A_bi B_bj'      grid (2 rem, 2 rem), waves 2 x 2
+// with leading dimension = 1 mod 16 doubles (129 / 65: the 16 rows of an MFMA operand start two 4-byte banks apart) and
+// runs the k-steps from there, SIXTEEN waves of one 16 x 16 tile each (one wave issues an fp64 MFMA only every
+// ~140-196 cycles, tools/mfma_probe.hip: four waves of 2 x 2 tiles took 12.5 / 8.7 us per launch).
+// (Loading the MFMA fragments straight from global memory, 8 bytes per lane in 32-byte runs, was measured first:
+// 18 / 22 us per launch -- the address unit serialises such loads.)
+//   MODE 0: trailing update, tile (bi, bj) of 64 x 64, bi >= bj:  C -= A_bi B_bj'      grid (2 rem, 2 rem), waves 4 x 4
 //   MODE 1: panel IN PLACE, rows [32 bi, 32 bi + 32):  P <- P X'  (B = X = the 128 x 128 inverse block, lower
-//           triangular: wave w takes the 16-column tiles w and 7 - w and only the k <= column part of the sum -- the
-//           same work for every wave); X goes through LDS in two k-halves (the second only for columns >= 64).
-constexpr int kG128Ld = 130, kG128LdX = 66;
+//           triangular: a wave sums only the k <= column part); waves 2 (row tiles) x 8 (column tiles); X goes through
+//           LDS in two k-halves (the second only for columns >= 64).
+constexpr int kG128Ld = 129, kG128LdX = 65;
 constexpr int kG128Lds0 = 2 * 64 * kG128Ld * 8;
 constexpr int kG128Lds1 = (32 * kG128Ld + 128 * kG128LdX) * 8;
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gemm128_lds(double* C, int ldc, const double* A, int lda, const double* B,
-                                                     int ldb, BlockStrides bs) {
+__global__ __launch_bounds__(1024) void k_gemm128_lds(double* C, int ldc, const double* A, int lda, const double* B,
+                                                      int ldb, BlockStrides bs) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (MODE == 0 && bi < bj) return;
   extern __shared__ __attribute__((aligned(16))) double gsm[];
@@ -349,54 +351,43 @@ __global__ __launch_bounds__(256) void k_gemm128_lds(double* C, int ldc, const d
   if (MODE == 0) {
     double* sA = gsm;
     double* sB = gsm + 64 * LD;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int wr = (wave >> 2) * 16, wc = (wave & 3) * 16;
     const int Ib = bi >> 1, Jb = bj >> 1, si = (bi & 1) * 64, sj = (bj & 1) * 64;
     const double* Ab = A + (bs.on ? (size_t)Ib * bs.a : (size_t)Ib * kDB * lda) + (size_t)si * lda;
     const double* Bb = B + (bs.on ? (size_t)Jb * bs.b : (size_t)Jb * kDB * ldb) + (size_t)sj * ldb;
     double* Cb = C + (bs.on ? (size_t)Ib * bs.ci + (size_t)Jb * bs.cj : (size_t)Ib * kDB * ldc + (size_t)Jb * kDB) +
                  (size_t)(si + wr) * ldc + sj + wc;
-    f64x2 va[16], vb[16];
-    double cold[2][2][4];
+    f64x2 va[4], vb[4];
+    double cold[4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      va[u] = *reinterpret_cast<const f64x2*>(Ab + (size_t)(u * 4 + wave) * lda + 2 * lane);
-      vb[u] = *reinterpret_cast<const f64x2*>(Bb + (size_t)(u * 4 + wave) * ldb + 2 * lane);
+    for (int u = 0; u < 4; ++u) {
+      va[u] = *reinterpret_cast<const f64x2*>(Ab + (size_t)(u * 16 + wave) * lda + 2 * lane);
+      vb[u] = *reinterpret_cast<const f64x2*>(Bb + (size_t)(u * 16 + wave) * ldb + 2 * lane);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cold[i][j][r] = Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr];
+    for (int r = 0; r < 4; ++r) cold[r] = Cb[(size_t)(fk + 4 * r) * ldc + fr];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      *reinterpret_cast<f64x2*>(sA + (u * 4 + wave) * LD + 2 * lane) = va[u];
-      *reinterpret_cast<f64x2*>(sB + (u * 4 + wave) * LD + 2 * lane) = vb[u];
+    for (int u = 0; u < 4; ++u) {
+      double* qa = sA + (u * 16 + wave) * LD + 2 * lane;
+      double* qb = sB + (u * 16 + wave) * LD + 2 * lane;
+      qa[0] = va[u][0];
+      qa[1] = va[u][1];
+      qb[0] = vb[u][0];
+      qb[1] = vb[u][1];
     }
     __syncthreads();
-    f64x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     const double* ar = sA + (wr + fr) * LD + fk;
     const double* br = sB + (wc + fr) * LD + fk;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) {
-      const double a0 = ar[4 * s], a1 = ar[16 * LD + 4 * s], b0 = br[4 * s], b1 = br[16 * LD + 4 * s];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll 4
+    for (int s = 0; s < 32; s += 2) {
+      const double a0 = ar[4 * s], b0 = br[4 * s], a1 = ar[4 * s + 4], b1 = br[4 * s + 4];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr] = cold[i][j][r] - acc[i][j][r];
+    for (int r = 0; r < 4; ++r) Cb[(size_t)(fk + 4 * r) * ldc + fr] = cold[r] - (acc0[r] + acc1[r]);
   } else {
     constexpr int LX = kG128LdX;
     double* sA = gsm;
@@ -404,63 +395,60 @@ __global__ __launch_bounds__(256) void k_gemm128_lds(double* C, int ldc, const d
     const int Ib = bi >> 2, si = (bi & 3) * 32;
     const double* Ab = A + (bs.on ? (size_t)Ib * bs.a : (size_t)Ib * kDB * lda) + (size_t)si * lda;
     double* Cb = C + (bs.on ? (size_t)Ib * bs.ci : (size_t)Ib * kDB * ldc) + (size_t)si * ldc;
-    f64x2 va[8], vx[32];
+    f64x2 va[2], vx[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) va[u] = *reinterpret_cast<const f64x2*>(Ab + (size_t)(u * 4 + wave) * lda + 2 * lane);
+    for (int u = 0; u < 2; ++u) va[u] = *reinterpret_cast<const f64x2*>(Ab + (size_t)(u * 16 + wave) * lda + 2 * lane);
 #pragma unroll
-    for (int u = 0; u < 32; ++u) vx[u] = *reinterpret_cast<const f64x2*>(B + (size_t)(u * 4 + wave) * ldb + 2 * lane);
+    for (int u = 0; u < 8; ++u) vx[u] = *reinterpret_cast<const f64x2*>(B + (size_t)(u * 16 + wave) * ldb + 2 * lane);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) *reinterpret_cast<f64x2*>(sA + (u * 4 + wave) * LD + 2 * lane) = va[u];
-    if (lane < 32) {
-#pragma unroll
-      for (int u = 0; u < 32; ++u) *reinterpret_cast<f64x2*>(sX + (u * 4 + wave) * LX + 2 * lane) = vx[u];
+    for (int u = 0; u < 2; ++u) {
+      double* qa = sA + (u * 16 + wave) * LD + 2 * lane;
+      qa[0] = va[u][0];
+      qa[1] = va[u][1];
     }
-    __syncthreads();  // (every wave has read its rows of the panel: stores below cannot overtake a load)
-    const int c0 = wave, c1 = 7 - wave;  // column tiles; c0 <= 3 < c1
-    f64x4 acc[2][2];
+    if (lane < 32) {  // first k-half of X, all rows
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-    const double* ar = sA + fr * LD + fk;
+      for (int u = 0; u < 8; ++u) {
+        double* qx = sX + (u * 16 + wave) * LX + 2 * lane;
+        qx[0] = vx[u][0];
+        qx[1] = vx[u][1];
+      }
+    }
+    __syncthreads();  // (every wave has read its rows of the panel: the stores below cannot overtake a load)
+    const int ri = wave & 1, c = wave >> 1;  // row tile, column tile
+    f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double* ar = sA + (16 * ri + fr) * LD + fk;
     {
-      const double* x0 = sX + (16 * c0 + fr) * LX + fk;
-      const double* x1 = sX + (16 * c1 + fr) * LX + fk;
-      const int lim0 = 4 * (c0 + 1);  // k-steps of tile c0 (X[j][k] = 0 for k > j); tile c1 takes all 16 of this half
-      for (int s = 0; s < 16; ++s) {
-        const double a0 = ar[4 * s], a1 = ar[16 * LD + 4 * s], b1 = x1[4 * s];
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        if (s < lim0) {
-          const double b0 = x0[4 * s];
-          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        }
+      const double* xr = sX + (16 * c + fr) * LX + fk;
+      const int lim = min(16, 4 * (c + 1));  // (a multiple of 4) X[j][k] = 0 for k > j
+      for (int s = 0; s < lim; s += 2) {
+        const double a0 = ar[4 * s], b0 = xr[4 * s], a1 = ar[4 * s + 4], b1 = xr[4 * s + 4];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
       }
     }
     __syncthreads();
     if (lane >= 32) {  // second k-half of X, rows j >= 64 only, row j - 64 of the buffer
 #pragma unroll
-      for (int u = 16; u < 32; ++u) *reinterpret_cast<f64x2*>(sX + (u * 4 + wave - 64) * LX + 2 * lane - 64) = vx[u];
+      for (int u = 4; u < 8; ++u) {
+        double* qx = sX + (u * 16 + wave - 64) * LX + 2 * lane - 64;
+        qx[0] = vx[u][0];
+        qx[1] = vx[u][1];
+      }
     }
     __syncthreads();
-    {
-      const double* x1 = sX + (16 * c1 - 64 + fr) * LX + fk;
-      const int lim1 = 4 * (c1 + 1) - 16;  // remaining k-steps of tile c1
-      for (int s = 0; s < lim1; ++s) {
-        const double a0 = ar[64 + 4 * s], a1 = ar[16 * LD + 64 + 4 * s], b1 = x1[4 * s];
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    if (c >= 4) {
+      const double* xr = sX + (16 * c - 64 + fr) * LX + fk;
+      const int lim = 4 * (c + 1) - 16;
+      for (int s = 0; s < lim; s += 2) {
+        const double a0 = ar[64 + 4 * s], b0 = xr[4 * s], a1 = ar[64 + 4 * s + 4], b1 = xr[4 * s + 4];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + 16 * c0 + fr] = acc[i][0][r];
-        Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + 16 * c1 + fr] = acc[i][1][r];
-      }
+    for (int r = 0; r < 4; ++r) Cb[(size_t)(16 * ri + fk + 4 * r) * ldc + 16 * c + fr] = acc0[r] + acc1[r];
   }
 }
 
