@@ -294,7 +294,7 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
     double* Mkk = d->M + (size_t)k * kDB * ld + (size_t)k * kDB;
     double* inv = d->invs + (size_t)k * kDB * kDB;
     if (d->potrf_gen >= 5)
-      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(256), kPotrfLds5, s, Mkk, ld, inv,
+      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, s, Mkk, ld, inv,
                          d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
     else if (d->potrf_gen == 4)
       hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, ld, inv,
@@ -762,7 +762,7 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
     double* Mkk = b->Mb + blk_off(b, k, k);
     double* inv = b->invs + (size_t)k * kDB * kDB;
     if (b->potrf_gen >= 5)
-      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(256), kPotrfLds5, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
+      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
                          k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
     else
       hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,

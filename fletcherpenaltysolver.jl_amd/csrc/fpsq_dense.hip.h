@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, doub
 //   (d) the doubling steps T = L21 X11 and X21 = -X22 T are MFMA tile products too (T kept transposed, 32 columns at a
 //       time, so both operands of both products are read k-contiguous); entries of the triangular 16 x 16 diagonal
 //       sub-blocks of X are selected on load (strictly lower from the transposed store, diagonal from `dinv`, else 0).
-// Steps (b), (c) and the 16 x 16 inverses are generation 4's.
+// Step (b) also yields the 16 x 16 inverse (see wave_diag16x), which turns (c) into an MFMA product as well.
 #ifndef FPSQ_POTRF_LD5
 #define FPSQ_POTRF_LD5 (kDB + 2)
 #endif
@@ -1178,13 +1178,22 @@ constexpr int kPotrfLds5 = (kDB * kPotrfLd5 + 32 * kPotrfTld5 + kDB) * 8;
 // v_rsq_f64 + refinement -> scale -> broadcast -> update of the next pivot.  Spreading the tile over all 64 lanes, 4
 // columns each with ds_bpermute fetches, halves the instruction count but not that chain: measured 7.0k against 6.6k
 // cycles per tile, not kept.)
-__device__ __forceinline__ void wave_diag16s(double* L, int LD, int o, int row0, int* info, double tol, double reg,
+// Lanes 16 .. 31 -- idle copies in the plain routine -- compute X16 = L16^-1 ALONGSIDE, for free: lane 16 + c carries
+// column c of X through the same instruction stream (its a[r] starts as e_c; at step j its a[j] * rp is X[j][c], and
+// `a[r] -= X[j][c] * L[r][j]` is the same fused multiply-add with the same broadcast L[r][j] the factor lanes use).
+// X16 goes, transposed, to the upper triangle of the tile (where the doubling steps expect it) and lets step (c) be a
+// matrix-core product.
+__device__ __forceinline__ void wave_diag16x(double* L, int LD, int o, int row0, int* info, double tol, double reg,
                                              double* dinv) {
   const int lane = threadIdx.x & 63;
-  const int rl = lane & 15;  // lanes 16..63 mirror 0..15
+  const int rl = lane & 15;
+  const bool inv = (lane >> 4) == 1;
   double a[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) a[c] = L[(o + rl) * LD + o + c];
+  for (int c = 0; c < 16; ++c) {
+    const double v = L[(o + rl) * LD + o + c];
+    a[c] = inv ? (c == rl ? 1.0 : 0.0) : v;
+  }
   double rdiag = 1.0;  // this lane's 1 / L[rl][rl]
   const bool dyn = reg > 0.0;
   const double thr = dyn ? tol : 0.0, sub = dyn ? reg : 1.0;  // (a unit pivot keeps the kernel finite when none is set)
@@ -1199,7 +1208,8 @@ __device__ __forceinline__ void wave_diag16s(double* L, int LD, int o, int row0,
     const double rp = rsqrt(d);
     const double piv = d * rp;
     rdiag = rl == j ? rp : rdiag;
-    const double l = rl > j ? a[j] * rp : (rl == j ? piv : 0.0);
+    const double t = a[j] * rp;
+    const double l = inv ? t : (rl > j ? t : (rl == j ? piv : 0.0));
     a[j] = l;
 #pragma unroll
     for (int c = j + 1; c < 16; ++c) a[c] -= l * rdlane(l, c);
@@ -1209,6 +1219,10 @@ __device__ __forceinline__ void wave_diag16s(double* L, int LD, int o, int row0,
 #pragma unroll
     for (int c = 0; c < 16; ++c)
       if (c <= lane) L[(o + lane) * LD + o + c] = a[c];  // L16, lower
+  } else if (inv) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r > rl) L[(o + rl) * LD + o + r] = a[r];  // X16(r, rl), r > rl, transposed into the upper triangle
   }
   if (lane == 0 && nbad) {
     if (dyn)
@@ -1219,8 +1233,11 @@ __device__ __forceinline__ void wave_diag16s(double* L, int LD, int o, int row0,
 }
 
 // inv / invT are written in their non-zero triangles only: the caller zero-fills both buffers ONCE (at allocation).
-__global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, double* inv, double* invT, int row0,
-                                                       int* info, double tol, double reg POTRF_TIMING_ARG) {
+// 512 threads: a wave issues an fp64 MFMA only every ~140-196 cycles (tools/mfma_probe.hip), so the MFMA phases want
+// more than one wave per SIMD.
+constexpr int kPotrfThreads5 = 512;
+__global__ __launch_bounds__(kPotrfThreads5) void k_potrf_inv128m(double* Mkk, int ld, double* inv, double* invT, int row0,
+                                                                  int* info, double tol, double reg POTRF_TIMING_ARG) {
 #ifdef FPSQ_POTRF_TIMING
   int nst = 0;
 #endif
@@ -1228,29 +1245,38 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* L = sm;
   constexpr int LD = kPotrfLd5;
+  constexpr int NW = kPotrfThreads5 / 64;
   double* Tt = sm + kDB * LD;  // Tt[c][row]: 32 columns x 64 rows of the doubling steps' T, transposed
   constexpr int TLD = kPotrfTld5;
   double* dinv = Tt + 32 * TLD;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int fr = lane & 15, fk = lane >> 4;
-  const int tr = tid >> 4, tc = tid & 15;  // element of a 16 x 16 tile
+  const int tr = (tid & 255) >> 4, tc = tid & 15, th = tid >> 8;  // element of a 16 x 16 tile; tiles 2 u + th
   // the 36 lower tiles, every load in flight at once (one HBM round trip for the block)
   {
-    double v[36];
+    double v[18];
 #pragma unroll
-    for (int t = 0; t < 36; ++t) {
-      int ti = 0;
-      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-      const int tj = t - ti * (ti + 1) / 2;
-      v[t] = Mkk[(size_t)(16 * ti + tr) * ld + 16 * tj + tc];
+    for (int u = 0; u < 18; ++u) {
+      int t0 = 2 * u, ti0 = 0;
+      while ((ti0 + 1) * (ti0 + 2) / 2 <= t0) ++ti0;
+      const int tj0 = t0 - ti0 * (ti0 + 1) / 2;
+      int t1 = 2 * u + 1, ti1 = 0;
+      while ((ti1 + 1) * (ti1 + 2) / 2 <= t1) ++ti1;
+      const int tj1 = t1 - ti1 * (ti1 + 1) / 2;
+      const int ti = th ? ti1 : ti0, tj = th ? tj1 : tj0;
+      v[u] = Mkk[(size_t)(16 * ti + tr) * ld + 16 * tj + tc];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 36; ++t) {
-      int ti = 0;
-      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-      const int tj = t - ti * (ti + 1) / 2;
-      L[(16 * ti + tr) * LD + 16 * tj + tc] = v[t];
+    for (int u = 0; u < 18; ++u) {
+      int t0 = 2 * u, ti0 = 0;
+      while ((ti0 + 1) * (ti0 + 2) / 2 <= t0) ++ti0;
+      const int tj0 = t0 - ti0 * (ti0 + 1) / 2;
+      int t1 = 2 * u + 1, ti1 = 0;
+      while ((ti1 + 1) * (ti1 + 2) / 2 <= t1) ++ti1;
+      const int tj1 = t1 - ti1 * (ti1 + 1) / 2;
+      const int ti = th ? ti1 : ti0, tj = th ? tj1 : tj0;
+      L[(16 * ti + tr) * LD + 16 * tj + tc] = v[u];
     }
   }
   __syncthreads();
@@ -1272,70 +1298,61 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
   for (int pb = 0; pb < 8; ++pb) {
     const int o = pb * 16;
     if (pb > 0) {  // (a)
+      // wave 0 runs the serial part; wave 4 shares its SIMD and stays out of its way (with it busy the 16 x 16 routine
+      // took 8.0k instead of 6.6k cycles); the other six waves update the tiles below
       if (wave == 0) {
         tile_update(pb, pb, o - 16, o);  // the diagonal tile: earlier panels were applied one iteration ago (below)
-      } else {
-        if (wave == 3 && pb < 7) tile_update(pb + 1, pb + 1, 0, o);  // next diagonal tile, the panels before this one
-        for (int t = pb + wave; t < 8; t += 3) tile_update(t, pb, 0, o);
+      } else if (wave != 4) {
+        const int wi = wave < 4 ? wave - 1 : wave - 2;  // 0 .. 5
+        if (wi == 5 && pb < 7) tile_update(pb + 1, pb + 1, 0, o);  // next diagonal tile, the panels before this one
+        for (int t = pb + 1 + wi; t < 8; t += 6) tile_update(t, pb, 0, o);
       }
     }
-    if (wave == 0) wave_diag16s(L, LD, o, row0, info, tol, reg, dinv);  // (b)
+    if (wave == 0) wave_diag16x(L, LD, o, row0, info, tol, reg, dinv);  // (b)
     __syncthreads();
     POTRF_STAMP();
-    {  // (c)
-      const int r = o + 16 + tid;
-      if (r < kDB) {
-        // x L16' = a, column by column with the later columns updated at once: the dependent chain is 16 x (scale,
-        // update), not the 120 terms of a dot-product form
-        double x[16];
+    // (c) tiles below: P <- P X16' on the matrix cores.  B[k][j] = X16(j, k): strictly lower entries from the transposed
+    // store, the diagonal from dinv, zero above
+    for (int t = pb + 1 + wave; t < 8; t += NW) {
+      double av[4], bv[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = L[r * LD + o + c];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          x[c] *= dinv[o + c];
-#pragma unroll
-          for (int c2 = c + 1; c2 < 16; ++c2) x[c2] -= x[c] * L[(o + c2) * LD + o + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) L[r * LD + o + c] = x[c];
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * q + fk;
+        av[q] = L[(16 * t + fr) * LD + o + k];
+        const double xv = L[(o + k) * LD + o + fr];
+        bv[q] = fr > k ? xv : (fr == k ? dinv[o + fr] : 0.0);
       }
+      f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[(16 * t + fk + 4 * r) * LD + o + fr] = acc0[r] + acc1[r];
     }
     __syncthreads();
     POTRF_STAMP();
   }
 #pragma unroll
-  for (int t = 0; t < 36; ++t) {
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
+  for (int u = 0; u < 18; ++u) {
+    int t0 = 2 * u, ti0 = 0;
+    while ((ti0 + 1) * (ti0 + 2) / 2 <= t0) ++ti0;
+    const int tj0 = t0 - ti0 * (ti0 + 1) / 2;
+    int t1 = 2 * u + 1, ti1 = 0;
+    while ((ti1 + 1) * (ti1 + 2) / 2 <= t1) ++ti1;
+    const int tj1 = t1 - ti1 * (ti1 + 1) / 2;
+    const int ti = th ? ti1 : ti0, tj = th ? tj1 : tj0;
     if (ti != tj || tc <= tr) Mkk[(size_t)(16 * ti + tr) * ld + 16 * tj + tc] = L[(16 * ti + tr) * LD + 16 * tj + tc];
   }
   POTRF_STAMP();
-  if (tid < kDB) {  // the eight 16 x 16 diagonal inverses, stored transposed in the upper triangle
-    const int b0 = (tid >> 4) * 16, c = tid & 15;
-    double x[16];  // L16 x = e_c, rows eliminated one at a time (x[r] = 0 above row c falls out)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = r == c ? 1.0 : 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      x[r] *= dinv[b0 + r];
-#pragma unroll
-      for (int r2 = r + 1; r2 < 16; ++r2) x[r2] -= L[(b0 + r2) * LD + b0 + r] * x[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (r > c) L[(b0 + c) * LD + b0 + r] = x[r];
-  }
-  __syncthreads();
-  POTRF_STAMP();
-  // (d) X(r, c), r > c, lives at L[c * LD + r]
+  // (d) X = L^-1 by doubling; X(r, c), r > c, lives at L[c * LD + r] (the 16 x 16 diagonal inverses are there already)
 #pragma unroll 1
   for (int h = 16; h < kDB; h *= 2) {
     const int w = h < 32 ? h : 32;
     const int ntile = 4 * (w / 16);  // 64 rows (all pairs of the level) x w columns of T in 16 x 16 tiles
 #pragma unroll 1
     for (int cc = 0; cc < h; cc += w) {
-      for (int tl = wave; tl < ntile; tl += 4) {  // T[q h + r][c] = sum_{p >= c} L21[r][p] X11(p, c)
+      for (int tl = wave; tl < ntile; tl += NW) {  // T[q h + r][c] = sum_{p >= c} L21[r][p] X11(p, c)
         const int gr0 = (tl & 3) * 16, ct = tl >> 2;
         const int q = gr0 / h, r0 = gr0 % h, b0 = q * 2 * h, c0 = cc + ct * 16;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1368,7 +1385,7 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
       }
       __syncthreads();
       POTRF_STAMP();
-      for (int tl = wave; tl < ntile; tl += 4) {  // X21[r][c] = - sum_{p <= r} X22(r, p) T[p][c]
+      for (int tl = wave; tl < ntile; tl += NW) {  // X21[r][c] = - sum_{p <= r} X22(r, p) T[p][c]
         const int gr0 = (tl & 3) * 16, ct = tl >> 2;
         const int q = gr0 / h, r0 = gr0 % h, b0 = q * 2 * h;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1403,10 +1420,14 @@ __global__ __launch_bounds__(256) void k_potrf_inv128m(double* Mkk, int ld, doub
   }
   // inv = X (lower), invT = X' (upper): tile (ti, tj), tj <= ti, of inv and its mirror image (tj, ti) of invT
 #pragma unroll
-  for (int t = 0; t < 36; ++t) {
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
+  for (int u = 0; u < 18; ++u) {
+    int t0 = 2 * u, ti0 = 0;
+    while ((ti0 + 1) * (ti0 + 2) / 2 <= t0) ++ti0;
+    const int tj0 = t0 - ti0 * (ti0 + 1) / 2;
+    int t1 = 2 * u + 1, ti1 = 0;
+    while ((ti1 + 1) * (ti1 + 2) / 2 <= t1) ++ti1;
+    const int tj1 = t1 - ti1 * (ti1 + 1) / 2;
+    const int ti = th ? ti1 : ti0, tj = th ? tj1 : tj0;
     const int r = 16 * ti + tr, c = 16 * tj + tc;  // element (r, c) of inv, r >= c except above a diagonal tile's diagonal
     const double xl = L[c * LD + r];               // X(r, c) for r > c
     const int r2 = 16 * tj + tr, c2 = 16 * ti + tc;  // element (r2, c2) of invT, c2 >= r2 except below the diagonal

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dM, M.data(), n * n * 8, hipMemcpyHostToDevice));
     CK(hipMemset(info, 0, 16)); CK(hipMemset(stamps, 0, 64 * 8));
     if (gen >= 5)
-      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(256), kPotrfLds5, 0, dM, n, dinv, dinvT, 0, info, 0.0, 0.0, stamps);
+      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, 0, dM, n, dinv, dinvT, 0, info, 0.0, 0.0, stamps);
     else
       hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, 0, dM, n, dinv, dinvT, 0, info, 0.0, 0.0, stamps);
     CK(hipDeviceSynchronize());
