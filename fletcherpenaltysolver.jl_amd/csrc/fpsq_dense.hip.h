@@ -1183,6 +1183,10 @@ constexpr int kPotrfLds5 = (kDB * kPotrfLd5 + 32 * kPotrfTld5 + kDB) * 8;
 // `a[r] -= X[j][c] * L[r][j]` is the same fused multiply-add with the same broadcast L[r][j] the factor lanes use).
 // X16 goes, transposed, to the upper triangle of the tile (where the doubling steps expect it) and lets step (c) be a
 // matrix-core product.
+// (Also tried, both slower: an UNNORMALISED elimination -- columns scaled by 1 / d_j, reciprocal square roots at the end,
+// so that the chain between pivots is reciprocal + one multiply-add -- 9.4k cycles per tile as the compiler orders it,
+// 10.9k with the other columns' updates deferred a step and fenced between the links of the next chain by hand.  The
+// routine is ~900 instructions of one wave at ~7 cycles each; reordering does not shorten it.)
 __device__ __forceinline__ void wave_diag16x(double* L, int LD, int o, int row0, int* info, double tol, double reg,
                                              double* dinv) {
   const int lane = threadIdx.x & 63;
