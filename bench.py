@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--delta", type=float, default=None, help="regularisation; default 0 = first outer iteration "
                     "(algo.jl:46); 1e-3 for the dense-block workload")
     ap.add_argument("--fuse", type=int, default=1)
+    ap.add_argument("--kkt-method", default="lsqr-craig", choices=["lsqr-craig", "minres-k"],
+                    help="lsqr-craig: the reference's iterative path (default, the headline).  minres-k: MINRES on "
+                         "K = [I A'; A -delta I] itself (fpsq_options.kkt_method = FPSQ_KKT_MINRES_K; named by "
+                         "BASELINE.json's north_star / configs[1], not a path of the reference) -- with --op hprod-solves")
     ap.add_argument("--lookahead", type=int, default=0, help="override fpsq_options.lookahead (0 = library default)")
     ap.add_argument("--cpu-evals", type=int, default=6, help="evaluations timed for cpu_baseline (0 = skip)")
     ap.add_argument("--pointers", default="device", choices=["device", "host", "host+jac"],
@@ -293,6 +297,11 @@ def main():
     sigma, rho = 1e3, 1.0  # parameters.jl:71,75 (first outer iteration)
     delta = 0.0 if args.delta is None else args.delta
     extra = {"lookahead": args.lookahead} if args.lookahead > 0 else {}
+    mk = args.kkt_method == "minres-k"
+    if mk:
+        if args.op != "hprod-solves":
+            raise SystemExit("--kkt-method minres-k: use --op hprod-solves (the fused QP entries keep the reference's method)")
+        extra["kkt_method"] = 1
 
     # ---- how the N ranks share the work
     plan = None
@@ -551,8 +560,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "m": m, "nnz": nnz, "sigma": sigma, "rho": rho,
                    "delta": delta, "fuse_two_rhs": args.fuse, "pointers": args.pointers,
-                   "krylov": ("LSQR+MINRES" if extras else "LSQR+LSQR" if hp else "LSQR+CRAIG") +
-                             ", atol=rtol=sqrt(eps) (reference defaults)",
+                   "krylov": ("MINRES on K = [I A'; A -delta I], two systems in lock-step" if mk else "LSQR+MINRES" if extras
+                              else "LSQR+LSQR" if hp else "LSQR+CRAIG") + ", atol=rtol=sqrt(eps) (reference defaults)",
                    "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
                    "all_solved": soft[0] == 0, "parallelism": par},
         "roofline": roofline,
@@ -574,6 +583,10 @@ def main():
             if extras:
                 r1 = qp.point(1 + W + t)
                 oracle.solve_two_extras(m, n, qp.rowptr, qp.colind, qp.vals, delta, r1, np.ascontiguousarray(r1[::-1][:m]))
+            elif mk:
+                r1 = qp.point(1 + W + t)
+                oracle.minres_kkt(m, n, qp.rowptr, qp.colind, qp.vals, delta, bp=r1)
+                oracle.minres_kkt(m, n, qp.rowptr, qp.colind, qp.vals, delta, bp=np.ascontiguousarray(r1[::-1]))
             elif hp:  # (hprod: the solves are all of its CPU cost but two products and three vector passes)
                 r1 = qp.point(1 + W + t)
                 oracle.solve_two_least_squares(m, n, qp.rowptr, qp.colind, qp.vals, delta, r1,
@@ -596,7 +609,7 @@ def main():
             t0 = time.perf_counter()
             done2 = 0
             for t in range(args.cpu_evals):
-                if extras:
+                if extras or mk:
                     break
                 if hp:
                     r1 = qp.point(1 + W + t)

@@ -31,7 +31,7 @@ class Options(C.Structure):
                 ("ls_axtol", C.c_double), ("ls_btol", C.c_double), ("ls_etol", C.c_double),
                 ("ls_conlim", C.c_double),
                 ("fuse_two_rhs", C.c_int32), ("lookahead", C.c_int32), ("device", C.c_int32),
-                ("jac_format", C.c_int32), ("ln_method", C.c_int32), ("reserved", C.c_int32)]
+                ("jac_format", C.c_int32), ("ln_method", C.c_int32), ("kkt_method", C.c_int32)]
 
 
 class Info(C.Structure):

@@ -277,6 +277,12 @@ struct fpsq_solver_s {
   fpsq_stats* hstats_dev = nullptr;
   double* hscal = nullptr;        // host-mapped: scalar results (phi, f, c'c) written by the kernel that computes them
   double* hscal_dev = nullptr;
+  // MINRES on K itself (kkt_method = FPSQ_KKT_MINRES_K): allocated at the first call
+  bool mk_ready = false;
+  MkVecs mk_long{}, mk_short{};
+  MinresState* mk_state = nullptr;  // [2]
+  double* mk_part[2] = {nullptr, nullptr};
+  int mk_gl = 0, mk_gs = 0;
   // Speculative epilogue (run_krylov): kernels launched while gate0 is set only act once BOTH lane controls say `done`.
   const LaneCtl* gate0 = nullptr;
   const LaneCtl* gate1 = nullptr;
@@ -920,6 +926,8 @@ __device__ __forceinline__ void minres_set_params(MinresState* S, const MinresPa
   S->ctlT.upd_iter = -1;
   S->ctlT.ca = 1.0;  // tmp = A' r2, raw
   S->ctlT.cb = 0.0;
+  S->kmode = 0;
+  S->kdelta = 0.0;
 }
 
 // Start-up of a run in ONE launch: lane parameters (workgroup 0), the right-hand sides loaded into their interleaved
@@ -1639,12 +1647,131 @@ bool on_this_device(fpsq_handle h, const void* p) {
 
 int soft_rc(const fpsq_stats st[2]) { return (st[0].solved ? 0 : 1) | (st[1].solved ? 0 : 2); }
 
+__global__ void k_mk_params(MinresState* S, MinresParams P, double kdelta) {
+  MinresState* s = S + blockIdx.x;
+  minres_set_params(s, P);
+  s->kmode = 1;
+  s->kdelta = kdelta;
+  s->lambda = 0.0;
+  s->ctl.skip = 0;
+}
+
+// Both systems K [p; q] = [bp_l; bq_l], l = 0, 1, by MINRES on K = [I A'; A -delta I] (order n + m), the two recurrences
+// in lock-step on interleaved vectors: per iteration one two-RHS A' product, one two-RHS A product, three element-wise
+// stages over n + m and three scalar steps.  Not a path of the reference (its `solve_two_mixed` is LSQR + CRAIG, the
+// default here): BASELINE.json's north_star / configs[1] name it ("MINRES matrix-free") and SURVEY 8(b) lists it in the
+// method enum.  Tolerances: the reference's MINRES set (ne_atol, ne_rtol, ne_etol, ne_conlim; ne_itmax = 0 -> 2 (n + m)).
+// Null right-hand sides are zero.  Solutions to (p0, q0, p1, q1); stats to h->hstats[0 / 1].
+int minres_k_device(fpsq_handle h, const double* bp0, const double* bq0, const double* bp1, const double* bq1, double* p0,
+                    double* q0, double* p1, double* q1) {
+  if (h->comm) {
+    h->err = "kkt_method = MINRES_K is single-GPU (use the default LSQR + CRAIG method on a sharded handle)";
+    return FPSQ_ERR_STATE;
+  }
+  hipStream_t s = h->stream;
+  const int64_t n = h->n, m = h->m;
+  if (!h->mk_ready) {
+    double** lv[] = {&h->mk_long.Y, &h->mk_long.R1, &h->mk_long.R2, &h->mk_long.W1, &h->mk_long.W2, &h->mk_long.X};
+    for (auto p : lv)
+      if (int rc = dalloc(h, p, 2 * (size_t)n)) return rc;
+    double** sv[] = {&h->mk_short.Y, &h->mk_short.R1, &h->mk_short.R2, &h->mk_short.W1, &h->mk_short.W2, &h->mk_short.X};
+    for (auto p : sv)
+      if (int rc = dalloc(h, p, 2 * (size_t)m)) return rc;
+    h->mk_gl = (int)((n + kMkPerBlock - 1) / kMkPerBlock);
+    h->mk_gs = (int)((m + kMkPerBlock - 1) / kMkPerBlock);
+    for (int l = 0; l < 2; ++l)
+      if (int rc = dalloc(h, &h->mk_part[l], (size_t)(h->mk_gl + h->mk_gs))) return rc;
+    if (int rc = dalloc(h, &h->mk_state, 2)) return rc;
+    h->mk_ready = true;
+  }
+  const int gl = h->mk_gl, gt = h->mk_gl + h->mk_gs;
+  const fpsq_options& o = h->opt;
+  const int64_t itmax = o.ne_itmax > 0 ? o.ne_itmax : 2 * (n + m);
+  MinresParams P{0.0, o.ne_atol, o.ne_rtol, o.ne_etol, o.ne_conlim, itmax, INT32_MAX};
+  hipLaunchKernelGGL(k_mk_params, dim3(2), dim3(1), 0, s, h->mk_state, P, h->delta);
+  hipLaunchKernelGGL(k_mk_init, dim3(gt), dim3(kBlock), 0, s, h->mk_long, bp0, bp1, n, h->mk_short, bq0, bq1, m, gl,
+                     h->mk_part[0], h->mk_part[1]);
+  h->launches += 2;
+  MinresState* S0 = h->mk_state;
+  MinresState* S1 = h->mk_state + 1;
+  for (int l = 0; l < 2; ++l) {
+    h->prog_host[l].iter = 0;
+    h->prog_host[l].done = 0;
+    h->hstats[l] = fpsq_stats{};
+  }
+  auto sargs = [&](int kind, int l, int it) {
+    StepArgs a{};
+    a.kind = kind;
+    a.it = it;
+    a.state = h->mk_state + l;
+    a.p0 = h->mk_part[l];
+    a.n0 = gt;
+    a.p1 = nullptr;
+    a.n1 = 0;
+    a.prog = h->prog_dev + l;
+    a.host_stats = h->hstats_dev + l;
+    return a;
+  };
+  launch_step_raw(h, sargs(STEP_MINRES_BEGIN, 0, 0), sargs(STEP_MINRES_BEGIN, 1, 0));
+  const LaneCtl* gsave0 = h->gate0;
+  const LaneCtl* gsave1 = h->gate1;
+  h->gate0 = h->gate1 = nullptr;
+  int64_t it = 0, chunk = 8;
+  int rc = 0;
+  while (true) {
+    for (int64_t k = 0; k < chunk && it < itmax; ++k) {
+      ++it;
+      // y = K r2 / beta: long part through A', short part through A (both read the pair r2, write the pair y)
+      launch_spmv<2>(h, TAG_AT, h->mk_short.R2, h->mk_long.R2, h->mk_long.Y, &S0->ctlT, &S1->ctlT, nullptr);
+      launch_spmv<2>(h, TAG_A, h->mk_long.R2, h->mk_short.R2, h->mk_short.Y, &S0->ctl, &S1->ctl, nullptr);
+      hipLaunchKernelGGL(k_mk_stage<1>, dim3(gt), dim3(kBlock), 0, s, &S0->ctl, &S1->ctl, (int)it, h->mk_long, n, h->mk_short,
+                         m, gl, h->mk_part[0], h->mk_part[1]);
+      launch_step_raw(h, sargs(STEP_MINRES_A, 0, (int)it), sargs(STEP_MINRES_A, 1, (int)it));
+      hipLaunchKernelGGL(k_mk_stage<2>, dim3(gt), dim3(kBlock), 0, s, &S0->ctl, &S1->ctl, (int)it, h->mk_long, n, h->mk_short,
+                         m, gl, h->mk_part[0], h->mk_part[1]);
+      launch_step_raw(h, sargs(STEP_MINRES_B, 0, (int)it), sargs(STEP_MINRES_B, 1, (int)it));
+      hipLaunchKernelGGL(k_mk_stage<3>, dim3(gt), dim3(kBlock), 0, s, &S0->ctl, &S1->ctl, (int)it, h->mk_long, n, h->mk_short,
+                         m, gl, h->mk_part[0], h->mk_part[1]);
+      launch_step_raw(h, sargs(STEP_MINRES_C, 0, (int)it), sargs(STEP_MINRES_C, 1, (int)it));
+      h->launches += 3;
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      h->err = std::string("minres_k: ") + hipGetErrorString(e);
+      rc = FPSQ_ERR_HIP;
+      break;
+    }
+    if ((h->prog_host[0].done && h->prog_host[1].done) || it >= itmax) break;
+    chunk = std::min<int64_t>(chunk * 2, 64);
+  }
+  h->gate0 = gsave0;
+  h->gate1 = gsave1;
+  if (rc) return rc;
+  if (!(h->prog_host[0].done && h->prog_host[1].done)) {  // (the mapped words lag: read the states)
+    MinresState hs[2];
+    HIPCHK(h, hipMemcpy(hs, h->mk_state, sizeof hs, hipMemcpyDeviceToHost));
+    for (int l = 0; l < 2; ++l) h->hstats[l] = hs[l].stats;
+  }
+  hipLaunchKernelGGL(k_mk_unpack, dim3(ew_grid(n)), dim3(kBlock), 0, s, h->mk_long.X, p0, p1, n);
+  hipLaunchKernelGGL(k_mk_unpack, dim3(ew_grid(m)), dim3(kBlock), 0, s, h->mk_short.X, q0, q1, m);
+  h->launches += 2;
+  return 0;
+}
+
 // device-side solve_two_mixed: g (n), c (m) device pointers; results left in h->p1, h->Lx[0] (q1), h->Cx (p2), h->Cy (q2)
 // defer_p1: the caller forms p1 = g - A'q1 itself (qp_objgrad pairs that product with A'c in one two-RHS launch)
 // affine_shift != null (fast start): c is NOT formed yet; CRAIG's right-hand side -(A z - shift), z in the long pair's
 // CRAIG lane, comes out of the LSQR start-up product and A z - shift is left in `c` (see run_krylov)
 int two_mixed_device(fpsq_handle h, const double* g, double* c, bool defer_p1 = false,
                      const double* affine_shift = nullptr, const TailFn* tail = nullptr) {
+  if (h->opt.kkt_method == FPSQ_KKT_MINRES_K) {
+    if (defer_p1 || affine_shift || tail) {
+      h->err = "kkt_method = MINRES_K serves fpsq_solve_two_mixed / fpsq_solve_two_least_squares / fpsq_ys_gs only";
+      return FPSQ_ERR_STATE;
+    }
+    // K [p1; q1] = [g; 0], K [p2; q2] = [0; c]
+    return minres_k_device(h, g, nullptr, nullptr, c, h->p1, h->Lx[0], h->Cx, h->Cy);
+  }
   Lane lanes[2];
   // (q1, stats1) = solve_least_square(qds, Aop', rhs1, sqrt(delta))      src/solve_linear_system.jl:123
   lanes[0].kind = LANE_LSQR;
@@ -1680,6 +1807,13 @@ int two_mixed_device(fpsq_handle h, const double* g, double* c, bool defer_p1 = 
 
 // device-side solve_two_least_squares: results in h->p1, h->Lx[0], h->p2b, h->Lx[1]
 int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2, const TailFn* tail = nullptr) {
+  if (h->opt.kkt_method == FPSQ_KKT_MINRES_K) {
+    if (tail) {
+      h->err = "kkt_method = MINRES_K serves fpsq_solve_two_mixed / fpsq_solve_two_least_squares / fpsq_ys_gs only";
+      return FPSQ_ERR_STATE;
+    }
+    return minres_k_device(h, r1, nullptr, r2, nullptr, h->p1, h->Lx[0], h->p2b, h->Lx[1]);
+  }
   Lane lanes[2];
   const double* rhs[2] = {r1, r2};
   for (int l = 0; l < 2; ++l) {

@@ -1001,4 +1001,112 @@ __global__ __launch_bounds__(kBlock) void k_qp_hprod_fin(const double* __restric
   }
 }
 
+// ---- MINRES on K = [I A'; A -delta I] itself (fpsq_options.kkt_method = FPSQ_KKT_MINRES_K): both systems of a call are
+// lanes of interleaved (n + m)-vectors, stored as a long (n) and a short (m) part.  One launch of a stage covers both
+// parts (blocks [0, gl) the long one) and both lanes; partial sums go to part0 / part1 [gl + gs].
+struct MkVecs {
+  double *Y, *R1, *R2, *W1, *W2, *X;  // [len][2]
+};
+constexpr int kMkPerBlock = kBlock * 8;
+
+// R1 = R2 = right-hand sides (b0: lane 0, b1: lane 1; null = zero), W1 = W2 = X = 0; partial sums of b^2
+__global__ __launch_bounds__(kBlock) void k_mk_init(MkVecs lg, const double* bl0, const double* bl1, int64_t n, MkVecs sh,
+                                                    const double* bs0, const double* bs1, int64_t m, int gl,
+                                                    double* part0, double* part1) {
+  __shared__ double red[2 * 32];
+  const int blk = blockIdx.x;
+  const bool is_long = blk < gl;
+  const MkVecs& v = is_long ? lg : sh;
+  const double* b0 = is_long ? bl0 : bs0;
+  const double* b1 = is_long ? bl1 : bs1;
+  const int64_t len = is_long ? n : m;
+  const int64_t beg = (int64_t)(is_long ? blk : blk - gl) * kMkPerBlock;
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t i = beg + threadIdx.x; i < beg + kMkPerBlock && i < len; i += kBlock) {
+    const double x0 = b0 ? b0[i] : 0.0, x1 = b1 ? b1[i] : 0.0;
+    v.R1[2 * i] = x0;
+    v.R1[2 * i + 1] = x1;
+    v.R2[2 * i] = x0;
+    v.R2[2 * i + 1] = x1;
+    v.W1[2 * i] = v.W1[2 * i + 1] = 0.0;
+    v.W2[2 * i] = v.W2[2 * i + 1] = 0.0;
+    v.X[2 * i] = v.X[2 * i + 1] = 0.0;
+    a0 += x0 * x0;
+    a1 += x1 * x1;
+  }
+  const double t0 = block_sum(a0, red);
+  const double t1 = block_sum(a1, red + 32);
+  if (threadIdx.x == 0) {
+    part0[blk] = t0;
+    part1[blk] = t1;
+  }
+}
+
+// The three element-wise stages of an iteration (Paige & Saunders; same coefficients e[] as upd_minres):
+//   1: y0 = y - e0 r1,                         partial <r2, y0>
+//   2: y = y0 - e1 r2; r1 = r2; r2 = y; w1 <- w2, w2 <- e2 r2_old - e3 w2 - e4 w1 (unscaled),   partial <y, y>
+//   3: w2 *= e5; x += e6 w2,                    partial <x, x>      (only when stage B of iteration `it` ran)
+template <int STAGE>
+__global__ __launch_bounds__(kBlock) void k_mk_stage(const LaneCtl* c0, const LaneCtl* c1, int it, MkVecs lg, int64_t n,
+                                                     MkVecs sh, int64_t m, int gl, double* part0, double* part1) {
+  __shared__ double red[2 * 32];
+  const LaneCtl* cs[2] = {c0, c1};
+  bool act[2];
+  double e[2][7];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    act[l] = STAGE == 3 ? cs[l]->upd_iter == it : !cs[l]->done;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) e[l][q] = cs[l]->e[q];
+  }
+  if (!act[0] && !act[1]) return;
+  const int blk = blockIdx.x;
+  const bool is_long = blk < gl;
+  const MkVecs& v = is_long ? lg : sh;
+  const int64_t len = is_long ? n : m;
+  const int64_t beg = (int64_t)(is_long ? blk : blk - gl) * kMkPerBlock;
+  double acc[2] = {0.0, 0.0};
+  for (int64_t i = beg + threadIdx.x; i < beg + kMkPerBlock && i < len; i += kBlock) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (!act[l]) continue;
+      const int64_t k = 2 * i + l;
+      if (STAGE == 1) {
+        const double y0 = v.Y[k] - (e[l][0] != 0.0 ? e[l][0] * v.R1[k] : 0.0);
+        v.Y[k] = y0;
+        acc[l] += v.R2[k] * y0;
+      } else if (STAGE == 2) {
+        const double r = v.R2[k];
+        const double y = v.Y[k] - e[l][1] * r;
+        v.R1[k] = r;
+        v.R2[k] = y;
+        const double w2 = v.W2[k];
+        v.W2[k] = e[l][2] * r - e[l][3] * w2 - e[l][4] * v.W1[k];
+        v.W1[k] = w2;
+        acc[l] += y * y;
+      } else {
+        const double w = v.W2[k] * e[l][5];
+        v.W2[k] = w;
+        const double xn = v.X[k] + e[l][6] * w;
+        v.X[k] = xn;
+        acc[l] += xn * xn;
+      }
+    }
+  }
+  const double t0 = block_sum(acc[0], red);
+  const double t1 = block_sum(acc[1], red + 32);
+  if (threadIdx.x == 0) {
+    if (act[0]) part0[blk] = t0;
+    if (act[1]) part1[blk] = t1;
+  }
+}
+
+// out0 / out1 = lanes 0 / 1 of an interleaved pair vector
+__global__ __launch_bounds__(kBlock) void k_mk_unpack(const double* __restrict__ pair, double* out0, double* out1, int64_t len) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+    out0[i] = pair[2 * i];
+    out1[i] = pair[2 * i + 1];
+  }
+}
+
 }  // namespace fpsq

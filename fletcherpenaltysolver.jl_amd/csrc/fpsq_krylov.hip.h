@@ -565,6 +565,10 @@ struct MinresState {
   int32_t iter;
   int32_t pub_from;
   fpsq_stats stats;
+  // kmode = 1: the operator is K = [I A'; A -kdelta I] itself on stacked (n + m)-vectors (fpsq_options.kkt_method =
+  // FPSQ_KKT_MINRES_K): y_p = (r2_p + A' r2_q) / beta through ctlT, y_q = (A r2_p - kdelta r2_q) / beta through ctl
+  int32_t kmode, pad_;
+  double kdelta;
 };
 
 __device__ __forceinline__ void minres_begin_step(MinresState* S, double bb, Progress* prog) {
@@ -616,6 +620,10 @@ __device__ __forceinline__ void minres_begin_step(MinresState* S, double bb, Pro
   S->ctlT.cb = 0.0;
   S->ctl.ca = 1.0 / beta1;         // q = (A tmp + lambda r2) / beta
   S->ctl.cb = S->lambda / beta1;
+  if (S->kmode) {
+    S->ctlT.ca = S->ctlT.cb = 1.0 / beta1;
+    S->ctl.cb = -S->kdelta / beta1;
+  }
   S->ctl.e[0] = 0.0;               // E1: beta/oldbeta (no r1 term at iteration 1)
 }
 
@@ -663,6 +671,10 @@ __device__ __forceinline__ void minres_b_step(MinresState* S, double yy, int it)
   // THIS iteration rides) and A product need not wait for the stopping tests of stage C.
   S->ctl.ca = (beta != 0.0) ? 1.0 / beta : 0.0;
   S->ctl.cb = (beta != 0.0) ? S->lambda / beta : 0.0;
+  if (S->kmode) {
+    S->ctlT.ca = S->ctlT.cb = S->ctl.ca;
+    S->ctl.cb = -S->kdelta * S->ctl.ca;
+  }
   S->ctl.e[0] = (S->oldbeta != 0.0) ? beta / S->oldbeta : 0.0;
 }
 

@@ -22,7 +22,7 @@ mutable struct FpsqOptions  # fpsq_options (same field order as include/fpsq.h)
   ls_axtol::Float64; ls_btol::Float64; ls_etol::Float64; ls_conlim::Float64
   fuse_two_rhs::Int32; lookahead::Int32; device::Int32; jac_format::Int32
   ln_method::Int32   # 0 = craig! (the default workspace, struct.jl:121), 1 = lnlq! through the generic solve_least_norm
-  reserved::Int32
+  kkt_method::Int32  # 0 = LSQR + CRAIG (the reference's path), 1 = MINRES on K itself (not a reference path)
   FpsqOptions() = new()
 end
 

@@ -62,6 +62,18 @@ enum {
   FPSQ_ST_SOLVED_LQ = 9     /* LNLQ: "solutions xL and yL good enough" (FPSQ_ST_SOLVED: the CRAIG point xC, yC) */
 };
 
+/* how the two saddle-point systems of a call are solved (fpsq_options.kkt_method) */
+enum {
+  FPSQ_KKT_LSQR_CRAIG = 0, /* the reference's iterative path: LSQR on A' + CRAIG / LNLQ on A (solve_linear_system.jl:107-140)
+                              for solve_two_mixed, two LSQR for solve_two_least_squares (:79-105).  Default. */
+  FPSQ_KKT_MINRES_K = 1    /* MINRES on K = [I A'; A -delta I] itself, order n + m, both systems in lock-step.  NOT a path
+                              of the reference: BASELINE.json north_star / configs[1] ("MINRES matrix-free") and SURVEY
+                              8(b)'s method enum name it.  Stops on the reference's MINRES tolerances (ne_atol, ne_rtol,
+                              ne_etol, ne_conlim; ne_itmax = 0 -> 2 (n + m)); stats are MINRES's.  Serves
+                              fpsq_solve_two_mixed, fpsq_solve_two_least_squares and fpsq_ys_gs on a single-GPU handle;
+                              the fused fpsq_qp_* entries and sharded handles return FPSQ_ERR_STATE with it. */
+};
+
 /* least-norm method of solve_two_mixed / ys_gs / qp_objgrad (fpsq_options.ln_method) */
 enum {
   FPSQ_LN_CRAIG = 0, /* craig! with sqd and M = (1/delta) I: the reference's default workspace (struct.jl:121, :210-244) */
@@ -101,7 +113,7 @@ typedef struct {
                             < 2^21 columns, else CSR), 1 = CSR only */
   int32_t ln_method;     /* FPSQ_LN_CRAIG (default) or FPSQ_LN_LNLQ: which Krylov.jl workspace `solver_struct_least_norm`
                             would be (src/solve_two_systems_struct.jl:121) */
-  int32_t reserved;
+  int32_t kkt_method;    /* FPSQ_KKT_LSQR_CRAIG (default, the reference's path) or FPSQ_KKT_MINRES_K */
 } fpsq_options;
 
 /* defaults of src/solve_two_systems_struct.jl:99-115 for an (n, m) problem; fuse_two_rhs = 1 */

@@ -656,18 +656,48 @@ done:
   return 0;
 }
 
-/* ------------------------------------------------------------------ MINRES on (A A' + lambda I) y = b
- * Krylov.jl minres! with M = I, applied to the product operator `nlp.Aop * nlp.Aop'`
- * (solve_linear_system.jl:58-70). */
-int fpo_minres_aat(const fpo_csr *A, const double *b, double lambda, double atol, double rtol, double etol,
-                   double conlim, int64_t itmax, double *x, fpo_stats *st) {
-  const int64_t n = A->m; /* the operator is m x m */
+/* ------------------------------------------------------------------ MINRES (Krylov.jl minres! with M = I) on a
+ * symmetric operator given as a callback y = Op v.  Two uses:
+ *   (A A' + lambda I) y = b   -- the product operator `nlp.Aop * nlp.Aop'` of solve_linear_system.jl:58-70 (fpo_minres_aat)
+ *   K [p; q] = b, K = [I A'; A -delta I] -- not a path of the reference; BASELINE.json north_star / configs[1] name it and
+ *                                the library offers it as fpsq_options.kkt_method = FPSQ_KKT_MINRES_K (fpo_minres_kkt) */
+typedef void (*fpo_symop)(const void *ctx, const double *v, double *y);
+
+typedef struct {
+  const fpo_csr *A;
+  double lambda;
+  double *tmp;
+} aat_ctx;
+
+static void op_aat(const void *c, const double *v, double *y) {
+  const aat_ctx *k = (const aat_ctx *)c;
+  csr_tmul(k->A, v, k->tmp);
+  csr_mul(k->A, k->tmp, y);
+  if (k->lambda != 0.0) axpy(k->A->m, k->lambda, v, y);
+}
+
+typedef struct {
+  const fpo_csr *A;
+  double delta;
+} kkt_ctx;
+
+static void op_kkt(const void *c, const double *v, double *y) { /* v = [p; q]: y = [p + A' q; A p - delta q] */
+  const kkt_ctx *k = (const kkt_ctx *)c;
+  const int64_t n = k->A->n, m = k->A->m;
+  csr_tmul(k->A, v + n, y);
+  axpy(n, 1.0, v, y);
+  csr_mul(k->A, v, y + n);
+  if (k->delta != 0.0) axpy(m, -k->delta, v + n, y + n);
+}
+
+static int minres_core(fpo_symop op, const void *ctx, int64_t n, const double *b, double atol, double rtol, double etol,
+                       double conlim, int64_t itmax, double *x, fpo_stats *st) {
   const double epsM = 2.220446049250313e-16;
   const double ctol = conlim > 0 ? 1.0 / conlim : 0.0;
   enum { WINDOW = 5 };
   double err_vec[WINDOW] = {0, 0, 0, 0, 0};
   double *r1 = malloc((size_t)n * 8), *r2 = malloc((size_t)n * 8), *w1 = malloc((size_t)n * 8);
-  double *w2 = malloc((size_t)n * 8), *yv = malloc((size_t)n * 8), *tmp = malloc((size_t)A->n * 8);
+  double *w2 = malloc((size_t)n * 8), *yv = malloc((size_t)n * 8);
   memset(st, 0, sizeof *st);
   memset(x, 0, (size_t)n * 8);
   memcpy(r1, b, (size_t)n * 8);
@@ -693,10 +723,8 @@ int fpo_minres_aat(const fpo_csr *A, const double *b, double lambda, double atol
 
   while (!(solved || tired || ill_cond)) {
     iter++;
-    /* y = (A A' + lambda I) v / beta */
-    csr_tmul(A, v, tmp);
-    csr_mul(A, tmp, yv);
-    if (lambda != 0.0) axpy(n, lambda, v, yv);
+    /* y = Op v / beta */
+    op(ctx, v, yv);
     scal(n, 1.0 / beta, yv);
     if (iter >= 2) axpy(n, -beta / oldbeta, r1, yv);
     const double alpha = dotp(n, v, yv) / beta;
@@ -789,8 +817,30 @@ int fpo_minres_aat(const fpo_csr *A, const double *b, double lambda, double atol
     st->arnorm = ArNorm;
   }
 done:
-  free(r1); free(r2); free(w1); free(w2); free(yv); free(tmp);
+  free(r1); free(r2); free(w1); free(w2); free(yv);
   return 0;
+}
+
+int fpo_minres_aat(const fpo_csr *A, const double *b, double lambda, double atol, double rtol, double etol,
+                   double conlim, int64_t itmax, double *x, fpo_stats *st) {
+  aat_ctx c = {A, lambda, malloc((size_t)A->n * 8)};
+  const int rc = minres_core(op_aat, &c, A->m, b, atol, rtol, etol, conlim, itmax, x, st);
+  free(c.tmp);
+  return rc;
+}
+
+/* K [p; q] = [bp; bq] (null = zero); x = [p (n); q (m)] */
+int fpo_minres_kkt(int64_t m, int64_t n, const int64_t *rowptr, const int64_t *colind, const double *vals, double delta,
+                   const double *bp, const double *bq, double atol, double rtol, double etol, double conlim,
+                   int64_t itmax, double *x, fpo_stats *st) {
+  fpo_csr A = {m, n, rowptr, colind, vals};
+  kkt_ctx c = {&A, delta};
+  double *b = calloc((size_t)(n + m), 8);
+  if (bp) memcpy(b, bp, (size_t)n * 8);
+  if (bq) memcpy(b + n, bq, (size_t)m * 8);
+  const int rc = minres_core(op_kkt, &c, n + m, b, atol, rtol, etol, conlim, itmax, x, st);
+  free(b);
+  return rc;
 }
 
 /* ------------------------------------------------------------------ flat entry points for ctypes */

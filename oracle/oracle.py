@@ -158,6 +158,28 @@ def minres_aat(m, n, rowptr, colind, vals, b, lam=0.0, atol=None, rtol=None, eto
     return x, st
 
 
+def minres_kkt(m, n, rowptr, colind, vals, delta, bp=None, bq=None, atol=None, rtol=None, etol=None, conlim=None,
+               itmax=0):
+    """MINRES on K = [I A'; A -delta I] (fpo_minres_kkt): K [p; q] = [bp; bq]; returns (p, q, stats).  Not a path of the
+    reference -- the checker of the library's kkt_method = FPSQ_KKT_MINRES_K."""
+    se = np.sqrt(np.finfo(float).eps)
+    atol = se if atol is None else atol
+    rtol = se if rtol is None else rtol
+    etol = se if etol is None else etol
+    conlim = 1 / se if conlim is None else conlim
+    rp, ci, va = _csr64(rowptr, colind, vals)
+    bp = None if bp is None else np.ascontiguousarray(bp, dtype=np.float64)
+    bq = None if bq is None else np.ascontiguousarray(bq, dtype=np.float64)
+    x = np.empty(n + m)
+    st = Stats()
+    fn = lib().fpo_minres_kkt
+    fn.restype = C.c_int
+    fn(C.c_int64(m), C.c_int64(n), _p(rp, C.c_int64), _p(ci, C.c_int64), _p(va), C.c_double(delta),
+       None if bp is None else _p(bp), None if bq is None else _p(bq), C.c_double(atol), C.c_double(rtol),
+       C.c_double(etol), C.c_double(conlim), C.c_int64(itmax), _p(x), C.byref(st))
+    return x[:n].copy(), x[n:].copy(), st
+
+
 def _two(fn, m, n, rowptr, colind, vals, delta, rhs1, rhs2, opts, outs, threaded=False):
     rp, ci, va = _csr64(rowptr, colind, vals)
     if threaded:

@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Stats) == 32
-    assert C.sizeof(_lib.Options) == 8 * 17 + 24  # + ln_method, reserved
-    assert _lib.Options.ln_method.offset == 8 * 17 + 16
+    assert C.sizeof(_lib.Options) == 8 * 17 + 24  # + ln_method, kkt_method
+    assert _lib.Options.ln_method.offset == 8 * 17 + 16 and _lib.Options.kkt_method.offset == 8 * 17 + 20
     assert C.sizeof(_lib.Info) == 72 + 32
 
 
@@ -45,6 +45,7 @@ def test_default_options_follow_reference_defaults():
     assert o.ln_atol == se and o.ln_rtol == se and o.ln_btol == se and o.ln_conlim == 1 / se and o.ln_itmax == 550
     assert o.ne_atol == se and o.ne_rtol == se and o.ne_etol == se and o.ne_itmax == 0 and o.ne_conlim == 1 / se
     assert o.ln_method == 0 and o.fuse_two_rhs == 1  # CRAIG is the default least-norm workspace (struct.jl:121)
+    assert o.kkt_method == 0  # LSQR + CRAIG, the reference's iterative path
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -421,6 +421,58 @@ def test_lnlq_method_parity(oracle, delta, fuse):
     dev.close()
 
 
+@pytest.mark.parametrize("delta", [0.0, SE, 0.25])
+def test_minres_on_k_method_parity(oracle, delta):
+    """fpsq_options.kkt_method = FPSQ_KKT_MINRES_K: both saddle-point systems by MINRES on K = [I A'; A -delta I] itself
+    (named by BASELINE.json's north_star / configs[1]; NOT a path of the reference, so the checker is the generic MINRES
+    restatement applied to K): niter / status / solved identical, vectors to 1e-9, the exact KKT solution to 1e-6 at the
+    reference's sqrt(eps) tolerances and to 1e-11 at tight ones; fpsq_ys_gs through it; the fused QP entry refuses."""
+    qp = _small_pde(seed=23, n=4000, m=400)
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    g2 = np.random.default_rng(2).standard_normal(qp.n)
+    H = _Handle(A, delta=delta, kkt_method=1)
+    p1, q1, p2, q2, rc = H.solve_two_mixed(g, c)
+    w1 = oracle.minres_kkt(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, bp=g)
+    w2 = oracle.minres_kkt(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, bq=c)
+    assert rc == 0
+    for k, w in enumerate((w1, w2)):
+        assert (H.st[k].niter, H.st[k].status, H.st[k].solved) == (w[2].niter, w[2].status, w[2].solved)
+        assert H.st[k].niter > 20 and H.st[k].solved == 1
+    for got, want in zip((p1, q1, p2, q2), (w1[0], w1[1], w2[0], w2[1])):
+        assert _rel(got, want) < 1e-9
+    for got, want in zip((p1, q1, p2, q2), oracle.exact_two_mixed(A, delta, g, c)):
+        assert _rel(got, want) < 1e-6
+    # solve_two_least_squares: K [p; q] = [rhs; 0] twice
+    a1, b1, a2, b2, rc = H.solve_two_least_squares(g, g2)
+    w3 = oracle.minres_kkt(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, bp=g2)
+    assert rc == 0 and H.st[1].niter == w3[2].niter
+    assert _rel(a1, w1[0]) < 1e-9 and _rel(b1, w1[1]) < 1e-9 and _rel(a2, w3[0]) < 1e-9 and _rel(b2, w3[1]) < 1e-9
+    # zero right-hand side: that lane ends at once, the other is unaffected
+    z = H.solve_two_mixed(g, 0.0 * c)
+    assert not z[2].any() and not z[3].any() and H.st[1].niter == 0 and H.st[1].solved == 1
+    assert np.array_equal(z[0], p1) and np.array_equal(z[1], q1)
+    H.close()
+    Ht = _Handle(A, delta=delta, kkt_method=1, ne_atol=1e-14, ne_rtol=1e-14, ne_etol=1e-16)
+    tight = Ht.solve_two_mixed(g, c)
+    for got, want in zip(tight[:4], oracle.exact_two_mixed(A, delta, g, c)):
+        assert _rel(got, want) < 1e-11
+    Ht.close()
+    Hi = _Handle(A, delta=delta, kkt_method=1, ne_itmax=5)
+    Hi.solve_two_mixed(g, c)
+    wi = oracle.minres_kkt(qp.m, qp.n, qp.rowptr, qp.colind, qp.vals, delta, bp=g, itmax=5)
+    assert (Hi.st[0].niter, Hi.st[0].status, Hi.st[0].solved) == (wi[2].niter, wi[2].status, wi[2].solved) == (5, 7, 0)
+    Hi.close()
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, kkt_method=1)
+    gs, ys, v, w = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)
+    assert dev.ys_gs(g, c, gs, ys, v, w) == 0
+    assert _rel(ys, q1 + 1e3 * q2) < 1e-12 and _rel(gs, p1 + 1e3 * p2) < 1e-12
+    with pytest.raises(Exception):
+        dev.objgrad(qp.x, gx=np.empty(qp.n))
+    dev.close()
+
+
 def test_zero_right_hand_sides():
     """Edge cases of lsqr!/craig!: b = 0 returns x = 0, solved, 0 iterations."""
     qp = _small_pde(n=600, m=60)

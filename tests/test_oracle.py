@@ -315,3 +315,29 @@ def test_oracle_matches_krylov_jl_golden(oracle):
         w = run["minres"]
         assert (st.niter, bool(st.solved)) == (w["stats"]["niter"], w["stats"]["solved"])
         np.testing.assert_allclose(xm, w["x"], rtol=0, atol=1e-12 * np.linalg.norm(w["x"]))
+
+
+def test_minres_on_k_restatement_matches_exact_kkt(oracle):
+    """fpo_minres_kkt (the checker of the library's kkt_method = FPSQ_KKT_MINRES_K: the MINRES restatement applied to
+    K = [I A'; A -delta I] instead of A A' + lambda I): both saddle-point systems against the exact KKT solve -- 1e-6 at
+    the reference's sqrt(eps) tolerances, 1e-11 at tight ones -- and the refactored A A' variant against a direct solve."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from fps_amd import problems
+
+    qp = problems.pde_control_like(n=3000, m=300, per_row=20, window=256, seed=5)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(0)
+    g, c = rng.standard_normal(3000), rng.standard_normal(300)
+    for delta in (0.0, 1e-2):
+        ex = oracle.exact_two_mixed(A, delta, g, c)
+        p, q, st = oracle.minres_kkt(300, 3000, A.indptr, A.indices, A.data, delta, bp=g)
+        assert st.solved == 1 and 20 < st.niter < 100
+        assert np.linalg.norm(p - ex[0]) <= 1e-6 * np.linalg.norm(ex[0]) and np.linalg.norm(q - ex[1]) <= 1e-6 * np.linalg.norm(ex[1])
+        p, q, st = oracle.minres_kkt(300, 3000, A.indptr, A.indices, A.data, delta, bq=c, atol=1e-13, rtol=1e-13, etol=1e-15)
+        assert np.linalg.norm(p - ex[2]) <= 1e-11 * np.linalg.norm(ex[2]) and np.linalg.norm(q - ex[3]) <= 1e-11 * np.linalg.norm(ex[3])
+    x, st = oracle.minres_aat(300, 3000, A.indptr, A.indices, A.data, c, lam=1e-3)
+    M = (A @ A.T + 1e-3 * sp.identity(300)).tocsc()
+    assert st.solved == 1 and np.linalg.norm(x - spla.spsolve(M, c)) <= 1e-6 * np.linalg.norm(x)
+    p, q, st = oracle.minres_kkt(300, 3000, A.indptr, A.indices, A.data, 0.0)  # zero right-hand side
+    assert st.niter == 0 and st.solved == 1 and not p.any() and not q.any()
