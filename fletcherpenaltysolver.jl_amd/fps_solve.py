@@ -20,6 +20,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+from .nlpmodels import SlackModel, has_bounds, has_inequalities
 from .penalty_nlp import FletcherPenaltyNLP
 from .qdsolver import qdsolver_correspondence
 
@@ -146,6 +147,64 @@ def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
     return x, "max_iter", g
 
 
+def _plbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
+    """Bound-constrained sub-problem  min phi(x), lvar <= x <= uvar  (the role `tron` / `ipopt` play for the reference when
+    the model has bounds, src/parameters.jl:84, :323): limited-memory BFGS on the free variables with a projected Armijo
+    search along P(x + t d).  `fp.bounds = (lvar, uvar)`.  Stops on the projected gradient x - P(x - g) (optim_check_bounded).
+    Returns (x, status, g)."""
+    lo, hi = fp.bounds
+    proj = lambda z: np.minimum(np.maximum(z, lo), hi)
+    x = proj(x)
+    g = _empty_like(x)
+    f, _ = fp.objgrad_(x, g)
+    pg = x - proj(x - g)
+    tol = atol + rtol * _nrminf(pg)
+    S, Y = [], []
+    for it in range(max_iter):
+        pg = x - proj(x - g)
+        if _nrminf(pg) <= tol:
+            return x, "optimal", g
+        if f < -unbounded_below:
+            return x, "unbounded", g
+        free = ~(((x <= lo) & (g > 0.0)) | ((x >= hi) & (g < 0.0)))   # not pressed against an active bound
+        q = np.where(free, g, 0.0)
+        al = []
+        for s, y in zip(reversed(S), reversed(Y)):
+            a = _dot(s, q) / _dot(y, s)
+            al.append(a)
+            q -= a * y
+        if S:
+            q *= _dot(S[-1], Y[-1]) / _dot(Y[-1], Y[-1])
+        for (s, y), a in zip(zip(S, Y), reversed(al)):
+            b = _dot(y, q) / _dot(y, s)
+            q += (a - b) * s
+        d = np.where(free, -q, 0.0)
+        if _dot(g, d) >= 0.0:  # not a descent direction: projected steepest descent
+            S, Y = [], []
+            d = -pg
+        t = 1.0 if S else min(1.0, 1.0 / max(_nrm2(pg), 1e-16))
+        gn = _empty_like(x)
+        for _ in range(60):
+            xn = proj(x + t * d)
+            fn, _ = fp.objgrad_(xn, gn)
+            if np.isfinite(fn) and fn <= f + 1e-4 * _dot(g, xn - x):
+                break
+            t *= 0.5
+        else:
+            return x, "stalled", g
+        s, y = xn - x, gn - g
+        if not s.any():
+            return x, "stalled", g
+        if _dot(s, y) > 1e-12 * _nrm2(s) * _nrm2(y):
+            S.append(s)
+            Y.append(y)
+            if len(S) > mem:
+                S.pop(0)
+                Y.pop(0)
+        x, f, g = xn, fn, gn
+    return x, "max_iter", g
+
+
 def _trunk(fp, x, atol, rtol, max_iter, unbounded_below):
     """Trust-region Newton-CG (Steihaug-Toint) on hprod!.  Returns (x, status, g)."""
     n = x.shape[0]
@@ -215,6 +274,7 @@ class _HostPenalty:
     def __init__(self, fp, nlp):
         self.fp, self.nlp = fp, nlp
         self.objgrad_, self.hprod_ = fp.objgrad_, fp.hprod_
+        self.bounds = (nlp.meta.lvar, nlp.meta.uvar) if has_bounds(nlp) else None
 
     sigma = property(lambda s: s.fp.sigma, lambda s, v: setattr(s.fp, "sigma", v))
     rho = property(lambda s: s.fp.rho, lambda s, v: setattr(s.fp, "rho", v))
@@ -233,7 +293,9 @@ class _HostPenalty:
         return self.fp.fx, _nrm2(self.fp.cx), self.fp.ys
 
     def primal_inf(self, x):
-        return _nrminf(self.nlp.cons(x) - self.nlp.meta.lcon)
+        c = self.nlp.cons(x)
+        ucon = getattr(self.nlp.meta, "ucon", self.nlp.meta.lcon)
+        return _nrminf(np.maximum(np.maximum(c - ucon, self.nlp.meta.lcon - c), 0.0))   # FletcherPenaltySolver.jl:41
 
     def grad_f(self, x):
         return self.nlp.grad(x)
@@ -245,14 +307,33 @@ class _HostPenalty:
     def random_restoration(self, x, atol, rng):
         """random_restoration! (src/algo.jl:340-359): x += radius * rand(n), radius = min(max(atol, 1/sigma, 1e-3), 1)."""
         radius = min(max(atol, 1.0 / self.sigma, 1e-3), 1.0)
-        return x + radius * rng.random(x.size)
+        z = x + radius * rng.random(x.size)
+        return z if self.bounds is None else np.minimum(np.maximum(z, self.bounds[0]), self.bounds[1])
 
     def restoration_feasibility(self, x, feas_tol, atol, rng):
         """restoration_feasibility! (src/algo.jl:295-333): a feasibility step; if it fails, a random perturbation."""
         nlp = self.nlp
         c = nlp.cons(x) - nlp.meta.lcon
         z, ok = feasibility_step(nlp, x, c, feas_tol, feas_tol)
+        if ok and self.bounds is not None:   # (the reference's feasibility step ignores the bounds too; keep the iterate inside)
+            z = np.minimum(np.maximum(z, self.bounds[0]), self.bounds[1])
         return z if ok else self.random_restoration(x, atol, rng)
+
+
+class _PlainModel:
+    """The user model itself as a sub-problem (ncon = 0): objgrad_ / hprod_ of f, bounds passed through."""
+
+    def __init__(self, nlp):
+        self.nlp = nlp
+        self.bounds = (nlp.meta.lvar, nlp.meta.uvar) if has_bounds(nlp) else None
+
+    def objgrad_(self, x, g):
+        g[:] = self.nlp.grad(x)
+        return float(self.nlp.obj(x)), g
+
+    def hprod_(self, x, v, Hv):
+        Hv[:] = self.nlp.hprod(x, np.zeros(0), v)
+        return Hv
 
 
 def _tr_step(J, c, radius):
@@ -319,18 +400,41 @@ def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0,
     """stats = fps_solve(nlp, x0; kwargs...)   (src/FletcherPenaltySolver.jl:127-186 -> src/algo.jl:26-288).
     Keyword arguments are the fields of `AlgoData`; `qds` overrides the back-end instance."""
     meta = AlgoData(**{k: v for k, v in kwargs.items() if k in AlgoData.__dataclass_fields__})
-    if getattr(nlp.meta, "ncon", 0) == 0:
-        raise ValueError("fps_solve: this mirror covers equality-constrained problems (ncon > 0)")
     x = np.array(nlp.meta.x0 if x0 is None else x0, float)
+    if getattr(nlp.meta, "ncon", 0) == 0:
+        # no constraints: the sub-problem solver is called on the model itself (algo.jl:63-75)
+        t0 = time.perf_counter()
+        plain = _PlainModel(nlp)
+        sub = _plbfgs if plain.bounds is not None else _SUBSOLVERS[meta.subproblem_solver]
+        xs, sub_status, g = sub(plain, x, atol, rtol, max(meta.subsolver_max_iter, 1000), meta.subpb_unbounded_threshold)
+        st = ExecutionStats(solution=xs)
+        st.status = {"optimal": "first_order", "unbounded": "unbounded", "max_iter": "max_iter"}.get(sub_status, "stalled")
+        st.objective = float(nlp.obj(xs))
+        st.primal_feas = 0.0
+        st.dual_feas = _nrminf(g if plain.bounds is None else xs - np.minimum(np.maximum(xs - g, plain.bounds[0]), plain.bounds[1]))
+        st.iter, st.elapsed_time, st.multipliers = 1, time.perf_counter() - t0, np.zeros(0)
+        return st
+    orig = nlp
+    if has_inequalities(nlp):                                                   # FletcherPenaltySolver.jl:139-143
+        ns = int((np.asarray(nlp.meta.lcon) != np.asarray(nlp.meta.ucon)).sum())
+        x = np.concatenate([x, np.zeros(ns)])
+        nlp = SlackModel(nlp)
+    if has_bounds(nlp):
+        x = np.minimum(np.maximum(x, nlp.meta.lvar), nlp.meta.uvar)
     qds = qds if qds is not None else qdsolver_correspondence[meta.qds_solver](nlp, 0.0)
     fp = FletcherPenaltyNLP(nlp, sigma=meta.sigma_0, rho=meta.rho_0, delta=0.0, hessian_approx=meta.hessian_approx,
                             x0=x, qds=qds)                                                     # algo.jl:45-52
-    return _outer_loop(_HostPenalty(fp, nlp), x, meta, atol, rtol, max_iter, max_time, verbose)
+    stats = _outer_loop(_HostPenalty(fp, nlp), x, meta, atol, rtol, max_iter, max_time, verbose)
+    if nlp is not orig:                                                          # :153-170: back to the user's variables
+        stats.solver_specific["slack"] = stats.solution[orig.meta.nvar:].copy()
+        stats.solution = stats.solution[: orig.meta.nvar].copy()
+    return stats
 
 
 def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
     """src/algo.jl:26-288 on a penalty model `pen` (host mirror or device-resident); x: numpy array or torch tensor."""
-    sub = _SUBSOLVERS[meta.subproblem_solver]
+    bounds = getattr(pen, "bounds", None)
+    sub = _plbfgs if bounds is not None else _SUBSOLVERS[meta.subproblem_solver]
     t_start = time.perf_counter()
     stats = ExecutionStats(solution=_copy(x))
 
@@ -338,6 +442,8 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
         """Fletcher_penalty_optimality_check (FletcherPenaltySolver.jl:28-50), no bounds."""
         nxk = max(_nrm2(x), 1.0)
         nlk = max(_nrm2(lam), 1.0) if lam is not None else 1.0
+        if bounds is not None:   # x - max(min(x - res, uvar), lvar), not scaled (FletcherPenaltySolver.jl:42-43)
+            return pen.primal_inf(x) / nxk, _nrminf(x - np.minimum(np.maximum(x - res, bounds[0]), bounds[1]))
         return pen.primal_inf(x) / nxk, _nrminf(res) / nlk
 
     p0, d0 = score(x, None, pen.grad_f(x))

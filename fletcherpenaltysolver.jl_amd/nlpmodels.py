@@ -11,11 +11,15 @@ import numpy as np
 
 
 class _Model:
-    def __init__(self, nvar, ncon, nnzj, x0, lcon=None, name="model", lin=()):
+    def __init__(self, nvar, ncon, nnzj, x0, lcon=None, name="model", lin=(), ucon=None, lvar=None, uvar=None):
         lin = np.asarray(sorted(lin), dtype=np.int64)          # 0-based indices of the linear constraints
         nln = np.setdiff1d(np.arange(ncon, dtype=np.int64), lin)
-        self.meta = SimpleNamespace(nvar=nvar, ncon=ncon, nnzj=nnzj, x0=np.asarray(x0, float),
-                                    lcon=np.zeros(ncon) if lcon is None else np.asarray(lcon, float), name=name,
+        lcon = np.zeros(ncon) if lcon is None else np.asarray(lcon, float)
+        ucon = lcon.copy() if ucon is None else np.asarray(ucon, float)   # default: equalities c(x) = lcon
+        self.meta = SimpleNamespace(nvar=nvar, ncon=ncon, nnzj=nnzj, x0=np.asarray(x0, float), lcon=lcon, ucon=ucon,
+                                    lvar=np.full(nvar, -np.inf) if lvar is None else np.asarray(lvar, float),
+                                    uvar=np.full(nvar, np.inf) if uvar is None else np.asarray(uvar, float),
+                                    jfix=np.flatnonzero(lcon == ucon), name=name,
                                     lin=lin, nln=nln, nlin=int(lin.size), nnln=int(nln.size))
 
     def jtprod(self, x, v):
@@ -33,6 +37,58 @@ class _Model:
     def ghjvprod(self, x, g, v):
         """(g' Hess c_i v)_i; zero unless a model overrides it (linear constraints)."""
         return np.zeros(self.meta.ncon)
+
+
+def has_bounds(nlp):
+    """NLPModels.has_bounds: some variable has a finite bound."""
+    lv, uv = getattr(nlp.meta, "lvar", None), getattr(nlp.meta, "uvar", None)
+    return bool((lv is not None and np.isfinite(lv).any()) or (uv is not None and np.isfinite(uv).any()))
+
+
+def has_inequalities(nlp):
+    """NLPModels.has_inequalities: some constraint is not an equality (lcon < ucon)."""
+    uc = getattr(nlp.meta, "ucon", None)
+    return bool(uc is not None and (np.asarray(uc) != np.asarray(nlp.meta.lcon)).any())
+
+
+class SlackModel(_Model):
+    """NLPModelsModifiers.SlackModel as fps_solve applies it (src/FletcherPenaltySolver.jl:139-143): every inequality
+    lcon_i <= c_i(x) <= ucon_i becomes the equality c_i(x) - s_i = 0 with the bounds on the new variable s_i; equalities
+    and the bounds of x are kept.  Variables [x; s], s in the order of the inequality constraints."""
+
+    def __init__(self, nlp):
+        self.model = nlp
+        bm = nlp.meta
+        self._ineq = np.flatnonzero(bm.lcon != bm.ucon)
+        ns = int(self._ineq.size)
+        rows, cols = nlp.jac_structure()
+        self._rows = np.concatenate([np.asarray(rows), self._ineq + 1])
+        self._cols = np.concatenate([np.asarray(cols), bm.nvar + 1 + np.arange(ns)])
+        lcon = bm.lcon.copy()
+        lcon[self._ineq] = 0.0
+        super().__init__(bm.nvar + ns, bm.ncon, bm.nnzj + ns, np.concatenate([bm.x0, np.zeros(ns)]), lcon=lcon,
+                         name=bm.name + "-slack", lin=bm.lin,
+                         lvar=np.concatenate([bm.lvar, bm.lcon[self._ineq]]),
+                         uvar=np.concatenate([bm.uvar, bm.ucon[self._ineq]]))
+        self._n0 = bm.nvar
+
+    def obj(self, x): return self.model.obj(x[: self._n0])
+    def grad(self, x): return np.concatenate([self.model.grad(x[: self._n0]), np.zeros(self.meta.nvar - self._n0)])
+
+    def cons(self, x):
+        c = np.array(self.model.cons(x[: self._n0]), float)
+        c[self._ineq] -= x[self._n0:]
+        return c
+
+    def jac_structure(self): return self._rows, self._cols
+    def jac_coord(self, x): return np.concatenate([self.model.jac_coord(x[: self._n0]), -np.ones(self._ineq.size)])
+
+    def hprod(self, x, y, v, obj_weight=1.0):
+        out = np.zeros(self.meta.nvar)
+        out[: self._n0] = self.model.hprod(x[: self._n0], y, v[: self._n0], obj_weight=obj_weight)
+        return out
+
+    def ghjvprod(self, x, g, v): return self.model.ghjvprod(x[: self._n0], g[: self._n0], v[: self._n0])
 
 
 class NonlinearConstraintsView(_Model):
@@ -203,13 +259,13 @@ class ADModel(_Model):
     ADNLPModels.jl).  `f` and `c` take a 1-D torch tensor and return a scalar / a 1-D tensor (or a list of scalars).
     Dense Jacobian structure, like ADNLPModel's default."""
 
-    def __init__(self, f, x0, c, lcon, name="admodel", lin=()):
+    def __init__(self, f, x0, c, lcon, name="admodel", lin=(), ucon=None, lvar=None, uvar=None):
         import torch
 
         x0 = np.asarray(x0, float)
         lcon = np.asarray(lcon, float)
         n, m = x0.size, lcon.size
-        super().__init__(n, m, n * m, x0, lcon=lcon, name=name, lin=lin)
+        super().__init__(n, m, n * m, x0, lcon=lcon, name=name, lin=lin, ucon=ucon, lvar=lvar, uvar=uvar)
         self._t = torch
         self._f = f
         self._c = lambda x: (lambda v: torch.stack(list(v)) if isinstance(v, (list, tuple)) else v)(c(x))
@@ -294,4 +350,26 @@ def reference_test_problems():
     P["hs61"] = ADModel(lambda x: 4 * x[0] ** 2 + 2 * x[1] ** 2 + 2 * x[2] ** 2 - 33 * x[0] + 16 * x[1] - 24 * x[2],
                         [0.0, 0.0, 0.0], lambda x: [3 * x[0] - 2 * x[1] ** 2 - 7, 4 * x[0] - x[2] ** 2 - 11],
                         [0.0, 0.0], name="HS61")                                           # rank-deficient.jl:23-29
+    return P
+
+
+def bounded_test_problems():
+    """Problems with bounds and / or inequality constraints (the classes of the reference's test/solvertest.jl:
+    bound_constrained_nlp and the :bnd / :ineq / :eqnbnd / :gen families): name -> (model, x*, f*)."""
+    P = {}
+    P["bnd_eq"] = (ADModel(lambda x: (x[0] - 2.0) ** 2 + (x[1] - 1.0) ** 2, [0.0, 0.0], lambda x: [x[0] + x[1]], [2.0],
+                           lvar=[0.0, -np.inf], uvar=[0.5, np.inf], name="active bound + linear equality"),
+                   np.array([0.5, 1.5]), 2.5)
+    P["inactive_bounds"] = (ADModel(lambda x: (x[0] - 1.0) ** 2 + 100 * (x[1] - x[0] ** 2) ** 2, [-1.2, 1.0],
+                                    lambda x: [x.sum()], [1.0], lvar=[-5.0, -5.0], uvar=[5.0, 5.0],
+                                    name="Rosenbrock, sum x = 1, inactive bounds"),
+                            np.array([0.61879562, 0.38120438]), None)
+    P["hs14"] = (ADModel(lambda x: (x[0] - 2.0) ** 2 + (x[1] - 1.0) ** 2, [2.0, 2.0],
+                         lambda x: [x[0] - 2 * x[1] + 1.0, -x[0] ** 2 / 4 - x[1] ** 2 + 1.0], [0.0, 0.0],
+                         ucon=[0.0, np.inf], name="HS14"),
+                 np.array([0.5 * (np.sqrt(7) - 1), 0.25 * (np.sqrt(7) + 1)]), 9 - 2.875 * np.sqrt(7))
+    P["hs71"] = (ADModel(lambda x: x[0] * x[3] * (x[0] + x[1] + x[2]) + x[2], [1.0, 5.0, 5.0, 1.0],
+                         lambda x: [x[0] * x[1] * x[2] * x[3], (x * x).sum()], [25.0, 40.0], ucon=[np.inf, 40.0],
+                         lvar=[1.0] * 4, uvar=[5.0] * 4, name="HS71"),
+                 np.array([1.0, 4.7429994, 3.8211503, 1.3794082]), 17.0140173)
     return P

@@ -66,6 +66,20 @@ def test_reference_integration_problems(name, qds, sub, ha):
         assert abs(stats.solution[0] - 1.0) < 1e-6
 
 
+@pytest.mark.parametrize("qds", ["hip_direct", "hip"])
+@pytest.mark.parametrize("name", ["bnd_eq", "inactive_bounds", "hs14", "hs71"])
+def test_bounds_and_inequalities_through_the_hip_backends(name, qds):
+    """Bounds and inequality constraints (SlackModel + the projected sub-problem solver, FletcherPenaltySolver.jl:139-143,
+    :42-43) with the two systems solved on the MI355X: same acceptance as the CPU suite's exact-back-end run."""
+    model, xstar, fstar = nlpmodels.bounded_test_problems()[name]
+    tol = np.sqrt(np.finfo(float).eps) if name == "inactive_bounds" else 1e-6
+    st = fps_solve(model, qds_solver=qds, atol=tol, rtol=tol, max_iter=200, max_time=120)
+    assert st.status == "first_order" and st.solution.size == model.meta.nvar
+    np.testing.assert_allclose(st.solution, xstar, rtol=0, atol=5e-5)
+    if fstar is not None:
+        assert abs(st.objective - fstar) <= 1e-4 * max(1.0, abs(fstar))
+
+
 @pytest.mark.parametrize("backend", ["hip", "hip_direct"])
 @pytest.mark.parametrize("ha", [1, 2])
 def test_explicit_linear_constraints_penalise_only_the_nonlinear_ones(backend, ha):

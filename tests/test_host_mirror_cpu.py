@@ -133,3 +133,48 @@ def test_feasibility_step_reaches_the_constraint_manifold():
     nlp = P["huyer_neumaier"]
     z, ok = feasibility_step(nlp, nlp.meta.x0, nlp.cons(nlp.meta.x0), 1e-8, 1e-8)
     assert not ok and np.allclose(z, 0.0)  # J = 0 and H = 2 c I = -2 I, J'c = 0: no direction -- the caller perturbs x
+
+
+@pytest.mark.parametrize("name", ["bnd_eq", "inactive_bounds", "hs14", "hs71"])
+def test_fps_solve_with_bounds_and_inequalities(oracle, name):
+    """Bounds and inequality constraints (src/FletcherPenaltySolver.jl:139-143: inequalities through SlackModel, the bounds
+    handled by the sub-problem solver; optimality on the projected residual, :42-43).  The penalty function of the
+    reference knows only the equality multipliers, so with ACTIVE bounds it is not exact: the outer loop then converges at
+    the rate sigma is increased (|c| ~ 1 / sigma), which is why these run at 1e-6; with inactive bounds the exactness, and
+    the sqrt(eps) tolerance, is kept."""
+    model, xstar, fstar = nlpmodels.bounded_test_problems()[name]
+    inner = nlpmodels.SlackModel(model) if nlpmodels.has_inequalities(model) else model
+    tol = np.sqrt(np.finfo(float).eps) if name == "inactive_bounds" else 1e-6
+    st = fps_solve(model, qds=OracleQDSolver(inner, 0.0), atol=tol, rtol=tol, max_iter=200)
+    assert st.status == "first_order" and st.solution.size == model.meta.nvar
+    np.testing.assert_allclose(st.solution, xstar, rtol=0, atol=2e-5)
+    if fstar is not None:
+        assert abs(st.objective - fstar) <= 1e-4 * max(1.0, abs(fstar))
+    lv, uv = model.meta.lvar, model.meta.uvar
+    assert np.all(st.solution >= lv - 1e-12) and np.all(st.solution <= uv + 1e-12)
+    c = model.cons(st.solution)
+    assert np.all(c >= model.meta.lcon - 1e-5) and np.all(c <= model.meta.ucon + 1e-5)
+
+
+def test_slack_model_and_bound_only_problems():
+    """SlackModel: variables [x; s], c_i(x) - s_i = 0 with the constraint bounds moved to s; derivatives consistent.
+    ncon = 0: fps_solve hands the model to the sub-problem solver (projected when it has bounds)."""
+    model, _, _ = nlpmodels.bounded_test_problems()["hs71"]
+    sm = nlpmodels.SlackModel(model)
+    assert (sm.meta.nvar, sm.meta.ncon, sm.meta.nnzj) == (5, 2, 9) and not nlpmodels.has_inequalities(sm)
+    assert sm.meta.lvar[4] == 25.0 and np.isinf(sm.meta.uvar[4]) and nlpmodels.has_bounds(sm)
+    z = np.array([1.1, 4.0, 3.5, 1.4, 20.0])
+    np.testing.assert_allclose(sm.cons(z), model.cons(z[:4]) - np.array([20.0, 0.0]))
+    rows, cols = sm.jac_structure()
+    J = np.zeros((2, 5))
+    np.add.at(J, (rows - 1, cols - 1), sm.jac_coord(z))
+    h = 1e-6
+    for j in range(5):
+        e = np.zeros(5)
+        e[j] = h
+        np.testing.assert_allclose((sm.cons(z + e) - sm.cons(z - e)) / (2 * h), J[:, j], rtol=0, atol=1e-6)
+    box = nlpmodels.ADModel(lambda x: ((x - 2.0) ** 2).sum(), [0.0, 0.0, 0.0], lambda x: x[:0], [],
+                            lvar=[-1.0, -1.0, 3.0], uvar=[1.0, 5.0, 4.0], name="box")
+    st = fps_solve(box)
+    assert st.status == "first_order"
+    np.testing.assert_allclose(st.solution, [1.0, 2.0, 3.0], atol=1e-7)
