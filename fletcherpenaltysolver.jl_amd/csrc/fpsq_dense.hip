@@ -443,6 +443,11 @@ struct fpsq_band_s {
   int64_t n = 0, m = 0, nnz = 0, mpad = 0, nb = 0;
   int band_w = 1;  // blocks per block row of the band storage = half bandwidth (in blocks) + 1
   int span = 0;    // widest column span of a row (LDS window of k_band_form)
+  // row reordering chosen by the symbolic phase (reverse Cuthill-McKee on the rows of A, adjacent = sharing a column):
+  // row p of the stored structure is row rperm[p] of the caller's; vperm maps stored entries to the caller's
+  bool reordered = false;
+  int32_t *rperm = nullptr, *vperm = nullptr;
+  double *vals_in = nullptr, *in_bp = nullptr;
   int form_gen = 2, form_R = 1;  // 2: k_band_form_t (by columns of A, form_R rows per pass); 1: k_band_form (row pairs)
   int device = 0;
   hipStream_t stream = nullptr;
@@ -488,6 +493,71 @@ int bmalloc(fpsq_band b, T** p, size_t count) {
   return 0;
 }
 
+// Reverse Cuthill-McKee on the rows of A (two rows adjacent when they share a column: the graph of A A').  Returns the new
+// order (position -> caller's row) or an empty vector when the adjacency is too large to walk (sum over the columns of
+// length^2 > 4e8).  Start nodes: minimum degree, moved to a pseudo-peripheral node by two breadth-first sweeps.
+std::vector<int32_t> rcm_rows(int64_t m, int64_t n, const std::vector<int32_t>& rp, const std::vector<int32_t>& ci) {
+  std::vector<int32_t> cp(n + 1, 0);
+  for (int64_t i = 0; i < m; ++i)
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) cp[ci[k] + 1]++;
+  double work = 0.0;
+  for (int64_t c = 0; c < n; ++c) {
+    work += (double)cp[c + 1] * cp[c + 1];
+    cp[c + 1] += cp[c];
+  }
+  if (work > 4e8) return {};
+  std::vector<int32_t> cr(std::max<int64_t>(rp[m], 1)), nxt(cp.begin(), cp.end() - 1);
+  for (int64_t i = 0; i < m; ++i)
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) cr[nxt[ci[k]]++] = (int32_t)i;
+  std::vector<int64_t> deg(m, 0);
+  for (int64_t i = 0; i < m; ++i)
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k) deg[i] += cp[ci[k] + 1] - cp[ci[k]] - 1;
+  std::vector<int32_t> order;
+  order.reserve(m);
+  std::vector<int32_t> mark(m, -1);  // mark[i] = id of the sweep that reached row i
+  std::vector<char> placed(m, 0);
+  std::vector<int32_t> level, nbr;
+  int sweep = 0;
+  // breadth-first sweep from `root` over the not yet placed rows; returns the visiting order (neighbours by degree)
+  auto bfs = [&](int32_t root, std::vector<int32_t>& out) {
+    out.clear();
+    ++sweep;
+    mark[root] = sweep;
+    out.push_back(root);
+    for (size_t h = 0; h < out.size(); ++h) {
+      const int32_t u = out[h];
+      nbr.clear();
+      for (int32_t k = rp[u]; k < rp[u + 1]; ++k)
+        for (int32_t t = cp[ci[k]]; t < cp[ci[k] + 1]; ++t) {
+          const int32_t v = cr[t];
+          if (!placed[v] && mark[v] != sweep) {
+            mark[v] = sweep;
+            nbr.push_back(v);
+          }
+        }
+      std::sort(nbr.begin(), nbr.end(), [&](int32_t a, int32_t b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+      out.insert(out.end(), nbr.begin(), nbr.end());
+    }
+  };
+  std::vector<int32_t> byd(m);
+  for (int64_t i = 0; i < m; ++i) byd[i] = (int32_t)i;
+  std::sort(byd.begin(), byd.end(), [&](int32_t a, int32_t b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+  size_t cursor = 0;
+  while ((int64_t)order.size() < m) {
+    while (placed[byd[cursor]]) ++cursor;
+    int32_t root = byd[cursor];
+    for (int pass = 0; pass < 2; ++pass) {  // towards a pseudo-peripheral node: restart from the last node reached
+      bfs(root, level);
+      root = level.back();
+    }
+    bfs(root, level);
+    for (int32_t v : level) placed[v] = 1;
+    order.insert(order.end(), level.begin(), level.end());
+  }
+  std::reverse(order.begin(), order.end());
+  return order;
+}
+
 inline size_t blk_off(const fpsq_band b, int64_t i, int64_t j) {  // block (i, j), i - (band_w - 1) <= j <= i
   return ((size_t)i * b->band_w + (size_t)(j - i + b->band_w - 1)) * kDB * kDB;
 }
@@ -522,8 +592,12 @@ int band_finish(fpsq_band b, const double* a1, double* p1, double* q1, double* p
                      b->r2, b->atq, (int)b->n);
   hipLaunchKernelGGL(k_band_finish, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, s, b->atq, b->in_a, a1, b->o_p1,
                      b->o_p2, (int)b->n);
-  hipLaunchKernelGGL(k_dense_unpack2, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->r2, b->o_q1, b->o_q2,
-                     (int)b->m);
+  if (b->reordered)  // back to the caller's row order
+    hipLaunchKernelGGL(k_unpack2_scatter, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->r2, b->rperm, b->o_q1,
+                       b->o_q2, (int)b->m);
+  else
+    hipLaunchKernelGGL(k_dense_unpack2, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->r2, b->o_q1, b->o_q2,
+                       (int)b->m);
   hipEventRecord(b->e1, s);
   BCHK(b, hipMemcpyAsync(p1, b->o_p1, (size_t)b->n * 8, hipMemcpyDefault, s));
   BCHK(b, hipMemcpyAsync(p2, b->o_p2, (size_t)b->n * 8, hipMemcpyDefault, s));
@@ -588,6 +662,64 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   if (nnz > 0 && (!colind || hipMemcpy(ci.data(), colind, (size_t)nnz * 4, hipMemcpyDefault) != hipSuccess)) {
     g_band_create_error = "fpsq_band_create: cannot read colind";
     return FPSQ_ERR_ARG;
+  }
+  // validate, then the natural half bandwidth (rows): if the band is wide, try a reverse Cuthill-McKee ordering of the rows
+  // (LDLFactorizations' ldl_analyze computes a fill-reducing ordering at this point; for a band factorisation the
+  // ordering to look for is the bandwidth-reducing one).  FPSQ_BAND_REORDER = 0 never, 1 always tries.
+  for (int64_t i = 0; i < m; ++i) {
+    if (rp[i + 1] < rp[i] || rp[i + 1] > nnz) {
+      g_band_create_error = "fpsq_band_create: rowptr not monotone";
+      return FPSQ_ERR_ARG;
+    }
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k)
+      if (ci[k] < 0 || ci[k] >= n) {
+        g_band_create_error = "fpsq_band_create: column index out of range";
+        return FPSQ_ERR_ARG;
+      }
+  }
+  std::vector<int32_t> rperm_h, vperm_h;
+  {
+    auto bandwidth_rows = [&](const std::vector<int32_t>& pos) {  // pos[row] = position; empty = identity
+      std::vector<int32_t> lo(n, INT32_MAX), hi(n, -1);
+      for (int64_t i = 0; i < m; ++i) {
+        const int32_t p = pos.empty() ? (int32_t)i : pos[i];
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+          lo[ci[k]] = std::min(lo[ci[k]], p);
+          hi[ci[k]] = std::max(hi[ci[k]], p);
+        }
+      }
+      int64_t w = 0;
+      for (int64_t c = 0; c < n; ++c)
+        if (hi[c] >= 0) w = std::max<int64_t>(w, hi[c] - lo[c]);
+      return w;
+    };
+    int mode = -1;  // auto
+    if (const char* ev = std::getenv("FPSQ_BAND_REORDER")) mode = std::atoi(ev);
+    const int64_t nbk = (m + kDB - 1) / kDB;
+    const int64_t bw_nat = bandwidth_rows({});
+    if (mode != 0 && (mode == 1 || bw_nat / kDB > std::max<int64_t>(nbk / 8, 2))) {
+      std::vector<int32_t> ord = rcm_rows(m, n, rp, ci);
+      if (!ord.empty()) {
+        std::vector<int32_t> pos(m);
+        for (int64_t p = 0; p < m; ++p) pos[ord[p]] = (int32_t)p;
+        const int64_t bw_new = bandwidth_rows(pos);
+        if (bw_new / kDB < bw_nat / kDB) {  // fewer blocks in the band: take it
+          std::vector<int32_t> rp2(m + 1, 0), ci2(std::max<int64_t>(nnz, 1));
+          vperm_h.resize(std::max<int64_t>(nnz, 1));
+          for (int64_t p = 0; p < m; ++p) {
+            const int32_t r = ord[p];
+            rp2[p + 1] = rp2[p] + (rp[r + 1] - rp[r]);
+            for (int32_t k = rp[r], t = rp2[p]; k < rp[r + 1]; ++k, ++t) {
+              ci2[t] = ci[k];
+              vperm_h[t] = k;
+            }
+          }
+          rp.swap(rp2);
+          ci.swap(ci2);
+          rperm_h.swap(ord);
+        }
+      }
+    }
   }
   std::vector<int32_t> cfirst(n, INT32_MAX), clast(n, -1), tcnt(n + 1, 0);
   std::vector<int2> span(m);
@@ -689,10 +821,18 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   rc |= bmalloc(b, &b->in_a, (size_t)n) | bmalloc(b, &b->in_b, (size_t)std::max(n, b->mpad));
   rc |= bmalloc(b, &b->o_p1, (size_t)n) | bmalloc(b, &b->o_p2, (size_t)n);
   rc |= bmalloc(b, &b->o_q1, (size_t)b->mpad) | bmalloc(b, &b->o_q2, (size_t)b->mpad) | bmalloc(b, &b->info_dev, 4);
+  b->reordered = !rperm_h.empty();
+  if (b->reordered)
+    rc |= bmalloc(b, &b->rperm, (size_t)m) | bmalloc(b, &b->vperm, nz) | bmalloc(b, &b->vals_in, nz) |
+          bmalloc(b, &b->in_bp, (size_t)b->mpad);
   if (rc) {
     g_band_create_error = b->err;
     fpsq_band_destroy(b);
     return FPSQ_ERR_HIP;
+  }
+  if (b->reordered) {
+    hipMemcpy(b->rperm, rperm_h.data(), (size_t)m * 4, hipMemcpyHostToDevice);
+    if (nnz > 0) hipMemcpy(b->vperm, vperm_h.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
   }
   hipMemset(b->invs, 0, (size_t)b->nb * kDB * kDB * 8);  // k_potrf_inv128m writes the non-zero triangles only
   hipMemset(b->invsT, 0, (size_t)b->nb * kDB * kDB * 8);
@@ -723,6 +863,7 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   b->info.nnz = nnz;
   b->info.nblocks = b->nb;
   b->info.bandwidth_blocks = b->band_w - 1;
+  b->info.reordered = b->reordered ? 1 : 0;
   b->info.factor_bytes = (int64_t)fbytes;
   *out = b;
   return FPSQ_OK;
@@ -742,7 +883,13 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
   const int nb = (int)b->nb, W = b->band_w, bw = W - 1;
   b->factored = false;
   if (b->nnz > 0) {
-    BCHK(b, hipMemcpyAsync(b->vals, vals, (size_t)b->nnz * 8, hipMemcpyDefault, s));
+    if (b->reordered) {
+      BCHK(b, hipMemcpyAsync(b->vals_in, vals, (size_t)b->nnz * 8, hipMemcpyDefault, s));
+      hipLaunchKernelGGL(k_gather_d, dim3((unsigned)std::min<int64_t>((b->nnz + 255) / 256, 4096)), dim3(256), 0, s, b->vals_in,
+                         b->vperm, b->vals, b->nnz);
+    } else {
+      BCHK(b, hipMemcpyAsync(b->vals, vals, (size_t)b->nnz * 8, hipMemcpyDefault, s));
+    }
     hipLaunchKernelGGL(k_gather_d, dim3((unsigned)std::min<int64_t>((b->nnz + 255) / 256, 4096)), dim3(256), 0, s, b->vals,
                        b->t_perm, b->t_vals, b->nnz);
   }
@@ -845,7 +992,12 @@ int fpsq_band_solve_two_mixed(fpsq_band b, const double* rhs1, const double* rhs
                      (const double*)nullptr, 0.0, b->xn, (int)b->n, (int)b->n);
   hipLaunchKernelGGL(k_csr_mv2, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->rowptr, b->colind, b->vals, b->xn,
                      b->ym, (int)b->m);
-  hipLaunchKernelGGL(k_band_rhs, dim3((unsigned)((b->mpad + 255) / 256)), dim3(256), 0, s, b->ym, 0, b->in_b, -1.0, b->r2,
+  const double* cperm = b->in_b;
+  if (b->reordered) {
+    hipLaunchKernelGGL(k_gather_d, dim3((unsigned)((b->m + 255) / 256)), dim3(256), 0, s, b->in_b, b->rperm, b->in_bp, b->m);
+    cperm = b->in_bp;
+  }
+  hipLaunchKernelGGL(k_band_rhs, dim3((unsigned)((b->mpad + 255) / 256)), dim3(256), 0, s, b->ym, 0, cperm, -1.0, b->r2,
                      (int)b->m, (int)b->mpad, 0);
   return band_finish(b, nullptr, p1, q1, p2, q2);
 }

@@ -1519,6 +1519,15 @@ __global__ __launch_bounds__(256) void k_dense_pack2(const double* a, double sa,
 }
 
 // out0[i] = in[i][0], out1[i] = in[i][1]
+// the same with a row permutation: out{0,1}[perm[i]] = in[i][{0,1}]
+__global__ __launch_bounds__(256) void k_unpack2_scatter(const double* __restrict__ in, const int32_t* __restrict__ perm,
+                                                         double* out0, double* out1, int len) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  out0[perm[i]] = in[(size_t)i * 2];
+  out1[perm[i]] = in[(size_t)i * 2 + 1];
+}
+
 __global__ __launch_bounds__(256) void k_dense_unpack2(const double* in, double* out0, double* out1, int len) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= len) return;

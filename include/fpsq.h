@@ -260,7 +260,11 @@ int fpsq_dense_get_info(fpsq_dense d, fpsq_dense_info *info);
  *   fpsq_band_create      = the constructor's symbolic work (src/solve_two_systems_struct.jl:326-344: the COO pattern of
  *                           triu(K) and `ldl_analyze`): here the block band structure of M = A A' + delta I -- the Schur
  *                           complement of the identity block of K = [I A'; A -delta I] -- from the CSR pattern of A
- *                           (half bandwidth = the largest row distance of two entries of one column).
+ *                           (half bandwidth = the largest row distance of two entries of one column).  When the
+ *                           natural band is wide (> 1/8 of the matrix) the rows are first reordered by reverse
+ *                           Cuthill-McKee on the graph of A A' -- the bandwidth-reducing counterpart of the fill-reducing
+ *                           ordering `ldl_analyze` computes -- and the ordering is kept if it narrows the band; the
+ *                           permutation is internal (right-hand sides and solutions stay in the caller's row order).
  *   fpsq_band_factorize   = `jac_coord!` + `sparse(...)` + `ldl_factorize!` (src/solve_linear_system.jl:223-234): forms M
  *                           into 128 x 128 blocks of the band on the device and factors it with a right-looking
  *                           block-banded Cholesky (the dense back-end's MFMA block kernels); returns 1 (soft) with *info
@@ -278,6 +282,7 @@ typedef struct {
   int64_t factor_bytes;      /* storage of the banded factor */
   double last_form_ms, last_chol_ms, last_solve_ms;
   int64_t regularized_pivots;
+  int64_t reordered;         /* 1: the symbolic phase reordered the rows of A (reverse Cuthill-McKee) to narrow the band */
 } fpsq_band_info;
 int fpsq_band_create(fpsq_band *out, int64_t n, int64_t m, const int32_t *rowptr, const int32_t *colind, int32_t device);
 int fpsq_band_destroy(fpsq_band b);
