@@ -60,7 +60,7 @@ class BandInfo(C.Structure):
     _fields_ = [("n", C.c_int64), ("m", C.c_int64), ("nnz", C.c_int64), ("nblocks", C.c_int64),
                 ("bandwidth_blocks", C.c_int64), ("factor_bytes", C.c_int64), ("last_form_ms", C.c_double),
                 ("last_chol_ms", C.c_double), ("last_solve_ms", C.c_double), ("regularized_pivots", C.c_int64),
-                ("reordered", C.c_int64)]
+                ("reordered", C.c_int64), ("chains", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

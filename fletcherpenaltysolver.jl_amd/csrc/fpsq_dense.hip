@@ -446,6 +446,10 @@ struct fpsq_band_s {
   // row reordering chosen by the symbolic phase (reverse Cuthill-McKee on the rows of A, adjacent = sharing a column):
   // row p of the stored structure is row rperm[p] of the caller's; vperm maps stored entries to the caller's
   bool reordered = false;
+  std::vector<int32_t> rperm_host;
+  // two elimination chains (see fpsq_band_create): blocks 2 c / 2 c + 1, c < chain_safe, are eliminated side by side on
+  // two streams; their couplings reach chain_bw blocks of the same chain (stride 2 in the stored order)
+  int chain_safe = 0, chain_bw = 0;
   int32_t *rperm = nullptr, *vperm = nullptr;
   double *vals_in = nullptr, *in_bp = nullptr;
   int form_gen = 2, form_R = 1;  // 2: k_band_form_t (by columns of A, form_R rows per pass); 1: k_band_form (row pairs)
@@ -567,12 +571,40 @@ void band_solve(fpsq_band b) {
   hipStream_t s = b->stream;
   const int nb = (int)b->nb, bw = b->band_w - 1;
   if (b->potrf_gen >= 5) {
-    for (int k = 0; k < nb; ++k)
+    int k0 = 0;
+    const int cs = b->chain_safe, cb = b->chain_bw;
+    hipStream_t s2 = b->stream2;
+    if (cs > 0) {  // forward: the two chains side by side (each touches the blocks of its own parity only), then the rest
+      hipEventRecord(b->evA, s);
+      hipStreamWaitEvent(s2, b->evA, 0);
+      for (int c = 0; c < cs; ++c) {
+        hipLaunchKernelGGL(k_trsv_step3<true>, dim3(cb + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT, b->r2, b->y2, 2 * c,
+                           b->band_w, 2);
+        hipLaunchKernelGGL(k_trsv_step3<true>, dim3(cb + 1), dim3(256), 0, s2, b->Mb, kDB, b->invs, b->invsT, b->r2, b->y2,
+                           2 * c + 1, b->band_w, 2);
+      }
+      hipEventRecord(b->evB, s2);
+      hipStreamWaitEvent(s, b->evB, 0);
+      k0 = 2 * cs;
+    }
+    for (int k = k0; k < nb; ++k)
       hipLaunchKernelGGL(k_trsv_step3<true>, dim3(std::min(bw, nb - 1 - k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs,
-                         b->invsT, b->r2, b->y2, k, b->band_w);
-    for (int k = nb - 1; k >= 0; --k)
+                         b->invsT, b->r2, b->y2, k, b->band_w, 1);
+    for (int k = nb - 1; k >= k0; --k)
       hipLaunchKernelGGL(k_trsv_step3<false>, dim3(std::min(bw, k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT,
-                         b->y2, b->r2, k, b->band_w);
+                         b->y2, b->r2, k, b->band_w, 1);
+    if (cs > 0) {
+      hipEventRecord(b->evA, s);
+      hipStreamWaitEvent(s2, b->evA, 0);
+      for (int c = cs - 1; c >= 0; --c) {
+        hipLaunchKernelGGL(k_trsv_step3<false>, dim3(std::min(cb, c) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT,
+                           b->y2, b->r2, 2 * c, b->band_w, 2);
+        hipLaunchKernelGGL(k_trsv_step3<false>, dim3(std::min(cb, c) + 1), dim3(256), 0, s2, b->Mb, kDB, b->invs, b->invsT,
+                           b->y2, b->r2, 2 * c + 1, b->band_w, 2);
+      }
+      hipEventRecord(b->evB, s2);
+      hipStreamWaitEvent(s, b->evB, 0);
+    }
     return;
   }
   for (int k = 0; k < nb; ++k)
@@ -677,7 +709,8 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
         return FPSQ_ERR_ARG;
       }
   }
-  std::vector<int32_t> rperm_h, vperm_h;
+  std::vector<int32_t> rperm_h, vperm_h;  // stored row / entry -> the caller's (empty: identity)
+  int chain_safe = 0, chain_bw = 0;
   {
     auto bandwidth_rows = [&](const std::vector<int32_t>& pos) {  // pos[row] = position; empty = identity
       std::vector<int32_t> lo(n, INT32_MAX), hi(n, -1);
@@ -693,32 +726,60 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
         if (hi[c] >= 0) w = std::max<int64_t>(w, hi[c] - lo[c]);
       return w;
     };
+    // row `ord[p]` of the current structure becomes row p; the maps to the caller's numbering are composed
+    auto apply_order = [&](const std::vector<int32_t>& ord) {
+      std::vector<int32_t> rp2(m + 1, 0), ci2(std::max<int64_t>(nnz, 1)), vp2(std::max<int64_t>(nnz, 1)), rr2(m);
+      for (int64_t p = 0; p < m; ++p) {
+        const int32_t r = ord[p];
+        rr2[p] = rperm_h.empty() ? r : rperm_h[r];
+        rp2[p + 1] = rp2[p] + (rp[r + 1] - rp[r]);
+        for (int32_t k = rp[r], t = rp2[p]; k < rp[r + 1]; ++k, ++t) {
+          ci2[t] = ci[k];
+          vp2[t] = vperm_h.empty() ? k : vperm_h[k];
+        }
+      }
+      rp.swap(rp2);
+      ci.swap(ci2);
+      rperm_h.swap(rr2);
+      vperm_h.swap(vp2);
+    };
     int mode = -1;  // auto
     if (const char* ev = std::getenv("FPSQ_BAND_REORDER")) mode = std::atoi(ev);
     const int64_t nbk = (m + kDB - 1) / kDB;
-    const int64_t bw_nat = bandwidth_rows({});
-    if (mode != 0 && (mode == 1 || bw_nat / kDB > std::max<int64_t>(nbk / 8, 2))) {
+    int64_t bw_rows = bandwidth_rows({});
+    if (mode != 0 && (mode == 1 || bw_rows / kDB > std::max<int64_t>(nbk / 8, 2))) {
       std::vector<int32_t> ord = rcm_rows(m, n, rp, ci);
       if (!ord.empty()) {
         std::vector<int32_t> pos(m);
         for (int64_t p = 0; p < m; ++p) pos[ord[p]] = (int32_t)p;
         const int64_t bw_new = bandwidth_rows(pos);
-        if (bw_new / kDB < bw_nat / kDB) {  // fewer blocks in the band: take it
-          std::vector<int32_t> rp2(m + 1, 0), ci2(std::max<int64_t>(nnz, 1));
-          vperm_h.resize(std::max<int64_t>(nnz, 1));
-          for (int64_t p = 0; p < m; ++p) {
-            const int32_t r = ord[p];
-            rp2[p + 1] = rp2[p] + (rp[r + 1] - rp[r]);
-            for (int32_t k = rp[r], t = rp2[p]; k < rp[r + 1]; ++k, ++t) {
-              ci2[t] = ci[k];
-              vperm_h[t] = k;
-            }
-          }
-          rp.swap(rp2);
-          ci.swap(ci2);
-          rperm_h.swap(ord);
+        if (bw_new / kDB < bw_rows / kDB) {  // fewer blocks in the band: take it
+          apply_order(ord);
+          bw_rows = bw_new;
         }
       }
+    }
+    // TWO ELIMINATION CHAINS.  A banded Cholesky is a chain of m / 128 dependent block steps, each a few latency-bound
+    // launches.  Ordering the blocks from BOTH ends towards the middle -- stored block 2 c = block c from the top, stored
+    // block 2 c + 1 = the c-th block of 128 rows from the bottom (rows descending) -- keeps the matrix banded (twice as
+    // wide) and makes the even and the odd blocks two independent chains until they meet: their steps run side by side
+    // on two streams, the chain is half as long.  Only the last 2 (chain_bw + 1) blocks and the rows left in the middle
+    // are eliminated one after the other.  FPSQ_BAND_TWOCHAIN=0 turns it off.
+    int two = 1;
+    if (const char* ev = std::getenv("FPSQ_BAND_TWOCHAIN")) two = std::atoi(ev);
+    const int64_t C = m / (2 * kDB);
+    const int64_t bwc = (bw_rows + kDB - 1) / kDB;  // block distance two coupled rows of one chain can have
+    if (two && bwc >= 1 && C - bwc - 1 >= 4 * (bwc + 1)) {
+      std::vector<int32_t> ord(m);
+      int64_t p = 0;
+      for (int64_t c = 0; c < C; ++c) {
+        for (int64_t t = 0; t < kDB; ++t) ord[p++] = (int32_t)(c * kDB + t);
+        for (int64_t t = 0; t < kDB; ++t) ord[p++] = (int32_t)(m - 1 - c * kDB - t);
+      }
+      for (int64_t r = C * kDB; r < m - C * kDB; ++r) ord[p++] = (int32_t)r;
+      apply_order(ord);
+      chain_safe = (int)(C - bwc - 1);
+      chain_bw = (int)bwc;
     }
   }
   std::vector<int32_t> cfirst(n, INT32_MAX), clast(n, -1), tcnt(n + 1, 0);
@@ -762,6 +823,8 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   b->nb = b->mpad / kDB;
   b->band_w = (int)std::min<int64_t>(bwb, b->nb - 1) + 1;
   b->span = maxspan;
+  b->chain_safe = chain_safe;
+  b->chain_bw = std::min(chain_bw, (b->band_w - 1) / 2);
   if (has_dup) {
     g_band_create_error = "fpsq_band_create: the CSR pattern has duplicate entries (sum them first)";
     delete b;
@@ -822,6 +885,7 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   rc |= bmalloc(b, &b->o_p1, (size_t)n) | bmalloc(b, &b->o_p2, (size_t)n);
   rc |= bmalloc(b, &b->o_q1, (size_t)b->mpad) | bmalloc(b, &b->o_q2, (size_t)b->mpad) | bmalloc(b, &b->info_dev, 4);
   b->reordered = !rperm_h.empty();
+  b->rperm_host = rperm_h;
   if (b->reordered)
     rc |= bmalloc(b, &b->rperm, (size_t)m) | bmalloc(b, &b->vperm, nz) | bmalloc(b, &b->vals_in, nz) |
           bmalloc(b, &b->in_bp, (size_t)b->mpad);
@@ -864,6 +928,7 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   b->info.nblocks = b->nb;
   b->info.bandwidth_blocks = b->band_w - 1;
   b->info.reordered = b->reordered ? 1 : 0;
+  b->info.chains = b->chain_safe > 0 ? 2 : 1;
   b->info.factor_bytes = (int64_t)fbytes;
   *out = b;
   return FPSQ_OK;
@@ -904,17 +969,54 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
     hipLaunchKernelGGL(k_band_form_t, dim3(nb), dim3(256), (size_t)b->form_R * W * kDB * 8, s, b->rowptr, b->colind, b->vals,
                        b->t_rowptr, b->t_colind, b->t_vals, (int)b->m, (int)b->mpad, W, delta, b->Mb, b->form_R);
   hipEventRecord(b->e1, s);
-  // numeric phase 2: right-looking block-banded Cholesky (ldl_factorize!, :234), the dense back-end's block kernels
-  for (int k = 0; k < nb; ++k) {
+  // numeric phase 2: right-looking block-banded Cholesky (ldl_factorize!, :234), the dense back-end's block kernels.
+  // One step: diagonal block k, panel blocks (k + st j, k) and trailing blocks (k + st i, k + st j), 1 <= j <= i <= rem
+  // (st = 1: the whole band below k; st = 2: the blocks of k's own chain)
+  auto potrf = [&](hipStream_t q, int k) {
     double* Mkk = b->Mb + blk_off(b, k, k);
     double* inv = b->invs + (size_t)k * kDB * kDB;
     if (b->potrf_gen >= 5)
-      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
+      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, q, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
                          k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
     else
-      hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
+      hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, q, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
                          k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
+    return inv;
+  };
+  auto step = [&](hipStream_t q, int k, int st, int rem) {
+    double* inv = potrf(q, k);
+    if (rem <= 0) return;
+    BlockStrides ps, ts;
+    ps.on = ts.on = 1;
+    ps.a = ps.ci = (size_t)st * bw * kDB * kDB;  // block (k + st (1 + bi), k): st block rows down, st columns of the band left
+    ps.b = ps.cj = 0;
+    ts.a = ts.b = ts.ci = ps.a;
+    ts.cj = (size_t)st * kDB * kDB;
+    double* panel = b->Mb + blk_off(b, k + st, k);
+    double* trail = b->Mb + blk_off(b, k + st, k + st);
+    hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(1024), kG128Lds1, q, panel, kDB, panel, kDB, inv, kDB, ps);
+    hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(1024), kG128Lds0, q, trail, kDB, panel, kDB, panel, kDB, ts);
+  };
+  int k0 = 0;
+  if (b->chain_safe > 0 && b->direct128 && !b->lookahead) {  // the two chains side by side
+    hipStream_t s2 = b->stream2;
+    hipEventRecord(b->evA, s);
+    hipStreamWaitEvent(s2, b->evA, 0);
+    for (int c = 0; c < b->chain_safe; ++c) {
+      step(s, 2 * c, 2, b->chain_bw);
+      step(s2, 2 * c + 1, 2, b->chain_bw);
+    }
+    hipEventRecord(b->evB, s2);
+    hipStreamWaitEvent(s, b->evB, 0);
+    k0 = 2 * b->chain_safe;
+  }
+  for (int k = k0; k < nb; ++k) {
     const int rem = std::min(bw, nb - 1 - k);
+    if (!b->lookahead && b->direct128) {
+      step(s, k, 1, rem);
+      continue;
+    }
+    double* inv = potrf(s, k);
     if (rem > 0) {
       BlockStrides ps;
       ps.on = 1;
@@ -927,12 +1029,6 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
       ts.a = ts.b = ts.ci = (size_t)bw * kDB * kDB;
       ts.cj = (size_t)kDB * kDB;
       double* trail = b->Mb + blk_off(b, k + 1, k + 1);
-      if (!b->lookahead && b->direct128) {
-        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(1024), kG128Lds1, s, panel, kDB, panel, kDB, inv, kDB, ps);
-        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(1024), kG128Lds0, s, trail, kDB, panel, kDB, panel, kDB,
-                           ts);
-        continue;
-      }
       if (!b->lookahead) {
         hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0,
                            0.0, 0, (size_t)0, ps);
@@ -970,7 +1066,8 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
   b->info.last_form_ms = t0;
   b->info.last_chol_ms = t1;
   b->info.regularized_pivots = hinfo[1];
-  if (info) *info = hinfo[0];
+  if (info)  // (first non-positive pivot, 1-based, in the CALLER's row numbering)
+    *info = hinfo[0] > 0 && b->reordered && hinfo[0] <= (int32_t)b->m ? b->rperm_host[hinfo[0] - 1] + 1 : hinfo[0];
   b->factored = hinfo[0] == 0;
   return hinfo[0] == 0 ? FPSQ_OK : 1;  // soft: not positive definite (factorized(str) == false, :242-246)
 }

@@ -1662,12 +1662,14 @@ __global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ L
 template <bool FORWARD>
 __global__ __launch_bounds__(256) void k_trsv_step3(const double* __restrict__ Lm, int ld, const double* __restrict__ inv,
                                                     const double* __restrict__ invT, double* r, double* out, int k,
-                                                    int band_w = 0) {
+                                                    int band_w = 0, int bstride = 1) {
   __shared__ double rk[kDB * 2];
   __shared__ double part[2][kDB * 2];
   __shared__ double yk[kDB * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int blk = FORWARD ? k + (int)blockIdx.x : (band_w > 0 ? k - (int)blockIdx.x : (int)blockIdx.x);
+  // (bstride = 2: the blocks of k's own elimination chain, fpsq_band_create)
+  const int blk = FORWARD ? k + bstride * (int)blockIdx.x
+                          : (band_w > 0 ? k - bstride * (int)blockIdx.x : (int)blockIdx.x);
   const int i = tid & 127, hf = tid >> 7;
   // forward: y_i = sum_{p <= i} X'[p][i] r_p;   backward: q_i = sum_{p >= i} X[p][i] y_p   (p in this thread's half)
   const double* Xc = (FORWARD ? invT : inv) + (size_t)k * kDB * kDB + (size_t)(hf * 64) * kDB + i;

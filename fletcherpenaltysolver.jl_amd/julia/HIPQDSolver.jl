@@ -122,7 +122,7 @@ end
 
 struct FpsqBandInfo
   n::Int64; m::Int64; nnz::Int64; nblocks::Int64; bandwidth_blocks::Int64; factor_bytes::Int64
-  last_form_ms::Float64; last_chol_ms::Float64; last_solve_ms::Float64; regularized_pivots::Int64; reordered::Int64
+  last_form_ms::Float64; last_chol_ms::Float64; last_solve_ms::Float64; regularized_pivots::Int64; reordered::Int64; chains::Int64
 end
 
 mutable struct HIPLDLtSolver{T, S} <: QDSolver

@@ -282,7 +282,9 @@ typedef struct {
   int64_t factor_bytes;      /* storage of the banded factor */
   double last_form_ms, last_chol_ms, last_solve_ms;
   int64_t regularized_pivots;
-  int64_t reordered;         /* 1: the symbolic phase reordered the rows of A (reverse Cuthill-McKee) to narrow the band */
+  int64_t reordered;         /* 1: the symbolic phase reordered the rows of A (reverse Cuthill-McKee and / or the two-ended
+                                order of the two elimination chains) */
+  int64_t chains;            /* 2: the band is eliminated from both ends at once (two streams), 1: one chain */
 } fpsq_band_info;
 int fpsq_band_create(fpsq_band *out, int64_t n, int64_t m, const int32_t *rowptr, const int32_t *colind, int32_t device);
 int fpsq_band_destroy(fpsq_band b);

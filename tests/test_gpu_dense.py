@@ -342,6 +342,52 @@ def test_banded_symbolic_phase_reorders_rows_to_narrow_the_band(oracle, monkeypa
     N.close()
 
 
+@pytest.mark.parametrize("m", [7700, 7680])
+def test_banded_two_elimination_chains(oracle, monkeypatch, m):
+    """A long narrow band is eliminated from BOTH ends at once (blocks ordered alternately from the top and from the
+    bottom, two streams): same answers as the one-chain elimination (FPSQ_BAND_TWOCHAIN=0) to rounding and exact-KKT
+    parity, with rows left over in the middle (m = 7700) and without (m = 60 blocks); regularised pivots are reported in
+    the caller's row numbering."""
+    from fps_amd import problems
+
+    n = 30000
+    qp = problems.pde_control_like(n=n, m=m, per_row=12, window=600, seed=11)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(m)
+    g, c, g2 = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(n)
+    B = _Band(A)
+    i = B.info()
+    assert i["chains"] == 2 and i["reordered"] == 1 and i["bandwidth_blocks"] <= 6
+    assert B.factorize(1e-4) == (0, 0)
+    two = B.solve(B.lib.fpsq_band_solve_two_mixed, g, c)
+    two_ls = B.solve(B.lib.fpsq_band_solve_two_least_squares, g, g2)
+    B.close()
+    monkeypatch.setenv("FPSQ_BAND_TWOCHAIN", "0")
+    N = _Band(A)
+    j = N.info()
+    assert j["chains"] == 1 and j["reordered"] == 0 and j["bandwidth_blocks"] <= 3
+    assert N.factorize(1e-4) == (0, 0)
+    one = N.solve(N.lib.fpsq_band_solve_two_mixed, g, c)
+    one_ls = N.solve(N.lib.fpsq_band_solve_two_least_squares, g, g2)
+    N.close()
+    monkeypatch.delenv("FPSQ_BAND_TWOCHAIN")
+    for a, b in zip(two + two_ls, one + one_ls):
+        assert _rel(a, b) < 1e-11
+    for a, b in zip(two, oracle.exact_two_mixed(A, 1e-4, g, c)):
+        assert _rel(a, b) < 1e-10
+    # a vanishing pivot deep in the bottom chain: reported as the caller's row
+    Ad = A.tolil()
+    Ad[m - 300, :] = 0.0
+    import scipy.sparse as sp
+    Z = _Band(sp.csr_matrix(A))  # same pattern, values with a zero row
+    vals = sp.csr_matrix(A).copy()
+    lo, hi = vals.indptr[m - 300], vals.indptr[m - 299]
+    vals.data[lo:hi] = 0.0
+    rc, info = Z.factorize(0.0, vals.data)
+    assert (rc, info) == (1, m - 300 + 1)
+    Z.close()
+
+
 def test_banded_direct_regularises_rank_deficient_rows(oracle):
     from fps_amd import problems
 
