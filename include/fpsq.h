@@ -263,8 +263,12 @@ int fpsq_dense_get_info(fpsq_dense d, fpsq_dense_info *info);
  *                           (half bandwidth = the largest row distance of two entries of one column).  When the
  *                           natural band is wide (> 1/8 of the matrix) the rows are first reordered by reverse
  *                           Cuthill-McKee on the graph of A A' -- the bandwidth-reducing counterpart of the fill-reducing
- *                           ordering `ldl_analyze` computes -- and the ordering is kept if it narrows the band; the
- *                           permutation is internal (right-hand sides and solutions stay in the caller's row order).
+ *                           ordering `ldl_analyze` computes -- and the ordering is kept if it narrows the band.  A long
+ *                           narrow band is further ordered from BOTH ends towards the middle (blocks alternately from
+ *                           the top and from the bottom), which makes its elimination two independent chains that
+ *                           fpsq_band_factorize and the solves run side by side on two streams.  All permutations are
+ *                           internal (right-hand sides, solutions and reported pivot rows stay in the caller's order).
+ *                           Environment switches for A/B runs: FPSQ_BAND_REORDER, FPSQ_BAND_TWOCHAIN (0 = off).
  *   fpsq_band_factorize   = `jac_coord!` + `sparse(...)` + `ldl_factorize!` (src/solve_linear_system.jl:223-234): forms M
  *                           into 128 x 128 blocks of the band on the device and factors it with a right-looking
  *                           block-banded Cholesky (the dense back-end's MFMA block kernels); returns 1 (soft) with *info
