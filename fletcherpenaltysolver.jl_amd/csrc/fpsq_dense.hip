@@ -22,7 +22,7 @@ struct fpsq_dense_s {
   double* A = nullptr;     // mpad x npad, row-major, zero padded
   double* M = nullptr;     // mpad x mpad: lower triangle holds the Cholesky factor after factorize
   double* invs = nullptr;  // nb inverses of the diagonal 128 x 128 blocks of L
-  double* invsT = nullptr; // ... and their transposes (k_potrf_inv128r / k_trsv_step2)
+  double* invsT = nullptr; // ... and their transposes (k_potrf_inv128p / 128m, k_trsv_step2 / step3)
   int64_t regularized = 0; // pivots replaced by the dynamic regularisation in the last factorisation
   double *r2 = nullptr, *y2 = nullptr, *x2 = nullptr, *part = nullptr;  // [mpad][2], [mpad][2], [npad][2], gemvt partials
   double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
@@ -30,10 +30,9 @@ struct fpsq_dense_s {
   int nchunk = 16;
   int gram_waves = 16;  // waves per 128 x 128 tile of the Gram product (FPSQ_DENSE_GRAM_WAVES=4: k_gemm_nt_f64)
   int direct128 = 1;  // panel / trailing update by k_gemm128_lds (FPSQ_DENSE_GEMM128=0: the staged kernels)
-  int potrf_gen = 5;  // diagonal-block kernel: 5 = generation 4 with its panel updates and doubling inverse on the matrix
-                      // cores (k_potrf_inv128m), 4 = compact 16-column panels (k_potrf_inv128p), 3 = 32-column panels
-                      // (k_potrf_inv128r), 2 = wave-level 64 (k_potrf_inv128w), 1 = unblocked (FPSQ_DENSE_POTRF selects;
-                      // 3 and 4 regularise pivots and feed the coalesced triangular solves)
+  int potrf_gen = 5;  // diagonal-block kernel: 5 = 16-column panels with the panel updates, row substitutions and the doubling
+                      // inverse on the matrix cores (k_potrf_inv128m), 4 = the same in scalar code (k_potrf_inv128p),
+                      // 1 = unblocked in LDS (k_potrf_inv128, round 1); FPSQ_DENSE_POTRF selects
   int gram_kd = 16;        // k-depth of an LDS stage of the Gram product (FPSQ_DENSE_GRAM_KD = 16 | 32; 32 measured
                            // slower, 0.83 against 0.78 ms: the kernel is not waiting for its operand prefetch)
   int splitk = 1;          // k-slices of the Gram-matrix product (balance of the 128 x 128 tiles over the CUs)
@@ -186,14 +185,14 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   // the potrf + inverse kernel keeps a 128 x 129 (+ 128) fp64 block in dynamic LDS
   hipFuncSetAttribute((const void*)k_potrf_inv128, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (kDB * (kDB + 1) + kDB) * 8);
-  hipFuncSetAttribute((const void*)k_potrf_inv128w, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (kDB * (kDB + 1) + kDB) * 8);
-  hipFuncSetAttribute((const void*)k_potrf_inv128r, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5);
   hipFuncSetAttribute((const void*)k_gemm128_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds0);
   hipFuncSetAttribute((const void*)k_gemm128_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds1);
-  if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) d->potrf_gen = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) {
+    const int gen = std::atoi(ev);
+    d->potrf_gen = gen >= 5 ? 5 : gen >= 2 ? 4 : 1;  // (generations 2 and 3 are no longer in the source)
+  }
   if (const char* ev = std::getenv("FPSQ_DENSE_GEMM128")) d->direct128 = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_WAVES")) d->gram_waves = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_KD")) d->gram_kd = std::atoi(ev);
@@ -299,14 +298,8 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
     else if (d->potrf_gen == 4)
       hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, ld, inv,
                          d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
-    else if (d->potrf_gen == 3)
-      hipLaunchKernelGGL(k_potrf_inv128r, dim3(1), dim3(256), kPotrfLds, s, Mkk, ld, inv,
-                         d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
-    else if (d->potrf_gen == 1)
-      hipLaunchKernelGGL(k_potrf_inv128, dim3(1), dim3(kPotrfThreads), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
-                         d->info_dev);
     else
-      hipLaunchKernelGGL(k_potrf_inv128w, dim3(1), dim3(256), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
+      hipLaunchKernelGGL(k_potrf_inv128, dim3(1), dim3(kPotrfThreads), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
                          d->info_dev);
     const int rem = nb - k - 1;
     if (rem > 0) {

@@ -15,7 +15,7 @@ constexpr int kDB = 128;      // block size of the Cholesky / GEMM tiles
 constexpr int kDK = 16;       // k-depth of one LDS stage
 constexpr int kGemmLds16 = 4 * 16 * 144 * 8;  // dynamic LDS of k_gemm_nt_f64<., 16> / <., 32>
 constexpr int kGemmLds32 = 4 * 32 * 144 * 8;
-constexpr int kPotrfLds = (kDB * (kDB + 1) + 3 * 32 * 33 + kDB) * 8;  // k_potrf_inv128r / 128p: block + scratch + 1/diag
+constexpr int kPotrfLds = (kDB * (kDB + 1) + 3 * 32 * 33 + kDB) * 8;  // k_potrf_inv128p: block + scratch + 1/diag
 constexpr int kDLd = 144;     // LDS leading dimension (doubles) of a [k][row] tile: 128 + 16 so that the four k-planes a
                               // wave reads with one ds_read_b64 fall in disjoint bank halves
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -554,337 +554,18 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv128(double* Mkk, int
   }
 }
 
-// ---- the same diagonal-block job, second generation: 64 x 64 sub-blocks factored and inverted by ONE WAVE with the
-// rows in registers (lane i = row i; broadcasts are v_readlane, no LDS traffic and no workgroup barrier in the 64
-// column steps), glued by 4 x 4 register-tiled 64^3 products on the LDS copy:
-//   A = [A11 0; A21 A22]:  L11 = chol(A11), X11 = L11^-1, L21 = A21 X11', A22 -= L21 L21', L22 = chol(A22), X22 = L22^-1,
-//   X21 = -X22 (L21 X11).
-// The unblocked kernel above costs ~1.07 us per column step (three 16-wave barriers each): 274 us per block.
+// ---- generations 2 and 3 of the diagonal-block job are gone from the source (git history, round 2): 64 x 64 and 32 x 32
+// sub-blocks factored and inverted by ONE wave with the rows in registers (v_readlane broadcasts), glued by register-tiled
+// products on the LDS copy.  Both ran at ~220 us per block whatever their arithmetic -- thousands of straight-line
+// instructions executed once per call.  (The unblocked kernel above: three 16-wave barriers per column, 274 us.)
 __device__ __forceinline__ double rdlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
 
-// Cholesky of the 64 x 64 block at (o, o) of the LDS matrix, by the calling wave; the factor replaces the block's lower
-// triangle in LDS.  a[] (the lane's row of the factor) stays live for the caller.
-__device__ __forceinline__ void wave_potrf64(double* L, int LD, int o, int row0, int* info, double* a) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < 64; ++c) a[c] = L[(o + lane) * LD + o + c];
-#pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const double d = rdlane(a[j], j);
-    const bool bad = !(d > 0.0);
-    if (bad && lane == 0) atomicCAS(info, 0, row0 + o + j + 1);
-    const double piv = bad ? 1.0 : sqrt(d);  // a unit pivot keeps the kernel finite; the caller reports `info`
-    const double rp = 1.0 / piv;              // (uniform: one division per column, not one per row)
-    const double l = lane > j ? a[j] * rp : (lane == j ? piv : 0.0);
-    a[j] = l;
-#pragma unroll
-    for (int c = j + 1; c < 64; ++c) a[c] -= l * rdlane(l, c);  // (meaningful for lanes >= c; the rest is never read)
-  }
-#pragma unroll
-  for (int c = 0; c < 64; ++c) L[(o + lane) * LD + o + c] = c <= lane ? a[c] : 0.0;
-}
-
-// X = L^-1 for the 64 x 64 lower-triangular block whose rows are in a[] (wave_potrf64); X replaces the block in LDS.
-// acc_i = e_i - sum_{k<i} L[i][k] X[k][.] is built by sweeping k; row k of X = acc_k / L[k][k] is broadcast on the fly.
-__device__ __forceinline__ void wave_trtri64(double* L, int LD, int o, const double* a) {
-  const int lane = threadIdx.x & 63;
-  double acc[64];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) acc[c] = c == lane ? 1.0 : 0.0;
-  double dsel = 1.0;  // this lane's diagonal entry (a[lane]), selected without dynamic register indexing
-#pragma unroll
-  for (int c = 0; c < 64; ++c) dsel = c == lane ? a[c] : dsel;
-  const double dinv = 1.0 / dsel;
-#pragma unroll
-  for (int k = 0; k < 63; ++k) {
-    const double dk = rdlane(dinv, k);
-    const double lik = lane > k ? a[k] : 0.0;
-#pragma unroll
-    for (int c = 0; c <= k; ++c) acc[c] -= lik * (rdlane(acc[c], k) * dk);
-  }
-#pragma unroll
-  for (int c = 0; c < 64; ++c) L[(o + lane) * LD + o + c] = c <= lane ? acc[c] * dinv : 0.0;
-}
-
-// C (64 x 64 at LDS (cr, cc)) = alpha * A B^T or alpha * A B (+ C) with A at (ar, ac), B at (br, bc); 256 threads, 4 x 4
-// outputs each.  TB: 0 -> sum_k A[i][k] B[j][k], 1 -> sum_k A[i][k] B[k][j].  The result is RETURNED in registers: the caller
-// synchronises before storing (outputs may overlay inputs).
-template <int TB>
-__device__ __forceinline__ void tile64(const double* L, int LD, int ar, int ac, int br, int bc, double out[4][4]) {
-  const int ti = (threadIdx.x >> 4) * 4, tj = (threadIdx.x & 15) * 4;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) out[r][c] = 0.0;
-  for (int k = 0; k < 64; ++k) {
-    double av[4], bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) av[r] = L[(ar + ti + r) * LD + ac + k];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) bv[c] = TB == 0 ? L[(br + tj + c) * LD + bc + k] : L[(br + k) * LD + bc + tj + c];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) out[r][c] += av[r] * bv[c];
-  }
-}
-
-__global__ __launch_bounds__(256) void k_potrf_inv128w(double* Mkk, int ld, double* inv, int row0, int* info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* L = sm;
-  constexpr int LD = kDB + 1;
-  const int tid = threadIdx.x, wave = tid >> 6;
-  const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    L[r * LD + c] = (c <= r) ? Mkk[(size_t)r * ld + c] : 0.0;
-  }
-  __syncthreads();
-  double t[4][4];
-  // L11, then X11 in its place (L11 goes to global first)
-  if (wave == 0) {
-    double a[64];
-    wave_potrf64(L, LD, 0, row0, info, a);
-    const int lane = tid;
-    for (int c = 0; c <= lane; ++c) Mkk[(size_t)lane * ld + c] = L[lane * LD + c];
-    wave_trtri64(L, LD, 0, a);
-  }
-  __syncthreads();
-  // L21 = A21 X11'   (X11 lower: terms with k > column vanish because X11's upper part is stored as zeros)
-  tile64<0>(L, LD, 64, 0, 0, 0, t);
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      L[(64 + ti + r) * LD + tj + c] = t[r][c];
-      Mkk[(size_t)(64 + ti + r) * ld + tj + c] = t[r][c];
-    }
-  __syncthreads();
-  // A22 -= L21 L21'
-  tile64<0>(L, LD, 64, 0, 64, 0, t);
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L[(64 + ti + r) * LD + 64 + tj + c] -= t[r][c];
-  __syncthreads();
-  // L22, X22
-  if (wave == 0) {
-    double a[64];
-    wave_potrf64(L, LD, 64, row0, info, a);
-    const int lane = tid;
-    for (int c = 0; c <= lane; ++c) Mkk[(size_t)(64 + lane) * ld + 64 + c] = L[(64 + lane) * LD + 64 + c];
-    wave_trtri64(L, LD, 64, a);
-  }
-  __syncthreads();
-  // X21 = -X22 (L21 X11)
-  tile64<1>(L, LD, 64, 0, 0, 0, t);   // T = L21 X11
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L[(64 + ti + r) * LD + tj + c] = t[r][c];
-  __syncthreads();
-  tile64<1>(L, LD, 64, 64, 64, 0, t);  // X22 T
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L[(64 + ti + r) * LD + tj + c] = -t[r][c];
-  __syncthreads();
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    inv[(size_t)r * kDB + c] = (c <= r) ? L[r * LD + c] : 0.0;
-  }
-}
-
-// ---- third generation of the diagonal-block job: left-looking over 32-column panels inside the 128 x 128 block.
-// Per panel: (a) all 256 threads apply the previous panels to it (4 x 4 register tiles on the LDS copy), (b) ONE wave
-// factors the 32 x 32 diagonal block with its rows in registers (v_readlane broadcasts: the only serial part, ~1/4 of the
-// 64-wide routine's dependent chain per call), (c) one thread per row below solves its 32 entries by forward
-// substitution against the (broadcast-read) diagonal block.  The inverse X = L^-1 -- the panel of the outer
-// factorisation and the triangular solves apply diagonal blocks through it -- is then built blockwise in the UPPER
-// triangle of the same LDS matrix (X' there, its diagonal kept implicitly as 1 / L_ii): the four diagonal 32 x 32
-// inverses column by column (128 threads, substitution in registers), the off-diagonal blocks level by level,
-// X_ij = -X_ii (sum_k L_ik X_kj).
-// PIVOTS: `reg` > 0 switches on the dynamic regularisation of LDLFactorizations.jl as the reference configures it
-// (src/solve_two_systems_struct.jl:345-348: tol = r1 = sqrt(eps), r2 = -sqrt(eps)): a pivot of M = A A' + delta I that
-// does not exceed `tol` -- minus that pivot is the pivot of the (2,2) block of K = [I A'; A -delta I] once the identity
-// block has been eliminated -- is replaced by `reg` (= -r2) and counted in info[1]; with reg <= 0 a non-positive pivot is
-// reported in info[0] (first offending row, 1-based) like before.
-__device__ __forceinline__ void wave_potrf32(double* L, int LD, int o, int row0, int* info, double tol, double reg,
-                                             double* dinv) {
-  const int lane = threadIdx.x & 63;
-  const int rl = lane & 31;  // (lanes 32..63 mirror 0..31: their results are never stored)
-  double a[32];
-#pragma unroll
-  for (int c = 0; c < 32; ++c) a[c] = L[(o + rl) * LD + o + c];
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    double d = rdlane(a[j], j);
-    if (reg > 0.0) {
-      if (!(d > tol)) {
-        d = reg;
-        if (lane == 0) atomicAdd(info + 1, 1);
-      }
-    } else if (!(d > 0.0)) {
-      if (lane == 0) atomicCAS(info, 0, row0 + o + j + 1);
-      d = 1.0;  // a unit pivot keeps the kernel finite; the caller reports `info`
-    }
-    const double piv = sqrt(d);
-    const double rp = 1.0 / piv;
-    if (lane == j) dinv[o + j] = rp;  // reciprocals of the diagonal, for the substitutions and the inverse
-    const double l = rl > j ? a[j] * rp : (rl == j ? piv : 0.0);
-    a[j] = l;
-#pragma unroll
-    for (int c = j + 1; c < 32; ++c) a[c] -= l * rdlane(l, c);
-  }
-  if (lane < 32) {
-#pragma unroll
-    for (int c = 0; c < 32; ++c)
-      if (c <= lane) L[(o + lane) * LD + o + c] = a[c];
-  }
-}
-
-__global__ __launch_bounds__(256) void k_potrf_inv128r(double* Mkk, int ld, double* inv, double* invT, int row0,
-                                                       int* info, double tol, double reg) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* L = sm;
-  constexpr int LD = kDB + 1;
-  double* T = sm + kDB * LD;  // 3 scratch blocks of 32 x 33
-  constexpr int TLD = 33;
-  double* dinv = T + 3 * 32 * TLD;  // 128 reciprocals of the diagonal of L
-  const int tid = threadIdx.x, wave = tid >> 6;
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    L[r * LD + c] = (c <= r) ? Mkk[(size_t)r * ld + c] : 0.0;
-  }
-  __syncthreads();
-  const int tr = tid >> 3, tc = (tid & 7) * 4;  // 32 x 8 thread grid: rows tr + 32 i, columns tc .. tc + 3 of a panel
-  for (int kb = 0; kb < 4; ++kb) {
-    const int c0 = kb * 32;
-    if (kb > 0) {  // (a) A[c0:, c0:c0+32] -= L[c0:, 0:c0] L[c0:c0+32, 0:c0]'
-      double acc[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-      for (int p = 0; p < c0; ++p) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = c0 + tr + 32 * i;
-          av[i] = r < kDB ? L[r * LD + p] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = L[(c0 + tc + j) * LD + p];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = c0 + tr + 32 * i;
-        if (r < kDB) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (c0 + tc + j <= r) L[r * LD + c0 + tc + j] -= acc[i][j];
-        }
-      }
-      __syncthreads();
-    }
-    if (wave == 0) wave_potrf32(L, LD, c0, row0, info, tol, reg, dinv);  // (b)
-    __syncthreads();
-    {  // (c) rows below the diagonal block: x L_kk' = a, one thread per row
-      const int r = c0 + 32 + tid;
-      if (r < kDB) {
-        double x[32];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) x[c] = L[r * LD + c0 + c];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          double s = x[c];
-#pragma unroll
-          for (int p = 0; p < c; ++p) s -= x[p] * L[(c0 + c) * LD + c0 + p];
-          x[c] = s * dinv[c0 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 32; ++c) L[r * LD + c0 + c] = x[c];
-      }
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    if (c <= r) Mkk[(size_t)r * ld + c] = L[r * LD + c];
-  }
-  // ---- X = L^-1 into the upper triangle (X(r, c), r > c, at L[c * LD + r])
-  if (tid < kDB) {  // diagonal blocks: column c of block b by substitution, L_bb x = e_c
-    const int b0 = (tid >> 5) * 32, c = tid & 31;
-    double x[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      double s = r == c ? 1.0 : 0.0;
-#pragma unroll
-      for (int p = 0; p < r; ++p) s -= L[(b0 + r) * LD + b0 + p] * x[p];  // (x[p] = 0 for p < c)
-      x[r] = r >= c ? s * dinv[b0 + r] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < 32; ++r)
-      if (r > c) L[(b0 + c) * LD + b0 + r] = x[r];
-  }
-  __syncthreads();
-  auto Xe = [&](int r, int c) -> double {  // X(r, c) for r >= c
-    return r == c ? dinv[r] : L[c * LD + r];
-  };
-  for (int dlev = 1; dlev < 4; ++dlev) {
-    const int nblk = 4 - dlev;  // blocks (i, i - dlev)
-    // T_b = sum_{k = j}^{i - 1} L_ik X_kj
-    for (int b = 0; b < nblk; ++b) {
-      const int i0 = (b + dlev) * 32, j0 = b * 32;
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      const int r = tr;  // 32 rows x 8 column groups of 4: one 32 x 32 block per pass
-      for (int k = j0; k < i0; ++k) {
-        const double lv = L[(i0 + r) * LD + k];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = j0 + tc + j;
-          acc[j] += k >= c ? lv * Xe(k, c) : 0.0;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) T[b * 32 * TLD + r * TLD + tc + j] = acc[j];
-    }
-    __syncthreads();
-    // X_ij = -X_ii T_b
-    for (int b = 0; b < nblk; ++b) {
-      const int i0 = (b + dlev) * 32, j0 = b * 32;
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      const int r = tr;
-      for (int k = 0; k <= r; ++k) {
-        const double xv = Xe(i0 + r, i0 + k);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += xv * T[b * 32 * TLD + k * TLD + tc + j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) L[(j0 + tc + j) * LD + i0 + r] = -acc[j];
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    inv[(size_t)r * kDB + c] = c < r ? L[c * LD + r] : (c == r ? dinv[r] : 0.0);
-    invT[(size_t)r * kDB + c] = c > r ? L[r * LD + c] : (c == r ? dinv[r] : 0.0);  // X' (upper), for coalesced X r products
-  }
-}
-
-// ---- fourth generation (the default): the same left-looking scheme over 16-column panels with COMPACT code.
-// The 64- and 32-wide register routines above are thousands of straight-line instructions executed once per call: the
+// ---- fourth generation: a left-looking scheme over 16-column panels with COMPACT code.
+// The 64- and 32-wide register routines of generations 2 and 3 were thousands of straight-line instructions executed once per call: the
 // wave spends its time waiting for instruction fetches (both run at ~220 us per block whatever their arithmetic).  Here
 // the only unrolled part is a 16 x 16 factor routine (~500 instructions) that is the body of a ROLLED loop over the eight
 // panels, so it is fetched once and reused; everything else is rolled / lightly unrolled loops over the LDS copy whose
