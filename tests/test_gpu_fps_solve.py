@@ -141,3 +141,25 @@ def test_fps_solve_device_resident_qp_reaches_the_kkt_point(sub):
     assert np.linalg.norm(stats.multipliers.cpu().numpy() - lam) <= 1e-4 * max(1.0, np.linalg.norm(lam))
     assert abs(stats.objective - (0.5 * xstar @ (qp.qdiag * xstar) + qp.d @ xstar)) <= 1e-6 * max(1.0, abs(stats.objective))
     dev.close()
+
+
+@pytest.mark.parametrize("sub,ha", [("trunk", 2), ("lbfgs", 2)])
+def test_fps_solve_through_the_banded_direct_backend(sub, ha):
+    """fps_solve with qds_solver = "hip_ldlt" (the reference's DEFAULT is its LDLt back-end, parameters.jl:290): the outer loop
+    on a host eq-QP model, every pair of systems through fpsq_band_* (sparse block-banded factorisation on the MI355X),
+    must reach the solution of the QP's KKT system at the reference's sqrt(eps) tolerances."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    from fps_amd import problems
+
+    qp = problems.pde_control_like(n=4000, m=400, per_row=16, window=512, seed=21)
+    A = qp.scipy_csr()
+    K = sp.bmat([[sp.diags(qp.qdiag), A.T], [A, None]], format="csc")
+    sol = spla.spsolve(K, np.concatenate([-qp.d, qp.b]))
+    xstar, lam = sol[:qp.n], sol[qp.n:]
+    model = nlpmodels.EqQPModel(qp)
+    stats = fps_solve(model, qp.x, qds_solver="hip_ldlt", subproblem_solver=sub, hessian_approx=ha, max_time=120)
+    assert stats.status == "first_order", (stats.status, stats.solver_specific)
+    assert np.linalg.norm(stats.solution - xstar) <= 1e-6 * np.linalg.norm(xstar)
+    assert np.linalg.norm(stats.multipliers - lam) <= 1e-5 * max(1.0, np.linalg.norm(lam))
