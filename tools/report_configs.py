@@ -85,6 +85,44 @@ for delta in (0.0, SE):
     rows.append((f"cfg5 PDE-control-like n={qh.n} m={qh.m} nnz={qh.nnz}", f"LSQR+CRAIG fused, delta={delta:.3g}", f"{1 / dt:.0f} evals/s ({dt * 1e3:.3f} ms)",
                  f"iterations {its}, rc {rc}"))
 
+# the sparse direct (block-banded) back-end on the banded configurations: numeric factorisation + two-system solve
+import ctypes as C
+from fps_amd import _lib  # noqa: E402
+
+
+def band_row(label, q, delta):
+    lib = _lib.load()
+    A = q.scipy_csr()
+    A.sort_indices()
+    b = C.c_void_p()
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    if lib.fpsq_band_create(C.byref(b), q.n, q.m, rp.ctypes.data, ci.ctypes.data, 0) != 0:
+        rows.append((label, "sparse direct (fpsq_band_*)", "not applicable", lib.fpsq_band_last_error(None).decode()))
+        return
+    vals = np.ascontiguousarray(A.data)
+    g, c = q.qdiag * q.x + q.d, A @ q.x - q.b
+    outs = [np.empty(q.n), np.empty(q.m), np.empty(q.n), np.empty(q.m)]
+    info = C.c_int32()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = lib.fpsq_band_factorize(b, vals.ctypes.data, delta, C.byref(info))
+        t1 = time.perf_counter()
+        lib.fpsq_band_solve_two_mixed(b, g.ctypes.data, c.ctypes.data, *[o.ctypes.data for o in outs])
+        t2 = time.perf_counter()
+    bi = _lib.BandInfo()
+    lib.fpsq_band_get_info(b, C.byref(bi))
+    p1, q1, p2, q2 = outs
+    res = max(np.linalg.norm(A @ p1 - delta * q1) / max(np.linalg.norm(g), 1e-300),
+              np.linalg.norm(A @ p2 - delta * q2 - c) / max(np.linalg.norm(c), 1e-300))
+    rows.append((label, f"sparse direct (fpsq_band_*), delta={delta:.3g}",
+                 f"factorise {(t1 - t0) * 1e3:.2f} ms + solve {(t2 - t1) * 1e3:.2f} ms = {1 / (t2 - t0):.1f} evals/s",
+                 f"rc {rc}, {bi.nblocks} blocks, half bandwidth {bi.bandwidth_blocks}, {bi.chains} chain(s), KKT residual {res:.1e}"))
+    lib.fpsq_band_destroy(b)
+
+
+band_row(f"cfg4 AUG2DC-like n={qa.n} m={qa.m} nnz={qa.nnz}", qa, SE)
+band_row(f"cfg5 PDE-control-like n={qh.n} m={qh.m} nnz={qh.nnz}", qh, 0.0)
+
 # B3 of BASELINE.md: the direct path's CPU stand-in -- scipy.sparse.linalg.splu (SuperLU, NOT LDL') on K = [I A'; A -delta I]
 # with two right-hand sides, for configs 1, 2 and 4; each in a child process with a 60 s cap (cfg2's K fills in heavily)
 import multiprocessing as mp
