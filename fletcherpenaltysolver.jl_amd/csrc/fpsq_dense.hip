@@ -201,10 +201,9 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   {
-    // k-slices of the Gram product (FPSQ_DENSE_SPLITK, default 1 = off).  Measured at n = 4096, m = 2048 on the MI355X:
-    // 0.76 / 0.94 / 1.09 / 1.18 ms for 1 / 8 / 12 / 15 slices -- the product kernel itself takes the same ~0.77 ms however
-    // its 136 tiles are cut (it is bound by its operand staging, not by the 136-of-256 CU occupancy), and the reduction of
-    // the planes comes on top.
+    // k-slices of the Gram product (FPSQ_DENSE_SPLITK, default 1 = off).  Measured at n = 4096, m = 2048 on the MI355X with
+    // the sixteen-wave kernel: 0.56 / 0.60 / 0.64 ms for 1 / 2 / 4 slices (four-wave kernel: 0.76 / 0.94 / 1.09 / 1.18 ms
+    // for 1 / 8 / 12 / 15) -- cutting the 136 tiles finer does not help, and the reduction of the planes comes on top.
     int64_t S = 1;
     if (const char* ev = std::getenv("FPSQ_DENSE_SPLITK")) S = std::max(1, std::atoi(ev));
     d->splitk = (int)S;
