@@ -396,9 +396,12 @@ def feasibility_step(nlp, x, cx, rho, ctol, *, eta1=1e-3, eta2=0.66, sigma1=0.25
     return z, bool(normcz <= rho)
 
 
-def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0, verbose=0, qds=None, **kwargs):
+def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0, verbose=0, qds=None, callback=None,
+              **kwargs):
     """stats = fps_solve(nlp, x0; kwargs...)   (src/FletcherPenaltySolver.jl:127-186 -> src/algo.jl:26-288).
-    Keyword arguments are the fields of `AlgoData`; `qds` overrides the back-end instance."""
+    Keyword arguments are the fields of `AlgoData`; `qds` overrides the back-end instance.  `callback(nlp, pen, stats)` is
+    called before the first and after every outer iteration (algo.jl:109, :283) with the running statistics (solution,
+    objective, residuals, multipliers, iter); setting `stats.status = "user"` stops the loop."""
     meta = AlgoData(**{k: v for k, v in kwargs.items() if k in AlgoData.__dataclass_fields__})
     x = np.array(nlp.meta.x0 if x0 is None else x0, float)
     if getattr(nlp.meta, "ncon", 0) == 0:
@@ -424,14 +427,14 @@ def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0,
     qds = qds if qds is not None else qdsolver_correspondence[meta.qds_solver](nlp, 0.0)
     fp = FletcherPenaltyNLP(nlp, sigma=meta.sigma_0, rho=meta.rho_0, delta=0.0, hessian_approx=meta.hessian_approx,
                             x0=x, qds=qds)                                                     # algo.jl:45-52
-    stats = _outer_loop(_HostPenalty(fp, nlp), x, meta, atol, rtol, max_iter, max_time, verbose)
+    stats = _outer_loop(_HostPenalty(fp, nlp), x, meta, atol, rtol, max_iter, max_time, verbose, callback)
     if nlp is not orig:                                                          # :153-170: back to the user's variables
         stats.solver_specific["slack"] = stats.solution[orig.meta.nvar:].copy()
         stats.solution = stats.solution[: orig.meta.nvar].copy()
     return stats
 
 
-def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
+def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose, callback=None):
     """src/algo.jl:26-288 on a penalty model `pen` (host mirror or device-resident); x: numpy array or torch tensor."""
     bounds = getattr(pen, "bounds", None)
     sub = _plbfgs if bounds is not None else _SUBSOLVERS[meta.subproblem_solver]
@@ -458,6 +461,10 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
     it = 0
     if max(p0, d0) <= tol:
         status = "first_order"
+    if callback is not None:                      # algo.jl:109
+        callback(getattr(pen, "nlp", None), pen, stats)
+        if stats.status == "user":
+            status = "user"
     while status == "unknown":
         it += 1
         x_prev = x
@@ -553,6 +560,13 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose):
         if verbose:
             print(f"fps_solve it {it:3d} sub={sub_status:9s} f={fx_user: .6e} |c|={ncx:.2e} sigma={pen.sigma:.1e} "
                   f"rho={pen.rho:.1e} delta={pen.delta:.1e}")
+        if callback is not None:                  # algo.jl:283 (end of the main loop; `:user` ends it, :111)
+            stats.iter = it
+            if stats.solution is None or sub_status != "optimal":
+                stats.solution = _copy(x)
+            callback(getattr(pen, "nlp", None), pen, stats)
+            if stats.status == "user":
+                status = "user"
     stats.status = status
     stats.iter = it
     stats.elapsed_time = time.perf_counter() - t_start

@@ -178,3 +178,31 @@ def test_slack_model_and_bound_only_problems():
     st = fps_solve(box)
     assert st.status == "first_order"
     np.testing.assert_allclose(st.solution, [1.0, 2.0, 3.0], atol=1e-7)
+
+
+def test_callback_and_restart_like_the_reference(oracle):
+    """test/runtests.jl:11-34: a callback that records the iterates and stops the solve with `:user` (sigma_0 = 1,
+    rho_0 = 0 on HS26; the reference stops at its 4th outer iteration -- with this mirror's sub-problem solver the problem
+    is solved in fewer, so the stop is asked for after the first).  test/restart.jl: the feasibility problem mgh01feas (constant objective,
+    -x1 = -1 and 10 (x2 - x1^2) = 0) from its x0 and again from x0 = (10, 10) at 1e-10."""
+    nlp = nlpmodels.reference_test_problems()["hs26"]
+    seen = []
+
+    def cb(model, solver, stats):
+        seen.append(np.array(stats.solution, float))
+        if stats.iter == 1:
+            stats.status = "user"
+
+    st = fps_solve(nlp, qds=OracleQDSolver(nlp, 0.0), sigma_0=1.0, rho_0=0.0, callback=cb)
+    assert st.status == "user" and st.iter == 1 and len(seen) == 2
+    np.testing.assert_allclose(seen[0], nlp.meta.x0)
+    free = fps_solve(nlp, qds=OracleQDSolver(nlp, 0.0), sigma_0=1.0, rho_0=0.0)
+    assert free.status == "first_order" and free.iter >= 1
+    mgh = nlpmodels.ADModel(lambda x: 0.0 * x[0], [-1.2, 1.0], lambda x: [-x[0], 10 * (x[1] - x[0] ** 2)], [-1.0, 0.0],
+                            name="mgh01feas", lin=(0,))
+    st = fps_solve(mgh, qds=OracleQDSolver(mgh, 0.0))
+    assert st.status == "first_order"
+    np.testing.assert_allclose(st.solution, [1.0, 1.0], atol=1e-6)
+    st = fps_solve(mgh, np.array([10.0, 10.0]), qds=OracleQDSolver(mgh, 0.0), atol=1e-10, rtol=1e-10)
+    assert st.status == "first_order"
+    np.testing.assert_allclose(st.solution, [1.0, 1.0], atol=1e-6)
