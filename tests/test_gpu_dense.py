@@ -430,3 +430,25 @@ def test_banded_qdsolver_through_the_seam(oracle):
     assert _rel(fp.hprod(qp.x, v), oracle.exact_qp_hprod(qp, v, 1e3, 1.0, 1e-6)) < 1e-9
     assert qds.info()["bandwidth_blocks"] >= 0
     qds.close()
+
+
+def test_config4_aug2dc_like_through_the_banded_direct_backend(oracle):
+    """BASELINE configs[3] (AUG2DC-like grid incidence Jacobian, n = 20200, m = 10000; CUTEst itself is not available):
+    the iterative path stops UNSOLVED on ln_conlim here (tests/test_gpu_parity.py) -- the sparse direct back-end (the
+    reference's default for such a problem) solves both systems to the exact-KKT answer: 79 blocks, a band of two
+    blocks, two elimination chains."""
+    from fps_amd import problems
+
+    se = float(np.sqrt(np.finfo(float).eps))
+    qp = problems.aug2dc_like(N=100)
+    A = qp.scipy_csr()
+    g = qp.qdiag * qp.x + qp.d
+    c = A @ qp.x - qp.b
+    B = _Band(A)
+    i = B.info()
+    assert i["nblocks"] == 79 and i["bandwidth_blocks"] <= 3 and i["chains"] == 2
+    assert B.factorize(se) == (0, 0)
+    got = B.solve(B.lib.fpsq_band_solve_two_mixed, g, c)
+    for a, b in zip(got, oracle.exact_two_mixed(A, se, g, c)):
+        assert _rel(a, b) < 1e-9
+    B.close()
