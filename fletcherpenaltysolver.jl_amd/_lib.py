@@ -106,6 +106,7 @@ SYMBOLS = [
     ("fpsq_dense_get_factor", C.c_int, [_VP, _DP]),
     ("fpsq_dense_get_info", C.c_int, [_VP, C.POINTER(DenseInfo)]),
     ("fpsq_band_create", C.c_int, [C.POINTER(_VP), _I64, _I64, _DP, _DP, _I32]),
+    ("fpsq_band_analyze", C.c_int, [_I64, _I64, _DP, _DP, _DP, C.POINTER(BandInfo)]),
     ("fpsq_band_destroy", C.c_int, [_VP]),
     ("fpsq_band_last_error", C.c_char_p, [_VP]),
     ("fpsq_band_set_regularization", C.c_int, [_VP, _D, _D]),

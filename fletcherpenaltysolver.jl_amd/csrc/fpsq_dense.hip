@@ -554,6 +554,100 @@ std::vector<int32_t> rcm_rows(int64_t m, int64_t n, const std::vector<int32_t>& 
   return order;
 }
 
+// The ordering part of the symbolic phase, host only (also behind fpsq_band_analyze, which needs no device): validates
+// the pattern, reorders the rows when that pays (rp / ci are replaced by the reordered structure; rperm_h / vperm_h map
+// stored rows / entries to the caller's, empty = identity) and decides on the two elimination chains.  Returns an error
+// text, empty on success.
+std::string band_order(int64_t n, int64_t m, std::vector<int32_t>& rp, std::vector<int32_t>& ci, std::vector<int32_t>& rperm_h,
+                       std::vector<int32_t>& vperm_h, int& chain_safe, int& chain_bw) {
+  const int64_t nnz = rp[m];
+  chain_safe = chain_bw = 0;
+  // validate, then the natural half bandwidth (rows): if the band is wide, try a reverse Cuthill-McKee ordering of the rows
+  // (LDLFactorizations' ldl_analyze computes a fill-reducing ordering at this point; for a band factorisation the
+  // ordering to look for is the bandwidth-reducing one).  FPSQ_BAND_REORDER = 0 never, 1 always tries.
+  for (int64_t i = 0; i < m; ++i) {
+    if (rp[i + 1] < rp[i] || rp[i + 1] > nnz) {
+      return "fpsq_band_create: rowptr not monotone";
+    }
+    for (int32_t k = rp[i]; k < rp[i + 1]; ++k)
+      if (ci[k] < 0 || ci[k] >= n) {
+        return "fpsq_band_create: column index out of range";
+      }
+  }
+  {
+    auto bandwidth_rows = [&](const std::vector<int32_t>& pos) {  // pos[row] = position; empty = identity
+      std::vector<int32_t> lo(n, INT32_MAX), hi(n, -1);
+      for (int64_t i = 0; i < m; ++i) {
+        const int32_t p = pos.empty() ? (int32_t)i : pos[i];
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+          lo[ci[k]] = std::min(lo[ci[k]], p);
+          hi[ci[k]] = std::max(hi[ci[k]], p);
+        }
+      }
+      int64_t w = 0;
+      for (int64_t c = 0; c < n; ++c)
+        if (hi[c] >= 0) w = std::max<int64_t>(w, hi[c] - lo[c]);
+      return w;
+    };
+    // row `ord[p]` of the current structure becomes row p; the maps to the caller's numbering are composed
+    auto apply_order = [&](const std::vector<int32_t>& ord) {
+      std::vector<int32_t> rp2(m + 1, 0), ci2(std::max<int64_t>(nnz, 1)), vp2(std::max<int64_t>(nnz, 1)), rr2(m);
+      for (int64_t p = 0; p < m; ++p) {
+        const int32_t r = ord[p];
+        rr2[p] = rperm_h.empty() ? r : rperm_h[r];
+        rp2[p + 1] = rp2[p] + (rp[r + 1] - rp[r]);
+        for (int32_t k = rp[r], t = rp2[p]; k < rp[r + 1]; ++k, ++t) {
+          ci2[t] = ci[k];
+          vp2[t] = vperm_h.empty() ? k : vperm_h[k];
+        }
+      }
+      rp.swap(rp2);
+      ci.swap(ci2);
+      rperm_h.swap(rr2);
+      vperm_h.swap(vp2);
+    };
+    int mode = -1;  // auto
+    if (const char* ev = std::getenv("FPSQ_BAND_REORDER")) mode = std::atoi(ev);
+    const int64_t nbk = (m + kDB - 1) / kDB;
+    int64_t bw_rows = bandwidth_rows({});
+    if (mode != 0 && (mode == 1 || bw_rows / kDB > std::max<int64_t>(nbk / 8, 2))) {
+      std::vector<int32_t> ord = rcm_rows(m, n, rp, ci);
+      if (!ord.empty()) {
+        std::vector<int32_t> pos(m);
+        for (int64_t p = 0; p < m; ++p) pos[ord[p]] = (int32_t)p;
+        const int64_t bw_new = bandwidth_rows(pos);
+        if (bw_new / kDB < bw_rows / kDB) {  // fewer blocks in the band: take it
+          apply_order(ord);
+          bw_rows = bw_new;
+        }
+      }
+    }
+    // TWO ELIMINATION CHAINS.  A banded Cholesky is a chain of m / 128 dependent block steps, each a few latency-bound
+    // launches.  Ordering the blocks from BOTH ends towards the middle -- stored block 2 c = block c from the top, stored
+    // block 2 c + 1 = the c-th block of 128 rows from the bottom (rows descending) -- keeps the matrix banded (twice as
+    // wide) and makes the even and the odd blocks two independent chains until they meet: their steps run side by side
+    // on two streams, the chain is half as long.  Only the last 2 (chain_bw + 1) blocks and the rows left in the middle
+    // are eliminated one after the other.  FPSQ_BAND_TWOCHAIN=0 turns it off.
+    int two = 1;
+    if (const char* ev = std::getenv("FPSQ_BAND_TWOCHAIN")) two = std::atoi(ev);
+    const int64_t C = m / (2 * kDB);
+    const int64_t bwc = (bw_rows + kDB - 1) / kDB;  // block distance two coupled rows of one chain can have
+    if (two && bwc >= 1 && C - bwc - 1 >= 4 * (bwc + 1)) {
+      std::vector<int32_t> ord(m);
+      int64_t p = 0;
+      for (int64_t c = 0; c < C; ++c) {
+        for (int64_t t = 0; t < kDB; ++t) ord[p++] = (int32_t)(c * kDB + t);
+        for (int64_t t = 0; t < kDB; ++t) ord[p++] = (int32_t)(m - 1 - c * kDB - t);
+      }
+      for (int64_t r = C * kDB; r < m - C * kDB; ++r) ord[p++] = (int32_t)r;
+      apply_order(ord);
+      chain_safe = (int)(C - bwc - 1);
+      chain_bw = (int)bwc;
+    }
+  }
+  return std::string();
+}
+
 inline size_t blk_off(const fpsq_band b, int64_t i, int64_t j) {  // block (i, j), i - (band_w - 1) <= j <= i
   return ((size_t)i * b->band_w + (size_t)(j - i + b->band_w - 1)) * kDB * kDB;
 }
@@ -639,6 +733,58 @@ extern "C" {
 
 const char* fpsq_band_last_error(fpsq_band b) { return b ? b->err.c_str() : g_band_create_error.c_str(); }
 
+int fpsq_band_analyze(int64_t n, int64_t m, const int32_t* rowptr, const int32_t* colind, int32_t* row_perm,
+                      fpsq_band_info* info) {
+  if (n <= 0 || m <= 0 || !rowptr || n >= INT32_MAX || m >= INT32_MAX - 256 || rowptr[0] != 0) {
+    g_band_create_error = "fpsq_band_analyze: bad arguments (0-based CSR in HOST memory expected)";
+    return FPSQ_ERR_ARG;
+  }
+  std::vector<int32_t> rp(rowptr, rowptr + m + 1);
+  for (int64_t i = 0; i < m; ++i)
+    if (rp[i + 1] < rp[i]) {
+      g_band_create_error = "fpsq_band_analyze: rowptr not monotone";
+      return FPSQ_ERR_ARG;
+    }
+  const int64_t nnz = rp[m];
+  if (nnz > 0 && !colind) {
+    g_band_create_error = "fpsq_band_analyze: colind missing";
+    return FPSQ_ERR_ARG;
+  }
+  std::vector<int32_t> ci(colind, colind + nnz), rperm_h, vperm_h;
+  ci.resize(std::max<int64_t>(nnz, 1));
+  int chain_safe = 0, chain_bw = 0;
+  const std::string msg = band_order(n, m, rp, ci, rperm_h, vperm_h, chain_safe, chain_bw);
+  if (!msg.empty()) {
+    g_band_create_error = msg;
+    return FPSQ_ERR_ARG;
+  }
+  if (row_perm)
+    for (int64_t p = 0; p < m; ++p) row_perm[p] = rperm_h.empty() ? (int32_t)p : rperm_h[p];
+  if (info) {
+    std::vector<int32_t> lo(n, INT32_MAX), hi(n, -1);
+    for (int64_t i = 0; i < m; ++i)
+      for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
+        lo[ci[k]] = std::min(lo[ci[k]], (int32_t)(i / kDB));
+        hi[ci[k]] = std::max(hi[ci[k]], (int32_t)(i / kDB));
+      }
+    int64_t bwb = 0;
+    for (int64_t c = 0; c < n; ++c)
+      if (hi[c] >= 0) bwb = std::max<int64_t>(bwb, hi[c] - lo[c]);
+    const int64_t nb = (m + kDB - 1) / kDB;
+    bwb = std::min(bwb, nb - 1);
+    *info = fpsq_band_info{};
+    info->n = n;
+    info->m = m;
+    info->nnz = nnz;
+    info->nblocks = nb;
+    info->bandwidth_blocks = bwb;
+    info->factor_bytes = nb * (bwb + 1) * (int64_t)kDB * kDB * 8;
+    info->reordered = rperm_h.empty() ? 0 : 1;
+    info->chains = chain_safe > 0 ? 2 : 1;
+  }
+  return FPSQ_OK;
+}
+
 int fpsq_band_destroy(fpsq_band b) {
   if (!b) return FPSQ_ERR_ARG;
   hipSetDevice(b->device);
@@ -687,91 +833,13 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
     g_band_create_error = "fpsq_band_create: cannot read colind";
     return FPSQ_ERR_ARG;
   }
-  // validate, then the natural half bandwidth (rows): if the band is wide, try a reverse Cuthill-McKee ordering of the rows
-  // (LDLFactorizations' ldl_analyze computes a fill-reducing ordering at this point; for a band factorisation the
-  // ordering to look for is the bandwidth-reducing one).  FPSQ_BAND_REORDER = 0 never, 1 always tries.
-  for (int64_t i = 0; i < m; ++i) {
-    if (rp[i + 1] < rp[i] || rp[i + 1] > nnz) {
-      g_band_create_error = "fpsq_band_create: rowptr not monotone";
-      return FPSQ_ERR_ARG;
-    }
-    for (int32_t k = rp[i]; k < rp[i + 1]; ++k)
-      if (ci[k] < 0 || ci[k] >= n) {
-        g_band_create_error = "fpsq_band_create: column index out of range";
-        return FPSQ_ERR_ARG;
-      }
-  }
   std::vector<int32_t> rperm_h, vperm_h;  // stored row / entry -> the caller's (empty: identity)
   int chain_safe = 0, chain_bw = 0;
   {
-    auto bandwidth_rows = [&](const std::vector<int32_t>& pos) {  // pos[row] = position; empty = identity
-      std::vector<int32_t> lo(n, INT32_MAX), hi(n, -1);
-      for (int64_t i = 0; i < m; ++i) {
-        const int32_t p = pos.empty() ? (int32_t)i : pos[i];
-        for (int32_t k = rp[i]; k < rp[i + 1]; ++k) {
-          lo[ci[k]] = std::min(lo[ci[k]], p);
-          hi[ci[k]] = std::max(hi[ci[k]], p);
-        }
-      }
-      int64_t w = 0;
-      for (int64_t c = 0; c < n; ++c)
-        if (hi[c] >= 0) w = std::max<int64_t>(w, hi[c] - lo[c]);
-      return w;
-    };
-    // row `ord[p]` of the current structure becomes row p; the maps to the caller's numbering are composed
-    auto apply_order = [&](const std::vector<int32_t>& ord) {
-      std::vector<int32_t> rp2(m + 1, 0), ci2(std::max<int64_t>(nnz, 1)), vp2(std::max<int64_t>(nnz, 1)), rr2(m);
-      for (int64_t p = 0; p < m; ++p) {
-        const int32_t r = ord[p];
-        rr2[p] = rperm_h.empty() ? r : rperm_h[r];
-        rp2[p + 1] = rp2[p] + (rp[r + 1] - rp[r]);
-        for (int32_t k = rp[r], t = rp2[p]; k < rp[r + 1]; ++k, ++t) {
-          ci2[t] = ci[k];
-          vp2[t] = vperm_h.empty() ? k : vperm_h[k];
-        }
-      }
-      rp.swap(rp2);
-      ci.swap(ci2);
-      rperm_h.swap(rr2);
-      vperm_h.swap(vp2);
-    };
-    int mode = -1;  // auto
-    if (const char* ev = std::getenv("FPSQ_BAND_REORDER")) mode = std::atoi(ev);
-    const int64_t nbk = (m + kDB - 1) / kDB;
-    int64_t bw_rows = bandwidth_rows({});
-    if (mode != 0 && (mode == 1 || bw_rows / kDB > std::max<int64_t>(nbk / 8, 2))) {
-      std::vector<int32_t> ord = rcm_rows(m, n, rp, ci);
-      if (!ord.empty()) {
-        std::vector<int32_t> pos(m);
-        for (int64_t p = 0; p < m; ++p) pos[ord[p]] = (int32_t)p;
-        const int64_t bw_new = bandwidth_rows(pos);
-        if (bw_new / kDB < bw_rows / kDB) {  // fewer blocks in the band: take it
-          apply_order(ord);
-          bw_rows = bw_new;
-        }
-      }
-    }
-    // TWO ELIMINATION CHAINS.  A banded Cholesky is a chain of m / 128 dependent block steps, each a few latency-bound
-    // launches.  Ordering the blocks from BOTH ends towards the middle -- stored block 2 c = block c from the top, stored
-    // block 2 c + 1 = the c-th block of 128 rows from the bottom (rows descending) -- keeps the matrix banded (twice as
-    // wide) and makes the even and the odd blocks two independent chains until they meet: their steps run side by side
-    // on two streams, the chain is half as long.  Only the last 2 (chain_bw + 1) blocks and the rows left in the middle
-    // are eliminated one after the other.  FPSQ_BAND_TWOCHAIN=0 turns it off.
-    int two = 1;
-    if (const char* ev = std::getenv("FPSQ_BAND_TWOCHAIN")) two = std::atoi(ev);
-    const int64_t C = m / (2 * kDB);
-    const int64_t bwc = (bw_rows + kDB - 1) / kDB;  // block distance two coupled rows of one chain can have
-    if (two && bwc >= 1 && C - bwc - 1 >= 4 * (bwc + 1)) {
-      std::vector<int32_t> ord(m);
-      int64_t p = 0;
-      for (int64_t c = 0; c < C; ++c) {
-        for (int64_t t = 0; t < kDB; ++t) ord[p++] = (int32_t)(c * kDB + t);
-        for (int64_t t = 0; t < kDB; ++t) ord[p++] = (int32_t)(m - 1 - c * kDB - t);
-      }
-      for (int64_t r = C * kDB; r < m - C * kDB; ++r) ord[p++] = (int32_t)r;
-      apply_order(ord);
-      chain_safe = (int)(C - bwc - 1);
-      chain_bw = (int)bwc;
+    const std::string msg = band_order(n, m, rp, ci, rperm_h, vperm_h, chain_safe, chain_bw);
+    if (!msg.empty()) {
+      g_band_create_error = msg;
+      return FPSQ_ERR_ARG;
     }
   }
   std::vector<int32_t> cfirst(n, INT32_MAX), clast(n, -1), tcnt(n + 1, 0);

@@ -291,6 +291,11 @@ typedef struct {
   int64_t chains;            /* 2: the band is eliminated from both ends at once (two streams), 1: one chain */
 } fpsq_band_info;
 int fpsq_band_create(fpsq_band *out, int64_t n, int64_t m, const int32_t *rowptr, const int32_t *colind, int32_t device);
+/* the ordering decisions of fpsq_band_create alone, on the host (no device needed; rowptr / colind in HOST memory): row_perm
+ * (m entries, may be null) = the caller's row stored at each position, info = blocks / half bandwidth / factor bytes /
+ * reordered / chains of the structure fpsq_band_create would set up. */
+int fpsq_band_analyze(int64_t n, int64_t m, const int32_t *rowptr, const int32_t *colind, int32_t *row_perm,
+                      fpsq_band_info *info);
 int fpsq_band_destroy(fpsq_band b);
 const char *fpsq_band_last_error(fpsq_band b);
 int fpsq_band_set_regularization(fpsq_band b, double tol, double reg);

@@ -58,3 +58,62 @@ def test_no_cpu_fallback_without_gpu():
     rc = lib.fpsq_create(C.byref(h), 10, 1, None)
     assert rc < 0
     assert b"no HIP device" in lib.fpsq_last_error(None)
+
+
+def test_band_symbolic_phase_on_the_host():
+    """fpsq_band_analyze = the ordering decisions of fpsq_band_create without a device: a PDE-like Jacobian keeps its
+    natural order (one chain when short, two chains when long and narrow: blocks alternately from the top and the bottom,
+    a permutation); with its rows shuffled the natural band is full and reverse Cuthill-McKee restores a narrow one;
+    malformed patterns are argument errors."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    from fps_amd import problems
+
+    lib = _lib.load()
+
+    def analyze(A):
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        m, n = A.shape
+        rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+        perm = np.empty(m, dtype=np.int32)
+        info = _lib.BandInfo()
+        rc = lib.fpsq_band_analyze(n, m, rp.ctypes.data, ci.ctypes.data, perm.ctypes.data, C.byref(info))
+        return rc, perm, info.as_dict()
+
+    def block_bandwidth(A, perm):
+        B = sp.csr_matrix(A)[perm]
+        M = (abs(B) @ abs(B).T).tocoo()
+        return int(np.max(np.abs(M.row // 128 - M.col // 128)))
+
+    short = problems.pde_control_like(n=6000, m=600, per_row=24, window=512, seed=3).scipy_csr()
+    rc, perm, i = analyze(short)
+    assert rc == 0 and (i["chains"], i["reordered"]) == (1, 0) and np.array_equal(perm, np.arange(600))
+    assert i["nblocks"] == 5 and i["bandwidth_blocks"] == block_bandwidth(short, perm)
+
+    m = 7700
+    long_ = problems.pde_control_like(n=30000, m=m, per_row=12, window=600, seed=11).scipy_csr()
+    rc, perm, i = analyze(long_)
+    assert rc == 0 and (i["chains"], i["reordered"]) == (2, 1)
+    assert np.array_equal(np.sort(perm), np.arange(m))                      # a permutation
+    assert np.array_equal(perm[:128], np.arange(128))                       # block 0: the top block
+    assert np.array_equal(perm[128:256], m - 1 - np.arange(128))            # block 1: the bottom rows, descending
+    assert np.array_equal(perm[256:384], 128 + np.arange(128))              # block 2: the second block from the top
+    assert i["bandwidth_blocks"] == block_bandwidth(long_, perm) <= 6
+
+    rng = np.random.default_rng(5)
+    base = problems.pde_control_like(n=12000, m=2400, per_row=16, window=600, seed=8).scipy_csr()
+    shuffled = sp.csr_matrix(base[rng.permutation(2400)])
+    nat = block_bandwidth(shuffled, np.arange(2400))
+    rc, perm, i = analyze(shuffled)
+    assert rc == 0 and i["reordered"] == 1 and np.array_equal(np.sort(perm), np.arange(2400))
+    assert nat >= 15 and i["bandwidth_blocks"] == block_bandwidth(shuffled, perm) <= 4
+
+    rp = np.array([0, 2, 1], dtype=np.int32)
+    ci = np.array([0, 1], dtype=np.int32)
+    assert lib.fpsq_band_analyze(3, 2, rp.ctypes.data, ci.ctypes.data, None, None) == -1
+    rp = np.array([0, 1, 2], dtype=np.int32)
+    ci = np.array([0, 7], dtype=np.int32)
+    assert lib.fpsq_band_analyze(3, 2, rp.ctypes.data, ci.ctypes.data, None, None) == -1
+    assert b"column index out of range" in lib.fpsq_band_last_error(None)
