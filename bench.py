@@ -286,8 +286,41 @@ def main():
     dev = torch.device("cuda", local_rank)
     timer = Timer(world, rehearse, dev)
 
+    # ---- N > 1: a stalled or failed multi-rank phase must never be scored.  `fail` (watchdog timer or exception path)
+    # restores stdout if it was redirected, writes the reason -- and the replicas measurement if there is one, labelled
+    # as NOT the requested run -- to STDERR, and ends every rank with a non-zero exit code.  Nothing is printed on stdout.
+    state = {"saved_fd": None, "replicas": None}
+
+    def fail(reason):
+        try:
+            if state["saved_fd"] is not None:
+                os.dup2(state["saved_fd"], 1)
+            sys.stderr.write("bench.py: FAILED on rank %d: %s\n" % (rank, reason))
+            if rank == 0 and state["replicas"] is not None:
+                sys.stderr.write("bench.py: FALLBACK information only (independent replicas, NOT the requested sharded "
+                                 "run): " + json.dumps(state["replicas"]) + "\n")
+            sys.stderr.flush()
+        finally:
+            os._exit(3)
+
+    watchdog = None
+    if world > 1:
+        import threading
+
+        wd_s = float(os.environ.get("FPSQ_BENCH_WATCHDOG", "300"))
+        watchdog = threading.Timer(wd_s, fail, args=(f"the {world}-rank run did not finish within {wd_s:.0f} s (watchdog)",))
+        watchdog.daemon = True
+        watchdog.start()
+
     if args.workload.startswith("dense-block"):
-        bench_dense(args, rank, world, local_rank, timer, dev)
+        try:
+            bench_dense(args, rank, world, local_rank, timer, dev)
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            fail(f"dense-block run failed: {e}")
+        if watchdog is not None:
+            watchdog.cancel()
         if world > 1:
             dist.destroy_process_group()
         return
@@ -345,10 +378,9 @@ def main():
                                    comm=comm, **extra)
         return qp, DeviceEqQP(qp, sigma=sigma, rho=rho, delta=delta, device=local_rank, fuse_two_rhs=args.fuse, **extra)
 
-    # ---- N > 1, sharded: FIRST the same ranks as independent replicas (no collective: cannot hang) -- a second number
-    # for the record, and the line that is printed if the sharded phase fails or stalls (watchdog below)
+    # ---- N > 1, sharded: FIRST the same ranks as independent replicas (no data-path collective) -- a second number for
+    # the record (`replicas_alternative`), never the `value` of a sharded run
     replicas_alt = None
-    watchdog = None
     if sharded and world > 1 and args.op == "objgrad":
         _, rep = build_model("replicas")
         K0, W0 = args.steps, args.warmup
@@ -363,46 +395,28 @@ def main():
         replicas_alt = {"value": round(K0 * world / med0, 3), "unit": "evals/s", "scaling": "weak",
                         "ms_per_step": round(1e3 * med0 / K0, 4),
                         "note": "same ranks, each evaluating its own points with the whole Jacobian, no collective"}
+        replicas_alt["iters_lsqr_craig_median"] = [int(np.median([i[0] for i in its0])), int(np.median([i[1] for i in its0]))]
+        state["replicas"] = replicas_alt
         rep.close()
         del xs0, gx0
-
-        def fallback_line(reason):
-            if rank == 0:
-                print(json.dumps({
-                    "metric": "penalty grad-phi evals/sec", "value": replicas_alt["value"], "unit": "evals/s",
-                    "n_gpus": world, "steps": K0, "warmup": W0, "ms_per_step": replicas_alt["ms_per_step"],
-                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                    "config": {"workload": args.workload, "n": n, "m": m, "nnz": nnz, "sigma": sigma, "rho": rho,
-                               "delta": delta, "iters_lsqr_craig_median": [int(np.median([i[0] for i in its0])),
-                                                                           int(np.median([i[1] for i in its0]))],
-                               "parallelism": f"{world} independent replicas (FALLBACK: {reason})"},
-                    "roofline": None}), flush=True)
-            os._exit(0)
-
-        import threading
-
-        wd_s = float(os.environ.get("FPSQ_BENCH_WATCHDOG", "240"))
-        watchdog = threading.Timer(wd_s, fallback_line, args=(f"the row-sharded phase did not finish within {wd_s:.0f} s",))
-        watchdog.daemon = True
-        watchdog.start()
 
     # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
     if sharded:
         sys.stdout.flush()
-        saved_fd = os.dup(1)
+        state["saved_fd"] = os.dup(1)
         os.dup2(2, 1)
     try:
         local, model = build_model(layout)
     except Exception as e:  # noqa: BLE001  (RCCL unavailable / communicator cannot be formed)
-        if replicas_alt is None:
+        if world == 1:
             raise
-        os.dup2(saved_fd, 1)
-        fallback_line(f"sharded set-up failed: {e}")
+        fail(f"sharded set-up failed: {e}")
     finally:
         if sharded:
             sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+            os.dup2(state["saved_fd"], 1)
+            os.close(state["saved_fd"])
+            state["saved_fd"] = None
     n_loc = local.n  # window length in halo layout, n otherwise
 
     # distinct evaluation points, resident in HBM (sharded: every rank holds its window of the SAME points; replicas:
@@ -458,10 +472,10 @@ def main():
 
     try:
         times = timer.run(step, W, K, args.repeats, collect)
-    except Exception as e:  # noqa: BLE001  (a collective failed: keep the run's line)
-        if replicas_alt is None:
+    except Exception as e:  # noqa: BLE001  (a collective failed: every rank must end, non-zero)
+        if world == 1:
             raise
-        fallback_line(f"sharded run failed: {e}")
+        fail(f"timed run failed: {e}")
     med = float(np.median(times))
     evals = K if sharded else K * world  # sharded: all ranks work on the same K evaluations
     value = evals / med
@@ -491,8 +505,11 @@ def main():
         # Vector updates riding in the product launches (single GPU, fused run): LSQR's x/w update of the previous
         # iteration in the A' launch (read v, w, x; write w, x: 5 m-passes), CRAIG's in the A launch (read v, x; write x:
         # 3 n-passes, +2 for w2 when delta != 0; read u, w, y; write w, y: 5 m-passes).
-        upd_at = 0 if sharded else 8 * 5 * m
-        upd_a = 0 if sharded else 8 * ((3 if delta == 0.0 else 5) * n + 5 * m)
+        # (the halo layout runs the single-GPU launch pattern on the rank's block: riding updates, fast start, paired
+        # epilogue product; the replicated-n layout keeps separate update launches and single-RHS epilogue products)
+        separate = layout == "allreduce"
+        upd_at = 0 if separate else 8 * 5 * m_loc
+        upd_a = 0 if separate else 8 * ((3 if delta == 0.0 else 5) * n_loc + 5 * m_loc)
         for il, ic in its:
             if hp:  # two LSQR recurrences: J two-RHS A' products (both x/w updates riding), J + 1 two-RHS A products,
                 J = max(il, ic)  # then p_k = rhs_k - A'q_k with one right-hand side each
@@ -503,12 +520,12 @@ def main():
                     productive += 2
             elif args.fuse:
                 J = max(il, ic)
-                if sharded:  # c = Ax - b, then p1 = g - A'q1 and rho A'c as two single-RHS products
+                if separate:  # c = Ax - b, then p1 = g - A'q1 and rho A'c as two single-RHS products
                     nbytes += J * at2 + (J + 1) * a2 + a1 + 2 * at1
                     productive += 2 * J + 4
                 else:        # single GPU: c = Ax - b rides in the CRAIG lane of LSQR's start-up A product, and the
                              # last two share one raw two-RHS product A'[q1, c] (no yin read)
-                    nbytes += J * at2 + (J + 1) * a2 + (at2 - 8 * 2 * n)
+                    nbytes += J * at2 + (J + 1) * a2 + (at2 - 8 * 2 * n_loc)
                     productive += 2 * J + 2
                 nbytes += max(il - 1, 0) * upd_at + ic * upd_a
             else:
@@ -529,7 +546,7 @@ def main():
                     "whole_eval_frac_of_peak": round(nbytes / K / (med / K) / 1e9 / HBM_PEAK_GBS, 4) if not sharded else None}
         # HBM traffic per productive launch: PMC counters cannot be read from inside the run (rocprofv3 writes them when
         # the process ends); the number below is from the COMMITTED profile of this same command, labelled as such
-        for prof in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for prof in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1 and not hp \
@@ -542,9 +559,10 @@ def main():
                 continue
 
     par = {"single": "single GPU",
-           "halo": f"rows of A sharded over {world} GPUs, HALO layout: each rank holds its column window of the n-vectors, "
-                   f"RCCL send/recv of the A'u overlap regions with its neighbours (<= {plan.max_exchange_doubles() if plan else 0} "
-                   "doubles per rank and iteration) + two 4-double all-reduces per Krylov iteration",
+           "halo": f"rows of A sharded over {world} GPUs, HALO layout: each rank holds its column window of the n-vectors and "
+                   "runs the single-GPU launch pattern on its block; per Krylov iteration RCCL send/recv of the A'u overlap "
+                   f"regions with its neighbours (<= {plan.max_exchange_doubles() if plan else 0} doubles per rank) + one "
+                   "all-gather of the norm partials per product (summed in rank order by the scalar-step kernel)",
            "allreduce": f"rows of A sharded over {world} GPUs, replicated n-vectors: RCCL all-reduce of the partial A'u "
                         "products (n x 2 fp64) and of the m-vector norm partials every Krylov iteration",
            "replicas": f"{world} independent replicas (each rank evaluates its own points), no data-path collective"}[layout]
@@ -567,8 +585,6 @@ def main():
         "roofline": roofline,
     }
 
-    if watchdog is not None:
-        watchdog.cancel()
     if replicas_alt is not None:
         out["replicas_alternative"] = replicas_alt
 
@@ -627,6 +643,13 @@ def main():
                                                 "kind": "port, OpenMP (oracle/libfps_oracle_omp.so)"}
         except (OSError, AttributeError) as e:  # no libgomp on this host
             out["cpu_baseline"]["all_cores"] = {"value": None, "error": str(e)}
+    if world > 1:  # every rank reached the end of its measurements: only then is the line printed
+        try:
+            timer.barrier()
+        except Exception as e:  # noqa: BLE001
+            fail(f"final barrier failed: {e}")
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     model.close()

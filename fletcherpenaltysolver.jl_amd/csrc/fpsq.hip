@@ -70,6 +70,9 @@ struct Comm {
   // (stream order) recvL / recvR hold the neighbours' partials on those regions; vec itself is untouched.
   virtual int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL,
                             double* recvR, hipStream_t s) = 0;
+  // recv[r * count + i] = rank r's send[i].  Data movement only: the sums are formed by the step kernel in a fixed
+  // rank-major order, so replicated scalars are bitwise identical on every rank by construction.
+  virtual int allgather(const double* send, double* recv, size_t count, hipStream_t s) = 0;
   virtual ~Comm() {}
 };
 
@@ -78,6 +81,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -97,13 +101,14 @@ struct RcclApi {
     GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
     AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
     Send = (decltype(Send))dlsym(lib, "ncclSend");
     Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
     GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
-    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString || !Send || !Recv || !GroupStart ||
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !AllGather || !CommDestroy || !GetErrorString || !Send || !Recv || !GroupStart ||
         !GroupEnd) {
       err = "librccl is missing a required symbol";
       return false;
@@ -119,6 +124,14 @@ struct RcclComm : Comm {
     ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, c, s);
     if (r != ncclSuccess) {
       err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r);
+      return FPSQ_ERR_COMM;
+    }
+    return 0;
+  }
+  int allgather(const double* send, double* recv, size_t count, hipStream_t s) override {
+    ncclResult_t r = g_rccl.AllGather(send, recv, count, ncclDouble, c, s);
+    if (r != ncclSuccess) {
+      err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r);
       return FPSQ_ERR_COMM;
     }
     return 0;
@@ -196,6 +209,26 @@ struct LocalComm : Comm {
     g->barrier();  // nobody may start the next collective (and overwrite bufs[] / re-record events) before all queued the wait
     return 0;
   }
+  int allgather(const double* send, double* recv, size_t count, hipStream_t s) override {
+    g->vecs[rank] = send;
+    hipEventRecord(g->ready[rank], s);
+    g->barrier();  // every shard's source pointer and `ready` event are published
+    GatherSrc S;
+    S.n = g->n;
+    for (int r = 0; r < g->n; ++r) {
+      if (r != rank) hipStreamWaitEvent(s, g->ready[r], 0);
+      S.s[r] = g->vecs[r];
+    }
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((count * g->n + kBlock - 1) / kBlock, 256));
+    hipLaunchKernelGGL(k_local_allgather, dim3(grid), dim3(kBlock), 0, s, S, recv, (int64_t)count);
+    hipEventRecord(g->copied[rank], s);
+    g->barrier();  // every `copied` event is recorded
+    // a shard's next kernels rewrite its source array: every other shard must have taken its copy first
+    for (int r = 0; r < g->n; ++r)
+      if (r != rank) hipStreamWaitEvent(s, g->copied[r], 0);
+    g->barrier();  // the events may be re-recorded by the next collective only after everyone queued its waits
+    return 0;
+  }
   int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL, double* recvR,
                     hipStream_t s) override {
     g->vecs[rank] = vec;
@@ -251,8 +284,10 @@ struct fpsq_solver_s {
   // m-vectors
   double *Lw[2], *Lx[2], *Cw, *Cy, *in_m, *ys, *c, *Mr[2], *Mw[2], *Mx;
   // partial-sum buffers
-  double *pS, *pS2, *pW[2], *pE, *pE2, *pE3, *pQ[2];
+  double *pS, *pS2, *pW[2], *pE, *pE2, *pE3, *pQ[2], *pC[2];
+  double* pEm[2];               // squared-norm partials of the m-vector right-hand sides (pE / pE2: of the n-vector ones)
   int npS = 0;
+  int strT = 0, strA = 0;       // lane strides of pS (A' product partials) and pS2 (A product partials)
   LsqrState* lsqr[2];
   CraigState* craig;
   MinresState* minres;
@@ -267,7 +302,20 @@ struct fpsq_solver_s {
   // [0, n - ovr) and are all-reduced like the sums over the (row-sharded) m-vectors.
   bool halo = false;
   int64_t ovl = 0, ovr = 0;
-  double* halo_recv = nullptr;  // [(ovl + ovr)][2]
+  double* halo_recv = nullptr;  // [(ovl + ovr)][2]: the neighbours' raw sums on the two overlap regions
+  double* halo_raw = nullptr;   // [(ovl + ovr)][2]: this rank's raw sums there (k_spmv<.., HALO>), head region first
+  int halo_gf = 0;              // workgroups of k_halo_finish (0: no overlap at all)
+  // Halo mode keeps every partial-sum array of the Krylov loop in ONE per-rank segment `seg`, laid out
+  //   [E0 | E1 | M0 | M1 | T0 | T1 | A0 | A1 | W0 | W1 | E3]   (pE, pE2, pEm[0..1], pS lanes, pS2 lanes, pW[0..1], pE3)
+  // with counts cE / cW / cT / cA padded to the maxima over the ranks (zeros beyond a rank's own count -- every array is
+  // always written with the same local count, so the padding stays zero): the arrays a
+  // scalar step reads are then one contiguous range, which is all-gathered into `gath` ([nranks][range]) right before
+  // the step; the step kernel sums the ranks' copies itself (StepArgs::nseg).
+  double* seg = nullptr;
+  double* gath = nullptr;
+  int64_t seg_len = 0;
+  int cE = 0, cT = 0, cA = 0, cW = 0;
+  bool gather_ready = false;
   double* comm_vec = nullptr;   // [n][2] all-reduce payload (partial A' products)
   double* comm_scal = nullptr;  // 8 doubles: scalar all-reduce payload
   double* dscal;               // small device scalar scratch
@@ -630,7 +678,10 @@ int alloc_workspaces(fpsq_handle h) {
   h->npS = std::max(std::max(std::max(h->A.nblk, h->AT.nblk), kEwBlocksMax), npart_A(h));
   if (int rc = dalloc(h, &h->pS, (size_t)h->npS * 2)) return rc;
   if (int rc = dalloc(h, &h->pS2, (size_t)h->npS * 2)) return rc;
-  double** ev[] = {&h->pW[0], &h->pW[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1]};
+  h->strT = h->AT.nblk;
+  h->strA = npart_A(h);
+  double** ev[] = {&h->pW[0], &h->pW[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1], &h->pC[0], &h->pC[1],
+                   &h->pEm[0], &h->pEm[1]};
   for (auto p : ev)
     if (int rc = dalloc(h, p, (size_t)kEwBlocksMax * 2)) return rc;
   return 0;
@@ -692,34 +743,41 @@ UpdSeg seg_none() {
 
 // u0/u1: vector-update segments that ride in the product launch (run_fused_updates); they may only read what the
 // product reads.
+// halo_rows (A' products of a halo-mode handle): the overlap rows of the rank's column window only get their raw sums,
+// see HaloRows / halo_finish.
 template <int NL>
 void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, double* yout, const LaneCtl* c0,
-                 const LaneCtl* c1, double* partials, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none()) {
+                 const LaneCtl* c1, double* partials, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none(),
+                 bool halo_rows = false) {
   const int nupd = u0.nblk + u1.nblk;
+  const HaloRows hr{h->ovl, h->n - h->ovr, h->halo_raw};
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
     if (h->RA.view.stride)
       launch_product(h, k_spmv_rgcs<NL, true>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd,
-                     u0, u1, h->gate0, h->gate1);
+                     u0, u1, h->gate0, h->gate1, h->strA);
     else
       launch_product(h, k_spmv_rgcs<NL, false>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials,
-                     per_xcd, u0, u1, h->gate0, h->gate1);
+                     per_xcd, u0, u1, h->gate0, h->gate1, h->strA);
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
     const dim3 grid(per_xcd * 8 + nupd);
-    if (tag == TAG_A && M.col16)
-      launch_product(h, k_spmv<NL, TAG_A, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
-    else if (tag == TAG_A)
-      launch_product(h, k_spmv<NL, TAG_A, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
-    else if (M.col16 && M.padded)
-      launch_product(h, k_spmv<NL, TAG_AT, true, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
-    else if (M.col16)
-      launch_product(h, k_spmv<NL, TAG_AT, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
-    else if (M.padded)
-      launch_product(h, k_spmv<NL, TAG_AT, false, true>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
-    else
-      launch_product(h, k_spmv<NL, TAG_AT, false>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1);
+    const int ps = tag == TAG_A ? h->strA : h->strT;
+#define FPSQ_LAUNCH_SPMV(...) \
+    launch_product(h, k_spmv<__VA_ARGS__>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1, ps, hr)
+    if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_A, true);
+    else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(NL, TAG_A, false);
+    else if (halo_rows) {
+      if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true);
+      else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, false, true);
+      else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true, true);
+      else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, false, true);
+    } else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true);
+    else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true);
+    else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true);
+    else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false);
+#undef FPSQ_LAUNCH_SPMV
   }
   h->launches++;
   h->spmv_launches++;
@@ -734,17 +792,20 @@ __global__ void k_set_ctl(LaneCtl* c, double ca, double cb) {
   c->upd_iter = -1;
 }
 
+// control block holding the host-given coefficient pair (ca, cb)
+const LaneCtl* const_ctl(fpsq_handle h, double ca, double cb) {
+  // the coefficient pairs of the hot path are resident constants: no set-up launch
+  if (ca == 1.0 && cb == 0.0) return h->ctl_raw;
+  if (ca == 1.0 && cb == -1.0) return h->ctl_pm;
+  if (ca == -1.0 && cb == 1.0) return h->ctl_mp;
+  hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, h->stream, h->ctl_tmp, ca, cb);
+  h->launches++;
+  return h->ctl_tmp;
+}
+
 // out = ca * op(A) x + cb * yin with host-given constants
 void spmv_const(fpsq_handle h, int tag, double ca, const double* x, double cb, const double* yin, double* yout) {
-  const LaneCtl* c = nullptr;  // the coefficient pairs of the hot path are resident constants: no set-up launch
-  if (ca == 1.0 && cb == 0.0) c = h->ctl_raw;
-  else if (ca == 1.0 && cb == -1.0) c = h->ctl_pm;
-  else if (ca == -1.0 && cb == 1.0) c = h->ctl_mp;
-  if (!c) {
-    hipLaunchKernelGGL(k_set_ctl, dim3(1), dim3(1), 0, h->stream, h->ctl_tmp, ca, cb);
-    h->launches++;
-    c = h->ctl_tmp;
-  }
+  const LaneCtl* c = const_ctl(h, ca, cb);
   launch_spmv<1>(h, tag, x, yin, yout, c, c, nullptr);
 }
 
@@ -777,6 +838,24 @@ int comm_reduce_long(fpsq_handle h, double* buf, int NL) {
 
 // LP <- ca A' SP + cb LP with norm partials (count returned in *np).  Sharded: every rank holds a row block A_r, so
 // A'x = sum_r A_r' x_r: raw partial product -> all-reduce -> fused axpby + norm on the replicated result.
+// Halo mode, after k_spmv<.., HALO>: exchange the raw sums of the two overlap regions with the neighbours, then finish
+// those rows (yout = ca (own + neighbour's) + cb yin, squared-norm partials of the owned head region behind the product's).
+template <int NL>
+int halo_finish(fpsq_handle h, const double* yin, double* yout, const LaneCtl* c0, const LaneCtl* c1, double* partials) {
+  const int64_t t = h->ovl + h->ovr;
+  if (t == 0) return 0;
+  double* rl = h->halo_recv;
+  if (int rc = h->comm->halo_exchange(h->halo_raw, t, NL, h->ovl, h->ovr, rl, rl + (size_t)h->ovl * NL, h->stream)) {
+    h->err = h->comm->err;
+    return rc;
+  }
+  hipLaunchKernelGGL(k_halo_finish<NL>, dim3(h->halo_gf), dim3(kBlock), 0, h->stream, h->halo_raw, h->halo_recv, h->ovl,
+                     h->ovr, h->n - h->ovr, yin, yout, c0, c1, partials ? partials + h->AT.nblk : nullptr, h->strT, h->gate0,
+                     h->gate1);
+  h->launches++;
+  return 0;
+}
+
 template <int NL>
 int at_product(fpsq_handle h, const double* x, double* y, const LaneCtl* c0, const LaneCtl* c1, double* partials,
                int* np, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none()) {
@@ -785,9 +864,18 @@ int at_product(fpsq_handle h, const double* x, double* y, const LaneCtl* c0, con
     *np = h->AT.nblk;
     return 0;
   }
+  if (h->halo) {
+    // every row the rank alone contributes to is finished by the product kernel exactly as on one GPU (so the vector
+    // updates may ride in the launch); only the overlap rows wait for the neighbours
+    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials, u0, u1, /*halo_rows=*/true);
+    if (int rc = halo_finish<NL>(h, y, y, c0, c1, partials)) return rc;
+    *np = h->AT.nblk + h->halo_gf;
+    return 0;
+  }
   launch_spmv<NL>(h, TAG_AT, x, nullptr, h->comm_vec, h->ctl_raw, h->ctl_raw, nullptr);
   if (int rc = comm_reduce_long(h, h->comm_vec, NL)) return rc;
   const int g = ew_grid(h->n);
+  h->strT = g;  // replicated layout: the norm partials of the A' product come from this kernel, g per lane
   hipLaunchKernelGGL(k_axpby_norm<NL>, dim3(g), dim3(kBlock), 0, h->stream, h->comm_vec, y, c0, c1, h->n, n_owned(h),
                      partials);
   h->launches++;
@@ -800,6 +888,11 @@ int at_product_const(fpsq_handle h, double ca, const double* x, double cb, const
   if (!h->comm) {
     spmv_const(h, TAG_AT, ca, x, cb, yin, yout);
     return 0;
+  }
+  if (h->halo) {
+    const LaneCtl* c = const_ctl(h, ca, cb);
+    launch_spmv<1>(h, TAG_AT, x, yin, yout, c, c, nullptr, seg_none(), seg_none(), /*halo_rows=*/true);
+    return halo_finish<1>(h, yin, yout, c, c, nullptr);
   }
   launch_spmv<1>(h, TAG_AT, x, nullptr, h->comm_vec, h->ctl_raw, h->ctl_raw, nullptr);
   if (int rc = comm_reduce_long(h, h->comm_vec, 1)) return rc;
@@ -1014,7 +1107,7 @@ struct Lane {
 };
 
 StepArgs step_args(int kind, const Lane& L, int it, const double* p0, int n0, const double* p1, int n1, Progress* prog) {
-  StepArgs a;
+  StepArgs a{};
   a.kind = kind;
   a.it = it;
   a.state = L.state;
@@ -1035,8 +1128,56 @@ void launch_step_raw(fpsq_handle h, const StepArgs& a0, const StepArgs& a1) {
 
 // `sharded`: the partial arrays of these steps are sums over m-vectors, of which a rank only holds its rows:
 // local sums -> one scalar all-reduce (4 doubles) -> the step kernel reads the global sums.
+// padded (common to all ranks) count of the segment array that starts at p; 0: not an array of the segment
+int seg_count(fpsq_handle h, const double* p) {
+  if (p == h->pE || p == h->pE2) return h->cE;
+  if (p == h->pEm[0] || p == h->pEm[1]) return h->cW;
+  if (p == h->pS || p == h->pS + h->strT) return h->cT;
+  if (p == h->pS2 || p == h->pS2 + h->strA) return h->cA;
+  if (p == h->pW[0] || p == h->pW[1] || p == h->pE3) return h->cW;
+  return 0;
+}
+
 int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, int sharded1 = -1) {
   const bool sh[2] = {sharded, sharded1 < 0 ? sharded : sharded1 != 0};  // per step: its partials are per-rank sums
+  if (h->comm && h->halo && (sh[0] || sh[1])) {
+    // Halo mode: ONE all-gather of the contiguous segment range holding the arrays these steps read; the step kernel then
+    // sums the nranks copies of every array in rank-major order (no local pre-sum launch, no reduction by the library).
+    StepArgs* w[2] = {&a0, &a1};
+    const double *lo = nullptr, *hi = nullptr;
+    for (int k = 0; k < 2; ++k) {
+      if (w[k]->kind == STEP_NONE || !sh[k]) continue;
+      const double* ps[2] = {w[k]->p0, w[k]->p1};
+      for (const double* q : ps) {
+        if (!q) continue;
+        const int c = seg_count(h, q);
+        if (c == 0) {
+          h->err = "internal: a sharded step reads a partial array outside the gather segment";
+          return FPSQ_ERR_STATE;
+        }
+        if (!lo || q < lo) lo = q;
+        if (!hi || q + c > hi) hi = q + c;
+      }
+    }
+    const int64_t len = hi - lo;
+    if (int rc = h->comm->allgather(lo, h->gath, (size_t)len, h->stream)) {
+      h->err = h->comm->err;
+      return rc;
+    }
+    for (int k = 0; k < 2; ++k) {
+      if (w[k]->kind == STEP_NONE || !sh[k]) continue;
+      w[k]->n0 = seg_count(h, w[k]->p0);
+      w[k]->p0 = h->gath + (w[k]->p0 - lo);
+      if (w[k]->p1) {
+        w[k]->n1 = seg_count(h, w[k]->p1);
+        w[k]->p1 = h->gath + (w[k]->p1 - lo);
+      }
+      w[k]->nseg = h->comm->nranks;
+      w[k]->seg_stride = (int32_t)len;
+    }
+    launch_step_raw(h, a0, a1);
+    return 0;
+  }
   if (h->comm && (sh[0] || sh[1])) {
     PresumArgs P{};
     const StepArgs* a[2] = {&a0, &a1};
@@ -1103,7 +1244,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   // iteration count of the previous run with the same pair of recurrences (0: unknown).  The scalar steps publish their
   // progress to the host only from that iteration on (and when a recurrence ends): see publish().
   int64_t* expect_slot = &h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
-  const int64_t expect = (h->adaptive_runahead && !h->comm) ? *expect_slot : 0;
+  // (sharded: only in halo mode, where every rank derives the same count from the replicated recurrence state)
+  const bool local_vec = !h->comm || h->halo;  // vector updates touch rank-local data only
+  const int64_t expect = (h->adaptive_runahead && local_vec) ? *expect_slot : 0;
   const int32_t pub_from = (int32_t)std::min<int64_t>(expect, INT32_MAX);
   LsqrState* lsS[2] = {nullptr, nullptr};
   LsqrParams lsP[2] = {};
@@ -1168,7 +1311,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   const LaneCtl* t1 = lanes[NL - 1].ctlT;
   int affine_lane = -1;  // fast start: the CRAIG lane whose right-hand side the LSQR start-up product forms
   for (int l = 0; l < NL; ++l)
-    if (is_ln(lanes[l].kind) && lanes[l].affine_shift && any_lsqr && NL == 2 && !h->comm) affine_lane = l;
+    if (is_ln(lanes[l].kind) && lanes[l].affine_shift && any_lsqr && NL == 2 && local_vec) affine_lane = l;
 
   // ---- start-up: parameters, right-hand sides, beta_1 (one launch), then (LSQR) alpha_1 and w_1
   StepArgs none{};
@@ -1179,7 +1322,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   int nzblk = 0;
   for (int l = 0; l < NL; ++l) {
     Lane& L = lanes[l];
-    double* pe = l == 0 ? h->pE : h->pE2;
+    double* pe = L.kind == LANE_LSQR ? (l == 0 ? h->pE : h->pE2) : h->pEm[l];
     LoadSeg& g = ld[l];
     g.src = L.rhs;
     g.scale = L.rhs_scale;
@@ -1233,8 +1376,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
   // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
   // iteration it; CRAIG's updates of iteration it (read the long pair and the OLD short pair) go with the A product,
-  // which therefore writes the alternate short pair (ping-pong).  Sharded: separate update launch, in place.
-  const bool fuse_upd = h->comm == nullptr;
+  // which therefore writes the alternate short pair (ping-pong).  The same holds for a row-sharded handle in halo mode
+  // (every vector a rank updates is its own).  Sharded with replicated n-vectors: separate update launch, in place.
+  const bool fuse_upd = local_vec;
   UpdSeg winit[2] = {seg_none(), seg_none()};
   bool craig_begun = false;
   if (any_lsqr) {
@@ -1254,7 +1398,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     for (int l = 0; l < NL; ++l) {
       Lane& L = lanes[l];
       if (L.kind != LANE_LSQR) continue;
-      (s0.kind ? s1 : s0) = step_args(STEP_LSQR_BEGIN2, L, 0, h->pS2 + (size_t)l * nbA, nbA, nullptr, 0, prog[l]);
+      (s0.kind ? s1 : s0) = step_args(STEP_LSQR_BEGIN2, L, 0, h->pS2 + (size_t)l * h->strA, nbA, nullptr, 0, prog[l]);
       UpdSeg u{};
       u.kind = UPD_LSQR_WINIT;
       u.it = 0;
@@ -1274,9 +1418,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         if (is_ln(lanes[l].kind)) {
           const int kind = lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_BEGIN : STEP_LNLQ_BEGIN;
           if (l == affine_lane)  // ||rhs||^2 came out of the start-up product
-            s1 = step_args(kind, lanes[l], 0, h->pS2 + (size_t)l * nbA, nbA, nullptr, 0, prog[l]);
+            s1 = step_args(kind, lanes[l], 0, h->pS2 + (size_t)l * h->strA, nbA, nullptr, 0, prog[l]);
           else
-            s1 = step_args(kind, lanes[l], 0, l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]);
+            s1 = step_args(kind, lanes[l], 0, h->pEm[l], gm, nullptr, 0, prog[l]);
           craig_begun = true;
         }
     }
@@ -1301,12 +1445,12 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   for (int l = 0; l < NL; ++l)
     if (is_ln(lanes[l].kind) && !craig_begun)
       if (int rc = launch_step(h, step_args(lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_BEGIN : STEP_LNLQ_BEGIN, lanes[l], 0,
-                                            l == 0 ? h->pE : h->pE2, gm, nullptr, 0, prog[l]),
+                                            h->pEm[l], gm, nullptr, 0, prog[l]),
                                none, /*sharded=*/true))
         return rc;
 
   if (minres_lane >= 0)  // (un-parks the lane: must follow the LSQR lane's start-up product)
-    if (int rc = launch_step(h, step_args(STEP_MINRES_BEGIN, lanes[minres_lane], 0, minres_lane == 0 ? h->pE : h->pE2, gm,
+    if (int rc = launch_step(h, step_args(STEP_MINRES_BEGIN, lanes[minres_lane], 0, h->pEm[minres_lane], gm,
                                           nullptr, 0, prog[minres_lane]),
                              none, /*sharded=*/true))
       return rc;
@@ -1382,6 +1526,25 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   // a MINRES / LNLQ lane reports iteration k (step C; pass k) while the host is enqueueing iteration k + 1
   auto lag = [&](int l) { return lanes[l].kind == LANE_MINRES || lanes[l].kind == LANE_LNLQ ? 1 : 0; };
   const bool split_steps = h->comm && !h->halo;  // replicated n-sums and per-rank m-sums cannot share a presum launch
+  // the gated final LSQR flush + the caller's epilogue behind iteration `it` (see the comment above run_krylov)
+  auto enqueue_speculative = [&]() -> int {
+    if (tail == nullptr || !fuse_upd) return 0;
+    UpdSeg seg[2] = {seg_none(), seg_none()};
+    int ns = 0;
+    for (int l = 0; l < NL; ++l)
+      if (lanes[l].kind == LANE_LSQR) {
+        seg[ns] = lsqr_upd_seg(l, it);
+        seg[ns++].gate = lanes[NL - 1 - l].ctl;  // the other lane of the call (NL = 1: itself)
+      }
+    launch_updates<NL>(h, seg[0], seg[1], seg_none());
+    h->gate0 = lanes[0].ctl;
+    h->gate1 = lanes[NL - 1].ctl;
+    const int rc = (*tail)();
+    h->gate0 = h->gate1 = nullptr;
+    if (rc) return rc;
+    spec_it = it;
+    return 0;
+  };
   while (it < itmax_all) {
     ++it;
     // LSQR's x/w update of the PREVIOUS iteration
@@ -1415,7 +1578,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         continue;
       }
       sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SA : STEP_LNLQ_SA,
-                        lanes[l], (int)it, h->pS + (size_t)l * npT, npT, nullptr, 0, prog[l]);
+                        lanes[l], (int)it, h->pS + (size_t)l * h->strT, npT, nullptr, 0, prog[l]);
     }
     // sums over n-vectors: replicated (no all-reduce) unless the n-vectors are column windows (halo mode); MINRES' sums
     // run over (row-sharded) m-vectors
@@ -1480,7 +1643,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         sb[l] = step_args(STEP_MINRES_A, lanes[l], (int)it, h->pE3, gm, nullptr, 0, prog[l]);
       else
         sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SB : STEP_LNLQ_SB,
-                          lanes[l], (int)it, h->pS2 + (size_t)l * nbA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : h->pW[l],
+                          lanes[l], (int)it, h->pS2 + (size_t)l * h->strA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : h->pW[l],
                           gm, prog[l]);
     }
     if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
@@ -1493,8 +1656,21 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     }
     if (h->comm) {
       // every rank must enqueue the same collectives: decide at fixed iteration boundaries from the (replicated,
-      // bitwise identical) device state, never from the timing of the progress word
-      if (it % look == 0 || it == itmax_all) {
+      // bitwise identical) device state, never from the timing of the progress word.  With the iteration count of the
+      // previous call known (halo mode; the same on every rank) the first look is AT that count, with the gated flush
+      // and epilogue already enqueued behind it: a repeating count costs no stream synchronisation inside the loop.
+      bool boundary = it == itmax_all;
+      if (expect > 0) {
+        if (it == expect) {
+          if (int rc = enqueue_speculative()) return rc;
+          boundary = true;
+        } else if (it > expect && (it - expect) % look == 0) {
+          boundary = true;
+        }
+      } else if (it % look == 0) {
+        boundary = true;
+      }
+      if (boundary) {
         HIPCHK(h, hipStreamSynchronize(s));
         if (all_done()) break;
       }
@@ -1520,22 +1696,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     // `expect`.  When the count repeats, no launch is enqueued past convergence (each costs ~3.5 us of GPU time even
     // though it exits at once: ~50 us per evaluation at lookahead 4); when it does not, this is one short bubble.
     if (expect > 0 && it == expect) {
-      if (tail != nullptr && fuse_upd) {
-        UpdSeg seg[2] = {seg_none(), seg_none()};
-        int ns = 0;
-        for (int l = 0; l < NL; ++l)
-          if (lanes[l].kind == LANE_LSQR) {
-            seg[ns] = lsqr_upd_seg(l, it);
-            seg[ns++].gate = lanes[NL - 1 - l].ctl;  // the other lane of the call (NL = 1: itself)
-          }
-        launch_updates<NL>(h, seg[0], seg[1], seg_none());
-        h->gate0 = lanes[0].ctl;
-        h->gate1 = lanes[NL - 1].ctl;
-        const int rc = (*tail)();
-        h->gate0 = h->gate1 = nullptr;
-        if (rc) return rc;
-        spec_it = it;
-      }
+      if (int rc = enqueue_speculative()) return rc;
       for (int l = 0; l < NL; ++l) {
         if (h->prog_host[l].done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
@@ -1578,9 +1739,64 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
 
 int run_lanes(fpsq_handle h, Lane* lanes, int nlanes, const TailFn* tail = nullptr) {
   h->tail_was_run = false;
-  if (nlanes == 2 && h->opt.fuse_two_rhs) return run_krylov<2>(h, lanes, h->comm ? nullptr : tail);
+  if (nlanes == 2 && h->opt.fuse_two_rhs) return run_krylov<2>(h, lanes, (!h->comm || h->halo) ? tail : nullptr);
   for (int l = 0; l < nlanes; ++l)
     if (int rc = run_krylov<1>(h, lanes + l)) return rc;
+  return 0;
+}
+
+// Halo mode, once, at the first (collective) solve call: the padded counts of the gather segment = the maxima over
+// the ranks of the local partial counts, then the segment itself (see fpsq_solver_s::seg).
+int ensure_gather_layout(fpsq_handle h) {
+  if (!h->comm || !h->halo || h->gather_ready) return 0;
+  const int P = h->comm->nranks;
+  const int gn = ew_grid(h->n), gm = ew_grid(h->m);
+  const double mine[4] = {(double)gn, (double)(h->AT.nblk + h->halo_gf), (double)npart_A(h), (double)gm};
+  double* dsend = h->dscal;      // 4 doubles
+  double* drecv = nullptr;       // 4 P doubles
+  if (int rc = dalloc(h, &drecv, (size_t)4 * P)) return rc;
+  HIPCHK(h, hipMemcpyAsync(dsend, mine, sizeof mine, hipMemcpyHostToDevice, h->stream));
+  if (int rc = h->comm->allgather(dsend, drecv, 4, h->stream)) {
+    h->err = h->comm->err;
+    return rc;
+  }
+  std::vector<double> all((size_t)4 * P);
+  HIPCHK(h, hipMemcpyAsync(all.data(), drecv, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  dfree(h, &drecv);
+  int c[4] = {0, 0, 0, 0};
+  for (int r = 0; r < P; ++r)
+    for (int k = 0; k < 4; ++k) c[k] = std::max(c[k], (int)all[(size_t)4 * r + k]);
+  h->cE = c[0];
+  h->cT = c[1];
+  h->cA = c[2];
+  h->cW = c[3];
+  h->seg_len = 2 * (int64_t)h->cE + 2 * (int64_t)h->cT + 2 * (int64_t)h->cA + 5 * (int64_t)h->cW;
+  if (int rc = dalloc(h, &h->seg, (size_t)h->seg_len)) return rc;
+  if (int rc = dalloc(h, &h->gath, (size_t)h->seg_len * P)) return rc;
+  HIPCHK(h, hipMemsetAsync(h->seg, 0, (size_t)h->seg_len * 8, h->stream));  // the padding entries stay zero for good
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double* q = h->seg;
+  h->pE = q;
+  q += h->cE;
+  h->pE2 = q;
+  q += h->cE;
+  h->pEm[0] = q;
+  q += h->cW;
+  h->pEm[1] = q;
+  q += h->cW;
+  h->pS = q;
+  h->strT = h->cT;
+  q += 2 * h->cT;
+  h->pS2 = q;
+  h->strA = h->cA;
+  q += 2 * h->cA;
+  h->pW[0] = q;
+  q += h->cW;
+  h->pW[1] = q;
+  q += h->cW;
+  h->pE3 = q;
+  h->gather_ready = true;
   return 0;
 }
 
@@ -1590,7 +1806,8 @@ int check_ready(fpsq_handle h) {
     h->err = "Jacobian structure/values not set";
     return FPSQ_ERR_STATE;
   }
-  return 0;
+  hipSetDevice(h->opt.device);
+  return ensure_gather_layout(h);
 }
 
 // Device-resident arguments are produced on the caller's stream: everything queued there so far must be complete
@@ -2294,7 +2511,8 @@ int fpsq_qp_destroy(fpsq_qp qp) {
 
 namespace {
 // stand-alone form of qp_fx (sharded runs: the m-vector sums pass through an all-reduce first)
-__global__ __launch_bounds__(kBlock) void k_qp_fx(const FxArgs a) {
+__global__ __launch_bounds__(kBlock) void k_qp_fx(const FxArgs a, const LaneCtl* gate0, const LaneCtl* gate1) {
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   __shared__ double red[4];
   qp_fx(a, red);
 }
@@ -2332,76 +2550,80 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   // Fast start (single GPU, fused recurrences): the gradient kernel writes the long pair {g, x} itself and the LSQR
   // start-up product A u~_1, in which the CRAIG lane is otherwise parked, forms c = A x - b on the side: the separate
   // c = A x - b product and the right-hand-side loads of the start-up are not launched.
-  const bool fast = !h->comm && h->opt.fuse_two_rhs != 0;
+  const bool local_vec = !h->comm || h->halo;  // single GPU, or row-sharded with column windows (halo mode)
+  const bool fast = local_vec && h->opt.fuse_two_rhs != 0;
   hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1],
                      fast ? h->LP : (double*)nullptr, fast ? h->pE : (double*)nullptr, n_owned(h));
   h->launches++;
   if (!fast) spmv_const(h, TAG_A, 1.0, dx, -1.0, qp->b, h->c);  // c = A x - b
   // Single GPU with rho > 0: p1 = g - A'q1 and J'c (:424-428) share ONE two-right-hand-side product A'[q1, c], and
   // phi is reduced by an extra workgroup of the gradient kernel: 2 launches fewer at the end of every evaluation.
-  const bool paired = !h->comm && rho > 0.0;
+  // (halo mode: the same product, its overlap rows completed after the neighbour exchange; phi needs its all-reduce)
+  const bool paired = local_vec && rho > 0.0;
   // everything behind the two solves: enqueued speculatively (gated on the recurrences' `done` flags) by run_krylov when
   // the iteration count of the previous evaluation is known, else here
   TailFn epi = [&]() -> int {
     // ys = q1 + sigma q2 and the dots of objgrad!
-    hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pE, h->pE + kEwBlocksMax,
+    hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pC[0], h->pC[1],
                        paired ? h->SP : (double*)nullptr, h->gate0, h->gate1);
     h->launches++;
     FxArgs fa{};
     fa.pf = h->pQ[0];
     fa.pdx = h->pQ[1];
     fa.np_n = gn;
-    fa.pcy = h->pE;
-    fa.pcc = h->pE + kEwBlocksMax;
+    fa.pcy = h->pC[0];
+    fa.pcc = h->pC[1];
     fa.np_m = gm;
     fa.rho = rho;
     fa.eta = eta;
     fa.out = h->hscal_dev;
+    FxArgs none = fa;
+    none.out = nullptr;
     if (paired) {
-      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr);
-      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(gn + 1), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP, h->Cx, qp->q,
-                         (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, fa, h->gate0,
-                         h->gate1);
+      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), h->halo);
+      if (h->halo)
+        if (int rc = halo_finish<2>(h, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr)) return rc;
+      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(h->comm ? gn : gn + 1), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
+                         h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, h->comm ? none : fa,
+                         h->gate0, h->gate1);
       h->launches++;
     } else {
       if (rho > 0.0)
         if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
-      FxArgs none = fa;
-      none.out = nullptr;
       hipLaunchKernelGGL(k_qp_penalty_grad, dim3(h->comm ? gn : gn + 1), dim3(kBlock), 0, s, h->p1, h->g,
                          (const double*)nullptr, h->Cx, qp->q, h->jc, dx, dxk, sigma, rho, eta, h->gs, dgx, n,
                          h->comm ? none : fa, h->gate0, h->gate1);
-      if (h->comm) {  // c'ys and c'c are sums over the rank's rows only
-        PresumArgs P{};
-        P.p[0] = fa.pcy;
-        P.n[0] = gm;
-        P.p[1] = fa.pcc;
-        P.n[1] = gm;
-        if (h->halo) {  // f and ||x - xk||^2 are sums over the owned part of the rank's column window
-          P.p[2] = fa.pf;
-          P.n[2] = gn;
-          P.p[3] = fa.pdx;
-          P.n[3] = gn;
-        }
-        hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
-        if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
-        fa.pcy = h->comm_scal;
-        fa.pcc = h->comm_scal + 1;
-        fa.np_m = 1;
-        if (h->halo) {
-          fa.pf = h->comm_scal + 2;
-          fa.pdx = h->comm_scal + 3;
-          fa.np_n = 1;
-        }
-        hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa);
-        h->launches += 2;
-      }
       h->launches++;
+    }
+    if (h->comm) {  // phi: c'ys and c'c are sums over the rank's rows only
+      PresumArgs P{};
+      P.p[0] = fa.pcy;
+      P.n[0] = gm;
+      P.p[1] = fa.pcc;
+      P.n[1] = gm;
+      if (h->halo) {  // f and ||x - xk||^2 are sums over the owned part of the rank's column window
+        P.p[2] = fa.pf;
+        P.n[2] = gn;
+        P.p[3] = fa.pdx;
+        P.n[3] = gn;
+      }
+      hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
+      if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
+      fa.pcy = h->comm_scal;
+      fa.pcc = h->comm_scal + 1;
+      fa.np_m = 1;
+      if (h->halo) {
+        fa.pf = h->comm_scal + 2;
+        fa.pdx = h->comm_scal + 3;
+        fa.np_n = 1;
+      }
+      hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa, h->gate0, h->gate1);
+      h->launches += 2;
     }
     return 0;
   };
-  if (int rc = two_mixed_device(h, h->g, h->c, paired, fast ? qp->b : nullptr, h->comm ? nullptr : &epi)) return rc;
-  if (h->comm)
+  if (int rc = two_mixed_device(h, h->g, h->c, paired, fast ? qp->b : nullptr, local_vec ? &epi : nullptr)) return rc;
+  if (!local_vec)
     if (int rc = epi()) return rc;
   if (gx && dgx != gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
   if (ys) HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
@@ -2444,8 +2666,9 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
     h->launches += 2;
     return 0;
   };
-  if (int rc = two_least_squares_device(h, dv, h->in_n2, h->comm ? nullptr : &epi)) return rc;           // :542
-  if (h->comm)
+  const bool local_vec = !h->comm || h->halo;
+  if (int rc = two_least_squares_device(h, dv, h->in_n2, local_vec ? &epi : nullptr)) return rc;         // :542
+  if (!local_vec)
     if (int rc = epi()) return rc;
   if (dhv != Hv) HIPCHK(h, hipMemcpyAsync(Hv, dhv, nb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;
@@ -2540,8 +2763,15 @@ int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_righ
     return FPSQ_ERR_ARG;
   }
   hipSetDevice(h->opt.device);
+  if (h->gather_ready) {
+    h->err = "comm_set_halo: call before the first solve";
+    return FPSQ_ERR_STATE;
+  }
   if (h->halo_recv) dfree(h, &h->halo_recv);
+  if (h->halo_raw) dfree(h, &h->halo_raw);
   if (int rc = dalloc(h, &h->halo_recv, (size_t)(overlap_left + overlap_right) * 2)) return rc;
+  if (int rc = dalloc(h, &h->halo_raw, (size_t)(overlap_left + overlap_right) * 2)) return rc;
+  h->halo_gf = overlap_left + overlap_right > 0 ? ew_grid(overlap_left + overlap_right) : 0;
   h->halo = true;
   h->ovl = overlap_left;
   h->ovr = overlap_right;

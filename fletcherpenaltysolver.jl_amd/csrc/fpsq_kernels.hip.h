@@ -382,6 +382,15 @@ __device__ __forceinline__ bool run_fused_updates(const UpdSeg& u0, const UpdSeg
   return true;
 }
 
+// Halo mode of the row-sharded A' product (k_spmv<.., HALO>): the rows [0, lo) and [hi, nrows) of the product -- the two
+// regions of the rank's column window that a neighbour also contributes to -- are NOT finalised: their raw sums go to
+// raw[(r < lo ? r : lo + r - hi)][NL] (head region first) and k_halo_finish completes them once the neighbours' sums have
+// arrived.  Interior rows get the fused axpby + squared-norm epilogue exactly as on one GPU.
+struct HaloRows {
+  int64_t lo, hi;
+  double* raw;
+};
+
 // ------------------------------------------------------------------------------------------------ SpMV / SpMM
 //
 // out[r][l] = ca_l * sum_k vals[k] * x[colind[k]][l] + cb_l * yin[r][l],  partial[l][blk] = sum_r out[r][l]^2
@@ -396,11 +405,14 @@ __device__ __forceinline__ bool run_fused_updates(const UpdSeg& u0, const UpdSeg
 // col16 / colind then point to the padded arrays): the matrix stream needs neither the block descriptor (one link
 // less in the workgroup's chain of dependent memory round trips) nor bounds checks.  Requires that no block is a
 // long row.
-template <int NL, int TAG, bool IDX16 = false, bool PAD = false>
+// partials[l * pstride + L]: the lane stride of the partial array is the caller's (the workgroup count on one GPU; a
+// padded count common to all ranks when the arrays are all-gathered, see run_krylov).
+template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
-                                                 const LaneCtl* gate0, const LaneCtl* gate1) {
+                                                 const LaneCtl* gate0, const LaneCtl* gate1, int pstride,
+                                                 const HaloRows hr) {
   // exactly 32 KB of LDS for two right-hand sides (five workgroups fit the CU's 160 KB): the reduction scratch
   // aliases the head of the product buffer
   __shared__ double prod[kSpmvNnz * NL];
@@ -450,9 +462,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     for (int l = 0; l < NL; ++l) {
       const double t = block_sum(acc[l], red);
       if (tid == 0 && act[l]) {
-        const double o = ca[l] * t + (cb[l] != 0.0 ? cb[l] * yin[(size_t)r0 * NL + l] : 0.0);
-        yout[(size_t)r0 * NL + l] = o;
-        sq[l] = o * o;
+        if (HALO && (r0 < hr.lo || r0 >= hr.hi)) {
+          hr.raw[(size_t)(r0 < hr.lo ? r0 : hr.lo + (r0 - hr.hi)) * NL + l] = t;
+        } else {
+          const double o = ca[l] * t + (cb[l] != 0.0 ? cb[l] * yin[(size_t)r0 * NL + l] : 0.0);
+          yout[(size_t)r0 * NL + l] = o;
+          sq[l] = o * o;
+        }
       }
     }
   } else {
@@ -527,8 +543,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] += __shfl_down(acc[l], off, 64);
       }
-      if (valid && gl == 0)
-        row_epilogue<NL>((size_t)(r0 + rr), acc, ca, cb, act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
+      if (valid && gl == 0) {
+        const int64_t row = r0 + rr;
+        if (HALO && (row < hr.lo || row >= hr.hi)) {
+          double* dst = hr.raw + (size_t)(row < hr.lo ? row : hr.lo + (row - hr.hi)) * NL;
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+            if (act[l]) dst[l] = acc[l];
+        } else {
+          row_epilogue<NL>((size_t)row, acc, ca, cb, act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
+        }
+      }
     }
   }
   if (partials != nullptr) {
@@ -536,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     block_sum_lanes<NL>(sq, red);
     if (tid == 0) {
 #pragma unroll
-      for (int l = 0; l < NL; ++l) partials[(size_t)l * A.nblk + L] = sq[l];
+      for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + L] = sq[l];
     }
   }
 }
@@ -593,7 +618,8 @@ template <int NL, bool PAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                       double* partials, int grp_per_xcd, const UpdSeg u0,
-                                                      const UpdSeg u1, const LaneCtl* gate0, const LaneCtl* gate1) {
+                                                      const UpdSeg u1, const LaneCtl* gate0, const LaneCtl* gate1,
+                                                      int pstride) {
   __shared__ double prod[kRgcsTile * NL];
   double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
@@ -708,7 +734,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     block_sum_lanes<NL>(sq, red);
     if (tid == 0) {
 #pragma unroll
-      for (int l = 0; l < NL; ++l) partials[(size_t)l * M.ng + g] = sq[l];
+      for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + g] = sq[l];
     }
   }
 }
@@ -809,6 +835,66 @@ __global__ __launch_bounds__(kBlock) void k_halo_add(double* vec, const double* 
   }
 }
 
+// Halo mode, second half of the row-sharded A' product.  k_spmv<.., HALO> finalised the interior rows of the rank's column
+// window and left the raw sums of its two overlap regions in `raw` ([tl + tr][NL], head region first); `recv` holds the
+// neighbours' raw sums of the same global columns (same layout).  Here, for the overlap rows,
+//   yout[row] = ca * (raw + recv) + cb * yin[row]      (a + b on one rank, b + a on the other: bitwise identical)
+// with the squared-norm partials of the HEAD region only (owned by this rank; the tail region is owned -- and counted --
+// by the right neighbour).  partials[l * pstride + blockIdx.x], may be null.
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_halo_finish(const double* __restrict__ raw, const double* __restrict__ recv,
+                                                        int64_t tl, int64_t tr, int64_t tail0, const double* yin,
+                                                        double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
+                                                        double* partials, int pstride, const LaneCtl* gate0,
+                                                        const LaneCtl* gate1) {
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
+  const LaneCtl* c[2] = {ctl0, ctl1};
+  bool act[NL];
+  double ca[NL], cb[NL];
+  bool any = false;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    act[l] = !(c[l]->done | c[l]->skip);
+    ca[l] = c[l]->ca;
+    cb[l] = c[l]->cb;
+    any |= act[l];
+  }
+  if (!any) return;
+  __shared__ double red[4];
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < tl + tr; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = i < tl ? i : tail0 + (i - tl);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!act[l]) continue;
+      const double o = ca[l] * (raw[i * NL + l] + recv[i * NL + l]) + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0);
+      yout[row * NL + l] = o;
+      if (i < tl) sq[l] += o * o;
+    }
+  }
+  if (partials != nullptr) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double t = block_sum(sq[l], red);
+      if (threadIdx.x == 0) partials[(size_t)l * pstride + blockIdx.x] = t;
+    }
+  }
+}
+
+// recv[r * count + i] = src_r[i]: the in-process all-gather over the logical shards of one GPU (LocalComm)
+struct GatherSrc {
+  const double* s[8];
+  int32_t n;
+};
+__global__ __launch_bounds__(kBlock) void k_local_allgather(GatherSrc S, double* recv, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < (int64_t)S.n * count; i += (int64_t)gridDim.x * kBlock) {
+    const int r = (int)(i / count);
+    recv[i] = S.s[r][i - (int64_t)r * count];
+  }
+}
+
 // out = a * P + b * y (plain vectors, host-given constants), for the p1 = g - A'q1 and J'c products
 __global__ __launch_bounds__(kBlock) void k_axpby_plain(const double* __restrict__ P, double a, const double* y,
                                                         double b, double* out, int64_t len) {
@@ -861,11 +947,9 @@ __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q
     const double xi = x[i], qi = q[i], di = d[i];
     const double gi = qi * xi + di;
     g[i] = gi;
-    if (lp) {
-      *reinterpret_cast<double2*>(lp + 2 * i) = make_double2(gi, xi);
-      gg += gi * gi;
-    }
+    if (lp) *reinterpret_cast<double2*>(lp + 2 * i) = make_double2(gi, xi);
     if (i < n_sum) {  // (halo mode: sums over the rank's owned prefix of its column window)
+      if (lp) gg += gi * gi;
       f += xi * (0.5 * qi * xi + di);
       if (xk) {
         const double t = xi - xk[i];

@@ -765,6 +765,11 @@ struct StepArgs {
   int32_t n0, n1;
   Progress* prog;
   fpsq_stats* host_stats;  // host-mapped: the step that ends the recurrence leaves the final stats there (no copy)
+  // Row-sharded runs in halo mode: p0 / p1 point into an ALL-GATHERED buffer holding `nseg` ranks' copies of the array,
+  // `seg_stride` doubles apart, n0 / n1 entries each (zero-padded to a count common to all ranks).  Every rank sums the
+  // same numbers in the same (rank-major) order: the replicated scalars stay bitwise identical whatever reduction
+  // algorithm the collective library would use.  nseg <= 1: one plain array.
+  int32_t nseg, seg_stride;
 };
 
 // 256 threads: the <= ~5000 norm partials are still summed with a few batches of independent loads per thread, and a
@@ -787,6 +792,74 @@ __device__ __forceinline__ double partial_batch(const double* p, int base, int n
 #pragma unroll
   for (int u = 0; u < U; ++u) a += (base + u * kStepThreads + t < n) ? v[u] : 0.0;
   return a;
+}
+
+// the same for entries [base, base + U * kStepThreads) of a flattened [nseg][n] array whose segments lie `stride` doubles
+// apart (one integer division per thread, then incremental index arithmetic)
+template <int U>
+__device__ __forceinline__ double seg_batch(const double* p, int n, int nseg, int stride, int base, int t) {
+  const int total = nseg * n;
+  int j = base + t;
+  int sg = j / n, i = j - sg * n;
+  const int q = kStepThreads / n, r = kStepThreads - q * n;
+  double v[U];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    ok[u] = j < total;
+    v[u] = p[ok[u] ? (size_t)sg * stride + i : 0];
+    j += kStepThreads;
+    i += r;
+    sg += q;
+    if (i >= n) {
+      i -= n;
+      ++sg;
+    }
+  }
+  double a = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) a += ok[u] ? v[u] : 0.0;
+  return a;
+}
+
+__device__ __forceinline__ void block_reduce_two(double a, double b, double* red, double& s0, double& s1) {
+  const int t = threadIdx.x;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = t & 63, w = t >> 6;
+  if (lane == 0) {
+    red[w] = a;
+    red[16 + w] = b;
+  }
+  __syncthreads();
+  if (t == 0) {
+    s0 = 0.0;
+    s1 = 0.0;
+    for (int k = 0; k < kStepThreads / 64; ++k) {
+      s0 += red[k];
+      s1 += red[16 + k];
+    }
+  }
+}
+
+// all-gathered arrays (StepArgs::nseg > 1)
+__device__ __forceinline__ void reduce_two_seg(const double* p0, int n0, const double* p1, int n1, int nseg, int stride,
+                                               double* red, double& s0, double& s1) {
+  double a = 0.0, b = 0.0;
+  const int t = threadIdx.x;
+  const int t0 = nseg * n0, t1 = nseg * n1;
+  if (t0 > 0 && t0 <= kStepThreads * 24 && t1 <= kStepThreads * 4) {  // one batch of loads
+    const double x = t0 <= kStepThreads * 8 ? seg_batch<8>(p0, n0, nseg, stride, 0, t) : seg_batch<24>(p0, n0, nseg, stride, 0, t);
+    const double y = t1 > 0 ? seg_batch<4>(p1, n1, nseg, stride, 0, t) : 0.0;
+    a = x;
+    b = y;
+  } else {
+    if (n0 > 0)
+      for (int base = 0; base < t0; base += kStepThreads * 8) a += seg_batch<8>(p0, n0, nseg, stride, base, t);
+    if (n1 > 0)
+      for (int base = 0; base < t1; base += kStepThreads * 8) b += seg_batch<8>(p1, n1, nseg, stride, base, t);
+  }
+  block_reduce_two(a, b, red, s0, s1);
 }
 
 __device__ __forceinline__ void reduce_two(const double* p0, int n0, const double* p1, int n1, double* red,
@@ -862,7 +935,9 @@ __global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1)
   const unsigned long long* gsrc = reinterpret_cast<const unsigned long long*>(a.state);
   if ((int)threadIdx.x < nq) st[threadIdx.x] = gsrc[threadIdx.x];
   double s0 = 0.0, s1 = 0.0;
-  reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);  // contains the workgroup barrier that publishes `st`
+  // (contains the workgroup barrier that publishes `st`)
+  if (a.nseg > 1) reduce_two_seg(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, a.nseg, a.seg_stride, red, s0, s1);
+  else reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);
   if (threadIdx.x == 0) {
     void* S = st;
     switch (a.kind) {
