@@ -116,6 +116,7 @@ SYMBOLS = [
     ("fpsq_band_get_info", C.c_int, [_VP, C.POINTER(BandInfo)]),
     ("fpsq_get_info", C.c_int, [_VP, C.POINTER(Info)]),
     ("fpsq_set_profiling", C.c_int, [_VP, _I32]),
+    ("fpsq_debug_expect_iterations", C.c_int, [_VP, _I64]),
 ]
 
 _LIB = None

@@ -337,6 +337,7 @@ struct fpsq_solver_s {
   bool tail_was_run = false;   // the caller's epilogue was enqueued (gated) inside run_krylov and the gates were open
   int64_t expect_iters[5][5] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
   bool adaptive_runahead = true;    // FPSQ_ADAPTIVE_RUNAHEAD=0 disables (A/B)
+  int64_t force_expect = -1;        // fpsq_debug_expect_iterations: overrides the expected count of the next run (test hook)
 
   // instrumentation
   bool profile = false;
@@ -1246,7 +1247,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   int64_t* expect_slot = &h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
   // (sharded: only in halo mode, where every rank derives the same count from the replicated recurrence state)
   const bool local_vec = !h->comm || h->halo;  // vector updates touch rank-local data only
-  const int64_t expect = (h->adaptive_runahead && local_vec) ? *expect_slot : 0;
+  int64_t expect_v = (h->adaptive_runahead && local_vec) ? *expect_slot : 0;
+  if (h->force_expect >= 0 && local_vec) expect_v = h->force_expect;
+  h->force_expect = -1;
+  const int64_t expect = expect_v;
   const int32_t pub_from = (int32_t)std::min<int64_t>(expect, INT32_MAX);
   LsqrState* lsS[2] = {nullptr, nullptr};
   LsqrParams lsP[2] = {};
@@ -2781,6 +2785,12 @@ int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_righ
 int fpsq_get_info(fpsq_handle h, fpsq_info* info) {
   if (!h || !info) return FPSQ_ERR_ARG;
   *info = h->info;
+  return FPSQ_OK;
+}
+
+int fpsq_debug_expect_iterations(fpsq_handle h, int64_t expect) {
+  if (!h) return FPSQ_ERR_ARG;
+  h->force_expect = expect;
   return FPSQ_OK;
 }
 

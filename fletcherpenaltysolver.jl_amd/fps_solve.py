@@ -99,13 +99,15 @@ def _same(a, b):
 
 # ------------------------------------------------------------------ sub-problem solvers (unconstrained min of phi)
 
-def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
+def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7, deadline=None):
     """Limited-memory BFGS with an Armijo backtracking line search.  Returns (x, status, g)."""
     g = _empty_like(x)
     f, _ = fp.objgrad_(x, g)
     tol = atol + rtol * _nrminf(g)
     S, Y = [], []
     for it in range(max_iter):
+        if deadline is not None and time.perf_counter() > deadline:  # the caller's max_time (Stopping.jl hands it to the sub-solver)
+            return x, "max_time", g
         if _nrminf(g) <= tol:
             return x, "optimal", g
         if f < -unbounded_below:
@@ -128,15 +130,20 @@ def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
             d, slope = -g, -_dot(g, g)
         t = 1.0 if S else min(1.0, 1.0 / max(_nrm2(g), 1e-16))
         gn = _empty_like(x)
+        # Armijo up to the rounding of phi itself (close to a solution the decrease g's ~ |g|^2 / |H| drops below
+        # eps |phi| long before |g| reaches the tolerance: a plain test then rejects every step, or accepts a null one)
+        fnoise = 10.0 * np.finfo(float).eps * max(abs(f), 1.0)
         for _ in range(60):
             xn = x + t * d
             fn, _ = fp.objgrad_(xn, gn)
-            if np.isfinite(fn) and fn <= f + 1e-4 * t * slope:
+            if np.isfinite(fn) and fn <= f + 1e-4 * t * slope + fnoise:
                 break
             t *= 0.5
         else:
             return x, "stalled", g
         s, y = xn - x, gn - g
+        if _nrm2(s) <= np.finfo(float).eps * max(1.0, _nrm2(x)):  # a null step: no way forward from here
+            return x, "stalled", g
         if _dot(s, y) > 1e-12 * _nrm2(s) * _nrm2(y):
             S.append(s)
             Y.append(y)
@@ -147,7 +154,7 @@ def _lbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
     return x, "max_iter", g
 
 
-def _plbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
+def _plbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7, deadline=None):
     """Bound-constrained sub-problem  min phi(x), lvar <= x <= uvar  (the role `tron` / `ipopt` play for the reference when
     the model has bounds, src/parameters.jl:84, :323): limited-memory BFGS on the free variables with a projected Armijo
     search along P(x + t d).  `fp.bounds = (lvar, uvar)`.  Stops on the projected gradient x - P(x - g) (optim_check_bounded).
@@ -161,6 +168,8 @@ def _plbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
     tol = atol + rtol * _nrminf(pg)
     S, Y = [], []
     for it in range(max_iter):
+        if deadline is not None and time.perf_counter() > deadline:  # the caller's max_time (Stopping.jl hands it to the sub-solver)
+            return x, "max_time", g
         pg = x - proj(x - g)
         if _nrminf(pg) <= tol:
             return x, "optimal", g
@@ -205,7 +214,7 @@ def _plbfgs(fp, x, atol, rtol, max_iter, unbounded_below, mem=7):
     return x, "max_iter", g
 
 
-def _trunk(fp, x, atol, rtol, max_iter, unbounded_below):
+def _trunk(fp, x, atol, rtol, max_iter, unbounded_below, deadline=None):
     """Trust-region Newton-CG (Steihaug-Toint) on hprod!.  Returns (x, status, g)."""
     n = x.shape[0]
     g = _empty_like(x)
@@ -214,6 +223,8 @@ def _trunk(fp, x, atol, rtol, max_iter, unbounded_below):
     radius = max(1.0, 0.1 * _nrm2(g))
     Hd = _empty_like(x)
     for it in range(max_iter):
+        if deadline is not None and time.perf_counter() > deadline:  # the caller's max_time (Stopping.jl hands it to the sub-solver)
+            return x, "max_time", g
         gnorm = _nrm2(g)
         if _nrminf(g) <= tol:
             return x, "optimal", g
@@ -288,9 +299,9 @@ class _HostPenalty:
         self.fp.shahx = None  # phi changed: the memo of _compute_ys_gs! is stale
 
     def state(self, x):
-        """(f(x), ||c(x)||_2, ys(x)) -- memoised: no new solve when x was the last point evaluated."""
+        """(f(x), ||c(x)||_2, ys(x), ||c(x)||_inf) -- memoised: no new solve when x was the last point evaluated."""
         self.fp._compute_ys_gs(x)
-        return self.fp.fx, _nrm2(self.fp.cx), self.fp.ys
+        return self.fp.fx, _nrm2(self.fp.cx), self.fp.ys, _nrminf(self.fp.cx)
 
     def primal_inf(self, x):
         c = self.nlp.cons(x)
@@ -469,8 +480,8 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose, callback=
         it += 1
         x_prev = x
         xs, sub_status, res = sub(pen, _copy(x), sub_atol, sub_rtol, meta.subsolver_max_iter,
-                                  meta.subpb_unbounded_threshold)
-        fx_user, ncx, ys = pen.state(xs)
+                                  meta.subpb_unbounded_threshold, deadline=t_start + max_time)
+        fx_user, ncx, ys, ncx_inf = pen.state(xs)
         unb_mult = _nrminf(ys) >= meta.lagrange_bound
         feas = ncx < feas_tol
         if sub_status == "optimal":                      # algo.jl:121-151 (taken whatever the multiplier bound says)
@@ -487,7 +498,7 @@ def _outer_loop(pen, x, meta, atol, rtol, max_iter, max_time, verbose, callback=
         elif sub_status == "unbounded" or unb_mult:                                             # :152-160
             stalling = unsuccessful = 0
             unbounded += 1
-            if feas:
+            if ncx_inf < feas_tol:                      # :156-157 (the Inf-norm here, the 2-norm everywhere else)
                 status = "unbounded"
                 break
         else:                                                                                   # :161-181
@@ -638,7 +649,8 @@ class _DevicePenalty:
         if self._at is None or self._at is not x:
             self.objgrad_(x, self.scratch)
         f = float(0.5 * (x @ (self.q * x)) + self.d @ x)
-        return f, _nrm2(self._cons(x)), self.ys
+        c = self._cons(x)
+        return f, _nrm2(c), self.ys, _nrminf(c)
 
     def primal_inf(self, x):
         return _nrminf(self._cons(x))

@@ -28,6 +28,8 @@ class QDSolver:
         raise NotImplementedError
 
 
+REG_DROP = 1e200  # include/fpsq.h FPSQ_REG_DROP: a vanishing pivot of M is dropped (its multiplier comes out as zero)
+
 class FpsqError(RuntimeError):
     pass
 
@@ -153,9 +155,17 @@ class HIPDirectQDSolver(QDSolver):
     SYRK + blocked Cholesky) and solves both systems with two right-hand sides; like `ldl_factorize!` it refactorises
     on every `solve_two_mixed` (src/solve_linear_system.jl:233-234) and re-uses the factors in
     `solve_two_least_squares` (:194-195).  A non positive definite M only warns (:244-246).
-    Keywords of `LDLtSolver` (struct.jl:308-316): ldlt_tol = sqrt(eps), ldlt_r2 = -sqrt(eps) drive the DYNAMIC
-    REGULARISATION of the factorisation (a vanishing pivot of M is replaced by -ldlt_r2; ldlt_r1 concerns the identity
-    block of K, whose pivots are 1 and never regularised).  Dense storage: m <= 65536."""
+    Keywords of `LDLtSolver` (struct.jl:308-316): ldlt_tol (sqrt(eps)) and ldlt_r2 drive the DYNAMIC REGULARISATION of
+    the factorisation; ldlt_r1 concerns the identity block of K, whose pivots are 1 and never regularised.  A pivot of M
+    not above ldlt_tol marks a constraint row that depends linearly on the earlier ones at working precision.
+    * ldlt_r2 given: the pivot is replaced by -ldlt_r2 -- the value LDLFactorizations.jl puts in the (2,2) block of K.
+    * ldlt_r2 = None (default): the pivot is DROPPED (replaced by FPSQ_REG_DROP = 1e200: that row's multiplier comes out
+      as zero, the basic solution of the consistent normal equations).  The reference's -sqrt(eps) acts on pivots of K in a
+      fill-reducing order (on FLT, test/test-2.jl:264-287, AMD eliminates both constraint nodes first, which amounts to the
+      uniform shift M + sqrt(eps) I); the same number on a pivot of M in natural order is NOT the same rule, and either way
+      the multiplier estimates grow like 1 / sqrt(eps) on an inconsistent right-hand side (phi ~ 1e10 at FLT's x0: the
+      Newton-CG sub-solver crawls).  Dropping keeps them bounded like the exact back-end's minimum-norm solve; all of
+      test-2.jl and rank-deficient.jl then pass with every sub-solver.  Dense storage: m <= 65536."""
 
     def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, ldlt_tol=None, ldlt_r1=None, ldlt_r2=None,
                  **kwargs):
@@ -176,7 +186,7 @@ class HIPDirectQDSolver(QDSolver):
         self.factorized = False
         se = float(np.sqrt(np.finfo(float).eps))
         self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)        # struct.jl:312
-        self.ldlt_r2 = -se if ldlt_r2 is None else float(ldlt_r2)          # struct.jl:314
+        self.ldlt_r2 = -REG_DROP if ldlt_r2 is None else float(ldlt_r2)    # struct.jl:314 (None: drop, see the docstring)
         self._check(self._lib.fpsq_dense_set_regularization(self._d, self.ldlt_tol, -self.ldlt_r2))
         self._fact_key = None
 
@@ -283,7 +293,7 @@ class HIPBandedDirectQDSolver(QDSolver):
         self._b = b
         se = float(np.sqrt(np.finfo(float).eps))
         self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)
-        self.ldlt_r2 = -se if ldlt_r2 is None else float(ldlt_r2)
+        self.ldlt_r2 = -REG_DROP if ldlt_r2 is None else float(ldlt_r2)    # (None: drop, see HIPDirectQDSolver)
         self._check(self._lib.fpsq_band_set_regularization(b, self.ldlt_tol, -self.ldlt_r2))
         self.factorized = False
         self._fact_key = None

@@ -245,7 +245,12 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t *info);
  * d <= tol -- minus d is the pivot of the (2,2) block of K = [I A'; A -delta I] once the identity block is eliminated
  * (its pivots are 1: r1 never fires) -- is replaced by `reg` = -r2 and counted (fpsq_dense_info.regularized_pivots); the
  * factorisation then succeeds on rank-deficient Jacobians (test/rank-deficient.jl) instead of reporting a non-positive
- * pivot.  reg <= 0 switches it off (the default).  `tol` is absolute, like the scaled threshold the reference uses. */
+ * pivot.  reg <= 0 switches it off (the default).  `tol` is absolute, like the scaled threshold the reference uses.
+ * reg = FPSQ_REG_DROP drops the pivot instead: the row counts as linearly dependent on the earlier ones, its multiplier comes
+ * out as (numerically) zero and the other rows solve the consistent part of the normal equations -- multiplier estimates
+ * stay bounded on rank-deficient Jacobians (test/test-2.jl:264-287 FLT), where a pivot of sqrt(eps) makes them ~ 1/sqrt(eps).
+ * The host bindings use it when the caller gives no ldlt_r2. */
+#define FPSQ_REG_DROP 1e200
 int fpsq_dense_set_regularization(fpsq_dense d, double tol, double reg);
 int fpsq_dense_solve_two_mixed(fpsq_dense d, const double *rhs1, const double *rhs2, double *p1, double *q1, double *p2,
                                double *q2);
@@ -321,6 +326,13 @@ int fpsq_get_info(fpsq_handle h, fpsq_info *info);
 /* on != 0: bracket every SpMV/SpMM launch with HIP events on the solver's stream so that last_spmv_ms is filled
  * (adds event records between kernels; leave off when timing whole evaluations) */
 int fpsq_set_profiling(fpsq_handle h, int32_t on);
+
+/* Test hook for the run-ahead heuristics of the Krylov loop.  A solve normally enqueues the iterations of the PREVIOUS call
+ * of the same kind without looking at the device and, right behind them, its final vector update and the caller's epilogue
+ * kernels gated on the recurrences' `done` flags (csrc/fpsq.hip run_krylov).  This call overrides that expected count for
+ * the NEXT solve call of the handle only (expect >= 0; 0 = "unknown": no speculation), so that tests can place the
+ * speculation before, at and behind the true iteration count deterministically.  Results never depend on it. */
+int fpsq_debug_expect_iterations(fpsq_handle h, int64_t expect);
 
 const char *fpsq_version(void);
 

@@ -52,13 +52,10 @@ def test_reference_integration_problems(name, qds, sub, ha):
     deficient Jacobian: the direct back-end goes through its dynamic pivot regularisation, the reference's
     ldlt_tol / ldlt_r2) through both MI355X back-ends, with the reference's acceptance bounds.  The models are ADModels
     (torch.autograd on the host, where the reference uses ADNLPModels.jl).  The reference runs these tests with its
-    default (direct) back-end only; the iterative back-end is exercised with the first-order sub-solver (on FLT, whose
-    Jacobian [2 x1 0; 3 x1^2 0] loses rank at the solution, Krylov at the default sqrt(eps) tolerances leaves the
-    Newton-CG sub-solver with Val(1) crawling: 4e4 evaluations without reaching 1e-6 -- not asserted)."""
-    if name == "flt" and sub == "trunk":
-        pytest.skip("FLT (multiplier estimates unbounded by construction, Jacobian of rank <= 1): with the regularised "
-                    "pivot of the direct back-end the built-in Newton-CG sub-solver crawls (> 1e4 evaluations); asserted "
-                    "with L-BFGS here and with Newton-CG on the exact-KKT back-end in the CPU suite")
+    default (direct) back-end only; the iterative back-end is exercised with the first-order sub-solver.  FLT (Jacobian
+    [2 x1 0; 3 x1^2 0]: rank <= 1 everywhere, 0 at the solution) passes with Newton-CG on the direct back-end because a
+    vanishing pivot is dropped (HIPDirectQDSolver docstring): with the pivot set to sqrt(eps) phi(x0) ~ 1e10 and the
+    sub-solver crawled (round 2 skipped the case)."""
     nlp = nlpmodels.reference_test_problems()[name]
     stats = fps_solve(nlp, nlp.meta.x0, qds_solver=qds, subproblem_solver=sub, hessian_approx=ha, max_time=120)
     _accept(stats, nlp.meta.x0)

@@ -734,6 +734,51 @@ def test_speculative_epilogue_is_bitwise_neutral(monkeypatch):
     dev.close()
 
 
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_speculative_epilogue_every_alignment_is_bitwise_neutral(delta):
+    """The same property, deterministically: fpsq_debug_expect_iterations places the speculation (gated final LSQR update +
+    gated epilogue kernels) at EVERY position relative to the true iteration counts of the two lanes -- before the first
+    lane ends, between the two ends, exactly at the last end (the hit), behind it -- for objgrad (LSQR + CRAIG lanes, the
+    paired two-RHS epilogue product), hprod (two LSQR lanes, the single-RHS epilogue products), solve_two_mixed and
+    solve_two_least_squares (no caller epilogue).  Every result must be bitwise the one of a handle that never speculates
+    (round 2 saw an intermittent mismatch in the hprod leg with an experimental A' kernel that also replaced the single-RHS
+    instantiation only that leg runs; this test pins the kept host logic independently of timing)."""
+    qp = _small_pde(seed=7, n=3000, m=300)
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    lib = dev._lib
+    rng = np.random.default_rng(1)
+    x = qp.xhat + 0.3 * rng.standard_normal(qp.n)
+    v = rng.standard_normal(qp.n)
+    g, c = qp.qdiag * x + qp.d, qp.scipy_csr() @ x - qp.b
+
+    def run(model, which):
+        if which == "objgrad":
+            gx, ys = np.empty(qp.n), np.empty(qp.m)
+            f, rc = model.objgrad(x, gx=gx, ys=ys)
+            return (np.array([f]), gx, ys), rc
+        if which == "hprod":
+            hv = np.empty(qp.n)
+            return (hv,), model.hprod(v, hv)
+        o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+        rc = model.solve_two_mixed(g, c, *o) if which == "mixed" else model.solve_two_least_squares(g, v, *o)
+        return tuple(o), rc
+
+    for which in ("objgrad", "hprod", "mixed", "lsq"):
+        lib.fpsq_debug_expect_iterations(ref._h, 0)  # never speculates
+        want, rc0 = run(ref, which)
+        its = (ref.stats[0].niter, ref.stats[1].niter)
+        assert min(its) >= 2, its
+        for e in range(0, max(its) + 4):
+            assert lib.fpsq_debug_expect_iterations(dev._h, e) == 0
+            got, rc = run(dev, which)
+            assert rc == rc0 and (dev.stats[0].niter, dev.stats[1].niter) == its, (which, e)
+            for a_, b_ in zip(want, got):
+                assert np.array_equal(a_, b_), (which, e, its)
+    ref.close()
+    dev.close()
+
+
 # ---------------------------------------------------------------------------------------------- row sharding
 
 @pytest.mark.parametrize("nshards", [2, 3])
