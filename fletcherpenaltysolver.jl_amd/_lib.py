@@ -78,6 +78,7 @@ SYMBOLS = [
     ("fpsq_set_jacobian_structure_csr", C.c_int, [_VP, _DP, _DP]),
     ("fpsq_set_jacobian_values", C.c_int, [_VP, _DP]),
     ("fpsq_set_input_stream", C.c_int, [_VP, _I32, _VP]),
+    ("fpsq_set_output_ordering", C.c_int, [_VP, _I32]),
     ("fpsq_set_delta", C.c_int, [_VP, _D]),
     ("fpsq_solve_two_mixed", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP, C.POINTER(Stats)]),
     ("fpsq_solve_two_least_squares", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP, C.POINTER(Stats)]),

@@ -337,6 +337,26 @@ struct fpsq_solver_s {
   bool tail_was_run = false;   // the caller's epilogue was enqueued (gated) inside run_krylov and the gates were open
   int64_t expect_iters[5][5] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
   bool adaptive_runahead = true;    // FPSQ_ADAPTIVE_RUNAHEAD=0 disables (A/B)
+  // FPSQ_HOST_TRACE=1: host timestamps at fixed points of fpsq_qp_objgrad, averaged and printed at destroy (developer aid)
+  bool host_trace = false;
+  double ht_sum[12] = {};
+  int64_t ht_calls = 0;
+  std::chrono::steady_clock::time_point ht_last, ht_exit;
+  bool ht_have_exit = false;
+  // start-up launch of the next run also evaluates the eq-QP gradient (qp_objgrad's fast start): nblk > 0
+  QpGradArgs startup_qg{};
+  // The final LSQR x update may be left to the caller's epilogue when its FIRST kernel is k_ys (absorb_flush, set by
+  // qp_objgrad): run_krylov then parks the segment here instead of launching it.
+  bool absorb_flush = false;
+  UpdSeg pending_flush{};
+  // stream-ordered outputs (fpsq_set_output_ordering)
+  bool out_ordered = false;
+  hipEvent_t ev_out = nullptr;
+  double call_seq = 0.0;            // sequence number the phi reduction stores behind its results (hscal[3])
+  // FPSQ_AB_MASK (developer A/B, tools/ab_modes.py): 1 = gradient kernel not merged into the start-up launch, 2 = final
+  // LSQR update not absorbed by k_ys, 4 = phi reduced by the gradient kernel's extra workgroup, 8 = no stream-ordered return
+  int ab_mask = 0;
+  bool ab_dynamic = false;          // FPSQ_AB_DYNAMIC=1: the mask is re-read from the environment at every qp_objgrad call
   int64_t force_expect = -1;        // fpsq_debug_expect_iterations: overrides the expected count of the next run (test hook)
 
   // instrumentation
@@ -714,6 +734,14 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
 
 // ------------------------------------------------------------------ launch helpers
 
+inline void ht_mark(fpsq_handle h, int k) {
+  if (!h->host_trace) return;
+  const auto now = std::chrono::steady_clock::now();
+  h->ht_sum[k] += std::chrono::duration<double>(now - h->ht_last).count();
+  h->ht_last = now;
+}
+
+
 enum { TAG_A = 0, TAG_AT = 1 };
 
 // Profiled product launches attach the event pair to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time
@@ -1039,7 +1067,8 @@ struct LoadSeg {
 template <int NL>
 __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0, LsqrState* S1, LsqrParams P1, CraigState* C,
                                                     CraigParams PC, MinresState* M, MinresParams PM, LnlqState* Q,
-                                                    LnlqParams PQ, LoadSeg l0, LoadSeg l1, ZeroArgs z, int nzblk) {
+                                                    LnlqParams PQ, LoadSeg l0, LoadSeg l1, ZeroArgs z, int nzblk,
+                                                    const QpGradArgs qg) {
   __shared__ double red[4];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (S0) lsqr_set_params(S0, P0);
@@ -1048,7 +1077,14 @@ __global__ __launch_bounds__(kBlock) void k_startup(LsqrState* S0, LsqrParams P0
     if (M) minres_set_params(M, PM);
     if (Q) lnlq_set_params(Q, PQ);
   }
-  int blk = blockIdx.x;
+  // qp_objgrad's fast start: the first qg.nblk workgroups evaluate g = q .* x + d, write the long pair {g, x} and the
+  // partial sums of f and ||g||^2 (the user-model evaluation of _compute_ys_gs!, model:238-240) -- one launch, no
+  // kernel boundary between the model evaluation and the start-up of the recurrences
+  if ((int)blockIdx.x < qg.nblk) {
+    qp_grad_body(qg, blockIdx.x, red);
+    return;
+  }
+  int blk = blockIdx.x - qg.nblk;
   if (blk < l0.nblk + l1.nblk) {
     const bool first = blk < l0.nblk;
     if (!first) blk -= l0.nblk;
@@ -1374,8 +1410,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       nzblk = gn;
     }
   }
-  hipLaunchKernelGGL(k_startup<NL>, dim3(ld[0].nblk + ld[1].nblk + nzblk), dim3(kBlock), 0, s, lsS[0], lsP[0], lsS[1], lsP[1],
-                     crS, crP, mrS, mrP, lqS, lqP, ld[0], ld[1], z, nzblk);
+  ht_mark(h, 3);
+  hipLaunchKernelGGL(k_startup<NL>, dim3(h->startup_qg.nblk + ld[0].nblk + ld[1].nblk + nzblk), dim3(kBlock), 0, s, lsS[0],
+                     lsP[0], lsS[1], lsP[1], crS, crP, mrS, mrP, lqS, lqP, ld[0], ld[1], z, nzblk, h->startup_qg);
+  h->startup_qg.nblk = 0;
   h->launches++;
   // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
   // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
@@ -1540,11 +1578,13 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         seg[ns] = lsqr_upd_seg(l, it);
         seg[ns++].gate = lanes[NL - 1 - l].ctl;  // the other lane of the call (NL = 1: itself)
       }
-    launch_updates<NL>(h, seg[0], seg[1], seg_none());
+    if (h->absorb_flush && ns == 1) h->pending_flush = seg[0];  // applied by the tail's first kernel (k_ys)
+    else launch_updates<NL>(h, seg[0], seg[1], seg_none());
     h->gate0 = lanes[0].ctl;
     h->gate1 = lanes[NL - 1].ctl;
     const int rc = (*tail)();
     h->gate0 = h->gate1 = nullptr;
+    h->pending_flush.kind = UPD_NONE;
     if (rc) return rc;
     spec_it = it;
     return 0;
@@ -1714,6 +1754,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter + lag(l));
     *expect_slot = e;
   }
+  ht_mark(h, 4);
   if (spec_it >= 0 && spec_it == it && all_done()) {
     // every recurrence ended at or before the iteration the speculative flush + tail were enqueued behind: their gates
     // were open, the call's epilogue is already in the stream
@@ -1731,7 +1772,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       seg[1] = winit[1];
     }
     // MINRES: stage E3 and the stopping tests of the last enqueued iteration (no-ops when it ended earlier)
-    launch_updates<NL>(h, seg[0], seg[1], minres_lane >= 0 && it >= 1 ? minres_seg(3, it, SPcur) : seg_none());
+    if (h->absorb_flush && tail != nullptr && ns == 1 && it >= 1 && minres_lane < 0)
+      h->pending_flush = seg[0];  // the caller's epilogue starts with k_ys, which applies it
+    else
+      launch_updates<NL>(h, seg[0], seg[1], minres_lane >= 0 && it >= 1 ? minres_seg(3, it, SPcur) : seg_none());
     if (minres_lane >= 0 && it >= 1)
       if (int rc = launch_step(h, step_args(STEP_MINRES_C, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
                                             prog[minres_lane]),
@@ -1823,6 +1867,9 @@ void order_inputs(fpsq_handle h) {
 }
 
 void call_begin(fpsq_handle h) {
+  h->absorb_flush = false;
+  h->pending_flush.kind = UPD_NONE;
+  h->startup_qg.nblk = 0;
   h->launches = 0;
   h->spmv_launches = 0;
   h->prod_a[0] = h->prod_a[1] = h->prod_at[0] = h->prod_at[1] = 0;
@@ -1853,6 +1900,41 @@ int call_end(fpsq_handle h) {
     sp += t;
   }
   h->info.last_spmv_ms = sp;
+  return 0;
+}
+
+// End of a call with stream-ordered outputs: the caller's stream waits (event, no host block) for everything enqueued so
+// far; the host only waits until the phi reduction -- which rides in the first kernel of the epilogue's tail -- has stored
+// the call's sequence number behind its results (host-mapped memory, release store: the values and, from the earlier
+// step kernels, the final statistics are there when the number is).
+int call_end_ordered(fpsq_handle h, double seq) {
+  HIPCHK(h, hipEventRecord(h->ev_out, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->in_stream, h->ev_out, 0));
+  volatile double* flag = h->hscal + 3;
+  const auto t0 = std::chrono::steady_clock::now();
+  int spins = 0;
+  while (*flag != seq) {
+    if ((++spins & 255) == 0) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) break;  // everything ran (the mapped store is then visible too; if not, the values below are read after a full drain anyway)
+      if (q != hipErrorNotReady) {
+        h->err = std::string("stream failed in the epilogue: ") + hipGetErrorString(q);
+        return FPSQ_ERR_HIP;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+        h->err = "timeout waiting for the evaluation's scalar results";
+        return FPSQ_ERR_TIMEOUT;
+      }
+    }
+  }
+  h->info.last_solve_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->t_call).count();
+  h->info.last_kernel_launches = h->launches;
+  h->info.last_spmv_launches = h->spmv_launches;
+  for (int i = 0; i < 2; ++i) {
+    h->info.last_prod_a[i] = h->prod_a[i];
+    h->info.last_prod_at[i] = h->prod_at[i];
+  }
+  h->info.last_spmv_ms = 0.0;
   return 0;
 }
 
@@ -2127,6 +2209,9 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
       hipSuccess)
     return fail("hipHostMalloc", e);
   if (const char* ev = std::getenv("FPSQ_ADAPTIVE_RUNAHEAD")) h->adaptive_runahead = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_HOST_TRACE")) h->host_trace = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_AB_DYNAMIC")) h->ab_dynamic = std::atoi(ev) != 0;
   std::memset(h->hstats, 0, 4 * sizeof(fpsq_stats));
   std::memset(h->hscal, 0, 16 * sizeof(double));
   if ((e = hipHostGetDevicePointer((void**)&h->hstats_dev, h->hstats, 0)) != hipSuccess)
@@ -2181,6 +2266,13 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
 
 int fpsq_destroy(fpsq_handle h) {
   if (!h) return FPSQ_ERR_ARG;
+  if (h->host_trace && h->ht_calls > 0) {
+    static const char* nm[12] = {"between calls", "entry->inputs ordered", "->first launch", "->krylov start", "->krylov end",
+                                 "->epilogue enqueued", "->synchronised", "->exit", "", "", "", ""};
+    std::fprintf(stderr, "fpsq host trace (%lld qp_objgrad calls), us per call:", (long long)h->ht_calls);
+    for (int k = 0; k < 8; ++k) std::fprintf(stderr, "  %s %.1f", nm[k], 1e6 * h->ht_sum[k] / (double)h->ht_calls);
+    std::fprintf(stderr, "\n");
+  }
   hipSetDevice(h->opt.device);
   if (h->stream) hipStreamSynchronize(h->stream);
   delete h->comm;
@@ -2192,6 +2284,7 @@ int fpsq_destroy(fpsq_handle h) {
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->ev_in) hipEventDestroy(h->ev_in);
+  if (h->ev_out) hipEventDestroy(h->ev_out);
   if (h->prog_host) hipHostFree(h->prog_host);
   if (h->hstats) hipHostFree(h->hstats);
   if (h->hscal) hipHostFree(h->hscal);
@@ -2335,6 +2428,14 @@ int fpsq_set_input_stream(fpsq_handle h, int32_t enabled, void* hip_stream) {
   return FPSQ_OK;
 }
 
+int fpsq_set_output_ordering(fpsq_handle h, int32_t stream_ordered) {
+  if (!h) return FPSQ_ERR_ARG;
+  hipSetDevice(h->opt.device);
+  if (stream_ordered && !h->ev_out) HIPCHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+  h->out_ordered = stream_ordered != 0;
+  return FPSQ_OK;
+}
+
 int fpsq_set_delta(fpsq_handle h, double delta) {
   if (!h || !(delta >= 0.0)) {
     if (h) h->err = "set_delta: delta must be >= 0";
@@ -2451,7 +2552,7 @@ int fpsq_ys_gs(fpsq_handle h, const double* g, const double* c, double sigma, do
   hipLaunchKernelGGL(k_gs, dim3(ew_grid(h->n)), dim3(kBlock), 0, s, h->p1, h->Cx, sigma, h->gs, h->n);
   hipLaunchKernelGGL(k_ys, dim3(ew_grid(h->m)), dim3(kBlock), 0, s, h->Lx[0], h->Cy, (const double*)nullptr, sigma, h->ys,
                      h->m, (double*)nullptr, (double*)nullptr, (double*)nullptr, (const LaneCtl*)nullptr,
-                     (const LaneCtl*)nullptr);
+                     (const LaneCtl*)nullptr, seg_none());
   h->launches += 2;
   HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
   HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
@@ -2526,6 +2627,14 @@ extern "C" {
 
 int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, double rho, double eta,
                     const double* xk, double* fx, double* gx, double* ys, double* gs, fpsq_stats st[2]) {
+  if (h && h->ab_dynamic)
+    if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
+  if (h && h->host_trace) {
+    const auto now = std::chrono::steady_clock::now();
+    if (h->ht_have_exit) h->ht_sum[0] += std::chrono::duration<double>(now - h->ht_exit).count();
+    h->ht_last = now;
+    h->ht_calls++;
+  }
   if (int rc = check_ready(h)) return rc;
   if (!qp || qp->h != h || !x || !st || (eta > 0.0 && !xk)) {
     h->err = "qp_objgrad: bad argument";
@@ -2534,6 +2643,7 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
   order_inputs(h);
+  ht_mark(h, 1);
   const int64_t n = h->n, m = h->m;
   const size_t nb = (size_t)n * 8, mb = (size_t)m * 8;
   const int gn = ew_grid(n), gm = ew_grid(m);
@@ -2555,23 +2665,36 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   // start-up product A u~_1, in which the CRAIG lane is otherwise parked, forms c = A x - b on the side: the separate
   // c = A x - b product and the right-hand-side loads of the start-up are not launched.
   const bool local_vec = !h->comm || h->halo;  // single GPU, or row-sharded with column windows (halo mode)
-  const bool fast = local_vec && h->opt.fuse_two_rhs != 0;
-  hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1],
-                     fast ? h->LP : (double*)nullptr, fast ? h->pE : (double*)nullptr, n_owned(h));
-  h->launches++;
+  const bool fast = local_vec && h->opt.fuse_two_rhs != 0 && h->opt.kkt_method == FPSQ_KKT_LSQR_CRAIG;
+  {
+    QpGradArgs qg{qp->q, qp->d, dx, dxk, h->g, n, h->pQ[0], h->pQ[1], fast ? h->LP : (double*)nullptr,
+                  fast ? h->pE : (double*)nullptr, n_owned(h), gn};
+    if (fast && !(h->ab_mask & 1)) {
+      h->startup_qg = qg;  // evaluated by the start-up launch of the recurrences (k_startup): no launch of its own
+    } else {
+      hipLaunchKernelGGL(k_qp_grad, dim3(gn), dim3(kBlock), 0, s, qg);
+      h->launches++;
+    }
+  }
+  ht_mark(h, 2);
   if (!fast) spmv_const(h, TAG_A, 1.0, dx, -1.0, qp->b, h->c);  // c = A x - b
   // Single GPU with rho > 0: p1 = g - A'q1 and J'c (:424-428) share ONE two-right-hand-side product A'[q1, c], and
   // phi is reduced by an extra workgroup of the gradient kernel: 2 launches fewer at the end of every evaluation.
   // (halo mode: the same product, its overlap rows completed after the neighbour exchange; phi needs its all-reduce)
   const bool paired = local_vec && rho > 0.0;
+  // the epilogue then starts with k_ys, which also applies the final LSQR x update (no launch of its own for it)
+  h->absorb_flush = paired && fast && !(h->ab_mask & 2);
+  const double seq = (h->call_seq += 1.0);
   // everything behind the two solves: enqueued speculatively (gated on the recurrences' `done` flags) by run_krylov when
   // the iteration count of the previous evaluation is known, else here
   TailFn epi = [&]() -> int {
     // ys = q1 + sigma q2 and the dots of objgrad!
     hipLaunchKernelGGL(k_ys, dim3(gm), dim3(kBlock), 0, s, h->Lx[0], h->Cy, h->c, sigma, h->ys, m, h->pC[0], h->pC[1],
-                       paired ? h->SP : (double*)nullptr, h->gate0, h->gate1);
+                       paired ? h->SP : (double*)nullptr, h->gate0, h->gate1, h->pending_flush);
+    h->pending_flush.kind = UPD_NONE;
     h->launches++;
     FxArgs fa{};
+    fa.seq = seq;
     fa.pf = h->pQ[0];
     fa.pdx = h->pQ[1];
     fa.np_n = gn;
@@ -2584,11 +2707,31 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
     FxArgs none = fa;
     none.out = nullptr;
     if (paired) {
-      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), h->halo);
+      // phi rides in this launch as one extra workgroup (everything it sums is complete after k_ys): the scalar result
+      // is on the host a whole product + gradient kernel before the evaluation ends
+      UpdSeg fxs = seg_none();
+      const bool ride_fx = !h->comm && !(h->ab_mask & 4);
+      if (ride_fx) {
+        fxs.kind = UPD_QP_FX;
+        fxs.nblk = 1;
+        fxs.a = const_cast<double*>(fa.pf);
+        fxs.b = const_cast<double*>(fa.pdx);
+        fxs.c = const_cast<double*>(fa.pcy);
+        fxs.d = const_cast<double*>(fa.pcc);
+        fxs.len = (int64_t)fa.np_n | ((int64_t)fa.np_m << 32);
+        fxs.s0 = rho;
+        fxs.s1 = eta;
+        fxs.partials = fa.out;
+        long long bits;
+        std::memcpy(&bits, &seq, 8);
+        fxs.src = (const double*)(size_t)bits;  // (the sequence number travels in the unused source pointer)
+      }
+      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, fxs, seg_none(), h->halo);
       if (h->halo)
         if (int rc = halo_finish<2>(h, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr)) return rc;
-      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(h->comm ? gn : gn + 1), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
-                         h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, h->comm ? none : fa,
+      const bool grad_fx = !h->comm && !ride_fx;
+      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(grad_fx ? gn + 1 : gn), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
+                         h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, grad_fx ? fa : none,
                          h->gate0, h->gate1);
       h->launches++;
     } else {
@@ -2629,13 +2772,29 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   if (int rc = two_mixed_device(h, h->g, h->c, paired, fast ? qp->b : nullptr, local_vec ? &epi : nullptr)) return rc;
   if (!local_vec)
     if (int rc = epi()) return rc;
+  h->absorb_flush = false;
   if (gx && dgx != gx) HIPCHK(h, hipMemcpyAsync(gx, h->gx, nb, hipMemcpyDefault, s));
   if (ys) HIPCHK(h, hipMemcpyAsync(ys, h->ys, mb, hipMemcpyDefault, s));
   if (gs) HIPCHK(h, hipMemcpyAsync(gs, h->gs, nb, hipMemcpyDefault, s));
-  if (int rc = call_end(h)) return rc;
+  ht_mark(h, 5);
+  // Stream-ordered outputs (fpsq_set_output_ordering): with every vector argument resident on this GPU the call returns
+  // once phi and the statistics are on the host; the registered stream is made to wait for the rest of the epilogue.
+  const bool ordered = h->out_ordered && !(h->ab_mask & 8) && h->in_stream_on && !h->profile && !h->comm && paired && dx == x &&
+                       (!gx || dgx == gx) && (!ys || on_this_device(h, ys)) && (!gs || on_this_device(h, gs));
+  if (ordered) {
+    if (int rc = call_end_ordered(h, seq)) return rc;
+  } else {
+    if (int rc = call_end(h)) return rc;
+  }
+  ht_mark(h, 6);
   if (fx) *fx = h->hscal[0];
   st[0] = h->hstats[0];
   st[1] = h->hstats[1];
+  if (h->host_trace) {
+    ht_mark(h, 7);
+    h->ht_exit = h->ht_last;
+    h->ht_have_exit = true;
+  }
   return soft_rc(st);
 }
 

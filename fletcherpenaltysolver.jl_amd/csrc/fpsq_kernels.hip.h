@@ -180,7 +180,8 @@ enum UpdKind : int32_t {
   UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT,
   UPD_NEG_COPY,  // a[i] = -src[i][lane]: keeps c = -(CRAIG's right-hand side) when the start-up product formed it
   UPD_MINRES_E1, UPD_MINRES_E2, UPD_MINRES_E3,  // the three element-wise stages of a MINRES iteration (upd_minres)
-  UPD_LNLQ_LONG, UPD_LNLQ_SHORT                 // LNLQ: x and (y, wbar) updates (upd_lnlq_*)
+  UPD_LNLQ_LONG, UPD_LNLQ_SHORT,                // LNLQ: x and (y, wbar) updates (upd_lnlq_*)
+  UPD_QP_FX     // one workgroup: phi of the eq-QP evaluation from its partial sums (qp_fx), riding in the epilogue product
 };
 
 struct UpdSeg {
@@ -201,6 +202,7 @@ struct UpdSeg {
   double* d;         // MINRES E2: w1 (read, overwritten by the new w~)
   int64_t len;
   double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
+  double s0, s1;     // UPD_QP_FX: rho, eta (a..d = the four partial arrays, len = their counts, partials = the output)
 };
 
 // LSQR (Krylov.jl lsqr!): x += (phi/rho) w; w = v - (theta/rho) w, with v = vt / alpha deferred.
@@ -346,9 +348,33 @@ __device__ __forceinline__ void upd_lnlq_short(const UpdSeg& s, int blk) {
   }
 }
 
+// phi = f - c'ys + rho/2 c'c + eta/2 ||x - xk||^2 from the partial sums of the evaluation
+// (src/model-Fletcherpenaltynlp.jl:419-433).  out = {phi, f, c'c, seq}: `seq` is stored LAST with system-scope release
+// semantics, so a host that polls it (stream-ordered outputs, see fpsq_set_output_ordering) finds the three values there.
+__device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, const double* pcy, const double* pcc, int np_n,
+                                           int np_m, double rho, double eta, double* out, double seq, double* red) {
+  const double f = reduce_partials(pf, np_n, red);
+  const double dx = reduce_partials(pdx, np_n, red);
+  const double cy = reduce_partials(pcy, np_m, red);
+  const double cc = reduce_partials(pcc, np_m, red);
+  if (threadIdx.x == 0) {
+    double fx = f - cy;
+    if (rho > 0.0) fx += rho / 2 * cc;
+    if (eta > 0.0) fx += eta / 2 * dx;
+    out[0] = fx;
+    out[1] = f;
+    out[2] = cc;
+    __hip_atomic_store(out + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <int NL>
 __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
   switch (s.kind) {
+    case UPD_QP_FX:
+      qp_fx_core(s.a, s.b, s.c, s.d, (int)(s.len & 0xffffffff), (int)(s.len >> 32), s.s0, s.s1, s.partials,
+                 __longlong_as_double((long long)(size_t)s.src), red);
+      break;
     case UPD_LNLQ_LONG: upd_lnlq_long<NL>(s, blk); break;
     case UPD_LNLQ_SHORT: upd_lnlq_short<NL>(s, blk); break;
     case UPD_MINRES_E1: upd_minres<NL, 1>(s, blk, red); break;
@@ -419,10 +445,26 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   double* red = prod;
   // speculatively enqueued epilogue product: runs only once both recurrences of the call have ended
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
-  if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
+  // A' launches (identity block map): a phi reduction (UPD_QP_FX, one workgroup) is the FIRST workgroup of the grid, not one
+  // of the riding workgroups at its end -- the host waits for that scalar (stream-ordered outputs), and the last workgroups
+  // of a product only start when the kernel is almost over
+  int bid = blockIdx.x;
+  if (TAG == 1 && u0.kind == UPD_QP_FX) {
+    if (bid == 0) {
+      upd_run<NL>(u0, 0, red);
+      return;
+    }
+    bid -= 1;
+    if (bid >= 8 * blk_per_xcd) {  // u1's riding workgroups (none today) keep their place at the end
+      if (bid - 8 * blk_per_xcd < u1.nblk) upd_run<NL>(u1, bid - 8 * blk_per_xcd, red);
+      return;
+    }
+  } else if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) {
+    return;
+  }
   // A (TAG 0): XCD-contiguous eighths, so an XCD's L2 holds one slice of the long gathered vector.  A' (TAG 1): the gathered
   // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
-  const int L = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
+  const int L = TAG == 1 ? bid : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
   if (L >= A.nblk) return;
   // issued before the (dependent) done-check below: one memory round trip at the head of the workgroup, not two
   const int4 bd = A.blkdesc[L];
@@ -937,13 +979,27 @@ __global__ __launch_bounds__(kBlock) void k_local_allreduce(ShardBufs B, int64_t
 // lp != null (fast start of qp_objgrad): also lp[i] = {g_i, x_i} -- the long Golub-Kahan pair with LSQR's u~_1 = g in lane 0
 // and, in the still unused CRAIG lane, the point whose constraint values the start-up product will form -- and the
 // partials of ||g||^2 in pg.
-__global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q, const double* __restrict__ d,
-                                                    const double* __restrict__ x, const double* xk, double* g,
-                                                    int64_t n, double* pf, double* pdx, double* lp, double* pg,
-                                                    int64_t n_sum) {
-  __shared__ double red[4];
+struct QpGradArgs {
+  const double *q, *d, *x, *xk;
+  double* g;
+  int64_t n;
+  double *pf, *pdx, *lp, *pg;
+  int64_t n_sum;
+  int32_t nblk;  // workgroups of this body (k_startup: the first nblk of the launch; 0 = none)
+};
+__device__ __forceinline__ void qp_grad_body(const QpGradArgs& a, int blk, double* red) {
+  const double* __restrict__ q = a.q;
+  const double* __restrict__ d = a.d;
+  const double* __restrict__ x = a.x;
+  const double* xk = a.xk;
+  double* g = a.g;
+  double* lp = a.lp;
+  double* pf = a.pf;
+  double* pdx = a.pdx;
+  double* pg = a.pg;
+  const int64_t n = a.n, n_sum = a.n_sum;
   double f = 0.0, dx2 = 0.0, gg = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+  for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < n; i += (int64_t)a.nblk * kBlock) {
     const double xi = x[i], qi = q[i], di = d[i];
     const double gi = qi * xi + di;
     g[i] = gi;
@@ -958,27 +1014,47 @@ __global__ __launch_bounds__(kBlock) void k_qp_grad(const double* __restrict__ q
     }
   }
   const double tf = block_sum(f, red);
-  if (threadIdx.x == 0) pf[blockIdx.x] = tf;
+  if (threadIdx.x == 0) pf[blk] = tf;
   const double td = block_sum(dx2, red);
-  if (threadIdx.x == 0) pdx[blockIdx.x] = td;
+  if (threadIdx.x == 0) pdx[blk] = td;
   if (lp) {
     const double tg = block_sum(gg, red);
-    if (threadIdx.x == 0) pg[blockIdx.x] = tg;
+    if (threadIdx.x == 0) pg[blk] = tg;
   }
+}
+__global__ __launch_bounds__(kBlock) void k_qp_grad(const QpGradArgs a) {
+  __shared__ double red[4];
+  qp_grad_body(a, blockIdx.x, red);
 }
 
 // ys = q1 + sigma q2 ; partials of c'ys and c'c            (m-vectors)
-__global__ __launch_bounds__(kBlock) void k_ys(const double* __restrict__ q1, const double* __restrict__ q2,
+// `flush` (kind UPD_LSQR, two-lane source pair): the LAST x update of the LSQR recurrence whose solution is q1 (= flush.a),
+// applied element-wise right here instead of by a launch of its own -- under exactly upd_lsqr's conditions (the recurrence
+// ended at iteration flush.it; speculative: the other lane ended too).  w is left alone: nothing reads it any more.
+__global__ __launch_bounds__(kBlock) void k_ys(const double* q1, const double* __restrict__ q2,
                                                const double* __restrict__ c, double sigma, double* ys, int64_t m,
                                                double* pcy, double* pcc, double* pack, const LaneCtl* gate0,
-                                               const LaneCtl* gate1) {
+                                               const LaneCtl* gate1, const UpdSeg flush) {
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   __shared__ double red[4];
   double cy = 0.0, cc = 0.0;
+  bool fl = flush.kind == UPD_LSQR;
+  double sg = 0.0;
+  if (fl) {
+    const LaneCtl* ctl = flush.ctl;
+    if (ctl->done && ctl->upd_iter != flush.it) fl = false;
+    if (fl && flush.gate != nullptr && !(ctl->done && flush.gate->done)) fl = false;
+    sg = ctl->e[0];
+  }
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-    const double y = q1[i] + sigma * q2[i];
+    double q1i = q1[i];
+    if (fl) {
+      q1i += sg * flush.b[i];
+      flush.a[i] = q1i;
+    }
+    const double y = q1i + sigma * q2[i];
     ys[i] = y;
-    if (pack) *reinterpret_cast<double2*>(pack + 2 * i) = make_double2(q1[i], c[i]);  // input pair of the A'[q1, c] product
+    if (pack) *reinterpret_cast<double2*>(pack + 2 * i) = make_double2(q1i, c[i]);  // input pair of the A'[q1, c] product
     if (c) {
       const double ci = c[i];
       cy += ci * y;
@@ -1006,20 +1082,10 @@ struct FxArgs {
   int32_t np_n, np_m;
   double rho, eta;
   double* out;  // null: not computed by this launch
+  double seq;   // call sequence number stored behind the results (out[3])
 };
 __device__ __forceinline__ void qp_fx(const FxArgs& a, double* red) {
-  const double f = reduce_partials(a.pf, a.np_n, red);
-  const double dx = reduce_partials(a.pdx, a.np_n, red);
-  const double cy = reduce_partials(a.pcy, a.np_m, red);
-  const double cc = reduce_partials(a.pcc, a.np_m, red);
-  if (threadIdx.x == 0) {
-    double fx = f - cy;
-    if (a.rho > 0.0) fx += a.rho / 2 * cc;
-    if (a.eta > 0.0) fx += a.eta / 2 * dx;
-    a.out[0] = fx;
-    a.out[1] = f;
-    a.out[2] = cc;
-  }
+  qp_fx_core(a.pf, a.pdx, a.pcy, a.pcc, a.np_n, a.np_m, a.rho, a.eta, a.out, a.seq, red);
 }
 
 // QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2.

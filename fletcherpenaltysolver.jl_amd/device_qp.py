@@ -72,6 +72,9 @@ class DeviceEqQP:
         st = _lib.producer_stream(*args)
         if st is not None and st != self._in_stream:
             self._check(self._lib.fpsq_set_input_stream(self._h, 1, st))
+            # torch consumes the device-resident outputs on that same stream: let the library order them there instead of
+            # blocking the host until the last kernel has ended (include/fpsq.h, "STREAM-ORDERED OUTPUTS")
+            self._check(self._lib.fpsq_set_output_ordering(self._h, 1))
             self._in_stream = st
 
     def set_delta(self, delta):

@@ -143,6 +143,18 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double *vals);
  * READINESS" above.  `hip_stream` is a hipStream_t (NULL = the legacy default stream). */
 int fpsq_set_input_stream(fpsq_handle h, int32_t enabled, void *hip_stream);
 
+/* STREAM-ORDERED OUTPUTS (optional; needs a stream registered with fpsq_set_input_stream).  By default every call returns
+ * with all outputs complete.  With stream_ordered != 0, fpsq_qp_objgrad on a single-GPU handle whose vector arguments
+ * (x, gx, ys, gs) all reside on the handle's GPU returns as soon as its HOST-visible results -- the return code, *fx and
+ * the statistics -- are final, while the last kernels that write the DEVICE-resident outputs may still be running: the
+ * registered stream has been made to wait for them (event, no host block), so work queued there afterwards -- the caller's
+ * next kernels reading gx, its updates of x -- is ordered behind the evaluation, exactly as a stream-ordered library call.
+ * A caller that touches the outputs from the host or from another stream must synchronise the registered stream first.
+ * The host turn-around between dependent evaluations (return, the caller's decision, the next call's set-up) then overlaps
+ * the GPU's tail instead of leaving it idle.  Every other case (host-resident arguments, sharded handles, profiling) keeps
+ * the synchronous behaviour. */
+int fpsq_set_output_ordering(fpsq_handle h, int32_t stream_ordered);
+
 /* `nlp.delta`, mutated by the outer loop (src/algo.jl:389-393). */
 int fpsq_set_delta(fpsq_handle h, double delta);
 

@@ -38,6 +38,17 @@ for lp in libs:
                 extra.update(ls_itmax=int(os.environ["AB_ITMAX"]), ln_itmax=int(os.environ["AB_ITMAX"]))
             models[(os.path.basename(lp), f"{ev}/{optname}={ov}#{len(models)}")] = DeviceEqQP(
                 qp, sigma=1e3, rho=1.0, delta=0.0, device=0, fuse_two_rhs=1, **extra)
+dyn_name, dyn_vals = None, None
+if os.environ.get("AB_DYN"):  # ONE handle, the variable re-read by the library at every call (FPSQ_AB_DYNAMIC): cancels the
+    dyn_name, vals = os.environ["AB_DYN"].split("=")  # +-3 % spread between handles (buffer placement)
+    dyn_vals = vals.split(",")
+    os.environ["FPSQ_AB_DYNAMIC"] = "1"
+    (k0, m0), = list(models.items())[:1]
+    for mdl in list(models.values())[1:]:
+        mdl.close()
+    m0.close()
+    m0 = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, device=0, fuse_two_rhs=1)
+    models = {(k0[0], f"{dyn_name}={v}"): m0 for v in dyn_vals}
 xs = torch.empty((batch, qp.n), dtype=torch.float64, device=dev)
 for t in range(batch):
     xs[t].copy_(torch.from_numpy(qp.point(1 + t)))
@@ -45,6 +56,8 @@ gx = torch.empty(qp.n, dtype=torch.float64, device=dev)
 res = {k: [] for k in models}
 for r in range(rounds + 1):
     for k, mdl in models.items():
+        if dyn_name:
+            os.environ[dyn_name] = k[1].split("=")[1]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for t in range(batch):
