@@ -51,6 +51,8 @@ def parse_args():
                          "device-resident hprod! Val(2) (model-Fletcherpenaltynlp.jl:521-570): SURVEY 8(f) rank 1; extras = "
                          "solve_two_extras (LSQR + MINRES on AA' + tau I, solve_linear_system.jl:45-77: the extra solves "
                          "of hprod! Val(1)) -- timing only, no roofline accounting")
+    ap.add_argument("--hessian-approx", type=int, default=2, choices=[1, 2],
+                    help="--op hprod: Val(2) (model-Fletcherpenaltynlp.jl:521-570) or Val(1) (:572-634: + the solve_two_extras lanes)")
     ap.add_argument("--delta", type=float, default=None, help="regularisation; default 0 = first outer iteration "
                     "(algo.jl:46); 1e-3 for the dense-block workload")
     ap.add_argument("--fuse", type=int, default=1)
@@ -450,7 +452,7 @@ def main():
     def make_step(mdl, pts, out):
         def step(t):
             if hfull:
-                return None, mdl.hprod(pts[t], hp_out[0])
+                return None, mdl.hprod(pts[t], hp_out[0], args.hessian_approx)
             if extras:
                 mdl._order(pts[t], xm[t], hp_out[1], hp_out[3])
                 return None, mdl._check(mdl._lib.fpsq_solve_two_extras(mdl._h, pts[t].data_ptr(), xm[t].data_ptr(),
@@ -567,7 +569,7 @@ def main():
                         "products (n x 2 fp64) and of the m-vector norm partials every Krylov iteration",
            "replicas": f"{world} independent replicas (each rank evaluates its own points), no data-path collective"}[layout]
     out = {
-        "metric": "penalty hprod! (Val(2)) evals/sec" if hfull
+        "metric": f"penalty hprod! (Val({args.hessian_approx})) evals/sec" if hfull
         else "solve_two_extras calls/sec (LSQR + MINRES lanes, the extra solves of hprod! Val(1))" if extras
         else "solve_two_least_squares calls/sec (the two KKT solves of one hprod!)" if hp
         else "penalty grad-phi evals/sec", "value": round(value, 3), "unit": "calls/s" if hp else "evals/s",

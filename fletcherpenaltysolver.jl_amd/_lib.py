@@ -89,7 +89,7 @@ SYMBOLS = [
     ("fpsq_qp_destroy", C.c_int, [_VP]),
     ("fpsq_qp_objgrad", C.c_int, [_VP, _VP, _DP, _D, _D, _D, _DP, C.POINTER(C.c_double), _DP, _DP, _DP,
                                   C.POINTER(Stats)]),
-    ("fpsq_qp_hprod", C.c_int, [_VP, _VP, _DP, _D, _D, _D, _DP, C.POINTER(Stats)]),
+    ("fpsq_qp_hprod", C.c_int, [_VP, _VP, _DP, _D, _D, _D, _I32, _DP, C.POINTER(Stats)]),
     ("fpsq_comm_unique_id", C.c_int, [_DP]),
     ("fpsq_comm_init", C.c_int, [_VP, _I32, _I32, _DP]),
     ("fpsq_comm_set_halo", C.c_int, [_VP, _I64, _I64]),

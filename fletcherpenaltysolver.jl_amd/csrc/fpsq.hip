@@ -2798,11 +2798,11 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   return soft_rc(st);
 }
 
-int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta, double* Hv,
-                  fpsq_stats st[2]) {
+int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta,
+                  int32_t hessian_approx, double* Hv, fpsq_stats* st) {
   if (int rc = check_ready(h)) return rc;
-  if (!qp || qp->h != h || !v || !Hv || !st) {
-    h->err = "qp_hprod: bad argument";
+  if (!qp || qp->h != h || !v || !Hv || !st || (hessian_approx != 1 && hessian_approx != 2)) {
+    h->err = "qp_hprod: bad argument (hessian_approx is 1 or 2)";
     return FPSQ_ERR_ARG;
   }
   hipSetDevice(h->opt.device);
@@ -2833,11 +2833,42 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
   if (int rc = two_least_squares_device(h, dv, h->in_n2, local_vec ? &epi : nullptr)) return rc;         // :542
   if (!local_vec)
     if (int rc = epi()) return rc;
+  if (hessian_approx == 1) {
+    // Val(1) (src/model-Fletcherpenaltynlp.jl:572-634) adds, on top of everything above:
+    //   Ssv = ghjvprod(x, gs, v) = 0 (linear constraints);  (invJtJJv, invJtJSsv) = solve_two_extras(v, Ssv)   :601-602
+    //   Hv -= J' invJtJSsv                                                                                  :603-611
+    //   Hv -= hprod_nln(x, invJtJJv, gs; obj_weight = 0) = 0                                                :613-614
+    // i.e. the LSQR + MINRES lanes of solve_two_extras (tau = max(delta, 1e-14)) on the right-hand sides (v, 0) and one
+    // more A' product; the two recurrences' statistics go to st[2], st[3].
+    const double tau = std::max(h->delta, 1e-14);
+    HIPCHK(h, hipMemsetAsync(h->in_m, 0, (size_t)h->m * 8, s));
+    Lane lanes[2];
+    lanes[0].kind = LANE_LSQR;
+    lanes[0].rhs = dv;
+    lanes[0].lambda = std::sqrt(tau);
+    lanes[0].x = h->Lx[0];
+    lanes[0].st = &h->hstats[2];
+    lanes[1].kind = LANE_MINRES;
+    lanes[1].rhs = h->in_m;
+    lanes[1].lambda = tau;
+    lanes[1].x = h->Mx;
+    lanes[1].st = &h->hstats[3];
+    if (int rc = run_lanes(h, lanes, 2)) return rc;
+    if (int rc = at_product_const(h, 1.0, h->Mx, 0.0, nullptr, h->jc)) return rc;  // J' invJtJSsv
+    hipLaunchKernelGGL(k_axpby_plain, dim3(gn), dim3(kBlock), 0, s, h->jc, -1.0, dhv, 1.0, dhv, n);
+    h->launches++;
+  }
   if (dhv != Hv) HIPCHK(h, hipMemcpyAsync(Hv, dhv, nb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;
   st[0] = h->hstats[0];
   st[1] = h->hstats[1];
-  return soft_rc(st);
+  int rc = soft_rc(st);
+  if (hessian_approx == 1) {
+    st[2] = h->hstats[2];
+    st[3] = h->hstats[3];
+    rc |= soft_rc(st + 2) << 2;
+  }
+  return rc;
 }
 
 int fpsq_comm_unique_id(uint8_t id[128]) {

@@ -40,6 +40,7 @@ class DeviceEqQP:
         self._check(self._lib.fpsq_qp_create(h, qp.qdiag.ctypes.data, qp.d.ctypes.data, qp.b.ctypes.data, C.byref(q)))
         self._q = q
         self.stats = (_lib.Stats * 2)()
+        self.stats4 = (_lib.Stats * 4)()   # hprod with hessian_approx = 1: + the two recurrences of solve_two_extras
         self._in_stream = -1
         try:
             self._attach_comm(comm, halo)
@@ -119,12 +120,15 @@ class DeviceEqQP:
         self._order(x, y)
         return self._check(self._lib.fpsq_jac_mul(self._h, int(trans), float(alpha), _lib.ptr(x), float(beta), _lib.ptr(y)))
 
-    def hprod(self, v, Hv):
-        """hprod!(::FletcherPenaltyNLP, x, v, Hv), hessian_approx = Val(2) (model-Fletcherpenaltynlp.jl:521-570), on the
-        device; the model is quadratic with linear constraints, so the product does not depend on x.  Returns rc."""
+    def hprod(self, v, Hv, hessian_approx=2):
+        """hprod!(::FletcherPenaltyNLP, x, v, Hv) on the device, hessian_approx = Val(2) (model-Fletcherpenaltynlp.jl:521-570)
+        or Val(1) (:572-634: additionally the solve_two_extras lanes; their statistics land in self.stats4[2:4]); the model
+        is quadratic with linear constraints, so the product does not depend on x.  Returns rc."""
         self._order(v, Hv)
-        return self._check(self._lib.fpsq_qp_hprod(self._h, self._q, _lib.ptr(v), self.sigma, self.rho, self.eta,
-                                                   _lib.ptr(Hv), self.stats))
+        rc = self._check(self._lib.fpsq_qp_hprod(self._h, self._q, _lib.ptr(v), self.sigma, self.rho, self.eta,
+                                                 int(hessian_approx), _lib.ptr(Hv), self.stats4))
+        self.stats[0], self.stats[1] = self.stats4[0], self.stats4[1]
+        return rc
 
     def info(self):
         i = _lib.Info()

@@ -603,8 +603,8 @@ class _DevicePenalty:
     """The penalty function of a DeviceEqQP (fpsq_qp_objgrad / fpsq_qp_hprod): every vector stays in HBM (torch
     tensors); the host only sees scalars."""
 
-    def __init__(self, dev, torch):
-        self.dev, self.torch = dev, torch
+    def __init__(self, dev, torch, hessian_approx=2):
+        self.dev, self.torch, self.hessian_approx = dev, torch, int(hessian_approx)
         d = torch.device("cuda", int(dev.opts.device))
         qp = dev.qp
         self.q = torch.from_numpy(np.ascontiguousarray(qp.qdiag)).to(d)
@@ -629,7 +629,7 @@ class _DevicePenalty:
 
     def hprod_(self, x, v, Hv):
         self.nhprod += 1
-        self.dev.hprod(v, Hv)
+        self.dev.hprod(v, Hv, self.hessian_approx)   # Val(2) (model:521-570) or Val(1) (:572-634)
         return Hv
 
     _xk = None
@@ -671,4 +671,4 @@ def fps_solve_device(dev, x0, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.
     meta = AlgoData(**{k: v for k, v in kwargs.items() if k in AlgoData.__dataclass_fields__})
     dev.sigma, dev.rho, dev.eta = meta.sigma_0, meta.rho_0, 0.0
     dev.set_delta(0.0)
-    return _outer_loop(_DevicePenalty(dev, torch), x0, meta, atol, rtol, max_iter, max_time, verbose)
+    return _outer_loop(_DevicePenalty(dev, torch, meta.hessian_approx), x0, meta, atol, rtol, max_iter, max_time, verbose)

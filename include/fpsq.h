@@ -197,13 +197,18 @@ int fpsq_qp_create(fpsq_handle h, const double *qdiag, const double *d, const do
 int fpsq_qp_destroy(fpsq_qp qp);
 int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double *x, double sigma, double rho, double eta,
                     const double *xk, double *fx, double *gx, double *ys, double *gs, fpsq_stats st[2]);
-/* One `hprod!(::FletcherPenaltyNLP, x, v, Hv)` with hessian_approx = Val(2)
- * (src/model-Fletcherpenaltynlp.jl:521-570) on the same model, entirely on the device:
+/* One `hprod!(::FletcherPenaltyNLP, x, v, Hv)` on the same model, entirely on the device.
+ * hessian_approx = 2, Val(2) (src/model-Fletcherpenaltynlp.jl:521-570):
  *   Hsv = q .* v;  (p1, _, p2, _) = solve_two_least_squares(v, Hsv);  Ptv = v - p1;
  *   Hv = p2 - q .* Ptv + 2 sigma Ptv (+ rho A'(A v)) (+ eta v)      (the constraint Hessians vanish: c is linear).
- * The Hessian-free sub-solvers call this once per inner CG iteration (SURVEY.md 8f rank 1). */
-int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double *v, double sigma, double rho, double eta, double *Hv,
-                  fpsq_stats st[2]);
+ *   st[0], st[1] = the two LSQR recurrences.
+ * hessian_approx = 1, Val(1) (:572-634): the same, then Ssv = ghjvprod(x, gs, v) (= 0 for linear constraints),
+ *   (invJtJJv, invJtJSsv) = solve_two_extras(v, Ssv) and Hv -= A' invJtJSsv (- hprod_nln(x, invJtJJv, gs; obj_weight = 0) = 0):
+ *   the LSQR + MINRES lanes of fpsq_solve_two_extras and one more A' product; st must then hold FOUR entries, st[2], st[3] =
+ *   the statistics of those two recurrences, and bits 2, 3 of a positive return code flag their `solved == false`.
+ * The Hessian-free sub-solvers call this once per inner CG iteration (SURVEY.md 8f ranks 1 and 2). */
+int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double *v, double sigma, double rho, double eta, int32_t hessian_approx,
+                  double *Hv, fpsq_stats *st);
 
 /* ---- multi-GPU: 1-D row sharding of A across ranks.  Each rank creates its handle with
  * the GLOBAL n and its LOCAL m (its block of constraints), passes its local rows to set_jacobian_*, and

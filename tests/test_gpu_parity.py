@@ -577,6 +577,44 @@ def test_device_qp_hprod_matches_oracle(oracle, delta, rho, eta):
     dev.close()
 
 
+@pytest.mark.parametrize("delta,rho,eta", [(0.0, 1.0, 0.0), (SE, 0.0, 0.0), (1e-2, 2.0, 0.5)])
+def test_device_qp_hprod_val1_matches_oracle_and_host_mirror(oracle, delta, rho, eta):
+    """fpsq_qp_hprod with hessian_approx = 1 (hprod! Val(1), model-Fletcherpenaltynlp.jl:572-634) against the C restatement
+    (fpo_qp_hprod, approx = 1): the statistics of all FOUR recurrences (two LSQR of solve_two_least_squares, LSQR + MINRES of
+    solve_two_extras with tau = max(delta, 1e-14) and the zero right-hand side Ssv), Hv to 1e-8; against the host mirror of
+    the reference's Val(1) driven through the iterative back-end; and -- the constraint Hessians vanish -- equal to Val(2)'s
+    product bit for bit."""
+    qp = _small_pde(seed=31, n=3000, m=300)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(qp.n)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=rho, delta=delta, eta=eta)
+    Hv1, Hv2 = np.empty(qp.n), np.empty(qp.n)
+    rc = dev.hprod(v, Hv1, 1)
+    o = oracle.qp_hprod(qp, v, 1e3, rho, delta, eta, approx=1)
+    assert rc == o["rc"]
+    for k in range(4):
+        got, want = dev.stats4[k], o["stats"][k]
+        assert (got.niter, got.status, got.solved) == (want.niter, want.status, want.solved), k
+    assert dev.stats4[2].niter > 10 and dev.stats4[3].status == 1  # MINRES on the zero right-hand side: "x = 0 ..."
+    assert _rel(Hv1, o["Hv"]) < 1e-8
+    assert dev.hprod(v, Hv2, 2) == 0
+    assert np.array_equal(Hv1, Hv2)
+    # a device-resident argument pair takes the in-place path
+    import torch
+    vt, ht = torch.from_numpy(v).cuda(), torch.empty(qp.n, dtype=torch.float64, device="cuda")
+    assert dev.hprod(vt, ht, 1) == rc and np.array_equal(ht.cpu().numpy(), Hv1)
+    dev.close()
+    model = nlpmodels.EqQPModel(qp)
+    qds = HIPQDSolver(model, 0.0, **TIGHT)
+    fp = FletcherPenaltyNLP(model, sigma=1e3, rho=rho, delta=delta, hessian_approx=1, qds=qds)
+    fp.eta = eta
+    dev = DeviceEqQP(qp, sigma=1e3, rho=rho, delta=delta, eta=eta, **TIGHT)
+    assert dev.hprod(v, Hv1, 1) == 0
+    assert _rel(Hv1, fp.hprod(qp.x, v)) < 1e-9
+    dev.close()
+    qds.close()
+
+
 @pytest.mark.parametrize("where", ["host", "device"])
 @pytest.mark.parametrize("delta", [0.0, SE, 0.25])
 def test_ys_gs_entry_point(oracle, where, delta):
@@ -869,6 +907,11 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, delta):
     assert all(rc == 0 for rc in rcs)
     assert all((sh.stats[0].niter, sh.stats[1].niter) == ith_ref for sh in shards)
     assert _rel(plan.assemble(hv), hv_ref) < 1e-9
+    # ... and Val(1) (adds the LSQR + MINRES lanes of solve_two_extras): the same product on this model
+    hv1 = [np.empty(l.n) for l in locs]
+    rcs = group.run([lambda r=r: shards[r].hprod(v[plan.window(r)], hv1[r], 1) for r in range(nshards)])
+    assert all(rc == 0 for rc in rcs) and all(np.array_equal(a, b) for a, b in zip(hv, hv1))
+    assert all(sh.stats4[3].status == 1 for sh in shards)  # MINRES, zero right-hand side
     # the seam itself: solve_two_mixed / solve_two_least_squares with window right-hand sides
     A = qp.scipy_csr()
     g = qp.qdiag * qp.x + qp.d
@@ -1003,6 +1046,15 @@ def test_config_headline_full_size_matches_oracle(oracle):
         assert rc == oh["rc"] == 0
         assert (dev.stats[0].niter, dev.stats[1].niter) == (oh["stats"][0].niter, oh["stats"][1].niter)
         assert _rel(Hv, oh["Hv"]) < 1e-8
+        # hprod! Val(1) (model:572-634) at full size: + the two recurrences of solve_two_extras
+        Hv1 = np.empty(qp.n)
+        rc = dev.hprod(v, Hv1, 1)
+        o1 = oracle.qp_hprod(qp, v, sigma, rho, delta, approx=1)
+        assert rc == o1["rc"]
+        for k in range(4):
+            assert (dev.stats4[k].niter, dev.stats4[k].status, dev.stats4[k].solved) == \
+                   (o1["stats"][k].niter, o1["stats"][k].status, o1["stats"][k].solved), k
+        assert _rel(Hv1, o1["Hv"]) < 1e-8
         dev.close()
 
 
