@@ -157,41 +157,30 @@ class Timer:
 
 def bench_dense(args, rank, world, local_rank, timer, dev):
     """BASELINE configs[2]: dense-block Jacobian through the direct back-end (fp64 MFMA SYRK + blocked Cholesky + two
-    right-hand sides).  One step = new Jacobian values (resident in HBM) -> M = AA' + delta I -> factorisation ->
-    solve_two_mixed(g_t, c_t), the reference's LDLt `solve_two_mixed` (solve_linear_system.jl:206-252)."""
-    import ctypes as C
-
+    right-hand sides), timed AT THE SEAM: one step = one `objgrad!(::FletcherPenaltyNLP, x, gx)` at a fresh x with
+    qds = HIPDirectQDSolver -- the user model's f, g, c (a model whose Jacobian lives in HBM, TorchEqQPModel), `jac_coord!`
+    handed over as a device pointer (fpsq_dense_set_jacobian_coo), M = AA' + delta I, factorisation, solve_two_mixed (the
+    reference's LDLt path, solve_linear_system.jl:206-252), the two hprod! and rho J'c of the gradient (model:372-401)."""
     import torch
-    from fps_amd import _lib
+    from fps_amd import nlpmodels
+    from fps_amd.penalty_nlp import FletcherPenaltyNLP
+    from fps_amd.qdsolver import HIPDirectQDSolver
 
     qp = make_workload(args.workload)
     n, m = qp.n, qp.m
     delta = 1e-3 if args.delta is None else args.delta
-    lib = _lib.load()
-    d = C.c_void_p()
-    if lib.fpsq_dense_create(C.byref(d), n, m, local_rank) != 0:
-        raise SystemExit(lib.fpsq_dense_last_error(None).decode())
-    A = torch.from_numpy(qp.scipy_csr().toarray()).to(dev)
+    model = nlpmodels.TorchEqQPModel(qp, device=local_rank)
+    qds = HIPDirectQDSolver(model, 0.0, device=local_rank)
+    fp = FletcherPenaltyNLP(model, sigma=1e3, rho=1.0, delta=delta, hessian_approx=2, qds=qds)
     K, W = args.steps, args.warmup
-    As = qp.scipy_csr()
-    gs = torch.empty((K + W, n), dtype=torch.float64, device=dev)
-    cs = torch.empty((K + W, m), dtype=torch.float64, device=dev)
-    for t in range(K + W):
-        x = qp.point(1 + t + rank * (K + W))
-        gs[t].copy_(torch.from_numpy(qp.qdiag * x + qp.d))
-        cs[t].copy_(torch.from_numpy(As @ x - qp.b))
-    outs = [torch.empty(k, dtype=torch.float64, device=dev) for k in (n, m, n, m)]
-    info_i = C.c_int32()
+    xs = [qp.point(1 + t + rank * (K + W)) for t in range(K + W)]
     tsum = np.zeros(3)
 
     def step(t):
-        assert lib.fpsq_dense_set_jacobian(d, A.data_ptr()) == 0
-        rc = lib.fpsq_dense_factorize(d, delta, C.byref(info_i))
-        assert rc == 0, (rc, info_i.value)
-        assert lib.fpsq_dense_solve_two_mixed(d, gs[t].data_ptr(), cs[t].data_ptr(), *[o.data_ptr() for o in outs]) == 0
-        i = _lib.DenseInfo()
-        lib.fpsq_dense_get_info(d, C.byref(i))
-        return np.array([i.last_syrk_ms, i.last_chol_ms, i.last_solve_ms])
+        fp.objgrad(xs[t])
+        assert qds.factorized
+        i = qds.info()
+        return np.array([i["last_syrk_ms"], i["last_chol_ms"], i["last_solve_ms"]])
 
     def collect(v):
         tsum.__iadd__(v)
@@ -211,8 +200,9 @@ def bench_dense(args, rank, world, local_rank, timer, dev):
            "repeats": int(times.size), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": args.workload, "n": n, "m": m, "delta": delta,
-                      "path": "direct back-end: M = AA' + delta I (v_mfma_f64_16x16x4_f64), blocked Cholesky, 2 RHS; one "
-                              "step = Jacobian values + factorisation + solve_two_mixed (no user-model f/g/c)",
+                      "path": "direct back-end behind the QDSolver seam: one step = FletcherPenaltyNLP.objgrad (user model "
+                              "with its Jacobian in HBM; jac_coord! values taken in place) -> M = AA' + delta I "
+                              "(v_mfma_f64_16x16x4_f64), blocked Cholesky, solve_two_mixed with 2 RHS, gradient assembly",
                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas"},
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(tf / F64_MFMA_PEAK_TF, 4), "traffic": None,
@@ -252,7 +242,7 @@ def bench_dense(args, rank, world, local_rank, timer, dev):
                                          "reference's LDLFactorizations.jl path, which cannot run here (no Julia)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    lib.fpsq_dense_destroy(d)
+    qds.close()
 
 
 def main():

@@ -100,6 +100,8 @@ SYMBOLS = [
     ("fpsq_dense_destroy", C.c_int, [_VP]),
     ("fpsq_dense_last_error", C.c_char_p, [_VP]),
     ("fpsq_dense_set_jacobian", C.c_int, [_VP, _DP]),
+    ("fpsq_dense_set_structure_coo", C.c_int, [_VP, _I64, _DP, _DP, _I32]),
+    ("fpsq_dense_set_jacobian_coo", C.c_int, [_VP, _DP]),
     ("fpsq_dense_factorize", C.c_int, [_VP, _D, C.POINTER(C.c_int32)]),
     ("fpsq_dense_set_regularization", C.c_int, [_VP, _D, _D]),
     ("fpsq_dense_solve_two_mixed", C.c_int, [_VP, _DP, _DP, _DP, _DP, _DP, _DP]),
@@ -107,6 +109,8 @@ SYMBOLS = [
     ("fpsq_dense_get_factor", C.c_int, [_VP, _DP]),
     ("fpsq_dense_get_info", C.c_int, [_VP, C.POINTER(DenseInfo)]),
     ("fpsq_band_create", C.c_int, [C.POINTER(_VP), _I64, _I64, _DP, _DP, _I32]),
+    ("fpsq_band_create_coo", C.c_int, [C.POINTER(_VP), _I64, _I64, _I64, _DP, _DP, _I32, _I32]),
+    ("fpsq_band_factorize_coo", C.c_int, [_VP, _DP, _D, C.POINTER(C.c_int32)]),
     ("fpsq_band_analyze", C.c_int, [_I64, _I64, _DP, _DP, _DP, C.POINTER(BandInfo)]),
     ("fpsq_band_destroy", C.c_int, [_VP]),
     ("fpsq_band_last_error", C.c_char_p, [_VP]),

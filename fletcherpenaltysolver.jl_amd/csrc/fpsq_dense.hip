@@ -45,12 +45,55 @@ struct fpsq_dense_s {
                                                // the rest of the step on a second one.  Off: it measured 2.62 ms against 2.45 ms
                                                // (n = 4096, m = 2048) -- a step's tiles all run concurrently on their own CUs, so
                                                // taking most of them off the stream shortens nothing, and the extra launches cost
+  // jac_coord! hand-over (fpsq_dense_set_structure_coo): the caller's COO entries sorted by target, duplicates grouped
+  int64_t coo_nnz = -1, coo_slots = 0;
+  int32_t *coo_perm = nullptr, *coo_slotptr = nullptr;
+  int64_t* coo_target = nullptr;
+  double* coo_in = nullptr;
   fpsq_dense_info info{};
   std::vector<void*> allocs;
 };
 
 namespace {
 thread_local std::string g_dense_create_error;
+
+// COO triplets (any order, duplicates allowed, `base`-based) -> row-major sorted slots.  order[k]: the caller's index of the
+// k-th sorted entry (stable: duplicates keep the caller's order); slotptr: one range of sorted entries per distinct (row,
+// col); srow / scol: the slots' coordinates.  Returns an error text, empty on success.
+std::string coo_sort(int64_t m, int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, int32_t base,
+                     std::vector<int32_t>& order, std::vector<int32_t>& slotptr, std::vector<int32_t>& srow,
+                     std::vector<int32_t>& scol) {
+  std::vector<int32_t> cnt(m + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t r = rows[k] - base, c = cols[k] - base;
+    if (r < 0 || r >= m || c < 0 || c >= n) return "COO index out of range";
+    cnt[r + 1]++;
+  }
+  for (int64_t i = 0; i < m; ++i) cnt[i + 1] += cnt[i];
+  order.resize(nnz);
+  {
+    std::vector<int32_t> next(cnt.begin(), cnt.end() - 1);
+    for (int64_t k = 0; k < nnz; ++k) order[next[rows[k] - base]++] = (int32_t)k;
+  }
+  for (int64_t i = 0; i < m; ++i)
+    std::stable_sort(order.begin() + cnt[i], order.begin() + cnt[i + 1],
+                     [&](int32_t a, int32_t b) { return cols[a] < cols[b]; });
+  slotptr.assign(1, 0);
+  srow.clear();
+  scol.clear();
+  for (int64_t i = 0; i < m; ++i)
+    for (int32_t k = cnt[i]; k < cnt[i + 1]; ++k) {
+      const int64_t c = cols[order[k]] - base;
+      if (k > cnt[i] && c == cols[order[k - 1]] - base) {
+        slotptr.back() = k + 1;
+      } else {
+        srow.push_back((int32_t)i);
+        scol.push_back((int32_t)c);
+        slotptr.push_back(k + 1);
+      }
+    }
+  return "";
+}
 
 #define DCHK(d, call)                                                          \
   do {                                                                         \
@@ -243,6 +286,56 @@ int fpsq_dense_set_jacobian(fpsq_dense d, const double* a_rowmajor) {
   hipSetDevice(d->device);
   DCHK(d, hipMemcpy2DAsync(d->A, (size_t)d->npad * 8, a_rowmajor, (size_t)d->n * 8, (size_t)d->n * 8, (size_t)d->m,
                            hipMemcpyDefault, d->stream));
+  DCHK(d, hipStreamSynchronize(d->stream));
+  d->have_jac = true;
+  d->factored = false;
+  return FPSQ_OK;
+}
+
+int fpsq_dense_set_structure_coo(fpsq_dense d, int64_t nnz, const int64_t* rows, const int64_t* cols, int32_t index_base) {
+  if (!d || nnz < 0 || nnz >= INT32_MAX || (nnz > 0 && (!rows || !cols))) return FPSQ_ERR_ARG;
+  hipSetDevice(d->device);
+  std::vector<int64_t> r(nnz), c(nnz);
+  if (nnz) {
+    DCHK(d, hipMemcpy(r.data(), rows, (size_t)nnz * 8, hipMemcpyDefault));
+    DCHK(d, hipMemcpy(c.data(), cols, (size_t)nnz * 8, hipMemcpyDefault));
+  }
+  std::vector<int32_t> order, slotptr, srow, scol;
+  const std::string msg = coo_sort(d->m, d->n, nnz, r.data(), c.data(), index_base, order, slotptr, srow, scol);
+  if (!msg.empty()) {
+    d->err = "dense_set_structure_coo: " + msg;
+    return FPSQ_ERR_ARG;
+  }
+  const int64_t ns = (int64_t)srow.size();
+  std::vector<int64_t> target(std::max<int64_t>(ns, 1));
+  for (int64_t i = 0; i < ns; ++i) target[i] = (int64_t)srow[i] * d->npad + scol[i];
+  const bool dup = ns != nnz;
+  if (dmalloc(d, &d->coo_perm, (size_t)std::max<int64_t>(nnz, 1)) || dmalloc(d, &d->coo_in, (size_t)std::max<int64_t>(nnz, 1)) ||
+      dmalloc(d, &d->coo_target, target.size()) || (dup && dmalloc(d, &d->coo_slotptr, slotptr.size())))
+    return FPSQ_ERR_HIP;
+  if (nnz) DCHK(d, hipMemcpy(d->coo_perm, order.data(), (size_t)nnz * 4, hipMemcpyHostToDevice));
+  DCHK(d, hipMemcpy(d->coo_target, target.data(), target.size() * 8, hipMemcpyHostToDevice));
+  if (dup) DCHK(d, hipMemcpy(d->coo_slotptr, slotptr.data(), slotptr.size() * 4, hipMemcpyHostToDevice));
+  // entries outside the pattern are zero for good: the value hand-over only rewrites the pattern's slots
+  DCHK(d, hipMemsetAsync(d->A, 0, (size_t)d->mpad * d->npad * 8, d->stream));
+  DCHK(d, hipStreamSynchronize(d->stream));
+  d->coo_nnz = nnz;
+  d->coo_slots = ns;
+  d->have_jac = false;
+  return FPSQ_OK;
+}
+
+int fpsq_dense_set_jacobian_coo(fpsq_dense d, const double* vals) {
+  if (!d || d->coo_nnz < 0 || (!vals && d->coo_nnz > 0)) {
+    if (d) d->err = "dense_set_jacobian_coo: structure not set (fpsq_dense_set_structure_coo) or null values";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(d->device);
+  if (d->coo_nnz > 0) {
+    DCHK(d, hipMemcpyAsync(d->coo_in, vals, (size_t)d->coo_nnz * 8, hipMemcpyDefault, d->stream));
+    hipLaunchKernelGGL(k_coo_to_slots, dim3((unsigned)std::min<int64_t>((d->coo_slots + 255) / 256, 4096)), dim3(256), 0,
+                       d->stream, d->coo_in, d->coo_perm, d->coo_slotptr, d->coo_target, d->A, d->coo_slots);
+  }
   DCHK(d, hipStreamSynchronize(d->stream));
   d->have_jac = true;
   d->factored = false;
@@ -464,6 +557,10 @@ struct fpsq_band_s {
   int lookahead = 0;
   int potrf_gen = 5;  // as fpsq_dense_s (4 or 5)
   int direct128 = 1;  // as fpsq_dense_s
+  // jac_coord! hand-over (fpsq_band_create_coo): the caller's COO entries sorted into the CSR slots
+  int64_t coo_nnz = -1;
+  int32_t *coo_perm = nullptr, *coo_slotptr = nullptr;
+  double *coo_in = nullptr, *csr_in = nullptr;
   fpsq_band_info info{};
   std::vector<void*> allocs;
 };
@@ -992,6 +1089,63 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   b->info.factor_bytes = (int64_t)fbytes;
   *out = b;
   return FPSQ_OK;
+}
+
+int fpsq_band_create_coo(fpsq_band* out, int64_t n, int64_t m, int64_t nnz, const int64_t* rows, const int64_t* cols,
+                         int32_t index_base, int32_t device) {
+  if (!out || n <= 0 || m <= 0 || nnz < 0 || nnz >= INT32_MAX || (nnz > 0 && (!rows || !cols))) {
+    g_band_create_error = "fpsq_band_create_coo: bad arguments";
+    return FPSQ_ERR_ARG;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_band_create_error = "fpsq_band_create_coo: cannot select the device";
+    return FPSQ_ERR_HIP;
+  }
+  std::vector<int64_t> r(nnz), c(nnz);
+  if (nnz && (hipMemcpy(r.data(), rows, (size_t)nnz * 8, hipMemcpyDefault) != hipSuccess ||
+              hipMemcpy(c.data(), cols, (size_t)nnz * 8, hipMemcpyDefault) != hipSuccess)) {
+    g_band_create_error = "fpsq_band_create_coo: cannot read the triplets";
+    return FPSQ_ERR_ARG;
+  }
+  std::vector<int32_t> order, slotptr, srow, scol;
+  const std::string msg = coo_sort(m, n, nnz, r.data(), c.data(), index_base, order, slotptr, srow, scol);
+  if (!msg.empty()) {
+    g_band_create_error = "fpsq_band_create_coo: " + msg;
+    return FPSQ_ERR_ARG;
+  }
+  const int64_t ns = (int64_t)srow.size();
+  std::vector<int32_t> rp(m + 1, 0);
+  for (int64_t i = 0; i < ns; ++i) rp[srow[i] + 1]++;
+  for (int64_t i = 0; i < m; ++i) rp[i + 1] += rp[i];
+  if (int rc = fpsq_band_create(out, n, m, rp.data(), scol.data(), device)) return rc;
+  fpsq_band b = *out;
+  const bool dup = ns != nnz;
+  if (bmalloc(b, &b->coo_perm, (size_t)std::max<int64_t>(nnz, 1)) || bmalloc(b, &b->coo_in, (size_t)std::max<int64_t>(nnz, 1)) ||
+      bmalloc(b, &b->csr_in, (size_t)std::max<int64_t>(ns, 1)) || (dup && bmalloc(b, &b->coo_slotptr, slotptr.size()))) {
+    g_band_create_error = b->err;
+    fpsq_band_destroy(b);
+    *out = nullptr;
+    return FPSQ_ERR_HIP;
+  }
+  if (nnz) hipMemcpy(b->coo_perm, order.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
+  if (dup) hipMemcpy(b->coo_slotptr, slotptr.data(), slotptr.size() * 4, hipMemcpyHostToDevice);
+  hipDeviceSynchronize();
+  b->coo_nnz = nnz;
+  return FPSQ_OK;
+}
+
+int fpsq_band_factorize_coo(fpsq_band b, const double* vals, double delta, int32_t* info) {
+  if (!b || b->coo_nnz < 0 || (!vals && b->coo_nnz > 0)) {
+    if (b) b->err = "band_factorize_coo: the handle was not created with fpsq_band_create_coo, or null values";
+    return FPSQ_ERR_ARG;
+  }
+  hipSetDevice(b->device);
+  if (b->coo_nnz > 0) {
+    BCHK(b, hipMemcpyAsync(b->coo_in, vals, (size_t)b->coo_nnz * 8, hipMemcpyDefault, b->stream));
+    hipLaunchKernelGGL(k_coo_to_slots, dim3((unsigned)std::min<int64_t>((b->nnz + 255) / 256, 4096)), dim3(256), 0, b->stream,
+                       b->coo_in, b->coo_perm, b->coo_slotptr, (const int64_t*)nullptr, b->csr_in, b->nnz);
+  }
+  return fpsq_band_factorize(b, b->csr_in, delta, info);  // (same stream: the slots are complete when it reads them)
 }
 
 int fpsq_band_set_regularization(fpsq_band b, double tol, double reg) {

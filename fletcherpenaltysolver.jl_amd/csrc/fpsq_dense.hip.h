@@ -1571,6 +1571,25 @@ __global__ __launch_bounds__(256) void k_csr_mv2(const int32_t* __restrict__ row
   y[(size_t)r * 2 + 1] = a1;
 }
 
+// jac_coord! hand-over on the device (src/solve_linear_system.jl:223-233: `jac_coord!` then `sparse(rows, cols, vals)`):
+// slot i of the back-end's own storage = the sum of the caller's COO entries perm[slotptr[i] .. slotptr[i + 1]) in that
+// (sorted, fixed) order -- duplicates are summed like SparseArrays.sparse does, deterministically; slotptr == null: one
+// entry per slot.  target != null: the slot lives at out[target[i]] (dense row-major storage), else at out[i].
+__global__ __launch_bounds__(256) void k_coo_to_slots(const double* __restrict__ coo, const int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ slotptr, const int64_t* __restrict__ target,
+                                                      double* __restrict__ out, int64_t nslots) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nslots; i += (int64_t)gridDim.x * 256) {
+    double v;
+    if (slotptr) {
+      v = 0.0;
+      for (int k = slotptr[i]; k < slotptr[i + 1]; ++k) v += coo[perm[k]];
+    } else {
+      v = coo[perm[i]];
+    }
+    out[target ? target[i] : i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gather_d(const double* __restrict__ in, const int32_t* __restrict__ perm,
                                                   double* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[perm[i]];

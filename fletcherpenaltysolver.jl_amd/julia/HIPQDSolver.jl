@@ -129,10 +129,10 @@ mutable struct HIPLDLtSolver{T, S} <: QDSolver
   handle::Ptr{Cvoid}
   nvar::Int
   ncon::Int
-  coo_vals::S          # jac_coord! output (model order)
-  csr_vals::S          # the same values in the CSR order handed to fpsq_band_create
-  slot::Vector{Int}    # CSR position of COO entry k (duplicates accumulate)
+  coo_vals::S          # jac_coord! output (model order); sorted into the CSR slots ON THE DEVICE (fpsq_band_factorize_coo)
   p1::S; q1::S; p2::S; q2::S
+  e1::S; e2::S; ep::S  # solve_two_extras has outputs of its own: hprod! Val(1) still reads p2 of the preceding
+                       # solve_two_least_squares after it (src/model-Fletcherpenaltynlp.jl:593-611)
   factorized::Bool
   explicit_linear_constraints::Bool
 end
@@ -143,48 +143,39 @@ function HIPLDLtSolver(nlp::AbstractNLPModel{T, S}, ::T; explicit_linear_constra
   nvar = nlp.meta.nvar
   ncon = explicit_linear_constraints ? nlp.meta.nnln : nlp.meta.ncon
   rows, cols = explicit_linear_constraints ? jac_nln_structure(nlp) : jac_structure(nlp)       # struct.jl:331-337
-  pat = sparse(cols, rows, collect(1.0:length(rows)), nvar, ncon)   # CSC of A' = CSR of A; values = (summed) COO indices, unused
-  rowptr = Int32.(pat.colptr .- 1); colind = Int32.(pat.rowval .- 1)
-  key(r, c) = (r - 1) * nvar + c
-  csrkeys = [key(j, pat.rowval[k]) for j in 1:ncon for k in pat.colptr[j]:(pat.colptr[j + 1] - 1)]
-  slot = [searchsortedfirst(csrkeys, key(rows[k], cols[k])) for k in eachindex(rows)]
   h = Ref{Ptr{Cvoid}}(C_NULL)
-  rc = ccall((:fpsq_band_create, libfpsq), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Int32),
-             h, nvar, ncon, rowptr, colind, 0)                       # symbolic phase = ldl_analyze, struct.jl:344
+  # symbolic phase = ldl_analyze (struct.jl:344); the COO triplets go over as they are (1-based, duplicates summed)
+  rc = ccall((:fpsq_band_create_coo, libfpsq), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Int32),
+             h, nvar, ncon, length(rows), Int64.(rows), Int64.(cols), 1, 0)
   rc == 0 || error(unsafe_string(ccall((:fpsq_band_last_error, libfpsq), Cstring, (Ptr{Cvoid},), C_NULL)))
   ccall((:fpsq_band_set_regularization, libfpsq), Cint, (Ptr{Cvoid}, Float64, Float64), h[], ldlt_tol, -ldlt_r2)  # :345-348
-  qds = HIPLDLtSolver{T, S}(h[], nvar, ncon, S(undef, length(rows)), S(undef, length(csrkeys)), slot, S(undef, nvar),
-                            S(undef, ncon), S(undef, nvar), S(undef, ncon), false, explicit_linear_constraints)
+  qds = HIPLDLtSolver{T, S}(h[], nvar, ncon, S(undef, length(rows)), S(undef, nvar), S(undef, ncon), S(undef, nvar),
+                            S(undef, ncon), S(undef, ncon), S(undef, ncon), S(undef, nvar), false, explicit_linear_constraints)
   finalizer(q -> ccall((:fpsq_band_destroy, libfpsq), Cint, (Ptr{Cvoid},), q.handle), qds)
   return qds
 end
 
 function _factorize!(qds::HIPLDLtSolver, nlp, x, δ)
   qds.explicit_linear_constraints ? jac_nln_coord!(nlp.nlp, x, qds.coo_vals) : jac_coord!(nlp.nlp, x, qds.coo_vals)  # :223-228
-  fill!(qds.csr_vals, 0)
-  for k in eachindex(qds.slot)
-    qds.csr_vals[qds.slot[k]] += qds.coo_vals[k]
-  end
   info = Ref{Int32}(0)
-  rc = ccall((:fpsq_band_factorize, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Float64, Ref{Int32}),
-             qds.handle, qds.csr_vals, δ, info)                       # sparse(...) + ldl_factorize!, :233-234
+  rc = ccall((:fpsq_band_factorize_coo, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Float64, Ref{Int32}),
+             qds.handle, qds.coo_vals, δ, info)                       # sparse(...) + ldl_factorize!, :233-234
   rc < 0 && error(unsafe_string(ccall((:fpsq_band_last_error, libfpsq), Cstring, (Ptr{Cvoid},), qds.handle)))
   qds.factorized = rc == 0
 end
 
-function _band_solve!(qds::HIPLDLtSolver, fn::Symbol, rhs1, rhs2)
+function _band_solve!(qds::HIPLDLtSolver, fn::Symbol, rhs1, rhs2, p1 = qds.p1, q1 = qds.q1, p2 = qds.p2, q2 = qds.q2)
   if !qds.factorized
     @warn "_solve_ldlt_factorization: failed _factorization"                        # linear_system.jl:196-198, :244-246
-    return qds.p1, qds.q1, qds.p2, qds.q2
+    return p1, q1, p2, q2
   end
-  f = fn == :mixed ? :fpsq_band_solve_two_mixed : :fpsq_band_solve_two_least_squares
   rc = fn == :mixed ?
     ccall((:fpsq_band_solve_two_mixed, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-          qds.handle, rhs1, rhs2, qds.p1, qds.q1, qds.p2, qds.q2) :
+          qds.handle, rhs1, rhs2, p1, q1, p2, q2) :
     ccall((:fpsq_band_solve_two_least_squares, libfpsq), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-          qds.handle, rhs1, rhs2, qds.p1, qds.q1, qds.p2, qds.q2)
+          qds.handle, rhs1, rhs2, p1, q1, p2, q2)
   rc < 0 && error(unsafe_string(ccall((:fpsq_band_last_error, libfpsq), Cstring, (Ptr{Cvoid},), qds.handle)))
-  return qds.p1, qds.q1, qds.p2, qds.q2
+  return p1, q1, p2, q2
 end
 
 function solve_two_mixed(nlp::FletcherPenaltyNLP{T, S, A, P, HIPLDLtSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
@@ -197,7 +188,14 @@ function solve_two_least_squares(nlp::FletcherPenaltyNLP{T, S, A, P, HIPLDLtSolv
 end
 
 function solve_two_extras(nlp::FletcherPenaltyNLP{T, S, A, P, HIPLDLtSolver{T, S}}, x::AbstractVector, rhs1, rhs2) where {T, S, A, P}
-  _factorize!(nlp.qdsolver, nlp, x, max(nlp.δ, 1e-14))                                           # :148: tau, Jacobian at x
-  _, q1, _, q2 = _band_solve!(nlp.qdsolver, :mixed, rhs1, rhs2)
-  return q1, -q2                                          # (A A' + tau I)^-1 A rhs1,  (A A' + tau I)^-1 rhs2
+  qds = nlp.qdsolver
+  τ = max(nlp.δ, 1e-14)                                                                          # :148: tau, Jacobian at x
+  _factorize!(qds, nlp, x, τ)
+  # own output buffers: p1 / p2 of the preceding solve_two_least_squares stay intact (hprod! Val(1) reads p2 afterwards)
+  _, q1, _, q2 = _band_solve!(qds, :mixed, rhs1, rhs2, qds.ep, qds.e1, qds.ep, qds.e2)
+  qds.e2 .= .-q2
+  # the reference's extras (cgls / minres on the operator) never touch the LDL' factors: leave the cached factor the one
+  # of δ, which the next solve_two_least_squares re-uses (:194-195)
+  τ != nlp.δ && _factorize!(qds, nlp, x, nlp.δ)
+  return q1, qds.e2                                       # (A A' + tau I)^-1 A rhs1,  (A A' + tau I)^-1 rhs2
 end

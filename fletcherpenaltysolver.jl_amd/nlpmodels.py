@@ -253,6 +253,41 @@ class EqQPModel(_Model):
     def hprod(self, x, y, v, obj_weight=1.0): return obj_weight * self.qp.qdiag * np.asarray(v)
 
 
+class TorchEqQPModel(EqQPModel):
+    """The same model with its Jacobian RESIDENT ON THE GPU (torch): `jac_coord` returns a device tensor, which the direct
+    back-ends take in place (fpsq_dense_set_jacobian_coo / fpsq_band_factorize_coo: no Jacobian value crosses PCIe), and
+    c(x), J v, J'v run on the device -- a device-resident user model behind the host-side seam (x, g, c stay host
+    vectors of length n / m, as the seam's signatures have them)."""
+
+    def __init__(self, qp, device=0):
+        import torch
+
+        super().__init__(qp)
+        self._t = torch
+        self._dev = torch.device("cuda", device)
+        crow = torch.from_numpy(np.ascontiguousarray(qp.rowptr, dtype=np.int64)).to(self._dev)
+        col = torch.from_numpy(np.ascontiguousarray(qp.colind, dtype=np.int64)).to(self._dev)
+        self._vals = torch.from_numpy(np.ascontiguousarray(qp.vals, dtype=np.float64)).to(self._dev)
+        if qp.nnz == qp.m * qp.n:   # a dense block: plain GEMV
+            self._Ad = self._vals.view(qp.m, qp.n)
+            self._mv = lambda v: self._Ad @ v
+            self._tmv = lambda v: self._Ad.T @ v
+        else:
+            A = torch.sparse_csr_tensor(crow, col, self._vals, size=(qp.m, qp.n))
+            At = A.to_sparse_coo().t().to_sparse_csr()
+            self._mv = lambda v: (A @ v.unsqueeze(1)).squeeze(1)
+            self._tmv = lambda v: (At @ v.unsqueeze(1)).squeeze(1)
+        self._b = torch.from_numpy(np.ascontiguousarray(qp.b)).to(self._dev)
+
+    def _up(self, v):
+        return self._t.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(self._dev)
+
+    def cons(self, x): return (self._mv(self._up(x)) - self._b).cpu().numpy()
+    def jprod(self, x, v): return self._mv(self._up(v)).cpu().numpy()
+    def jtprod(self, x, v): return self._tmv(self._up(v)).cpu().numpy()
+    def jac_coord(self, x): return self._vals
+
+
 class ADModel(_Model):
     """`ADNLPModel(f, x0, c, lcon, ucon)` of the reference's tests: a host user model whose derivatives come from
     automatic differentiation (here torch.autograd on the CPU in fp64, where the reference uses ForwardDiff through

@@ -28,6 +28,20 @@ class QDSolver:
         raise NotImplementedError
 
 
+
+def _coord_values(vals):
+    """The output of jac_coord! as the library takes it: a contiguous fp64 array on the host, or a torch CUDA tensor
+    (a device-resident model: the values never leave HBM; its producer stream is synchronised first, the direct back-ends
+    read on their own stream)."""
+    if getattr(vals, "is_cuda", False):
+        import torch
+
+        vals = vals.contiguous()
+        assert vals.dtype == torch.float64
+        torch.cuda.current_stream(vals.device).synchronize()
+        return vals
+    return np.ascontiguousarray(vals, dtype=np.float64)
+
 REG_DROP = 1e200  # include/fpsq.h FPSQ_REG_DROP: a vanishing pivot of M is dropped (its multiplier comes out as zero)
 
 class FpsqError(RuntimeError):
@@ -179,10 +193,12 @@ class HIPDirectQDSolver(QDSolver):
         if self._lib.fpsq_dense_create(C.byref(d), self.nvar, self.ncon, int(kwargs.get("device", 0))) != 0:
             raise FpsqError(self._lib.fpsq_dense_last_error(None).decode())
         self._d = d
+        # jac_structure! once (struct.jl:331-337): the COO pattern stays on the device, sorted; per x only the output of
+        # jac_coord! crosses the boundary (host or device memory) -- no dense array, no re-ordering on the host
         rows, cols = nlp.jac_structure()
-        self._rows = np.asarray(rows, dtype=np.int64) - 1
-        self._cols = np.asarray(cols, dtype=np.int64) - 1
-        self._A = np.zeros((self.ncon, self.nvar))
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        self._check(self._lib.fpsq_dense_set_structure_coo(d, rows.size, rows.ctypes.data, cols.ctypes.data, 1))
         self.factorized = False
         se = float(np.sqrt(np.finfo(float).eps))
         self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)        # struct.jl:312
@@ -208,9 +224,8 @@ class HIPDirectQDSolver(QDSolver):
 
     def _factorize(self, nlp, x, delta=None):
         delta = float(nlp.delta if delta is None else delta)
-        self._A[:] = 0.0
-        np.add.at(self._A, (self._rows, self._cols), np.asarray(nlp.pen.jac_coord(x), dtype=np.float64))
-        self._check(self._lib.fpsq_dense_set_jacobian(self._d, self._A.ctypes.data))
+        vals = _coord_values(nlp.pen.jac_coord(x))                                     # linear_system.jl:223-228
+        self._check(self._lib.fpsq_dense_set_jacobian_coo(self._d, _lib.ptr(vals)))
         info = C.c_int32()
         rc = self._check(self._lib.fpsq_dense_factorize(self._d, delta, C.byref(info)))
         self.factorized = rc == 0
@@ -246,6 +261,10 @@ class HIPDirectQDSolver(QDSolver):
         if self._fact_key != (np.asarray(x, dtype=np.float64).tobytes(), tau):
             self._factorize(nlp, x, tau)
         _, q1, _, q2 = self._solve(self._lib.fpsq_dense_solve_two_mixed, rhs1, rhs2)
+        if tau != float(nlp.delta):
+            # the reference's extras never touch the LDL' factors (cgls / minres on the operator): leave the cached factor
+            # the one of delta, which the next solve_two_least_squares re-uses (linear_system.jl:194-195)
+            self._factorize(nlp, x)
         return q1, -q2
 
     def info(self):
@@ -266,28 +285,20 @@ class HIPBandedDirectQDSolver(QDSolver):
 
     def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, ldlt_tol=None, ldlt_r1=None, ldlt_r2=None,
                  **kwargs):
-        import scipy.sparse as sp
-
         if explicit_linear_constraints:
             from .nlpmodels import NonlinearConstraintsView
             nlp = NonlinearConstraintsView(nlp)
         self.explicit_linear_constraints = bool(explicit_linear_constraints)
         self._lib = _lib.load()
         self.nvar, self.ncon = int(nlp.meta.nvar), int(nlp.meta.ncon)
+        # jac_structure! once (struct.jl:331-337), in the model's COO order (1-based, duplicates allowed): sorted into CSR
+        # slots by the library, the order kept on the device
         rows, cols = nlp.jac_structure()
-        rows, cols = np.asarray(rows, dtype=np.int64) - 1, np.asarray(cols, dtype=np.int64) - 1
-        # COO (model order, duplicates allowed) -> CSR slots; `_slot[k]` = CSR position of COO entry k
-        pat = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(self.ncon, self.nvar))
-        pat.sum_duplicates()
-        pat.sort_indices()
-        self._rp, self._ci = pat.indptr.astype(np.int32), pat.indices.astype(np.int32)
-        key = rows * self.nvar + cols
-        csr_key = np.repeat(np.arange(self.ncon, dtype=np.int64), np.diff(pat.indptr)) * self.nvar + pat.indices
-        self._slot = np.searchsorted(csr_key, key)
-        self._nnz = int(pat.nnz)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
         b = C.c_void_p()
-        rc = self._lib.fpsq_band_create(C.byref(b), self.nvar, self.ncon, self._rp.ctypes.data, self._ci.ctypes.data,
-                                        int(kwargs.get("device", 0)))
+        rc = self._lib.fpsq_band_create_coo(C.byref(b), self.nvar, self.ncon, rows.size, rows.ctypes.data, cols.ctypes.data,
+                                            1, int(kwargs.get("device", 0)))
         if rc != 0:
             raise FpsqError(self._lib.fpsq_band_last_error(None).decode())
         self._b = b
@@ -316,10 +327,9 @@ class HIPBandedDirectQDSolver(QDSolver):
 
     def _factorize(self, nlp, x, delta=None):
         delta = float(nlp.delta if delta is None else delta)
-        vals = np.zeros(self._nnz)
-        np.add.at(vals, self._slot, np.asarray(nlp.pen.jac_coord(x), dtype=np.float64))
+        vals = _coord_values(nlp.pen.jac_coord(x))                                     # linear_system.jl:223-228
         info = C.c_int32()
-        rc = self._check(self._lib.fpsq_band_factorize(self._b, vals.ctypes.data, delta, C.byref(info)))
+        rc = self._check(self._lib.fpsq_band_factorize_coo(self._b, _lib.ptr(vals), delta, C.byref(info)))
         self.factorized = rc == 0
         self._fact_key = (np.asarray(x, dtype=np.float64).tobytes(), delta) if rc == 0 else None
         return rc
@@ -348,6 +358,8 @@ class HIPBandedDirectQDSolver(QDSolver):
         if self._fact_key != (np.asarray(x, dtype=np.float64).tobytes(), tau):
             self._factorize(nlp, x, tau)
         _, q1, _, q2 = self._solve(self._lib.fpsq_band_solve_two_mixed, rhs1, rhs2)
+        if tau != float(nlp.delta):
+            self._factorize(nlp, x)   # (the cached factor stays the one of delta, see HIPDirectQDSolver.solve_two_extras)
         return q1, -q2
 
     def info(self):

@@ -256,6 +256,12 @@ int fpsq_dense_create(fpsq_dense *out, int64_t n, int64_t m, int32_t device);
 int fpsq_dense_destroy(fpsq_dense d);
 const char *fpsq_dense_last_error(fpsq_dense d);
 int fpsq_dense_set_jacobian(fpsq_dense d, const double *a_rowmajor); /* m x n, the Jacobian at the current x */
+/* The reference's hand-over instead of a dense array: `jac_structure!` once (src/solve_two_systems_struct.jl:331-337: COO
+ * triplets in the model's order, index_base 1 for Julia, duplicates allowed), then per x the output of `jac_coord!`
+ * (src/solve_linear_system.jl:223-228) -- nnz values in that order, HOST or DEVICE memory; one scatter kernel puts them into
+ * the dense storage, duplicates summed in a fixed order like `sparse(rows, cols, vals)` (:233). */
+int fpsq_dense_set_structure_coo(fpsq_dense d, int64_t nnz, const int64_t *rows, const int64_t *cols, int32_t index_base);
+int fpsq_dense_set_jacobian_coo(fpsq_dense d, const double *vals);
 int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t *info);
 /* Dynamic regularisation of LDLFactorizations.jl as the reference's LDLtSolver configures it
  * (src/solve_two_systems_struct.jl:345-348: tol = r1 = sqrt(eps), r2 = -sqrt(eps)).  A pivot d of M = A A' + delta I with
@@ -313,6 +319,13 @@ typedef struct {
   int64_t chains;            /* 2: the band is eliminated from both ends at once (two streams), 1: one chain */
 } fpsq_band_info;
 int fpsq_band_create(fpsq_band *out, int64_t n, int64_t m, const int32_t *rowptr, const int32_t *colind, int32_t device);
+/* The same from the model's COO structure (`jac_structure!`, struct.jl:331-337; index_base 1 for Julia; duplicates allowed
+ * and summed) -- with fpsq_band_factorize_coo taking the output of `jac_coord!` (nnz values in that order, HOST or DEVICE
+ * memory): the sorted order is kept on the device and one gather(-sum) kernel fills the CSR slots, so neither the caller nor
+ * the binding re-orders anything per x (src/solve_linear_system.jl:223-234). */
+int fpsq_band_create_coo(fpsq_band *out, int64_t n, int64_t m, int64_t nnz, const int64_t *rows, const int64_t *cols,
+                         int32_t index_base, int32_t device);
+int fpsq_band_factorize_coo(fpsq_band b, const double *vals, double delta, int32_t *info);
 /* the ordering decisions of fpsq_band_create alone, on the host (no device needed; rowptr / colind in HOST memory): row_perm
  * (m entries, may be null) = the caller's row stored at each position, info = blocks / half bandwidth / factor bytes /
  * reordered / chains of the structure fpsq_band_create would set up. */
