@@ -22,29 +22,18 @@ struct fpsq_dense_s {
   double* A = nullptr;     // mpad x npad, row-major, zero padded
   double* M = nullptr;     // mpad x mpad: lower triangle holds the Cholesky factor after factorize
   double* invs = nullptr;  // nb inverses of the diagonal 128 x 128 blocks of L
-  double* invsT = nullptr; // ... and their transposes (k_potrf_inv128p / 128m, k_trsv_step2 / step3)
+  double* invsT = nullptr; // ... and their transposes (k_potrf_inv128m, k_trsv_step3)
   int64_t regularized = 0; // pivots replaced by the dynamic regularisation in the last factorisation
   double *r2 = nullptr, *y2 = nullptr, *x2 = nullptr, *part = nullptr;  // [mpad][2], [mpad][2], [npad][2], gemvt partials
   double *in_a = nullptr, *in_b = nullptr, *o_p1 = nullptr, *o_p2 = nullptr, *o_q1 = nullptr, *o_q2 = nullptr;
   int* info_dev = nullptr;
   int nchunk = 16;
-  int gram_waves = 16;  // waves per 128 x 128 tile of the Gram product (FPSQ_DENSE_GRAM_WAVES=4: k_gemm_nt_f64)
-  int direct128 = 1;  // panel / trailing update by k_gemm128_lds (FPSQ_DENSE_GEMM128=0: the staged kernels)
-  int potrf_gen = 5;  // diagonal-block kernel: 5 = 16-column panels with the panel updates, row substitutions and the doubling
-                      // inverse on the matrix cores (k_potrf_inv128m), 4 = the same in scalar code (k_potrf_inv128p),
-                      // 1 = unblocked in LDS (k_potrf_inv128, round 1); FPSQ_DENSE_POTRF selects
-  int gram_kd = 16;        // k-depth of an LDS stage of the Gram product (FPSQ_DENSE_GRAM_KD = 16 | 32; 32 measured
-                           // slower, 0.83 against 0.78 ms: the kernel is not waiting for its operand prefetch)
-  int splitk = 1;          // k-slices of the Gram-matrix product (balance of the 128 x 128 tiles over the CUs)
-  double* planes = nullptr;  // splitk partial planes of M
+  // (one generation of every kernel is left in the source: the sixteen-wave Gram product k_gemm_nt_f64_w16, the diagonal-block
+  // kernel k_potrf_inv128m, the single-round-trip step products k_gemm128_lds and the latency-organised solve step
+  // k_trsv_step3.  Their predecessors, the look-ahead and split-K variants -- all measured slower, DESIGN.md section 7 --
+  // and the environment switches that selected them were removed in round 3.)
   double piv_tol = 0.0, piv_reg = 0.0;  // dynamic regularisation (fpsq_dense_set_regularization); reg <= 0: off
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  hipStream_t stream2 = nullptr;               // look-ahead: trailing updates off the critical path
-  hipEvent_t evA = nullptr, evB = nullptr;
-  int lookahead = 0;                           // FPSQ_DENSE_LOOKAHEAD=1: first panel / trailing tile + next potrf on this stream,
-                                               // the rest of the step on a second one.  Off: it measured 2.62 ms against 2.45 ms
-                                               // (n = 4096, m = 2048) -- a step's tiles all run concurrently on their own CUs, so
-                                               // taking most of them off the stream shortens nothing, and the extra launches cost
   // jac_coord! hand-over (fpsq_dense_set_structure_coo): the caller's COO entries sorted by target, duplicates grouped
   int64_t coo_nnz = -1, coo_slots = 0;
   int32_t *coo_perm = nullptr, *coo_slotptr = nullptr;
@@ -117,24 +106,10 @@ int dmalloc(fpsq_dense d, T** p, size_t count) {
 void solve_two_rhs(fpsq_dense d) {
   hipStream_t s = d->stream;
   const int nb = (int)d->nb, ld = (int)d->mpad;
-  if (d->potrf_gen >= 5) {
-    for (int k = 0; k < nb; ++k)
-      hipLaunchKernelGGL(k_trsv_step3<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, k, 0);
-    for (int k = nb - 1; k >= 0; --k)
-      hipLaunchKernelGGL(k_trsv_step3<false>, dim3(k + 1), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->y2, d->r2, k, 0);
-    return;
-  }
-  if (d->potrf_gen >= 3) {
-    for (int k = 0; k < nb; ++k)
-      hipLaunchKernelGGL(k_trsv_step2<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, k);
-    for (int k = nb - 1; k >= 0; --k)
-      hipLaunchKernelGGL(k_trsv_step2<false>, dim3(k + 1), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->y2, d->r2, k);
-    return;
-  }
   for (int k = 0; k < nb; ++k)
-    hipLaunchKernelGGL(k_trsv_step<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->r2, d->y2, k);
+    hipLaunchKernelGGL(k_trsv_step3<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, k, 0);
   for (int k = nb - 1; k >= 0; --k)
-    hipLaunchKernelGGL(k_trsv_step<false>, dim3(k + 1), dim3(256), 0, s, d->M, ld, d->invs, d->y2, d->r2, k);
+    hipLaunchKernelGGL(k_trsv_step3<false>, dim3(k + 1), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->y2, d->r2, k, 0);
   // solution now in d->r2
 }
 
@@ -182,7 +157,7 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   d->m = m;
   d->device = device;
   d->mpad = (m + kDB - 1) / kDB * kDB;
-  d->npad = (n + kDK - 1) / kDK * kDK;
+  d->npad = (n + kW16Kd - 1) / kW16Kd * kW16Kd;  // whole k-stages of the Gram product
   d->nb = d->mpad / kDB;
   d->nchunk = (int)std::min<int64_t>(32, d->nb * 4);
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -193,10 +168,6 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   hipEventCreate(&d->e0);
   hipEventCreate(&d->e1);
   hipEventCreate(&d->e2);
-  hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking);
-  hipEventCreateWithFlags(&d->evA, hipEventDisableTiming);
-  hipEventCreateWithFlags(&d->evB, hipEventDisableTiming);
-  if (const char* ev = std::getenv("FPSQ_DENSE_LOOKAHEAD")) d->lookahead = std::atoi(ev);
   int rc = 0;
   rc |= dmalloc(d, &d->A, (size_t)d->mpad * d->npad);
   rc |= dmalloc(d, &d->M, (size_t)d->mpad * d->mpad);
@@ -225,37 +196,10 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   // on the solver's own (non-blocking) stream: a null-stream memset is not ordered against it
   hipMemsetAsync(d->A, 0, (size_t)d->mpad * d->npad * 8, d->stream);
   hipStreamSynchronize(d->stream);
-  // the potrf + inverse kernel keeps a 128 x 129 (+ 128) fp64 block in dynamic LDS
-  hipFuncSetAttribute((const void*)k_potrf_inv128, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (kDB * (kDB + 1) + kDB) * 8);
-  hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5);
   hipFuncSetAttribute((const void*)k_gemm128_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds0);
   hipFuncSetAttribute((const void*)k_gemm128_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds1);
-  if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) {
-    const int gen = std::atoi(ev);
-    d->potrf_gen = gen >= 5 ? 5 : gen >= 2 ? 4 : 1;  // (generations 2 and 3 are no longer in the source)
-  }
-  if (const char* ev = std::getenv("FPSQ_DENSE_GEMM128")) d->direct128 = std::atoi(ev);
-  if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_WAVES")) d->gram_waves = std::atoi(ev);
-  if (const char* ev = std::getenv("FPSQ_DENSE_GRAM_KD")) d->gram_kd = std::atoi(ev);
-  hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds32);
   hipFuncSetAttribute((const void*)k_gemm_nt_f64_w16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kW16Lds);
-  hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
-  hipFuncSetAttribute((const void*)k_gemm_nt_f64<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
-  {
-    // k-slices of the Gram product (FPSQ_DENSE_SPLITK, default 1 = off).  Measured at n = 4096, m = 2048 on the MI355X with
-    // the sixteen-wave kernel: 0.56 / 0.60 / 0.64 ms for 1 / 2 / 4 slices (four-wave kernel: 0.76 / 0.94 / 1.09 / 1.18 ms
-    // for 1 / 8 / 12 / 15) -- cutting the 136 tiles finer does not help, and the reduction of the planes comes on top.
-    int64_t S = 1;
-    if (const char* ev = std::getenv("FPSQ_DENSE_SPLITK")) S = std::max(1, std::atoi(ev));
-    d->splitk = (int)S;
-    if (S > 1 && dmalloc(d, &d->planes, (size_t)S * d->mpad * d->mpad)) {
-      g_dense_create_error = d->err;
-      fpsq_dense_destroy(d);
-      return FPSQ_ERR_HIP;
-    }
-  }
   d->info.n = n;
   d->info.m = m;
   *out = d;
@@ -270,12 +214,6 @@ int fpsq_dense_destroy(fpsq_dense d) {
   if (d->e0) hipEventDestroy(d->e0);
   if (d->e1) hipEventDestroy(d->e1);
   if (d->e2) hipEventDestroy(d->e2);
-  if (d->evA) hipEventDestroy(d->evA);
-  if (d->evB) hipEventDestroy(d->evB);
-  if (d->stream2) {
-    hipStreamSynchronize(d->stream2);
-    hipStreamDestroy(d->stream2);
-  }
   if (d->stream) hipStreamDestroy(d->stream);
   delete d;
   return FPSQ_OK;
@@ -354,92 +292,28 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
   DCHK(d, hipMemsetAsync(d->info_dev, 0, 8, s));
   hipEventRecord(d->e0, s);
   // M = A A' (lower tiles) on the fp64 matrix cores, then + delta I
-  if (d->splitk > 1) {
-    const int ksteps = (int)(d->npad / kDK);
-    const int kchunk = (ksteps + d->splitk - 1) / d->splitk * kDK;
-    const size_t zs = (size_t)d->mpad * d->mpad;
-    if (d->gram_waves == 16 && kchunk % kW16Kd == 0)
-      hipLaunchKernelGGL(k_gemm_nt_f64_w16<true>, dim3(nb, nb, d->splitk), dim3(1024), kW16Lds, s, d->planes, ld, d->A,
-                         (int)d->npad, d->A, (int)d->npad, (int)d->npad, 1.0, 0.0, kchunk, zs);
-    else
-      hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb, d->splitk), dim3(256), kGemmLds16, s, d->planes, ld, d->A, (int)d->npad,
-                         d->A, (int)d->npad, (int)d->npad, 1.0, 0.0, kchunk, zs);
-    hipLaunchKernelGGL(k_syrk_reduce, dim3(nb, nb), dim3(256), 0, s, d->M, ld, d->planes, zs, d->splitk, (int)d->m, delta);
-  } else {
-    if (d->gram_waves == 16 && d->npad % kW16Kd == 0)
-      hipLaunchKernelGGL(k_gemm_nt_f64_w16<true>, dim3(nb, nb), dim3(1024), kW16Lds, s, d->M, ld, d->A, (int)d->npad, d->A,
-                         (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
-    else if (d->gram_kd == 32 && d->npad % 32 == 0)
-      hipLaunchKernelGGL((k_gemm_nt_f64<true, 32>), dim3(nb, nb), dim3(256), kGemmLds32, s, d->M, ld, d->A, (int)d->npad, d->A,
-                         (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
-    else
-      hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(nb, nb), dim3(256), kGemmLds16, s, d->M, ld, d->A, (int)d->npad, d->A,
-                         (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
-    hipLaunchKernelGGL(k_dense_diag, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->M, ld, (int)d->m,
-                       (int)d->mpad, delta);
-  }
+  hipLaunchKernelGGL(k_gemm_nt_f64_w16<true>, dim3(nb, nb), dim3(1024), kW16Lds, s, d->M, ld, d->A, (int)d->npad, d->A,
+                     (int)d->npad, (int)d->npad, 1.0, 0.0, 0, (size_t)0);
+  hipLaunchKernelGGL(k_dense_diag, dim3((unsigned)((d->mpad + 255) / 256)), dim3(256), 0, s, d->M, ld, (int)d->m, (int)d->mpad,
+                     delta);
   hipEventRecord(d->e1, s);
   // right-looking blocked Cholesky, block 128: potrf + inverse of the diagonal block (one workgroup), panel
   // L_ik = M_ik Linv_kk' and trailing update M_ij -= L_ik L_jk' on the matrix cores
   for (int k = 0; k < nb; ++k) {
     double* Mkk = d->M + (size_t)k * kDB * ld + (size_t)k * kDB;
     double* inv = d->invs + (size_t)k * kDB * kDB;
-    if (d->potrf_gen >= 5)
-      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, s, Mkk, ld, inv,
-                         d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
-    else if (d->potrf_gen == 4)
-      hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, s, Mkk, ld, inv,
-                         d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
-    else
-      hipLaunchKernelGGL(k_potrf_inv128, dim3(1), dim3(kPotrfThreads), (kDB * (kDB + 1) + kDB) * 8, s, Mkk, ld, inv, k * kDB,
-                         d->info_dev);
+    hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, s, Mkk, ld, inv,
+                       d->invsT + (size_t)k * kDB * kDB, k * kDB, d->info_dev, d->piv_tol, d->piv_reg);
     const int rem = nb - k - 1;
-    if (rem > 0) {
+    if (rem > 0) {  // the K = 128 products of the step, each in one memory round trip (k_gemm128_lds)
       double* panel = d->M + (size_t)(k + 1) * kDB * ld + (size_t)k * kDB;
       double* trail = d->M + (size_t)(k + 1) * kDB * ld + (size_t)(k + 1) * kDB;
-      if (d->potrf_gen < 3) {  // (the older generations keep the round-1 launch sequence)
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0,
-                           0, (size_t)0);
-        hipLaunchKernelGGL(k_gemm_nt_f64<true>, dim3(rem, rem), dim3(256), kGemmLds16, s, trail, ld, panel, ld, panel, ld, kDB, -1.0,
-                           1.0, 0, (size_t)0);
-        continue;
-      }
-      if (!d->lookahead && d->direct128) {  // unstaged K = 128 products (k_gemm128_lds)
-        hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(1024), kG128Lds1, s, panel, ld, panel, ld, inv, kDB,
-                           BlockStrides{});
-        hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(1024), kG128Lds0, s, trail, ld, panel, ld, panel, ld,
-                           BlockStrides{});
-        continue;
-      }
-      if (!d->lookahead) {  // 64 x 64 tiles for the K = 128 products (k_gemm_nt_f64_t64)
-        // (the panel is updated IN PLACE: its tiles must own whole rows, so it stays on the 128-wide kernel)
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0,
-                           0, (size_t)0);
-        hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s, trail, ld, panel, ld, panel, ld,
-                           kDB, -1.0, 1.0, BlockStrides{}, 0);
-        continue;
-      }
-      // LOOK-AHEAD: the next diagonal block only needs the first panel tile and the first tile of the trailing update;
-      // they stay on this stream, in front of the next potrf (one workgroup, ~100 us), while the rest of the panel and of
-      // the trailing update runs next to that potrf on the second stream.
-      hipStream_t s2 = d->stream2;
-      if (k > 0) hipStreamWaitEvent(s, d->evB, 0);  // step k - 1's trailing rest wrote M(k+1, k) and M(k+1, k+1)
-      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, 1), dim3(256), kGemmLds16, s, panel, ld, panel, ld, inv, kDB, kDB, 1.0, 0.0, 0,
-                         (size_t)0);
-      hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2, 2), dim3(256), 0, s, trail, ld, panel, ld, panel, ld, kDB, -1.0, 1.0,
-                         BlockStrides{}, 0);
-      hipEventRecord(d->evA, s);
-      hipStreamWaitEvent(s2, d->evA, 0);
-      if (rem > 1) {
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem - 1), dim3(256), kGemmLds16, s2, panel + (size_t)kDB * ld, ld,
-                           panel + (size_t)kDB * ld, ld, inv, kDB, kDB, 1.0, 0.0, 0, (size_t)0);
-        hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s2, trail, ld, panel, ld, panel, ld,
-                           kDB, -1.0, 1.0, BlockStrides{}, 1);
-      }
-      hipEventRecord(d->evB, s2);
+      hipLaunchKernelGGL(k_gemm128_lds<1>, dim3(1, 4 * rem), dim3(1024), kG128Lds1, s, panel, ld, panel, ld, inv, kDB,
+                         BlockStrides{});
+      hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(1024), kG128Lds0, s, trail, ld, panel, ld, panel, ld,
+                         BlockStrides{});
     }
   }
-  if (d->lookahead && d->potrf_gen >= 3 && nb > 1) hipStreamWaitEvent(s, d->evB, 0);
   hipEventRecord(d->e2, s);
   int32_t hinfo2[2] = {0, 0};
   DCHK(d, hipMemcpyAsync(hinfo2, d->info_dev, 8, hipMemcpyDeviceToHost, s));
@@ -459,10 +333,6 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t* info) {
 
 int fpsq_dense_set_regularization(fpsq_dense d, double tol, double reg) {
   if (!d || !(tol >= 0.0)) return FPSQ_ERR_ARG;
-  if (reg > 0.0 && d->potrf_gen < 3) {
-    d->err = "dense_set_regularization: the diagonal-block kernels 1 and 2 (FPSQ_DENSE_POTRF) do not regularise pivots";
-    return FPSQ_ERR_STATE;
-  }
   d->piv_tol = tol;
   d->piv_reg = reg;
   return FPSQ_OK;
@@ -552,11 +422,8 @@ struct fpsq_band_s {
   int* info_dev = nullptr;
   double piv_tol = 0.0, piv_reg = 0.0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  hipStream_t stream2 = nullptr;  // look-ahead (see fpsq_dense_factorize)
+  hipStream_t stream2 = nullptr;  // the second elimination chain
   hipEvent_t evA = nullptr, evB = nullptr;
-  int lookahead = 0;
-  int potrf_gen = 5;  // as fpsq_dense_s (4 or 5)
-  int direct128 = 1;  // as fpsq_dense_s
   // jac_coord! hand-over (fpsq_band_create_coo): the caller's COO entries sorted into the CSR slots
   int64_t coo_nnz = -1;
   int32_t *coo_perm = nullptr, *coo_slotptr = nullptr;
@@ -753,7 +620,7 @@ inline size_t blk_off(const fpsq_band b, int64_t i, int64_t j) {  // block (i, j
 void band_solve(fpsq_band b) {
   hipStream_t s = b->stream;
   const int nb = (int)b->nb, bw = b->band_w - 1;
-  if (b->potrf_gen >= 5) {
+  {
     int k0 = 0;
     const int cs = b->chain_safe, cb = b->chain_bw;
     hipStream_t s2 = b->stream2;
@@ -788,14 +655,7 @@ void band_solve(fpsq_band b) {
       hipEventRecord(b->evB, s2);
       hipStreamWaitEvent(s, b->evB, 0);
     }
-    return;
   }
-  for (int k = 0; k < nb; ++k)
-    hipLaunchKernelGGL(k_trsv_step2<true>, dim3(std::min(bw, nb - 1 - k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT,
-                       b->r2, b->y2, k, b->band_w);
-  for (int k = nb - 1; k >= 0; --k)
-    hipLaunchKernelGGL(k_trsv_step2<false>, dim3(std::min(bw, k) + 1), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT, b->y2,
-                       b->r2, k, b->band_w);
 }
 
 // shared tail of the two solve entry points: right-hand sides of the M-solves are in b->r2
@@ -1028,7 +888,6 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking);
   hipEventCreateWithFlags(&b->evA, hipEventDisableTiming);
   hipEventCreateWithFlags(&b->evB, hipEventDisableTiming);
-  if (const char* ev = std::getenv("FPSQ_DENSE_LOOKAHEAD")) b->lookahead = std::atoi(ev);
   int rc = 0;
   const size_t nz = (size_t)std::max<int64_t>(nnz, 1);
   rc |= bmalloc(b, &b->rowptr, (size_t)m + 1) | bmalloc(b, &b->colind, nz) | bmalloc(b, &b->vals, nz);
@@ -1066,19 +925,14 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
     hipMemcpy(b->t_perm, tperm.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
   }
   hipDeviceSynchronize();
-  hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds);
   hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5);
   hipFuncSetAttribute((const void*)k_gemm128_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds0);
   hipFuncSetAttribute((const void*)k_gemm128_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kG128Lds1);
-  if (const char* ev = std::getenv("FPSQ_DENSE_POTRF")) b->potrf_gen = std::atoi(ev) >= 5 ? 5 : 4;
-  if (const char* ev = std::getenv("FPSQ_DENSE_GEMM128")) b->direct128 = std::atoi(ev);
   if (b->form_gen == 1)
     hipFuncSetAttribute((const void*)k_band_form, hipFuncAttributeMaxDynamicSharedMemorySize, maxspan * 16);
   else
     hipFuncSetAttribute((const void*)k_band_form_t, hipFuncAttributeMaxDynamicSharedMemorySize,
                         b->form_R * b->band_w * kDB * 8);
-  hipFuncSetAttribute((const void*)k_gemm_nt_f64<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
-  hipFuncSetAttribute((const void*)k_gemm_nt_f64<false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds16);
   b->info.n = n;
   b->info.m = m;
   b->info.nnz = nnz;
@@ -1189,12 +1043,8 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
   auto potrf = [&](hipStream_t q, int k) {
     double* Mkk = b->Mb + blk_off(b, k, k);
     double* inv = b->invs + (size_t)k * kDB * kDB;
-    if (b->potrf_gen >= 5)
-      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, q, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
-                         k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
-    else
-      hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, q, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
-                         k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
+    hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, q, Mkk, kDB, inv, b->invsT + (size_t)k * kDB * kDB,
+                       k * kDB, b->info_dev, b->piv_tol, b->piv_reg);
     return inv;
   };
   auto step = [&](hipStream_t q, int k, int st, int rem) {
@@ -1212,7 +1062,7 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
     hipLaunchKernelGGL(k_gemm128_lds<0>, dim3(2 * rem, 2 * rem), dim3(1024), kG128Lds0, q, trail, kDB, panel, kDB, panel, kDB, ts);
   };
   int k0 = 0;
-  if (b->chain_safe > 0 && b->direct128 && !b->lookahead) {  // the two chains side by side
+  if (b->chain_safe > 0) {  // the two chains side by side
     hipStream_t s2 = b->stream2;
     hipEventRecord(b->evA, s);
     hipStreamWaitEvent(s2, b->evA, 0);
@@ -1224,52 +1074,7 @@ int fpsq_band_factorize(fpsq_band b, const double* vals, double delta, int32_t* 
     hipStreamWaitEvent(s, b->evB, 0);
     k0 = 2 * b->chain_safe;
   }
-  for (int k = k0; k < nb; ++k) {
-    const int rem = std::min(bw, nb - 1 - k);
-    if (!b->lookahead && b->direct128) {
-      step(s, k, 1, rem);
-      continue;
-    }
-    double* inv = potrf(s, k);
-    if (rem > 0) {
-      BlockStrides ps;
-      ps.on = 1;
-      ps.a = ps.ci = (size_t)bw * kDB * kDB;  // block (k + 1 + bi, k): one block row down, one column of the band left
-      ps.b = 0;
-      ps.cj = 0;
-      double* panel = b->Mb + blk_off(b, k + 1, k);
-      BlockStrides ts;
-      ts.on = 1;
-      ts.a = ts.b = ts.ci = (size_t)bw * kDB * kDB;
-      ts.cj = (size_t)kDB * kDB;
-      double* trail = b->Mb + blk_off(b, k + 1, k + 1);
-      if (!b->lookahead) {
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem), dim3(256), kGemmLds16, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0,
-                           0.0, 0, (size_t)0, ps);
-        hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s, trail, kDB, panel, kDB, panel,
-                           kDB, kDB, -1.0, 1.0, ts, 0);
-        continue;
-      }
-      // look-ahead as in fpsq_dense_factorize: first panel tile + first trailing tile here, the rest on the second stream
-      hipStream_t s2 = b->stream2;
-      if (k > 0) hipStreamWaitEvent(s, b->evB, 0);
-      hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, 1), dim3(256), kGemmLds16, s, panel, kDB, panel, kDB, inv, kDB, kDB, 1.0, 0.0, 0,
-                         (size_t)0, ps);
-      hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2, 2), dim3(256), 0, s, trail, kDB, panel, kDB, panel, kDB, kDB, -1.0,
-                         1.0, ts, 0);
-      hipEventRecord(b->evA, s);
-      hipStreamWaitEvent(s2, b->evA, 0);
-      if (rem > 1) {
-        double* panel2 = b->Mb + blk_off(b, k + 2, k);
-        hipLaunchKernelGGL(k_gemm_nt_f64<false>, dim3(1, rem - 1), dim3(256), kGemmLds16, s2, panel2, kDB, panel2, kDB, inv, kDB, kDB,
-                           1.0, 0.0, 0, (size_t)0, ps);
-        hipLaunchKernelGGL(k_gemm_nt_f64_t64<true>, dim3(2 * rem, 2 * rem), dim3(256), 0, s2, trail, kDB, panel, kDB, panel,
-                           kDB, kDB, -1.0, 1.0, ts, 1);
-      }
-      hipEventRecord(b->evB, s2);
-    }
-  }
-  if (b->lookahead && nb > 1 && bw > 0) hipStreamWaitEvent(s, b->evB, 0);
+  for (int k = k0; k < nb; ++k) step(s, k, 1, std::min(bw, nb - 1 - k));
   hipEventRecord(b->e2, s);
   int32_t hinfo[2] = {0, 0};
   BCHK(b, hipMemcpyAsync(hinfo, b->info_dev, 8, hipMemcpyDeviceToHost, s));

@@ -3,8 +3,8 @@
 // small / dense problems (reference: LDLtSolver path, src/solve_linear_system.jl:206-252 and the dense
 // A A' + tau I contraction of src/model-Fletcherpenaltynlp.jl:478-484); MFMA is used only here.
 //
-// All matrices are row-major fp64, padded with zeros to multiples of kDB = 128 (rows of A, order of M) and 16 (columns
-// of A); the padded diagonal of M is set to 1 so the factorisation is unaffected.
+// All matrices are row-major fp64, padded with zeros to multiples of kDB = 128 (rows of A, order of M) and 32 (columns
+// of A: whole k-stages of the Gram product); the padded diagonal of M is set to 1 so the factorisation is unaffected.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,138 +12,30 @@
 namespace fpsq {
 
 constexpr int kDB = 128;      // block size of the Cholesky / GEMM tiles
-constexpr int kDK = 16;       // k-depth of one LDS stage
-constexpr int kGemmLds16 = 4 * 16 * 144 * 8;  // dynamic LDS of k_gemm_nt_f64<., 16> / <., 32>
-constexpr int kGemmLds32 = 4 * 32 * 144 * 8;
-constexpr int kPotrfLds = (kDB * (kDB + 1) + 3 * 32 * 33 + kDB) * 8;  // k_potrf_inv128p: block + scratch + 1/diag
-constexpr int kDLd = 144;     // LDS leading dimension (doubles) of a [k][row] tile: 128 + 16 so that the four k-planes a
-                              // wave reads with one ds_read_b64 fall in disjoint bank halves
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 using f64x2 = __attribute__((ext_vector_type(2))) double;  // (HIP's double2 is a struct: arrays of it stay in scratch)
 
-// Tile addressing of k_gemm_nt_f64 on a BLOCK-BANDED matrix (fpsq_band): 128 x 128 blocks stored contiguously (row
+// Tile addressing of k_gemm128_lds on a BLOCK-BANDED matrix (fpsq_band): 128 x 128 blocks stored contiguously (row
 // stride 128), tile (bi, bj) of C at C + bi * ci + bj * cj, tile bi of A at A + bi * a, tile bj of B at B + bj * b.
 struct BlockStrides {
   int on = 0;
   size_t a = 0, b = 0, ci = 0, cj = 0;
 };
 
-// C (M x N, ldc) = alpha * A (M x K, lda) * B (N x K, ldb)' + beta * C.   M, N multiples of 128, K multiple of 16.
-// One workgroup = one 128 x 128 tile of C, 4 waves in a 2 x 2 grid, each wave 64 x 64 = 4 x 4 MFMA tiles of 16 x 16.
-// LOWER: only tiles with blockIdx.y >= blockIdx.x are computed (symmetric rank-k update of the lower triangle).
+// C (M x N, ldc) = alpha * A (M x K, lda) * B (N x K, ldb)' + beta * C on the fp64 matrix cores.  M, N multiples of 128, K (or
+// the k-chunk of a slice, when gridDim.z > 1: slice z writes the plane C + z * zstride) a multiple of 32.
+// One workgroup = one 128 x 128 tile of C on SIXTEEN waves, each a 32 x 32 sub-tile (2 x 2 MFMA tiles).  LOWER: only tiles with
+// blockIdx.y >= blockIdx.x are computed (symmetric rank-k update of the lower triangle: the Gram product M = A A').
 // Fragment maps of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md section 3): lane l holds A[i = l & 15][k = l >> 4],
 // B[k = l >> 4][j = l & 15]; D register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
-// SPLIT-K (gridDim.z > 1): slice z handles k in [z * kchunk, min(K, (z + 1) * kchunk)) and writes its partial tile to
-// the plane C + z * zstride (beta must be 0); k_syrk_reduce sums the planes in a fixed order.  A 128 x 128 x 4096 tile
-// keeps one CU's matrix cores busy for >= 0.44 ms (v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD on gfx950), so the
-// 136 lower tiles of the m = 2048 Gram matrix leave half the chip idle however fast the kernel is; slices restore the
-// balance.
-// KD = k-depth of one LDS stage (16, or 32 as an experiment: a deeper stage gives the next stage's operand loads twice
-// the time to arrive -- measured slower for the Gram product, 0.83 against 0.78 ms, so that latency is not the bound).
-template <bool LOWER, int KD = kDK>
-__global__ __launch_bounds__(256) void k_gemm_nt_f64(double* C, int ldc, const double* __restrict__ A, int lda,
-                                                     const double* __restrict__ B, int ldb, int K, double alpha,
-                                                     double beta, int kchunk = 0, size_t zstride = 0, BlockStrides bs = {},
-                                                     int skip00 = 0) {
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (LOWER && bi < bj) return;
-  if (skip00 && bi == 0 && bj == 0) return;  // look-ahead: tile (0, 0) of the trailing update is done on the critical stream
-  int kbeg = 0;
-  if (kchunk > 0) {
-    kbeg = (int)blockIdx.z * kchunk;
-    K = min(K, kbeg + kchunk);
-    C += (size_t)blockIdx.z * zstride;
-    A += kbeg;
-    B += kbeg;
-    K -= kbeg;
-    if (K < 0) K = 0;
-  }
-  extern __shared__ __attribute__((aligned(16))) double gsm[];
-  double* sA0 = gsm;                 // [2][KD * kDLd]
-  double* sB0 = gsm + 2 * KD * kDLd;  // [2][KD * kDLd]
-  constexpr int KT = KD / 2;         // k per staging thread (two threads per row)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;  // this wave's 64 x 64 sub-tile
-  // operand / result tiles: rows of a dense matrix, or (bs.on) blocks of a block-banded storage at affine offsets
-  const double* Ab = A + (bs.on ? (size_t)bi * bs.a : (size_t)bi * kDB * lda);
-  const double* Bb = B + (bs.on ? (size_t)bj * bs.b : (size_t)bj * kDB * ldb);
-  // staging: thread t copies 8 consecutive k of row (t >> 1) for both operands
-  const int srow = tid >> 1, sk = (tid & 1) * KT;
-  f64x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-  double ra[KT], rb[KT];
-  auto gload = [&](int k0) {
-    const double2* pa = reinterpret_cast<const double2*>(Ab + (size_t)srow * lda + k0 + sk);
-    const double2* pb = reinterpret_cast<const double2*>(Bb + (size_t)srow * ldb + k0 + sk);
-#pragma unroll
-    for (int q = 0; q < KT / 2; ++q) {
-      const double2 a = pa[q], b = pb[q];
-      ra[2 * q] = a.x;
-      ra[2 * q + 1] = a.y;
-      rb[2 * q] = b.x;
-      rb[2 * q + 1] = b.y;
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < KT; ++q) {
-      sA0[buf * KD * kDLd + (sk + q) * kDLd + srow] = ra[q];
-      sB0[buf * KD * kDLd + (sk + q) * kDLd + srow] = rb[q];
-    }
-  };
-  const int fr = lane & 15, fk = lane >> 4;
-  int buf = 0;
-  if (K > 0) {  // (an empty k-slice still stores its zero tile)
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int k0 = 0; k0 < K; k0 += KD) {
-    const bool more = k0 + KD < K;
-    if (more) gload(k0 + KD);
-#pragma unroll
-    for (int ks = 0; ks < KD / 4; ++ks) {
-      double a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = sA0[buf * KD * kDLd + (ks * 4 + fk) * kDLd + wr + i * 16 + fr];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = sB0[buf * KD * kDLd + (ks * 4 + fk) * kDLd + wc + j * 16 + fr];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-  double* Cb = C + (bs.on ? (size_t)bi * bs.ci + (size_t)bj * bs.cj + (size_t)wr * ldc + wc
-                          : (size_t)(bi * kDB + wr) * ldc + bj * kDB + wc);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* p = Cb + (size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr;
-        const double v = alpha * acc[i][j][r];
-        *p = (beta != 0.0) ? v + beta * *p : v;
-      }
-}
-
-// The same 128 x 128 tile with SIXTEEN waves (the default for the Gram product).  tools/mfma_probe.hip: one wave issues a
-// v_mfma_f64_16x16x4_f64 only every ~140 cycles (196 when it depends on the previous one), whatever the number of
-// independent accumulators; a SIMD reaches its rate only with several waves resident (2 per SIMD: 99 cycles per MFMA).
-// The four-wave kernel above has one wave per SIMD and m = 2048 gives 136 tiles for 256 CUs, so its 0.77 ms was
-// 8192 MFMAs per wave x 140 cycles.  Here each wave owns a 32 x 32 sub-tile (2 x 2 MFMA tiles), four waves per SIMD.
+// Why sixteen waves (tools/mfma_probe.hip): one wave issues a v_mfma_f64_16x16x4_f64 only every ~140 cycles (196 when it
+// depends on the previous one), whatever the number of independent accumulators; a SIMD reaches its rate only with several
+// waves resident (2 per SIMD: 99 cycles per MFMA).  The four-wave kernel of rounds 1-2 (one wave per SIMD, 64 x 64 per wave,
+// removed in round 3) took 0.77 ms for the m = 2048 Gram matrix where this one takes 0.55.
 // LDS tiles are [row][k] with leading dimension KD + 1 doubles: the banks are 4 bytes wide and a ds_read_b64 is served 16
 // lanes at a time, so the 16 rows of an MFMA operand must start 2 banks apart (leading dimension = 1 mod 16) to cover the
 // 32 banks once -- KD + 2, two 8-byte banks apart, measured 50 % conflict cycles.  KD = 32 per stage halves the barriers
-// of sixteen waves.  K (or the split-K chunk) must be a multiple of 32.  Split-K as k_gemm_nt_f64.
+// of sixteen waves.
 constexpr int kW16Kd = 32, kW16Ld = kW16Kd + 1;
 constexpr int kW16Lds = 2 * 2 * kDB * kW16Ld * 8;
 template <bool LOWER>
@@ -229,96 +121,6 @@ __global__ __launch_bounds__(1024) void k_gemm_nt_f64_w16(double* C, int ldc, co
         double* p = Cb + (size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr;
         const double v = alpha * acc[i][j][r];
         *p = (beta != 0.0) ? v + beta * *p : v;
-      }
-}
-
-// The same product on 64 x 64 tiles, for the SHORT-K (K = 128) panel and trailing updates of the blocked Cholesky.  One
-// 128 x 128 x 128 tile keeps a CU's matrix cores busy for >= 13.7 us (a v_mfma_f64_16x16x4_f64 issues every 64 cycles per
-// SIMD on gfx950) and a factorisation step has at most ~120 of them for 256 CUs -- with 64 x 64 tiles four CUs share that
-// work.  4 waves in a 2 x 2 grid, each 32 x 32 = 2 x 2 MFMA tiles.  Tile indices are in units of 64; block addressing
-// (dense rows or BlockStrides) stays in units of 128.
-template <bool LOWER>
-__global__ __launch_bounds__(256) void k_gemm_nt_f64_t64(double* C, int ldc, const double* __restrict__ A, int lda,
-                                                         const double* __restrict__ B, int ldb, int K, double alpha,
-                                                         double beta, BlockStrides bs = {}, int skip00 = 0) {
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (LOWER && bi < bj) return;
-  if (skip00 && (bi >> 1) == 0 && (bj >> 1) == 0) return;
-  constexpr int T = 64, LDT = T + 16;
-  __shared__ double sA[2][kDK * LDT];
-  __shared__ double sB[2][kDK * LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
-  const int Ib = bi >> 1, Jb = bj >> 1, si = (bi & 1) * T, sj = (bj & 1) * T;
-  const double* Ab = A + (bs.on ? (size_t)Ib * bs.a : (size_t)Ib * kDB * lda) + (size_t)si * lda;
-  const double* Bb = B + (bs.on ? (size_t)Jb * bs.b : (size_t)Jb * kDB * ldb) + (size_t)sj * ldb;
-  const int srow = tid >> 2, sk = (tid & 3) * 4;  // staging: 4 consecutive k of row (t >> 2) for both operands
-  f64x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-  double ra[4], rb[4];
-  auto gload = [&](int k0) {
-    const double2* pa = reinterpret_cast<const double2*>(Ab + (size_t)srow * lda + k0 + sk);
-    const double2* pb = reinterpret_cast<const double2*>(Bb + (size_t)srow * ldb + k0 + sk);
-    const double2 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
-    ra[0] = a0.x; ra[1] = a0.y; ra[2] = a1.x; ra[3] = a1.y;
-    rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      sA[buf][(sk + q) * LDT + srow] = ra[q];
-      sB[buf][(sk + q) * LDT + srow] = rb[q];
-    }
-  };
-  const int fr = lane & 15, fk = lane >> 4;
-  int buf = 0;
-  if (K > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int k0 = 0; k0 < K; k0 += kDK) {
-    const bool more = k0 + kDK < K;
-    if (more) gload(k0 + kDK);
-#pragma unroll
-    for (int ks = 0; ks < kDK / 4; ++ks) {
-      double a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = sA[buf][(ks * 4 + fk) * LDT + wr + i * 16 + fr];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = sB[buf][(ks * 4 + fk) * LDT + wc + j * 16 + fr];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-  double* Cb = C + (bs.on ? (size_t)Ib * bs.ci + (size_t)Jb * bs.cj : (size_t)Ib * kDB * ldc + (size_t)Jb * kDB) +
-               (size_t)(si + wr) * ldc + sj + wc;
-  // beta != 0: all loads of the tile first, then the stores
-  double cold[2][2][4];
-  if (beta != 0.0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cold[i][j][r] = Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr];
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double v = alpha * acc[i][j][r];
-        Cb[(size_t)(i * 16 + fk + 4 * r) * ldc + j * 16 + fr] = (beta != 0.0) ? v + beta * cold[i][j][r] : v;
       }
 }
 
@@ -452,164 +254,23 @@ __global__ __launch_bounds__(1024) void k_gemm128_lds(double* C, int ldc, const 
   }
 }
 
-// M (lower 128 x 128 tiles) = sum of the S split-K planes, in plane order; + delta on the diagonal, 1 on the padded diagonal
-__global__ __launch_bounds__(256) void k_syrk_reduce(double* M, int ld, const double* __restrict__ P, size_t zstride, int S,
-                                                     int m, double delta) {
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bi < bj) return;
-  for (int e = threadIdx.x; e < kDB * kDB; e += 256) {
-    const int r = bi * kDB + (e >> 7), c = bj * kDB + (e & 127);
-    const size_t off = (size_t)r * ld + c;
-    double s = 0.0;
-    for (int z = 0; z < S; ++z) s += P[(size_t)z * zstride + off];
-    if (r == c) s = r < m ? s + delta : 1.0;
-    M[off] = s;
-  }
-}
-
 // M[i][i] += delta for i < m; M[i][i] = 1 on the padding
 __global__ void k_dense_diag(double* M, int ld, int m, int mpad, double delta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < mpad) M[(size_t)i * ld + i] = i < m ? M[(size_t)i * ld + i] + delta : 1.0;
 }
 
-// Cholesky of ONE 128 x 128 diagonal block (lower, in place in global memory) AND the inverse of its factor
-// (`inv`, 128 x 128 row-major lower).  One workgroup of 256 threads; the block lives in LDS (dynamic: 128 x 129 + 128
-// doubles).  After L has been written back, it is inverted IN PLACE in LDS (unblocked lower inversion, column by
-// column from the right: X[j+1:, j] = -X[j+1:, j+1:] L[j+1:, j] / L[j][j]).
-// info[0] = first non-positive pivot (1-based global row) or stays 0.
-constexpr int kPotrfThreads = 1024;  // 8 threads per row: the loops are LDS-latency bound, so spread each row thin
-__global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv128(double* Mkk, int ld, double* inv, int row0, int* info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* L = sm;
-  constexpr int LD = kDB + 1, NT = kPotrfThreads, TPR = NT / kDB;
-  double* col = sm + kDB * LD;  // 128 doubles
-  const int tid = threadIdx.x;
-  const int i = tid / TPR, h = tid % TPR;
-  for (int e = tid; e < kDB * kDB; e += NT) {
-    const int r = e >> 7, c = e & 127;
-    L[r * LD + c] = (c <= r) ? Mkk[(size_t)r * ld + c] : 0.0;
-  }
-  __syncthreads();
-  for (int j = 0; j < kDB; ++j) {
-    const double d = L[j * LD + j];
-    const bool bad = !(d > 0.0);
-    if (bad && tid == 0) atomicCAS(info, 0, row0 + j + 1);
-    const double piv = bad ? 1.0 : sqrt(d);  // a unit pivot keeps the kernel finite; the caller reports `info`
-    const double lij = (i > j) ? L[i * LD + j] / piv : 0.0;  // every thread of row i computes the same scaled entry
-    __syncthreads();
-    if (h == 0) {
-      if (i > j) L[i * LD + j] = lij;
-      if (i == j) L[j * LD + j] = piv;
-    }
-    // the scaled column j is needed by all rows: stage it
-    if (h == 1 && i > j) col[i] = lij;
-    __syncthreads();
-    // trailing update of the lower triangle: L[i][c] -= L[i][j] L[c][j], j < c <= i
-    if (i > j) {
-      int c = j + 1 + h;
-      for (; c + 3 * TPR <= i; c += 4 * TPR) {  // four independent read-modify-writes in flight
-        const double a0 = col[c], a1 = col[c + TPR], a2 = col[c + 2 * TPR], a3 = col[c + 3 * TPR];
-        const double b0 = L[i * LD + c], b1 = L[i * LD + c + TPR], b2 = L[i * LD + c + 2 * TPR], b3 = L[i * LD + c + 3 * TPR];
-        L[i * LD + c] = b0 - lij * a0;
-        L[i * LD + c + TPR] = b1 - lij * a1;
-        L[i * LD + c + 2 * TPR] = b2 - lij * a2;
-        L[i * LD + c + 3 * TPR] = b3 - lij * a3;
-      }
-      for (; c <= i; c += TPR) L[i * LD + c] -= lij * col[c];
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < kDB * kDB; e += NT) {
-    const int r = e >> 7, c = e & 127;
-    if (c <= r) Mkk[(size_t)r * ld + c] = L[r * LD + c];
-  }
-  __syncthreads();
-  // in-place inverse of the lower-triangular L, column by column from the right
-  for (int j = kDB - 1; j >= 0; --j) {
-    const double djj = 1.0 / L[j * LD + j];
-    if (tid < kDB) col[tid] = (tid > j) ? L[tid * LD + j] : 0.0;  // column j of L below the diagonal
-    __syncthreads();
-    if (tid == 0) L[j * LD + j] = djj;
-    {
-      double s0 = 0.0, s1 = 0.0;
-      if (i > j) {
-        int p = j + 1 + h;
-        for (; p + TPR <= i; p += 2 * TPR) {
-          s0 += L[i * LD + p] * col[p];
-          s1 += L[i * LD + p + TPR] * col[p + TPR];
-        }
-        for (; p <= i; p += TPR) s0 += L[i * LD + p] * col[p];
-      }
-      double s = s0 + s1;
-#pragma unroll
-      for (int off = TPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      if (i > j && h == 0) L[i * LD + j] = -s * djj;
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < kDB * kDB; e += NT) {
-    const int r = e >> 7, c = e & 127;
-    inv[(size_t)r * kDB + c] = (c <= r) ? L[r * LD + c] : 0.0;
-  }
-}
-
-// ---- generations 2 and 3 of the diagonal-block job are gone from the source (git history, round 2): 64 x 64 and 32 x 32
-// sub-blocks factored and inverted by ONE wave with the rows in registers (v_readlane broadcasts), glued by register-tiled
-// products on the LDS copy.  Both ran at ~220 us per block whatever their arithmetic -- thousands of straight-line
-// instructions executed once per call.  (The unblocked kernel above: three 16-wave barriers per column, 274 us.)
+// ---- Cholesky of ONE 128 x 128 diagonal block AND the inverse of its factor (one workgroup; the serial heart of the blocked
+// factorisation).  One generation is left in the source, the fifth (k_potrf_inv128m, 44 us per block); the others are in
+// the git history of rounds 1-2: (1) unblocked in LDS, three 16-wave barriers per column, 274 us; (2, 3) 64 x 64 / 32 x 32
+// sub-blocks factored by ONE wave with the rows in registers, ~220 us whatever their arithmetic -- thousands of straight-line
+// instructions executed once per call; (4) a ROLLED loop over eight 16-column panels whose only unrolled part is a 16 x 16
+// factor routine on v_readlane broadcasts, left-looking panel updates and row substitutions on the LDS copy, X = L^-1 by
+// doubling: 104 us.
 __device__ __forceinline__ double rdlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
-}
-
-// ---- fourth generation: a left-looking scheme over 16-column panels with COMPACT code.
-// The 64- and 32-wide register routines of generations 2 and 3 were thousands of straight-line instructions executed once per call: the
-// wave spends its time waiting for instruction fetches (both run at ~220 us per block whatever their arithmetic).  Here
-// the only unrolled part is a 16 x 16 factor routine (~500 instructions) that is the body of a ROLLED loop over the eight
-// panels, so it is fetched once and reused; everything else is rolled / lightly unrolled loops over the LDS copy whose
-// LDS reads are issued in batches ahead of the arithmetic (one workgroup has no other wave to hide a round trip behind):
-//   per panel  (a) all threads: panel -= L[:, previous] L[panel rows, previous]'      (4 x 2 register tiles, 8 columns a step)
-//              (b) wave 0: L16 = chol(A16) in registers (v_readlane broadcasts; one rsqrt per column)
-//              (c) one thread per row below: row <- row L16^-T by forward substitution
-//   then the eight diagonal inverses X16 = L16^-1 (128 threads, one column each) and
-//   X = L^-1 by doubling: X(2h) = [X11 0; -X22 (L21 X11) X22] for h = 16, 32, 64, all pairs of a level together,
-//   stored transposed in the upper triangle of the LDS matrix (diagonal kept as 1 / L_ii in `dinv`).
-__device__ __forceinline__ void wave_diag16(double* L, int LD, int o, int row0, int* info, double tol, double reg,
-                                            double* dinv) {
-  const int lane = threadIdx.x & 63;
-  const int rl = lane & 15;  // lanes 16..63 mirror 0..15
-  double a[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) a[c] = L[(o + rl) * LD + o + c];
-  double rdiag = 1.0;  // this lane's 1 / L[rl][rl]
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    double d = rdlane(a[j], j);
-    if (reg > 0.0) {
-      if (!(d > tol)) {
-        d = reg;
-        if (lane == 0) atomicAdd(info + 1, 1);
-      }
-    } else if (!(d > 0.0)) {
-      if (lane == 0) atomicCAS(info, 0, row0 + o + j + 1);
-      d = 1.0;  // a unit pivot keeps the kernel finite; the caller reports `info`
-    }
-    const double rp = rsqrt(d);  // one reciprocal square root per column instead of a square root and a division
-    const double piv = d * rp;
-    rdiag = rl == j ? rp : rdiag;
-    const double l = rl > j ? a[j] * rp : (rl == j ? piv : 0.0);
-    a[j] = l;
-#pragma unroll
-    for (int c = j + 1; c < 16; ++c) a[c] -= l * rdlane(l, c);
-  }
-  if (lane < 16) {
-    dinv[o + lane] = rdiag;
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-      if (c <= lane) L[(o + lane) * LD + o + c] = a[c];  // L16, lower
-  }
 }
 
 #ifdef FPSQ_POTRF_TIMING  // tools/potrf_probe.hip: s_memtime stamps of thread 0 after every phase
@@ -619,223 +280,7 @@ __device__ __forceinline__ void wave_diag16(double* L, int LD, int o, int row0, 
 #define POTRF_STAMP() do {} while (0)
 #define POTRF_TIMING_ARG
 #endif
-__global__ __launch_bounds__(256) void k_potrf_inv128p(double* Mkk, int ld, double* inv, double* invT, int row0,
-                                                       int* info, double tol, double reg POTRF_TIMING_ARG) {
-#ifdef FPSQ_POTRF_TIMING
-  int nst = 0;
-#endif
-  POTRF_STAMP();
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* L = sm;
-  constexpr int LD = kDB + 1;
-  double* T = sm + kDB * LD;  // 64 x 33 scratch of the doubling steps
-  constexpr int TLD = 33;
-  double* dinv = T + 64 * TLD;
-  const int tid = threadIdx.x, wave = tid >> 6;
-  // (16 unconditional loads in flight per thread and pass: a predicated load per element serialises on its latency --
-  // the straightforward loop took 24 us of the kernel's 178)
-#pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = (pass * 16 + u) * 256 + tid;
-      v[u] = Mkk[(size_t)(e >> 7) * ld + (e & 127)];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = (pass * 16 + u) * 256 + tid;
-      const int r = e >> 7, c = e & 127;
-      L[r * LD + c] = (c <= r) ? v[u] : 0.0;
-    }
-  }
-  __syncthreads();
-  POTRF_STAMP();
-  auto Xe = [&](int r, int c) -> double { return r == c ? dinv[r] : L[c * LD + r]; };  // X(r, c), r >= c
-  const int tr = tid >> 3, tc = (tid & 7) * 2;  // 32 x 8 thread grid: rows tr + 32 i, columns tc, tc + 1 of a panel
-#pragma unroll 1
-  for (int pb = 0; pb < 8; ++pb) {
-    const int o = pb * 16;
-    if (pb > 0) {  // (a)
-      double acc[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = 0.0;
-      // o is a multiple of 16: eight columns per step, all 48 LDS reads of a step issued before its 64 FMAs (one read
-      // round trip per step instead of one per column)
-      int rr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rr[i] = min(o + tr + 32 * i, kDB - 1);  // (clamped rows are never stored)
-#pragma unroll 1
-      for (int p0 = 0; p0 < o; p0 += 8) {
-        double b0[8], b1[8], av[4][8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          b0[q] = L[(o + tc) * LD + p0 + q];
-          b1[q] = L[(o + tc + 1) * LD + p0 + q];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) av[i][q] = L[rr[i] * LD + p0 + q];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[i][0] += av[i][q] * b0[q];
-            acc[i][1] += av[i][q] * b1[q];
-          }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = o + tr + 32 * i;
-        if (r < kDB) {
-          if (o + tc <= r) L[r * LD + o + tc] -= acc[i][0];
-          if (o + tc + 1 <= r) L[r * LD + o + tc + 1] -= acc[i][1];
-        }
-      }
-      __syncthreads();
-  POTRF_STAMP();
-    }
-    if (wave == 0) wave_diag16(L, LD, o, row0, info, tol, reg, dinv);  // (b)
-    __syncthreads();
-  POTRF_STAMP();
-    {  // (c)
-      const int r = o + 16 + tid;
-      if (r < kDB) {
-        // x L16' = a by forward substitution (L16 read as LDS broadcasts; a 120-term dependent chain per row, but the
-        // rows run in parallel -- cheaper than inverting L16 inside the single-wave routine)
-        double x[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = L[r * LD + o + c];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double s = x[c];
-#pragma unroll
-          for (int p = 0; p < c; ++p) s -= x[p] * L[(o + c) * LD + o + p];
-          x[c] = s * dinv[o + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) L[r * LD + o + c] = x[c];
-      }
-    }
-    __syncthreads();
-  POTRF_STAMP();
-  }
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    if (c <= r) Mkk[(size_t)r * ld + c] = L[r * LD + c];
-  }
-  POTRF_STAMP();
-  // ---- X = L^-1: the eight diagonal 16 x 16 inverses (column c of block b: L16 x = e_c by substitution, 128 threads),
-  // then by doubling
-  if (tid < kDB) {
-    const int b0 = (tid >> 4) * 16, c = tid & 15;
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      double sacc = r == c ? 1.0 : 0.0;
-#pragma unroll
-      for (int p = 0; p < r; ++p) sacc -= L[(b0 + r) * LD + b0 + p] * x[p];  // (x[p] = 0 for p < c)
-      x[r] = r >= c ? sacc * dinv[b0 + r] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (r > c) L[(b0 + c) * LD + b0 + r] = x[r];
-  }
-  __syncthreads();
-  POTRF_STAMP();
-#pragma unroll 1
-  for (int h = 16; h < kDB; h *= 2) {
-    const int w = h < 32 ? h : 32;  // column chunk; all 128 / (2h) pairs of the level together: 64 x w outputs per chunk
-    const int tpr = w / 4;          // threads per output row (4 columns each)
-#pragma unroll 1
-    for (int cc = 0; cc < h; cc += w) {
-      // T[q h + r][c] = sum_{p >= c} L21[r][p] X11(p, c)
-      for (int t = tid; t < 64 * tpr; t += 256) {
-        const int gr = t / tpr, c4 = (t % tpr) * 4;
-        const int q = gr / h, r = gr % h, b0 = q * 2 * h;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const int pc = cc + c4;
-        // the four leading columns (diagonal / not-yet-lower entries of X): general form
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int p = pc + q;
-          const double lv = L[(b0 + h + r) * LD + b0 + p];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += q >= j ? lv * Xe(b0 + p, b0 + pc + j) : 0.0;
-        }
-        // below them X(p, c) is a plain (transposed) LDS entry: no branch, four columns of loads in flight
-        const double* lrow = L + (b0 + h + r) * LD + b0;
-        const double* x0 = L + (b0 + pc) * LD + b0;  // X(p, pc + j) = x0[j * LD + p]
-        int p = pc + 4;
-        for (; p + 3 < h; p += 4) {
-          double lv[4], xv[4][4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            lv[q] = lrow[p + q];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[q][j] = x0[j * LD + p + q];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += lv[q] * xv[q][j];
-        }
-        for (; p < h; ++p) {
-          const double lv = lrow[p];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += lv * x0[j * LD + p];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) T[gr * TLD + c4 + j] = acc[j];
-      }
-      __syncthreads();
-  POTRF_STAMP();
-      // X21[r][c] = - sum_{p <= r} X22(r, p) T[p][c]
-      for (int t = tid; t < 64 * tpr; t += 256) {
-        const int gr = t / tpr, c4 = (t % tpr) * 4;
-        const int q = gr / h, r = gr % h, b0 = q * 2 * h;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const double* xr = L + (b0 + h) * LD + b0 + h + r;  // X(h + r, h + p) = xr[p * LD] for p < r
-        const double* tq = T + (q * h) * TLD + c4;
-        int p = 0;
-        for (; p + 3 < r; p += 4) {
-          double xv[4], tv[4][4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            xv[u] = xr[(p + u) * LD];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tv[u][j] = tq[(p + u) * TLD + j];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += xv[u] * tv[u][j];
-        }
-        for (; p < r; ++p) {
-          const double xv = xr[p * LD];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += xv * tq[p * TLD + j];
-        }
-        {
-          const double xd = dinv[b0 + h + r];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += xd * tq[r * TLD + j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) L[(b0 + cc + c4 + j) * LD + b0 + h + r] = -acc[j];
-      }
-      __syncthreads();
-  POTRF_STAMP();
-    }
-  }
-  for (int e = tid; e < kDB * kDB; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    inv[(size_t)r * kDB + c] = c < r ? L[c * LD + r] : (c == r ? dinv[r] : 0.0);
-    invT[(size_t)r * kDB + c] = c > r ? L[r * LD + c] : (c == r ? dinv[r] : 0.0);  // X' (upper), for coalesced X r products
-  }
-  POTRF_STAMP();
-}
-
-// ---- fifth generation (the default): generation 4 with its two GEMM-shaped parts on the matrix cores.  The phase
+// ---- the fifth generation: generation 4's scheme with its two GEMM-shaped parts on the matrix cores.  The phase
 // probe of generation 4 (profiles/r02_potrf_phase_probe.txt, cycles of 276k): left-looking panel updates 55k (LDS
 // bandwidth: 6 reads per 8 FMAs), the 16 x 16 factor routine 8 x 8.1k, row substitutions 8 x 2.8k, doubling inverse 84k,
 // load / stores 44k.  Here
@@ -1221,118 +666,6 @@ __global__ __launch_bounds__(256) void k_dense_unpack2(const double* in, double*
 // One launch per step, one workgroup per 128-row block still to be updated plus one that stores the solved block.
 // Every workgroup first recomputes the (tiny) diagonal solve of block k redundantly into LDS -- block k of `r` is
 // only READ in this launch (the solved values go to `out`), so there is no race.
-template <bool FORWARD>
-__global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ Lm, int ld, const double* __restrict__ invs,
-                                                   double* r, double* out, int k) {
-  __shared__ double yk[kDB * 2];
-  const int tid = threadIdx.x;
-  const int blk = FORWARD ? k + (int)blockIdx.x : (int)blockIdx.x;  // forward: blocks k..nb-1, backward: blocks 0..k
-  const double* inv = invs + (size_t)k * kDB * kDB;
-  const int i = tid >> 1, rr = tid & 1;
-  {
-    double s = 0.0;
-    if (FORWARD) {
-      for (int p = 0; p <= i; ++p) s += inv[(size_t)i * kDB + p] * r[(size_t)(k * kDB + p) * 2 + rr];
-    } else {
-      for (int p = i; p < kDB; ++p) s += inv[(size_t)p * kDB + i] * r[(size_t)(k * kDB + p) * 2 + rr];
-    }
-    yk[i * 2 + rr] = s;
-  }
-  __syncthreads();
-  if (blk == k) {
-    out[(size_t)(k * kDB) * 2 + tid] = yk[tid];
-    return;
-  }
-  double s = 0.0;
-  if (FORWARD) {
-    const double* Lb = Lm + (size_t)(blk * kDB + i) * ld + k * kDB;
-    for (int p = 0; p < kDB; ++p) s += Lb[p] * yk[p * 2 + rr];
-  } else {
-    const double* Lb = Lm + (size_t)(k * kDB) * ld + blk * kDB + i;
-    for (int p = 0; p < kDB; ++p) s += Lb[(size_t)p * ld] * yk[p * 2 + rr];
-  }
-  r[(size_t)(blk * kDB + i) * 2 + rr] -= s;
-}
-
-// Second generation of the triangular-solve step: every global access is coalesced.  The diagonal solve reads the
-// inverse in the layout whose rows run along the threads (X' for the forward sweep, X for the backward one: 128
-// independent loads per thread instead of a chain of 128 strided ones), the forward update streams each row of the L
-// block with one wave (2 x 64 lanes x 8 B) and reduces with shuffles; the backward update already reads along rows.
-// band_w > 0: Lm is the block-banded storage of fpsq_band (band_w = blocks per block row, half bandwidth band_w - 1):
-// block (i, j) at Lm + (i * band_w + (j - i + band_w - 1)) * 128 * 128, row stride 128; the grid then only spans the
-// blocks inside the band (forward: k .. k + rem, backward: k - rem .. k, block = k -/+ blockIdx.x).
-template <bool FORWARD>
-__global__ __launch_bounds__(256) void k_trsv_step2(const double* __restrict__ Lm, int ld, const double* __restrict__ inv,
-                                                    const double* __restrict__ invT, double* r, double* out, int k,
-                                                    int band_w = 0) {
-  __shared__ double rk[kDB * 2];
-  __shared__ double yk[kDB * 2];
-  const int tid = threadIdx.x;
-  // dense: forward blocks k..nb-1, backward blocks 0..k
-  const int blk = FORWARD ? k + (int)blockIdx.x : (band_w > 0 ? k - (int)blockIdx.x : (int)blockIdx.x);
-  rk[tid] = r[(size_t)(k * kDB) * 2 + tid];
-  __syncthreads();
-  const int i = tid >> 1, rr = tid & 1;
-  {
-    // forward: y_i = sum_{p <= i} X[i][p] r_p = sum_p X'[p][i] r_p;   backward: q_i = sum_{p >= i} X[p][i] y_p
-    const double* Xc = (FORWARD ? invT : inv) + (size_t)k * kDB * kDB + i;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 8
-    for (int p = 0; p < kDB; p += 4) {
-      s0 += Xc[(size_t)p * kDB] * rk[p * 2 + rr];
-      s1 += Xc[(size_t)(p + 1) * kDB] * rk[(p + 1) * 2 + rr];
-      s2 += Xc[(size_t)(p + 2) * kDB] * rk[(p + 2) * 2 + rr];
-      s3 += Xc[(size_t)(p + 3) * kDB] * rk[(p + 3) * 2 + rr];
-    }
-    yk[i * 2 + rr] = (s0 + s1) + (s2 + s3);
-  }
-  __syncthreads();
-  if (blk == k) {
-    out[(size_t)(k * kDB) * 2 + tid] = yk[tid];
-    return;
-  }
-  if (FORWARD) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const double y00 = yk[lane * 2], y01 = yk[lane * 2 + 1], y10 = yk[(lane + 64) * 2], y11 = yk[(lane + 64) * 2 + 1];
-    for (int q = 0; q < 32; q += 4) {  // 4 rows in flight per wave
-      double a[4][2];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double* Lb = band_w > 0 ? Lm + ((size_t)blk * band_w + (k - blk + band_w - 1)) * kDB * kDB +
-                                            (size_t)(wave * 32 + q + u) * kDB
-                                      : Lm + (size_t)(blk * kDB + wave * 32 + q + u) * ld + k * kDB;
-        a[u][0] = Lb[lane];
-        a[u][1] = Lb[lane + 64];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        double t0 = a[u][0] * y00 + a[u][1] * y10, t1 = a[u][0] * y01 + a[u][1] * y11;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          t0 += __shfl_down(t0, off, 64);
-          t1 += __shfl_down(t1, off, 64);
-        }
-        if (lane == 0) {
-          double* rp = r + (size_t)(blk * kDB + wave * 32 + q + u) * 2;
-          rp[0] -= t0;
-          rp[1] -= t1;
-        }
-      }
-    }
-  } else {
-    const double* Lb = band_w > 0 ? Lm + ((size_t)k * band_w + (blk - k + band_w - 1)) * kDB * kDB + i
-                                  : Lm + (size_t)(k * kDB) * ld + blk * kDB + i;
-    const size_t lds = band_w > 0 ? (size_t)kDB : (size_t)ld;
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-    for (int p = 0; p < kDB; p += 2) {
-      s0 += Lb[(size_t)p * lds] * yk[p * 2 + rr];
-      s1 += Lb[(size_t)(p + 1) * lds] * yk[(p + 1) * 2 + rr];
-    }
-    r[(size_t)(blk * kDB + i) * 2 + rr] -= s0 + s1;
-  }
-}
-
 // The same step organised for LATENCY (the default): a step is a chain link of the triangular solve -- nb (dense) or
 // 2 m / 128 (band) of them run back to back, each with a handful of workgroups -- so what counts is the number of
 // dependent memory round trips inside it.  Here every global load of the step (the 128 x 128 inverse block AND the

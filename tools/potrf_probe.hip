@@ -1,5 +1,5 @@
 // Developer probe (not part of the product): phase timing inside the 128 x 128 diagonal-block kernel of the direct
-// back-ends (k_potrf_inv128p), via s_memtime stamps of thread 0.
+// back-ends (k_potrf_inv128m), via s_memtime stamps of thread 0.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFPSQ_POTRF_TIMING -I fletcherpenaltysolver.jl_amd/csrc -o tools/potrf_probe tools/potrf_probe.hip
 #include "fpsq_dense.hip.h"
 #include <stdio.h>
@@ -26,16 +26,13 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dM, n * n * 8)); CK(hipMalloc(&dinv, n * n * 8)); CK(hipMalloc(&dinvT, n * n * 8));
   CK(hipMalloc(&info, 16)); CK(hipMalloc(&stamps, 64 * 8));
   CK(hipMemset(dinv, 0, n * n * 8)); CK(hipMemset(dinvT, 0, n * n * 8));
-  CK(hipFuncSetAttribute((const void*)k_potrf_inv128p, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds));
   CK(hipFuncSetAttribute((const void*)k_potrf_inv128m, hipFuncAttributeMaxDynamicSharedMemorySize, kPotrfLds5));
   std::vector<long long> hs(64);
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemcpy(dM, M.data(), n * n * 8, hipMemcpyHostToDevice));
     CK(hipMemset(info, 0, 16)); CK(hipMemset(stamps, 0, 64 * 8));
-    if (gen >= 5)
-      hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, 0, dM, n, dinv, dinvT, 0, info, 0.0, 0.0, stamps);
-    else
-      hipLaunchKernelGGL(k_potrf_inv128p, dim3(1), dim3(256), kPotrfLds, 0, dM, n, dinv, dinvT, 0, info, 0.0, 0.0, stamps);
+    (void)gen;  // (the earlier generations were removed from the source in round 3)
+    hipLaunchKernelGGL(k_potrf_inv128m, dim3(1), dim3(kPotrfThreads5), kPotrfLds5, 0, dM, n, dinv, dinvT, 0, info, 0.0, 0.0, stamps);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hs.data(), stamps, 64 * 8, hipMemcpyDeviceToHost));
   }
