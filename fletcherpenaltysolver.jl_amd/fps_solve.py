@@ -45,7 +45,10 @@ class AlgoData:
     subpb_unbounded_threshold: float = 1.0 / _SE
     lagrange_bound: float = 1.0 / _SE
     hessian_approx: int = 2
-    qds_solver: str = "hip"  # key of qdsolver_correspondence (the reference's default is :ldlt, parameters.jl:290)
+    # key of qdsolver_correspondence.  The reference's default is :ldlt (parameters.jl:290); here "auto" = the device's direct
+    # back-end ("hip_ldlt") whenever the normal equations have a narrow band (every small model does), the iterative one
+    # ("hip") otherwise -- see qdsolver.AutoQDSolver.  "hip_direct": the dense direct back-end.
+    qds_solver: str = "auto"
     subproblem_solver: str = "lbfgs"
 
 

@@ -369,3 +369,49 @@ class HIPBandedDirectQDSolver(QDSolver):
 
 
 qdsolver_correspondence["hip_ldlt"] = HIPBandedDirectQDSolver
+
+
+# ---------------------------------------------------------------------------------------------- back-end selection
+
+AUTO_MAX_BAND_BLOCKS = 4    # half bandwidth of M = A A' + delta I (in 128-row blocks) up to which "auto" goes direct
+AUTO_MAX_BLOCKS = 512       # ... and length of the elimination chain (128-row blocks of M) up to which it does
+
+
+def band_analysis(nlp, explicit_linear_constraints=False):
+    """The symbolic phase alone (fpsq_band_analyze: host only, no device): blocks / half bandwidth / factor bytes / reordered /
+    chains of the block-banded structure `HIPBandedDirectQDSolver` would set up for this model's Jacobian pattern."""
+    import scipy.sparse as sp
+
+    if explicit_linear_constraints:
+        from .nlpmodels import NonlinearConstraintsView
+        nlp = NonlinearConstraintsView(nlp)
+    n, m = int(nlp.meta.nvar), int(nlp.meta.ncon)
+    rows, cols = nlp.jac_structure()
+    pat = sp.csr_matrix((np.ones(len(rows)), (np.asarray(rows) - 1, np.asarray(cols) - 1)), shape=(m, n))
+    pat.sum_duplicates()
+    pat.sort_indices()
+    rp, ci = pat.indptr.astype(np.int32), pat.indices.astype(np.int32)
+    info = _lib.BandInfo()
+    rc = _lib.load().fpsq_band_analyze(n, m, rp.ctypes.data, ci.ctypes.data, None, C.byref(info))
+    return None if rc != 0 else info.as_dict()
+
+
+def AutoQDSolver(nlp, _zero=0.0, *, explicit_linear_constraints=False, **kwargs):
+    """`qdsolver_correspondence["auto"]` -- the default of `fps_solve`.  The reference defaults to its direct back-end
+    (`qds_solver = :ldlt`, src/parameters.jl:290), whose general sparse LDL' copes with any pattern; on the device the direct
+    route is the block-banded factorisation of M = A A' + delta I ("hip_ldlt"), which is exact AND fast only when that band
+    is narrow (small models, grid / PDE-like Jacobians: cfg4 runs at 295 evaluations/s there against 206, unsolved, on the
+    iterative path), and falls off an O(m^3) cliff when the band is full (cfg2: the random Jacobian makes A A' dense).  So:
+    direct when the symbolic phase reports a half bandwidth <= AUTO_MAX_BAND_BLOCKS blocks and <= AUTO_MAX_BLOCKS blocks
+    (chain length), the iterative back-end ("hip", the reference's `:iterative`) otherwise.  `"hip_ldlt"` forces the
+    reference's default behaviour, `"hip"` the matrix-free one."""
+    info = band_analysis(nlp, explicit_linear_constraints)
+    if info is not None and info["bandwidth_blocks"] <= AUTO_MAX_BAND_BLOCKS and info["nblocks"] <= AUTO_MAX_BLOCKS:
+        try:
+            return HIPBandedDirectQDSolver(nlp, _zero, explicit_linear_constraints=explicit_linear_constraints, **kwargs)
+        except FpsqError:
+            pass   # (does not fit the device after all)
+    return HIPQDSolver(nlp, _zero, explicit_linear_constraints=explicit_linear_constraints, **kwargs)
+
+
+qdsolver_correspondence["auto"] = AutoQDSolver

@@ -117,3 +117,32 @@ def test_band_symbolic_phase_on_the_host():
     ci = np.array([0, 7], dtype=np.int32)
     assert lib.fpsq_band_analyze(3, 2, rp.ctypes.data, ci.ctypes.data, None, None) == -1
     assert b"column index out of range" in lib.fpsq_band_last_error(None)
+
+
+def test_auto_backend_choice_follows_the_band(monkeypatch):
+    """qdsolver_correspondence["auto"] (fps_solve's default; the reference's default is :ldlt, parameters.jl:290): the banded
+    direct back-end when the symbolic phase (fpsq_band_analyze: host only) reports a narrow band of A A', the iterative one
+    otherwise.  The constructors are stubbed: no device is needed for the decision."""
+    import fps_amd  # noqa: F401
+    from fps_amd import nlpmodels, problems, qdsolver
+
+    grid = nlpmodels.EqQPModel(problems.aug2dc_like(N=30))            # grid incidence matrix: a few blocks wide
+    rnd = nlpmodels.EqQPModel(problems.random_eqqp(n=20000, m=2000))  # random columns: A A' is dense
+    a, r = qdsolver.band_analysis(grid), qdsolver.band_analysis(rnd)
+    assert a["bandwidth_blocks"] <= qdsolver.AUTO_MAX_BAND_BLOCKS and a["nblocks"] == (grid.meta.ncon + 127) // 128
+    assert r["bandwidth_blocks"] == r["nblocks"] - 1 > qdsolver.AUTO_MAX_BAND_BLOCKS
+    made = []
+    monkeypatch.setattr(qdsolver, "HIPBandedDirectQDSolver", lambda nlp, z, **kw: made.append("hip_ldlt") or "direct")
+    monkeypatch.setattr(qdsolver, "HIPQDSolver", lambda nlp, z, **kw: made.append("hip") or "iterative")
+    assert qdsolver.qdsolver_correspondence["auto"](grid, 0.0) == "direct"
+    assert qdsolver.qdsolver_correspondence["auto"](rnd, 0.0) == "iterative"
+    assert qdsolver.qdsolver_correspondence["auto"](nlpmodels.HS6(), 0.0) == "direct"   # every small model goes direct
+    assert made == ["hip_ldlt", "hip", "hip_ldlt"]
+
+    def refuse(nlp, z, **kw):
+        raise qdsolver.FpsqError("does not fit")
+
+    monkeypatch.setattr(qdsolver, "HIPBandedDirectQDSolver", refuse)   # the device says no after all: iterative
+    assert qdsolver.qdsolver_correspondence["auto"](grid, 0.0) == "iterative"
+    from fps_amd.fps_solve import AlgoData
+    assert AlgoData().qds_solver == "auto"

@@ -160,3 +160,54 @@ def test_fps_solve_through_the_banded_direct_backend(sub, ha):
     assert stats.status == "first_order", (stats.status, stats.solver_specific)
     assert np.linalg.norm(stats.solution - xstar) <= 1e-6 * np.linalg.norm(xstar)
     assert np.linalg.norm(stats.multipliers - lam) <= 1e-5 * max(1.0, np.linalg.norm(lam))
+
+
+def test_default_backend_is_auto_and_goes_direct_on_small_models():
+    """fps_solve without `qds_solver`: "auto" (the reference's default is its direct back-end, parameters.jl:290) -- the
+    banded direct back-end on every small model (exact: the reference's acceptance bounds AND its LDLt-level accuracy), the
+    iterative one where A A' has no narrow band."""
+    from fps_amd import problems
+    from fps_amd.qdsolver import HIPBandedDirectQDSolver, HIPQDSolver, qdsolver_correspondence
+
+    nlp = nlpmodels.HS6()
+    stats = fps_solve(nlp, nlp.meta.x0)
+    _accept(stats, nlp.meta.x0)
+    assert np.linalg.norm(stats.solution - np.array([1.0, 1.0])) < 1e-5
+    q = qdsolver_correspondence["auto"](nlp, 0.0)
+    assert isinstance(q, HIPBandedDirectQDSolver)
+    q.close()
+    q = qdsolver_correspondence["auto"](nlpmodels.EqQPModel(problems.aug2dc_like(N=40)), 0.0)   # cfg4's family
+    assert isinstance(q, HIPBandedDirectQDSolver) and q.info()["bandwidth_blocks"] <= 4
+    q.close()
+    q = qdsolver_correspondence["auto"](nlpmodels.EqQPModel(problems.random_eqqp(n=20000, m=2000)), 0.0)  # cfg2's family
+    assert isinstance(q, HIPQDSolver)
+    q.close()
+
+
+def test_config2_pattern_through_the_direct_backend_at_reduced_size(oracle):
+    """BASELINE configs[1]'s Jacobian (100 random columns per row: A A' is DENSE) through "hip_ldlt", the reference's default
+    route: the band is full (every block of M is stored and factored: O(m^3) work -- the cliff `auto` steers around), the
+    answers are exact.  m = 800 here (the oracle's dense KKT solve stays cheap); the full-size row is in
+    profiles/r03_configs.md: 79 blocks, factorise 20.7 ms + solve 1.8 ms against 0.5 ms per evaluation on the iterative path."""
+    from fps_amd import problems
+    from fps_amd.penalty_nlp import FletcherPenaltyNLP
+    from fps_amd.qdsolver import HIPBandedDirectQDSolver
+
+    qp = problems.random_eqqp(n=2100, m=800)
+    model = nlpmodels.EqQPModel(qp)
+    qds = HIPBandedDirectQDSolver(model, 0.0)
+    i = qds.info()
+    assert i["bandwidth_blocks"] == i["nblocks"] - 1 == 6
+    se = float(np.sqrt(np.finfo(float).eps))
+    for delta in (0.0, se):
+        fp = FletcherPenaltyNLP(model, sigma=1e3, rho=1.0, delta=delta, hessian_approx=2, qds=qds)
+        x = qp.point(3)
+        g, c = model.grad(x), model.cons(x)
+        got = qds.solve_two_mixed(fp, x, g, c)
+        want = oracle.exact_two_mixed(qp.scipy_csr(), delta, g, c)
+        for a, b in zip(got, want):
+            assert np.max(np.abs(a - b)) <= 1e-9 * max(np.max(np.abs(b)), 1e-300)
+        f, gx = fp.objgrad(x)
+        ref = oracle.exact_qp_objgrad(qp, x, 1e3, 1.0, delta)
+        assert abs(f - ref["fx"]) <= 1e-9 * abs(ref["fx"]) and np.max(np.abs(gx - ref["gx"])) <= 1e-8 * np.max(np.abs(ref["gx"]))
+    qds.close()
