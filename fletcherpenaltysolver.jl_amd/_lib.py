@@ -96,6 +96,7 @@ SYMBOLS = [
     ("fpsq_local_group_create", C.c_int, [_I32, C.POINTER(_VP)]),
     ("fpsq_local_group_destroy", C.c_int, [_VP]),
     ("fpsq_comm_init_local", C.c_int, [_VP, _VP, _I32]),
+    ("fpsq_local_group_set_p2p", C.c_int, [_VP, _I32]),
     ("fpsq_dense_create", C.c_int, [C.POINTER(_VP), _I64, _I64, _I32]),
     ("fpsq_dense_destroy", C.c_int, [_VP]),
     ("fpsq_dense_last_error", C.c_char_p, [_VP]),

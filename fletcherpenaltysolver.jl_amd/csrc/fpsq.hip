@@ -73,6 +73,14 @@ struct Comm {
   // recv[r * count + i] = rank r's send[i].  Data movement only: the sums are formed by the step kernel in a fixed
   // rank-major order, so replicated scalars are bitwise identical on every rank by construction.
   virtual int allgather(const double* send, double* recv, size_t count, hipStream_t s) = 0;
+  // halo mode, once the handle's exchange buffers exist (collective): a peer-to-peer communicator learns its peers' here
+  struct Buffers {
+    double* gath[2];      // the two (parity) receive buffers of the all-gathers, [nranks][seg_len] each
+    double* halo_recv;    // [(ovl + ovr)][2]
+    int64_t ovl, ovr;
+  };
+  virtual int arm(const Buffers&) { return 0; }
+  virtual bool failed() { return false; }  // a bounded wait of the peer-to-peer route expired
   virtual ~Comm() {}
 };
 
@@ -174,6 +182,14 @@ struct LocalGroup {
   hipEvent_t ready[8] = {};
   hipEvent_t copied[8] = {};
   hipEvent_t done = nullptr;
+  // peer-to-peer route (fpsq_local_group_set_p2p): what every shard published at arm()
+  bool p2p = false;
+  struct Pub {
+    double* gath[2];
+    unsigned long long* flags;  // 8 gather flag words (one per sender), then "from left", "from right"
+    double* halo_recv;
+    int64_t ovl, ovr;
+  } pub[8] = {};
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const long gen = generation;
@@ -254,6 +270,78 @@ struct LocalComm : Comm {
   }
 };
 
+// The same logical shards with NO collective call inside the Krylov loop (SURVEY 8e / VERDICT: the route that replaces
+// the three RCCL operations per iteration): records are written straight into the peers' buffers and announced by sequence
+// numbers (k_p2p_gather, k_p2p_halo).  Between the GPUs of a node the peers' pointers would come from hipIpcOpenMemHandle
+// and the stores travel over xGMI; here they are the other shards' buffers on the same device, which exercises the protocol
+// (ordering, double buffering, bounded waits), not the link.  Set-up collectives (before arm()) use LocalComm's.
+struct P2PLocalComm : LocalComm {
+  bool armed = false;
+  Buffers mine{};
+  unsigned long long* flags = nullptr;  // device: 8 gather words + 2 halo words (sequence numbers, monotone)
+  int* fail_host = nullptr;             // host-mapped
+  int* fail_dev = nullptr;
+  unsigned long long gather_seq = 0, halo_seq = 0;
+  int arm(const Buffers& b) override {
+    mine = b;
+    if (hipMalloc((void**)&flags, 16 * 8) != hipSuccess || hipMemset(flags, 0, 16 * 8) != hipSuccess ||
+        hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&fail_dev, fail_host, 0) != hipSuccess) {
+      err = "p2p arm: allocation failed";
+      return FPSQ_ERR_HIP;
+    }
+    *fail_host = 0;
+    hipDeviceSynchronize();
+    LocalGroup::Pub& me = g->pub[rank];
+    me.gath[0] = b.gath[0];
+    me.gath[1] = b.gath[1];
+    me.flags = flags;
+    me.halo_recv = b.halo_recv;
+    me.ovl = b.ovl;
+    me.ovr = b.ovr;
+    g->barrier();  // every shard has published
+    armed = true;
+    g->barrier();
+    return 0;
+  }
+  bool failed() override { return fail_host && *fail_host != 0; }
+  int allgather(const double* send, double* recv, size_t count, hipStream_t s) override {
+    if (!armed || (recv != mine.gath[0] && recv != mine.gath[1])) return LocalComm::allgather(send, recv, count, s);
+    const int par = recv == mine.gath[1];
+    P2PPeers P{};
+    P.n = nranks;
+    for (int r = 0; r < nranks; ++r) {
+      P.buf[r] = g->pub[r].gath[par];
+      P.flag[r] = g->pub[r].flags;
+    }
+    hipLaunchKernelGGL(k_p2p_gather, dim3(1), dim3(1024), 0, s, send, (int64_t)count, P, rank, ++gather_seq, fail_dev);
+    return 0;
+  }
+  int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL, double* recvR,
+                    hipStream_t s) override {
+    if (!armed) return LocalComm::halo_exchange(vec, n_loc, NL, tl, tr, recvL, recvR, s);
+    P2PHalo H{};
+    if (rank > 0 && tl > 0) {  // my head region = the left neighbour's tail slot (behind its own head slot)
+      const LocalGroup::Pub& L = g->pub[rank - 1];
+      H.left_dst = L.halo_recv + (size_t)L.ovl * NL;
+      H.left_flag = L.flags + 9;      // its "from right" word
+      H.my_from_left = flags + 8;
+    }
+    if (rank < nranks - 1 && tr > 0) {
+      const LocalGroup::Pub& R = g->pub[rank + 1];
+      H.right_dst = R.halo_recv;
+      H.right_flag = R.flags + 8;     // its "from left" word
+      H.my_from_right = flags + 9;
+    }
+    hipLaunchKernelGGL(k_p2p_halo, dim3(1), dim3(1024), 0, s, vec, tl * NL, tr * NL, H, ++halo_seq, fail_dev);
+    return 0;
+  }
+  ~P2PLocalComm() override {
+    if (flags) hipFree(flags);
+    if (fail_host) hipHostFree(fail_host);
+  }
+};
+
 }  // namespace
 
 struct fpsq_solver_s {
@@ -316,6 +404,8 @@ struct fpsq_solver_s {
   int64_t seg_len = 0;
   int cE = 0, cT = 0, cA = 0, cW = 0;
   bool gather_ready = false;
+  uint64_t gather_calls = 0;    // the all-gathers alternate between the two halves of `gath`: a peer that is one reduction
+                                // ahead never overwrites a record its neighbour has not read yet
   double* comm_vec = nullptr;   // [n][2] all-reduce payload (partial A' products)
   double* comm_scal = nullptr;  // 8 doubles: scalar all-reduce payload
   double* dscal;               // small device scalar scratch
@@ -1197,17 +1287,18 @@ int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, i
       }
     }
     const int64_t len = hi - lo;
-    if (int rc = h->comm->allgather(lo, h->gath, (size_t)len, h->stream)) {
+    double* gbuf = h->gath + (size_t)(h->gather_calls++ & 1) * (size_t)h->seg_len * h->comm->nranks;
+    if (int rc = h->comm->allgather(lo, gbuf, (size_t)len, h->stream)) {
       h->err = h->comm->err;
       return rc;
     }
     for (int k = 0; k < 2; ++k) {
       if (w[k]->kind == STEP_NONE || !sh[k]) continue;
       w[k]->n0 = seg_count(h, w[k]->p0);
-      w[k]->p0 = h->gath + (w[k]->p0 - lo);
+      w[k]->p0 = gbuf + (w[k]->p0 - lo);
       if (w[k]->p1) {
         w[k]->n1 = seg_count(h, w[k]->p1);
-        w[k]->p1 = h->gath + (w[k]->p1 - lo);
+        w[k]->p1 = gbuf + (w[k]->p1 - lo);
       }
       w[k]->nseg = h->comm->nranks;
       w[k]->seg_stride = (int32_t)len;
@@ -1821,7 +1912,7 @@ int ensure_gather_layout(fpsq_handle h) {
   h->cW = c[3];
   h->seg_len = 2 * (int64_t)h->cE + 2 * (int64_t)h->cT + 2 * (int64_t)h->cA + 5 * (int64_t)h->cW;
   if (int rc = dalloc(h, &h->seg, (size_t)h->seg_len)) return rc;
-  if (int rc = dalloc(h, &h->gath, (size_t)h->seg_len * P)) return rc;
+  if (int rc = dalloc(h, &h->gath, (size_t)h->seg_len * P * 2)) return rc;
   HIPCHK(h, hipMemsetAsync(h->seg, 0, (size_t)h->seg_len * 8, h->stream));  // the padding entries stay zero for good
   HIPCHK(h, hipStreamSynchronize(h->stream));
   double* q = h->seg;
@@ -1844,6 +1935,18 @@ int ensure_gather_layout(fpsq_handle h) {
   h->pW[1] = q;
   q += h->cW;
   h->pE3 = q;
+  {
+    Comm::Buffers B{};
+    B.gath[0] = h->gath;
+    B.gath[1] = h->gath + (size_t)h->seg_len * P;
+    B.halo_recv = h->halo_recv;
+    B.ovl = h->ovl;
+    B.ovr = h->ovr;
+    if (int rc = h->comm->arm(B)) {
+      h->err = h->comm->err;
+      return rc;
+    }
+  }
   h->gather_ready = true;
   return 0;
 }
@@ -1883,6 +1986,10 @@ void call_begin(fpsq_handle h) {
 int call_end(fpsq_handle h) {
   if (h->profile) hipEventRecord(h->ev1, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->comm && h->comm->failed()) {
+    h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
+    return FPSQ_ERR_TIMEOUT;
+  }
   float ms = 0.f;
   if (h->profile) hipEventElapsedTime(&ms, h->ev0, h->ev1);
   else ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->t_call).count();
@@ -2936,13 +3043,20 @@ int fpsq_local_group_destroy(void* group) {
   return FPSQ_OK;
 }
 
+int fpsq_local_group_set_p2p(void* group, int32_t on) {
+  LocalGroup* g = (LocalGroup*)group;
+  if (!g) return FPSQ_ERR_ARG;
+  g->p2p = on != 0;
+  return FPSQ_OK;
+}
+
 int fpsq_comm_init_local(fpsq_handle h, void* group, int32_t shard) {
   LocalGroup* g = (LocalGroup*)group;
   if (!h || !g || shard < 0 || shard >= g->n || h->comm) {
     if (h) h->err = "comm_init_local: bad arguments or communicator already set";
     return FPSQ_ERR_ARG;
   }
-  LocalComm* c = new LocalComm();
+  LocalComm* c = g->p2p ? new P2PLocalComm() : new LocalComm();
   c->nranks = g->n;
   c->rank = shard;
   c->g = g;

@@ -937,6 +937,70 @@ __global__ __launch_bounds__(kBlock) void k_local_allgather(GatherSrc S, double*
   }
 }
 
+// ---- peer-to-peer route of the halo-sharded loop (P2PLocalComm today: the shards of ONE process on one GPU; the same
+// kernels with hipIpc-mapped pointers are the xGMI route between the GPUs of a node).  No collective library call: a rank
+// WRITES its record straight into its peers' buffers, then a sequence number into their flag words, and waits -- in the
+// same one-workgroup kernel -- until its own flag words carry that number (the guide's "handoff-flag": plain payload ->
+// release fence -> flag; bounded spins: a missing peer ends in an error flag, never in a hang).
+struct P2PPeers {
+  double* buf[8];               // peer p's receive buffer
+  unsigned long long* flag[8];  // peer p's flag words (one per sender)
+  int32_t n;
+};
+// all-gather: buf[p][rank * count + i] = send[i] for every peer p (itself included); flag[p][rank] = seq; wait own flags
+__global__ __launch_bounds__(1024) void k_p2p_gather(const double* __restrict__ send, int64_t count, P2PPeers P, int rank,
+                                                     unsigned long long seq, int* fail) {
+  for (int p = 0; p < P.n; ++p) {
+    double* dst = P.buf[p] + (size_t)rank * count;
+    for (int64_t i = threadIdx.x; i < count; i += 1024) dst[i] = send[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if ((int)threadIdx.x < P.n)
+    __hip_atomic_store(P.flag[threadIdx.x] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((int)threadIdx.x < P.n) {
+    long spins = 0;
+    while (__hip_atomic_load(P.flag[rank] + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (++spins > 50000000L) {
+        *fail = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __threadfence_system();  // (acquire side: the peers' records are read by the NEXT kernel of this stream)
+}
+// halo exchange: my head region (tl rows) -> the left neighbour's tail slot, my tail region (tr rows) -> the right
+// neighbour's head slot; their flags; then wait for both neighbours' records of this sequence number.
+struct P2PHalo {
+  double *left_dst, *right_dst;                 // where my two regions go (null: no such neighbour)
+  unsigned long long *left_flag, *right_flag;   // the neighbours' flag words for records coming from me
+  unsigned long long *my_from_left, *my_from_right;
+};
+__global__ __launch_bounds__(1024) void k_p2p_halo(const double* __restrict__ raw, int64_t nl, int64_t nr, P2PHalo H,
+                                                   unsigned long long seq, int* fail) {
+  if (H.left_dst)
+    for (int64_t i = threadIdx.x; i < nl; i += 1024) H.left_dst[i] = raw[i];
+  if (H.right_dst)
+    for (int64_t i = threadIdx.x; i < nr; i += 1024) H.right_dst[i] = raw[nl + i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && H.left_flag) __hip_atomic_store(H.left_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 1 && H.right_flag) __hip_atomic_store(H.right_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x < 2) {
+    unsigned long long* f = threadIdx.x == 0 ? H.my_from_left : H.my_from_right;
+    long spins = 0;
+    while (f && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (++spins > 50000000L) {
+        *fail = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __threadfence_system();
+}
+
 // out = a * P + b * y (plain vectors, host-given constants), for the p1 = g - A'q1 and J'c products
 __global__ __launch_bounds__(kBlock) void k_axpby_plain(const double* __restrict__ P, double a, const double* y,
                                                         double b, double* out, int64_t len) {

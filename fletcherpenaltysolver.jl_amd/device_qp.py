@@ -160,12 +160,16 @@ def rccl_unique_id() -> bytes:
 class LocalGroup:
     """In-process stand-in for RCCL: `nshards` row-shard models on ONE GPU, one host thread each."""
 
-    def __init__(self, nshards):
+    def __init__(self, nshards, p2p=False):
+        """p2p: the shards exchange peer to peer (records written into the peers' buffers + sequence flags, no collective call
+        in the Krylov loop: include/fpsq.h fpsq_local_group_set_p2p) instead of through event-ordered copy kernels."""
         self._lib = _lib.load()
         g = C.c_void_p()
         if self._lib.fpsq_local_group_create(nshards, C.byref(g)) != 0:
             raise FpsqError("local_group_create failed")
         self.ptr, self.nshards = g, nshards
+        if p2p:
+            self._lib.fpsq_local_group_set_p2p(g, 1)
 
     def run(self, fns):
         """Run one callable per shard concurrently (collectives rendezvous across the threads)."""

@@ -234,6 +234,13 @@ int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_righ
 int fpsq_local_group_create(int32_t nshards, void **group);
 int fpsq_local_group_destroy(void *group);
 int fpsq_comm_init_local(fpsq_handle h, void *group, int32_t shard);
+/* on != 0 (before the shards attach): the shards of the group exchange their halo records and norm partials PEER TO PEER --
+ * every rank writes its record straight into its peers' buffers, announces it with a sequence number and waits (bounded)
+ * for theirs, one small kernel per exchange and no collective call inside the Krylov loop.  This is the protocol of the
+ * xGMI route between the GPUs of a node (peers' buffers mapped with hipIpcOpenMemHandle instead of living on the same
+ * device); it is exercised here between logical shards of one GPU (<= 3: every shard needs a hardware queue of its own while
+ * it waits), not measured on a multi-GPU node.  Halo mode only. */
+int fpsq_local_group_set_p2p(void *group, int32_t on);
 
 
 /* ---- dense-block Jacobian variant (BASELINE configs[2]; the DIRECT back-end of the seam for small / dense problems).

@@ -856,15 +856,17 @@ def test_row_sharded_objgrad_matches_single_gpu(oracle, nshards, delta):
     group.close()
 
 
-@pytest.mark.parametrize("nshards", [2, 3, 8])
+@pytest.mark.parametrize("nshards,p2p", [(2, False), (3, False), (8, False), (2, True), (3, True)])
 @pytest.mark.parametrize("delta", [0.0, SE])
-def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, delta):
+def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta):
     """HALO mode (include/fpsq.h fpsq_comm_set_halo; the SURVEY 8e contract path): every shard holds only its column
     window of the n-vectors and exchanges the partial A'u products of its two overlap regions with its neighbours
     (in-process communicator: copy kernels instead of ncclSend/ncclRecv) plus 4-double all-reduces.  objgrad and hprod
     on 2 / 3 / 8 shards reproduce the unsharded handle (iteration counts identical, values to 1e-9: only the order of
     the reductions differs); overlaps are bitwise identical on the two ranks that share them; phi is bitwise
-    identical on all shards (replicated scalars)."""
+    identical on all shards (replicated scalars).  p2p: the same through the PEER-TO-PEER route (fpsq_local_group_set_p2p:
+    halo records and norm partials written straight into the peers' buffers, sequence flags, bounded waits -- the protocol
+    of the xGMI route, no collective call in the loop)."""
     from fps_amd.device_qp import LocalGroup
     from fps_amd.distributed import halo_plan, row_partition, shard_qp_halo
 
@@ -883,7 +885,7 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, delta):
     bounds = row_partition(qp.rowptr, nshards)
     plan = halo_plan(qp.rowptr, qp.colind, qp.n, bounds)
     assert plan is not None and plan.max_exchange_doubles() <= 2 * 2 * 512
-    group = LocalGroup(nshards)
+    group = LocalGroup(nshards, p2p=p2p)
     locs = [shard_qp_halo(qp, plan, r) for r in range(nshards)]
     shards = [DeviceEqQP(locs[r], sigma=sigma, rho=rho, delta=delta, comm=("local", group.ptr, r),
                          halo=plan.overlaps(r)) for r in range(nshards)]
