@@ -474,7 +474,7 @@ def main():
 
     # ---- roofline of the dominant kernel: a second pass over the same K points with per-launch HIP events
     roofline = None
-    if not args.no_roofline_pass and not extras:
+    if not args.no_roofline_pass and not extras and not (hfull and args.hessian_approx == 1):  # (timing only for those)
         model.set_profiling(True)
         pa, pat, t_ms, tot_ms = np.zeros(2), np.zeros(2), 0.0, 0.0
         for t in range(W, W + K):

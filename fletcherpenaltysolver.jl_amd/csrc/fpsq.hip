@@ -321,15 +321,17 @@ struct P2PLocalComm : LocalComm {
                     hipStream_t s) override {
     if (!armed) return LocalComm::halo_exchange(vec, n_loc, NL, tl, tr, recvL, recvR, s);
     P2PHalo H{};
+    const int par = recvL != mine.halo_recv;  // which half of the (double-buffered) slots this exchange uses: the same on
+                                              // every rank (all ranks make the same sequence of exchanges)
     if (rank > 0 && tl > 0) {  // my head region = the left neighbour's tail slot (behind its own head slot)
       const LocalGroup::Pub& L = g->pub[rank - 1];
-      H.left_dst = L.halo_recv + (size_t)L.ovl * NL;
+      H.left_dst = L.halo_recv + (size_t)par * (size_t)(L.ovl + L.ovr) * 2 + (size_t)L.ovl * NL;
       H.left_flag = L.flags + 9;      // its "from right" word
       H.my_from_left = flags + 8;
     }
     if (rank < nranks - 1 && tr > 0) {
       const LocalGroup::Pub& R = g->pub[rank + 1];
-      H.right_dst = R.halo_recv;
+      H.right_dst = R.halo_recv + (size_t)par * (size_t)(R.ovl + R.ovr) * 2;
       H.right_flag = R.flags + 8;     // its "from left" word
       H.my_from_right = flags + 9;
     }
@@ -390,7 +392,11 @@ struct fpsq_solver_s {
   // [0, n - ovr) and are all-reduced like the sums over the (row-sharded) m-vectors.
   bool halo = false;
   int64_t ovl = 0, ovr = 0;
-  double* halo_recv = nullptr;  // [(ovl + ovr)][2]: the neighbours' raw sums on the two overlap regions
+  double* halo_recv = nullptr;  // 2 x [(ovl + ovr)][2]: the neighbours' raw sums on the two overlap regions; consecutive
+                                // exchanges alternate between the two halves (a neighbour that is one exchange ahead --
+                                // the epilogue runs several without a reduction in between -- never overwrites a record
+                                // this rank has not consumed yet)
+  uint64_t halo_calls = 0;
   double* halo_raw = nullptr;   // [(ovl + ovr)][2]: this rank's raw sums there (k_spmv<.., HALO>), head region first
   int halo_gf = 0;              // workgroups of k_halo_finish (0: no overlap at all)
   // Halo mode keeps every partial-sum array of the Krylov loop in ONE per-rank segment `seg`, laid out
@@ -936,24 +942,9 @@ int comm_allreduce(fpsq_handle h, double* buf, size_t count) {
   return 0;
 }
 
-// Sum over the ranks of the raw partial A' products in buf ([n][NL]): all-reduce of the replicated n-vector, or, in
-// halo mode, the neighbour exchange of the two overlap regions of the rank's column window.
-int comm_reduce_long(fpsq_handle h, double* buf, int NL) {
-  if (!h->halo) return comm_allreduce(h, buf, (size_t)h->n * NL);
-  double* rl = h->halo_recv;
-  double* rr = h->halo_recv + (size_t)h->ovl * NL;
-  if (int rc = h->comm->halo_exchange(buf, h->n, NL, h->ovl, h->ovr, rl, rr, h->stream)) {
-    h->err = h->comm->err;
-    return rc;
-  }
-  const int64_t cnt = (h->ovl + h->ovr) * NL;
-  if (cnt > 0) {
-    hipLaunchKernelGGL(k_halo_add, dim3(ew_grid(cnt)), dim3(kBlock), 0, h->stream, buf, rl, h->ovl * NL, rr, h->ovr * NL,
-                       (h->n - h->ovr) * NL);
-    h->launches++;
-  }
-  return 0;
-}
+// Sum over the ranks of the raw partial A' products in buf ([n][NL]): all-reduce of the replicated n-vector (the
+// replicated layout; halo mode never comes here: see halo_finish)
+int comm_reduce_long(fpsq_handle h, double* buf, int NL) { return comm_allreduce(h, buf, (size_t)h->n * NL); }
 
 // LP <- ca A' SP + cb LP with norm partials (count returned in *np).  Sharded: every rank holds a row block A_r, so
 // A'x = sum_r A_r' x_r: raw partial product -> all-reduce -> fused axpby + norm on the replicated result.
@@ -963,12 +954,12 @@ template <int NL>
 int halo_finish(fpsq_handle h, const double* yin, double* yout, const LaneCtl* c0, const LaneCtl* c1, double* partials) {
   const int64_t t = h->ovl + h->ovr;
   if (t == 0) return 0;
-  double* rl = h->halo_recv;
+  double* rl = h->halo_recv + (size_t)(h->halo_calls++ & 1) * (size_t)t * 2;
   if (int rc = h->comm->halo_exchange(h->halo_raw, t, NL, h->ovl, h->ovr, rl, rl + (size_t)h->ovl * NL, h->stream)) {
     h->err = h->comm->err;
     return rc;
   }
-  hipLaunchKernelGGL(k_halo_finish<NL>, dim3(h->halo_gf), dim3(kBlock), 0, h->stream, h->halo_raw, h->halo_recv, h->ovl,
+  hipLaunchKernelGGL(k_halo_finish<NL>, dim3(h->halo_gf), dim3(kBlock), 0, h->stream, h->halo_raw, rl, h->ovl,
                      h->ovr, h->n - h->ovr, yin, yout, c0, c1, partials ? partials + h->AT.nblk : nullptr, h->strT, h->gate0,
                      h->gate1);
   h->launches++;
@@ -1023,15 +1014,28 @@ int at_product_const(fpsq_handle h, double ca, const double* x, double cb, const
 // Bounded wait until the device has reached `target` iterations (or finished).  The progress word lives in
 // host-mapped memory and is stored by the scalar kernels; if the stream drains without the word moving (which
 // would mean the mapped store is not visible) we fall back to reading the device state explicitly.
+// one consistent snapshot {iter, done} of a lane's progress word (a single 8-byte load: see publish())
+inline Progress load_progress(const Progress* p) {
+  const uint64_t v = *reinterpret_cast<const volatile uint64_t*>(p);
+  Progress r;
+  r.iter = (int32_t)(uint32_t)(v & 0xffffffffu);
+  r.done = (int32_t)(uint32_t)(v >> 32);
+  return r;
+}
+
 int wait_progress(fpsq_handle h, int lane, int target, const int32_t* dev_done, const int32_t* dev_iter) {
-  volatile Progress* p = &h->prog_host[lane];
+  Progress* p = &h->prog_host[lane];
   const auto t0 = std::chrono::steady_clock::now();
   int spins = 0;
-  while (!p->done && p->iter < target) {
+  auto reached = [&]() {
+    const Progress s = load_progress(p);
+    return s.done || s.iter >= target;
+  };
+  while (!reached()) {
     if ((++spins & 63) == 0) {
       hipError_t q = hipStreamQuery(h->stream);
       if (q == hipSuccess) {
-        if (p->done || p->iter >= target) break;
+        if (reached()) break;
         int32_t d = 0, it = 0;
         HIPCHK(h, hipMemcpy(&d, dev_done, 4, hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy(&it, dev_iter, 4, hipMemcpyDeviceToHost));
@@ -1615,7 +1619,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   };
   auto all_done = [&]() {
     for (int l = 0; l < NL; ++l)
-      if (!h->prog_host[l].done) return false;
+      if (!load_progress(&h->prog_host[l]).done) return false;
     return true;
   };
   // MINRES stage segments of iteration `k` (the Lanczos vector under construction sits in lane l of `pair`)
@@ -1816,11 +1820,13 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (it < expect) continue;
     // bound the run-ahead of the host on the slowest unfinished lane
     int slow = INT32_MAX;
-    for (int l = 0; l < NL; ++l)
-      if (!h->prog_host[l].done) slow = std::min(slow, (int)h->prog_host[l].iter + lag(l));
+    for (int l = 0; l < NL; ++l) {
+      const Progress ps = load_progress(&h->prog_host[l]);
+      if (!ps.done) slow = std::min(slow, (int)ps.iter + lag(l));
+    }
     if (it > expect && it - slow >= look) {
       for (int l = 0; l < NL; ++l) {
-        if (h->prog_host[l].done) continue;
+        if (load_progress(&h->prog_host[l]).done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
         if (int rc = wait_progress(h, l, (int)(it - look + 1) - lag(l), ddone, iter_ptr(l))) return rc;
       }
@@ -1833,7 +1839,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (expect > 0 && it == expect) {
       if (int rc = enqueue_speculative()) return rc;
       for (int l = 0; l < NL; ++l) {
-        if (h->prog_host[l].done) continue;
+        if (load_progress(&h->prog_host[l]).done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
         if (int rc = wait_progress(h, l, (int)it - lag(l), ddone, iter_ptr(l))) return rc;
       }
@@ -2725,7 +2731,7 @@ namespace {
 // stand-alone form of qp_fx (sharded runs: the m-vector sums pass through an all-reduce first)
 __global__ __launch_bounds__(kBlock) void k_qp_fx(const FxArgs a, const LaneCtl* gate0, const LaneCtl* gate1) {
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
-  __shared__ double red[4];
+  __shared__ double red[16];
   qp_fx(a, red);
 }
 }  // namespace
@@ -2814,29 +2820,19 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
     FxArgs none = fa;
     none.out = nullptr;
     if (paired) {
-      // phi rides in this launch as one extra workgroup (everything it sums is complete after k_ys): the scalar result
-      // is on the host a whole product + gradient kernel before the evaluation ends
-      UpdSeg fxs = seg_none();
-      const bool ride_fx = !h->comm && !(h->ab_mask & 4);
-      if (ride_fx) {
-        fxs.kind = UPD_QP_FX;
-        fxs.nblk = 1;
-        fxs.a = const_cast<double*>(fa.pf);
-        fxs.b = const_cast<double*>(fa.pdx);
-        fxs.c = const_cast<double*>(fa.pcy);
-        fxs.d = const_cast<double*>(fa.pcc);
-        fxs.len = (int64_t)fa.np_n | ((int64_t)fa.np_m << 32);
-        fxs.s0 = rho;
-        fxs.s1 = eta;
-        fxs.partials = fa.out;
-        long long bits;
-        std::memcpy(&bits, &seq, 8);
-        fxs.src = (const double*)(size_t)bits;  // (the sequence number travels in the unused source pointer)
+      // phi in a one-workgroup launch of its own right behind k_ys (everything it sums is complete there): the scalar
+      // result is on the host a whole product + gradient kernel before the evaluation ends (stream-ordered outputs).
+      // (Round 3 first let it ride in the product launch below as its first workgroup: the extra case in the product
+      // kernel's update switch cost the A' kernel 11 VGPRs and ~5 % of its time -- 2 % of an evaluation.)
+      const bool early_fx = !h->comm && !(h->ab_mask & 4);
+      if (early_fx) {
+        hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa, h->gate0, h->gate1);
+        h->launches++;
       }
-      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, fxs, seg_none(), h->halo);
+      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), h->halo);
       if (h->halo)
         if (int rc = halo_finish<2>(h, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr)) return rc;
-      const bool grad_fx = !h->comm && !ride_fx;
+      const bool grad_fx = !h->comm && !early_fx;
       hipLaunchKernelGGL(k_qp_penalty_grad, dim3(grad_fx ? gn + 1 : gn), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
                          h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, grad_fx ? fa : none,
                          h->gate0, h->gate1);
@@ -3077,7 +3073,7 @@ int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_righ
   }
   if (h->halo_recv) dfree(h, &h->halo_recv);
   if (h->halo_raw) dfree(h, &h->halo_raw);
-  if (int rc = dalloc(h, &h->halo_recv, (size_t)(overlap_left + overlap_right) * 2)) return rc;
+  if (int rc = dalloc(h, &h->halo_recv, (size_t)(overlap_left + overlap_right) * 2 * 2)) return rc;
   if (int rc = dalloc(h, &h->halo_raw, (size_t)(overlap_left + overlap_right) * 2)) return rc;
   h->halo_gf = overlap_left + overlap_right > 0 ? ew_grid(overlap_left + overlap_right) : 0;
   h->halo = true;

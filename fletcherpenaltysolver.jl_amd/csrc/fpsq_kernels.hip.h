@@ -180,8 +180,7 @@ enum UpdKind : int32_t {
   UPD_NONE = 0, UPD_LSQR, UPD_LSQR_WINIT, UPD_CRAIG_LONG_REG, UPD_CRAIG_LONG, UPD_CRAIG_SHORT,
   UPD_NEG_COPY,  // a[i] = -src[i][lane]: keeps c = -(CRAIG's right-hand side) when the start-up product formed it
   UPD_MINRES_E1, UPD_MINRES_E2, UPD_MINRES_E3,  // the three element-wise stages of a MINRES iteration (upd_minres)
-  UPD_LNLQ_LONG, UPD_LNLQ_SHORT,                // LNLQ: x and (y, wbar) updates (upd_lnlq_*)
-  UPD_QP_FX     // one workgroup: phi of the eq-QP evaluation from its partial sums (qp_fx), riding in the epilogue product
+  UPD_LNLQ_LONG, UPD_LNLQ_SHORT                 // LNLQ: x and (y, wbar) updates (upd_lnlq_*)
 };
 
 struct UpdSeg {
@@ -202,7 +201,6 @@ struct UpdSeg {
   double* d;         // MINRES E2: w1 (read, overwritten by the new w~)
   int64_t len;
   double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
-  double s0, s1;     // UPD_QP_FX: rho, eta (a..d = the four partial arrays, len = their counts, partials = the output)
 };
 
 // LSQR (Krylov.jl lsqr!): x += (phi/rho) w; w = v - (theta/rho) w, with v = vt / alpha deferred.
@@ -352,12 +350,50 @@ __device__ __forceinline__ void upd_lnlq_short(const UpdSeg& s, int blk) {
 // (src/model-Fletcherpenaltynlp.jl:419-433).  out = {phi, f, c'c, seq}: `seq` is stored LAST with system-scope release
 // semantics, so a host that polls it (stream-ordered outputs, see fpsq_set_output_ordering) finds the three values there.
 __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, const double* pcy, const double* pcc, int np_n,
-                                           int np_m, double rho, double eta, double* out, double seq, double* red) {
-  const double f = reduce_partials(pf, np_n, red);
-  const double dx = reduce_partials(pdx, np_n, red);
-  const double cy = reduce_partials(pcy, np_m, red);
-  const double cc = reduce_partials(pcc, np_m, red);
-  if (threadIdx.x == 0) {
+                                           int np_m, double rho, double eta, double* out, double seq, double* red16) {
+  // All four arrays in ONE batch of loads (<= 4 entries per thread and array: the grids of the kernels that wrote them
+  // are capped at kEwBlocksMax = 4 x kBlock), unconditional with clamped indices like k_step's partial_batch; a longer
+  // array falls back to the strided loop.  Fixed summation order.
+  const double* arr[4] = {pf, pdx, pcy, pcc};
+  const int cnt[4] = {np_n, np_n, np_m, np_m};
+  const int t = threadIdx.x;
+  double v[4];
+  if (np_n <= 4 * kBlock && np_m <= 4 * kBlock) {
+    double x[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = u * kBlock + t;
+        x[k][u] = cnt[k] > 0 ? arr[k][i < cnt[k] ? i : cnt[k] - 1] : 0.0;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[k] += (u * kBlock + t < cnt[k]) ? x[k][u] : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = 0.0;
+      for (int i = t; i < cnt[k]; i += kBlock) v[k] += arr[k][i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+  const int lane = t & 63, w = t >> 6;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red16[w * 4 + k] = v[k];
+  }
+  __syncthreads();
+  if (t == 0) {
+    const double f = (red16[0] + red16[4]) + (red16[8] + red16[12]);
+    const double dx = (red16[1] + red16[5]) + (red16[9] + red16[13]);
+    const double cy = (red16[2] + red16[6]) + (red16[10] + red16[14]);
+    const double cc = (red16[3] + red16[7]) + (red16[11] + red16[15]);
     double fx = f - cy;
     if (rho > 0.0) fx += rho / 2 * cc;
     if (eta > 0.0) fx += eta / 2 * dx;
@@ -371,10 +407,6 @@ __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, 
 template <int NL>
 __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
   switch (s.kind) {
-    case UPD_QP_FX:
-      qp_fx_core(s.a, s.b, s.c, s.d, (int)(s.len & 0xffffffff), (int)(s.len >> 32), s.s0, s.s1, s.partials,
-                 __longlong_as_double((long long)(size_t)s.src), red);
-      break;
     case UPD_LNLQ_LONG: upd_lnlq_long<NL>(s, blk); break;
     case UPD_LNLQ_SHORT: upd_lnlq_short<NL>(s, blk); break;
     case UPD_MINRES_E1: upd_minres<NL, 1>(s, blk, red); break;
@@ -445,26 +477,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   double* red = prod;
   // speculatively enqueued epilogue product: runs only once both recurrences of the call have ended
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
-  // A' launches (identity block map): a phi reduction (UPD_QP_FX, one workgroup) is the FIRST workgroup of the grid, not one
-  // of the riding workgroups at its end -- the host waits for that scalar (stream-ordered outputs), and the last workgroups
-  // of a product only start when the kernel is almost over
-  int bid = blockIdx.x;
-  if (TAG == 1 && u0.kind == UPD_QP_FX) {
-    if (bid == 0) {
-      upd_run<NL>(u0, 0, red);
-      return;
-    }
-    bid -= 1;
-    if (bid >= 8 * blk_per_xcd) {  // u1's riding workgroups (none today) keep their place at the end
-      if (bid - 8 * blk_per_xcd < u1.nblk) upd_run<NL>(u1, bid - 8 * blk_per_xcd, red);
-      return;
-    }
-  } else if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) {
-    return;
-  }
+  if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   // A (TAG 0): XCD-contiguous eighths, so an XCD's L2 holds one slice of the long gathered vector.  A' (TAG 1): the gathered
   // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
-  const int L = TAG == 1 ? bid : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
+  const int L = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
   if (L >= A.nblk) return;
   // issued before the (dependent) done-check below: one memory round trip at the head of the workgroup, not two
   const int4 bd = A.blkdesc[L];
@@ -866,17 +882,6 @@ __global__ __launch_bounds__(kBlock) void k_axpby_norm(const double* __restrict_
   }
 }
 
-// Halo mode of the row-sharded A' product: the raw partial products on the two overlap regions of the rank's column
-// window receive the neighbour's partials of the same global columns (a + b on one side, b + a on the other: the
-// overlap ends up bitwise identical on both ranks).  vec: [n_loc][NL]; recvL: [TL][NL] (head), recvR: [TR][NL] (tail).
-__global__ __launch_bounds__(kBlock) void k_halo_add(double* vec, const double* __restrict__ recvL, int64_t nl,
-                                                     const double* __restrict__ recvR, int64_t nr, int64_t tail0) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nl + nr; i += (int64_t)gridDim.x * kBlock) {
-    if (i < nl) vec[i] += recvL[i];
-    else vec[tail0 + (i - nl)] += recvR[i - nl];
-  }
-}
-
 // Halo mode, second half of the row-sharded A' product.  k_spmv<.., HALO> finalised the interior rows of the rank's column
 // window and left the raw sums of its two overlap regions in `raw` ([tl + tr][NL], head region first); `recv` holds the
 // neighbours' raw sums of the same global columns (same layout).  Here, for the overlap rows,
@@ -1168,7 +1173,7 @@ __global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __rest
   if (fx.out) {
     --nb;
     if ((int)blockIdx.x == nb) {
-      __shared__ double red[4];
+      __shared__ double red[16];
       qp_fx(fx, red);
       return;
     }

@@ -18,7 +18,7 @@
 
 namespace fpsq {
 
-struct Progress {  // host-mapped, written by the device, polled by the host
+struct alignas(8) Progress {  // host-mapped, written by the device, polled by the host: ONE 8-byte word, see publish()
   int32_t iter;
   int32_t done;
 };
@@ -29,8 +29,13 @@ __device__ __forceinline__ void publish(Progress* p, int iter, int done) {
   // PCIe round trip on every step.  Even so the END of the kernel waits for these stores to be acknowledged over the
   // host link (measured: the next kernel starts ~3.6 us later than after a step that published nothing), so the steps
   // only publish when the host is going to look: at the end of a recurrence and from iteration `pub_from` on.
-  __hip_atomic_store(&p->iter, iter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(&p->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // {iter, done} go out as ONE naturally aligned 8-byte store and the host reads them with one 8-byte load
+  // (load_progress).  As two stores (rounds 1-2) the host could see iter = k with done still 0 for an instant and take a
+  // recurrence that HAD ended at iteration k for one that had not: it then went on for an iteration whose (otherwise
+  // no-op) A' launch carried the final LSQR update a second time -- the gated speculative flush, whose gates the device
+  // rightly found open, had already applied it.  That was the intermittent last-digits mismatch of hprod (round 2's logs).
+  const unsigned long long v = (unsigned long long)(unsigned)iter | ((unsigned long long)(unsigned)done << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ double dsign(double a) { return (double)((a > 0.0) - (a < 0.0)); }

@@ -1149,7 +1149,8 @@ def test_error_codes_of_the_c_abi():
     assert lib.fpsq_qp_create(h2, ones.ctypes.data, z.ctypes.data, zm.ctypes.data, C.byref(q)) == 0
     fx = C.c_double()
     assert lib.fpsq_qp_objgrad(h, q, z.ctypes.data, 1.0, 1.0, 0.0, None, C.byref(fx), None, None, None, st) == -1
-    assert lib.fpsq_qp_hprod(h, q, z.ctypes.data, 1.0, 1.0, 0.0, z.ctypes.data, st) == -1
+    assert lib.fpsq_qp_hprod(h, q, z.ctypes.data, 1.0, 1.0, 0.0, 2, z.ctypes.data, st) == -1
+    assert lib.fpsq_qp_hprod(h2, q, z.ctypes.data, 1.0, 1.0, 0.0, 3, z.ctypes.data, st) == -1   # hessian_approx is 1 or 2
     # and the right pairing works
     assert lib.fpsq_qp_objgrad(h2, q, z.ctypes.data, 1.0, 1.0, 0.0, None, C.byref(fx), None, None, None, st) >= 0
     lib.fpsq_qp_destroy(q)

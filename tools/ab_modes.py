@@ -26,9 +26,18 @@ workload = os.environ.get("AB_WORKLOAD", "headline")
 qp = problems.pde_control_like(n=1_000_000, m=100_000) if workload == "headline" else problems.random_eqqp(n=100_000, m=10_000)
 dev = torch.device("cuda", 0)
 models = {}
+import ctypes as _C
+_ALL_SYMBOLS = list(_lib.SYMBOLS)
 for lp in libs:
     _lib._LIB = None
     _lib.LIB_PATH = lp
+    # an OLDER build may lack entry points added since: type what it has, stub the optional setters the Python layer calls
+    probe = _C.CDLL(lp)
+    _lib.SYMBOLS = [sy for sy in _ALL_SYMBOLS if hasattr(probe, sy[0])]
+    lib_ = _lib.load()
+    for name in ("fpsq_set_output_ordering",):
+        if not any(sy[0] == name for sy in _lib.SYMBOLS):
+            setattr(lib_, name, lambda *a: 0)
     for ev in envvals:
         if envname:
             os.environ[envname] = ev
