@@ -450,7 +450,8 @@ struct fpsq_solver_s {
   hipEvent_t ev_out = nullptr;
   double call_seq = 0.0;            // sequence number the phi reduction stores behind its results (hscal[3])
   // FPSQ_AB_MASK (developer A/B, tools/ab_modes.py): 1 = gradient kernel not merged into the start-up launch, 2 = final
-  // LSQR update not absorbed by k_ys, 4 = phi reduced by the gradient kernel's extra workgroup, 8 = no stream-ordered return
+  // LSQR update not absorbed by k_ys, 4 = phi reduced by a launch of its own right behind k_ys (default: the gradient
+  // kernel's extra workgroup), 8 = no stream-ordered return
   int ab_mask = 0;
   bool ab_dynamic = false;          // FPSQ_AB_DYNAMIC=1: the mask is re-read from the environment at every qp_objgrad call
   int64_t force_expect = -1;        // fpsq_debug_expect_iterations: overrides the expected count of the next run (test hook)
@@ -2820,11 +2821,13 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
     FxArgs none = fa;
     none.out = nullptr;
     if (paired) {
-      // phi in a one-workgroup launch of its own right behind k_ys (everything it sums is complete there): the scalar
-      // result is on the host a whole product + gradient kernel before the evaluation ends (stream-ordered outputs).
-      // (Round 3 first let it ride in the product launch below as its first workgroup: the extra case in the product
-      // kernel's update switch cost the A' kernel 11 VGPRs and ~5 % of its time -- 2 % of an evaluation.)
-      const bool early_fx = !h->comm && !(h->ab_mask & 4);
+      // phi: by default the extra workgroup of the gradient kernel below.  FPSQ_AB_MASK & 4: a one-workgroup launch of its
+      // own right behind k_ys (everything it sums is complete there), which puts the scalar on the host a whole product +
+      // gradient kernel earlier for the stream-ordered return -- measured on one handle: 814.7 against 818.8 evals/s, the
+      // extra launch costs more than the earlier return gains.  (Round 3 first let it ride in the product launch as its
+      // first workgroup: the extra case in the product kernel's update switch cost the A' kernel 11 VGPRs and ~5 % of its
+      // time -- 2 % of an evaluation.)
+      const bool early_fx = !h->comm && (h->ab_mask & 4);
       if (early_fx) {
         hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa, h->gate0, h->gate1);
         h->launches++;

@@ -817,6 +817,29 @@ def test_speculative_epilogue_every_alignment_is_bitwise_neutral(delta):
     dev.close()
 
 
+def test_repeated_hprod_and_objgrad_calls_are_bitwise_identical():
+    """The same call repeated on fresh and on warm handles gives the same bits every time (all reductions run in fixed
+    orders; no atomics).  Regression test of the round-2 / round-3 race: the progress word used to be two stores, and a host
+    that caught `iter` without `done` applied the final LSQR update twice (~1e-6 in Hv, 2-8 % of the calls of this loop)."""
+    qp = _small_pde(seed=31, n=3000, m=300)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(qp.n)
+    x = qp.xhat + 0.2 * rng.standard_normal(qp.n)
+    want = None
+    for rep in range(12):
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+        for call in range(4):
+            hv, gx, ys = np.empty(qp.n), np.empty(qp.n), np.empty(qp.m)
+            assert dev.hprod(v, hv, 1 + call % 2) == 0
+            f, rc = dev.objgrad(x, gx=gx, ys=ys)
+            got = (hv, gx, ys, np.array([f]))
+            if want is None:
+                want = [a.copy() for a in got]
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (rep, call)
+        dev.close()
+
+
 # ---------------------------------------------------------------------------------------------- row sharding
 
 @pytest.mark.parametrize("nshards", [2, 3])
