@@ -170,15 +170,25 @@ def test_dense_block_config3_size_and_timing():
     rng = np.random.default_rng(0)
     g, c = rng.standard_normal(n), rng.standard_normal(m)
     D = _Dense(A)
+    # the reference's delta schedule (algo.jl:46: 0 first; parameters.jl:77: sqrt(eps) next) and the bench's 1e-3: KKT residuals
+    # AND the solution itself against a host LAPACK solve of the normal equations (round 2 checked one delta, residuals only)
+    import scipy.linalg as sla
+    G = A @ A.T
+    for delta in (0.0, float(np.sqrt(np.finfo(float).eps)), 1e-3):
+        rc, info = D.factorize(delta)
+        assert rc == 0
+        p1, q1, p2, q2 = D.solve(D.lib.fpsq_dense_solve_two_mixed, g, c)
+        r1 = np.linalg.norm(p1 + A.T @ q1 - g) / np.linalg.norm(g)
+        r1b = np.linalg.norm(A @ p1 - delta * q1) / np.linalg.norm(g)
+        r2 = np.linalg.norm(A @ p2 - delta * q2 - c) / np.linalg.norm(c)
+        r2b = np.linalg.norm(p2 + A.T @ q2) / np.linalg.norm(c)
+        assert max(r1, r1b, r2, r2b) < 1e-11, (delta, r1, r1b, r2, r2b)
+        cf = sla.cho_factor(G + delta * np.eye(m), lower=True)
+        w1, w2 = sla.cho_solve(cf, A @ g), -sla.cho_solve(cf, c)
+        assert _rel(q1, w1) < 1e-9 and _rel(q2, w2) < 1e-9 and _rel(p1, g - A.T @ w1) < 1e-9 and _rel(p2, -A.T @ w2) < 1e-9
+        h1, k1, h2, k2 = D.solve(D.lib.fpsq_dense_solve_two_least_squares, g, g[::-1].copy())
+        assert _rel(k2, sla.cho_solve(cf, A @ g[::-1])) < 1e-9 and np.array_equal(k1, q1)
     delta = 1e-3
-    rc, info = D.factorize(delta)
-    assert rc == 0
-    p1, q1, p2, q2 = D.solve(D.lib.fpsq_dense_solve_two_mixed, g, c)
-    r1 = np.linalg.norm(p1 + A.T @ q1 - g) / np.linalg.norm(g)
-    r1b = np.linalg.norm(A @ p1 - delta * q1) / np.linalg.norm(g)
-    r2 = np.linalg.norm(A @ p2 - delta * q2 - c) / np.linalg.norm(c)
-    r2b = np.linalg.norm(p2 + A.T @ q2) / np.linalg.norm(c)
-    assert max(r1, r1b, r2, r2b) < 1e-11
     t0 = time.perf_counter()
     for _ in range(5):
         D.factorize(delta)
