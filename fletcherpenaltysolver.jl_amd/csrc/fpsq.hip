@@ -4,7 +4,7 @@
 // Reference path replaced: src/solve_linear_system.jl:45-140 + src/solve_two_systems_struct.jl:167-244
 // (FletcherPenaltySolver.jl v0.3.0), whose arithmetic runs in Krylov.jl on the CPU.
 #include "../../include/fpsq.h"
-#include "fpsq_krylov.hip.h"
+#include "fpsq_spmv.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -380,6 +380,9 @@ struct fpsq_solver_s {
   int strT = 0, strA = 0;       // lane strides of pS (A' product partials) and pS2 (A product partials)
   LsqrState* lsqr[2];
   CraigState* craig;
+  LsqrState* lsqr_alt[2];       // second copies: the target of a step that rides in a product launch (see run_krylov)
+  CraigState* craig_alt;
+  int stepin_max = 640;         // riding steps when neither product has more workgroups than this (FPSQ_STEPIN_MAX; 0: never)
   MinresState* minres;
   LnlqState* lnlq;
   LaneCtl* ctl_tmp;
@@ -871,28 +874,53 @@ UpdSeg seg_none() {
 // product reads.
 // halo_rows (A' products of a halo-mode handle): the overlap rows of the rank's column window only get their raw sums,
 // see HaloRows / halo_finish.
+// pre (two entries, single-GPU small problems): the scalar steps of the two lanes that follow the previous product ride in
+// this launch (k_spmv / k_spmv_rgcs <.., STEPIN>; stepin_supported() says for which storage variants that exists)
 template <int NL>
 void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, double* yout, const LaneCtl* c0,
                  const LaneCtl* c1, double* partials, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none(),
-                 bool halo_rows = false) {
+                 bool halo_rows = false, const StepArgs* pre = nullptr) {
   const int nupd = u0.nblk + u1.nblk;
   const HaloRows hr{h->ovl, h->n - h->ovr, h->halo_raw};
+  StepArgs z0{}, z1{};
+  if (pre) {
+    z0 = pre[0];
+    z1 = pre[1];
+  }
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
-    if (h->RA.view.stride)
-      launch_product(h, k_spmv_rgcs<NL, true>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd,
-                     u0, u1, h->gate0, h->gate1, h->strA);
-    else
-      launch_product(h, k_spmv_rgcs<NL, false>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials,
-                     per_xcd, u0, u1, h->gate0, h->gate1, h->strA);
+#define FPSQ_LAUNCH_RGCS(...) \
+    launch_product(h, k_spmv_rgcs<__VA_ARGS__>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd, u0, u1, \
+                   h->gate0, h->gate1, h->strA, z0, z1)
+    if constexpr (NL == 2) {
+      if (pre && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true);
+      else if (pre) FPSQ_LAUNCH_RGCS(2, false, true);
+    }
+    if (!pre) {
+      if (h->RA.view.stride) FPSQ_LAUNCH_RGCS(NL, true);
+      else FPSQ_LAUNCH_RGCS(NL, false);
+    }
+#undef FPSQ_LAUNCH_RGCS
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
     const dim3 grid(per_xcd * 8 + nupd);
     const int ps = tag == TAG_A ? h->strA : h->strT;
 #define FPSQ_LAUNCH_SPMV(...) \
-    launch_product(h, k_spmv<__VA_ARGS__>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1, ps, hr)
-    if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_A, true);
+    launch_product(h, k_spmv<__VA_ARGS__>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1, ps, hr, \
+                   z0, z1)
+    bool done_pre = false;
+    if constexpr (NL == 2) {
+      if (pre) {  // (only the variants stepin_supported() admits)
+        done_pre = true;
+        if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(2, TAG_A, true, false, false, true);
+        else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(2, TAG_A, false, false, false, true);
+        else if (M.col16) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true);
+        else FPSQ_LAUNCH_SPMV(2, TAG_AT, false, true, false, true);
+      }
+    }
+    if (done_pre) {
+    } else if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_A, true);
     else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(NL, TAG_A, false);
     else if (halo_rows) {
       if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true);
@@ -969,9 +997,9 @@ int halo_finish(fpsq_handle h, const double* yin, double* yout, const LaneCtl* c
 
 template <int NL>
 int at_product(fpsq_handle h, const double* x, double* y, const LaneCtl* c0, const LaneCtl* c1, double* partials,
-               int* np, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none()) {
+               int* np, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none(), const StepArgs* pre = nullptr) {
   if (!h->comm) {
-    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials, u0, u1);
+    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials, u0, u1, false, pre);
     *np = h->AT.nblk;
     return 0;
   }
@@ -1233,6 +1261,7 @@ struct Lane {
   double* affine_out = nullptr;         //        LSQR start-up product (the lane is otherwise parked there); A z - shift -> affine_out
   // filled by run_krylov
   void* state = nullptr;
+  void* state_alt = nullptr;    // the other copy of the state (riding steps alternate between the two)
   LaneCtl* ctl = nullptr;       // coefficients of the A product (and of the A' product for LSQR / CRAIG)
   LaneCtl* ctlT = nullptr;      // coefficients of the A' product (MINRES: the raw tmp = A' r2)
   int64_t itmax = 0;
@@ -1402,7 +1431,8 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     *L.st = fpsq_stats{};
     if (L.kind == LANE_LSQR) {
       any_lsqr = true;
-      LsqrState* S = h->lsqr[nlsqr++];
+      LsqrState* S = h->lsqr[nlsqr];
+      L.state_alt = h->lsqr_alt[nlsqr++];
       L.state = S;
       L.ctl = &S->ctl;
       L.itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
@@ -1430,6 +1460,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       lqS = S;
     } else {
       CraigState* S = h->craig;
+      L.state_alt = h->craig_alt;
       L.state = S;
       L.ctl = &S->ctl;
       L.itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
@@ -1441,10 +1472,55 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (!L.ctlT) L.ctlT = L.ctl;
     itmax_all = std::max(itmax_all, L.itmax);
   }
-  const LaneCtl* c0 = lanes[0].ctl;  // A product
-  const LaneCtl* c1 = lanes[NL - 1].ctl;
-  const LaneCtl* t0 = lanes[0].ctlT;  // A' product
-  const LaneCtl* t1 = lanes[NL - 1].ctlT;
+  // Riding steps (small problems, LSQR / CRAIG lanes on one GPU): instead of a one-workgroup k_step launch behind every
+  // product, the step is handed to the NEXT product launch, whose workgroups all recompute it in their prologue
+  // (k_spmv / k_spmv_rgcs <.., STEPIN>, step_run).  Such a step reads the lane's current state copy and workgroup 0 writes
+  // the other one; the lane's pointers (state, ctl) switch to it once the launch is enqueued.
+  bool stepin = NL == 2 && !h->comm && h->stepin_max > 0 && h->AT.padded && h->AT.nblk <= h->stepin_max &&
+                npart_A(h) <= h->stepin_max;
+  for (int l = 0; l < NL; ++l) stepin = stepin && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
+#define c0 (lanes[0].ctl)       /* A product */
+#define c1 (lanes[NL - 1].ctl)
+#define t0 (lanes[0].ctlT)      /* A' product */
+#define t1 (lanes[NL - 1].ctlT)
+  StepArgs pend[2];
+  bool have_pend = false;
+  // hands the pending steps to a stand-alone launch (needed whenever the host or a gated kernel must see their effect now)
+  auto flush_pend = [&](bool sharded) -> int {
+    if (!have_pend) return 0;
+    have_pend = false;
+    return launch_step(h, pend[0], pend[1], sharded);
+  };
+  // after a product launch that carried the pending steps: the lanes live in their other state copies now
+  auto adopt_pend = [&]() {
+    for (int l = 0; l < NL; ++l) {
+      if (pend[l].kind == STEP_NONE) continue;
+      std::swap(lanes[l].state, lanes[l].state_alt);
+      lanes[l].ctl = reinterpret_cast<LaneCtl*>(lanes[l].state);  // LaneCtl is the first member of every state
+      lanes[l].ctlT = lanes[l].ctl;
+    }
+    have_pend = false;
+  };
+  // the steps behind a product: riding in the next product launch when both lanes have one, else their own launch now
+  auto post_step = [&](const StepArgs& a0, const StepArgs& a1, bool sharded) -> int {
+    if (stepin && a0.kind != STEP_NONE && a1.kind != STEP_NONE) {
+      pend[0] = a0;
+      pend[1] = a1;
+      have_pend = true;
+      return 0;
+    }
+    StepArgs nn{};
+    nn.kind = STEP_NONE;
+    return launch_step(h, a0.kind ? a0 : a1, a0.kind ? a1 : nn, sharded);
+  };
+  auto pre_args = [&]() -> const StepArgs* {
+    if (!have_pend) return nullptr;
+    for (int l = 0; l < NL; ++l) {
+      pend[l].state = lanes[l].state;
+      pend[l].state_out = lanes[l].state_alt;
+    }
+    return pend;
+  };
   int affine_lane = -1;  // fast start: the CRAIG lane whose right-hand side the LSQR start-up product forms
   for (int l = 0; l < NL; ++l)
     if (is_ln(lanes[l].kind) && lanes[l].affine_shift && any_lsqr && NL == 2 && local_vec) affine_lane = l;
@@ -1707,7 +1783,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     // first half-step of every lane: one A' product
     int npT = 0;
     if (fuse_upd) {
-      if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT, lu[0], lu[1])) return rc;
+      const StepArgs* pre = pre_args();
+      if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT, lu[0], lu[1], pre)) return rc;
+      if (pre) adopt_pend();
     } else {
       if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT)) return rc;
     }
@@ -1725,7 +1803,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     {
       const bool sh0 = lanes[0].kind == LANE_MINRES ? true : h->halo;
       const bool sh1 = lanes[NL - 1].kind == LANE_MINRES ? true : h->halo;
-      if (NL == 2 && split_steps && sh0 != sh1) {
+      if (!h->comm) {
+        if (int rc = post_step(sa[0], NL == 2 ? sa[1] : none, false)) return rc;
+      } else if (NL == 2 && split_steps && sh0 != sh1) {
         if (int rc = launch_step(h, sa[0], none, sh0)) return rc;
         if (int rc = launch_step(h, sa[1], none, sh1)) return rc;
       } else if (NL == 2) {
@@ -1767,7 +1847,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     }
     // second half-step: one A product
     if (fuse_upd) {
-      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPalt, c0, c1, h->pS2, cu[0], cu[1]);
+      const StepArgs* pre = pre_args();
+      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPalt, c0, c1, h->pS2, cu[0], cu[1], false, pre);
+      if (pre) adopt_pend();
       std::swap(SPcur, SPalt);
     } else {
       // (at most three segments: lanes <= 2 and only one of them can be CRAIG)
@@ -1786,7 +1868,11 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
                           lanes[l], (int)it, h->pS2 + (size_t)l * h->strA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : h->pW[l],
                           gm, prog[l]);
     }
-    if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
+    if (!h->comm) {
+      if (int rc = post_step(sb[0], NL == 2 ? sb[1] : none, true)) return rc;
+    } else {
+      if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
+    }
     if (minres_lane >= 0) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
       launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
       if (int rc = launch_step(h, step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
@@ -1826,6 +1912,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       if (!ps.done) slow = std::min(slow, (int)ps.iter + lag(l));
     }
     if (it > expect && it - slow >= look) {
+      if (int rc = flush_pend(true)) return rc;  // (the host is about to wait for the pending steps' progress)
       for (int l = 0; l < NL; ++l) {
         if (load_progress(&h->prog_host[l]).done) continue;
         const int32_t* ddone = &lanes[l].ctl->done;
@@ -1838,6 +1925,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     // `expect`.  When the count repeats, no launch is enqueued past convergence (each costs ~3.5 us of GPU time even
     // though it exits at once: ~50 us per evaluation at lookahead 4); when it does not, this is one short bubble.
     if (expect > 0 && it == expect) {
+      if (int rc = flush_pend(true)) return rc;  // (the gated kernels and the host must see this iteration's verdict)
       if (int rc = enqueue_speculative()) return rc;
       for (int l = 0; l < NL; ++l) {
         if (load_progress(&h->prog_host[l]).done) continue;
@@ -1852,6 +1940,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter + lag(l));
     *expect_slot = e;
   }
+  if (int rc = flush_pend(true)) return rc;
   ht_mark(h, 4);
   if (spec_it >= 0 && spec_it == it && all_done()) {
     // every recurrence ended at or before the iteration the speculative flush + tail were enqueued behind: their gates
@@ -1881,6 +1970,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         return rc;
   }
   return 0;  // the final stats were left in lanes[l].st by the step that ended each recurrence
+#undef c0
+#undef c1
+#undef t0
+#undef t1
 }
 
 int run_lanes(fpsq_handle h, Lane* lanes, int nlanes, const TailFn* tail = nullptr) {
@@ -2324,6 +2417,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     return fail("hipHostMalloc", e);
   if (const char* ev = std::getenv("FPSQ_ADAPTIVE_RUNAHEAD")) h->adaptive_runahead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_HOST_TRACE")) h->host_trace = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_STEPIN_MAX")) h->stepin_max = std::min(std::atoi(ev), 4 * kStepThreads);  // (step2_issue's shape)
   if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_AB_DYNAMIC")) h->ab_dynamic = std::atoi(ev) != 0;
   std::memset(h->hstats, 0, 4 * sizeof(fpsq_stats));
@@ -2335,7 +2429,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  const size_t state_bytes = sizeof(LsqrState) * 2 + sizeof(CraigState) + sizeof(MinresState) + sizeof(LnlqState) +
+  const size_t state_bytes = sizeof(LsqrState) * 4 + sizeof(CraigState) * 2 + sizeof(MinresState) + sizeof(LnlqState) +
                              4 * sizeof(LaneCtl) + 64 * sizeof(double);
   if ((e = hipMalloc(&p, state_bytes)) != hipSuccess) return fail("hipMalloc", e);
   h->allocs.push_back(p);
@@ -2345,6 +2439,11 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   h->lsqr[1] = h->lsqr[0] + 1;
   cp += sizeof(LsqrState) * 2;
   h->craig = (CraigState*)cp;
+  cp += sizeof(CraigState);
+  h->lsqr_alt[0] = (LsqrState*)cp;
+  h->lsqr_alt[1] = h->lsqr_alt[0] + 1;
+  cp += sizeof(LsqrState) * 2;
+  h->craig_alt = (CraigState*)cp;
   cp += sizeof(CraigState);
   h->minres = (MinresState*)cp;
   cp += sizeof(MinresState);

@@ -34,6 +34,7 @@ __device__ __forceinline__ void publish(Progress* p, int iter, int done) {
   // recurrence that HAD ended at iteration k for one that had not: it then went on for an iteration whose (otherwise
   // no-op) A' launch carried the final LSQR update a second time -- the gated speculative flush, whose gates the device
   // rightly found open, had already applied it.  That was the intermittent last-digits mismatch of hprod (round 2's logs).
+  if (p == nullptr) return;  // (a workgroup that only needs the step's RESULT: see step_run)
   const unsigned long long v = (unsigned long long)(unsigned)iter | ((unsigned long long)(unsigned)done << 32);
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -775,6 +776,10 @@ struct StepArgs {
   // same numbers in the same (rank-major) order: the replicated scalars stay bitwise identical whatever reduction
   // algorithm the collective library would use.  nseg <= 1: one plain array.
   int32_t nseg, seg_stride;
+  // where the advanced state goes; null = in place.  Steps that ride in a product launch (step_run with many readers)
+  // alternate between two copies of the state: every workgroup of the launch reads `state`, only workgroup 0 writes
+  // `state_out`, so no reader can ever see a half-written or an already advanced state.
+  void* state_out;
 };
 
 // 256 threads: the <= ~5000 norm partials are still summed with a few batches of independent loads per thread, and a
@@ -928,41 +933,50 @@ __device__ __forceinline__ int state_bytes(int kind) {
   }
 }
 
-__global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1) {
-  const StepArgs& a = blockIdx.x == 0 ? a0 : a1;
-  if (a.kind == STEP_NONE || lane_done(a)) return;
-  __shared__ double red[32];
+// One scalar step by the calling workgroup (kStepThreads threads): the state is staged in `st` (LDS, 80 words), the partial
+// sums are reduced in the fixed order, thread 0 advances the recurrence IN `st`.  On return (after the closing barrier) `st`
+// holds the new state for every thread of the workgroup.  commit: this workgroup also performs the step's side effects --
+// the progress word, the final statistics in host-mapped memory, the state written to a.state_out (or back in place).
+// Without commit the workgroup only wants the result: the riding form of a step (product kernels with STEPIN), where every
+// workgroup of the NEXT product launch recomputes the step of the previous one in its prologue -- same inputs, same
+// instructions, same bits -- instead of waiting for a one-workgroup launch in between.
+__device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */, unsigned long long* st /* 80 */, bool commit) {
   // The recurrence state (<= 0.5 KB) is staged in LDS with one coalesced read issued together with the partial-sum
   // loads, advanced there by thread 0, and written back with one coalesced store: the ~40 dependent scalar accesses of
   // a step then cost LDS latency instead of a global round trip each.
-  __shared__ __attribute__((aligned(16))) unsigned long long st[80];
   const int nq = state_bytes(a.kind) / 8;
   const unsigned long long* gsrc = reinterpret_cast<const unsigned long long*>(a.state);
   if ((int)threadIdx.x < nq) st[threadIdx.x] = gsrc[threadIdx.x];
+  const bool skip = lane_done(a);  // (uniform: read from global memory by every thread)
   double s0 = 0.0, s1 = 0.0;
-  // (contains the workgroup barrier that publishes `st`)
-  if (a.nseg > 1) reduce_two_seg(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, a.nseg, a.seg_stride, red, s0, s1);
-  else reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);
-  if (threadIdx.x == 0) {
+  if (!skip) {
+    // (contains the workgroup barrier that publishes `st`)
+    if (a.nseg > 1) reduce_two_seg(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, a.nseg, a.seg_stride, red, s0, s1);
+    else reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);
+  } else {
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && !skip) {
     void* S = st;
+    Progress* prog = commit ? a.prog : nullptr;
     switch (a.kind) {
-      case STEP_LSQR_BEGIN: lsqr_begin_step((LsqrState*)S, s0, a.prog); break;
-      case STEP_LSQR_BEGIN2: lsqr_begin2_step((LsqrState*)S, s0, a.prog); break;
+      case STEP_LSQR_BEGIN: lsqr_begin_step((LsqrState*)S, s0, prog); break;
+      case STEP_LSQR_BEGIN2: lsqr_begin2_step((LsqrState*)S, s0, prog); break;
       case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)S, s0); break;
-      case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)S, s0, s1, a.it, a.prog); break;
-      case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)S, s0, a.prog); break;
-      case STEP_CRAIG_SA: craig_sa_step((CraigState*)S, s0, a.it, a.prog); break;
-      case STEP_CRAIG_SB: craig_sb_step((CraigState*)S, s0, s1, a.it, a.prog); break;
-      case STEP_MINRES_BEGIN: minres_begin_step((MinresState*)S, s0, a.prog); break;
+      case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)S, s0, s1, a.it, prog); break;
+      case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)S, s0, prog); break;
+      case STEP_CRAIG_SA: craig_sa_step((CraigState*)S, s0, a.it, prog); break;
+      case STEP_CRAIG_SB: craig_sb_step((CraigState*)S, s0, s1, a.it, prog); break;
+      case STEP_MINRES_BEGIN: minres_begin_step((MinresState*)S, s0, prog); break;
       case STEP_MINRES_A: minres_a_step((MinresState*)S, s0); break;
       case STEP_MINRES_B: minres_b_step((MinresState*)S, s0, a.it); break;
-      case STEP_MINRES_C: minres_c_step((MinresState*)S, s0, a.it, a.prog); break;
-      case STEP_LNLQ_BEGIN: lnlq_begin_step((LnlqState*)S, s0, a.prog); break;
-      case STEP_LNLQ_SA: lnlq_sa_step((LnlqState*)S, s0, a.it, a.prog); break;
+      case STEP_MINRES_C: minres_c_step((MinresState*)S, s0, a.it, prog); break;
+      case STEP_LNLQ_BEGIN: lnlq_begin_step((LnlqState*)S, s0, prog); break;
+      case STEP_LNLQ_SA: lnlq_sa_step((LnlqState*)S, s0, a.it, prog); break;
       case STEP_LNLQ_SB: lnlq_sb_step((LnlqState*)S, s0); break;
       default: break;
     }
-    if (a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
+    if (commit && a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
       const fpsq_stats* fin = a.kind >= STEP_LNLQ_BEGIN ? &((LnlqState*)S)->stats
                               : a.kind >= STEP_MINRES_BEGIN ? &((MinresState*)S)->stats
                               : a.kind >= STEP_CRAIG_BEGIN ? &((CraigState*)S)->stats
@@ -971,8 +985,125 @@ __global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1)
     }
   }
   __syncthreads();
-  unsigned long long* gdst = reinterpret_cast<unsigned long long*>(a.state);
-  if ((int)threadIdx.x < nq) gdst[threadIdx.x] = st[threadIdx.x];
+  if (commit && (!skip || a.state_out != nullptr)) {
+    unsigned long long* gdst = reinterpret_cast<unsigned long long*>(a.state_out ? a.state_out : a.state);
+    if ((int)threadIdx.x < nq) gdst[threadIdx.x] = st[threadIdx.x];
+  }
+}
+
+// the per-thread part of reduce_two (same batch shapes, hence the same summation order), loads only
+__device__ __forceinline__ void reduce_two_issue(const double* p0, int n0, const double* p1, int n1, double& a, double& b) {
+  const int t = threadIdx.x;
+  a = 0.0;
+  b = 0.0;
+  constexpr int U0 = 24, U1 = 4;
+  if (n0 > 0 && n0 <= kStepThreads * U0 && n1 <= kStepThreads * U1) {
+    if (n0 <= kStepThreads * 4) a = partial_batch<4>(p0, 0, n0, t);
+    else if (n0 <= kStepThreads * 8) a = partial_batch<8>(p0, 0, n0, t);
+    else a = partial_batch<U0>(p0, 0, n0, t);
+    b = n1 > 0 ? partial_batch<U1>(p1, 0, n1, t) : 0.0;
+  } else {
+    for (int base = 0; base < n0; base += kStepThreads * 8) a += partial_batch<8>(p0, base, n0, t);
+    for (int base = 0; base < n1; base += kStepThreads * 8) b += partial_batch<8>(p1, base, n1, t);
+  }
+}
+
+__device__ __forceinline__ void step_advance(const StepArgs& a, void* S, double s0, double s1, bool commit) {
+  Progress* prog = commit ? a.prog : nullptr;
+  switch (a.kind) {
+    case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)S, s0); break;
+    case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)S, s0, s1, a.it, prog); break;
+    case STEP_CRAIG_SA: craig_sa_step((CraigState*)S, s0, a.it, prog); break;
+    case STEP_CRAIG_SB: craig_sb_step((CraigState*)S, s0, s1, a.it, prog); break;
+    default: break;
+  }
+  if (commit && a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
+    const fpsq_stats* fin = a.kind >= STEP_CRAIG_BEGIN ? &((CraigState*)S)->stats : &((LsqrState*)S)->stats;
+    *a.host_stats = *fin;
+  }
+}
+
+// The riding form for TWO lanes at once (LSQR / CRAIG SA and SB steps only; every partial array <= 4 x kStepThreads entries,
+// i.e. reduce_two's partial_batch<4> shape), in two halves so that the caller can put its own memory requests between
+// them: step2_issue only REQUESTS both lanes' states and partial sums (raw values into registers), step2_finish sums them
+// in reduce_two's order behind one barrier and lets thread 0 (lane 0) and thread 64 (lane 1: another wave) advance their
+// recurrences side by side.  Bit for bit what two k_step workgroups compute.
+struct Step2Regs {
+  unsigned long long sv0, sv1;
+  double v[4][4];
+  bool skip0, skip1;
+};
+__device__ __forceinline__ void step2_issue(const StepArgs& a0, const StepArgs& a1, Step2Regs& R) {
+  const int t = threadIdx.x;
+  const int nq0 = state_bytes(a0.kind) / 8, nq1 = state_bytes(a1.kind) / 8;
+  R.sv0 = t < nq0 ? reinterpret_cast<const unsigned long long*>(a0.state)[t] : 0ull;
+  R.sv1 = (t >= 128 && t - 128 < nq1) ? reinterpret_cast<const unsigned long long*>(a1.state)[t - 128] : 0ull;
+  R.skip0 = lane_done(a0);
+  R.skip1 = lane_done(a1);
+  const double* arr[4] = {a0.p0, a0.p1, a1.p0, a1.p1};
+  const int cnt[4] = {a0.n0, a0.p1 ? a0.n1 : 0, a1.n0, a1.p1 ? a1.n1 : 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = u * kStepThreads + t;
+      R.v[k][u] = cnt[k] > 0 ? arr[k][i < cnt[k] ? i : cnt[k] - 1] : 0.0;
+    }
+}
+__device__ __forceinline__ void step2_finish(const StepArgs& a0, const StepArgs& a1, const Step2Regs& R, double* red /* 32 */,
+                                             unsigned long long* st0 /* 80 */, unsigned long long* st1 /* 80 */,
+                                             bool commit) {
+  const int t = threadIdx.x;
+  const int nq0 = state_bytes(a0.kind) / 8, nq1 = state_bytes(a1.kind) / 8;
+  if (t < nq0) st0[t] = R.sv0;
+  if (t >= 128 && t - 128 < nq1) st1[t - 128] = R.sv1;
+  const int cnt[4] = {a0.n0, a0.p1 ? a0.n1 : 0, a1.n0, a1.p1 ? a1.n1 : 0};
+  double sum[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // partial_batch<4>'s masked sum, then wave_sum: reduce_two's order
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a += (u * kStepThreads + t < cnt[k]) ? R.v[k][u] : 0.0;
+    sum[k] = wave_sum(a);
+  }
+  const int lane = t & 63, w = t >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[4 * k + w] = sum[k];
+  }
+  __syncthreads();
+  if (t == 0 && !R.skip0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < kStepThreads / 64; ++k) {
+      s0 += red[k];
+      s1 += red[4 + k];
+    }
+    step_advance(a0, st0, s0, s1, commit);
+  }
+  if (t == 64 && !R.skip1) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < kStepThreads / 64; ++k) {
+      s0 += red[8 + k];
+      s1 += red[12 + k];
+    }
+    step_advance(a1, st1, s0, s1, commit);
+  }
+  __syncthreads();
+  if (commit) {
+    unsigned long long* d0 = reinterpret_cast<unsigned long long*>(a0.state_out ? a0.state_out : a0.state);
+    unsigned long long* d1 = reinterpret_cast<unsigned long long*>(a1.state_out ? a1.state_out : a1.state);
+    if (t < nq0 && (!R.skip0 || a0.state_out)) d0[t] = st0[t];
+    if (t >= 128 && t - 128 < nq1 && (!R.skip1 || a1.state_out)) d1[t - 128] = st1[t - 128];
+  }
+}
+
+__global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1) {
+  const StepArgs& a = blockIdx.x == 0 ? a0 : a1;
+  if (a.kind == STEP_NONE) return;
+  if (a.state_out == nullptr && lane_done(a)) return;  // (in place and nothing to do)
+  __shared__ double red[32];
+  __shared__ __attribute__((aligned(16))) unsigned long long st[80];
+  step_run(a, red, st, true);
 }
 
 static_assert(sizeof(LsqrState) % 8 == 0 && sizeof(LsqrState) <= 640, "state staging");

@@ -1,0 +1,439 @@
+// fpsq_spmv.hip.h -- the two product kernels of libfpsq (CSR-stream k_spmv for A' and the CSR fallback of A; column-sorted
+// row groups k_spmv_rgcs for A): SpMV / SpMM with the fused axpby + norm-partial epilogue, the riding vector updates and
+// -- for small problems -- the riding scalar steps (STEPIN).  Split from fpsq_kernels.hip.h because the riding steps need
+// the recurrences of fpsq_krylov.hip.h.
+#pragma once
+#include "fpsq_krylov.hip.h"
+
+namespace fpsq {
+
+// Halo mode of the row-sharded A' product (k_spmv<.., HALO>): the rows [0, lo) and [hi, nrows) of the product -- the two
+// regions of the rank's column window that a neighbour also contributes to -- are NOT finalised: their raw sums go to
+// raw[(r < lo ? r : lo + r - hi)][NL] (head region first) and k_halo_finish completes them once the neighbours' sums have
+// arrived.  Interior rows get the fused axpby + squared-norm epilogue exactly as on one GPU.
+struct HaloRows {
+  int64_t lo, hi;
+  double* raw;
+};
+
+// ------------------------------------------------------------------------------------------------ SpMV / SpMM
+//
+// out[r][l] = ca_l * sum_k vals[k] * x[colind[k]][l] + cb_l * yin[r][l],  partial[l][blk] = sum_r out[r][l]^2
+//
+// CSR-stream: a workgroup owns a run of consecutive rows holding <= kSpmvNnz nonzeros.  Phase 1 streams that
+// run's (colind, vals) with unit-stride, fully coalesced loads (every lane busy whatever the row lengths), gathers
+// x and parks the products in LDS; phase 2 reduces each row's LDS segment with G lanes per row (G = power of two
+// chosen from the block's row count: ~100-nnz rows of A get 8 lanes each, ~10-nnz rows of A' one lane each).
+// blockIdx is remapped so that each XCD walks a contiguous eighth of the matrix: its private L2 then caches one
+// slice of x instead of all of it.  Summation order is a pure function of the sparsity => reproducible.
+// PAD: every row block's entries are stored at [L * kSpmvNnz, ...) and zero-padded to kSpmvNnz (CsrView::vals /
+// col16 / colind then point to the padded arrays): the matrix stream needs neither the block descriptor (one link
+// less in the workgroup's chain of dependent memory round trips) nor bounds checks.  Requires that no block is a
+// long row.
+// partials[l * pstride + L]: the lane stride of the partial array is the caller's (the workgroup count on one GPU; a
+// padded count common to all ranks when the arrays are all-gathered, see run_krylov).
+// STEPIN (small problems: a few hundred workgroups per product): the scalar steps that follow the PREVIOUS product -- one per
+// lane, s0 / s1 -- ride in this launch: every workgroup (product and riding-update workgroups alike) first recomputes them
+// from that product's partial sums (step_run: same inputs, same instructions, same bits in every workgroup), takes the
+// coefficients from its own LDS copy of the advanced state, and workgroup 0 alone commits the state (to the OTHER of its
+// two copies: nobody reads what it writes during this launch), the progress word and the statistics.  Two one-workgroup
+// launches and two kernel boundaries per Krylov iteration disappear.  The redundant work is a few KB of L2 reads and ~3 us
+// of scalar code per workgroup -- too much for the thousands of workgroups of a large product, which keep k_step.
+template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool STEPIN = false>
+__global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
+                                                 double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
+                                                 double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
+                                                 const LaneCtl* gate0, const LaneCtl* gate1, int pstride,
+                                                 const HaloRows hr, const StepArgs s0, const StepArgs s1) {
+  // exactly 32 KB of LDS for two right-hand sides (five workgroups fit the CU's 160 KB): the reduction scratch
+  // aliases the head of the product buffer
+  __shared__ double prod[kSpmvNnz * NL];
+  double* red = prod;
+  // speculatively enqueued epilogue product: runs only once both recurrences of the call have ended
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
+  // (STEPIN with the padded layout: the workgroup's matrix stream depends on nothing but its index, so it is requested
+  // BEFORE the riding steps and is in flight while they are computed)
+  constexpr int kPerS = kSpmvNnz / kBlock;
+  [[maybe_unused]] int cpre[kPerS];
+  [[maybe_unused]] double vpre[kPerS];
+  [[maybe_unused]] double2 xpre[kPerS];
+  if constexpr (STEPIN) {
+    static_assert(NL == 2, "riding steps: two lanes");
+    __shared__ __attribute__((aligned(16))) unsigned long long stl[2 * 80];
+    __shared__ double sred[32];
+    if ((int)blockIdx.x >= 8 * blk_per_xcd + u0.nblk + u1.nblk) return;
+    // request order: matrix stream, the steps' states and partial sums, then (stream arrived) the gathers of x; the
+    // steps' arithmetic runs while the gathers are in flight
+    bool pre_ok = false;
+    if constexpr (PAD) {
+      const int Lp = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
+      pre_ok = (int)blockIdx.x < 8 * blk_per_xcd && Lp < A.nblk;
+      if (pre_ok) {
+        const int cb0 = IDX16 ? A.colbase[Lp] : 0;
+#pragma unroll
+        for (int k = 0; k < kPerS; ++k) {
+          const size_t ii = (size_t)Lp * kSpmvNnz + threadIdx.x + k * kBlock;
+          cpre[k] = IDX16 ? cb0 + (int)A.col16[ii] : A.colind[ii];
+          vpre[k] = A.vals[ii];
+        }
+      }
+    }
+    Step2Regs SR;
+    step2_issue(s0, s1, SR);
+    if constexpr (PAD) {
+      if (pre_ok) {
+#pragma unroll
+        for (int k = 0; k < kPerS; ++k) xpre[k] = *reinterpret_cast<const double2*>(x + (size_t)cpre[k] * 2);
+      }
+    }
+    step2_finish(s0, s1, SR, sred, stl, stl + 80, blockIdx.x == 0);
+    ctl0 = reinterpret_cast<const LaneCtl*>(stl);
+    ctl1 = reinterpret_cast<const LaneCtl*>(stl + 80);
+    if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red, ctl0, ctl1)) return;
+  } else {
+    if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
+  }
+  // A (TAG 0): XCD-contiguous eighths, so an XCD's L2 holds one slice of the long gathered vector.  A' (TAG 1): the gathered
+  // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
+  const int L = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
+  if (L >= A.nblk) return;
+  // issued before the (dependent) done-check below: one memory round trip at the head of the workgroup, not two
+  const int4 bd = A.blkdesc[L];
+  const int cbase = IDX16 ? A.colbase[L] : 0;
+  bool act[NL];
+  double ca[NL], cb[NL];
+  {
+    const LaneCtl* c[2] = {ctl0, ctl1};
+    bool any = false;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      act[l] = !(c[l]->done | c[l]->skip);
+      ca[l] = c[l]->ca;
+      cb[l] = c[l]->cb;
+      any |= act[l];
+    }
+    if (!any) return;
+  }
+  const int tid = threadIdx.x;
+  const int r0 = bd.x, nr = bd.y, s = bd.z, e = bd.w;
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+
+  if (!PAD && e - s > kSpmvNnz) {
+    // one long row (nr == 1): every thread strides over it, no LDS staging
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    for (int i = s + tid; i < e; i += kBlock) {
+      const int c = IDX16 ? cbase + (int)A.col16[i] : A.colind[i];
+      const double v = A.vals[i];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] += v * x[(size_t)c * NL + l];
+    }
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double t = block_sum(acc[l], red);
+      if (tid == 0 && act[l]) {
+        if (HALO && (r0 < hr.lo || r0 >= hr.hi)) {
+          hr.raw[(size_t)(r0 < hr.lo ? r0 : hr.lo + (r0 - hr.hi)) * NL + l] = t;
+        } else {
+          const double o = ca[l] * t + (cb[l] != 0.0 ? cb[l] * yin[(size_t)r0 * NL + l] : 0.0);
+          yout[(size_t)r0 * NL + l] = o;
+          sq[l] = o * o;
+        }
+      }
+    }
+  } else {
+    // phase 1: coalesced stream of the block's nonzeros -> products in LDS.  Every lane issues all of its loads and
+    // all of its gathers unconditionally (out-of-range lanes use column 0 with value 0 and park a zero in an unused
+    // slot): a per-element branch would make hipcc wait for each gather before issuing the next one.
+    // (the row-segment boundaries of phase 2 are loaded here too, ahead of the barrier that would expose their latency)
+    int G = 1;
+    while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
+    const int rows_per_pass = kBlock / G;
+    const int g = tid / G, gl = tid % G;
+    const int rq0 = g < nr ? g : 0;
+    const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
+    // the yin values of the first row pass, requested now: the epilogue would otherwise expose their latency (a
+    // workgroup's life is a chain of ~4 memory round trips; measured +4 % evaluations/s at the headline size)
+    double ypre[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ypre[l] = 0.0;
+    if (yin != nullptr) {
+      if (NL == 2) {
+        const double2 t = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
+        ypre[0] = t.x;
+        ypre[NL - 1] = t.y;
+      } else {
+        ypre[0] = yin[r0 + rq0];
+      }
+    }
+    constexpr int kPer = kSpmvNnz / kBlock;
+    int cidx[kPer];
+    double v[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (PAD && STEPIN) {  // requested at the head of the workgroup
+        cidx[k] = cpre[k];
+        v[k] = vpre[k];
+      } else if (PAD) {
+        const size_t ii = (size_t)L * kSpmvNnz + tid + k * kBlock;
+        cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
+        v[k] = A.vals[ii];
+      } else {
+        const int i = s + tid + k * kBlock;
+        const bool ok = i < e;
+        const int ii = ok ? i : s;
+        cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
+        v[k] = ok ? A.vals[ii] : 0.0;
+      }
+    }
+    if (NL == 1) {
+      double xv[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) xv[k] = x[cidx[k]];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) prod[tid + k * kBlock] = v[k] * xv[k];
+    } else {
+      double2 xv[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        if (PAD && STEPIN) xv[k] = xpre[k];  // gathered at the head of the workgroup
+        else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k)
+        *reinterpret_cast<double2*>(prod + 2 * (tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
+    }
+    lds_barrier();
+    // phase 2: G lanes per row
+    for (int base = 0; base < nr; base += rows_per_pass) {
+      const int rr = base + g;
+      const bool valid = rr < nr;
+      double acc[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+      if (valid) {
+        const int a = (base == 0 ? seg_a0 : A.rowptr[r0 + rr]) - s, b = (base == 0 ? seg_b0 : A.rowptr[r0 + rr + 1]) - s;
+        row_segment_sum<NL>(prod, a + gl, b, G, acc);
+      }
+      for (int off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) acc[l] += __shfl_down(acc[l], off, 64);
+      }
+      if (valid && gl == 0) {
+        const int64_t row = r0 + rr;
+        if (HALO && (row < hr.lo || row >= hr.hi)) {
+          double* dst = hr.raw + (size_t)(row < hr.lo ? row : hr.lo + (row - hr.hi)) * NL;
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+            if (act[l]) dst[l] = acc[l];
+        } else {
+          row_epilogue<NL>((size_t)row, acc, ca, cb, act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
+        }
+      }
+    }
+  }
+  if (partials != nullptr) {
+    lds_barrier();  // `red` aliases `prod`: every wave must be past its phase-2 reads
+    block_sum_lanes<NL>(sq, red);
+    if (tid == 0) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + L] = sq[l];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ RGCS product
+//
+// RGCS = Row Groups, Column-Sorted.  The CSR-stream kernel gathers x in ROW order: for a wide matrix whose rows spread
+// over thousands of columns (the constraint Jacobian: 100 nonzeros in an 8192-column window) the 64 gathers of one
+// wave instruction land in 64 different 128-byte lines and the L2->L1 line traffic, not HBM, bounds the product
+// (rocSPARSE's csrmv hits the same wall: tools/spmv_bench.hip).  Here the entries of a group of consecutive rows
+// (<= kRgcsGroupNnz nonzeros, <= kRgcsMaxRows rows) are stored sorted by COLUMN and cut into tiles of kRgcsTile
+// entries, so consecutive lanes gather neighbouring columns (~10 lines per wave instruction).  Each entry carries, packed
+// with its group-relative column in one 32-bit word (12 B/nnz like CSR), its slot in the tile's ROW-major order:
+// products are scattered to LDS by slot and every row's segment is reduced exactly as in the CSR-stream kernel;
+// the per-row sums accumulate in registers across the tiles of the group.  Deterministic, no atomics.
+#ifndef FPSQ_RGCS_TILE
+#define FPSQ_RGCS_TILE 2048
+#endif
+#ifndef FPSQ_RGCS_GROUP_NNZ
+#define FPSQ_RGCS_GROUP_NNZ 12800
+#endif
+#ifndef FPSQ_RGCS_MAX_ROWS
+#define FPSQ_RGCS_MAX_ROWS 128
+#endif
+constexpr int kRgcsTile = FPSQ_RGCS_TILE;
+constexpr int kRgcsColBits = 21;     // group-relative column < 2^21, slot < 2^11
+constexpr int kRgcsGroupNnz = FPSQ_RGCS_GROUP_NNZ;
+constexpr int kRgcsMaxRows = FPSQ_RGCS_MAX_ROWS;
+// row passes of the segment reduction: G lanes per row with G * R <= kBlock, so rows <= kBlock need a single pass
+constexpr int kRgcsMaxPass = (kRgcsMaxRows + kBlock - 1) / kBlock;
+static_assert(kRgcsTile <= 2048 && kRgcsTile % kBlock == 0, "slot field is 11 bits");
+
+struct RgcsGroup {        // 32 bytes, fetched with two independent 16-byte loads at the head of the workgroup
+  int32_t r0, R;          // first row, #rows
+  int32_t e0, e1;         // entry range
+  int32_t cmin;           // smallest column of the group
+  int32_t tp;             // offset into tptr
+  int32_t pad[2];
+};
+
+struct RgcsView {
+  const uint32_t* pidx;   // (slot << kRgcsColBits) | (col - cmin)
+  const double* vals;     // same (column-sorted) order
+  const RgcsGroup* grp;   // ng group descriptors
+  const uint16_t* tptr;   // per tile: R + 1 row-segment boundaries in slot space
+  int32_t ng;
+  int32_t nrows;
+  int32_t stride;         // padded layout: group g's entries start at g * stride (0: compact, start = grp[g].e0)
+};
+
+// PAD: the groups' entries are stored at a fixed stride and zero-padded to whole tiles, so the first tile's stream
+// does not wait for the group descriptor and no load needs a bounds check.
+template <int NL, bool PAD = false, bool STEPIN = false>
+__global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
+                                                      double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
+                                                      double* partials, int grp_per_xcd, const UpdSeg u0,
+                                                      const UpdSeg u1, const LaneCtl* gate0, const LaneCtl* gate1,
+                                                      int pstride, const StepArgs s0, const StepArgs s1) {
+  __shared__ double prod[kRgcsTile * NL];
+  double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
+  if constexpr (STEPIN) {  // (see k_spmv)
+    static_assert(NL == 2, "riding steps: two lanes");
+    if ((int)blockIdx.x >= 8 * grp_per_xcd + u0.nblk + u1.nblk) return;
+  }
+  // (XCD-contiguous eighths: essential here -- with the identity map the product takes 43 us instead of 29 us)
+  const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
+  constexpr int kPer = kRgcsTile / kBlock;
+  const int tid = threadIdx.x;
+  uint32_t pk[kPer];
+  double v[kPer];
+  // everything the next tile needs from global memory, issued together and left untouched until it is consumed
+  auto fetch_stream = [&](int base, int lo, int hi) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = base + tid + k * kBlock;
+      const int ii = PAD ? i : (i < hi ? i : lo);
+      pk[k] = M.pidx[ii];
+      v[k] = M.vals[ii];
+    }
+  };
+  const bool is_prod = (int)blockIdx.x < 8 * grp_per_xcd && g < M.ng;
+  if constexpr (STEPIN) {
+    __shared__ __attribute__((aligned(16))) unsigned long long stl[2 * 80];
+    __shared__ double sred[32];
+    // the first tile's stream is in flight while the riding steps are computed (padded layout: it needs no descriptor)
+    if (PAD && is_prod) fetch_stream(g * M.stride, 0, 0);
+    Step2Regs SR;
+    step2_issue(s0, s1, SR);
+    step2_finish(s0, s1, SR, sred, stl, stl + 80, blockIdx.x == 0);
+    ctl0 = reinterpret_cast<const LaneCtl*>(stl);
+    ctl1 = reinterpret_cast<const LaneCtl*>(stl + 80);
+    if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red, ctl0, ctl1)) return;
+  } else {
+    if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
+  }
+  if (g >= M.ng) return;
+  if (PAD && !STEPIN) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
+  const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
+  const LaneCtl* c[2] = {ctl0, ctl1};
+  double ca[NL], cb[NL];
+  bool act[NL];
+  bool any = false;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    act[l] = !(c[l]->done | c[l]->skip);
+    ca[l] = c[l]->ca;
+    cb[l] = c[l]->cb;
+    any |= act[l];
+  }
+  if (!any) return;
+  const int r0 = gd.r0, R = gd.R, e0 = PAD ? g * M.stride : gd.e0, e1 = PAD ? g * M.stride + (gd.e1 - gd.e0) : gd.e1;
+  const int cmin = gd.cmin;
+  const uint16_t* tp = M.tptr + gd.tp;
+  int G = 1;
+  while (G < 64 && G * 2 * R <= kBlock) G <<= 1;
+  const int rpp = kBlock / G, gid = tid / G, gl = tid % G;
+  double acc[kRgcsMaxPass][NL];
+#pragma unroll
+  for (int p = 0; p < kRgcsMaxPass; ++p)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[p][l] = 0.0;
+  uint32_t traw[kRgcsMaxPass];  // this tile's LDS segment [a, b) of each of my rows: two uint16 in one raw dword
+  auto fetch_segs = [&](int tile) {
+    const uint16_t* tpt = tp + (size_t)tile * (R + 1);
+#pragma unroll
+    for (int p = 0; p < kRgcsMaxPass; ++p) {
+      const int rr = p * rpp + gid;
+      const int rq = rr < R ? rr : 0;
+      __builtin_memcpy(&traw[p], tpt + rq, 4);
+    }
+  };
+  auto fetch = [&](int base, int tile) {
+    fetch_stream(base, e0, e1);
+    fetch_segs(tile);
+  };
+  if (PAD) fetch_segs(0);
+  else fetch(e0, 0);
+  int tile = 0;
+  for (int base = e0; base < e1; base += kRgcsTile, ++tile) {
+    int sa[kRgcsMaxPass], sb[kRgcsMaxPass];
+    {
+      double2 xv[kPer];
+      uint32_t pq[kPer];
+      double vq[kPer];
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        // out-of-range lanes park a zero in an unused slot (PAD: the stored padding entries already say so)
+        const bool ok = PAD || base + tid + k * kBlock < e1;
+        pq[k] = ok ? pk[k] : ((uint32_t)(tid + k * kBlock) << kRgcsColBits);
+        vq[k] = ok ? v[k] : 0.0;
+        const int col = cmin + (int)(pq[k] & ((1u << kRgcsColBits) - 1));
+        if (NL == 1) xv[k].x = x[col];
+        else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
+      }
+#pragma unroll
+      for (int p = 0; p < kRgcsMaxPass; ++p) {
+        const bool valid = p * rpp + gid < R;
+        sa[p] = (int)(traw[p] & 0xffffu);
+        sb[p] = valid ? (int)(traw[p] >> 16) : sa[p];
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const int slot = (int)(pq[k] >> kRgcsColBits);
+        if (NL == 1) prod[slot] = vq[k] * xv[k].x;
+        else *reinterpret_cast<double2*>(prod + 2 * slot) = make_double2(vq[k] * xv[k].x, vq[k] * xv[k].y);
+      }
+    }
+    if (base + kRgcsTile < e1) fetch(base + kRgcsTile, tile + 1);
+    lds_barrier();
+#pragma unroll
+    for (int p = 0; p < kRgcsMaxPass; ++p) row_segment_sum<NL>(prod, sa[p] + gl, sb[p], G, acc[p]);
+    lds_barrier();
+  }
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+#pragma unroll
+  for (int p = 0; p < kRgcsMaxPass; ++p) {
+    for (int off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[p][l] += __shfl_down(acc[p][l], off, 64);
+    }
+    const int rr = p * rpp + gid;
+    if (rr < R && gl == 0) row_epilogue<NL>((size_t)(r0 + rr), acc[p], ca, cb, act, yin, yout, sq);
+  }
+  if (partials != nullptr) {
+    block_sum_lanes<NL>(sq, red);
+    if (tid == 0) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + g] = sq[l];
+    }
+  }
+}
+
+}  // namespace fpsq

@@ -817,6 +817,43 @@ def test_speculative_epilogue_every_alignment_is_bitwise_neutral(delta):
     dev.close()
 
 
+@pytest.mark.parametrize("delta", [0.0, SE, 0.25])
+def test_riding_scalar_steps_are_bitwise_the_stand_alone_steps(monkeypatch, delta):
+    """Small problems hand the scalar steps of the Krylov loop to the NEXT product launch, whose workgroups all recompute them
+    in their prologue (k_spmv / k_spmv_rgcs <.., STEPIN>, double-buffered recurrence state) instead of launching k_step
+    behind every product.  Same recurrences, same reduction order: every output and every statistic must be BITWISE those of
+    a handle with the riding steps switched off (FPSQ_STEPIN_MAX=0), for objgrad (LSQR + CRAIG lanes, fast start,
+    speculative tail), hprod (two LSQR lanes), the seam solves, with the run-ahead in every regime (first call, repeated
+    counts, counts that move)."""
+    qp = _small_pde(seed=11, n=6000, m=600)
+    monkeypatch.setenv("FPSQ_STEPIN_MAX", "0")
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    monkeypatch.setenv("FPSQ_STEPIN_MAX", "640")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    assert ref.info()["spmv_at_blocks"] <= 640
+    rng = np.random.default_rng(2)
+    for k in range(10):
+        scale = 0.5 ** (k % 5) * (1.0 if k % 3 else 1e-2)
+        x = qp.xhat + scale * rng.standard_normal(qp.n)
+        v = scale * rng.standard_normal(qp.n)
+        for mdl, out in ((ref, []), (dev, [])):
+            gx, ys, gs, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.n)
+            f, rc = mdl.objgrad(x, gx=gx, ys=ys, gs=gs)
+            st = [(mdl.stats[i].niter, mdl.stats[i].status, mdl.stats[i].solved, mdl.stats[i].rnorm, mdl.stats[i].arnorm) for i in range(2)]
+            rch = mdl.hprod(v, hv, 1 + k % 2)
+            sth = [(mdl.stats4[i].niter, mdl.stats4[i].status, mdl.stats4[i].rnorm) for i in range(2)]
+            o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+            g, c = qp.qdiag * x + qp.d, qp.scipy_csr() @ x - qp.b
+            rcm = mdl.solve_two_mixed(g, c, *o)
+            out += [np.array([f, rc, rch, rcm]), gx, ys, gs, hv, *o, np.array(st, dtype=float).ravel(), np.array(sth, dtype=float).ravel()]
+            if mdl is ref:
+                want = out
+        for a_, b_ in zip(out, want):
+            assert np.array_equal(a_, b_), k
+    ref.close()
+    dev.close()
+
+
 def test_repeated_hprod_and_objgrad_calls_are_bitwise_identical():
     """The same call repeated on fresh and on warm handles gives the same bits every time (all reductions run in fixed
     orders; no atomics).  Regression test of the round-2 / round-3 race: the progress word used to be two stores, and a host
