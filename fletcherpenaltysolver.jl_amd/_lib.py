@@ -39,7 +39,7 @@ class Info(C.Structure):
                 ("spmv_a_blocks", C.c_int64), ("spmv_at_blocks", C.c_int64),
                 ("last_solve_ms", C.c_double), ("last_spmv_ms", C.c_double),
                 ("last_spmv_launches", C.c_int64), ("last_kernel_launches", C.c_int64),
-                ("last_prod_a", C.c_int64 * 2), ("last_prod_at", C.c_int64 * 2)]
+                ("last_prod_a", C.c_int64 * 2), ("last_prod_at", C.c_int64 * 2), ("at_sorted", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

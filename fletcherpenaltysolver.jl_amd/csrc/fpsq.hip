@@ -42,7 +42,13 @@ struct DevCsr {
   int4* blkdesc = nullptr;
   bool padded = false;         // vals / col16 / colind hold nblk blocks of kSpmvNnz slots (see k_spmv<.., PAD>)
   int64_t nstore = 0;          // stored value slots: nnz, or nblk * kSpmvNnz when padded
-  CsrView view() const { return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows, col16, colbase, blkdesc}; }
+  int32_t win = 0;             // with col16: widest column span of a row block
+  uint16_t* cs16 = nullptr;    // column-sorted padded blocks (k_spmv<.., CSORT>): slot | (col & 31) << 11 ...
+  uint8_t* cs8 = nullptr;      // ... and col >> 5 of every stored entry; col16 is then not kept
+  bool sorted = false;
+  CsrView view() const {
+    return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows, col16, colbase, blkdesc, cs16, cs8};
+  }
 };
 
 struct EventPair {
@@ -382,6 +388,7 @@ struct fpsq_solver_s {
   CraigState* craig;
   LsqrState* lsqr_alt[2];       // second copies: the target of a step that rides in a product launch (see run_krylov)
   CraigState* craig_alt;
+  bool at_sorted = true;        // A' blocks stored column-sorted where representable (FPSQ_AT_SORTED=0: row order)
   int stepin_max = 640;         // riding steps when neither product has more workgroups than this (FPSQ_STEPIN_MAX; 0: never)
   MinresState* minres;
   LnlqState* lnlq;
@@ -584,6 +591,7 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
     std::vector<int32_t> base(D.nblk, 0);
     std::vector<uint16_t> c16(D.nnz + 1, 0);
     bool ok = true;
+    int span = 0;
     for (int b = 0; b < D.nblk && ok; ++b) {
       const int s = H.rowptr[rb[b]], e = H.rowptr[rb[b + 1]];
       int lo = INT32_MAX, hi = -1;
@@ -593,6 +601,7 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
       }
       if (e == s) lo = hi = 0;
       if (hi - lo > 65535) ok = false;
+      span = std::max(span, hi - lo + 1);
       base[b] = lo;
       for (int k = s; k < e && ok; ++k) c16[k] = (uint16_t)(H.colind[k] - lo);
     }
@@ -601,6 +610,7 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
       if (int rc = dalloc(h, &D.colbase, base.size())) return rc;
       HIPCHK(h, hipMemcpy(D.col16, c16.data(), c16.size() * 2, hipMemcpyHostToDevice));
       HIPCHK(h, hipMemcpy(D.colbase, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+      D.win = span;
     }
   }
   return 0;
@@ -618,9 +628,22 @@ int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevC
   if (slots >= (size_t)INT32_MAX) return 0;
   std::vector<int32_t> pperm(slots, -1), pcol;
   std::vector<uint16_t> pc16;
-  std::vector<int32_t> base;
+  std::vector<uint8_t> pc8;
+  std::vector<int32_t> base, ord;
   const bool idx16 = D.col16 != nullptr;
-  if (idx16) {
+  // column-sorted blocks (k_spmv<.., CSORT>): 13 bits of block-relative column next to the 11-bit slot
+  const bool sorted = idx16 && D.win <= 8192 && h->at_sorted;
+  static_assert(kSpmvNnz <= 2048, "slot field of the column-sorted layout is 11 bits");
+  if (sorted) {
+    pc16.resize(slots);
+    for (size_t q = 0; q < slots; ++q) {  // padding: an unused slot (its own sorted position), column 0, value 0
+      const size_t t = q % kSpmvNnz;
+      pc16[q - t + 8 * ((t % 512) / 2) + 2 * (t / 512) + (t & 1)] = (uint16_t)t;
+    }
+    pc8.assign(slots, 0);
+    base.resize(nblk);
+    HIPCHK(h, hipMemcpy(base.data(), D.colbase, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+  } else if (idx16) {
     pc16.assign(slots, 0);
     base.resize(nblk);
     HIPCHK(h, hipMemcpy(base.data(), D.colbase, (size_t)nblk * 4, hipMemcpyDeviceToHost));
@@ -629,6 +652,21 @@ int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevC
   }
   for (int b = 0; b < nblk; ++b) {
     const int s = H.rowptr[rb[b]], e = H.rowptr[rb[b + 1]];
+    if (sorted) {
+      ord.resize(e - s);
+      for (int k = s; k < e; ++k) ord[k - s] = k;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return H.colind[a] < H.colind[c]; });
+      for (int t = 0; t < e - s; ++t) {
+        const int k = ord[t], col = H.colind[k] - base[b];
+        const size_t q = (size_t)b * kSpmvNnz + t;
+        pperm[q] = perm[k];
+        // (index planes: the eight entries of a thread contiguously, see csort_fetch)
+        const size_t qi = (size_t)b * kSpmvNnz + 8 * ((t % 512) / 2) + 2 * (t / 512) + (t & 1);
+        pc16[qi] = (uint16_t)((k - s) | ((col & 31) << 11));
+        pc8[qi] = (uint8_t)(col >> 5);
+      }
+      continue;
+    }
     for (int k = s; k < e; ++k) {
       const size_t q = (size_t)b * kSpmvNnz + (k - s);
       pperm[q] = perm[k];
@@ -639,7 +677,15 @@ int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevC
   dfree(h, &D.vals);
   if (int rc = dalloc(h, &D.vals, slots)) return rc;
   HIPCHK(h, hipMemset(D.vals, 0, slots * 8));
-  if (idx16) {
+  if (sorted) {
+    dfree(h, &D.col16);
+    dfree(h, &D.colind);
+    if (int rc = dalloc(h, &D.cs16, slots)) return rc;
+    if (int rc = dalloc(h, &D.cs8, slots)) return rc;
+    HIPCHK(h, hipMemcpy(D.cs16, pc16.data(), slots * 2, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(D.cs8, pc8.data(), slots, hipMemcpyHostToDevice));
+    D.sorted = true;
+  } else if (idx16) {
     dfree(h, &D.col16);
     dfree(h, &D.colind);  // the 16-bit form is the only one the padded kernel reads
     if (int rc = dalloc(h, &D.col16, slots)) return rc;
@@ -829,6 +875,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   h->info.nnz = h->nnz;
   h->info.spmv_a_blocks = npart_A(h);
   h->info.spmv_at_blocks = h->AT.nblk;
+  h->info.at_sorted = h->AT.sorted ? 1 : 0;
   return 0;
 }
 
@@ -915,6 +962,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
         done_pre = true;
         if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(2, TAG_A, true, false, false, true);
         else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(2, TAG_A, false, false, false, true);
+        else if (M.sorted) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true, true);
         else if (M.col16) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true);
         else FPSQ_LAUNCH_SPMV(2, TAG_AT, false, true, false, true);
       }
@@ -923,11 +971,13 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     } else if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_A, true);
     else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(NL, TAG_A, false);
     else if (halo_rows) {
-      if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true);
+      if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true, false, true);
+      else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true);
       else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, false, true);
       else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true, true);
       else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, false, true);
-    } else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true);
+    } else if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, false, false, true);
+    else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true);
     else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true);
     else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true);
     else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false);
@@ -2417,6 +2467,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     return fail("hipHostMalloc", e);
   if (const char* ev = std::getenv("FPSQ_ADAPTIVE_RUNAHEAD")) h->adaptive_runahead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_HOST_TRACE")) h->host_trace = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_AT_SORTED")) h->at_sorted = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_STEPIN_MAX")) h->stepin_max = std::min(std::atoi(ev), 4 * kStepThreads);  // (step2_issue's shape)
   if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_AB_DYNAMIC")) h->ab_dynamic = std::atoi(ev) != 0;

@@ -42,6 +42,10 @@ struct CsrView {
   // per row block {first row, #rows, first nonzero, end nonzero}: ONE 16-byte load instead of the dependent chain
   // rowblk[L] -> rowptr[r0] at the head of every workgroup
   const int4* blkdesc;
+  // column-sorted padded blocks (k_spmv<.., CSORT>): per stored entry its row-major slot and block-relative column,
+  // cs16 = slot | (col & 31) << 11, cs8 = col >> 5
+  const uint16_t* cs16;
+  const uint8_t* cs8;
 };
 
 // ------------------------------------------------------------------------------------------------ reductions

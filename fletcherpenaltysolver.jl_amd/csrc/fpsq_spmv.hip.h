@@ -16,6 +16,43 @@ struct HaloRows {
   double* raw;
 };
 
+// Column-sorted padded block L (k_spmv<.., CSORT>): thread t owns the entry pairs (2t, 2t + 1) + 512 j, j = 0..3, of the
+// block's sorted order.  Values: four 16-byte loads, each wave instruction one contiguous KB.  Index planes: the thread's
+// eight 16-bit words (slot | (col & 31) << 11) and eight bytes (col >> 5) are stored contiguously at [8t, 8t + 8) of the
+// block -- ONE 16-byte and ONE 8-byte load.  (Twenty-four loads per thread in entry order cost the product more than the
+// sorted gathers saved: the texture path is paid per wave instruction.)
+struct CsortRaw {
+  uint4 w16;
+  uint2 w8;
+  double2 vv[4];
+};
+__device__ __forceinline__ void csort_fetch_raw(const CsrView& A, int L, int tid, CsortRaw& r) {
+  static_assert(kSpmvNnz == 2048 && kBlock == 256, "column-sorted blocks: 8 entries per thread");
+  const size_t b0 = (size_t)L * kSpmvNnz;
+  r.w16 = *reinterpret_cast<const uint4*>(A.cs16 + b0 + 8 * tid);
+  r.w8 = *reinterpret_cast<const uint2*>(A.cs8 + b0 + 8 * tid);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r.vv[j] = *reinterpret_cast<const double2*>(A.vals + b0 + 2 * tid + 512 * j);
+}
+__device__ __forceinline__ void csort_decode(const CsortRaw& r, int cbase, int (&cidx)[8], int (&slot)[8], double (&v)[8]) {
+  const unsigned h16[4] = {r.w16.x, r.w16.y, r.w16.z, r.w16.w};
+  const unsigned h8[2] = {r.w8.x, r.w8.y};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int pk = (int)((h16[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+    const int hi = (int)((h8[q >> 2] >> (8 * (q & 3))) & 0xffu);
+    cidx[q] = cbase + ((hi << 5) | (pk >> 11));
+    slot[q] = pk & 2047;
+    v[q] = (q & 1) ? r.vv[q >> 1].y : r.vv[q >> 1].x;
+  }
+}
+__device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, int tid, int (&cidx)[8], int (&slot)[8],
+                                            double (&v)[8]) {
+  CsortRaw r;
+  csort_fetch_raw(A, L, tid, r);
+  csort_decode(r, cbase, cidx, slot, v);
+}
+
 // ------------------------------------------------------------------------------------------------ SpMV / SpMM
 //
 // out[r][l] = ca_l * sum_k vals[k] * x[colind[k]][l] + cb_l * yin[r][l],  partial[l][blk] = sum_r out[r][l]^2
@@ -39,7 +76,14 @@ struct HaloRows {
 // two copies: nobody reads what it writes during this launch), the progress word and the statistics.  Two one-workgroup
 // launches and two kernel boundaries per Krylov iteration disappear.  The redundant work is a few KB of L2 reads and ~3 us
 // of scalar code per workgroup -- too much for the thousands of workgroups of a large product, which keep k_step.
-template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool STEPIN = false>
+// CSORT (A' of a banded Jacobian: padded layout, every block's columns within 8192 of colbase): the block's entries are
+// STORED sorted by column, each carrying its slot in the block's row-major order (slot | (col & 31) << 11 in CsrView::cs16,
+// col >> 5 in CsrView::cs8: 11 B per entry; which thread reads what: csort_fetch).  Row-order gathers of ~10-entry rows put ~50 different 128-byte lines into every
+// wave instruction and the texture path takes them one after the other: that, not HBM, bounded the A' product (what-if
+// builds at the headline size: one address for all lanes 31 -> 20 us, the sorted order's addresses 31 -> 22 us).  In column
+// order 64 consecutive entries read ~4 lines; the products are scattered to their row-major LDS slots and phase 2 is
+// unchanged -- same values summed in the same order: BITWISE the row-order layout.
+template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool STEPIN = false, bool CSORT = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
@@ -57,6 +101,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   [[maybe_unused]] int cpre[kPerS];
   [[maybe_unused]] double vpre[kPerS];
   [[maybe_unused]] double2 xpre[kPerS];
+  static_assert(!CSORT || (IDX16 && PAD && TAG == 1), "column-sorted blocks: padded A' with block-relative columns only");
+  [[maybe_unused]] int spre[kPerS];
   if constexpr (STEPIN) {
     static_assert(NL == 2, "riding steps: two lanes");
     __shared__ __attribute__((aligned(16))) unsigned long long stl[2 * 80];
@@ -70,11 +116,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
       pre_ok = (int)blockIdx.x < 8 * blk_per_xcd && Lp < A.nblk;
       if (pre_ok) {
         const int cb0 = IDX16 ? A.colbase[Lp] : 0;
+        if constexpr (CSORT) {
+          csort_fetch(A, Lp, cb0, threadIdx.x, cpre, spre, vpre);
+        } else {
 #pragma unroll
-        for (int k = 0; k < kPerS; ++k) {
-          const size_t ii = (size_t)Lp * kSpmvNnz + threadIdx.x + k * kBlock;
-          cpre[k] = IDX16 ? cb0 + (int)A.col16[ii] : A.colind[ii];
-          vpre[k] = A.vals[ii];
+          for (int k = 0; k < kPerS; ++k) {
+            const size_t ii = (size_t)Lp * kSpmvNnz + threadIdx.x + k * kBlock;
+            cpre[k] = IDX16 ? cb0 + (int)A.col16[ii] : A.colind[ii];
+            vpre[k] = A.vals[ii];
+          }
         }
       }
     }
@@ -171,12 +221,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     }
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
+    [[maybe_unused]] int slot[kPer];  // CSORT: where the entry's product goes (its position in the block's row-major order)
     double v[kPer];
+    if constexpr (CSORT && !STEPIN) csort_fetch(A, L, cbase, tid, cidx, slot, v);
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       if (PAD && STEPIN) {  // requested at the head of the workgroup
         cidx[k] = cpre[k];
         v[k] = vpre[k];
+        if constexpr (CSORT) slot[k] = spre[k];
+      } else if (CSORT) {
       } else if (PAD) {
         const size_t ii = (size_t)L * kSpmvNnz + tid + k * kBlock;
         cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
@@ -194,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 #pragma unroll
       for (int k = 0; k < kPer; ++k) xv[k] = x[cidx[k]];
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) prod[tid + k * kBlock] = v[k] * xv[k];
+      for (int k = 0; k < kPer; ++k) prod[CSORT ? slot[k] : tid + k * kBlock] = v[k] * xv[k];
     } else {
       double2 xv[kPer];
 #pragma unroll
@@ -204,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
       }
 #pragma unroll
       for (int k = 0; k < kPer; ++k)
-        *reinterpret_cast<double2*>(prod + 2 * (tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
+        *reinterpret_cast<double2*>(prod + 2 * (CSORT ? slot[k] : tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
     }
     lds_barrier();
     // phase 2: G lanes per row

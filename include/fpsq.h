@@ -358,6 +358,7 @@ typedef struct {
   int64_t last_kernel_launches;
   int64_t last_prod_a[2];  /* launches of the A  product during that call with 1 and with 2 right-hand sides */
   int64_t last_prod_at[2]; /* same for the A' product */
+  int64_t at_sorted;       /* 1: the row blocks of A' are stored column-sorted (coalesced gathers, see k_spmv<.., CSORT>) */
 } fpsq_info;
 int fpsq_get_info(fpsq_handle h, fpsq_info *info);
 /* on != 0: bracket every SpMV/SpMM launch with HIP events on the solver's stream so that last_spmv_ms is filled

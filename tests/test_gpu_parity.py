@@ -854,6 +854,43 @@ def test_riding_scalar_steps_are_bitwise_the_stand_alone_steps(monkeypatch, delt
     dev.close()
 
 
+@pytest.mark.parametrize("stepin", ["0", "640"])
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_column_sorted_at_blocks_are_bitwise_the_row_order_layout(monkeypatch, delta, stepin):
+    """A' of a banded Jacobian is stored with every row block's entries sorted by COLUMN (coalesced gathers: the row-order
+    gather is what bounded the A' product), each entry carrying its row-major slot, to which its product is scattered
+    (k_spmv<.., CSORT>).  Same values summed in the same order: every output must be BITWISE that of a handle storing the
+    blocks in row order (FPSQ_AT_SORTED=0) -- objgrad, hprod (both Hessian approximations), the seam solves, the one-lane
+    kernels of an unfused handle, with the scalar steps riding in the products (small grids) and without."""
+    qp = _small_pde(seed=13, n=30000, m=3000)
+    monkeypatch.setenv("FPSQ_STEPIN_MAX", stepin)
+    monkeypatch.setenv("FPSQ_AT_SORTED", "0")
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    one_ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, fuse_two_rhs=0)
+    monkeypatch.setenv("FPSQ_AT_SORTED", "1")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    one = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, fuse_two_rhs=0)
+    assert ref.info()["at_sorted"] == 0 and dev.info()["at_sorted"] == 1 and one.info()["at_sorted"] == 1
+    rng = np.random.default_rng(3)
+    A = qp.scipy_csr()
+    for k in range(4):
+        x = qp.xhat + 0.3 * 0.5 ** k * rng.standard_normal(qp.n)
+        v = rng.standard_normal(qp.n)
+        res = []
+        for mdl in (ref, dev, one_ref, one):
+            gx, ys, gs, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.n)
+            f, rc = mdl.objgrad(x, gx=gx, ys=ys, gs=gs)
+            rch = mdl.hprod(v, hv, 1 + k % 2)
+            o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+            rcm = mdl.solve_two_mixed(qp.qdiag * x + qp.d, A @ x - qp.b, *o)
+            res.append([np.array([f, rc, rch, rcm]), gx, ys, gs, hv, *o])
+        for i, j in ((0, 1), (2, 3)):
+            for a_, b_ in zip(res[i], res[j]):
+                assert np.array_equal(a_, b_), (k, i)
+    for mdl in (ref, dev, one, one_ref):
+        mdl.close()
+
+
 def test_repeated_hprod_and_objgrad_calls_are_bitwise_identical():
     """The same call repeated on fresh and on warm handles gives the same bits every time (all reductions run in fixed
     orders; no atomics).  Regression test of the round-2 / round-3 race: the progress word used to be two stores, and a host
