@@ -59,6 +59,6 @@ out["per_evaluation_mix"] = mix
 out["traffic_bytes_per_productive_launch"] = round(tb / tot)
 out["algorithmic_bytes_per_productive_launch"] = round(ab / tot)
 out["traffic_over_algorithmic"] = round(tb / ab, 3)
-out["note"] = ("A' is stored with 16-bit block-relative columns (10 B/nnz against the 12 B/nnz of the algorithmic count), so its "
-               "HBM traffic is BELOW the algorithmic bytes; the column-sorted A product re-reads part of its x window through L2.")
+out["note"] = ("A' is stored in column-sorted padded blocks at 11 B per entry (8 value + 16-bit and 8-bit index planes; the algorithmic "
+               "count prices 12 B/nnz) plus its row pointers; the column-sorted A product re-reads part of its x window through L2.")
 print(json.dumps(out, indent=1))
