@@ -89,7 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
                                                  const LaneCtl* gate0, const LaneCtl* gate1, int pstride,
                                                  const HaloRows hr, const StepArgs s0, const StepArgs s1) {
-  // exactly 32 KB of LDS for two right-hand sides (five workgroups fit the CU's 160 KB): the reduction scratch
+  // exactly 32 KB of LDS for two right-hand sides (FOUR workgroups per CU -- measured, tools/stream_probe.hip: 30 KB would
+  // admit five, 24 KB six; tiles of 1536 entries were slower all the same): the reduction scratch
   // aliases the head of the product buffer
   __shared__ double prod[kSpmvNnz * NL];
   double* red = prod;

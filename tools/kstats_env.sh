@@ -1,12 +1,11 @@
 #!/bin/bash
 # developer script (GPU box): per-kernel average durations of the headline bench under each value of one environment
-# variable.  usage: tools/kstats_env.sh NAME v1 v2 ...
+# variable.  usage: tools/kstats_env.sh NAME v1 v2 ...   (FPSQ_LIB_PATH selects another build of the library)
 export TMPDIR=/tmp
 name=$1; shift
 for w in "$@"; do
   d=gpurun_out/ks_${name}_$w
   rm -rf $d
-  env $name=$w true
   export $name=$w
   timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o k -- python3 bench.py --steps 20 --warmup 3 --cpu-evals 0 --repeats 1 --no-roofline-pass > $d.log 2>&1 || exit 1
   rm -f $d/k_kernel_trace.csv
