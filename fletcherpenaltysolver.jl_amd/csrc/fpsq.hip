@@ -3073,6 +3073,7 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
     dv = h->in_n1;
   }
   double* dhv = on_this_device(h, Hv) ? Hv : h->gx;
+  bool lsq_repeats = false;
   call_begin(h);
   hipLaunchKernelGGL(k_qp_hsv, dim3(gn), dim3(kBlock), 0, s, qp->q, dv, h->in_n2, n);                    // :537
   TailFn epi = [&]() -> int {
@@ -3096,7 +3097,14 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
     //   Hv -= hprod_nln(x, invJtJJv, gs; obj_weight = 0) = 0                                                :613-614
     // i.e. the LSQR + MINRES lanes of solve_two_extras (tau = max(delta, 1e-14)) on the right-hand sides (v, 0) and one
     // more A' product; the two recurrences' statistics go to st[2], st[3].
+    // For this model two of those pieces are known in advance (FPSQ_AB_MASK bit 16 computes them all the same, for the test
+    // that holds the results bitwise equal): the MINRES lane's right-hand side is zero, so its solution is zero and so is
+    // J' invJtJSsv -- no A' product, nothing to subtract; and when tau == delta (delta >= 1e-14) the LSQR lane repeats, bit
+    // for bit, the first solve of solve_two_least_squares above (solve_least_square on the same operator, right-hand side v
+    // and damping: linear_system.jl:53 against :87) -- its statistics are that solve's.
     const double tau = std::max(h->delta, 1e-14);
+    const bool full = (h->ab_mask & 16) != 0;
+    lsq_repeats = !full && tau == h->delta;
     HIPCHK(h, hipMemsetAsync(h->in_m, 0, (size_t)h->m * 8, s));
     Lane lanes[2];
     lanes[0].kind = LANE_LSQR;
@@ -3109,10 +3117,16 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
     lanes[1].lambda = tau;
     lanes[1].x = h->Mx;
     lanes[1].st = &h->hstats[3];
-    if (int rc = run_lanes(h, lanes, 2)) return rc;
-    if (int rc = at_product_const(h, 1.0, h->Mx, 0.0, nullptr, h->jc)) return rc;  // J' invJtJSsv
-    hipLaunchKernelGGL(k_axpby_plain, dim3(gn), dim3(kBlock), 0, s, h->jc, -1.0, dhv, 1.0, dhv, n);
-    h->launches++;
+    if (lsq_repeats) {
+      if (int rc = run_lanes(h, lanes + 1, 1)) return rc;
+    } else {
+      if (int rc = run_lanes(h, lanes, 2)) return rc;
+    }
+    if (full) {
+      if (int rc = at_product_const(h, 1.0, h->Mx, 0.0, nullptr, h->jc)) return rc;  // J' invJtJSsv
+      hipLaunchKernelGGL(k_axpby_plain, dim3(gn), dim3(kBlock), 0, s, h->jc, -1.0, dhv, 1.0, dhv, n);
+      h->launches++;
+    }
   }
   if (dhv != Hv) HIPCHK(h, hipMemcpyAsync(Hv, dhv, nb, hipMemcpyDefault, s));
   if (int rc = call_end(h)) return rc;
@@ -3120,7 +3134,7 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, doub
   st[1] = h->hstats[1];
   int rc = soft_rc(st);
   if (hessian_approx == 1) {
-    st[2] = h->hstats[2];
+    st[2] = lsq_repeats ? h->hstats[0] : h->hstats[2];
     st[3] = h->hstats[3];
     rc |= soft_rc(st + 2) << 2;
   }

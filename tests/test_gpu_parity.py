@@ -615,6 +615,31 @@ def test_device_qp_hprod_val1_matches_oracle_and_host_mirror(oracle, delta, rho,
     qds.close()
 
 
+@pytest.mark.parametrize("delta", [0.0, SE, 1e-2])
+def test_device_qp_hprod_val1_shortcuts_are_bitwise_the_full_computation(monkeypatch, delta):
+    """hprod! Val(1) of the equality-QP model: the MINRES lane of solve_two_extras has a zero right-hand side (J' of its zero
+    solution is not formed), and for delta >= 1e-14 its LSQR lane repeats the first solve of solve_two_least_squares bit for
+    bit (statistics taken from there).  FPSQ_AB_MASK bit 16 computes everything: Hv and all four recurrences' statistics
+    must be identical."""
+    qp = _small_pde(seed=37, n=5000, m=500)
+    rng = np.random.default_rng(9)
+    monkeypatch.setenv("FPSQ_AB_MASK", "16")
+    full = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    monkeypatch.setenv("FPSQ_AB_MASK", "0")
+    fast = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    for k in range(3):
+        v = rng.standard_normal(qp.n)
+        res = []
+        for mdl in (full, fast):
+            hv = np.empty(qp.n)
+            rc = mdl.hprod(v, hv, 1)
+            st = [(s_.niter, s_.status, s_.solved, s_.rnorm, s_.arnorm) for s_ in (mdl.stats4[i] for i in range(4))]
+            res.append((rc, hv, st))
+        assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], k
+    full.close()
+    fast.close()
+
+
 @pytest.mark.parametrize("where", ["host", "device"])
 @pytest.mark.parametrize("delta", [0.0, SE, 0.25])
 def test_ys_gs_entry_point(oracle, where, delta):
