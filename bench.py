@@ -355,7 +355,7 @@ def main():
         if kind in ("halo", "allreduce"):
             from fps_amd.device_qp import rccl_unique_id
 
-            ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+            ident = torch.zeros(128, dtype=torch.uint8, device="cpu" if rehearse else dev)  # (gloo in a rehearsal)
             if rank == 0:
                 ident.copy_(torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8))
             if world > 1:

@@ -105,9 +105,15 @@ struct RcclApi {
   bool load(std::string& err) {
     if (lib) return true;
     // by SONAME first: a process that imported torch already holds librccl.so.1 and must keep using that copy
+    // FPSQ_RCCL_LIB: another build of the collectives library (a site build; the multi-process loopback stand-in of
+    // tests/shim, which lets the multi-rank path run on a one-GPU box) -- then that one or nothing
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names)
-      if ((lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (const char* ov = std::getenv("FPSQ_RCCL_LIB")) {
+      lib = dlopen(ov, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* nm : names)
+        if ((lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    }
     if (!lib) {
       err = std::string("cannot dlopen librccl: ") + dlerror();
       return false;

@@ -55,3 +55,35 @@ def test_failed_multi_rank_phase_exits_nonzero_with_empty_stdout():
     # (the gloo backend of the rehearsal prints a connection banner on stdout; what must be absent is a result line)
     assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines()), r.stdout
     assert "FAILED" in r.stderr and "bench.py" in r.stderr
+
+
+def _shim():
+    """The multi-process loopback stand-in for librccl (tests/shim/loopback_rccl.cpp), built on demand."""
+    so = os.path.join(ROOT, "tests", "shim", "libloopback_rccl.so")
+    src = os.path.join(ROOT, "tests", "shim", "loopback_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-Wno-unused-result", "-o", so, src])
+    return so
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_rank_sharded_bench_runs_through_the_loopback_collectives(ranks):
+    """bench.py --gpus N, sharded (halo layout), executed FOR REAL as N processes -- torch.distributed.run, unique-id
+    broadcast, fpsq_comm_init, the per-iteration all-gathers and grouped send / recv halo exchanges of the C++ RcclComm --
+    on this box's one GPU, with the collectives carried by the loopback stand-in for librccl (RCCL refuses two ranks on one
+    device).  Timing means nothing here; the run must end with rc 0, ONE JSON line saying strong scaling over a halo layout,
+    every evaluation solved, and the iteration counts of the single-GPU run of the same points."""
+    env = {"FPSQ_BENCH_REHEARSE": "1", "FPSQ_RCCL_LIB": _shim(), "FPSQ_BENCH_WATCHDOG": "400", "FPSQ_SHIM_TIMEOUT": "120"}
+    r = _run(["--gpus", str(ranks), "--parallel", "shard", "--steps", "2", "--warmup", "1", "--repeats", "1", "--cpu-evals", "0",
+              "--no-roofline-pass"], env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["scaling"] == "strong" and "HALO" in d["config"]["parallelism"]
+    assert d["config"]["all_solved"] is True
+    one = _run(["--steps", "2", "--warmup", "1", "--repeats", "1", "--cpu-evals", "0", "--no-roofline-pass"])
+    assert one.returncode == 0, one.stderr[-1500:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert d["config"]["iters_lsqr_craig_median"] == d1["config"]["iters_lsqr_craig_median"]
+    assert "replicas_alternative" in d and d["replicas_alternative"]["scaling"] == "weak"
