@@ -299,6 +299,93 @@ def test_solve_two_mixed_iteration_parity_with_c_restatement(oracle, delta, fuse
     H.close()
 
 
+def _random_structure(kind, rng):
+    """Jacobians of awkward shapes (full row rank with probability one): what the storage layouts have to cope with."""
+    if kind == "tiny":              # fewer entries than one lane group
+        m, n = 1, 3
+        A = sp.csr_matrix(rng.standard_normal((m, n)))
+    elif kind == "square-ish":      # m close to n, short rows of A'
+        m, n = 180, 200
+        A = sp.random(m, n, density=0.04, random_state=np.random.RandomState(3), format="csr") + sp.eye(m, n) * 3.0
+    elif kind == "wide-window":     # A' blocks span more than 8192 columns: 16-bit columns, but not the column-sorted layout
+        m, n = 10000, 12000
+        rows = np.repeat(np.arange(m), 3)
+        cols = np.concatenate([np.arange(m), (np.arange(m) * 7919) % n, (np.arange(m) * 104729 + 13) % n]).reshape(3, m).T.ravel()
+        A = sp.csr_matrix((rng.standard_normal(3 * m) + np.tile([4.0, 0.0, 0.0], m), (rows, cols)), shape=(m, n))
+    elif kind == "empty-columns":   # columns of A without entries = empty rows of A' (empty row blocks)
+        m, n = 300, 5000
+        A = sp.random(m, 600, density=0.03, random_state=np.random.RandomState(5), format="csr") + sp.eye(m, 600) * 2.0
+        A = sp.hstack([A, sp.csr_matrix((m, n - 600))], format="csr")
+    elif kind == "dense-row":       # one constraint touching every variable: a long row of A, a 1-entry-heavier A'
+        m, n = 120, 6000
+        A = sp.vstack([sp.random(m - 1, n, density=0.004, random_state=np.random.RandomState(7), format="csr")
+                       + sp.eye(m - 1, n) * 2.0, sp.csr_matrix(np.ones((1, n)))], format="csr")
+    elif kind == "dense-column":    # one variable in every constraint: a row of A' longer than an LDS stage
+        m, n = 3000, 9000
+        A = sp.random(m, n, density=0.0015, random_state=np.random.RandomState(9), format="lil")
+        A[:, 17] = rng.standard_normal((m, 1))
+        A = sp.csr_matrix(A) + sp.eye(m, n) * 2.0
+    elif kind == "duplicates-free-unsorted":  # CSR with unsorted column indices inside the rows
+        m, n = 400, 3000
+        A = sp.random(m, n, density=0.01, random_state=np.random.RandomState(11), format="csr") + sp.eye(m, n) * 2.0
+        A = sp.csr_matrix(A)
+        for i in range(m):
+            a, b = A.indptr[i], A.indptr[i + 1]
+            perm = rng.permutation(b - a)
+            A.indices[a:b] = A.indices[a:b][perm]
+            A.data[a:b] = A.data[a:b][perm]
+    else:
+        raise ValueError(kind)
+    A = sp.csr_matrix(A)
+    A.has_sorted_indices = kind != "duplicates-free-unsorted"
+    return A
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+@pytest.mark.parametrize("delta", [SE, 0.25])
+@pytest.mark.parametrize("kind", ["tiny", "square-ish", "wide-window", "empty-columns", "dense-row", "dense-column",
+                                  "duplicates-free-unsorted"])
+def test_awkward_jacobian_structures_match_the_c_restatement(oracle, kind, delta, fuse):
+    """Shapes the product layouts must survive (every one takes another path through the set-up: unpadded A' when a row is
+    longer than an LDS stage, row-order blocks when a block spans more than 8192 columns, empty row blocks, a Jacobian of one
+    row, unsorted CSR rows): A v / A' u equal scipy's to rounding; solve_two_mixed and solve_two_least_squares through the C
+    ABI follow the CPU restatement -- same statuses, iteration counts within two (a dominant dense row or column makes the
+    intermediate LSQR / CRAIG iterates sensitive to the summation order: scipy's lsqr, the restatement and the device differ
+    from each other by 1e-7 at a fixed iteration count there), the vectors within 1e-4
+    of the restatement's (an iteration more or fewer at the reference tolerances sqrt(eps)) and, at delta = 0.25, within
+    1e-3 of the exact KKT solve."""
+    rng = np.random.default_rng(12)
+    A = _random_structure(kind, rng)
+    m, n = A.shape
+    H = _Handle(A, delta=delta, fuse_two_rhs=fuse)
+    x, u = rng.standard_normal(n), rng.standard_normal(m)
+    As = sp.csr_matrix(A)
+    assert _rel(H.jac_mul(0, 1.0, x, 0.0, np.zeros(m)), As @ x) < 1e-13
+    assert _rel(H.jac_mul(1, 1.0, u, 0.0, np.zeros(n)), As.T @ u) < 1e-13
+    g, c = rng.standard_normal(n), rng.standard_normal(m)
+    rp, ci, va = A.indptr.astype(np.int64), A.indices.astype(np.int64), np.ascontiguousarray(A.data)
+    p1, q1, p2, q2, rc = H.solve_two_mixed(g, c)
+    o = oracle.solve_two_mixed(m, n, rp, ci, va, delta, g, c)
+    assert rc == o[5]
+    for k in range(2):
+        assert abs(H.st[k].niter - o[4][k].niter) <= 2, k
+        assert (H.st[k].status, H.st[k].solved) == (o[4][k].status, o[4][k].solved), k
+    exact = delta > 1e-3 and n + m <= 7000  # (at delta = sqrt(eps) CRAIG may stop on its conditioning limit, far from the solve)
+    e = oracle.exact_two_mixed(As, delta, g, c) if exact else o[:4]
+    for got, want, ex in zip((p1, q1, p2, q2), o[:4], e):
+        assert _rel(got, want) < 1e-4 and _rel(got, ex) < 1e-3  # (reference tolerances sqrt(eps) on an ill-conditioned system)
+    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
+    p1, q1, p2, q2, rc = H.solve_two_least_squares(r1, r2)
+    o = oracle.solve_two_least_squares(m, n, rp, ci, va, delta, r1, r2)
+    assert rc == o[5]
+    for k in range(2):
+        assert abs(H.st[k].niter - o[4][k].niter) <= 2 and H.st[k].status == o[4][k].status, k
+    e = oracle.exact_two_least_squares(As, delta, r1, r2) if exact else o[:4]
+    for got, want, ex in zip((p1, q1, p2, q2), o[:4], e):
+        assert _rel(got, want) < 1e-4 and _rel(got, ex) < 1e-3
+    H.close()
+
+
 def test_solve_two_mixed_tight_tolerance_vs_exact(oracle):
     qp = _small_pde(seed=9)
     A = qp.scipy_csr()
