@@ -386,6 +386,31 @@ def test_awkward_jacobian_structures_match_the_c_restatement(oracle, kind, delta
     H.close()
 
 
+@pytest.mark.parametrize("kind", ["tiny", "square-ish", "empty-columns", "dense-row", "dense-column", "wide-window"])
+def test_fused_qp_entries_on_awkward_structures(oracle, kind):
+    """The fused device entries (fpsq_qp_objgrad / fpsq_qp_hprod: fast start, riding updates and scalar steps, speculative
+    tail) on the same shapes, twice per model (first call, then with the run-ahead armed): fx / gx / ys and Hv follow the C
+    restatement of objgrad! / hprod! (1e-4: see the seam test above), same return codes."""
+    rng = np.random.default_rng(21)
+    A = _random_structure(kind, rng)
+    A.sort_indices()
+    m, n = A.shape
+    qp = problems._finish(kind, n, m, A.indptr.astype(np.int64), A.indices.astype(np.int64), np.ascontiguousarray(A.data), 7)
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.25)
+    v = rng.standard_normal(n)
+    for t in range(2):
+        x = qp.point(1 + t)
+        gx, ys, hv = np.empty(n), np.empty(m), np.empty(n)
+        fx, rc = dev.objgrad(x, gx=gx, ys=ys)
+        o = oracle.qp_objgrad(qp, x, 1e3, 1.0, 0.25)
+        assert rc == o["rc"] and abs(fx - o["fx"]) <= 1e-6 * max(1.0, abs(o["fx"]))
+        assert _rel(gx, o["gx"]) < 1e-4 and _rel(ys, o["ys"]) < 1e-4
+        rch = dev.hprod(v, hv, 2)
+        oh = oracle.qp_hprod(qp, v, 1e3, 1.0, 0.25)
+        assert rch == oh["rc"] and _rel(hv, oh["Hv"]) < 1e-4
+    dev.close()
+
+
 def test_solve_two_mixed_tight_tolerance_vs_exact(oracle):
     qp = _small_pde(seed=9)
     A = qp.scipy_csr()
