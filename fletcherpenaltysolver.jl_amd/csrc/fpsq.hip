@@ -395,7 +395,13 @@ struct fpsq_solver_s {
   LsqrState* lsqr_alt[2];       // second copies: the target of a step that rides in a product launch (see run_krylov)
   CraigState* craig_alt;
   bool at_sorted = true;        // A' blocks stored column-sorted where representable (FPSQ_AT_SORTED=0: row order)
-  int stepin_max = 640;         // riding steps when neither product has more workgroups than this (FPSQ_STEPIN_MAX; 0: never)
+  // steps riding with LEADERS (large grids, see fpsq_spmv.hip.h): the leaders' record (one line of device memory), a launch counter
+  unsigned long long* ride_flags = nullptr;
+  unsigned long long ride_seq = 0;
+  bool ride_lead = true;        // FPSQ_RIDE_LEAD=0: large grids keep the stand-alone k_step
+  bool lead_now = false;        // run_krylov: the pending steps ride with leaders (not the all-recompute form)
+  int stepin_max = 0;           // all-recompute form of the riding steps when neither product has more workgroups than this
+                                // (FPSQ_STEPIN_MAX; 0 = never: the leader form is faster at every size measured)
   MinresState* minres;
   LnlqState* lnlq;
   LaneCtl* ctl_tmp;
@@ -940,13 +946,22 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     z0 = pre[0];
     z1 = pre[1];
   }
+  RideArgs ra{};
+  const bool lead = pre && h->lead_now;
+  if (lead) {  // (run_krylov only sets lead_now where both products have the leader variants: lead_supported())
+    ra.rec = h->ride_flags;
+    ra.want = (unsigned int)++h->ride_seq;
+    ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
+  }
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
 #define FPSQ_LAUNCH_RGCS(...) \
-    launch_product(h, k_spmv_rgcs<__VA_ARGS__>, dim3(per_xcd * 8 + nupd), h->RA.view, x, yin, yout, c0, c1, partials, per_xcd, u0, u1, \
-                   h->gate0, h->gate1, h->strA, z0, z1)
+    launch_product(h, k_spmv_rgcs<__VA_ARGS__>, dim3(per_xcd * 8 + nupd + (lead ? 2 : 0)), h->RA.view, x, yin, yout, c0, c1, partials, \
+                   per_xcd, u0, u1, h->gate0, h->gate1, h->strA, z0, z1, ra)
     if constexpr (NL == 2) {
-      if (pre && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true);
+      if (lead && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, false, true);
+      else if (lead) FPSQ_LAUNCH_RGCS(2, false, false, true);
+      else if (pre && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true);
       else if (pre) FPSQ_LAUNCH_RGCS(2, false, true);
     }
     if (!pre) {
@@ -964,7 +979,14 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
                    z0, z1)
     bool done_pre = false;
     if constexpr (NL == 2) {
-      if (pre) {  // (only the variants stepin_supported() admits)
+      if (lead) {  // (tag == TAG_AT: padded blocks with block-relative columns, see lead_supported())
+        done_pre = true;
+        const dim3 lgrid(2 + M.nblk + nupd);
+        if (M.sorted)
+          launch_product(h, k_spmv_atl<true>, lgrid, M.view(), x, yin, yout, partials, M.nblk, u0, u1, ps, z0, z1, ra);
+        else
+          launch_product(h, k_spmv_atl<false>, lgrid, M.view(), x, yin, yout, partials, M.nblk, u0, u1, ps, z0, z1, ra);
+      } else if (pre) {  // (only the variants stepin_supported() admits)
         done_pre = true;
         if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(2, TAG_A, true, false, false, true);
         else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(2, TAG_A, false, false, false, true);
@@ -1535,6 +1557,12 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   bool stepin = NL == 2 && !h->comm && h->stepin_max > 0 && h->AT.padded && h->AT.nblk <= h->stepin_max &&
                 npart_A(h) <= h->stepin_max;
   for (int l = 0; l < NL; ++l) stepin = stepin && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
+  // Larger grids: the pending steps ride with two LEADER workgroups of the next product launch (k_spmv_atl,
+  // k_spmv_rgcs<.., LEAD>): computed once, picked up by the others on their way to the row epilogue.
+  bool lead = NL == 2 && !h->comm && h->ride_lead && !stepin && h->AT.padded && (h->AT.sorted || h->AT.col16) && h->RA.ok;
+  for (int l = 0; l < NL; ++l) lead = lead && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
+  h->lead_now = lead;
+  stepin = stepin || lead;  // (the same hand-over on the host side)
 #define c0 (lanes[0].ctl)       /* A product */
 #define c1 (lanes[NL - 1].ctl)
 #define t0 (lanes[0].ctlT)      /* A' product */
@@ -2139,6 +2167,14 @@ void call_begin(fpsq_handle h) {
   h->t_call = std::chrono::steady_clock::now();
 }
 
+// steps riding with leaders: a workgroup's bounded wait for the leaders' record expired (never observed; see kRidePolls)
+bool ride_failed(fpsq_handle h) {
+  if (h->hscal[15] == 0.0) return false;
+  h->hscal[15] = 0.0;
+  h->err = "riding scalar steps: the leaders' record did not arrive (bounded wait expired); FPSQ_RIDE_LEAD=0 avoids the path";
+  return true;
+}
+
 int call_end(fpsq_handle h) {
   if (h->profile) hipEventRecord(h->ev1, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2146,6 +2182,7 @@ int call_end(fpsq_handle h) {
     h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
     return FPSQ_ERR_TIMEOUT;
   }
+  if (ride_failed(h)) return FPSQ_ERR_TIMEOUT;
   float ms = 0.f;
   if (h->profile) hipEventElapsedTime(&ms, h->ev0, h->ev1);
   else ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->t_call).count();
@@ -2190,6 +2227,7 @@ int call_end_ordered(fpsq_handle h, double seq) {
       }
     }
   }
+  if (ride_failed(h)) return FPSQ_ERR_TIMEOUT;
   h->info.last_solve_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->t_call).count();
   h->info.last_kernel_launches = h->launches;
   h->info.last_spmv_launches = h->spmv_launches;
@@ -2474,6 +2512,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_ADAPTIVE_RUNAHEAD")) h->adaptive_runahead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_HOST_TRACE")) h->host_trace = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_AT_SORTED")) h->at_sorted = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_STEPIN_MAX")) h->stepin_max = std::min(std::atoi(ev), 4 * kStepThreads);  // (step2_issue's shape)
   if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_AB_DYNAMIC")) h->ab_dynamic = std::atoi(ev) != 0;
@@ -2491,6 +2530,13 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if ((e = hipMalloc(&p, state_bytes)) != hipSuccess) return fail("hipMalloc", e);
   h->allocs.push_back(p);
   hipMemset(p, 0, state_bytes);
+  {
+    void* q = nullptr;
+    if ((e = hipMalloc(&q, 512)) != hipSuccess) return fail("hipMalloc", e);
+    h->allocs.push_back(q);
+    hipMemset(q, 0, 512);
+    h->ride_flags = (unsigned long long*)q;
+  }
   char* cp = (char*)p;
   h->lsqr[0] = (LsqrState*)cp;
   h->lsqr[1] = h->lsqr[0] + 1;

@@ -300,6 +300,246 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------ steps riding with leaders
+//
+// LARGE product grids (thousands of workgroups: every workgroup recomputing the pending scalar steps, STEPIN above, would
+// read the partial sums thousands of times over): the two steps that follow the previous product are computed ONCE, by two
+// LEADER workgroups at the head of this launch's grid (blockIdx 0 / 1 = lane 0 / 1: exactly k_step's body), which then
+// publish a launch sequence number behind a device-scope release.  A product only needs the steps' coefficients in its
+// row epilogue -- out = ca (A x) + cb yin is linear in them -- so every other workgroup starts streaming at once and picks
+// them up on the way: it requests the two flag words TOGETHER WITH its matrix stream (nothing waits on them), looks at
+// them when the stream has landed, and, flags set, reads ca / cb / done / skip of both lanes with device-scope loads (this
+// XCD's L2 may hold an older image of those lines) while its gathers are in flight.  Workgroups of the first wave, which
+// started before the leaders finished, ask again behind their gathers; whoever still has nothing at the end of phase 1
+// polls a bounded number of times and then recomputes the steps itself (step_run without commit: same inputs, same
+// instructions, same bits) -- no workgroup ever depends on another one's progress for more than that bound.
+// The one-workgroup k_step launch between two products (~5 us in the running pipeline, 32 per evaluation at the headline
+// size) disappears; results are bitwise those of the stand-alone steps.
+struct RideArgs {
+  unsigned long long* rec;  // the leaders' record: 16 + 48 self-validating words (four 128-byte lines), see ride_publish
+  unsigned int want;        // this launch's number
+  unsigned long long* err;  // host-mapped: set when a bounded wait for the record expired (the call then fails)
+};
+struct RideCoef {
+  double ca[2], cb[2];
+  bool act[2];
+};
+
+__device__ __forceinline__ unsigned long long ride_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ride_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: on its way to memory at once)
+}
+
+// The record.  Every 8-byte word carries the launch number in its low half and half a word of payload in its high half;
+// a word is read and written in one piece, so whoever sees the number sees the payload that belongs to it -- no flag, no
+// ordering between loads, no fence on the leader's critical path, ONE wave instruction per look.
+//  * line 0, what a PRODUCT workgroup needs, written by the leader's thread 0 the moment the step is computed:
+//      rec[4 l + 0 / 1] = high / low half of ca_l,  rec[4 l + 2 / 3] = of cb_l,  rec[8 + l] = (done | skip) != 0
+//  * lines 1-3, the whole control blocks for the riding UPDATE workgroups (dispatched last), written right behind:
+//      rec[16 + 24 l + 2 i + 0 / 1] = high / low half of word i (of 12) of lane l's LaneCtl
+__device__ __forceinline__ void ride_publish(const LaneCtl* c, int l, unsigned long long* rec, unsigned int want) {
+  const unsigned long long a = (unsigned long long)__double_as_longlong(c->ca), b = (unsigned long long)__double_as_longlong(c->cb);
+  ride_store(rec + 4 * l + 0, (a & 0xffffffff00000000ull) | want);
+  ride_store(rec + 4 * l + 1, (a << 32) | want);
+  ride_store(rec + 4 * l + 2, (b & 0xffffffff00000000ull) | want);
+  ride_store(rec + 4 * l + 3, (b << 32) | want);
+  ride_store(rec + 8 + l, ((unsigned long long)((c->done | c->skip) != 0 ? 1u : 0u) << 32) | want);
+}
+__device__ __forceinline__ void ride_decode(const unsigned long long* w /* 10 words */, RideCoef& C) {
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    C.ca[l] = __longlong_as_double((long long)((w[4 * l] & 0xffffffff00000000ull) | (w[4 * l + 1] >> 32)));
+    C.cb[l] = __longlong_as_double((long long)((w[4 * l + 2] & 0xffffffff00000000ull) | (w[4 * l + 3] >> 32)));
+    C.act[l] = (w[8 + l] >> 32) == 0;
+  }
+}
+
+// blockIdx 0 / 1 of a launch with riding leaders: lane 0 / 1.  k_step's body (step_run) with line 0 of the record published
+// from the advanced state in LDS BEFORE the state is committed: that is all the product workgroups wait for.
+__device__ __forceinline__ void ride_leader(const StepArgs& a, int l, const RideArgs& ra, double* red32, unsigned long long* st80) {
+  auto early = [&]() { ride_publish(reinterpret_cast<const LaneCtl*>(st80), l, ra.rec, ra.want); };
+  if (a.kind != STEP_NONE) {
+    step_run(a, red32, st80, true, &early);
+  } else {
+    if (threadIdx.x < 12) st80[threadIdx.x] = reinterpret_cast<const unsigned long long*>(a.state)[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) early();
+  }
+  if (threadIdx.x < 12) {  // (step_run's closing barrier: st80 is final for every thread)
+    const unsigned long long w = st80[threadIdx.x];
+    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x, (w & 0xffffffff00000000ull) | ra.want);
+    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x + 1, (w << 32) | ra.want);
+  }
+}
+
+// One look of a PRODUCT workgroup, by the calling wave (one wave per workgroup looks): lanes 0..9 each request one word ...
+__device__ __forceinline__ unsigned long long ride_look(const RideArgs& ra) {
+  const int lane = threadIdx.x & 63;
+  return lane < 10 ? ride_load(ra.rec + lane) : 0ull;
+}
+// ... and its verdict (wave-uniform); a good look leaves the ten words in `crec` (LDS)
+__device__ __forceinline__ bool ride_take(const RideArgs& ra, unsigned long long w, unsigned long long* crec) {
+  const int lane = threadIdx.x & 63;
+  const bool good = lane >= 10 || (unsigned int)(w & 0xffffffffull) == ra.want;
+  if (!__all(good)) return false;
+  if (lane < 10) crec[lane] = w;
+  return true;
+}
+// The same for an UPDATE workgroup: lanes 0..47, the two control blocks end up in LDS at img[0..11] and img[80..91].
+__device__ __forceinline__ bool ride_take_ctl(const RideArgs& ra, unsigned long long* img) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long w = lane < 48 ? ride_load(ra.rec + 16 + lane) : 0ull;
+  const bool good = lane >= 48 || (unsigned int)(w & 0xffffffffull) == ra.want;
+  const unsigned int nlo = (unsigned int)__shfl_down((unsigned int)(w >> 32), 1, 64);  // the partner's payload (low half of the word)
+  if (!__all(good)) return false;
+  if (lane < 48 && (lane & 1) == 0) {
+    const int k = lane >> 1;  // word k % 12 of lane k / 12
+    img[(k / 12) * 80 + k % 12] = (w & 0xffffffff00000000ull) | nlo;
+  }
+  return true;
+}
+
+// The leaders are the first two workgroups of the grid -- dispatched first, running before any workgroup that waits for them
+// -- and need a few microseconds.  A wait nevertheless has an end every wave reaches: after kRidePolls looks (~1 us each,
+// tens of milliseconds) the workgroup raises the handle's error word and leaves without writing anything (the call returns
+// FPSQ_ERR_TIMEOUT).  (Recomputing the steps locally instead -- step_run twice -- was built first: inlined it took the product
+// kernels from 81 to 256 registers, as a called function it put their waves on a scratch stack: 64 us per product.)
+constexpr int kRidePolls = 1 << 15;
+
+// A workgroup whose looks have all failed by the time it needs the coefficients (every thread calls this; workgroup barriers
+// inside): wave 0 keeps looking (CTL: for the whole control blocks, an update workgroup).  Returns false when the bound expired.
+template <bool CTL>
+__device__ __forceinline__ bool ride_settle(const RideArgs& ra, unsigned long long* dst, int* got) {
+  if (threadIdx.x == 0) *got = 0;
+  __syncthreads();
+  for (int t = 0; t < kRidePolls; ++t) {
+    if (threadIdx.x < 64) {
+      if (t) __builtin_amdgcn_s_sleep(4);
+      const bool ok = CTL ? ride_take_ctl(ra, dst) : ride_take(ra, ride_look(ra), dst);
+      if (ok && threadIdx.x == 0) *got = 1;
+    }
+    __syncthreads();
+    if (*got) return true;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ra.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return false;
+}
+
+// The A' product (two lanes, padded blocks with block-relative columns, one GPU) of a launch with riding leaders: k_spmv's
+// main path with the coefficients taken as described above.  grid = 2 leaders + nprod row blocks + the riding updates.
+template <bool CSORT>
+__global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __restrict__ x, const double* yin, double* yout,
+                                                     double* partials, int nprod, const UpdSeg u0, const UpdSeg u1, int pstride,
+                                                     const StepArgs s0, const StepArgs s1, const RideArgs ra) {
+  constexpr int NL = 2;
+  __shared__ double prod[kSpmvNnz * NL];
+  __shared__ __attribute__((aligned(16))) unsigned long long fst[2 * 80];
+  __shared__ double fred[32];
+  __shared__ unsigned long long crec[10];
+  __shared__ int okf;
+  double* red = prod;
+  const int tid = threadIdx.x;
+  if (blockIdx.x < 2) {
+    ride_leader(blockIdx.x == 0 ? s0 : s1, (int)blockIdx.x, ra, fred, fst);
+    return;
+  }
+  const int L = (int)blockIdx.x - 2;
+  if (L >= nprod) {  // a riding-update workgroup (dispatched last: the record is up long before)
+    if (ride_settle<true>(ra, fst, &okf))
+      run_fused_updates<NL>(u0, u1, nprod + 2, red, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
+    return;
+  }
+  if (L >= A.nblk) return;
+  const int4 bd = A.blkdesc[L];
+  const int cbase = A.colbase[L];
+  const int r0 = bd.x, nr = bd.y, s = bd.z;
+  int G = 1;
+  while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
+  const int rows_per_pass = kBlock / G;
+  const int g = tid / G, gl = tid % G;
+  const int rq0 = g < nr ? g : 0;
+  const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
+  double ypre[NL] = {0.0, 0.0};
+  if (yin != nullptr) {
+    const double2 t = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
+    ypre[0] = t.x;
+    ypre[1] = t.y;
+  }
+  constexpr int kPer = kSpmvNnz / kBlock;
+  int cidx[kPer];
+  [[maybe_unused]] int slot[kPer];
+  double v[kPer];
+  if constexpr (CSORT) {
+    csort_fetch(A, L, cbase, tid, cidx, slot, v);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const size_t ii = (size_t)L * kSpmvNnz + tid + k * kBlock;
+      cidx[k] = cbase + (int)A.col16[ii];
+      v[k] = A.vals[ii];
+    }
+  }
+  // Wave 0 looks for the leaders' record: once behind the stream (examined behind the gathers), once more behind the
+  // gathers if that was too early (the first wave of workgroups).  Device-scope loads come back later than ordinary ones
+  // and the load counter is in-order, so each look is requested BEHIND the loads whose arrival the next step waits for.
+  unsigned long long look1 = 0;
+  if (tid < 64) look1 = ride_look(ra);
+  double2 xv[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+  bool ok = false;
+  unsigned long long look2 = 0;
+  if (tid < 64) {
+    ok = ride_take(ra, look1, crec);
+    if (!ok) look2 = ride_look(ra);
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k)
+    *reinterpret_cast<double2*>(prod + 2 * (CSORT ? slot[k] : tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
+  unsigned long long look3 = 0;
+  if (tid < 64 && !ok) {
+    ok = ride_take(ra, look2, crec);
+    if (!ok) look3 = ride_look(ra);  // third look: examined behind the row sums, right where the coefficients are first needed
+  }
+  lds_barrier();  // (publishes the products)
+  double sq[NL] = {0.0, 0.0};
+  RideCoef C;
+  for (int base = 0; base < nr; base += rows_per_pass) {
+    const int rr = base + g;
+    const bool valid = rr < nr;
+    double acc[NL] = {0.0, 0.0};
+    if (valid) {
+      const int a = (base == 0 ? seg_a0 : A.rowptr[r0 + rr]) - s, b = (base == 0 ? seg_b0 : A.rowptr[r0 + rr + 1]) - s;
+      row_segment_sum<NL>(prod, a + gl, b, G, acc);
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] += __shfl_down(acc[l], off, 64);
+    }
+    if (base == 0) {  // the coefficients: first needed here (every thread passes this point)
+      if (tid < 64) {
+        if (!ok) ok = ride_take(ra, look3, crec);
+        if (tid == 0) okf = ok ? 1 : 0;
+      }
+      lds_barrier();  // (publishes the record words and the verdict)
+      if (!okf && !ride_settle<false>(ra, crec, &okf)) return;  // (workgroup-uniform; the first wave of workgroups at most)
+      ride_decode(crec, C);
+    }
+    if (valid && gl == 0)
+      row_epilogue<NL>((size_t)(r0 + rr), acc, C.ca, C.cb, C.act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
+  }
+  if (partials != nullptr) {
+    lds_barrier();  // `red` aliases `prod`: every wave must be past its phase-2 reads
+    block_sum_lanes<NL>(sq, red);
+    if (tid == 0) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + L] = sq[l];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ RGCS product
 //
 // RGCS = Row Groups, Column-Sorted.  The CSR-stream kernel gathers x in ROW order: for a wide matrix whose rows spread
@@ -348,21 +588,43 @@ struct RgcsView {
 
 // PAD: the groups' entries are stored at a fixed stride and zero-padded to whole tiles, so the first tile's stream
 // does not wait for the group descriptor and no load needs a bounds check.
-template <int NL, bool PAD = false, bool STEPIN = false>
+// LEAD: the launch's first two workgroups are the leaders of the riding steps (see "steps riding with leaders" above); the
+// groups and the riding updates follow, the coefficients are picked up between the tiles.
+template <int NL, bool PAD = false, bool STEPIN = false, bool LEAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                       double* partials, int grp_per_xcd, const UpdSeg u0,
                                                       const UpdSeg u1, const LaneCtl* gate0, const LaneCtl* gate1,
-                                                      int pstride, const StepArgs s0, const StepArgs s1) {
+                                                      int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra) {
   __shared__ double prod[kRgcsTile * NL];
   double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
+  static_assert(!LEAD || (NL == 2 && !STEPIN), "riding leaders: two lanes, instead of the all-recompute form");
+  [[maybe_unused]] unsigned long long* fst = nullptr;
+  [[maybe_unused]] double* fred = nullptr;
+  [[maybe_unused]] unsigned long long* crec = nullptr;
+  [[maybe_unused]] int* okf = nullptr;
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
+  if constexpr (LEAD) {
+    __shared__ __attribute__((aligned(16))) unsigned long long fst_[2 * 80];
+    __shared__ double fred_[32];
+    __shared__ unsigned long long crec_[10];
+    __shared__ int okf_;
+    fst = fst_;
+    fred = fred_;
+    crec = crec_;
+    okf = &okf_;
+    if (blockIdx.x < 2) {
+      ride_leader(blockIdx.x == 0 ? s0 : s1, (int)blockIdx.x, ra, fred, fst);
+      return;
+    }
+  }
+  const int bid = LEAD ? (int)blockIdx.x - 2 : (int)blockIdx.x;
   if constexpr (STEPIN) {  // (see k_spmv)
     static_assert(NL == 2, "riding steps: two lanes");
     if ((int)blockIdx.x >= 8 * grp_per_xcd + u0.nblk + u1.nblk) return;
   }
   // (XCD-contiguous eighths: essential here -- with the identity map the product takes 43 us instead of 29 us)
-  const int g = (blockIdx.x & 7) * grp_per_xcd + (blockIdx.x >> 3);
+  const int g = (bid & 7) * grp_per_xcd + (bid >> 3);
   constexpr int kPer = kRgcsTile / kBlock;
   const int tid = threadIdx.x;
   uint32_t pk[kPer];
@@ -377,8 +639,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       v[k] = M.vals[ii];
     }
   };
-  const bool is_prod = (int)blockIdx.x < 8 * grp_per_xcd && g < M.ng;
-  if constexpr (STEPIN) {
+  const bool is_prod = bid < 8 * grp_per_xcd && g < M.ng;
+  [[maybe_unused]] unsigned long long look = 0;
+  if constexpr (LEAD) {
+    if (bid >= 8 * grp_per_xcd) {  // a riding-update workgroup
+      if (ride_settle<true>(ra, fst, okf))
+        run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd + 2, red, reinterpret_cast<const LaneCtl*>(fst),
+                              reinterpret_cast<const LaneCtl*>(fst + 80));
+      return;
+    }
+    if (g >= M.ng) return;
+    if (PAD) fetch_stream(g * M.stride, 0, 0);
+  } else if constexpr (STEPIN) {
     __shared__ __attribute__((aligned(16))) unsigned long long stl[2 * 80];
     __shared__ double sred[32];
     // the first tile's stream is in flight while the riding steps are computed (padded layout: it needs no descriptor)
@@ -393,20 +665,23 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
   }
   if (g >= M.ng) return;
-  if (PAD && !STEPIN) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
+  if (PAD && !STEPIN && !LEAD) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
   const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
-  const LaneCtl* c[2] = {ctl0, ctl1};
   double ca[NL], cb[NL];
   bool act[NL];
-  bool any = false;
+  [[maybe_unused]] bool ride_ok = false;  // (wave 0's)
+  if constexpr (!LEAD) {
+    const LaneCtl* c[2] = {ctl0, ctl1};
+    bool any = false;
 #pragma unroll
-  for (int l = 0; l < NL; ++l) {
-    act[l] = !(c[l]->done | c[l]->skip);
-    ca[l] = c[l]->ca;
-    cb[l] = c[l]->cb;
-    any |= act[l];
+    for (int l = 0; l < NL; ++l) {
+      act[l] = !(c[l]->done | c[l]->skip);
+      ca[l] = c[l]->ca;
+      cb[l] = c[l]->cb;
+      any |= act[l];
+    }
+    if (!any) return;
   }
-  if (!any) return;
   const int r0 = gd.r0, R = gd.R, e0 = PAD ? g * M.stride : gd.e0, e1 = PAD ? g * M.stride + (gd.e1 - gd.e0) : gd.e1;
   const int cmin = gd.cmin;
   const uint16_t* tp = M.tptr + gd.tp;
@@ -434,6 +709,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   };
   if (PAD) fetch_segs(0);
   else fetch(e0, 0);
+  if constexpr (LEAD) {  // first look (wave 0): requested BEHIND the first tile's stream (device-scope loads return late, in order)
+    if (tid < 64) look = ride_look(ra);
+  }
   int tile = 0;
   for (int base = e0; base < e1; base += kRgcsTile, ++tile) {
     int sa[kRgcsMaxPass], sb[kRgcsMaxPass];
@@ -465,10 +743,33 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       }
     }
     if (base + kRgcsTile < e1) fetch(base + kRgcsTile, tile + 1);
+    if constexpr (LEAD) {
+      // the coefficients are only needed behind the last tile: look at what the previous request brought, ask again
+      if (tid < 64 && !ride_ok) {
+        ride_ok = ride_take(ra, look, crec);
+        if (!ride_ok) look = ride_look(ra);
+      }
+    }
     lds_barrier();
 #pragma unroll
     for (int p = 0; p < kRgcsMaxPass; ++p) row_segment_sum<NL>(prod, sa[p] + gl, sb[p], G, acc[p]);
     lds_barrier();
+  }
+  if constexpr (LEAD) {
+    if (tid < 64) {
+      if (!ride_ok) ride_ok = ride_take(ra, look, crec);
+      if (tid == 0) *okf = ride_ok ? 1 : 0;
+    }
+    lds_barrier();
+    if (!*okf && !ride_settle<false>(ra, crec, okf)) return;  // (workgroup-uniform, rare)
+    RideCoef RC;
+    ride_decode(crec, RC);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      ca[l] = RC.ca[l];
+      cb[l] = RC.cb[l];
+      act[l] = RC.act[l];
+    }
   }
   double sq[NL];
 #pragma unroll

@@ -963,6 +963,7 @@ def test_riding_scalar_steps_are_bitwise_the_stand_alone_steps(monkeypatch, delt
     speculative tail), hprod (two LSQR lanes), the seam solves, with the run-ahead in every regime (first call, repeated
     counts, counts that move)."""
     qp = _small_pde(seed=11, n=6000, m=600)
+    monkeypatch.setenv("FPSQ_RIDE_LEAD", "0")  # (reference: stand-alone k_step launches)
     monkeypatch.setenv("FPSQ_STEPIN_MAX", "0")
     ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
     monkeypatch.setenv("FPSQ_STEPIN_MAX", "640")
@@ -1026,6 +1027,46 @@ def test_column_sorted_at_blocks_are_bitwise_the_row_order_layout(monkeypatch, d
                 assert np.array_equal(a_, b_), (k, i)
     for mdl in (ref, dev, one, one_ref):
         mdl.close()
+
+
+@pytest.mark.parametrize("size", [(6000, 600), (300000, 30000)])
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_steps_riding_with_leaders_are_bitwise_the_stand_alone_steps(monkeypatch, delta, size):
+    """Large product grids hand the scalar steps to two LEADER workgroups at the head of the next product launch
+    (k_spmv_atl / k_spmv_rgcs<.., LEAD>: the step computed once, published behind a device-scope release, picked up by the
+    other workgroups on their way to the row epilogue; whoever finds nothing recomputes it).  Same step code on the same
+    inputs: every output and every statistic must be BITWISE those of a handle with FPSQ_RIDE_LEAD=0 (stand-alone k_step
+    launches) -- small grids (all workgroups resident at once, most of them ahead of the leaders) and a grid of several
+    resident sets, objgrad / hprod / the seam solves, first calls and armed run-ahead."""
+    n, m = size
+    qp = _small_pde(seed=11, n=n, m=m)
+    monkeypatch.setenv("FPSQ_STEPIN_MAX", "0")  # (small grids would otherwise take the all-recompute form)
+    monkeypatch.setenv("FPSQ_RIDE_LEAD", "0")
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    monkeypatch.setenv("FPSQ_RIDE_LEAD", "1")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    rng = np.random.default_rng(2)
+    A = qp.scipy_csr()
+    for k in range(6):
+        scale = 0.5 ** (k % 5) * (1.0 if k % 3 else 1e-2)
+        x = qp.xhat + scale * rng.standard_normal(qp.n)
+        v = scale * rng.standard_normal(qp.n)
+        want = None
+        for mdl in (ref, dev):
+            gx, ys, gs, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.n)
+            f, rc = mdl.objgrad(x, gx=gx, ys=ys, gs=gs)
+            st = [(mdl.stats[i].niter, mdl.stats[i].status, mdl.stats[i].solved, mdl.stats[i].rnorm, mdl.stats[i].arnorm) for i in range(2)]
+            rch = mdl.hprod(v, hv, 1 + k % 2)
+            sth = [(mdl.stats4[i].niter, mdl.stats4[i].status, mdl.stats4[i].rnorm) for i in range(2)]
+            o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+            rcm = mdl.solve_two_mixed(qp.qdiag * x + qp.d, A @ x - qp.b, *o)
+            out = [np.array([f, rc, rch, rcm]), gx, ys, gs, hv, *o, np.array(st, dtype=float).ravel(), np.array(sth, dtype=float).ravel()]
+            if mdl is ref:
+                want = out
+        for a_, b_ in zip(out, want):
+            assert np.array_equal(a_, b_), k
+    ref.close()
+    dev.close()
 
 
 def test_repeated_hprod_and_objgrad_calls_are_bitwise_identical():
