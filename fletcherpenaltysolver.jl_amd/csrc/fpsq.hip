@@ -400,6 +400,8 @@ struct fpsq_solver_s {
   unsigned long long ride_seq = 0;
   bool ride_lead = true;        // FPSQ_RIDE_LEAD=0: large grids keep the stand-alone k_step
   bool lead_now = false;        // run_krylov: the pending steps ride with leaders (not the all-recompute form)
+  int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
+  bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   int stepin_max = 0;           // all-recompute form of the riding steps when neither product has more workgroups than this
                                 // (FPSQ_STEPIN_MAX; 0 = never: the leader form is faster at every size measured)
   MinresState* minres;
@@ -981,11 +983,15 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     if constexpr (NL == 2) {
       if (lead) {  // (tag == TAG_AT: padded blocks with block-relative columns, see lead_supported())
         done_pre = true;
-        const dim3 lgrid(2 + M.nblk + nupd);
+        // the first resident set of workgroups takes two row blocks each (see k_spmv_atl)
+        const int R = h->resident_wgs - 2;
+        const int n2 = !h->atl_two || M.nblk <= R ? 0 : std::min(R, M.nblk - R);
+        const int nwg = M.nblk - n2;
+        const dim3 lgrid(2 + nwg + nupd);
         if (M.sorted)
-          launch_product(h, k_spmv_atl<true>, lgrid, M.view(), x, yin, yout, partials, M.nblk, u0, u1, ps, z0, z1, ra);
+          launch_product(h, k_spmv_atl<true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra);
         else
-          launch_product(h, k_spmv_atl<false>, lgrid, M.view(), x, yin, yout, partials, M.nblk, u0, u1, ps, z0, z1, ra);
+          launch_product(h, k_spmv_atl<false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra);
       } else if (pre) {  // (only the variants stepin_supported() admits)
         done_pre = true;
         if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(2, TAG_A, true, false, false, true);
@@ -2513,6 +2519,12 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_HOST_TRACE")) h->host_trace = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_AT_SORTED")) h->at_sorted = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->opt.device) == hipSuccess && prop.multiProcessorCount > 0)
+      h->resident_wgs = 4 * prop.multiProcessorCount;
+  }
   if (const char* ev = std::getenv("FPSQ_STEPIN_MAX")) h->stepin_max = std::min(std::atoi(ev), 4 * kStepThreads);  // (step2_issue's shape)
   if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_AB_DYNAMIC")) h->ab_dynamic = std::atoi(ev) != 0;

@@ -428,11 +428,17 @@ __device__ __forceinline__ bool ride_settle(const RideArgs& ra, unsigned long lo
 }
 
 // The A' product (two lanes, padded blocks with block-relative columns, one GPU) of a launch with riding leaders: k_spmv's
-// main path with the coefficients taken as described above.  grid = 2 leaders + nprod row blocks + the riding updates.
+// main path with the coefficients taken as described above.  grid = 2 leaders + nwg product workgroups + the riding updates.
+// TWO BLOCKS for the first workgroups: the first resident set starts together with the leaders and would reach its row
+// epilogue before the record is up (2.6 us of waiting per launch, measured against a build that does not wait).  Product
+// workgroup b < n2 therefore takes blocks b and n2 + b: row sums of the first block are HELD in registers, the second block
+// is streamed, and both epilogues run behind it -- by then the record has long arrived.  Workgroups b >= n2 (dispatched as
+// slots free up, ~10 us into the launch) take the single block n2 + b.  Same blocks, same per-block arithmetic: bitwise.
+constexpr int kAtlPass = kMaxRowsPerBlk / kBlock;  // row passes of a block (one lane per row at most kBlock rows per pass)
 template <bool CSORT>
 __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __restrict__ x, const double* yin, double* yout,
-                                                     double* partials, int nprod, const UpdSeg u0, const UpdSeg u1, int pstride,
-                                                     const StepArgs s0, const StepArgs s1, const RideArgs ra) {
+                                                     double* partials, int nwg, int n2, const UpdSeg u0, const UpdSeg u1,
+                                                     int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra) {
   constexpr int NL = 2;
   __shared__ double prod[kSpmvNnz * NL];
   __shared__ __attribute__((aligned(16))) unsigned long long fst[2 * 80];
@@ -445,97 +451,123 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
     ride_leader(blockIdx.x == 0 ? s0 : s1, (int)blockIdx.x, ra, fred, fst);
     return;
   }
-  const int L = (int)blockIdx.x - 2;
-  if (L >= nprod) {  // a riding-update workgroup (dispatched last: the record is up long before)
+  const int b = (int)blockIdx.x - 2;
+  if (b >= nwg) {  // a riding-update workgroup (dispatched last: the record is up long before)
     if (ride_settle<true>(ra, fst, &okf))
-      run_fused_updates<NL>(u0, u1, nprod + 2, red, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
+      run_fused_updates<NL>(u0, u1, nwg + 2, red, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
     return;
   }
-  if (L >= A.nblk) return;
-  const int4 bd = A.blkdesc[L];
-  const int cbase = A.colbase[L];
-  const int r0 = bd.x, nr = bd.y, s = bd.z;
-  int G = 1;
-  while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
-  const int rows_per_pass = kBlock / G;
-  const int g = tid / G, gl = tid % G;
-  const int rq0 = g < nr ? g : 0;
-  const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
-  double ypre[NL] = {0.0, 0.0};
-  if (yin != nullptr) {
-    const double2 t = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
-    ypre[0] = t.x;
-    ypre[1] = t.y;
-  }
-  constexpr int kPer = kSpmvNnz / kBlock;
-  int cidx[kPer];
-  [[maybe_unused]] int slot[kPer];
-  double v[kPer];
-  if constexpr (CSORT) {
-    csort_fetch(A, L, cbase, tid, cidx, slot, v);
-  } else {
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const size_t ii = (size_t)L * kSpmvNnz + tid + k * kBlock;
-      cidx[k] = cbase + (int)A.col16[ii];
-      v[k] = A.vals[ii];
-    }
-  }
-  // Wave 0 looks for the leaders' record: once behind the stream (examined behind the gathers), once more behind the
-  // gathers if that was too early (the first wave of workgroups).  Device-scope loads come back later than ordinary ones
-  // and the load counter is in-order, so each look is requested BEHIND the loads whose arrival the next step waits for.
-  unsigned long long look1 = 0;
-  if (tid < 64) look1 = ride_look(ra);
-  double2 xv[kPer];
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
-  bool ok = false;
-  unsigned long long look2 = 0;
-  if (tid < 64) {
-    ok = ride_take(ra, look1, crec);
-    if (!ok) look2 = ride_look(ra);
-  }
-#pragma unroll
-  for (int k = 0; k < kPer; ++k)
-    *reinterpret_cast<double2*>(prod + 2 * (CSORT ? slot[k] : tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
-  unsigned long long look3 = 0;
-  if (tid < 64 && !ok) {
-    ok = ride_take(ra, look2, crec);
-    if (!ok) look3 = ride_look(ra);  // third look: examined behind the row sums, right where the coefficients are first needed
-  }
-  lds_barrier();  // (publishes the products)
-  double sq[NL] = {0.0, 0.0};
-  RideCoef C;
-  for (int base = 0; base < nr; base += rows_per_pass) {
-    const int rr = base + g;
-    const bool valid = rr < nr;
-    double acc[NL] = {0.0, 0.0};
-    if (valid) {
-      const int a = (base == 0 ? seg_a0 : A.rowptr[r0 + rr]) - s, b = (base == 0 ? seg_b0 : A.rowptr[r0 + rr + 1]) - s;
-      row_segment_sum<NL>(prod, a + gl, b, G, acc);
-    }
-    for (int off = G >> 1; off > 0; off >>= 1) {
-#pragma unroll
-      for (int l = 0; l < NL; ++l) acc[l] += __shfl_down(acc[l], off, 64);
-    }
-    if (base == 0) {  // the coefficients: first needed here (every thread passes this point)
-      if (tid < 64) {
-        if (!ok) ok = ride_take(ra, look3, crec);
-        if (tid == 0) okf = ok ? 1 : 0;
+  const int nt = b < n2 ? 2 : 1;
+  const int Lt[2] = {b < n2 ? b : n2 + b, n2 + b};
+  if (Lt[0] >= A.nblk) return;
+  // Wave 0 looks for the leaders' record at every point where a wait is free anyway: behind the stream (examined behind
+  // the gathers), behind the gathers, behind the products, behind the row sums.  Device-scope loads come back later than
+  // ordinary ones and the load counter is in-order, so each look is requested BEHIND the loads whose arrival the next
+  // step waits for.  peek(): examine the look in flight, request another one if it was too early.
+  bool ok = false, flying = false;
+  unsigned long long lk = 0;
+  auto peek = [&]() {
+    if (tid < 64 && !ok) {
+      if (flying) ok = ride_take(ra, lk, crec);
+      if (!ok) {
+        lk = ride_look(ra);
+        flying = true;
       }
-      lds_barrier();  // (publishes the record words and the verdict)
-      if (!okf && !ride_settle<false>(ra, crec, &okf)) return;  // (workgroup-uniform; the first wave of workgroups at most)
-      ride_decode(crec, C);
     }
-    if (valid && gl == 0)
-      row_epilogue<NL>((size_t)(r0 + rr), acc, C.ca, C.cb, C.act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
-  }
-  if (partials != nullptr) {
-    lds_barrier();  // `red` aliases `prod`: every wave must be past its phase-2 reads
-    block_sum_lanes<NL>(sq, red);
-    if (tid == 0) {
+  };
+  // what a block leaves behind for its epilogue
+  int hr0[2], hnr[2], hG[2];
+  double hacc[2][kAtlPass][NL], hypre[2][NL];
+  constexpr int kPer = kSpmvNnz / kBlock;
 #pragma unroll
-      for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + L] = sq[l];
+  for (int t = 0; t < 2; ++t) {
+    if (t >= nt) break;
+    const int L = Lt[t];
+    const int4 bd = A.blkdesc[L];
+    const int cbase = A.colbase[L];
+    const int r0 = bd.x, nr = bd.y, s = bd.z;
+    int G = 1;
+    while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
+    const int rows_per_pass = kBlock / G;
+    const int g = tid / G, gl = tid % G;
+    const int rq0 = g < nr ? g : 0;
+    const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
+    hypre[t][0] = hypre[t][1] = 0.0;
+    if (yin != nullptr) {
+      const double2 yy = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
+      hypre[t][0] = yy.x;
+      hypre[t][1] = yy.y;
+    }
+    int cidx[kPer];
+    [[maybe_unused]] int slot[kPer];
+    double v[kPer];
+    if constexpr (CSORT) {
+      csort_fetch(A, L, cbase, tid, cidx, slot, v);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const size_t ii = (size_t)L * kSpmvNnz + tid + k * kBlock;
+        cidx[k] = cbase + (int)A.col16[ii];
+        v[k] = A.vals[ii];
+      }
+    }
+    if (t == 0) peek();  // (requests the first look)
+    double2 xv[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+    peek();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      *reinterpret_cast<double2*>(prod + 2 * (CSORT ? slot[k] : tid + k * kBlock)) = make_double2(v[k] * xv[k].x, v[k] * xv[k].y);
+    peek();
+    lds_barrier();  // (publishes the products)
+    hr0[t] = r0;
+    hnr[t] = nr;
+    hG[t] = G;
+#pragma unroll
+    for (int p = 0; p < kAtlPass; ++p) {
+      const int rr = p * rows_per_pass + g;
+      hacc[t][p][0] = hacc[t][p][1] = 0.0;
+      if (p * rows_per_pass < nr) {  // (workgroup-uniform)
+        if (rr < nr) {
+          const int a = (p == 0 ? seg_a0 : A.rowptr[r0 + rr]) - s, e = (p == 0 ? seg_b0 : A.rowptr[r0 + rr + 1]) - s;
+          row_segment_sum<NL>(prod, a + gl, e, G, hacc[t][p]);
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) {
+#pragma unroll
+          for (int l = 0; l < NL; ++l) hacc[t][p][l] += __shfl_down(hacc[t][p][l], off, 64);
+        }
+      }
+    }
+    if (t + 1 < nt) lds_barrier();  // every wave is past its row sums: the next block's products may overwrite `prod`
+  }
+  // the coefficients: first needed here (every thread passes this point)
+  if (tid < 64) {
+    if (!ok && flying) ok = ride_take(ra, lk, crec);
+    if (tid == 0) okf = ok ? 1 : 0;
+  }
+  lds_barrier();  // (publishes the record words and the verdict; `red` aliases `prod`: every wave is past its row sums)
+  if (!okf && !ride_settle<false>(ra, crec, &okf)) return;  // (workgroup-uniform; single-block workgroups of a small grid at most)
+  RideCoef C;
+  ride_decode(crec, C);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t >= nt) break;
+    const int G = hG[t], rows_per_pass = kBlock / G, g = tid / G, gl = tid % G;
+    double sq[NL] = {0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < kAtlPass; ++p) {
+      const int rr = p * rows_per_pass + g;
+      if (rr < hnr[t] && gl == 0)
+        row_epilogue<NL>((size_t)(hr0[t] + rr), hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
+    }
+    if (partials != nullptr) {
+      if (t) lds_barrier();  // (thread 0 has read `red` for the previous block)
+      block_sum_lanes<NL>(sq, red);
+      if (tid == 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + Lt[t]] = sq[l];
+      }
     }
   }
 }
