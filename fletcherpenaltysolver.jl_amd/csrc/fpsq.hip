@@ -988,10 +988,14 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
         const int n2 = !h->atl_two || M.nblk <= R ? 0 : std::min(R, M.nblk - R);
         const int nwg = M.nblk - n2;
         const dim3 lgrid(2 + nwg + nupd);
-        if (M.sorted)
-          launch_product(h, k_spmv_atl<true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra);
+        if (M.sorted && halo_rows)
+          launch_product(h, k_spmv_atl<true, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
+        else if (M.sorted)
+          launch_product(h, k_spmv_atl<true, false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
+        else if (halo_rows)
+          launch_product(h, k_spmv_atl<false, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
         else
-          launch_product(h, k_spmv_atl<false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra);
+          launch_product(h, k_spmv_atl<false, false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
       } else if (pre) {  // (only the variants stepin_supported() admits)
         done_pre = true;
         if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(2, TAG_A, true, false, false, true);
@@ -1090,8 +1094,11 @@ int at_product(fpsq_handle h, const double* x, double* y, const LaneCtl* c0, con
   if (h->halo) {
     // every row the rank alone contributes to is finished by the product kernel exactly as on one GPU (so the vector
     // updates may ride in the launch); only the overlap rows wait for the neighbours
-    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials, u0, u1, /*halo_rows=*/true);
-    if (int rc = halo_finish<NL>(h, y, y, c0, c1, partials)) return rc;
+    launch_spmv<NL>(h, TAG_AT, x, y, y, c0, c1, partials, u0, u1, /*halo_rows=*/true, pre);
+    // (steps riding in that launch: the control blocks k_halo_finish must read are the ones the leaders have just written)
+    const LaneCtl* f0 = pre ? reinterpret_cast<const LaneCtl*>(pre[0].state_out) : c0;
+    const LaneCtl* f1 = pre ? reinterpret_cast<const LaneCtl*>(pre[NL - 1].state_out) : c1;
+    if (int rc = halo_finish<NL>(h, y, y, f0, f1, partials)) return rc;
     *np = h->AT.nblk + h->halo_gf;
     return 0;
   }
@@ -1383,7 +1390,10 @@ int seg_count(fpsq_handle h, const double* p) {
   return 0;
 }
 
-int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, int sharded1 = -1) {
+// Everything a step needs BEFORE its kernel: row-sharded runs gather (halo mode) or pre-sum + all-reduce the partial sums
+// its arguments point to, and the arguments are redirected to the gathered / reduced numbers.  A step that rides in the next
+// product launch is prepared when it is handed over (the collective must precede that launch in the stream).
+int prepare_step(fpsq_handle h, StepArgs& a0, StepArgs& a1, bool sharded = false, int sharded1 = -1) {
   const bool sh[2] = {sharded, sharded1 < 0 ? sharded : sharded1 != 0};  // per step: its partials are per-rank sums
   if (h->comm && h->halo && (sh[0] || sh[1])) {
     // Halo mode: ONE all-gather of the contiguous segment range holding the arrays these steps read; the step kernel then
@@ -1421,7 +1431,6 @@ int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, i
       w[k]->nseg = h->comm->nranks;
       w[k]->seg_stride = (int32_t)len;
     }
-    launch_step_raw(h, a0, a1);
     return 0;
   }
   if (h->comm && (sh[0] || sh[1])) {
@@ -1448,6 +1457,11 @@ int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, i
       }
     }
   }
+  return 0;
+}
+
+int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, int sharded1 = -1) {
+  if (int rc = prepare_step(h, a0, a1, sharded, sharded1)) return rc;
   launch_step_raw(h, a0, a1);
   return 0;
 }
@@ -1565,7 +1579,8 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   for (int l = 0; l < NL; ++l) stepin = stepin && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
   // Larger grids: the pending steps ride with two LEADER workgroups of the next product launch (k_spmv_atl,
   // k_spmv_rgcs<.., LEAD>): computed once, picked up by the others on their way to the row epilogue.
-  bool lead = NL == 2 && !h->comm && h->ride_lead && !stepin && h->AT.padded && (h->AT.sorted || h->AT.col16) && h->RA.ok;
+  bool lead = NL == 2 && (!h->comm || h->halo) && h->ride_lead && !stepin && h->AT.padded && (h->AT.sorted || h->AT.col16) &&
+              h->RA.ok;
   for (int l = 0; l < NL; ++l) lead = lead && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
   h->lead_now = lead;
   stepin = stepin || lead;  // (the same hand-over on the host side)
@@ -1579,6 +1594,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   auto flush_pend = [&](bool sharded) -> int {
     if (!have_pend) return 0;
     have_pend = false;
+    if (h->comm) {  // (prepared -- gathered -- when they were handed over)
+      launch_step_raw(h, pend[0], pend[1]);
+      return 0;
+    }
     return launch_step(h, pend[0], pend[1], sharded);
   };
   // after a product launch that carried the pending steps: the lanes live in their other state copies now
@@ -1596,6 +1615,8 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (stepin && a0.kind != STEP_NONE && a1.kind != STEP_NONE) {
       pend[0] = a0;
       pend[1] = a1;
+      if (h->comm)
+        if (int rc = prepare_step(h, pend[0], pend[1], sharded)) return rc;
       have_pend = true;
       return 0;
     }
@@ -1895,6 +1916,8 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       const bool sh1 = lanes[NL - 1].kind == LANE_MINRES ? true : h->halo;
       if (!h->comm) {
         if (int rc = post_step(sa[0], NL == 2 ? sa[1] : none, false)) return rc;
+      } else if (lead && sh0 && sh1) {  // (halo mode, LSQR / CRAIG lanes: both steps sum gathered n-sums)
+        if (int rc = post_step(sa[0], sa[1], true)) return rc;
       } else if (NL == 2 && split_steps && sh0 != sh1) {
         if (int rc = launch_step(h, sa[0], none, sh0)) return rc;
         if (int rc = launch_step(h, sa[1], none, sh1)) return rc;
@@ -1958,7 +1981,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
                           lanes[l], (int)it, h->pS2 + (size_t)l * h->strA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : h->pW[l],
                           gm, prog[l]);
     }
-    if (!h->comm) {
+    if (!h->comm || lead) {
       if (int rc = post_step(sb[0], NL == 2 ? sb[1] : none, true)) return rc;
     } else {
       if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
@@ -1978,6 +2001,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       bool boundary = it == itmax_all;
       if (expect > 0) {
         if (it == expect) {
+          if (int rc = flush_pend(true)) return rc;  // (the gated kernels must see this iteration's verdict)
           if (int rc = enqueue_speculative()) return rc;
           boundary = true;
         } else if (it > expect && (it - expect) % look == 0) {
@@ -1987,6 +2011,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         boundary = true;
       }
       if (boundary) {
+        if (int rc = flush_pend(true)) return rc;  // (so must the host; the same launches on every rank)
         HIPCHK(h, hipStreamSynchronize(s));
         if (all_done()) break;
       }

@@ -435,10 +435,12 @@ __device__ __forceinline__ bool ride_settle(const RideArgs& ra, unsigned long lo
 // is streamed, and both epilogues run behind it -- by then the record has long arrived.  Workgroups b >= n2 (dispatched as
 // slots free up, ~10 us into the launch) take the single block n2 + b.  Same blocks, same per-block arithmetic: bitwise.
 constexpr int kAtlPass = kMaxRowsPerBlk / kBlock;  // row passes of a block (one lane per row at most kBlock rows per pass)
-template <bool CSORT>
+// HALO: the row-sharded form (see k_spmv<.., HALO>): overlap rows only deposit their raw sums, k_halo_finish completes them.
+template <bool CSORT, bool HALO = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __restrict__ x, const double* yin, double* yout,
                                                      double* partials, int nwg, int n2, const UpdSeg u0, const UpdSeg u1,
-                                                     int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra) {
+                                                     int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra,
+                                                     const HaloRows hr) {
   constexpr int NL = 2;
   __shared__ double prod[kSpmvNnz * NL];
   __shared__ __attribute__((aligned(16))) unsigned long long fst[2 * 80];
@@ -558,8 +560,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
 #pragma unroll
     for (int p = 0; p < kAtlPass; ++p) {
       const int rr = p * rows_per_pass + g;
-      if (rr < hnr[t] && gl == 0)
-        row_epilogue<NL>((size_t)(hr0[t] + rr), hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
+      if (rr < hnr[t] && gl == 0) {
+        const int64_t row = hr0[t] + rr;
+        if (HALO && (row < hr.lo || row >= hr.hi)) {
+          double* dst = hr.raw + (size_t)(row < hr.lo ? row : hr.lo + (row - hr.hi)) * NL;
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+            if (C.act[l]) dst[l] = hacc[t][p][l];
+        } else {
+          row_epilogue<NL>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
+        }
+      }
     }
     if (partials != nullptr) {
       if (t) lds_barrier();  // (thread 0 has read `red` for the previous block)
