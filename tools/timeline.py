@@ -12,6 +12,10 @@ import numpy as np
 
 
 def short(name):
+    if "k_spmv_atl" in name:
+        return "k_spmv_atl"
+    if "k_spmv_rgcs" in name and name.split("(")[0].rstrip(">").endswith("true"):
+        return "k_spmv_rgcs(lead)"
     for k in ("k_spmv_rgcs", "k_spmv", "k_step", "k_qp_grad", "k_qp_penalty_grad", "k_startup", "k_ys", "k_updates",
               "k_minres_ew", "k_qp_hsv", "k_qp_hprod_fin", "k_gather", "k_persist", "k_axpby", "k_presum", "k_qp_fx",
               "k_halo_finish", "k_p2p_gather", "k_p2p_halo"):
