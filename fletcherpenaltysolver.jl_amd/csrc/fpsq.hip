@@ -399,6 +399,7 @@ struct fpsq_solver_s {
   unsigned long long* ride_flags = nullptr;
   unsigned long long ride_seq = 0;
   bool ride_lead = true;        // FPSQ_RIDE_LEAD=0: large grids keep the stand-alone k_step
+  bool ride_break = false;      // FPSQ_DEBUG_RIDE_BREAK=1 (tests): the leaders publish a wrong launch number, every wait expires
   bool lead_now = false;        // run_krylov: the pending steps ride with leaders (not the all-recompute form)
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
@@ -953,6 +954,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
   if (lead) {  // (run_krylov only sets lead_now where both products have the leader variants: lead_supported())
     ra.rec = h->ride_flags;
     ra.want = (unsigned int)++h->ride_seq;
+    ra.pub = h->ride_break ? ~ra.want : ra.want;
     ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
   }
   if (tag == TAG_A && h->RA.ok) {
@@ -2545,6 +2547,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_AT_SORTED")) h->at_sorted = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->opt.device) == hipSuccess && prop.multiProcessorCount > 0)

@@ -318,6 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 struct RideArgs {
   unsigned long long* rec;  // the leaders' record: 16 + 48 self-validating words (four 128-byte lines), see ride_publish
   unsigned int want;        // this launch's number
+  unsigned int pub;         // what the leaders publish: `want` (anything else only in the test of the bounded wait)
   unsigned long long* err;  // host-mapped: set when a bounded wait for the record expired (the call then fails)
 };
 struct RideCoef {
@@ -359,7 +360,7 @@ __device__ __forceinline__ void ride_decode(const unsigned long long* w /* 10 wo
 // blockIdx 0 / 1 of a launch with riding leaders: lane 0 / 1.  k_step's body (step_run) with line 0 of the record published
 // from the advanced state in LDS BEFORE the state is committed: that is all the product workgroups wait for.
 __device__ __forceinline__ void ride_leader(const StepArgs& a, int l, const RideArgs& ra, double* red32, unsigned long long* st80) {
-  auto early = [&]() { ride_publish(reinterpret_cast<const LaneCtl*>(st80), l, ra.rec, ra.want); };
+  auto early = [&]() { ride_publish(reinterpret_cast<const LaneCtl*>(st80), l, ra.rec, ra.pub); };
   if (a.kind != STEP_NONE) {
     step_run(a, red32, st80, true, &early);
   } else {
@@ -369,8 +370,8 @@ __device__ __forceinline__ void ride_leader(const StepArgs& a, int l, const Ride
   }
   if (threadIdx.x < 12) {  // (step_run's closing barrier: st80 is final for every thread)
     const unsigned long long w = st80[threadIdx.x];
-    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x, (w & 0xffffffff00000000ull) | ra.want);
-    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x + 1, (w << 32) | ra.want);
+    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x, (w & 0xffffffff00000000ull) | ra.pub);
+    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x + 1, (w << 32) | ra.pub);
   }
 }
 

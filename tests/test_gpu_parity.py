@@ -1069,6 +1069,29 @@ def test_steps_riding_with_leaders_are_bitwise_the_stand_alone_steps(monkeypatch
     dev.close()
 
 
+def test_riding_leaders_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
+    """Every wait of the leader protocol has an end each wave reaches: with the leaders made to publish a wrong launch number
+    (FPSQ_DEBUG_RIDE_BREAK=1) the workgroups of the product give up after their bounded number of looks, raise the handle's
+    error word and leave; the call returns FPSQ_ERR_TIMEOUT (-5) with a message, within seconds.  A fresh handle without
+    the switch works as ever."""
+    import time
+    qp = _small_pde(seed=5, n=4000, m=400)
+    monkeypatch.setenv("FPSQ_DEBUG_RIDE_BREAK", "1")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, ls_itmax=3, ln_itmax=3)
+    gx = np.empty(qp.n)
+    t0 = time.perf_counter()
+    with pytest.raises(Exception) as ei:
+        dev.objgrad(qp.x, gx=gx)
+    assert time.perf_counter() - t0 < 30.0
+    assert "bounded wait" in str(ei.value)
+    dev.close()
+    monkeypatch.setenv("FPSQ_DEBUG_RIDE_BREAK", "0")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+    f, rc = dev.objgrad(qp.x, gx=gx)
+    assert rc == 0 and np.all(np.isfinite(gx))
+    dev.close()
+
+
 def test_repeated_hprod_and_objgrad_calls_are_bitwise_identical():
     """The same call repeated on fresh and on warm handles gives the same bits every time (all reductions run in fixed
     orders; no atomics).  Regression test of the round-2 / round-3 race: the progress word used to be two stores, and a host
