@@ -527,8 +527,8 @@ def main():
         achieved = nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "fpsq::k_spmv_rgcs (A) + fpsq::k_spmv (A'): SpMV/SpMM with fused axpby + norm partials + "
-                              "riding vector updates",
+                    "kernel": "fpsq::k_spmv_rgcs (A) + fpsq::k_spmv_atl / k_spmv (A'): SpMV/SpMM with fused axpby + norm "
+                              "partials + riding vector updates + the previous product's scalar steps (leader workgroups)",
                     "productive_launches_per_eval": productive / K, "launches_per_eval": launches / K,
                     "avg_launch_us": round(1e3 * t_ms / max(launches, 1), 2),
                     "avg_productive_launch_us": round(1e3 * t_ms / max(productive, 1), 2),
