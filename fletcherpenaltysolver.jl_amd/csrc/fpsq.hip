@@ -955,12 +955,14 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     ra.rec = h->ride_flags;
     ra.want = (unsigned int)++h->ride_seq;
     ra.pub = h->ride_break ? ~ra.want : ra.want;
+    ra.tickets = h->ride_flags + 96;  // (behind the record's 64 words; a line of its own)
+    ra.ticket0 = (unsigned long long)kRideCand * (h->ride_seq - 1);
     ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
   }
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
 #define FPSQ_LAUNCH_RGCS(...) \
-    launch_product(h, k_spmv_rgcs<__VA_ARGS__>, dim3(per_xcd * 8 + nupd + (lead ? 2 : 0)), h->RA.view, x, yin, yout, c0, c1, partials, \
+    launch_product(h, k_spmv_rgcs<__VA_ARGS__>, dim3(per_xcd * 8 + nupd + (lead ? kRideCand : 0)), h->RA.view, x, yin, yout, c0, c1, partials, \
                    per_xcd, u0, u1, h->gate0, h->gate1, h->strA, z0, z1, ra)
     if constexpr (NL == 2) {
       if (lead && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, false, true);
@@ -986,10 +988,10 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
       if (lead) {  // (tag == TAG_AT: padded blocks with block-relative columns, see lead_supported())
         done_pre = true;
         // the first resident set of workgroups takes two row blocks each (see k_spmv_atl)
-        const int R = h->resident_wgs - 2;
+        const int R = h->resident_wgs - 2;  // (two of the candidates lead)
         const int n2 = !h->atl_two || M.nblk <= R ? 0 : std::min(R, M.nblk - R);
         const int nwg = M.nblk - n2;
-        const dim3 lgrid(2 + nwg + nupd);
+        const dim3 lgrid(kRideCand + nwg + nupd);
         if (M.sorted && halo_rows)
           launch_product(h, k_spmv_atl<true, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
         else if (M.sorted)
@@ -2572,9 +2574,9 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipMemset(p, 0, state_bytes);
   {
     void* q = nullptr;
-    if ((e = hipMalloc(&q, 512)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&q, 1024)) != hipSuccess) return fail("hipMalloc", e);
     h->allocs.push_back(q);
-    hipMemset(q, 0, 512);
+    hipMemset(q, 0, 1024);
     h->ride_flags = (unsigned long long*)q;
   }
   char* cp = (char*)p;

@@ -319,6 +319,8 @@ struct RideArgs {
   unsigned long long* rec;  // the leaders' record: 16 + 48 self-validating words (four 128-byte lines), see ride_publish
   unsigned int want;        // this launch's number
   unsigned int pub;         // what the leaders publish: `want` (anything else only in the test of the bounded wait)
+  unsigned long long* tickets;  // leader election: a counter that only grows ...
+  unsigned long long ticket0;   // ... and its value before this launch's kRideCand candidates draw theirs
   unsigned long long* err;  // host-mapped: set when a bounded wait for the record expired (the call then fails)
 };
 struct RideCoef {
@@ -357,7 +359,17 @@ __device__ __forceinline__ void ride_decode(const unsigned long long* w /* 10 wo
   }
 }
 
-// blockIdx 0 / 1 of a launch with riding leaders: lane 0 / 1.  k_step's body (step_run) with line 0 of the record published
+// WHO LEADS.  The first kRideCand workgroups of the grid are candidates and nothing else; each draws a ticket when it starts,
+// tickets 0 and 1 lead lanes 0 and 1, the others leave at once.  Why not simply blockIdx 0 and 1: workgroup i is dispatched
+// by XCD i mod 8, in order WITHIN that XCD -- when another kernel (another stream, another process sharing the GPU) has an
+// XCD full of workgroups that are themselves waiting for their leaders, a fixed leader assigned to that XCD never starts
+// while this kernel's workgroups on the other XCDs wait for it: a circular wait across kernels (seen as expired bounded
+// waits with three processes on one GPU).  With two candidates per XCD, any running workgroup of this launch has its own
+// XCD's two candidates dispatched ahead of it, so two RUNNING workgroups hold tickets 0 and 1 whatever else fills the device.
+constexpr int kRideCand = 16;
+__device__ __forceinline__ int ride_ticket(const struct RideArgs& ra, int* lds_slot);
+
+// A candidate that drew ticket 0 / 1: lane 0 / 1.  k_step's body (step_run) with line 0 of the record published
 // from the advanced state in LDS BEFORE the state is committed: that is all the product workgroups wait for.
 __device__ __forceinline__ void ride_leader(const StepArgs& a, int l, const RideArgs& ra, double* red32, unsigned long long* st80) {
   auto early = [&]() { ride_publish(reinterpret_cast<const LaneCtl*>(st80), l, ra.rec, ra.pub); };
@@ -373,6 +385,13 @@ __device__ __forceinline__ void ride_leader(const StepArgs& a, int l, const Ride
     ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x, (w & 0xffffffff00000000ull) | ra.pub);
     ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x + 1, (w << 32) | ra.pub);
   }
+}
+
+__device__ __forceinline__ int ride_ticket(const RideArgs& ra, int* lds_slot) {
+  if (threadIdx.x == 0)
+    *lds_slot = (int)(__hip_atomic_fetch_add(ra.tickets, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.ticket0);
+  __syncthreads();
+  return *lds_slot;
 }
 
 // One look of a PRODUCT workgroup, by the calling wave (one wave per workgroup looks): lanes 0..9 each request one word ...
@@ -450,14 +469,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
   __shared__ int okf;
   double* red = prod;
   const int tid = threadIdx.x;
-  if (blockIdx.x < 2) {
-    ride_leader(blockIdx.x == 0 ? s0 : s1, (int)blockIdx.x, ra, fred, fst);
+  if (blockIdx.x < kRideCand) {
+    const int t = ride_ticket(ra, &okf);
+    if (t < 2) ride_leader(t == 0 ? s0 : s1, t, ra, fred, fst);
     return;
   }
-  const int b = (int)blockIdx.x - 2;
+  const int b = (int)blockIdx.x - kRideCand;
   if (b >= nwg) {  // a riding-update workgroup (dispatched last: the record is up long before)
     if (ride_settle<true>(ra, fst, &okf))
-      run_fused_updates<NL>(u0, u1, nwg + 2, red, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
+      run_fused_updates<NL>(u0, u1, nwg + kRideCand, red, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
     return;
   }
   const int nt = b < n2 ? 2 : 1;
@@ -657,12 +677,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     fred = fred_;
     crec = crec_;
     okf = &okf_;
-    if (blockIdx.x < 2) {
-      ride_leader(blockIdx.x == 0 ? s0 : s1, (int)blockIdx.x, ra, fred, fst);
+    if (blockIdx.x < kRideCand) {
+      const int t = ride_ticket(ra, okf);
+      if (t < 2) ride_leader(t == 0 ? s0 : s1, t, ra, fred, fst);
       return;
     }
   }
-  const int bid = LEAD ? (int)blockIdx.x - 2 : (int)blockIdx.x;
+  const int bid = LEAD ? (int)blockIdx.x - kRideCand : (int)blockIdx.x;
   if constexpr (STEPIN) {  // (see k_spmv)
     static_assert(NL == 2, "riding steps: two lanes");
     if ((int)blockIdx.x >= 8 * grp_per_xcd + u0.nblk + u1.nblk) return;
@@ -688,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   if constexpr (LEAD) {
     if (bid >= 8 * grp_per_xcd) {  // a riding-update workgroup
       if (ride_settle<true>(ra, fst, okf))
-        run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd + 2, red, reinterpret_cast<const LaneCtl*>(fst),
+        run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd + kRideCand, red, reinterpret_cast<const LaneCtl*>(fst),
                               reinterpret_cast<const LaneCtl*>(fst + 80));
       return;
     }
