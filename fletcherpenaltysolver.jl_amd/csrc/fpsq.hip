@@ -955,8 +955,6 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     ra.rec = h->ride_flags;
     ra.want = (unsigned int)++h->ride_seq;
     ra.pub = h->ride_break ? ~ra.want : ra.want;
-    ra.tickets = h->ride_flags + 96;  // (behind the record's 64 words; a line of its own)
-    ra.ticket0 = (unsigned long long)kRideCand * (h->ride_seq - 1);
     ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
   }
   if (tag == TAG_A && h->RA.ok) {
@@ -988,7 +986,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
       if (lead) {  // (tag == TAG_AT: padded blocks with block-relative columns, see lead_supported())
         done_pre = true;
         // the first resident set of workgroups takes two row blocks each (see k_spmv_atl)
-        const int R = h->resident_wgs - 2;  // (two of the candidates lead)
+        const int R = h->resident_wgs - kRideCand;
         const int n2 = !h->atl_two || M.nblk <= R ? 0 : std::min(R, M.nblk - R);
         const int nwg = M.nblk - n2;
         const dim3 lgrid(kRideCand + nwg + nupd);
@@ -2574,9 +2572,9 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipMemset(p, 0, state_bytes);
   {
     void* q = nullptr;
-    if ((e = hipMalloc(&q, 1024)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc(&q, 8 * 512)) != hipSuccess) return fail("hipMalloc", e);  // (a record copy of 64 words per XCC)
     h->allocs.push_back(q);
-    hipMemset(q, 0, 1024);
+    hipMemset(q, 0, 8 * 512);
     h->ride_flags = (unsigned long long*)q;
   }
   char* cp = (char*)p;

@@ -940,11 +940,15 @@ __device__ __forceinline__ int state_bytes(int kind) {
 // Without commit the workgroup only wants the result: the riding form of a step (product kernels with STEPIN), where every
 // workgroup of the NEXT product launch recomputes the step of the previous one in its prologue -- same inputs, same
 // instructions, same bits -- instead of waiting for a one-workgroup launch in between.
-// early (optional): called by thread 0 as soon as the advanced state stands in `st`, before anything is written to global
-// memory (the riding leaders publish the next product's coefficients there).
-template <class Early = void (*)()>
+// hook (optional; the riding leaders, several of which compute a lane's step): hook->advanced() is called by thread 0 as soon
+// as the advanced state stands in `st`, before anything is written to global memory (the leaders publish the next product's
+// coefficients there).
+struct NoStepHook {
+  __device__ void advanced() const {}
+};
+template <class Hook = NoStepHook>
 __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */, unsigned long long* st /* 80 */, bool commit,
-                                         const Early* early = nullptr) {
+                                         const Hook* hook = nullptr) {
   // The recurrence state (<= 0.5 KB) is staged in LDS with one coalesced read issued together with the partial-sum
   // loads, advanced there by thread 0, and written back with one coalesced store: the ~40 dependent scalar accesses of
   // a step then cost LDS latency instead of a global round trip each.
@@ -960,7 +964,7 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
   } else {
     __syncthreads();
   }
-  if (threadIdx.x == 0 && skip && early) (*early)();  // (a finished lane: its state stands as it is)
+  if (threadIdx.x == 0 && hook && skip) hook->advanced();  // (a finished lane: its state stands as it is)
   if (threadIdx.x == 0 && !skip) {
     void* S = st;
     Progress* prog = commit ? a.prog : nullptr;
@@ -981,7 +985,7 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
       case STEP_LNLQ_SB: lnlq_sb_step((LnlqState*)S, s0); break;
       default: break;
     }
-    if (early) (*early)();
+    if (hook) hook->advanced();
     if (commit && a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
       const fpsq_stats* fin = a.kind >= STEP_LNLQ_BEGIN ? &((LnlqState*)S)->stats
                               : a.kind >= STEP_MINRES_BEGIN ? &((MinresState*)S)->stats

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 //
 // LARGE product grids (thousands of workgroups: every workgroup recomputing the pending scalar steps, STEPIN above, would
 // read the partial sums thousands of times over): the two steps that follow the previous product are computed ONCE, by two
-// LEADER workgroups at the head of this launch's grid (blockIdx 0 / 1 = lane 0 / 1: exactly k_step's body), which then
+// LEADER workgroups at the head of this launch's grid (elected among its first kRideCand workgroups, see "WHO LEADS": exactly
 // publish a launch sequence number behind a device-scope release.  A product only needs the steps' coefficients in its
 // row epilogue -- out = ca (A x) + cb yin is linear in them -- so every other workgroup starts streaming at once and picks
 // them up on the way: it requests the two flag words TOGETHER WITH its matrix stream (nothing waits on them), looks at
@@ -316,11 +316,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 // The one-workgroup k_step launch between two products (~5 us in the running pipeline, 32 per evaluation at the headline
 // size) disappears; results are bitwise those of the stand-alone steps.
 struct RideArgs {
-  unsigned long long* rec;  // the leaders' record: 16 + 48 self-validating words (four 128-byte lines), see ride_publish
+  unsigned long long* rec;  // the leaders' record, one copy per XCC: 16 + 48 self-validating words (four lines), see ride_publish
   unsigned int want;        // this launch's number
   unsigned int pub;         // what the leaders publish: `want` (anything else only in the test of the bounded wait)
-  unsigned long long* tickets;  // leader election: a counter that only grows ...
-  unsigned long long ticket0;   // ... and its value before this launch's kRideCand candidates draw theirs
   unsigned long long* err;  // host-mapped: set when a bounded wait for the record expired (the call then fails)
 };
 struct RideCoef {
@@ -359,45 +357,52 @@ __device__ __forceinline__ void ride_decode(const unsigned long long* w /* 10 wo
   }
 }
 
-// WHO LEADS.  The first kRideCand workgroups of the grid are candidates and nothing else; each draws a ticket when it starts,
-// tickets 0 and 1 lead lanes 0 and 1, the others leave at once.  Why not simply blockIdx 0 and 1: workgroup i is dispatched
-// by XCD i mod 8, in order WITHIN that XCD -- when another kernel (another stream, another process sharing the GPU) has an
-// XCD full of workgroups that are themselves waiting for their leaders, a fixed leader assigned to that XCD never starts
-// while this kernel's workgroups on the other XCDs wait for it: a circular wait across kernels (seen as expired bounded
-// waits with three processes on one GPU).  With two candidates per XCD, any running workgroup of this launch has its own
-// XCD's two candidates dispatched ahead of it, so two RUNNING workgroups hold tickets 0 and 1 whatever else fills the device.
+// WHO LEADS.  The first kRideCand = 16 workgroups of the grid are leaders and nothing else: leader c computes the step of lane
+// (c >> 3) & 1 -- eight per lane, redundantly (same inputs, same instructions, same bits) -- and publishes it in the record
+// copy OF THE XCC IT RUNS ON (hardware register XCC_ID); a waiting workgroup looks at its own XCC's copy.  One writer per
+// copy and lane, no election, no atomics.  The state is committed by leaders 0 and 8 alone (nobody inside the launch waits
+// for that: the next launch reads it).  Why not just two leaders: workgroup i is dispatched by XCD i mod 8, in order WITHIN
+// that XCD.  When another kernel (another stream, another process sharing the GPU) has an XCD full of workgroups that are
+// themselves waiting for their leaders, a leader assigned to that XCD never starts while this kernel's workgroups on the
+// other XCDs wait for it: a circular wait across kernels (seen as expired bounded waits with three processes on one GPU).
+// With leaders c and c + 8 -- one per lane -- on every XCD, any running workgroup of this launch has both lanes' leaders of
+// its own XCD dispatched ahead of it, whatever else fills the device.  (Measured on the way: an election by tickets BEFORE
+// the work adds ~1.5 us to every launch -- cfg2 2450 -> 2300 evals/s; tickets in flight with the loads are no better: the
+// atomic returns in order AHEAD of them; eight leaders writing ONE record collide on its lines -- headline 920 -> 830.)
 constexpr int kRideCand = 16;
-__device__ __forceinline__ int ride_ticket(const struct RideArgs& ra, int* lds_slot);
+__device__ __forceinline__ int ride_xcc() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7; }
 
-// A candidate that drew ticket 0 / 1: lane 0 / 1.  k_step's body (step_run) with line 0 of the record published
-// from the advanced state in LDS BEFORE the state is committed: that is all the product workgroups wait for.
-__device__ __forceinline__ void ride_leader(const StepArgs& a, int l, const RideArgs& ra, double* red32, unsigned long long* st80) {
-  auto early = [&]() { ride_publish(reinterpret_cast<const LaneCtl*>(st80), l, ra.rec, ra.pub); };
+// Leader c of lane l.  k_step's body (step_run); line 0 of the record copy is published from the advanced state in LDS BEFORE
+// the state is committed: that is all the product workgroups wait for.
+struct RideHook {
+  const RideArgs* ra;
+  const unsigned long long* st80;
+  unsigned long long* rec;  // this XCC's copy
+  int l;
+  __device__ void advanced() const { ride_publish(reinterpret_cast<const LaneCtl*>(st80), l, rec, ra->pub); }
+};
+__device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const RideArgs& ra, double* red32, unsigned long long* st80) {
+  const int l = (c >> 3) & 1;
+  unsigned long long* rec = ra.rec + 64 * ride_xcc();
+  const RideHook hook{&ra, st80, rec, l};
   if (a.kind != STEP_NONE) {
-    step_run(a, red32, st80, true, &early);
+    step_run(a, red32, st80, /*commit=*/(c & 7) == 0, &hook);
   } else {
     if (threadIdx.x < 12) st80[threadIdx.x] = reinterpret_cast<const unsigned long long*>(a.state)[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x == 0) early();
+    if (threadIdx.x == 0) hook.advanced();
   }
   if (threadIdx.x < 12) {  // (step_run's closing barrier: st80 is final for every thread)
     const unsigned long long w = st80[threadIdx.x];
-    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x, (w & 0xffffffff00000000ull) | ra.pub);
-    ride_store(ra.rec + 16 + 24 * l + 2 * threadIdx.x + 1, (w << 32) | ra.pub);
+    ride_store(rec + 16 + 24 * l + 2 * threadIdx.x, (w & 0xffffffff00000000ull) | ra.pub);
+    ride_store(rec + 16 + 24 * l + 2 * threadIdx.x + 1, (w << 32) | ra.pub);
   }
-}
-
-__device__ __forceinline__ int ride_ticket(const RideArgs& ra, int* lds_slot) {
-  if (threadIdx.x == 0)
-    *lds_slot = (int)(__hip_atomic_fetch_add(ra.tickets, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ra.ticket0);
-  __syncthreads();
-  return *lds_slot;
 }
 
 // One look of a PRODUCT workgroup, by the calling wave (one wave per workgroup looks): lanes 0..9 each request one word ...
 __device__ __forceinline__ unsigned long long ride_look(const RideArgs& ra) {
   const int lane = threadIdx.x & 63;
-  return lane < 10 ? ride_load(ra.rec + lane) : 0ull;
+  return lane < 10 ? ride_load(ra.rec + 64 * ride_xcc() + lane) : 0ull;
 }
 // ... and its verdict (wave-uniform); a good look leaves the ten words in `crec` (LDS)
 __device__ __forceinline__ bool ride_take(const RideArgs& ra, unsigned long long w, unsigned long long* crec) {
@@ -410,7 +415,7 @@ __device__ __forceinline__ bool ride_take(const RideArgs& ra, unsigned long long
 // The same for an UPDATE workgroup: lanes 0..47, the two control blocks end up in LDS at img[0..11] and img[80..91].
 __device__ __forceinline__ bool ride_take_ctl(const RideArgs& ra, unsigned long long* img) {
   const int lane = threadIdx.x & 63;
-  const unsigned long long w = lane < 48 ? ride_load(ra.rec + 16 + lane) : 0ull;
+  const unsigned long long w = lane < 48 ? ride_load(ra.rec + 64 * ride_xcc() + 16 + lane) : 0ull;
   const bool good = lane >= 48 || (unsigned int)(w & 0xffffffffull) == ra.want;
   const unsigned int nlo = (unsigned int)__shfl_down((unsigned int)(w >> 32), 1, 64);  // the partner's payload (low half of the word)
   if (!__all(good)) return false;
@@ -448,7 +453,7 @@ __device__ __forceinline__ bool ride_settle(const RideArgs& ra, unsigned long lo
 }
 
 // The A' product (two lanes, padded blocks with block-relative columns, one GPU) of a launch with riding leaders: k_spmv's
-// main path with the coefficients taken as described above.  grid = 2 leaders + nwg product workgroups + the riding updates.
+// main path with the coefficients taken as described above.  grid = kRideCand candidates + nwg product workgroups + the riding updates.
 // TWO BLOCKS for the first workgroups: the first resident set starts together with the leaders and would reach its row
 // epilogue before the record is up (2.6 us of waiting per launch, measured against a build that does not wait).  Product
 // workgroup b < n2 therefore takes blocks b and n2 + b: row sums of the first block are HELD in registers, the second block
@@ -470,8 +475,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
   double* red = prod;
   const int tid = threadIdx.x;
   if (blockIdx.x < kRideCand) {
-    const int t = ride_ticket(ra, &okf);
-    if (t < 2) ride_leader(t == 0 ? s0 : s1, t, ra, fred, fst);
+    ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
     return;
   }
   const int b = (int)blockIdx.x - kRideCand;
@@ -652,7 +656,7 @@ struct RgcsView {
 
 // PAD: the groups' entries are stored at a fixed stride and zero-padded to whole tiles, so the first tile's stream
 // does not wait for the group descriptor and no load needs a bounds check.
-// LEAD: the launch's first two workgroups are the leaders of the riding steps (see "steps riding with leaders" above); the
+// LEAD: the launch's first kRideCand workgroups are the candidates for leading the riding steps (see "steps riding with leaders" above); the
 // groups and the riding updates follow, the coefficients are picked up between the tiles.
 template <int NL, bool PAD = false, bool STEPIN = false, bool LEAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
@@ -678,8 +682,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     crec = crec_;
     okf = &okf_;
     if (blockIdx.x < kRideCand) {
-      const int t = ride_ticket(ra, okf);
-      if (t < 2) ride_leader(t == 0 ? s0 : s1, t, ra, fred, fst);
+      ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
       return;
     }
   }
