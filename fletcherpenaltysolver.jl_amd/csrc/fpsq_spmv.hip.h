@@ -302,17 +302,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 
 // ------------------------------------------------------------------------------------------------ steps riding with leaders
 //
-// LARGE product grids (thousands of workgroups: every workgroup recomputing the pending scalar steps, STEPIN above, would
-// read the partial sums thousands of times over): the two steps that follow the previous product are computed ONCE, by two
-// LEADER workgroups at the head of this launch's grid (elected among its first kRideCand workgroups, see "WHO LEADS": exactly
-// publish a launch sequence number behind a device-scope release.  A product only needs the steps' coefficients in its
-// row epilogue -- out = ca (A x) + cb yin is linear in them -- so every other workgroup starts streaming at once and picks
-// them up on the way: it requests the two flag words TOGETHER WITH its matrix stream (nothing waits on them), looks at
-// them when the stream has landed, and, flags set, reads ca / cb / done / skip of both lanes with device-scope loads (this
-// XCD's L2 may hold an older image of those lines) while its gathers are in flight.  Workgroups of the first wave, which
-// started before the leaders finished, ask again behind their gathers; whoever still has nothing at the end of phase 1
-// polls a bounded number of times and then recomputes the steps itself (step_run without commit: same inputs, same
-// instructions, same bits) -- no workgroup ever depends on another one's progress for more than that bound.
+// The default form of the riding steps (every grid size; STEPIN above, where EVERY workgroup recomputes the steps, reads the
+// partial sums thousands of times over on a large grid and is slower on a small one).  The two steps that follow the
+// previous product are computed by LEADER workgroups at the head of this launch's grid (see "WHO LEADS"): k_step's body, and
+// the step's outcome published as self-validating words (ride_publish) the moment its arithmetic is done.  A product only
+// needs the steps' coefficients in its row epilogue -- out = ca (A x) + cb yin is linear in them -- so every other workgroup
+// starts streaming at once and picks them up on the way: wave 0 LOOKS for the record (one wave-level device-scope load:
+// this XCD's L2 may hold an older image of those lines) behind its matrix stream, again behind its gathers, behind its
+// products and behind its row sums -- always behind the loads whose arrival the next step waits for, because device-scope
+// loads come back late and the load counter is in-order.  The first resident set of A' workgroups, which starts together
+// with the leaders, takes two row blocks and so never gets to an epilogue early (k_spmv_atl); RGCS groups run five tiles.
+// Whoever still has nothing when it needs the coefficients polls (ride_settle), a bounded number of times.
 // The one-workgroup k_step launch between two products (~5 us in the running pipeline, 32 per evaluation at the headline
 // size) disappears; results are bitwise those of the stand-alone steps.
 struct RideArgs {
