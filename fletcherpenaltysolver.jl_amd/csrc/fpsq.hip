@@ -1761,7 +1761,13 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       u.len = m;
       (w0.nblk ? w1 : w0) = u;
     }
-    if (int rc = launch_step(h, s0, s1, /*sharded=*/true)) return rc;
+    // (riding with leaders -- step_run knows every step kind, the all-recompute form only the loop's: alpha_1 / the CRAIG
+    // lane's beta_1 go with the first A' product of the loop)
+    if (lead) {
+      if (int rc = post_step(s0, s1, /*sharded=*/true)) return rc;
+    } else {
+      if (int rc = launch_step(h, s0, s1, /*sharded=*/true)) return rc;
+    }
     if (fuse_upd) {  // w_1 rides in the first A' product
       winit[0] = w0;
       winit[1] = w1;
