@@ -396,7 +396,7 @@ struct fpsq_solver_s {
   CraigState* craig_alt;
   bool at_sorted = true;        // A' blocks stored column-sorted where representable (FPSQ_AT_SORTED=0: row order)
   // steps riding with LEADERS (large grids, see fpsq_spmv.hip.h): the leaders' record (one line of device memory), a launch counter
-  unsigned long long* ride_flags = nullptr;
+  unsigned long long* ride_rec = nullptr;
   unsigned long long ride_seq = 0;
   bool ride_lead = true;        // FPSQ_RIDE_LEAD=0: large grids keep the stand-alone k_step
   bool ride_break = false;      // FPSQ_DEBUG_RIDE_BREAK=1 (tests): the leaders publish a wrong launch number, every wait expires
@@ -952,7 +952,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
   RideArgs ra{};
   const bool lead = pre && h->lead_now;
   if (lead) {  // (run_krylov only sets lead_now where both products have the leader variants: lead_supported())
-    ra.rec = h->ride_flags;
+    ra.rec = h->ride_rec;
     ra.want = (unsigned int)++h->ride_seq;
     ra.pub = h->ride_break ? ~ra.want : ra.want;
     ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
@@ -2581,7 +2581,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     if ((e = hipMalloc(&q, 8 * 512)) != hipSuccess) return fail("hipMalloc", e);  // (a record copy of 64 words per XCC)
     h->allocs.push_back(q);
     hipMemset(q, 0, 8 * 512);
-    h->ride_flags = (unsigned long long*)q;
+    h->ride_rec = (unsigned long long*)q;
   }
   char* cp = (char*)p;
   h->lsqr[0] = (LsqrState*)cp;
