@@ -400,11 +400,8 @@ struct fpsq_solver_s {
   unsigned long long ride_seq = 0;
   bool ride_lead = true;        // FPSQ_RIDE_LEAD=0: large grids keep the stand-alone k_step
   bool ride_break = false;      // FPSQ_DEBUG_RIDE_BREAK=1 (tests): the leaders publish a wrong launch number, every wait expires
-  bool lead_now = false;        // run_krylov: the pending steps ride with leaders (not the all-recompute form)
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
-  int stepin_max = 0;           // all-recompute form of the riding steps when neither product has more workgroups than this
-                                // (FPSQ_STEPIN_MAX; 0 = never: the leader form is faster at every size measured)
   MinresState* minres;
   LnlqState* lnlq;
   LaneCtl* ctl_tmp;
@@ -936,8 +933,8 @@ UpdSeg seg_none() {
 // product reads.
 // halo_rows (A' products of a halo-mode handle): the overlap rows of the rank's column window only get their raw sums,
 // see HaloRows / halo_finish.
-// pre (two entries, single-GPU small problems): the scalar steps of the two lanes that follow the previous product ride in
-// this launch (k_spmv / k_spmv_rgcs <.., STEPIN>; stepin_supported() says for which storage variants that exists)
+// pre (two entries): the scalar steps of the two lanes that follow the previous product ride in this launch, with leader
+// workgroups (k_spmv_atl / k_spmv_rgcs<.., LEAD>; run_krylov only hands steps over where both products have those variants)
 template <int NL>
 void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, double* yout, const LaneCtl* c0,
                  const LaneCtl* c1, double* partials, const UpdSeg& u0 = seg_none(), const UpdSeg& u1 = seg_none(),
@@ -950,8 +947,8 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     z1 = pre[1];
   }
   RideArgs ra{};
-  const bool lead = pre && h->lead_now;
-  if (lead) {  // (run_krylov only sets lead_now where both products have the leader variants: lead_supported())
+  const bool lead = pre != nullptr;
+  if (lead) {
     ra.rec = h->ride_rec;
     ra.want = (unsigned int)++h->ride_seq;
     ra.pub = h->ride_break ? ~ra.want : ra.want;
@@ -963,10 +960,8 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     launch_product(h, k_spmv_rgcs<__VA_ARGS__>, dim3(per_xcd * 8 + nupd + (lead ? kRideCand : 0)), h->RA.view, x, yin, yout, c0, c1, partials, \
                    per_xcd, u0, u1, h->gate0, h->gate1, h->strA, z0, z1, ra)
     if constexpr (NL == 2) {
-      if (lead && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, false, true);
-      else if (lead) FPSQ_LAUNCH_RGCS(2, false, false, true);
-      else if (pre && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true);
-      else if (pre) FPSQ_LAUNCH_RGCS(2, false, true);
+      if (lead && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true);
+      else if (lead) FPSQ_LAUNCH_RGCS(2, false, true);
     }
     if (!pre) {
       if (h->RA.view.stride) FPSQ_LAUNCH_RGCS(NL, true);
@@ -979,11 +974,10 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     const dim3 grid(per_xcd * 8 + nupd);
     const int ps = tag == TAG_A ? h->strA : h->strT;
 #define FPSQ_LAUNCH_SPMV(...) \
-    launch_product(h, k_spmv<__VA_ARGS__>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1, ps, hr, \
-                   z0, z1)
+    launch_product(h, k_spmv<__VA_ARGS__>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1, ps, hr)
     bool done_pre = false;
     if constexpr (NL == 2) {
-      if (lead) {  // (tag == TAG_AT: padded blocks with block-relative columns, see lead_supported())
+      if (lead) {  // (tag == TAG_AT: padded blocks with block-relative columns)
         done_pre = true;
         // the first resident set of workgroups takes two row blocks each (see k_spmv_atl)
         const int R = h->resident_wgs - kRideCand;
@@ -998,25 +992,18 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
           launch_product(h, k_spmv_atl<false, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
         else
           launch_product(h, k_spmv_atl<false, false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
-      } else if (pre) {  // (only the variants stepin_supported() admits)
-        done_pre = true;
-        if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(2, TAG_A, true, false, false, true);
-        else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(2, TAG_A, false, false, false, true);
-        else if (M.sorted) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true, true);
-        else if (M.col16) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true);
-        else FPSQ_LAUNCH_SPMV(2, TAG_AT, false, true, false, true);
       }
     }
     if (done_pre) {
     } else if (tag == TAG_A && M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_A, true);
     else if (tag == TAG_A) FPSQ_LAUNCH_SPMV(NL, TAG_A, false);
     else if (halo_rows) {
-      if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true, false, true);
+      if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true, true);
       else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, true);
       else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, false, true);
       else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true, true);
       else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, false, true);
-    } else if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, false, false, true);
+    } else if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, false, true);
     else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true);
     else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true);
     else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true);
@@ -1572,20 +1559,13 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (!L.ctlT) L.ctlT = L.ctl;
     itmax_all = std::max(itmax_all, L.itmax);
   }
-  // Riding steps (small problems, LSQR / CRAIG lanes on one GPU): instead of a one-workgroup k_step launch behind every
-  // product, the step is handed to the NEXT product launch, whose workgroups all recompute it in their prologue
-  // (k_spmv / k_spmv_rgcs <.., STEPIN>, step_run).  Such a step reads the lane's current state copy and workgroup 0 writes
-  // the other one; the lane's pointers (state, ctl) switch to it once the launch is enqueued.
-  bool stepin = NL == 2 && !h->comm && h->stepin_max > 0 && h->AT.padded && h->AT.nblk <= h->stepin_max &&
-                npart_A(h) <= h->stepin_max;
-  for (int l = 0; l < NL; ++l) stepin = stepin && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
-  // Larger grids: the pending steps ride with two LEADER workgroups of the next product launch (k_spmv_atl,
-  // k_spmv_rgcs<.., LEAD>): computed once, picked up by the others on their way to the row epilogue.
-  bool lead = NL == 2 && (!h->comm || h->halo) && h->ride_lead && !stepin && h->AT.padded && (h->AT.sorted || h->AT.col16) &&
-              h->RA.ok;
+  // Riding steps (two LSQR / CRAIG lanes; one GPU or the halo-sharded layout): instead of a one-workgroup k_step launch
+  // behind every product, the two steps are handed to the NEXT product launch, where leader workgroups compute them and the
+  // others pick the coefficients up on their way to the row epilogue (k_spmv_atl, k_spmv_rgcs<.., LEAD>).  Such a step reads
+  // the lane's current state copy and writes the other one; the lane's pointers (state, ctl) switch to it once the launch
+  // is enqueued.
+  bool lead = NL == 2 && (!h->comm || h->halo) && h->ride_lead && h->AT.padded && (h->AT.sorted || h->AT.col16) && h->RA.ok;
   for (int l = 0; l < NL; ++l) lead = lead && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
-  h->lead_now = lead;
-  stepin = stepin || lead;  // (the same hand-over on the host side)
 #define c0 (lanes[0].ctl)       /* A product */
 #define c1 (lanes[NL - 1].ctl)
 #define t0 (lanes[0].ctlT)      /* A' product */
@@ -1614,7 +1594,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   };
   // the steps behind a product: riding in the next product launch when both lanes have one, else their own launch now
   auto post_step = [&](const StepArgs& a0, const StepArgs& a1, bool sharded) -> int {
-    if (stepin && a0.kind != STEP_NONE && a1.kind != STEP_NONE) {
+    if (lead && a0.kind != STEP_NONE && a1.kind != STEP_NONE) {
       pend[0] = a0;
       pend[1] = a1;
       if (h->comm)
@@ -1761,8 +1741,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       u.len = m;
       (w0.nblk ? w1 : w0) = u;
     }
-    // (riding with leaders -- step_run knows every step kind, the all-recompute form only the loop's: alpha_1 / the CRAIG
-    // lane's beta_1 go with the first A' product of the loop)
+    // (riding steps: alpha_1 / the CRAIG lane's beta_1 go with the first A' product of the loop)
     if (lead) {
       if (int rc = post_step(s0, s1, /*sharded=*/true)) return rc;
     } else {
@@ -2559,7 +2538,6 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     if (hipGetDeviceProperties(&prop, h->opt.device) == hipSuccess && prop.multiProcessorCount > 0)
       h->resident_wgs = 4 * prop.multiProcessorCount;
   }
-  if (const char* ev = std::getenv("FPSQ_STEPIN_MAX")) h->stepin_max = std::min(std::atoi(ev), 4 * kStepThreads);  // (step2_issue's shape)
   if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_AB_DYNAMIC")) h->ab_dynamic = std::atoi(ev) != 0;
   std::memset(h->hstats, 0, 4 * sizeof(fpsq_stats));

@@ -403,7 +403,7 @@ __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, 
 }
 
 // ctl: the recurrence's control block the update reads its coefficients from -- s.ctl in global memory, or (product kernels
-// with STEPIN) the copy the workgroup has just advanced in LDS
+// with riding leaders) the copy the workgroup has taken from the leaders' record into LDS
 template <int NL>
 __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red, const LaneCtl* ctl) {
   switch (s.kind) {
@@ -430,7 +430,7 @@ __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red) {
 // Update segments riding in a product launch ("horizontal fusion"): the workgroups past the product's own grid
 // (they are dispatched last and fill the product's tail) run vector updates that only READ what the product reads, so one launch replaces two and the streaming updates
 // overlap the gather-bound product.  Returns true when this workgroup was an update workgroup.
-// lds0 / lds1 (STEPIN): the lanes' control blocks as the workgroup has just advanced them (null: the segments' own)
+// lds0 / lds1 (riding leaders): the lanes' control blocks as taken from the leaders' record (null: the segments' own)
 template <int NL>
 __device__ __forceinline__ bool run_fused_updates(const UpdSeg& u0, const UpdSeg& u1, int nprod, double* red,
                                                   const LaneCtl* lds0 = nullptr, const LaneCtl* lds1 = nullptr) {

@@ -937,9 +937,7 @@ __device__ __forceinline__ int state_bytes(int kind) {
 // sums are reduced in the fixed order, thread 0 advances the recurrence IN `st`.  On return (after the closing barrier) `st`
 // holds the new state for every thread of the workgroup.  commit: this workgroup also performs the step's side effects --
 // the progress word, the final statistics in host-mapped memory, the state written to a.state_out (or back in place).
-// Without commit the workgroup only wants the result: the riding form of a step (product kernels with STEPIN), where every
-// workgroup of the NEXT product launch recomputes the step of the previous one in its prologue -- same inputs, same
-// instructions, same bits -- instead of waiting for a one-workgroup launch in between.
+// Without commit a workgroup only wants the result (the redundant leaders of a launch with riding steps).
 // hook (optional; the riding leaders, several of which compute a lane's step): hook->advanced() is called by thread 0 as soon
 // as the advanced state stands in `st`, before anything is written to global memory (the leaders publish the next product's
 // coefficients there).
@@ -998,112 +996,6 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
   if (commit && (!skip || a.state_out != nullptr)) {
     unsigned long long* gdst = reinterpret_cast<unsigned long long*>(a.state_out ? a.state_out : a.state);
     if ((int)threadIdx.x < nq) gdst[threadIdx.x] = st[threadIdx.x];
-  }
-}
-
-// the per-thread part of reduce_two (same batch shapes, hence the same summation order), loads only
-__device__ __forceinline__ void reduce_two_issue(const double* p0, int n0, const double* p1, int n1, double& a, double& b) {
-  const int t = threadIdx.x;
-  a = 0.0;
-  b = 0.0;
-  constexpr int U0 = 24, U1 = 4;
-  if (n0 > 0 && n0 <= kStepThreads * U0 && n1 <= kStepThreads * U1) {
-    if (n0 <= kStepThreads * 4) a = partial_batch<4>(p0, 0, n0, t);
-    else if (n0 <= kStepThreads * 8) a = partial_batch<8>(p0, 0, n0, t);
-    else a = partial_batch<U0>(p0, 0, n0, t);
-    b = n1 > 0 ? partial_batch<U1>(p1, 0, n1, t) : 0.0;
-  } else {
-    for (int base = 0; base < n0; base += kStepThreads * 8) a += partial_batch<8>(p0, base, n0, t);
-    for (int base = 0; base < n1; base += kStepThreads * 8) b += partial_batch<8>(p1, base, n1, t);
-  }
-}
-
-__device__ __forceinline__ void step_advance(const StepArgs& a, void* S, double s0, double s1, bool commit) {
-  Progress* prog = commit ? a.prog : nullptr;
-  switch (a.kind) {
-    case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)S, s0); break;
-    case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)S, s0, s1, a.it, prog); break;
-    case STEP_CRAIG_SA: craig_sa_step((CraigState*)S, s0, a.it, prog); break;
-    case STEP_CRAIG_SB: craig_sb_step((CraigState*)S, s0, s1, a.it, prog); break;
-    default: break;
-  }
-  if (commit && a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
-    const fpsq_stats* fin = a.kind >= STEP_CRAIG_BEGIN ? &((CraigState*)S)->stats : &((LsqrState*)S)->stats;
-    *a.host_stats = *fin;
-  }
-}
-
-// The riding form for TWO lanes at once (LSQR / CRAIG SA and SB steps only; every partial array <= 4 x kStepThreads entries,
-// i.e. reduce_two's partial_batch<4> shape), in two halves so that the caller can put its own memory requests between
-// them: step2_issue only REQUESTS both lanes' states and partial sums (raw values into registers), step2_finish sums them
-// in reduce_two's order behind one barrier and lets thread 0 (lane 0) and thread 64 (lane 1: another wave) advance their
-// recurrences side by side.  Bit for bit what two k_step workgroups compute.
-struct Step2Regs {
-  unsigned long long sv0, sv1;
-  double v[4][4];
-  bool skip0, skip1;
-};
-__device__ __forceinline__ void step2_issue(const StepArgs& a0, const StepArgs& a1, Step2Regs& R) {
-  const int t = threadIdx.x;
-  const int nq0 = state_bytes(a0.kind) / 8, nq1 = state_bytes(a1.kind) / 8;
-  R.sv0 = t < nq0 ? reinterpret_cast<const unsigned long long*>(a0.state)[t] : 0ull;
-  R.sv1 = (t >= 128 && t - 128 < nq1) ? reinterpret_cast<const unsigned long long*>(a1.state)[t - 128] : 0ull;
-  R.skip0 = lane_done(a0);
-  R.skip1 = lane_done(a1);
-  const double* arr[4] = {a0.p0, a0.p1, a1.p0, a1.p1};
-  const int cnt[4] = {a0.n0, a0.p1 ? a0.n1 : 0, a1.n0, a1.p1 ? a1.n1 : 0};
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = u * kStepThreads + t;
-      R.v[k][u] = cnt[k] > 0 ? arr[k][i < cnt[k] ? i : cnt[k] - 1] : 0.0;
-    }
-}
-__device__ __forceinline__ void step2_finish(const StepArgs& a0, const StepArgs& a1, const Step2Regs& R, double* red /* 32 */,
-                                             unsigned long long* st0 /* 80 */, unsigned long long* st1 /* 80 */,
-                                             bool commit) {
-  const int t = threadIdx.x;
-  const int nq0 = state_bytes(a0.kind) / 8, nq1 = state_bytes(a1.kind) / 8;
-  if (t < nq0) st0[t] = R.sv0;
-  if (t >= 128 && t - 128 < nq1) st1[t - 128] = R.sv1;
-  const int cnt[4] = {a0.n0, a0.p1 ? a0.n1 : 0, a1.n0, a1.p1 ? a1.n1 : 0};
-  double sum[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {  // partial_batch<4>'s masked sum, then wave_sum: reduce_two's order
-    double a = 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) a += (u * kStepThreads + t < cnt[k]) ? R.v[k][u] : 0.0;
-    sum[k] = wave_sum(a);
-  }
-  const int lane = t & 63, w = t >> 6;
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) red[4 * k + w] = sum[k];
-  }
-  __syncthreads();
-  if (t == 0 && !R.skip0) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < kStepThreads / 64; ++k) {
-      s0 += red[k];
-      s1 += red[4 + k];
-    }
-    step_advance(a0, st0, s0, s1, commit);
-  }
-  if (t == 64 && !R.skip1) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < kStepThreads / 64; ++k) {
-      s0 += red[8 + k];
-      s1 += red[12 + k];
-    }
-    step_advance(a1, st1, s0, s1, commit);
-  }
-  __syncthreads();
-  if (commit) {
-    unsigned long long* d0 = reinterpret_cast<unsigned long long*>(a0.state_out ? a0.state_out : a0.state);
-    unsigned long long* d1 = reinterpret_cast<unsigned long long*>(a1.state_out ? a1.state_out : a1.state);
-    if (t < nq0 && (!R.skip0 || a0.state_out)) d0[t] = st0[t];
-    if (t >= 128 && t - 128 < nq1 && (!R.skip1 || a1.state_out)) d1[t - 128] = st1[t - 128];
   }
 }
 

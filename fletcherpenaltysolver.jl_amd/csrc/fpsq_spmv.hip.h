@@ -1,7 +1,7 @@
 // fpsq_spmv.hip.h -- the two product kernels of libfpsq (CSR-stream k_spmv for A' and the CSR fallback of A; column-sorted
-// row groups k_spmv_rgcs for A): SpMV / SpMM with the fused axpby + norm-partial epilogue, the riding vector updates and
-// -- for small problems -- the riding scalar steps (STEPIN).  Split from fpsq_kernels.hip.h because the riding steps need
-// the recurrences of fpsq_krylov.hip.h.
+// row groups k_spmv_rgcs for A; k_spmv_atl, the A' product of a launch with riding leaders): SpMV / SpMM with the fused
+// axpby + norm-partial epilogue, the riding vector updates and the riding scalar steps.  Split from fpsq_kernels.hip.h
+// because the riding steps need the recurrences of fpsq_krylov.hip.h.
 #pragma once
 #include "fpsq_krylov.hip.h"
 
@@ -69,13 +69,6 @@ __device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, 
 // long row.
 // partials[l * pstride + L]: the lane stride of the partial array is the caller's (the workgroup count on one GPU; a
 // padded count common to all ranks when the arrays are all-gathered, see run_krylov).
-// STEPIN (small problems: a few hundred workgroups per product): the scalar steps that follow the PREVIOUS product -- one per
-// lane, s0 / s1 -- ride in this launch: every workgroup (product and riding-update workgroups alike) first recomputes them
-// from that product's partial sums (step_run: same inputs, same instructions, same bits in every workgroup), takes the
-// coefficients from its own LDS copy of the advanced state, and workgroup 0 alone commits the state (to the OTHER of its
-// two copies: nobody reads what it writes during this launch), the progress word and the statistics.  Two one-workgroup
-// launches and two kernel boundaries per Krylov iteration disappear.  The redundant work is a few KB of L2 reads and ~3 us
-// of scalar code per workgroup -- too much for the thousands of workgroups of a large product, which keep k_step.
 // CSORT (A' of a banded Jacobian: padded layout, every block's columns within 8192 of colbase): the block's entries are
 // STORED sorted by column, each carrying its slot in the block's row-major order (slot | (col & 31) << 11 in CsrView::cs16,
 // col >> 5 in CsrView::cs8: 11 B per entry; which thread reads what: csort_fetch).  Row-order gathers of ~10-entry rows put ~50 different 128-byte lines into every
@@ -83,12 +76,12 @@ __device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, 
 // builds at the headline size: one address for all lanes 31 -> 20 us, the sorted order's addresses 31 -> 22 us).  In column
 // order 64 consecutive entries read ~4 lines; the products are scattered to their row-major LDS slots and phase 2 is
 // unchanged -- same values summed in the same order: BITWISE the row-order layout.
-template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool STEPIN = false, bool CSORT = false>
+template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool CSORT = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
                                                  const LaneCtl* gate0, const LaneCtl* gate1, int pstride,
-                                                 const HaloRows hr, const StepArgs s0, const StepArgs s1) {
+                                                 const HaloRows hr) {
   // exactly 32 KB of LDS for two right-hand sides (FOUR workgroups per CU -- measured, tools/stream_probe.hip: 30 KB would
   // admit five, 24 KB six; tiles of 1536 entries were slower all the same): the reduction scratch
   // aliases the head of the product buffer
@@ -96,54 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   double* red = prod;
   // speculatively enqueued epilogue product: runs only once both recurrences of the call have ended
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
-  // (STEPIN with the padded layout: the workgroup's matrix stream depends on nothing but its index, so it is requested
-  // BEFORE the riding steps and is in flight while they are computed)
-  constexpr int kPerS = kSpmvNnz / kBlock;
-  [[maybe_unused]] int cpre[kPerS];
-  [[maybe_unused]] double vpre[kPerS];
-  [[maybe_unused]] double2 xpre[kPerS];
   static_assert(!CSORT || (IDX16 && PAD && TAG == 1), "column-sorted blocks: padded A' with block-relative columns only");
-  [[maybe_unused]] int spre[kPerS];
-  if constexpr (STEPIN) {
-    static_assert(NL == 2, "riding steps: two lanes");
-    __shared__ __attribute__((aligned(16))) unsigned long long stl[2 * 80];
-    __shared__ double sred[32];
-    if ((int)blockIdx.x >= 8 * blk_per_xcd + u0.nblk + u1.nblk) return;
-    // request order: matrix stream, the steps' states and partial sums, then (stream arrived) the gathers of x; the
-    // steps' arithmetic runs while the gathers are in flight
-    bool pre_ok = false;
-    if constexpr (PAD) {
-      const int Lp = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
-      pre_ok = (int)blockIdx.x < 8 * blk_per_xcd && Lp < A.nblk;
-      if (pre_ok) {
-        const int cb0 = IDX16 ? A.colbase[Lp] : 0;
-        if constexpr (CSORT) {
-          csort_fetch(A, Lp, cb0, threadIdx.x, cpre, spre, vpre);
-        } else {
-#pragma unroll
-          for (int k = 0; k < kPerS; ++k) {
-            const size_t ii = (size_t)Lp * kSpmvNnz + threadIdx.x + k * kBlock;
-            cpre[k] = IDX16 ? cb0 + (int)A.col16[ii] : A.colind[ii];
-            vpre[k] = A.vals[ii];
-          }
-        }
-      }
-    }
-    Step2Regs SR;
-    step2_issue(s0, s1, SR);
-    if constexpr (PAD) {
-      if (pre_ok) {
-#pragma unroll
-        for (int k = 0; k < kPerS; ++k) xpre[k] = *reinterpret_cast<const double2*>(x + (size_t)cpre[k] * 2);
-      }
-    }
-    step2_finish(s0, s1, SR, sred, stl, stl + 80, blockIdx.x == 0);
-    ctl0 = reinterpret_cast<const LaneCtl*>(stl);
-    ctl1 = reinterpret_cast<const LaneCtl*>(stl + 80);
-    if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red, ctl0, ctl1)) return;
-  } else {
-    if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
-  }
+  if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   // A (TAG 0): XCD-contiguous eighths, so an XCD's L2 holds one slice of the long gathered vector.  A' (TAG 1): the gathered
   // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
   const int L = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
@@ -224,14 +171,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     int cidx[kPer];
     [[maybe_unused]] int slot[kPer];  // CSORT: where the entry's product goes (its position in the block's row-major order)
     double v[kPer];
-    if constexpr (CSORT && !STEPIN) csort_fetch(A, L, cbase, tid, cidx, slot, v);
+    if constexpr (CSORT) csort_fetch(A, L, cbase, tid, cidx, slot, v);
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      if (PAD && STEPIN) {  // requested at the head of the workgroup
-        cidx[k] = cpre[k];
-        v[k] = vpre[k];
-        if constexpr (CSORT) slot[k] = spre[k];
-      } else if (CSORT) {
+      if (CSORT) {
       } else if (PAD) {
         const size_t ii = (size_t)L * kSpmvNnz + tid + k * kBlock;
         cidx[k] = IDX16 ? cbase + (int)A.col16[ii] : A.colind[ii];
@@ -254,8 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
       double2 xv[kPer];
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
-        if (PAD && STEPIN) xv[k] = xpre[k];  // gathered at the head of the workgroup
-        else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+        xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
       }
 #pragma unroll
       for (int k = 0; k < kPer; ++k)
@@ -302,8 +244,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 
 // ------------------------------------------------------------------------------------------------ steps riding with leaders
 //
-// The default form of the riding steps (every grid size; STEPIN above, where EVERY workgroup recomputes the steps, reads the
-// partial sums thousands of times over on a large grid and is slower on a small one).  The two steps that follow the
+// (A first form, in which EVERY workgroup of the product recomputed the steps in its prologue, read the partial sums thousands
+// of times over on a large grid and was slower than this one on a small grid too: tools/experiments/stepin_all_recompute.patch.)
+// The two steps that follow the
 // previous product are computed by LEADER workgroups at the head of this launch's grid (see "WHO LEADS"): k_step's body, and
 // the step's outcome published as self-validating words (ride_publish) the moment its arithmetic is done.  A product only
 // needs the steps' coefficients in its row epilogue -- out = ca (A x) + cb yin is linear in them -- so every other workgroup
@@ -658,7 +601,7 @@ struct RgcsView {
 // does not wait for the group descriptor and no load needs a bounds check.
 // LEAD: the launch's first kRideCand workgroups are the candidates for leading the riding steps (see "steps riding with leaders" above); the
 // groups and the riding updates follow, the coefficients are picked up between the tiles.
-template <int NL, bool PAD = false, bool STEPIN = false, bool LEAD = false>
+template <int NL, bool PAD = false, bool LEAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                       double* partials, int grp_per_xcd, const UpdSeg u0,
@@ -666,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
                                                       int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra) {
   __shared__ double prod[kRgcsTile * NL];
   double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
-  static_assert(!LEAD || (NL == 2 && !STEPIN), "riding leaders: two lanes, instead of the all-recompute form");
+  static_assert(!LEAD || NL == 2, "riding leaders: two lanes");
   [[maybe_unused]] unsigned long long* fst = nullptr;
   [[maybe_unused]] double* fred = nullptr;
   [[maybe_unused]] unsigned long long* crec = nullptr;
@@ -687,10 +630,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     }
   }
   const int bid = LEAD ? (int)blockIdx.x - kRideCand : (int)blockIdx.x;
-  if constexpr (STEPIN) {  // (see k_spmv)
-    static_assert(NL == 2, "riding steps: two lanes");
-    if ((int)blockIdx.x >= 8 * grp_per_xcd + u0.nblk + u1.nblk) return;
-  }
   // (XCD-contiguous eighths: essential here -- with the identity map the product takes 43 us instead of 29 us)
   const int g = (bid & 7) * grp_per_xcd + (bid >> 3);
   constexpr int kPer = kRgcsTile / kBlock;
@@ -718,22 +657,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     }
     if (g >= M.ng) return;
     if (PAD) fetch_stream(g * M.stride, 0, 0);
-  } else if constexpr (STEPIN) {
-    __shared__ __attribute__((aligned(16))) unsigned long long stl[2 * 80];
-    __shared__ double sred[32];
-    // the first tile's stream is in flight while the riding steps are computed (padded layout: it needs no descriptor)
-    if (PAD && is_prod) fetch_stream(g * M.stride, 0, 0);
-    Step2Regs SR;
-    step2_issue(s0, s1, SR);
-    step2_finish(s0, s1, SR, sred, stl, stl + 80, blockIdx.x == 0);
-    ctl0 = reinterpret_cast<const LaneCtl*>(stl);
-    ctl1 = reinterpret_cast<const LaneCtl*>(stl + 80);
-    if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red, ctl0, ctl1)) return;
   } else {
     if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
   }
   if (g >= M.ng) return;
-  if (PAD && !STEPIN && !LEAD) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
+  if (PAD && !LEAD) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
   const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
   double ca[NL], cb[NL];
   bool act[NL];

@@ -954,54 +954,16 @@ def test_speculative_epilogue_every_alignment_is_bitwise_neutral(delta):
     dev.close()
 
 
-@pytest.mark.parametrize("delta", [0.0, SE, 0.25])
-def test_riding_scalar_steps_are_bitwise_the_stand_alone_steps(monkeypatch, delta):
-    """Small problems hand the scalar steps of the Krylov loop to the NEXT product launch, whose workgroups all recompute them
-    in their prologue (k_spmv / k_spmv_rgcs <.., STEPIN>, double-buffered recurrence state) instead of launching k_step
-    behind every product.  Same recurrences, same reduction order: every output and every statistic must be BITWISE those of
-    a handle with the riding steps switched off (FPSQ_STEPIN_MAX=0), for objgrad (LSQR + CRAIG lanes, fast start,
-    speculative tail), hprod (two LSQR lanes), the seam solves, with the run-ahead in every regime (first call, repeated
-    counts, counts that move)."""
-    qp = _small_pde(seed=11, n=6000, m=600)
-    monkeypatch.setenv("FPSQ_RIDE_LEAD", "0")  # (reference: stand-alone k_step launches)
-    monkeypatch.setenv("FPSQ_STEPIN_MAX", "0")
-    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
-    monkeypatch.setenv("FPSQ_STEPIN_MAX", "640")
-    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
-    assert ref.info()["spmv_at_blocks"] <= 640
-    rng = np.random.default_rng(2)
-    for k in range(10):
-        scale = 0.5 ** (k % 5) * (1.0 if k % 3 else 1e-2)
-        x = qp.xhat + scale * rng.standard_normal(qp.n)
-        v = scale * rng.standard_normal(qp.n)
-        for mdl, out in ((ref, []), (dev, [])):
-            gx, ys, gs, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.n)
-            f, rc = mdl.objgrad(x, gx=gx, ys=ys, gs=gs)
-            st = [(mdl.stats[i].niter, mdl.stats[i].status, mdl.stats[i].solved, mdl.stats[i].rnorm, mdl.stats[i].arnorm) for i in range(2)]
-            rch = mdl.hprod(v, hv, 1 + k % 2)
-            sth = [(mdl.stats4[i].niter, mdl.stats4[i].status, mdl.stats4[i].rnorm) for i in range(2)]
-            o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
-            g, c = qp.qdiag * x + qp.d, qp.scipy_csr() @ x - qp.b
-            rcm = mdl.solve_two_mixed(g, c, *o)
-            out += [np.array([f, rc, rch, rcm]), gx, ys, gs, hv, *o, np.array(st, dtype=float).ravel(), np.array(sth, dtype=float).ravel()]
-            if mdl is ref:
-                want = out
-        for a_, b_ in zip(out, want):
-            assert np.array_equal(a_, b_), k
-    ref.close()
-    dev.close()
-
-
-@pytest.mark.parametrize("stepin", ["0", "640"])
+@pytest.mark.parametrize("lead", ["0", "1"])
 @pytest.mark.parametrize("delta", [0.0, SE])
-def test_column_sorted_at_blocks_are_bitwise_the_row_order_layout(monkeypatch, delta, stepin):
+def test_column_sorted_at_blocks_are_bitwise_the_row_order_layout(monkeypatch, delta, lead):
     """A' of a banded Jacobian is stored with every row block's entries sorted by COLUMN (coalesced gathers: the row-order
     gather is what bounded the A' product), each entry carrying its row-major slot, to which its product is scattered
     (k_spmv<.., CSORT>).  Same values summed in the same order: every output must be BITWISE that of a handle storing the
     blocks in row order (FPSQ_AT_SORTED=0) -- objgrad, hprod (both Hessian approximations), the seam solves, the one-lane
-    kernels of an unfused handle, with the scalar steps riding in the products (small grids) and without."""
+    kernels of an unfused handle, with the scalar steps riding in the products (leader workgroups) and without."""
     qp = _small_pde(seed=13, n=30000, m=3000)
-    monkeypatch.setenv("FPSQ_STEPIN_MAX", stepin)
+    monkeypatch.setenv("FPSQ_RIDE_LEAD", lead)
     monkeypatch.setenv("FPSQ_AT_SORTED", "0")
     ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
     one_ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, fuse_two_rhs=0)
@@ -1040,7 +1002,6 @@ def test_steps_riding_with_leaders_are_bitwise_the_stand_alone_steps(monkeypatch
     resident sets, objgrad / hprod / the seam solves, first calls and armed run-ahead."""
     n, m = size
     qp = _small_pde(seed=11, n=n, m=m)
-    monkeypatch.setenv("FPSQ_STEPIN_MAX", "0")  # (small grids would otherwise take the all-recompute form)
     monkeypatch.setenv("FPSQ_RIDE_LEAD", "0")
     ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
     monkeypatch.setenv("FPSQ_RIDE_LEAD", "1")
