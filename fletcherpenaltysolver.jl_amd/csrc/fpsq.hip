@@ -404,6 +404,7 @@ struct fpsq_solver_s {
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   MinresState* minres;
   LnlqState* lnlq;
+  LnlqState* lnlq_alt;          // (second copy, see lsqr_alt)
   LaneCtl* ctl_tmp;
   LaneCtl* ctl_raw;             // constant {ca = 1, cb = 0, done = 0}: raw partial products before an all-reduce
   LaneCtl* ctl_pm;              // constant {1, -1}
@@ -1538,6 +1539,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       minres_lane = l;
     } else if (L.kind == LANE_LNLQ) {
       LnlqState* S = h->lnlq;
+      L.state_alt = h->lnlq_alt;
       L.state = S;
       L.ctl = &S->ctl;
       // pass k of lnlq!'s loop is completed (and tested) by the step after the A' product of iteration k + 1
@@ -1565,7 +1567,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   // the lane's current state copy and writes the other one; the lane's pointers (state, ctl) switch to it once the launch
   // is enqueued.
   bool lead = NL == 2 && (!h->comm || h->halo) && h->ride_lead && h->AT.padded && (h->AT.sorted || h->AT.col16) && h->RA.ok;
-  for (int l = 0; l < NL; ++l) lead = lead && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
+  for (int l = 0; l < NL; ++l) lead = lead && (lanes[l].kind == LANE_LSQR || is_ln(lanes[l].kind));
 #define c0 (lanes[0].ctl)       /* A product */
 #define c1 (lanes[NL - 1].ctl)
 #define t0 (lanes[0].ctlT)      /* A' product */
@@ -2549,7 +2551,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  const size_t state_bytes = sizeof(LsqrState) * 4 + sizeof(CraigState) * 2 + sizeof(MinresState) + sizeof(LnlqState) +
+  const size_t state_bytes = sizeof(LsqrState) * 4 + sizeof(CraigState) * 2 + sizeof(MinresState) + sizeof(LnlqState) * 2 +
                              4 * sizeof(LaneCtl) + 64 * sizeof(double);
   if ((e = hipMalloc(&p, state_bytes)) != hipSuccess) return fail("hipMalloc", e);
   h->allocs.push_back(p);
@@ -2575,6 +2577,8 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   h->minres = (MinresState*)cp;
   cp += sizeof(MinresState);
   h->lnlq = (LnlqState*)cp;
+  cp += sizeof(LnlqState);
+  h->lnlq_alt = (LnlqState*)cp;
   cp += sizeof(LnlqState);
   h->ctl_tmp = (LaneCtl*)cp;
   cp += sizeof(LaneCtl);
