@@ -405,6 +405,7 @@ struct fpsq_solver_s {
   MinresState* minres;
   LnlqState* lnlq;
   LnlqState* lnlq_alt;          // (second copy, see lsqr_alt)
+  MinresState* minres_alt;
   LaneCtl* ctl_tmp;
   LaneCtl* ctl_raw;             // constant {ca = 1, cb = 0, done = 0}: raw partial products before an all-reduce
   LaneCtl* ctl_pm;              // constant {1, -1}
@@ -1529,6 +1530,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       lsS[nlsqr - 1] = S;
     } else if (L.kind == LANE_MINRES) {
       MinresState* S = h->minres;
+      L.state_alt = h->minres_alt;
       L.state = S;
       L.ctl = &S->ctl;
       L.ctlT = &S->ctlT;
@@ -1567,7 +1569,9 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   // the lane's current state copy and writes the other one; the lane's pointers (state, ctl) switch to it once the launch
   // is enqueued.
   bool lead = NL == 2 && (!h->comm || h->halo) && h->ride_lead && h->AT.padded && (h->AT.sorted || h->AT.col16) && h->RA.ok;
-  for (int l = 0; l < NL; ++l) lead = lead && (lanes[l].kind == LANE_LSQR || is_ln(lanes[l].kind));
+  // (a MINRES lane -- solve_two_extras -- on one GPU only: its sums run over row-sharded m-vectors)
+  for (int l = 0; l < NL; ++l)
+    lead = lead && (lanes[l].kind == LANE_LSQR || is_ln(lanes[l].kind) || (lanes[l].kind == LANE_MINRES && !h->comm));
 #define c0 (lanes[0].ctl)       /* A product */
 #define c1 (lanes[NL - 1].ctl)
 #define t0 (lanes[0].ctlT)      /* A' product */
@@ -1590,7 +1594,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       if (pend[l].kind == STEP_NONE) continue;
       std::swap(lanes[l].state, lanes[l].state_alt);
       lanes[l].ctl = reinterpret_cast<LaneCtl*>(lanes[l].state);  // LaneCtl is the first member of every state
-      lanes[l].ctlT = lanes[l].ctl;
+      lanes[l].ctlT = lanes[l].kind == LANE_MINRES ? &reinterpret_cast<MinresState*>(lanes[l].state)->ctlT : lanes[l].ctl;
     }
     have_pend = false;
   };
@@ -1608,11 +1612,12 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     nn.kind = STEP_NONE;
     return launch_step(h, a0.kind ? a0 : a1, a0.kind ? a1 : nn, sharded);
   };
-  auto pre_args = [&]() -> const StepArgs* {
+  auto pre_args = [&](bool for_at) -> const StepArgs* {
     if (!have_pend) return nullptr;
     for (int l = 0; l < NL; ++l) {
       pend[l].state = lanes[l].state;
       pend[l].state_out = lanes[l].state_alt;
+      pend[l].prod_ctl_off = for_at && lanes[l].kind == LANE_MINRES ? (int32_t)(offsetof(MinresState, ctlT) / 8) : 0;
     }
     return pend;
   };
@@ -1883,7 +1888,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     // first half-step of every lane: one A' product
     int npT = 0;
     if (fuse_upd) {
-      const StepArgs* pre = pre_args();
+      const StepArgs* pre = pre_args(true);
       if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT, lu[0], lu[1], pre)) return rc;
       if (pre) adopt_pend();
     } else {
@@ -1949,7 +1954,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     }
     // second half-step: one A product
     if (fuse_upd) {
-      const StepArgs* pre = pre_args();
+      const StepArgs* pre = pre_args(false);
       launch_spmv<NL>(h, TAG_A, LP, SPcur, SPalt, c0, c1, h->pS2, cu[0], cu[1], false, pre);
       if (pre) adopt_pend();
       std::swap(SPcur, SPalt);
@@ -1970,17 +1975,28 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
                           lanes[l], (int)it, h->pS2 + (size_t)l * h->strA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : h->pW[l],
                           gm, prog[l]);
     }
-    if (!h->comm || lead) {
-      if (int rc = post_step(sb[0], NL == 2 ? sb[1] : none, true)) return rc;
-    } else {
-      if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
-    }
-    if (minres_lane >= 0) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
+    if (minres_lane >= 0 && lead && NL == 2) {
+      // MINRES' step A must run before E2; the other lane's step is only needed by the NEXT A' launch (its epilogue and its
+      // riding update) and waits for MINRES' step B to ride there with it
+      if (int rc = launch_step(h, sb[minres_lane], none, /*sharded=*/true)) return rc;
       launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
-      if (int rc = launch_step(h, step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
-                                            prog[minres_lane]),
-                               none, /*sharded=*/true))
-        return rc;
+      StepArgs pair[2];
+      pair[minres_lane] = step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0, prog[minres_lane]);
+      pair[1 - minres_lane] = sb[1 - minres_lane];
+      if (int rc = post_step(pair[0], pair[1], true)) return rc;
+    } else {
+      if (!h->comm || lead) {
+        if (int rc = post_step(sb[0], NL == 2 ? sb[1] : none, true)) return rc;
+      } else {
+        if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
+      }
+      if (minres_lane >= 0) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
+        launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
+        if (int rc = launch_step(h, step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
+                                              prog[minres_lane]),
+                                 none, /*sharded=*/true))
+          return rc;
+      }
     }
     if (h->comm) {
       // every rank must enqueue the same collectives: decide at fixed iteration boundaries from the (replicated,
@@ -2551,7 +2567,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  const size_t state_bytes = sizeof(LsqrState) * 4 + sizeof(CraigState) * 2 + sizeof(MinresState) + sizeof(LnlqState) * 2 +
+  const size_t state_bytes = sizeof(LsqrState) * 4 + sizeof(CraigState) * 2 + sizeof(MinresState) * 2 + sizeof(LnlqState) * 2 +
                              4 * sizeof(LaneCtl) + 64 * sizeof(double);
   if ((e = hipMalloc(&p, state_bytes)) != hipSuccess) return fail("hipMalloc", e);
   h->allocs.push_back(p);
@@ -2580,6 +2596,8 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   cp += sizeof(LnlqState);
   h->lnlq_alt = (LnlqState*)cp;
   cp += sizeof(LnlqState);
+  h->minres_alt = (MinresState*)cp;
+  cp += sizeof(MinresState);
   h->ctl_tmp = (LaneCtl*)cp;
   cp += sizeof(LaneCtl);
   h->ctl_raw = (LaneCtl*)cp;

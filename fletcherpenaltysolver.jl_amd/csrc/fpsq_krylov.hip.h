@@ -780,6 +780,9 @@ struct StepArgs {
   // alternate between two copies of the state: every workgroup of the launch reads `state`, only workgroup 0 writes
   // `state_out`, so no reader can ever see a half-written or an already advanced state.
   void* state_out;
+  // riding steps: the 8-byte-word offset, inside the state, of the control block whose ca / cb / done / skip the NEXT product
+  // reads (0: the state's first member; a MINRES lane has a second block, ctlT, for A' products)
+  int32_t prod_ctl_off, pad_;
 };
 
 // 256 threads: the <= ~5000 norm partials are still summed with a few batches of independent loads per thread, and a

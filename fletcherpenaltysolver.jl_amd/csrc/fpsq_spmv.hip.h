@@ -322,12 +322,13 @@ struct RideHook {
   const unsigned long long* st80;
   unsigned long long* rec;  // this XCC's copy
   int l;
-  __device__ void advanced() const { ride_publish(reinterpret_cast<const LaneCtl*>(st80), l, rec, ra->pub); }
+  int off;                  // StepArgs::prod_ctl_off
+  __device__ void advanced() const { ride_publish(reinterpret_cast<const LaneCtl*>(st80 + off), l, rec, ra->pub); }
 };
 __device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const RideArgs& ra, double* red32, unsigned long long* st80) {
   const int l = (c >> 3) & 1;
   unsigned long long* rec = ra.rec + 64 * ride_xcc();
-  const RideHook hook{&ra, st80, rec, l};
+  const RideHook hook{&ra, st80, rec, l, a.prod_ctl_off};
   if (a.kind != STEP_NONE) {
     step_run(a, red32, st80, /*commit=*/(c & 7) == 0, &hook);
   } else {

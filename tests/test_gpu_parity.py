@@ -1018,7 +1018,8 @@ def test_steps_riding_with_leaders_are_bitwise_the_stand_alone_steps(monkeypatch
             f, rc = mdl.objgrad(x, gx=gx, ys=ys, gs=gs)
             st = [(mdl.stats[i].niter, mdl.stats[i].status, mdl.stats[i].solved, mdl.stats[i].rnorm, mdl.stats[i].arnorm) for i in range(2)]
             rch = mdl.hprod(v, hv, 1 + k % 2)
-            sth = [(mdl.stats4[i].niter, mdl.stats4[i].status, mdl.stats4[i].rnorm) for i in range(2)]
+            # (Val(1): + the LSQR and MINRES lanes of solve_two_extras, whose steps ride too)
+            sth = [(mdl.stats4[i].niter, mdl.stats4[i].status, mdl.stats4[i].rnorm) for i in range(4 if k % 2 == 0 else 2)]
             o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
             rcm = mdl.solve_two_mixed(qp.qdiag * x + qp.d, A @ x - qp.b, *o)
             out = [np.array([f, rc, rch, rcm]), gx, ys, gs, hv, *o, np.array(st, dtype=float).ravel(), np.array(sth, dtype=float).ravel()]
