@@ -290,7 +290,7 @@ __device__ __forceinline__ double rdlane(double v, int lane) {
 //   (d) the doubling steps T = L21 X11 and X21 = -X22 T are MFMA tile products too (T kept transposed, 32 columns at a
 //       time, so both operands of both products are read k-contiguous); entries of the triangular 16 x 16 diagonal
 //       sub-blocks of X are selected on load (strictly lower from the transposed store, diagonal from `dinv`, else 0).
-// Step (b) also yields the 16 x 16 inverse (see wave_diag16x), which turns (c) into an MFMA product as well.
+// Step (b) also yields the 16 x 16 inverse (see wave_diag16), which turns (c) into an MFMA product as well.
 #ifndef FPSQ_POTRF_LD5
 #define FPSQ_POTRF_LD5 (kDB + 2)
 #endif
@@ -298,61 +298,80 @@ constexpr int kPotrfLd5 = FPSQ_POTRF_LD5;
 constexpr int kPotrfTld5 = 66;
 constexpr int kPotrfLds5 = (kDB * kPotrfLd5 + 32 * kPotrfTld5 + kDB) * 8;
 
-// the 16 x 16 factor routine of generation 5: wave_diag16 without branches (pivot tests by selects, the counters
-// reported once at the end), so the whole routine is one basic block and the scheduler can run the reciprocal square
-// root of column j + 1 under the updates of column j.  (~400 cycles per column remain: the dependent chain pivot ->
-// v_rsq_f64 + refinement -> scale -> broadcast -> update of the next pivot.  Spreading the tile over all 64 lanes, 4
-// columns each with ds_bpermute fetches, halves the instruction count but not that chain: measured 7.0k against 6.6k
-// cycles per tile, not kept.)
-// Lanes 16 .. 31 -- idle copies in the plain routine -- compute X16 = L16^-1 ALONGSIDE, for free: lane 16 + c carries
-// column c of X through the same instruction stream (its a[r] starts as e_c; at step j its a[j] * rp is X[j][c], and
-// `a[r] -= X[j][c] * L[r][j]` is the same fused multiply-add with the same broadcast L[r][j] the factor lanes use).
-// X16 goes, transposed, to the upper triangle of the tile (where the doubling steps expect it) and lets step (c) be a
-// matrix-core product.
-// (Also tried, both slower: an UNNORMALISED elimination -- columns scaled by 1 / d_j, reciprocal square roots at the end,
-// so that the chain between pivots is reciprocal + one multiply-add -- 9.4k cycles per tile as the compiler orders it,
-// 10.9k with the other columns' updates deferred a step and fenced between the links of the next chain by hand.  The
-// routine is ~900 instructions of one wave at ~7 cycles each; reordering does not shorten it.)
-__device__ __forceinline__ void wave_diag16x(double* L, int LD, int o, int row0, int* info, double tol, double reg,
+// the 16 x 16 factor routine (one wave, the serial heart of the kernel: 8 x 7.1k of its ~100k cycles).  Lane r < 16 holds
+// row r of the tile in registers and column j is eliminated with v_readlane broadcasts of L[c][j].  Lanes 16 .. 31
+// compute X16 = L16^-1 ALONGSIDE, for free: lane 16 + c carries column c of X through the same instruction stream (its
+// a[r] starts as e_c; at step j its a[j] * rp is X[j][c], and `a[r] -= X[j][c] * L[r][j]` is the same fused multiply-add
+// with the same broadcast L[r][j] the factor lanes use).  X16 goes, transposed, to the upper triangle of the tile (where
+// the doubling steps expect it) and lets step (c) be a matrix-core product.
+// The routine is ISSUE bound, not latency bound (tools/issue_probe.hip, one wave, counter units: an fp64 FMA 6.4, a
+// v_readlane_b32 4 in a batch but 8 when the FMA that consumes it follows at once, rsqrt(double) ~100 for ten dependent
+// instructions; eliminating TWO columns per link of the dependent chain -- 1 / l22 = rsqrt(a c - b^2) l11, two independent
+// reciprocal square roots -- was built and measured: 8.1k per tile against 7.7k).  So it carries few instructions:
+//   * no row selects: the registers of a factor lane above its diagonal hold values nobody reads (lane c is read only
+//     for columns < c, and only the lower triangle is stored), and the diagonal lane's own a[j] * rp IS the pivot;
+//   * a vanishing pivot is a (uniform, rare) branch instead of selects on every column;
+//   * the reciprocal square root is v_rsq_f64 + one third-order correction without the special-value tests (d > tol >= 0
+//     is finite here);  1 / L[j][j] is the diagonal of the 16 x 16 inverse the lanes 16 .. 31 carry;
+//   * the readlanes of a column's updates are issued as a batch ahead of its FMAs, behind the update of column j + 1 and
+//     the next pivot's broadcast.
+// 7.7k -> 7.1k per tile against the select-based form of round 2 (~900 instructions -> ~760).  Also tried, slower: the tile
+// spread over all 64 lanes, 4 columns each, with ds_bpermute fetches (7.0k against the 6.6k of its time); an unnormalised
+// elimination (reciprocal square roots at the end: 9.4k); one LDS store of rp by all lanes (same address: 7.7k).
+__device__ __forceinline__ double rsqrt_pos(double d) {
+  const double y0 = __builtin_amdgcn_rsq(d);  // ~2^-23 relative
+  const double e = fma(-(d * y0), y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);  // y0 (1 + e / 2 + 3 e^2 / 8): ~e^3
+}
+__device__ __forceinline__ void wave_diag16(double* L, int LD, int o, int row0, int* info, double tol, double reg,
                                              double* dinv) {
   const int lane = threadIdx.x & 63;
   const int rl = lane & 15;
   const bool inv = (lane >> 4) == 1;
   double a[16];
+  {
+    const f64x2* row = reinterpret_cast<const f64x2*>(L + (o + rl) * LD + o);  // (16-byte aligned: LD and o are even)
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const double v = L[(o + rl) * LD + o + c];
-    a[c] = inv ? (c == rl ? 1.0 : 0.0) : v;
+    for (int c = 0; c < 16; c += 2) {
+      const f64x2 v = row[c / 2];
+      a[c] = inv ? (c == rl ? 1.0 : 0.0) : v[0];
+      a[c + 1] = inv ? (c + 1 == rl ? 1.0 : 0.0) : v[1];
+    }
   }
-  double rdiag = 1.0;  // this lane's 1 / L[rl][rl]
   const bool dyn = reg > 0.0;
   const double thr = dyn ? tol : 0.0, sub = dyn ? reg : 1.0;  // (a unit pivot keeps the kernel finite when none is set)
   int nbad = 0, first = 0;
+  double d = rdlane(a[0], 0);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    double d = rdlane(a[j], j);
-    const bool bad = !(d > thr);
-    first = (bad && nbad == 0) ? j + 1 : first;
-    nbad += bad ? 1 : 0;
-    d = bad ? sub : d;
-    const double rp = rsqrt(d);
-    const double piv = d * rp;
-    rdiag = rl == j ? rp : rdiag;
-    const double t = a[j] * rp;
-    const double l = inv ? t : (rl > j ? t : (rl == j ? piv : 0.0));
+    if (__builtin_expect(!(d > thr), 0)) {
+      first = nbad == 0 ? j + 1 : first;
+      ++nbad;
+      d = sub;
+      if (!inv && rl == j) a[j] = sub;
+    }
+    const double rp = rsqrt_pos(d);
+    const double l = a[j] * rp;
     a[j] = l;
+    if (j < 15) {
+      a[j + 1] = fma(-l, rdlane(l, j + 1), a[j + 1]);
+      d = rdlane(a[j + 1], j + 1);
+      double sc[16];
 #pragma unroll
-    for (int c = j + 1; c < 16; ++c) a[c] -= l * rdlane(l, c);
+      for (int c = j + 2; c < 16; ++c) sc[c] = rdlane(l, c);
+#pragma unroll
+      for (int c = j + 2; c < 16; ++c) a[c] = fma(-l, sc[c], a[c]);
+    }
   }
   if (lane < 16) {
-    dinv[o + lane] = rdiag;
 #pragma unroll
     for (int c = 0; c < 16; ++c)
       if (c <= lane) L[(o + lane) * LD + o + c] = a[c];  // L16, lower
   } else if (inv) {
+    // X16(r, rl), r > rl, transposed into the upper triangle; X16(rl, rl) = 1 * rp_rl, bit for bit, is 1 / L[rl][rl]
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      if (r > rl) L[(o + rl) * LD + o + r] = a[r];  // X16(r, rl), r > rl, transposed into the upper triangle
+      if (r >= rl) *(r == rl ? dinv + o + rl : L + (o + rl) * LD + o + r) = a[r];
   }
   if (lane == 0 && nbad) {
     if (dyn)
@@ -438,7 +457,7 @@ __global__ __launch_bounds__(kPotrfThreads5) void k_potrf_inv128m(double* Mkk, i
         for (int t = pb + 1 + wi; t < 8; t += 6) tile_update(t, pb, 0, o);
       }
     }
-    if (wave == 0) wave_diag16x(L, LD, o, row0, info, tol, reg, dinv);  // (b)
+    if (wave == 0) wave_diag16(L, LD, o, row0, info, tol, reg, dinv);  // (b)
     __syncthreads();
     POTRF_STAMP();
     // (c) tiles below: P <- P X16' on the matrix cores.  B[k][j] = X16(j, k): strictly lower entries from the transposed
