@@ -1964,8 +1964,12 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       else launch_updates<NL>(h, lu[0], cu[0], cu[1]);
       launch_spmv<NL>(h, TAG_A, LP, SPcur, SPcur, c0, c1, h->pS2);
     }
+    // A MINRES lane the host has SEEN finished (a zero right-hand side -- hprod! Val(1) on a model without curvature in the
+    // constraints --, or an early convergence): its stand-alone launches would exit at once, ~3.5 us each; skipped.  One GPU
+    // only: sharded, every rank would have to see it at the same iteration.  (Its riding / shared steps stay: they cost nothing.)
+    const bool mdead = minres_lane >= 0 && !h->comm && load_progress(&h->prog_host[minres_lane]).done;
     // MINRES: E1 on q (now in the current pair's lane) before its scalar step A
-    if (minres_lane >= 0) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
+    if (minres_lane >= 0 && !mdead) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
     StepArgs sb[2] = {none, none};
     for (int l = 0; l < NL; ++l) {
       if (lanes[l].kind == LANE_MINRES)
@@ -1978,8 +1982,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (minres_lane >= 0 && lead && NL == 2) {
       // MINRES' step A must run before E2; the other lane's step is only needed by the NEXT A' launch (its epilogue and its
       // riding update) and waits for MINRES' step B to ride there with it
-      if (int rc = launch_step(h, sb[minres_lane], none, /*sharded=*/true)) return rc;
-      launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
+      if (!mdead) {
+        if (int rc = launch_step(h, sb[minres_lane], none, /*sharded=*/true)) return rc;
+        launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
+      }
       StepArgs pair[2];
       pair[minres_lane] = step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0, prog[minres_lane]);
       pair[1 - minres_lane] = sb[1 - minres_lane];
@@ -1990,7 +1996,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       } else {
         if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
       }
-      if (minres_lane >= 0) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
+      if (minres_lane >= 0 && !mdead) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
         launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
         if (int rc = launch_step(h, step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
                                               prog[minres_lane]),
