@@ -34,6 +34,12 @@ struct fpsq_dense_s {
   // and the environment switches that selected them were removed in round 3.)
   double piv_tol = 0.0, piv_reg = 0.0;  // dynamic regularisation (fpsq_dense_set_regularization); reg <= 0: off
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  // the triangular sweeps in one launch each (k_trsv_chain): publication buffer, launch number, host-mapped error word
+  unsigned long long* chain_pub = nullptr;
+  unsigned long long* chain_err = nullptr;
+  unsigned int chain_seq = 0;
+  bool chain = true;  // FPSQ_TRSV_CHAIN=0: one launch per step (k_trsv_step3)
+  bool chain_break = false;  // FPSQ_DEBUG_CHAIN_BREAK=1 (tests): the workgroups publish a wrong launch number
   // jac_coord! hand-over (fpsq_dense_set_structure_coo): the caller's COO entries sorted by target, duplicates grouped
   int64_t coo_nnz = -1, coo_slots = 0;
   int32_t *coo_perm = nullptr, *coo_slotptr = nullptr;
@@ -106,6 +112,15 @@ int dmalloc(fpsq_dense d, T** p, size_t count) {
 void solve_two_rhs(fpsq_dense d) {
   hipStream_t s = d->stream;
   const int nb = (int)d->nb, ld = (int)d->mpad;
+  if (d->chain) {
+    ChainArgs c{d->chain_pub, ++d->chain_seq, 0, nb, 0, 0, 0, d->chain_err};
+    c.pubseq = d->chain_break ? ~c.seq : c.seq;
+    hipLaunchKernelGGL(k_trsv_chain<true>, dim3(nb), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, c);
+    c.seq = ++d->chain_seq;
+    c.pubseq = d->chain_break ? ~c.seq : c.seq;
+    hipLaunchKernelGGL(k_trsv_chain<false>, dim3(nb), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->y2, d->r2, c);
+    return;
+  }
   for (int k = 0; k < nb; ++k)
     hipLaunchKernelGGL(k_trsv_step3<true>, dim3(nb - k), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, k, 0);
   for (int k = nb - 1; k >= 0; --k)
@@ -129,6 +144,11 @@ int finish(fpsq_dense d, const double* a0, const double* a1, double* p1, double*
   DCHK(d, hipMemcpyAsync(q1, d->o_q1, (size_t)d->m * 8, hipMemcpyDefault, s));
   DCHK(d, hipMemcpyAsync(q2, d->o_q2, (size_t)d->m * 8, hipMemcpyDefault, s));
   DCHK(d, hipStreamSynchronize(s));
+  if (d->chain_err && *d->chain_err) {
+    *d->chain_err = 0;
+    d->err = "triangular sweep: a block's solution did not arrive (bounded wait expired); FPSQ_TRSV_CHAIN=0 avoids the path";
+    return FPSQ_ERR_TIMEOUT;
+  }
   float ms = 0.f;
   hipEventElapsedTime(&ms, d->e0, d->e1);
   d->info.last_solve_ms = ms;
@@ -188,6 +208,12 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   rc |= dmalloc(d, &d->o_q1, (size_t)d->mpad);
   rc |= dmalloc(d, &d->o_q2, (size_t)d->mpad);
   rc |= dmalloc(d, &d->info_dev, 4);
+  rc |= dmalloc(d, &d->chain_pub, (size_t)d->nb * 512);
+  if (!rc) hipMemset(d->chain_pub, 0, (size_t)d->nb * 512 * 8);
+  if (hipHostMalloc((void**)&d->chain_err, 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = 1;
+  else *d->chain_err = 0;
+  if (const char* e = getenv("FPSQ_TRSV_CHAIN")) d->chain = atoi(e) != 0;
+  if (const char* e = getenv("FPSQ_DEBUG_CHAIN_BREAK")) d->chain_break = atoi(e) != 0;
   if (rc) {
     g_dense_create_error = d->err;
     fpsq_dense_destroy(d);
@@ -211,6 +237,7 @@ int fpsq_dense_destroy(fpsq_dense d) {
   hipSetDevice(d->device);
   if (d->stream) hipStreamSynchronize(d->stream);
   for (void* p : d->allocs) hipFree(p);
+  if (d->chain_err) hipHostFree(d->chain_err);
   if (d->e0) hipEventDestroy(d->e0);
   if (d->e1) hipEventDestroy(d->e1);
   if (d->e2) hipEventDestroy(d->e2);
@@ -423,6 +450,10 @@ struct fpsq_band_s {
   double piv_tol = 0.0, piv_reg = 0.0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   hipStream_t stream2 = nullptr;  // the second elimination chain
+  unsigned long long* chain_pub = nullptr;  // k_trsv_chain, as in fpsq_dense_s
+  unsigned long long* chain_err = nullptr;
+  unsigned int chain_seq = 0;
+  bool chain = true, chain_break = false;
   hipEvent_t evA = nullptr, evB = nullptr;
   // jac_coord! hand-over (fpsq_band_create_coo): the caller's COO entries sorted into the CSR slots
   int64_t coo_nnz = -1;
@@ -620,6 +651,15 @@ inline size_t blk_off(const fpsq_band b, int64_t i, int64_t j) {  // block (i, j
 void band_solve(fpsq_band b) {
   hipStream_t s = b->stream;
   const int nb = (int)b->nb, bw = b->band_w - 1;
+  if (b->chain) {  // (both elimination chains advance side by side inside the one launch)
+    ChainArgs c{b->chain_pub, ++b->chain_seq, 0, nb, b->band_w, b->chain_safe, b->chain_bw, b->chain_err};
+    c.pubseq = b->chain_break ? ~c.seq : c.seq;
+    hipLaunchKernelGGL(k_trsv_chain<true>, dim3(nb), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT, b->r2, b->y2, c);
+    c.seq = ++b->chain_seq;
+    c.pubseq = b->chain_break ? ~c.seq : c.seq;
+    hipLaunchKernelGGL(k_trsv_chain<false>, dim3(nb), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT, b->y2, b->r2, c);
+    return;
+  }
   {
     int k0 = 0;
     const int cs = b->chain_safe, cb = b->chain_bw;
@@ -679,6 +719,11 @@ int band_finish(fpsq_band b, const double* a1, double* p1, double* q1, double* p
   BCHK(b, hipMemcpyAsync(q1, b->o_q1, (size_t)b->m * 8, hipMemcpyDefault, s));
   BCHK(b, hipMemcpyAsync(q2, b->o_q2, (size_t)b->m * 8, hipMemcpyDefault, s));
   BCHK(b, hipStreamSynchronize(s));
+  if (b->chain_err && *b->chain_err) {
+    *b->chain_err = 0;
+    b->err = "triangular sweep: a block's solution did not arrive (bounded wait expired); FPSQ_TRSV_CHAIN=0 avoids the path";
+    return FPSQ_ERR_TIMEOUT;
+  }
   float ms = 0.f;
   hipEventElapsedTime(&ms, b->e0, b->e1);
   b->info.last_solve_ms = ms;
@@ -747,6 +792,7 @@ int fpsq_band_destroy(fpsq_band b) {
   hipSetDevice(b->device);
   if (b->stream) hipStreamSynchronize(b->stream);
   for (void* p : b->allocs) hipFree(p);
+  if (b->chain_err) hipHostFree(b->chain_err);
   if (b->e0) hipEventDestroy(b->e0);
   if (b->e1) hipEventDestroy(b->e1);
   if (b->e2) hipEventDestroy(b->e2);
@@ -900,6 +946,12 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   rc |= bmalloc(b, &b->in_a, (size_t)n) | bmalloc(b, &b->in_b, (size_t)std::max(n, b->mpad));
   rc |= bmalloc(b, &b->o_p1, (size_t)n) | bmalloc(b, &b->o_p2, (size_t)n);
   rc |= bmalloc(b, &b->o_q1, (size_t)b->mpad) | bmalloc(b, &b->o_q2, (size_t)b->mpad) | bmalloc(b, &b->info_dev, 4);
+  rc |= bmalloc(b, &b->chain_pub, (size_t)b->nb * 512);
+  if (!rc) hipMemset(b->chain_pub, 0, (size_t)b->nb * 512 * 8);
+  if (hipHostMalloc((void**)&b->chain_err, 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = 1;
+  else *b->chain_err = 0;
+  if (const char* e = getenv("FPSQ_TRSV_CHAIN")) b->chain = atoi(e) != 0;
+  if (const char* e = getenv("FPSQ_DEBUG_CHAIN_BREAK")) b->chain_break = atoi(e) != 0;
   b->reordered = !rperm_h.empty();
   b->rperm_host = rperm_h;
   if (b->reordered)

@@ -784,6 +784,151 @@ __global__ __launch_bounds__(256) void k_trsv_step3(const double* __restrict__ L
   }
 }
 
+// ---- the whole sweep in ONE launch (the default; FPSQ_TRSV_CHAIN=0 selects the step kernels above).  A sweep is a chain of
+// nb links and a launch per link costs ~3.5 us of dispatch before its single memory round trip starts (8.5 / 6.3 us per
+// forward / backward step).  Here workgroup w owns block b (forward: b = w, backward: b = nb - 1 - w) and PULLS: for every
+// coupled block j eliminated before b it takes the solved y_j from the publication buffer, subtracts L_bj y_j (forward) or
+// L_jb' q_j (backward) from its own right-hand side -- kept in registers, thread t <-> entry t of the [128][2] block --, then
+// solves with the diagonal inverse and publishes.  Publication as in the product kernels' leader records (fpsq_spmv.hip.h):
+// every 8-byte word carries half a double and the launch number `seq`, written through and read with agent-scope atomics,
+// so a reader that sees the number sees the payload: no flag, no fence, one round trip per look, and the look IS the
+// fetch.  Dependencies point to workgroups with a LOWER index only, which the dispatcher has placed before (workgroups of
+// an XCD are dispatched in order): no circular wait; and every wait is bounded (kChainPolls looks, then the error word is
+// raised and the workgroup goes on publishing, so nobody behind it waits in turn; the call fails with FPSQ_ERR_TIMEOUT).
+// coupled(b, j) for the banded factor with two elimination chains (fpsq_band_create): inside the chain region (both < 2 cs)
+// only blocks of the same parity within 2 cb; otherwise the plain band |b - j| <= w.  Dense: w = nb, cs = 0.
+// The off-diagonal block of a link is requested BEFORE the look at y_j: it is in flight while the workgroup waits.
+constexpr int kChainPolls = 1 << 20;
+struct ChainArgs {
+  unsigned long long* pub;  // [nb][512]: block j's 256 doubles as (high half | seq), (low half << 32 | seq)
+  unsigned int seq;
+  unsigned int pubseq;      // what a workgroup publishes: `seq` (anything else only in the test of the bounded wait)
+  int nb, band_w, cs, cb;
+  unsigned long long* err;  // host-mapped
+};
+__device__ __forceinline__ bool chain_coupled(const ChainArgs& c, int b, int j) {
+  const int w = c.band_w > 0 ? c.band_w - 1 : c.nb;
+  const int d = b > j ? b - j : j - b;
+  if (b < 2 * c.cs && j < 2 * c.cs) return (d & 1) == 0 && d <= 2 * c.cb;
+  return d <= w;
+}
+// this thread's entry of block j's published vector (bounded wait)
+__device__ __forceinline__ double chain_take(const ChainArgs& c, int j) {
+  const unsigned long long* p = c.pub + (size_t)j * 512 + 2 * threadIdx.x;
+  unsigned long long w0, w1;
+  int n = 0;
+  for (;;) {
+    w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (((unsigned int)w0 == c.seq && (unsigned int)w1 == c.seq) || ++n >= kChainPolls) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  if (n >= kChainPolls) __hip_atomic_store(c.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __longlong_as_double((long long)((w0 & 0xffffffff00000000ull) | (w1 >> 32)));
+}
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_trsv_chain(const double* __restrict__ Lm, int ld, const double* __restrict__ inv,
+                                                    const double* __restrict__ invT, const double* __restrict__ r, double* out,
+                                                    ChainArgs c) {
+  __shared__ double rk[kDB * 2];
+  __shared__ double part[2][kDB * 2];
+  __shared__ double yk[kDB * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = FORWARD ? (int)blockIdx.x : c.nb - 1 - (int)blockIdx.x;
+  const int i = tid & 127, hf = tid >> 7;
+  const double* Xc = (FORWARD ? invT : inv) + (size_t)b * kDB * kDB + (size_t)(hf * 64) * kDB + i;
+  const bool xskip = FORWARD ? (hf == 1 && i < 64) : (hf == 0 && i >= 64);  // (wave-uniform) all-zero part of the triangle
+  double xs[64];
+  if (!xskip) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q) xs[q] = Xc[(size_t)q * kDB];
+  }
+  double racc = r[(size_t)b * (kDB * 2) + tid];
+  const int band_w = c.band_w;
+  const size_t lds = band_w > 0 ? (size_t)kDB : (size_t)ld;
+  const int w = band_w > 0 ? band_w - 1 : c.nb;
+  if (FORWARD) {
+    for (int j = max(0, b - w); j < b; ++j) {
+      if (!chain_coupled(c, b, j)) continue;
+      // block (b, j), rows 32 wave .. + 31, lanes along the columns
+      const double* Lb = (band_w > 0 ? Lm + ((size_t)b * band_w + (j - b + band_w - 1)) * kDB * kDB
+                                     : Lm + (size_t)(b * kDB) * ld + j * kDB) + (size_t)(wave * 32) * lds + lane;
+      double lb[64];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        lb[2 * u] = Lb[(size_t)u * lds];
+        lb[2 * u + 1] = Lb[(size_t)u * lds + 64];
+      }
+      yk[tid] = chain_take(c, j);
+      __syncthreads();
+      const double y00 = yk[lane * 2], y01 = yk[lane * 2 + 1], y10 = yk[(lane + 64) * 2], y11 = yk[(lane + 64) * 2 + 1];
+      double v[64];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        v[2 * u] = lb[2 * u] * y00 + lb[2 * u + 1] * y10;
+        v[2 * u + 1] = lb[2 * u] * y01 + lb[2 * u + 1] * y11;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int idx = 0; idx < off; ++idx) {
+          const double send = hi ? v[idx] : v[idx + off];
+          const double keep = hi ? v[idx + off] : v[idx];
+          v[idx] = keep + __shfl_xor(send, off, 64);
+        }
+      }
+      racc -= v[0];
+      __syncthreads();  // (yk is overwritten by the next link)
+    }
+  } else {
+    for (int j = min(c.nb - 1, b + w); j > b; --j) {
+      if (!chain_coupled(c, b, j)) continue;
+      // block (j, b) read by columns: column i, rows of this thread's half
+      const double* Lb = (band_w > 0 ? Lm + ((size_t)j * band_w + (b - j + band_w - 1)) * kDB * kDB
+                                     : Lm + (size_t)(j * kDB) * ld + b * kDB) + (size_t)(hf * 64) * lds + i;
+      double lb[64];
+#pragma unroll
+      for (int q = 0; q < 64; ++q) lb[q] = Lb[(size_t)q * lds];
+      yk[tid] = chain_take(c, j);
+      __syncthreads();
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 64; ++q) {
+        s0 += lb[q] * yk[(hf * 64 + q) * 2];
+        s1 += lb[q] * yk[(hf * 64 + q) * 2 + 1];
+      }
+      part[hf][i * 2] = s0;
+      part[hf][i * 2 + 1] = s1;
+      __syncthreads();
+      racc -= part[0][tid] + part[1][tid];
+      __syncthreads();  // (part and yk are overwritten by the next link)
+    }
+  }
+  // forward: y_i = sum_{p <= i} X'[p][i] r_p;   backward: q_i = sum_{p >= i} X[p][i] y_p   (p in this thread's half)
+  rk[tid] = racc;
+  __syncthreads();
+  {
+    double s0 = 0.0, s1 = 0.0;
+    if (!xskip) {
+#pragma unroll
+      for (int q = 0; q < 64; ++q) {
+        s0 += xs[q] * rk[(hf * 64 + q) * 2];
+        s1 += xs[q] * rk[(hf * 64 + q) * 2 + 1];
+      }
+    }
+    part[hf][i * 2] = s0;
+    part[hf][i * 2 + 1] = s1;
+  }
+  __syncthreads();
+  const double y = part[0][tid] + part[1][tid];
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(y);
+  unsigned long long* p = c.pub + (size_t)b * 512 + 2 * tid;
+  __hip_atomic_store(p, (bits & 0xffffffff00000000ull) | c.pubseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p + 1, (bits << 32) | c.pubseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  out[(size_t)b * (kDB * 2) + tid] = y;
+}
+
 // ---- sparse direct path (fpsq_band): M = A A' + delta I of a BANDED sparse Jacobian as a block band
 // One workgroup per 128-row block I.  For each of its rows i in turn: scatter the row into a dense LDS window over its
 // column span, then every thread takes rows j <= i of the band (blocks I - bw .. I) and gathers its dot product with

@@ -606,3 +606,61 @@ def test_config3_objgrad_through_the_seam_with_a_device_resident_model():
     print(f"\nconfig3 objgrad through the seam (device-resident model): {med:.2f} ms wall, device {qds.info()}")
     assert med < 6.0   # (the round's target is 3 ms on an idle box; loose bound against a loaded one)
     qds.close()
+
+
+# ------------------------------------------------------------------------ triangular sweeps: one launch vs one launch per step
+
+@pytest.mark.parametrize("kind", ["dense", "band", "band-two-chains"])
+def test_chained_sweeps_match_the_step_kernels(oracle, monkeypatch, kind):
+    """The triangular sweeps run as ONE launch each by default (k_trsv_chain: every block's workgroup pulls the solved blocks
+    it depends on from a publication buffer); FPSQ_TRSV_CHAIN=0 keeps the one-launch-per-step kernels (k_trsv_step3).  Same
+    sums in the same order per block: the two must agree to rounding (1e-13 relative) and both with the exact KKT solve --
+    dense with several block rows, banded with a single elimination chain, banded with two chains side by side."""
+    from fps_amd import problems
+
+    rng = np.random.default_rng(3)
+    outs = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("FPSQ_TRSV_CHAIN", chain)
+        if kind == "dense":
+            m, n = 700, 1500
+            A = np.random.default_rng(5).uniform(-1, 1, (m, n)) / np.sqrt(n)
+            H = _Dense(A)
+        else:
+            m, n, window = (3000, 6000, 5000) if kind == "band" else (7700, 30000, 600)
+            qp = problems.pde_control_like(n=n, m=m, per_row=12, window=window, seed=11)
+            A = qp.scipy_csr()
+            H = _Band(A)
+            assert H.info()["chains"] == (2 if kind == "band-two-chains" else 1)
+        g, c = np.random.default_rng(6).standard_normal(n), np.random.default_rng(7).standard_normal(m)
+        rc, info = H.factorize(0.25)
+        assert rc == 0
+        fn = H.lib.fpsq_dense_solve_two_mixed if kind == "dense" else H.lib.fpsq_band_solve_two_mixed
+        outs[chain] = H.solve(fn, g, c)
+        H.close()
+    want = oracle.exact_two_mixed(A, 0.25, g, c)
+    for a, b, w in zip(outs["1"], outs["0"], want):
+        assert _rel(a, b) < 1e-13 and _rel(a, w) < 1e-10
+
+
+def test_chained_sweep_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
+    """Every wait of the chained sweep has an end each wave reaches: with the workgroups made to publish a wrong launch number
+    (FPSQ_DEBUG_CHAIN_BREAK=1) the readers give up after their bounded number of looks, raise the handle's error word and go
+    on; the solve returns FPSQ_ERR_TIMEOUT (-5) with a message, within seconds.  A fresh handle without the switch works."""
+    A = np.random.default_rng(1).uniform(-1, 1, (300, 700)) / np.sqrt(700)
+    g, c = np.ones(700), np.ones(300)
+    monkeypatch.setenv("FPSQ_DEBUG_CHAIN_BREAK", "1")
+    D = _Dense(A)
+    D.factorize(0.25)
+    outs = [np.empty(700), np.empty(300), np.empty(700), np.empty(300)]
+    t0 = time.perf_counter()
+    rc = D.lib.fpsq_dense_solve_two_mixed(D.d, g.ctypes.data, c.ctypes.data, *[o.ctypes.data for o in outs])
+    assert rc == -5 and b"bounded wait" in D.lib.fpsq_dense_last_error(D.d)
+    assert time.perf_counter() - t0 < 60.0
+    D.close()
+    monkeypatch.setenv("FPSQ_DEBUG_CHAIN_BREAK", "0")
+    D = _Dense(A)
+    D.factorize(0.25)
+    outs = D.solve(D.lib.fpsq_dense_solve_two_mixed, g, c)
+    assert all(np.all(np.isfinite(o)) for o in outs)
+    D.close()
