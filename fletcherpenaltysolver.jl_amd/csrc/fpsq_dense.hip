@@ -208,8 +208,8 @@ int fpsq_dense_create(fpsq_dense* out, int64_t n, int64_t m, int32_t device) {
   rc |= dmalloc(d, &d->o_q1, (size_t)d->mpad);
   rc |= dmalloc(d, &d->o_q2, (size_t)d->mpad);
   rc |= dmalloc(d, &d->info_dev, 4);
-  rc |= dmalloc(d, &d->chain_pub, (size_t)d->nb * 512);
-  if (!rc) hipMemset(d->chain_pub, 0, (size_t)d->nb * 512 * 8);
+  rc |= dmalloc(d, &d->chain_pub, (size_t)d->nb * 512 + 8);  // (+ the abort word)
+  if (!rc) hipMemset(d->chain_pub, 0, ((size_t)d->nb * 512 + 8) * 8);
   if (hipHostMalloc((void**)&d->chain_err, 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = 1;
   else *d->chain_err = 0;
   if (const char* e = getenv("FPSQ_TRSV_CHAIN")) d->chain = atoi(e) != 0;
@@ -946,8 +946,8 @@ int fpsq_band_create(fpsq_band* out, int64_t n, int64_t m, const int32_t* rowptr
   rc |= bmalloc(b, &b->in_a, (size_t)n) | bmalloc(b, &b->in_b, (size_t)std::max(n, b->mpad));
   rc |= bmalloc(b, &b->o_p1, (size_t)n) | bmalloc(b, &b->o_p2, (size_t)n);
   rc |= bmalloc(b, &b->o_q1, (size_t)b->mpad) | bmalloc(b, &b->o_q2, (size_t)b->mpad) | bmalloc(b, &b->info_dev, 4);
-  rc |= bmalloc(b, &b->chain_pub, (size_t)b->nb * 512);
-  if (!rc) hipMemset(b->chain_pub, 0, (size_t)b->nb * 512 * 8);
+  rc |= bmalloc(b, &b->chain_pub, (size_t)b->nb * 512 + 8);  // (+ the abort word)
+  if (!rc) hipMemset(b->chain_pub, 0, ((size_t)b->nb * 512 + 8) * 8);
   if (hipHostMalloc((void**)&b->chain_err, 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) rc = 1;
   else *b->chain_err = 0;
   if (const char* e = getenv("FPSQ_TRSV_CHAIN")) b->chain = atoi(e) != 0;

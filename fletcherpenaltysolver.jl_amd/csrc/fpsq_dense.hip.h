@@ -794,13 +794,15 @@ __global__ __launch_bounds__(256) void k_trsv_step3(const double* __restrict__ L
 // so a reader that sees the number sees the payload: no flag, no fence, one round trip per look, and the look IS the
 // fetch.  Dependencies point to workgroups with a LOWER index only, which the dispatcher has placed before (workgroups of
 // an XCD are dispatched in order): no circular wait; and every wait is bounded (kChainPolls looks, then the error word is
-// raised and the workgroup goes on publishing, so nobody behind it waits in turn; the call fails with FPSQ_ERR_TIMEOUT).
+// raised and the workgroup goes on publishing, so nobody behind it waits in turn; an abort word behind the buffer, set with
+// it and looked at before and during every wait, keeps the waits that are still to come short: a failed sweep ends after ONE
+// waiting time, not one per link; the call fails with FPSQ_ERR_TIMEOUT).
 // coupled(b, j) for the banded factor with two elimination chains (fpsq_band_create): inside the chain region (both < 2 cs)
 // only blocks of the same parity within 2 cb; otherwise the plain band |b - j| <= w.  Dense: w = nb, cs = 0.
 // The off-diagonal block of a link is requested BEFORE the look at y_j: it is in flight while the workgroup waits.
 constexpr int kChainPolls = 1 << 20;
 struct ChainArgs {
-  unsigned long long* pub;  // [nb][512]: block j's 256 doubles as (high half | seq), (low half << 32 | seq)
+  unsigned long long* pub;  // [nb][512]: block j's 256 doubles as (high half | seq), (low half << 32 | seq); [nb * 512]: abort
   unsigned int seq;
   unsigned int pubseq;      // what a workgroup publishes: `seq` (anything else only in the test of the bounded wait)
   int nb, band_w, cs, cb;
@@ -815,15 +817,20 @@ __device__ __forceinline__ bool chain_coupled(const ChainArgs& c, int b, int j) 
 // this thread's entry of block j's published vector (bounded wait)
 __device__ __forceinline__ double chain_take(const ChainArgs& c, int j) {
   const unsigned long long* p = c.pub + (size_t)j * 512 + 2 * threadIdx.x;
+  unsigned long long* ab = c.pub + (size_t)c.nb * 512;
   unsigned long long w0, w1;
-  int n = 0;
+  int n = __hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.seq ? kChainPolls : 0;
   for (;;) {
     w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (((unsigned int)w0 == c.seq && (unsigned int)w1 == c.seq) || ++n >= kChainPolls) break;
+    if ((n & 1023) == 0 && __hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.seq) n = kChainPolls - 1;
     __builtin_amdgcn_s_sleep(2);
   }
-  if (n >= kChainPolls) __hip_atomic_store(c.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (n >= kChainPolls) {
+    __hip_atomic_store(ab, (unsigned long long)c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   return __longlong_as_double((long long)((w0 & 0xffffffff00000000ull) | (w1 >> 32)));
 }
 template <bool FORWARD>

@@ -647,7 +647,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       v[k] = M.vals[ii];
     }
   };
-  const bool is_prod = bid < 8 * grp_per_xcd && g < M.ng;
   [[maybe_unused]] unsigned long long look = 0;
   if constexpr (LEAD) {
     if (bid >= 8 * grp_per_xcd) {  // a riding-update workgroup

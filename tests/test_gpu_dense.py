@@ -646,17 +646,18 @@ def test_chained_sweeps_match_the_step_kernels(oracle, monkeypatch, kind):
 def test_chained_sweep_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
     """Every wait of the chained sweep has an end each wave reaches: with the workgroups made to publish a wrong launch number
     (FPSQ_DEBUG_CHAIN_BREAK=1) the readers give up after their bounded number of looks, raise the handle's error word and go
-    on; the solve returns FPSQ_ERR_TIMEOUT (-5) with a message, within seconds.  A fresh handle without the switch works."""
-    A = np.random.default_rng(1).uniform(-1, 1, (300, 700)) / np.sqrt(700)
-    g, c = np.ones(700), np.ones(300)
+    on; the solve returns FPSQ_ERR_TIMEOUT (-5) with a message, within seconds -- ONE waiting time for the whole sweep, not one
+    per link (the abort word: 11 block rows here, the last one with 10 links).  A fresh handle without the switch works."""
+    A = np.random.default_rng(1).uniform(-1, 1, (1400, 2000)) / np.sqrt(2000)
+    g, c = np.ones(2000), np.ones(1400)
     monkeypatch.setenv("FPSQ_DEBUG_CHAIN_BREAK", "1")
     D = _Dense(A)
     D.factorize(0.25)
-    outs = [np.empty(700), np.empty(300), np.empty(700), np.empty(300)]
+    outs = [np.empty(2000), np.empty(1400), np.empty(2000), np.empty(1400)]
     t0 = time.perf_counter()
     rc = D.lib.fpsq_dense_solve_two_mixed(D.d, g.ctypes.data, c.ctypes.data, *[o.ctypes.data for o in outs])
     assert rc == -5 and b"bounded wait" in D.lib.fpsq_dense_last_error(D.d)
-    assert time.perf_counter() - t0 < 60.0
+    assert time.perf_counter() - t0 < 30.0
     D.close()
     monkeypatch.setenv("FPSQ_DEBUG_CHAIN_BREAK", "0")
     D = _Dense(A)
