@@ -408,6 +408,10 @@ def test_fused_qp_entries_on_awkward_structures(oracle, kind):
         rch = dev.hprod(v, hv, 2)
         oh = oracle.qp_hprod(qp, v, 1e3, 1.0, 0.25)
         assert rch == oh["rc"] and _rel(hv, oh["Hv"]) < 1e-4
+        # Val(1): + the LSQR / MINRES lanes of solve_two_extras (their steps ride with leaders too)
+        rch = dev.hprod(v, hv, 1)
+        oh = oracle.qp_hprod(qp, v, 1e3, 1.0, 0.25, approx=1)
+        assert rch == oh["rc"] and _rel(hv, oh["Hv"]) < 1e-4
     dev.close()
 
 
