@@ -440,6 +440,9 @@ def main():
     torch.cuda.synchronize()
 
     def make_step(mdl, pts, out):
+        if not host_ptr:
+            pts = pts.unbind(0)  # (the row handles once, outside the timed region: the points themselves are resident already)
+
         def step(t):
             if hfull:
                 return None, mdl.hprod(pts[t], hp_out[0], args.hessian_approx)

@@ -155,6 +155,9 @@ def producer_stream(*args):
         if getattr(a, "is_cuda", False):
             import torch
 
+            raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+            if raw is not None:  # (the raw handle without building a Stream object: ~0.3 us instead of ~5 per call)
+                return int(raw(a.device.index))
             return int(torch.cuda.current_stream(a.device).cuda_stream)
     return None
 
