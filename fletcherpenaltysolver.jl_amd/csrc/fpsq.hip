@@ -1696,15 +1696,26 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   UpdSeg winit[2] = {seg_none(), seg_none()};
   bool craig_begun = false;
   if (any_lsqr) {
-    if (int rc = launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none, /*sharded=*/h->halo)) return rc;
     // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes.  The CRAIG lane is parked by ctl.skip -- unless its
     // right-hand side is still to be formed (fast start): then it rides along with the constant pair (-1, +1):
     // SP[.][l] <- -A z + shift, and the norm partials of the launch are those of its right-hand side.
-    {
-      const LaneCtl* s0c = c0;
-      const LaneCtl* s1c = c1;
-      if (affine_lane == 0) s0c = h->ctl_mp;
-      if (affine_lane == NL - 1 && affine_lane >= 0) s1c = h->ctl_mp;
+    const LaneCtl* s0c = c0;
+    const LaneCtl* s1c = c1;
+    if (affine_lane == 0) s0c = h->ctl_mp;
+    if (affine_lane == NL - 1 && affine_lane >= 0) s1c = h->ctl_mp;
+    if (lead && !h->comm && fuse_upd) {
+      // riding steps: beta_1 of the LSQR lanes goes with THIS product's leaders too; a lane without a step of its own has the
+      // control block it brings to this product published as it is (ride_leader, kind NONE)
+      pend[0] = b0;
+      pend[1] = b1;
+      have_pend = true;
+      const StepArgs* pre = pre_args(false);
+      if (pend[0].kind == STEP_NONE) pend[0].state = const_cast<LaneCtl*>(s0c);
+      if (pend[1].kind == STEP_NONE) pend[1].state = const_cast<LaneCtl*>(s1c);
+      launch_spmv<NL>(h, TAG_A, LP, SP, SP, s0c, s1c, h->pS2, seg_none(), seg_none(), false, pre);
+      adopt_pend();
+    } else {
+      if (int rc = launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none, /*sharded=*/h->halo)) return rc;
       launch_spmv<NL>(h, TAG_A, LP, SP, SP, s0c, s1c, h->pS2);
     }
     StepArgs s0 = none, s1 = none;
