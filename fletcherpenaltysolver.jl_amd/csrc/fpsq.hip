@@ -1694,7 +1694,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   // (every vector a rank updates is its own).  Sharded with replicated n-vectors: separate update launch, in place.
   const bool fuse_upd = local_vec;
   UpdSeg winit[2] = {seg_none(), seg_none()};
-  bool craig_begun = false;
+  bool craig_begun = false, minres_begun = false;
   if (any_lsqr) {
     // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes.  The CRAIG lane is parked by ctl.skip -- unless its
     // right-hand side is still to be formed (fast start): then it rides along with the constant pair (-1, +1):
@@ -1748,6 +1748,11 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
             s1 = step_args(kind, lanes[l], 0, h->pEm[l], gm, nullptr, 0, prog[l]);
           craig_begun = true;
         }
+      // (riding steps: a MINRES lane's beta_1 step -- it un-parks the lane: must follow the start-up product -- pairs up too)
+      if (!s1.kind && lead && !h->comm && minres_lane == 1) {
+        s1 = step_args(STEP_MINRES_BEGIN, lanes[1], 0, h->pEm[1], gm, nullptr, 0, prog[1]);
+        minres_begun = true;
+      }
     }
     if (affine_lane >= 0) {  // keep A z - shift = -rhs before the first A product overwrites the lane
       UpdSeg u = seg_none();
@@ -1779,7 +1784,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
                                none, /*sharded=*/true))
         return rc;
 
-  if (minres_lane >= 0)  // (un-parks the lane: must follow the LSQR lane's start-up product)
+  if (minres_lane >= 0 && !minres_begun)  // (un-parks the lane: must follow the LSQR lane's start-up product)
     if (int rc = launch_step(h, step_args(STEP_MINRES_BEGIN, lanes[minres_lane], 0, h->pEm[minres_lane], gm,
                                           nullptr, 0, prog[minres_lane]),
                              none, /*sharded=*/true))
