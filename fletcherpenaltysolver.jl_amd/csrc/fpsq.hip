@@ -742,8 +742,7 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
     if (const char* ev = std::getenv("FPSQ_RGCS_TILES"))  // tuning override: tiles per group
       budget = (int)(std::max<int64_t>(1, std::min<int64_t>(kmax, std::atoi(ev))) * kRgcsTile);
   }
-  int64_t r = 0;
-  while (r < H.nrows) {
+  auto group_end = [&](int64_t r) {
     int64_t r1 = r, nz = 0;
     while (r1 < H.nrows && r1 - r < kRgcsMaxRows) {
       const int64_t len = H.rowptr[r1 + 1] - H.rowptr[r1];
@@ -751,6 +750,39 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
       nz += len;
       ++r1;
     }
+    return r1;
+  };
+  // ORDER OF THE ENTRIES INSIDE A GROUP: by column PHASE, (col mod P), P = the typical width of a group's column window.
+  // A workgroup sweeps its window tile by tile while all the groups of an XCD are resident together.  Sorted by column proper,
+  // group g reads column c when its sweep gets there -- (c - cmin_g) / width of the way through the launch -- and the ~9
+  // neighbouring groups whose windows overlap in c (PDE-like rows: the window moves by a fraction of its width from group to
+  // group) read it at nine different times, spread over the whole launch, while the matrix streams through the same L2:
+  // the x window was fetched 2.6 times (profiles/r03_pmc_traffic.json: 1.15 x the product's algorithmic bytes).  Sorted by
+  // phase every group is at the same ABSOLUTE columns at the same time -- a rotation of its column order, any order is valid
+  // -- and the overlap is served by the L2.  Windows as wide as the matrix (random patterns): P covers it, plain column order.
+  int64_t P = INT64_MAX;
+  {
+    std::vector<int64_t> widths;
+    for (int64_t r = 0; r < H.nrows;) {
+      const int64_t r1 = group_end(r);
+      int64_t cmin = INT64_MAX, cmax = -1;
+      for (int64_t k = H.rowptr[r]; k < H.rowptr[r1]; ++k) {
+        cmin = std::min<int64_t>(cmin, H.colind[k]);
+        cmax = std::max<int64_t>(cmax, H.colind[k]);
+      }
+      if (cmax >= cmin) widths.push_back(cmax - cmin + 1);
+      r = r1;
+    }
+    if (!widths.empty()) {
+      std::nth_element(widths.begin(), widths.begin() + widths.size() / 2, widths.end());
+      P = std::max<int64_t>(1, widths[widths.size() / 2]);
+    }
+    if (const char* ev = std::getenv("FPSQ_RGCS_PHASE"))  // 0: plain column order (A/B)
+      if (std::atoi(ev) == 0) P = INT64_MAX;
+  }
+  int64_t r = 0;
+  while (r < H.nrows) {
+    const int64_t r1 = group_end(r);
     const int R = (int)(r1 - r);
     const int e0 = H.rowptr[r], e1 = H.rowptr[r1], cnt = e1 - e0;
     int cmin = INT32_MAX, cmax = -1;
@@ -765,7 +797,11 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
       for (int k = H.rowptr[r + rr]; k < H.rowptr[r + rr + 1]; ++k) lrow[k - e0] = rr;
     ord.resize(cnt);
     for (int k = 0; k < cnt; ++k) ord[k] = k;
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return H.colind[e0 + a] < H.colind[e0 + b]; });
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+      const int64_t ca = H.colind[e0 + a], cb = H.colind[e0 + b];
+      const int64_t pa = ca % P, pb = cb % P;
+      return pa != pb ? pa < pb : ca < cb;
+    });
     const int ntile = (cnt + kRgcsTile - 1) / kRgcsTile;
     const int32_t tp_start = (int32_t)tptr.size();
     for (int t = 0; t < ntile; ++t) {
