@@ -797,9 +797,11 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
       for (int k = H.rowptr[r + rr]; k < H.rowptr[r + rr + 1]; ++k) lrow[k - e0] = rr;
     ord.resize(cnt);
     for (int k = 0; k < cnt; ++k) ord[k] = k;
+    // (a group much wider than the typical window would interleave several column ranges in one tile: plain order for it)
+    const int64_t Pg = (int64_t)cmax - cmin + 1 > P + P / 2 ? INT64_MAX : P;
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
       const int64_t ca = H.colind[e0 + a], cb = H.colind[e0 + b];
-      const int64_t pa = ca % P, pb = cb % P;
+      const int64_t pa = ca % Pg, pb = cb % Pg;
       return pa != pb ? pa < pb : ca < cb;
     });
     const int ntile = (cnt + kRgcsTile - 1) / kRgcsTile;
