@@ -958,6 +958,41 @@ def test_speculative_epilogue_every_alignment_is_bitwise_neutral(delta):
     dev.close()
 
 
+def test_column_phase_order_of_the_row_groups_is_a_reordering_only(oracle, monkeypatch):
+    """The entries of a row group of the A-product layout are stored sorted by column PHASE, (col mod P) -- a rotation of the
+    group's column order that lets all resident groups sweep the same absolute columns at the same time (the x window is
+    then served by the L2 instead of being fetched again).  Any order of a group's entries is valid: against a handle with
+    the plain column order (FPSQ_RGCS_PHASE=0) the plain products agree to rounding (different tiles, so different
+    summation orders: 1e-13), the recurrences take the same number of iterations and objgrad agrees to 1e-9 -- and both
+    with the C restatement as before."""
+    qp = _small_pde(seed=17, n=60000, m=6000)
+    monkeypatch.setenv("FPSQ_RGCS_PHASE", "0")
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+    monkeypatch.setenv("FPSQ_RGCS_PHASE", "1")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+    rng = np.random.default_rng(4)
+    A = qp.scipy_csr()
+    x = qp.xhat + 0.3 * rng.standard_normal(qp.n)
+    ys_ = []
+    for mdl in (ref, dev):
+        y = np.zeros(qp.m)
+        mdl.jac_mul(False, 1.0, x, 0.0, y)
+        ys_.append(y)
+    want = A @ x
+    assert _rel(ys_[0], want) < 1e-13 and _rel(ys_[1], want) < 1e-13
+    out = []
+    for mdl in (ref, dev):
+        gx, ys = np.empty(qp.n), np.empty(qp.m)
+        f, rc = mdl.objgrad(x, gx=gx, ys=ys)
+        out.append((f, rc, gx, ys, mdl.stats[0].niter, mdl.stats[1].niter))
+    assert out[0][1] == out[1][1] and out[0][4:] == out[1][4:]
+    assert abs(out[0][0] - out[1][0]) <= 1e-9 * abs(out[0][0]) and _rel(out[0][2], out[1][2]) < 1e-9 and _rel(out[0][3], out[1][3]) < 1e-9
+    o = oracle.qp_objgrad(qp, x, 1e3, 1.0, 0.0)
+    assert out[1][1] == o["rc"] and _rel(out[1][2], o["gx"]) < 1e-6
+    ref.close()
+    dev.close()
+
+
 @pytest.mark.parametrize("lead", ["0", "1"])
 @pytest.mark.parametrize("delta", [0.0, SE])
 def test_column_sorted_at_blocks_are_bitwise_the_row_order_layout(monkeypatch, delta, lead):
