@@ -387,6 +387,11 @@ struct fpsq_solver_s {
   double *Lw[2], *Lx[2], *Cw, *Cy, *in_m, *ys, *c, *Mr[2], *Mw[2], *Mx;
   // partial-sum buffers
   double *pS, *pS2, *pW[2], *pE, *pE2, *pE3, *pQ[2], *pC[2];
+  // second halves of the update partials.  A riding step and a riding update of ONE launch must never share an array:
+  // the leaders of the step (sixteen workgroups, any of which another kernel may hold up) read, the update workgroups --
+  // released by the record of their own XCC's leader -- write.  LSQR's / CRAIG's update partials therefore alternate
+  // between pW[l] and pWalt[l] by iteration (run_krylov: upd_part), MINRES' stage E3 writes pWalt where E2 writes pW.
+  double* pWalt[2];
   double* pEm[2];               // squared-norm partials of the m-vector right-hand sides (pE / pE2: of the n-vector ones)
   int npS = 0;
   int strT = 0, strA = 0;       // lane strides of pS (A' product partials) and pS2 (A product partials)
@@ -400,6 +405,7 @@ struct fpsq_solver_s {
   unsigned long long ride_seq = 0;
   bool ride_lead = true;        // FPSQ_RIDE_LEAD=0: large grids keep the stand-alone k_step
   bool ride_break = false;      // FPSQ_DEBUG_RIDE_BREAK=1 (tests): the leaders publish a wrong launch number, every wait expires
+  int ride_delay = 0;           // FPSQ_DEBUG_RIDE_DELAY=c+1 (tests): leader c of every launch starts ~100 us late
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   MinresState* minres;
@@ -424,7 +430,9 @@ struct fpsq_solver_s {
   double* halo_raw = nullptr;   // [(ovl + ovr)][2]: this rank's raw sums there (k_spmv<.., HALO>), head region first
   int halo_gf = 0;              // workgroups of k_halo_finish (0: no overlap at all)
   // Halo mode keeps every partial-sum array of the Krylov loop in ONE per-rank segment `seg`, laid out
-  //   [E0 | E1 | M0 | M1 | T0 | T1 | A0 | A1 | W0 | W1 | E3]   (pE, pE2, pEm[0..1], pS lanes, pS2 lanes, pW[0..1], pE3)
+  //   [E0 | E1 | M0 | M1 | T0 | T1 | V0 | V1 | A0 | A1 | W0 | W1 | E3]
+  //   (pE, pE2, pEm[0..1], pS lanes, pWalt[0..1], pS2 lanes, pW[0..1], pE3: the steps behind an A product read the A partials
+  //   and ONE half of the update partials -- with a half on either side of A both ranges are contiguous)
   // with counts cE / cW / cT / cA padded to the maxima over the ranks (zeros beyond a rank's own count -- every array is
   // always written with the same local count, so the padding stays zero): the arrays a
   // scalar step reads are then one contiguous range, which is all-gathered into `gath` ([nranks][range]) right before
@@ -899,7 +907,7 @@ int alloc_workspaces(fpsq_handle h) {
   if (int rc = dalloc(h, &h->pS2, (size_t)h->npS * 2)) return rc;
   h->strT = h->AT.nblk;
   h->strA = npart_A(h);
-  double** ev[] = {&h->pW[0], &h->pW[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1], &h->pC[0], &h->pC[1],
+  double** ev[] = {&h->pW[0], &h->pW[1], &h->pWalt[0], &h->pWalt[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1], &h->pC[0], &h->pC[1],
                    &h->pEm[0], &h->pEm[1]};
   for (auto p : ev)
     if (int rc = dalloc(h, p, (size_t)kEwBlocksMax * 2)) return rc;
@@ -993,6 +1001,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     ra.want = (unsigned int)++h->ride_seq;
     ra.pub = h->ride_break ? ~ra.want : ra.want;
     ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
+    ra.delay = h->ride_delay;
   }
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
@@ -1415,7 +1424,7 @@ int seg_count(fpsq_handle h, const double* p) {
   if (p == h->pEm[0] || p == h->pEm[1]) return h->cW;
   if (p == h->pS || p == h->pS + h->strT) return h->cT;
   if (p == h->pS2 || p == h->pS2 + h->strA) return h->cA;
-  if (p == h->pW[0] || p == h->pW[1] || p == h->pE3) return h->cW;
+  if (p == h->pW[0] || p == h->pW[1] || p == h->pWalt[0] || p == h->pWalt[1] || p == h->pE3) return h->cW;
   return 0;
 }
 
@@ -1772,7 +1781,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       u.a = L.x;
       u.b = h->Lw[l];
       u.len = m;
-      u.partials = h->pW[l];
+      u.partials = h->pW[l];  // (= upd_part(l, 0))
       (w0.nblk ? w1 : w0) = u;
     }
     if (fuse_upd && !s1.kind) {
@@ -1839,6 +1848,12 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   const int look = std::max(1, o.lookahead);
   int64_t it = 0;
   int64_t spec_it = -1;  // iteration behind which the gated flush + tail were enqueued
+  // Where the vector update of iteration k leaves its squared-norm partials (read by the step behind the NEXT A product):
+  // halves alternate, because the A' launch of iteration k + 1 carries both that step -- riding, computed by sixteen
+  // leaders of which any may be late -- and the update of iteration k + 1, whose workgroups only wait for the record of
+  // their own XCC's leader before they write.  (CRAIG's update rides one launch later than the step that reads its
+  // partials and would be safe in one array; it follows the same parity so that a sharded step gathers one range.)
+  auto upd_part = [&](int l, int64_t k) { return (k & 1) ? h->pWalt[l] : h->pW[l]; };
   auto lsqr_upd_seg = [&](int l, int64_t it_of_update) {
     UpdSeg u{};
     u.kind = UPD_LSQR;
@@ -1850,7 +1865,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     u.a = lanes[l].x;
     u.b = h->Lw[l];
     u.len = m;
-    u.partials = h->pW[l];
+    u.partials = upd_part(l, it_of_update);
     return u;
   };
   auto all_done = [&]() {
@@ -1886,7 +1901,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     } else {
       u.a = w1;
       u.b = lanes[l].x;
-      u.partials = h->pW[l];
+      u.partials = h->pWalt[l];  // (rides in the launch whose leaders compute step B from E2's partials in pW[l])
     }
     return u;
   };
@@ -1951,7 +1966,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     StepArgs sa[2] = {none, none};
     for (int l = 0; l < NL; ++l) {
       if (lanes[l].kind == LANE_MINRES) {  // the stopping tests of iteration it - 1
-        if (it > 1) sa[l] = step_args(STEP_MINRES_C, lanes[l], (int)it - 1, h->pW[l], gm, nullptr, 0, prog[l]);
+        if (it > 1) sa[l] = step_args(STEP_MINRES_C, lanes[l], (int)it - 1, h->pWalt[l], gm, nullptr, 0, prog[l]);
         continue;
       }
       sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SA : STEP_LNLQ_SA,
@@ -2003,7 +2018,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       v.a = h->Cw;
       v.b = L.y;
       v.len = m;
-      v.partials = h->pW[l];
+      v.partials = upd_part(l, it - 1);
       cu[1] = v;
     }
     // second half-step: one A product
@@ -2030,7 +2045,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
         sb[l] = step_args(STEP_MINRES_A, lanes[l], (int)it, h->pE3, gm, nullptr, 0, prog[l]);
       else
         sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SB : STEP_LNLQ_SB,
-                          lanes[l], (int)it, h->pS2 + (size_t)l * h->strA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : h->pW[l],
+                          lanes[l], (int)it, h->pS2 + (size_t)l * h->strA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : upd_part(l, it - 1),
                           gm, prog[l]);
     }
     if (minres_lane >= 0 && lead && NL == 2) {
@@ -2144,7 +2159,7 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     else
       launch_updates<NL>(h, seg[0], seg[1], minres_lane >= 0 && it >= 1 ? minres_seg(3, it, SPcur) : seg_none());
     if (minres_lane >= 0 && it >= 1)
-      if (int rc = launch_step(h, step_args(STEP_MINRES_C, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
+      if (int rc = launch_step(h, step_args(STEP_MINRES_C, lanes[minres_lane], (int)it, h->pWalt[minres_lane], gm, nullptr, 0,
                                             prog[minres_lane]),
                                none, /*sharded=*/true))
         return rc;
@@ -2190,7 +2205,7 @@ int ensure_gather_layout(fpsq_handle h) {
   h->cT = c[1];
   h->cA = c[2];
   h->cW = c[3];
-  h->seg_len = 2 * (int64_t)h->cE + 2 * (int64_t)h->cT + 2 * (int64_t)h->cA + 5 * (int64_t)h->cW;
+  h->seg_len = 2 * (int64_t)h->cE + 2 * (int64_t)h->cT + 2 * (int64_t)h->cA + 7 * (int64_t)h->cW;
   if (int rc = dalloc(h, &h->seg, (size_t)h->seg_len)) return rc;
   if (int rc = dalloc(h, &h->gath, (size_t)h->seg_len * P * 2)) return rc;
   HIPCHK(h, hipMemsetAsync(h->seg, 0, (size_t)h->seg_len * 8, h->stream));  // the padding entries stay zero for good
@@ -2207,6 +2222,10 @@ int ensure_gather_layout(fpsq_handle h) {
   h->pS = q;
   h->strT = h->cT;
   q += 2 * h->cT;
+  h->pWalt[0] = q;
+  q += h->cW;
+  h->pWalt[1] = q;
+  q += h->cW;
   h->pS2 = q;
   h->strA = h->cA;
   q += 2 * h->cA;
@@ -2265,8 +2284,10 @@ void call_begin(fpsq_handle h) {
 
 // steps riding with leaders: a workgroup's bounded wait for the leaders' record expired (never observed; see kRidePolls)
 bool ride_failed(fpsq_handle h) {
-  if (h->hscal[15] == 0.0) return false;
-  h->hscal[15] = 0.0;
+  // (the device stores the INTEGER 1 there -- as a double a denormal, which a host running with flush-to-zero would not see)
+  volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(h->hscal + 15);
+  if (*w == 0) return false;
+  *w = 0;
   h->err = "riding scalar steps: the leaders' record did not arrive (bounded wait expired); FPSQ_RIDE_LEAD=0 avoids the path";
   return true;
 }
@@ -2611,6 +2632,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY")) h->ride_delay = std::atoi(ev);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->opt.device) == hipSuccess && prop.multiProcessorCount > 0)

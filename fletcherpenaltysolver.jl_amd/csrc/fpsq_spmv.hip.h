@@ -263,6 +263,8 @@ struct RideArgs {
   unsigned int want;        // this launch's number
   unsigned int pub;         // what the leaders publish: `want` (anything else only in the test of the bounded wait)
   unsigned long long* err;  // host-mapped: set when a bounded wait for the record expired (the call then fails)
+  int delay;                // tests only (FPSQ_DEBUG_RIDE_DELAY = c + 1): leader c idles ~100 us before it starts -- what another
+                            // kernel holding its XCD would do to it; results must not depend on it
 };
 struct RideCoef {
   double ca[2], cb[2];
@@ -327,6 +329,10 @@ struct RideHook {
 };
 __device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const RideArgs& ra, double* red32, unsigned long long* st80) {
   const int l = (c >> 3) & 1;
+  if (ra.delay != 0 && c == ra.delay - 1) {
+    const unsigned long long t0 = wall_clock64();  // (100 MHz)
+    while (wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(32);
+  }
   unsigned long long* rec = ra.rec + 64 * ride_xcc();
   const RideHook hook{&ra, st80, rec, l, a.prod_ctl_off};
   if (a.kind != STEP_NONE) {

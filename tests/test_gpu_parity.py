@@ -1070,6 +1070,48 @@ def test_steps_riding_with_leaders_are_bitwise_the_stand_alone_steps(monkeypatch
     dev.close()
 
 
+@pytest.mark.parametrize("late", [0, 8, 3, 13])
+def test_a_late_leader_changes_nothing(monkeypatch, late):
+    """Sixteen leaders compute the riding steps redundantly and any of them may start late (another kernel holding its XCD).
+    The riding UPDATE workgroups of the same launch are released by the record of their own XCC's leader alone, so whatever
+    they write must not be an input of the step the late leader is still to compute: the update partials alternate between
+    two arrays (fpsq.hip: pW / pWalt).  FPSQ_DEBUG_RIDE_DELAY=c+1 holds leader c of every launch back by ~100 us -- a
+    committing leader (0: lane 0, 8: lane 1) or a publishing-only one -- and every output and statistic of objgrad, hprod
+    Val(1) / Val(2), solve_two_mixed and solve_two_extras (the MINRES lane: beta = sqrt of a sum of those partials) must stay
+    BITWISE that of a handle with stand-alone step launches (FPSQ_RIDE_LEAD=0)."""
+    qp = _small_pde(seed=13, n=60000, m=6000)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(4)
+    xs = [qp.xhat + 0.3 * rng.standard_normal(qp.n) for _ in range(3)]
+    r2 = [rng.standard_normal(qp.m) for _ in range(3)]
+
+    def run():
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+        raw = _Handle(A, 0.0)
+        out = []
+        for k, x in enumerate(xs):
+            gx, ys, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys)
+            rch = dev.hprod(x, hv, 1 + k % 2)
+            st = [(dev.stats4[i].niter, dev.stats4[i].status, dev.stats4[i].rnorm) for i in range(2)]
+            e1, e2, rce = raw.solve_two_extras(x, r2[k])
+            ste = [(raw.st[i].niter, raw.st[i].status, raw.st[i].rnorm, raw.st[i].arnorm) for i in range(2)]
+            out += [np.array([f, rc, rch, rce]), gx, ys, hv, e1, e2, np.array(st).ravel(), np.array(ste).ravel()]
+        dev.close()
+        raw.close()
+        return out
+
+    monkeypatch.setenv("FPSQ_RIDE_LEAD", "0")
+    want = run()
+    monkeypatch.setenv("FPSQ_RIDE_LEAD", "1")
+    monkeypatch.setenv("FPSQ_DEBUG_RIDE_DELAY", str(late + 1))
+    got = run()
+    assert got[0][3] >= 0 and want[6].size == 6  # (the MINRES lane iterated: niter of lane 1 of the extras call)
+    assert int(want[7][4]) > 3
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+
+
 def test_riding_leaders_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
     """Every wait of the leader protocol has an end each wave reaches: with the leaders made to publish a wrong launch number
     (FPSQ_DEBUG_RIDE_BREAK=1) the workgroups of the product give up after their bounded number of looks, raise the handle's
