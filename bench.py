@@ -73,6 +73,10 @@ def parse_args():
                          "n-vectors + n x 2 all-reduce when the Jacobian is not banded); 'shard-allreduce' forces that "
                          "fallback; 'replicas' = every rank evaluates its own points, no collective; 'auto' = halo "
                          "sharding when it applies, else replicas")
+    ap.add_argument("--comm-route", default="auto", choices=["auto", "p2p", "rccl"],
+                    help="halo-sharded runs: how the per-iteration exchanges travel (include/fpsq.h fpsq_comm_set_route).  auto = "
+                         "peer to peer (records written into the peers' hipIpc-mapped buffers, sequence flags, no collective "
+                         "call in the loop) when every rank can export and map, else RCCL; config.parallelism names what ran")
     ap.add_argument("--force-shard", action="store_true", default=False,
                     help="rehearsal on one GPU: run the sharded code path (RCCL communicator of size 1)")
     ap.add_argument("--no-roofline-pass", action="store_true", default=False,
@@ -364,7 +368,8 @@ def main():
             if kind == "halo":
                 loc = shard_qp_halo(qp, plan, rank)
                 return loc, DeviceEqQP(loc, sigma=sigma, rho=rho, delta=delta, device=local_rank,
-                                       fuse_two_rhs=args.fuse, comm=comm, halo=plan.overlaps(rank), **extra)
+                                       fuse_two_rhs=args.fuse, comm=comm, halo=plan.overlaps(rank),
+                                       comm_route=args.comm_route, **extra)
             loc = shard_qp(qp, int(bounds[rank]), int(bounds[rank + 1]))
             return loc, DeviceEqQP(loc, sigma=sigma, rho=rho, delta=delta, device=local_rank, fuse_two_rhs=args.fuse,
                                    comm=comm, **extra)
@@ -553,11 +558,15 @@ def main():
             except (OSError, KeyError, ValueError):
                 continue
 
+    route = model.info()["comm_route"] if sharded else 0
+    how = ("PEER-TO-PEER route: records written straight into the peers' hipIpc-mapped buffers + sequence flags, one "
+           "one-workgroup kernel per exchange, no collective call inside the loop" if route == 2
+           else "RCCL route: grouped ncclSend/ncclRecv + ncclAllGather on the solver's stream")
     par = {"single": "single GPU",
            "halo": f"rows of A sharded over {world} GPUs, HALO layout: each rank holds its column window of the n-vectors and "
-                   "runs the single-GPU launch pattern on its block; per Krylov iteration RCCL send/recv of the A'u overlap "
-                   f"regions with its neighbours (<= {plan.max_exchange_doubles() if plan else 0} doubles per rank) + one "
-                   "all-gather of the norm partials per product (summed in rank order by the scalar-step kernel)",
+                   f"runs the single-GPU launch pattern on its block; {how}; per Krylov iteration one exchange of the A'u "
+                   f"overlap regions with the neighbours (<= {plan.max_exchange_doubles() if plan else 0} doubles per rank) + "
+                   "one all-gather of the norm partials per product (summed in rank order by the leaders of the next product)",
            "allreduce": f"rows of A sharded over {world} GPUs, replicated n-vectors: RCCL all-reduce of the partial A'u "
                         "products (n x 2 fp64) and of the m-vector norm partials every Krylov iteration",
            "replicas": f"{world} independent replicas (each rank evaluates its own points), no data-path collective"}[layout]
@@ -576,7 +585,8 @@ def main():
                    "krylov": ("MINRES on K = [I A'; A -delta I], two systems in lock-step" if mk else "LSQR+MINRES" if extras
                               else "LSQR+LSQR" if hp else "LSQR+CRAIG") + ", atol=rtol=sqrt(eps) (reference defaults)",
                    "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
-                   "all_solved": soft[0] == 0, "parallelism": par},
+                   "all_solved": soft[0] == 0, "parallelism": par,
+                   **({"comm_route": DeviceEqQP.ROUTE_NAMES.get(route, str(route))} if sharded else {})},
         "roofline": roofline,
     }
 

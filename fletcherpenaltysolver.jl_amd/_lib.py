@@ -39,7 +39,8 @@ class Info(C.Structure):
                 ("spmv_a_blocks", C.c_int64), ("spmv_at_blocks", C.c_int64),
                 ("last_solve_ms", C.c_double), ("last_spmv_ms", C.c_double),
                 ("last_spmv_launches", C.c_int64), ("last_kernel_launches", C.c_int64),
-                ("last_prod_a", C.c_int64 * 2), ("last_prod_at", C.c_int64 * 2), ("at_sorted", C.c_int64)]
+                ("last_prod_a", C.c_int64 * 2), ("last_prod_at", C.c_int64 * 2), ("at_sorted", C.c_int64),
+                ("comm_route", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -93,6 +94,7 @@ SYMBOLS = [
     ("fpsq_comm_unique_id", C.c_int, [_DP]),
     ("fpsq_comm_init", C.c_int, [_VP, _I32, _I32, _DP]),
     ("fpsq_comm_set_halo", C.c_int, [_VP, _I64, _I64]),
+    ("fpsq_comm_set_route", C.c_int, [_VP, _I32]),
     ("fpsq_local_group_create", C.c_int, [_I32, C.POINTER(_VP)]),
     ("fpsq_local_group_destroy", C.c_int, [_VP]),
     ("fpsq_comm_init_local", C.c_int, [_VP, _VP, _I32]),

@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>  // types only; the library is dlopen'ed on first use
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -85,9 +86,83 @@ struct Comm {
     double* halo_recv;    // [(ovl + ovr)][2]
     int64_t ovl, ovr;
   };
-  virtual int arm(const Buffers&) { return 0; }
+  virtual int arm(const Buffers&, hipStream_t) { return 0; }
   virtual bool failed() { return false; }  // a bounded wait of the peer-to-peer route expired
+  // Memory a peer may write into (the gather buffers, the halo slots): a communicator that exports it to other processes
+  // or devices decides how it is allocated (fine-grained: visible to a polling kernel across devices).  Freed with hipFree.
+  virtual hipError_t alloc_exchange(void** p, size_t bytes) { return hipMalloc(p, bytes); }
+  // how the exchanges of the Krylov loop travel (fpsq_info.comm_route)
+  virtual int route() const { return FPSQ_ROUTE_RCCL; }
   virtual ~Comm() {}
+};
+
+// ---- the peer-to-peer exchange route (halo-sharded loop): NO collective call inside the Krylov loop.  A rank WRITES its
+// record straight into its peers' buffers, then its sequence number into their flag words, and waits -- in the same
+// one-workgroup kernel, a bounded number of polls -- until its own flag words carry that number (k_p2p_gather, k_p2p_halo).
+// Who the peers are is the communicator's business: the other shards of one process (P2PLocalComm: pointers on the same
+// device) or the other ranks of a node (IpcComm: their buffers mapped with hipIpcOpenMemHandle; the stores then travel over
+// xGMI).  Ordering: gathers alternate between two buffers -- a peer can be at most one reduction ahead, and what it then
+// overwrites was consumed before this rank's previous push (which the peer's current one waited for); halo slots alternate
+// the same way.
+struct P2PRoute {
+  int nranks = 1, rank = 0;
+  bool armed = false;
+  Comm::Buffers mine{};
+  double* peer_gath[2][8] = {};
+  unsigned long long* peer_flags[8] = {};  // 8 gather words (one per sender), then "from left", "from right"
+  double* peer_halo[8] = {};
+  int64_t peer_ovl[8] = {}, peer_ovr[8] = {};
+  unsigned long long* flags = nullptr;  // mine (device; sequence numbers, monotone)
+  int* fail_host = nullptr;             // host-mapped: a bounded wait expired
+  int* fail_dev = nullptr;
+  unsigned long long gather_seq = 0, halo_seq = 0;
+  long max_spins = 50000000L;           // bound of every in-kernel wait (FPSQ_P2P_POLLS; ~1-2 us per poll)
+  bool failed() const { return fail_host && *fail_host != 0; }
+  int alloc_fail_word(std::string& err) {
+    if (const char* ev = std::getenv("FPSQ_P2P_POLLS")) max_spins = std::max(1L, std::atol(ev));
+    if (hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&fail_dev, fail_host, 0) != hipSuccess) {
+      err = "p2p arm: allocation failed";
+      return FPSQ_ERR_HIP;
+    }
+    *fail_host = 0;
+    return 0;
+  }
+  bool is_gather_buffer(const double* recv) const { return armed && (recv == mine.gath[0] || recv == mine.gath[1]); }
+  void allgather(const double* send, double* recv, size_t count, hipStream_t s) {
+    const int par = recv == mine.gath[1];
+    P2PPeers P{};
+    P.n = nranks;
+    for (int r = 0; r < nranks; ++r) {
+      P.buf[r] = peer_gath[par][r];
+      P.flag[r] = peer_flags[r];
+    }
+    hipLaunchKernelGGL(k_p2p_gather, dim3(1), dim3(1024), 0, s, send, (int64_t)count, P, rank, ++gather_seq, fail_dev, max_spins);
+  }
+  void halo_exchange(const double* vec, int NL, int64_t tl, int64_t tr, const double* recvL, hipStream_t s) {
+    P2PHalo H{};
+    const int par = recvL != mine.halo_recv;  // which half of the (double-buffered) slots this exchange uses: the same on
+                                              // every rank (all ranks make the same sequence of exchanges)
+    if (rank > 0 && tl > 0) {  // my head region = the left neighbour's tail slot (behind its own head slot)
+      const int L = rank - 1;
+      H.left_dst = peer_halo[L] + (size_t)par * (size_t)(peer_ovl[L] + peer_ovr[L]) * 2 + (size_t)peer_ovl[L] * NL;
+      H.left_flag = peer_flags[L] + 9;  // its "from right" word
+      H.my_from_left = flags + 8;
+    }
+    if (rank < nranks - 1 && tr > 0) {
+      const int R = rank + 1;
+      H.right_dst = peer_halo[R] + (size_t)par * (size_t)(peer_ovl[R] + peer_ovr[R]) * 2;
+      H.right_flag = peer_flags[R] + 8;  // its "from left" word
+      H.my_from_right = flags + 9;
+    }
+    hipLaunchKernelGGL(k_p2p_halo, dim3(1), dim3(1024), 0, s, vec, tl * NL, tr * NL, H, ++halo_seq, fail_dev, max_spins);
+  }
+  void release() {
+    if (flags) hipFree(flags);
+    if (fail_host) hipHostFree(fail_host);
+    flags = nullptr;
+    fail_host = nullptr;
+  }
 };
 
 struct RcclApi {
@@ -181,6 +256,169 @@ struct RcclComm : Comm {
   }
 };
 
+// The ranks of ONE NODE, one process per GPU: RCCL for the set-up collectives and as the fallback, the peer-to-peer route
+// (P2PRoute) for the exchanges of the halo-sharded Krylov loop.  At arm() every rank exports its two gather buffers, its
+// halo slots and its flag words with hipIpcGetMemHandle, the handles travel through one RCCL all-gather, every rank maps
+// its peers' with hipIpcOpenMemHandle (peer access enabled lazily: the stores of k_p2p_gather / k_p2p_halo then go over
+// xGMI), and a second all-gather makes the decision unanimous: if ANY rank could not export or open, all stay on RCCL.
+// At the headline size the RCCL route pays three collective calls (15-30 us each) per joint iteration against ~8 us of
+// products on 8 GPUs; this one pays three one-workgroup kernels.  IPC handles open between processes sharing ONE device
+// too, which is how the route is tested here (tests/test_gpu_p2p_ipc.py: 2 and 3 processes on one GPU).
+struct IpcComm : RcclComm {
+  int want = FPSQ_ROUTE_AUTO;   // fpsq_comm_set_route / FPSQ_COMM_ROUTE
+  P2PRoute rt;
+  std::string note;             // why the route fell back to RCCL (fpsq_last_error after a FPSQ_ROUTE_P2P request)
+  void* opened[8][3] = {};
+  struct Blob {                 // what a rank tells its peers (padded to whole doubles)
+    hipIpcMemHandle_t h[3];     // gather buffers (one allocation, both halves), halo slots, flag words
+    int64_t ovl, ovr, gath_half; // gath_half: doubles between the two gather buffers
+    int32_t ok, pid;
+  };
+  static constexpr size_t kBlobDoubles = (sizeof(Blob) + 7) / 8;
+  hipError_t alloc_exchange(void** p, size_t bytes) override {
+    if (want == FPSQ_ROUTE_RCCL) return hipMalloc(p, bytes);
+    // fine-grained: a peer's stores must become visible to a kernel of this device that is polling / about to read
+    hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      e = hipMalloc(p, bytes);
+    }
+    return e;
+  }
+  int route() const override { return rt.armed ? FPSQ_ROUTE_P2P : FPSQ_ROUTE_RCCL; }
+  bool failed() override { return rt.failed(); }
+  int arm(const Buffers& b, hipStream_t s) override {
+    if (want == FPSQ_ROUTE_RCCL) return 0;
+    rt.nranks = nranks;
+    rt.rank = rank;
+    rt.mine = b;
+    Blob me{};
+    me.ok = 1;
+    me.pid = (int32_t)getpid();
+    me.ovl = b.ovl;
+    me.ovr = b.ovr;
+    me.gath_half = b.gath[1] - b.gath[0];
+    if (hipExtMallocWithFlags((void**)&rt.flags, 16 * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      rt.flags = nullptr;
+      me.ok = 0;
+      note = "fine-grained allocation of the flag words failed";
+    } else {
+      hipMemset(rt.flags, 0, 16 * 8);
+    }
+    if (int rc = rt.alloc_fail_word(err)) return rc;
+    if (me.ok && nranks > 1) {
+      void* base[3] = {b.gath[0], b.halo_recv, rt.flags};
+      for (int k = 0; k < 3 && me.ok; ++k)
+        if (hipIpcGetMemHandle(&me.h[k], base[k]) != hipSuccess) {
+          (void)hipGetLastError();
+          me.ok = 0;
+          note = "hipIpcGetMemHandle failed";
+        }
+    }
+    hipDeviceSynchronize();
+    // round 1: everybody's blob
+    std::vector<double> all(kBlobDoubles * nranks), mine_d(kBlobDoubles, 0.0);
+    std::memcpy(mine_d.data(), &me, sizeof me);
+    double *dsend = nullptr, *drecv = nullptr;
+    if (hipMalloc((void**)&dsend, kBlobDoubles * 8) != hipSuccess || hipMalloc((void**)&drecv, all.size() * 8) != hipSuccess) {
+      err = "p2p arm: allocation failed";
+      return FPSQ_ERR_HIP;
+    }
+    auto gather_round = [&](const std::vector<double>& snd, size_t cnt) -> int {
+      if (hipMemcpyAsync(dsend, snd.data(), cnt * 8, hipMemcpyHostToDevice, s) != hipSuccess) return FPSQ_ERR_HIP;
+      if (int rc = RcclComm::allgather(dsend, drecv, cnt, s)) return rc;
+      if (hipMemcpyAsync(all.data(), drecv, cnt * nranks * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess)
+        return FPSQ_ERR_HIP;
+      return 0;
+    };
+    int rc = gather_round(mine_d, kBlobDoubles);
+    std::vector<Blob> blobs(nranks);
+    bool ok = rc == 0;
+    if (rc == 0) {
+      for (int r = 0; r < nranks; ++r) {
+        std::memcpy(&blobs[r], all.data() + kBlobDoubles * r, sizeof(Blob));
+        if (!blobs[r].ok) {
+          ok = false;
+          if (note.empty()) note = "rank " + std::to_string(r) + " could not export its buffers";
+        }
+      }
+    }
+    // map the peers' buffers
+    if (ok) {
+      for (int r = 0; r < nranks && ok; ++r) {
+        if (r == rank) continue;
+        for (int k = 0; k < 3 && ok; ++k)
+          if (hipIpcOpenMemHandle(&opened[r][k], blobs[r].h[k], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipGetLastError();
+            opened[r][k] = nullptr;
+            ok = false;
+            note = "hipIpcOpenMemHandle failed for rank " + std::to_string(r) +
+                   (blobs[r].pid == me.pid ? " (same process: use the in-process group instead)" : "");
+          }
+      }
+    }
+    // round 2: unanimous or not at all
+    if (rc == 0) {
+      std::vector<double> v(1, ok ? 1.0 : 0.0);
+      rc = gather_round(v, 1);
+      if (rc == 0)
+        for (int r = 0; r < nranks; ++r)
+          if (all[r] == 0.0) {
+            if (ok && note.empty()) note = "rank " + std::to_string(r) + " could not map its peers' buffers";
+            ok = false;
+          }
+    }
+    hipFree(dsend);
+    hipFree(drecv);
+    if (rc) return rc;
+    if (!ok) {
+      close_peers();
+      if (want == FPSQ_ROUTE_P2P) {
+        err = "peer-to-peer route requested but not available: " + note;
+        return FPSQ_ERR_COMM;
+      }
+      return 0;  // (every rank took the same decision: the RCCL route)
+    }
+    for (int r = 0; r < nranks; ++r) {
+      const bool self = r == rank;
+      double* g0 = self ? b.gath[0] : (double*)opened[r][0];
+      rt.peer_gath[0][r] = g0;
+      rt.peer_gath[1][r] = g0 + blobs[r].gath_half;
+      rt.peer_halo[r] = self ? b.halo_recv : (double*)opened[r][1];
+      rt.peer_flags[r] = self ? rt.flags : (unsigned long long*)opened[r][2];
+      rt.peer_ovl[r] = blobs[r].ovl;
+      rt.peer_ovr[r] = blobs[r].ovr;
+    }
+    rt.armed = true;
+    return 0;
+  }
+  int allgather(const double* send, double* recv, size_t count, hipStream_t s) override {
+    if (!rt.is_gather_buffer(recv)) return RcclComm::allgather(send, recv, count, s);
+    rt.allgather(send, recv, count, s);
+    return 0;
+  }
+  int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL, double* recvR,
+                    hipStream_t s) override {
+    if (!rt.armed) return RcclComm::halo_exchange(vec, n_loc, NL, tl, tr, recvL, recvR, s);
+    rt.halo_exchange(vec, NL, tl, tr, recvL, s);
+    return 0;
+  }
+  void close_peers() {
+    for (int r = 0; r < 8; ++r)
+      for (int k = 0; k < 3; ++k)
+        if (opened[r][k]) {
+          hipIpcCloseMemHandle(opened[r][k]);
+          opened[r][k] = nullptr;
+        }
+  }
+  ~IpcComm() override {
+    close_peers();
+    rt.release();
+  }
+};
+
 // P logical shards in ONE process on ONE device (each handle driven by its own host thread): the sum is a kernel.
 struct LocalGroup {
   int n = 0;
@@ -217,6 +455,7 @@ struct LocalGroup {
 
 struct LocalComm : Comm {
   LocalGroup* g = nullptr;
+  int route() const override { return FPSQ_ROUTE_LOCAL; }
   int allreduce_sum(double* buf, size_t count, hipStream_t s) override {
     g->bufs[rank] = buf;
     hipEventRecord(g->ready[rank], s);
@@ -282,78 +521,56 @@ struct LocalComm : Comm {
   }
 };
 
-// The same logical shards with NO collective call inside the Krylov loop (SURVEY 8e / VERDICT: the route that replaces
-// the three RCCL operations per iteration): records are written straight into the peers' buffers and announced by sequence
-// numbers (k_p2p_gather, k_p2p_halo).  Between the GPUs of a node the peers' pointers would come from hipIpcOpenMemHandle
-// and the stores travel over xGMI; here they are the other shards' buffers on the same device, which exercises the protocol
-// (ordering, double buffering, bounded waits), not the link.  Set-up collectives (before arm()) use LocalComm's.
+// The same logical shards on the peer-to-peer route (P2PRoute): the peers are the other shards' buffers on the same
+// device, which exercises the protocol (ordering, double buffering, bounded waits), not a link.  Set-up collectives
+// (before arm()) use LocalComm's.
 struct P2PLocalComm : LocalComm {
-  bool armed = false;
-  Buffers mine{};
-  unsigned long long* flags = nullptr;  // device: 8 gather words + 2 halo words (sequence numbers, monotone)
-  int* fail_host = nullptr;             // host-mapped
-  int* fail_dev = nullptr;
-  unsigned long long gather_seq = 0, halo_seq = 0;
-  int arm(const Buffers& b) override {
-    mine = b;
-    if (hipMalloc((void**)&flags, 16 * 8) != hipSuccess || hipMemset(flags, 0, 16 * 8) != hipSuccess ||
-        hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&fail_dev, fail_host, 0) != hipSuccess) {
+  P2PRoute rt;
+  int route() const override { return FPSQ_ROUTE_LOCAL_P2P; }
+  int arm(const Buffers& b, hipStream_t) override {
+    rt.nranks = nranks;
+    rt.rank = rank;
+    rt.mine = b;
+    if (hipMalloc((void**)&rt.flags, 16 * 8) != hipSuccess || hipMemset(rt.flags, 0, 16 * 8) != hipSuccess) {
       err = "p2p arm: allocation failed";
       return FPSQ_ERR_HIP;
     }
-    *fail_host = 0;
+    if (int rc = rt.alloc_fail_word(err)) return rc;
     hipDeviceSynchronize();
     LocalGroup::Pub& me = g->pub[rank];
     me.gath[0] = b.gath[0];
     me.gath[1] = b.gath[1];
-    me.flags = flags;
+    me.flags = rt.flags;
     me.halo_recv = b.halo_recv;
     me.ovl = b.ovl;
     me.ovr = b.ovr;
     g->barrier();  // every shard has published
-    armed = true;
+    for (int r = 0; r < nranks; ++r) {
+      const LocalGroup::Pub& q = g->pub[r];
+      rt.peer_gath[0][r] = q.gath[0];
+      rt.peer_gath[1][r] = q.gath[1];
+      rt.peer_flags[r] = q.flags;
+      rt.peer_halo[r] = q.halo_recv;
+      rt.peer_ovl[r] = q.ovl;
+      rt.peer_ovr[r] = q.ovr;
+    }
+    rt.armed = true;
     g->barrier();
     return 0;
   }
-  bool failed() override { return fail_host && *fail_host != 0; }
+  bool failed() override { return rt.failed(); }
   int allgather(const double* send, double* recv, size_t count, hipStream_t s) override {
-    if (!armed || (recv != mine.gath[0] && recv != mine.gath[1])) return LocalComm::allgather(send, recv, count, s);
-    const int par = recv == mine.gath[1];
-    P2PPeers P{};
-    P.n = nranks;
-    for (int r = 0; r < nranks; ++r) {
-      P.buf[r] = g->pub[r].gath[par];
-      P.flag[r] = g->pub[r].flags;
-    }
-    hipLaunchKernelGGL(k_p2p_gather, dim3(1), dim3(1024), 0, s, send, (int64_t)count, P, rank, ++gather_seq, fail_dev);
+    if (!rt.is_gather_buffer(recv)) return LocalComm::allgather(send, recv, count, s);
+    rt.allgather(send, recv, count, s);
     return 0;
   }
   int halo_exchange(const double* vec, int64_t n_loc, int NL, int64_t tl, int64_t tr, double* recvL, double* recvR,
                     hipStream_t s) override {
-    if (!armed) return LocalComm::halo_exchange(vec, n_loc, NL, tl, tr, recvL, recvR, s);
-    P2PHalo H{};
-    const int par = recvL != mine.halo_recv;  // which half of the (double-buffered) slots this exchange uses: the same on
-                                              // every rank (all ranks make the same sequence of exchanges)
-    if (rank > 0 && tl > 0) {  // my head region = the left neighbour's tail slot (behind its own head slot)
-      const LocalGroup::Pub& L = g->pub[rank - 1];
-      H.left_dst = L.halo_recv + (size_t)par * (size_t)(L.ovl + L.ovr) * 2 + (size_t)L.ovl * NL;
-      H.left_flag = L.flags + 9;      // its "from right" word
-      H.my_from_left = flags + 8;
-    }
-    if (rank < nranks - 1 && tr > 0) {
-      const LocalGroup::Pub& R = g->pub[rank + 1];
-      H.right_dst = R.halo_recv + (size_t)par * (size_t)(R.ovl + R.ovr) * 2;
-      H.right_flag = R.flags + 8;     // its "from left" word
-      H.my_from_right = flags + 9;
-    }
-    hipLaunchKernelGGL(k_p2p_halo, dim3(1), dim3(1024), 0, s, vec, tl * NL, tr * NL, H, ++halo_seq, fail_dev);
+    if (!rt.armed) return LocalComm::halo_exchange(vec, n_loc, NL, tl, tr, recvL, recvR, s);
+    rt.halo_exchange(vec, NL, tl, tr, recvL, s);
     return 0;
   }
-  ~P2PLocalComm() override {
-    if (flags) hipFree(flags);
-    if (fail_host) hipHostFree(fail_host);
-  }
+  ~P2PLocalComm() override { rt.release(); }
 };
 
 }  // namespace
@@ -519,6 +736,16 @@ template <class T>
 int dalloc(fpsq_handle h, T** p, size_t count) {
   void* q = nullptr;
   HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+// a buffer the peers of a sharded handle may write into: allocated the way the communicator needs it (Comm::alloc_exchange)
+template <class T>
+int xalloc(fpsq_handle h, T** p, size_t count) {
+  void* q = nullptr;
+  HIPCHK(h, h->comm->alloc_exchange(&q, std::max<size_t>(count, 1) * sizeof(T)));
   h->allocs.push_back(q);
   *p = (T*)q;
   return 0;
@@ -2093,6 +2320,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       if (boundary) {
         if (int rc = flush_pend(true)) return rc;  // (so must the host; the same launches on every rank)
         HIPCHK(h, hipStreamSynchronize(s));
+        if (h->comm->failed()) {  // (peer-to-peer route: a peer's record never came; nothing later in this call can be right)
+          h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
+          return FPSQ_ERR_TIMEOUT;
+        }
         if (all_done()) break;
       }
       continue;
@@ -2207,7 +2438,7 @@ int ensure_gather_layout(fpsq_handle h) {
   h->cW = c[3];
   h->seg_len = 2 * (int64_t)h->cE + 2 * (int64_t)h->cT + 2 * (int64_t)h->cA + 7 * (int64_t)h->cW;
   if (int rc = dalloc(h, &h->seg, (size_t)h->seg_len)) return rc;
-  if (int rc = dalloc(h, &h->gath, (size_t)h->seg_len * P * 2)) return rc;
+  if (int rc = xalloc(h, &h->gath, (size_t)h->seg_len * P * 2)) return rc;
   HIPCHK(h, hipMemsetAsync(h->seg, 0, (size_t)h->seg_len * 8, h->stream));  // the padding entries stay zero for good
   HIPCHK(h, hipStreamSynchronize(h->stream));
   double* q = h->seg;
@@ -2241,12 +2472,13 @@ int ensure_gather_layout(fpsq_handle h) {
     B.halo_recv = h->halo_recv;
     B.ovl = h->ovl;
     B.ovr = h->ovr;
-    if (int rc = h->comm->arm(B)) {
+    if (int rc = h->comm->arm(B, h->stream)) {
       h->err = h->comm->err;
       return rc;
     }
   }
   h->gather_ready = true;
+  h->info.comm_route = h->comm->route();
   return 0;
 }
 
@@ -3148,6 +3380,7 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
     fa.rho = rho;
     fa.eta = eta;
     fa.out = h->hscal_dev;
+    fa.stride = 1;
     FxArgs none = fa;
     none.out = nullptr;
     if (paired) {
@@ -3191,14 +3424,27 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
         P.n[3] = gn;
       }
       hipLaunchKernelGGL(k_presum, dim3(1), dim3(kBlock), 0, s, P, h->comm_scal);
-      if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
-      fa.pcy = h->comm_scal;
-      fa.pcc = h->comm_scal + 1;
-      fa.np_m = 1;
       if (h->halo) {
-        fa.pf = h->comm_scal + 2;
-        fa.pdx = h->comm_scal + 3;
-        fa.np_n = 1;
+        // the ranks' four local sums are ALL-GATHERED like the norm partials of the loop (through the same two buffers:
+        // on the peer-to-peer route no collective call here either) and summed by every rank in rank order: phi is
+        // bitwise the same on every rank whatever a reduction algorithm would do
+        const int P_ = h->comm->nranks;
+        double* gbuf = h->gath + (size_t)(h->gather_calls++ & 1) * (size_t)h->seg_len * P_;
+        if (int rc = h->comm->allgather(h->comm_scal, gbuf, 4, s)) {
+          h->err = h->comm->err;
+          return rc;
+        }
+        fa.pcy = gbuf;
+        fa.pcc = gbuf + 1;
+        fa.pf = gbuf + 2;
+        fa.pdx = gbuf + 3;
+        fa.np_m = fa.np_n = P_;
+        fa.stride = 4;
+      } else {
+        if (int rc = comm_allreduce(h, h->comm_scal, 4)) return rc;
+        fa.pcy = h->comm_scal;
+        fa.pcc = h->comm_scal + 1;
+        fa.np_m = 1;
       }
       hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa, h->gate0, h->gate1);
       h->launches += 2;
@@ -3347,9 +3593,11 @@ int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id
   hipSetDevice(h->opt.device);
   ncclUniqueId u;
   std::memcpy(&u, id, 128);
-  RcclComm* c = new RcclComm();
+  IpcComm* c = new IpcComm();
   c->nranks = nranks;
   c->rank = rank;
+  if (const char* ev = std::getenv("FPSQ_COMM_ROUTE"))  // rccl | p2p | auto (developer A/B; fpsq_comm_set_route is the API)
+    c->want = !std::strcmp(ev, "rccl") ? FPSQ_ROUTE_RCCL : !std::strcmp(ev, "p2p") ? FPSQ_ROUTE_P2P : FPSQ_ROUTE_AUTO;
   ncclResult_t r = g_rccl.CommInitRank(&c->c, nranks, u, rank);
   if (r != ncclSuccess) {
     h->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
@@ -3358,6 +3606,21 @@ int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id
     return FPSQ_ERR_COMM;
   }
   h->comm = c;
+  h->info.comm_route = c->route();
+  return FPSQ_OK;
+}
+
+int fpsq_comm_set_route(fpsq_handle h, int32_t route) {
+  IpcComm* c = h ? dynamic_cast<IpcComm*>(h->comm) : nullptr;
+  if (!c || (route != FPSQ_ROUTE_AUTO && route != FPSQ_ROUTE_RCCL && route != FPSQ_ROUTE_P2P)) {
+    if (h) h->err = "comm_set_route: needs the communicator of fpsq_comm_init; route is FPSQ_ROUTE_AUTO / _RCCL / _P2P";
+    return FPSQ_ERR_ARG;
+  }
+  if (h->halo || h->gather_ready) {
+    h->err = "comm_set_route: call before fpsq_comm_set_halo (the exchange buffers are allocated for the route)";
+    return FPSQ_ERR_STATE;
+  }
+  c->want = route;
   return FPSQ_OK;
 }
 
@@ -3404,6 +3667,7 @@ int fpsq_comm_init_local(fpsq_handle h, void* group, int32_t shard) {
   c->rank = shard;
   c->g = g;
   h->comm = c;
+  h->info.comm_route = c->route();
   return FPSQ_OK;
 }
 
@@ -3420,7 +3684,7 @@ int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_righ
   }
   if (h->halo_recv) dfree(h, &h->halo_recv);
   if (h->halo_raw) dfree(h, &h->halo_raw);
-  if (int rc = dalloc(h, &h->halo_recv, (size_t)(overlap_left + overlap_right) * 2 * 2)) return rc;
+  if (int rc = xalloc(h, &h->halo_recv, (size_t)(overlap_left + overlap_right) * 2 * 2)) return rc;
   if (int rc = dalloc(h, &h->halo_raw, (size_t)(overlap_left + overlap_right) * 2)) return rc;
   h->halo_gf = overlap_left + overlap_right > 0 ? ew_grid(overlap_left + overlap_right) : 0;
   h->halo = true;

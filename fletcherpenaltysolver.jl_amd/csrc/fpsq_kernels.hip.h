@@ -347,8 +347,11 @@ __device__ __forceinline__ void upd_lnlq_short(const UpdSeg& s, int blk, const L
 // phi = f - c'ys + rho/2 c'c + eta/2 ||x - xk||^2 from the partial sums of the evaluation
 // (src/model-Fletcherpenaltynlp.jl:419-433).  out = {phi, f, c'c, seq}: `seq` is stored LAST with system-scope release
 // semantics, so a host that polls it (stream-ordered outputs, see fpsq_set_output_ordering) finds the three values there.
+// stride: distance (doubles) between consecutive entries of every array (4 when the arrays are the ranks' gathered
+// quadruples of a sharded run: entry r of array k at [4 r + k]; summed in rank order)
 __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, const double* pcy, const double* pcc, int np_n,
-                                           int np_m, double rho, double eta, double* out, double seq, double* red16) {
+                                           int np_m, double rho, double eta, double* out, double seq, double* red16,
+                                           int stride = 1) {
   // All four arrays in ONE batch of loads (<= 4 entries per thread and array: the grids of the kernels that wrote them
   // are capped at kEwBlocksMax = 4 x kBlock), unconditional with clamped indices like k_step's partial_batch; a longer
   // array falls back to the strided loop.  Fixed summation order.
@@ -363,7 +366,7 @@ __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, 
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = u * kBlock + t;
-        x[k][u] = cnt[k] > 0 ? arr[k][i < cnt[k] ? i : cnt[k] - 1] : 0.0;
+        x[k][u] = cnt[k] > 0 ? arr[k][(size_t)(i < cnt[k] ? i : cnt[k] - 1) * stride] : 0.0;
       }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -375,7 +378,7 @@ __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       v[k] = 0.0;
-      for (int i = t; i < cnt[k]; i += kBlock) v[k] += arr[k][i];
+      for (int i = t; i < cnt[k]; i += kBlock) v[k] += arr[k][(size_t)i * stride];
     }
   }
 #pragma unroll
@@ -598,8 +601,11 @@ struct P2PPeers {
   int32_t n;
 };
 // all-gather: buf[p][rank * count + i] = send[i] for every peer p (itself included); flag[p][rank] = seq; wait own flags
+// max_spins: the bound of every wait (~1-2 us per poll); *fail != 0 on entry (an earlier exchange of the call gave up): leave
+// at once -- the call is lost anyway and must not pay one waiting time per exchange still enqueued.
 __global__ __launch_bounds__(1024) void k_p2p_gather(const double* __restrict__ send, int64_t count, P2PPeers P, int rank,
-                                                     unsigned long long seq, int* fail) {
+                                                     unsigned long long seq, int* fail, long max_spins) {
+  if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
   for (int p = 0; p < P.n; ++p) {
     double* dst = P.buf[p] + (size_t)rank * count;
     for (int64_t i = threadIdx.x; i < count; i += 1024) dst[i] = send[i];
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(1024) void k_p2p_gather(const double* __restrict__ 
   if ((int)threadIdx.x < P.n) {
     long spins = 0;
     while (__hip_atomic_load(P.flag[rank] + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (++spins > 50000000L) {
+      if (++spins > max_spins) {
         *fail = 1;
         break;
       }
@@ -628,7 +634,8 @@ struct P2PHalo {
   unsigned long long *my_from_left, *my_from_right;
 };
 __global__ __launch_bounds__(1024) void k_p2p_halo(const double* __restrict__ raw, int64_t nl, int64_t nr, P2PHalo H,
-                                                   unsigned long long seq, int* fail) {
+                                                   unsigned long long seq, int* fail, long max_spins) {
+  if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
   if (H.left_dst)
     for (int64_t i = threadIdx.x; i < nl; i += 1024) H.left_dst[i] = raw[i];
   if (H.right_dst)
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(1024) void k_p2p_halo(const double* __restrict__ ra
     unsigned long long* f = threadIdx.x == 0 ? H.my_from_left : H.my_from_right;
     long spins = 0;
     while (f && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (++spins > 50000000L) {
+      if (++spins > max_spins) {
         *fail = 1;
         break;
       }
@@ -797,9 +804,10 @@ struct FxArgs {
   double rho, eta;
   double* out;  // null: not computed by this launch
   double seq;   // call sequence number stored behind the results (out[3])
+  int32_t stride, pad_;  // see qp_fx_core
 };
 __device__ __forceinline__ void qp_fx(const FxArgs& a, double* red) {
-  qp_fx_core(a.pf, a.pdx, a.pcy, a.pcc, a.np_n, a.np_m, a.rho, a.eta, a.out, a.seq, red);
+  qp_fx_core(a.pf, a.pdx, a.pcy, a.pcc, a.np_n, a.np_m, a.rho, a.eta, a.out, a.seq, red, a.stride);
 }
 
 // QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2.

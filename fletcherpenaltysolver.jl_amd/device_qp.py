@@ -16,9 +16,16 @@ from .qdsolver import FpsqError
 class DeviceEqQP:
     """`comm`: None (single GPU), ("rccl", nranks, rank, id_bytes) or ("local", group_ptr, shard) for a row-sharded
     model; `qp` is then the rank's row block (distributed.shard_qp).  `halo` = (overlap_left, overlap_right): the
-    n-vectors are column windows (distributed.shard_qp_halo / HaloPlan.overlaps) instead of replicated."""
+    n-vectors are column windows (distributed.shard_qp_halo / HaloPlan.overlaps) instead of replicated.
+    `comm_route` ("auto" | "rccl" | "p2p", with comm = ("rccl", ...)): how the exchanges of the halo-sharded loop travel
+    (include/fpsq.h fpsq_comm_set_route; "auto" = peer to peer over hipIpc-mapped buffers when every rank can, else RCCL);
+    `info()["comm_route"]` says what the handle ended up with after its first solve."""
 
-    def __init__(self, qp, sigma=1e3, rho=1.0, delta=0.0, eta=0.0, device=0, comm=None, halo=None, **opt_overrides):
+    ROUTES = {"auto": 0, "rccl": 1, "p2p": 2}
+    ROUTE_NAMES = {0: "single GPU", 1: "rccl", 2: "p2p-ipc", 3: "local", 4: "local-p2p"}
+
+    def __init__(self, qp, sigma=1e3, rho=1.0, delta=0.0, eta=0.0, device=0, comm=None, halo=None, comm_route=None,
+                 **opt_overrides):
         self._lib = _lib.load()
         self.qp, self.sigma, self.rho, self.delta, self.eta = qp, sigma, rho, delta, eta
         opts = _lib.Options()
@@ -43,18 +50,20 @@ class DeviceEqQP:
         self.stats4 = (_lib.Stats * 4)()   # hprod with hessian_approx = 1: + the two recurrences of solve_two_extras
         self._in_stream = -1
         try:
-            self._attach_comm(comm, halo)
+            self._attach_comm(comm, halo, comm_route)
         except Exception:
             self.close()
             raise
 
-    def _attach_comm(self, comm, halo):
+    def _attach_comm(self, comm, halo, comm_route=None):
         h = self._h
         if comm is not None:
             if comm[0] == "rccl":
                 _, nranks, rank, ident = comm
                 buf = (C.c_uint8 * 128).from_buffer_copy(bytes(ident))
                 self._check(self._lib.fpsq_comm_init(h, nranks, rank, C.addressof(buf)))
+                if comm_route is not None:
+                    self._check(self._lib.fpsq_comm_set_route(h, self.ROUTES[comm_route]))
             elif comm[0] == "local":
                 self._check(self._lib.fpsq_comm_init_local(h, comm[1], comm[2]))
             else:

@@ -218,6 +218,22 @@ int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double *v, double sigma, doub
  * fpsq_comm_init.  Without fpsq_comm_init the handle is single-GPU. */
 int fpsq_comm_unique_id(uint8_t id[128]);
 int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id[128]);
+/* How the exchanges of the halo-sharded Krylov loop travel between the ranks of a node (fpsq_info.comm_route reports what
+ * a handle ended up with):
+ *   FPSQ_ROUTE_P2P   peer to peer, no collective call inside the loop: every rank exports its gather buffers, halo slots
+ *                    and flag words (hipIpcGetMemHandle), maps its peers' (hipIpcOpenMemHandle, peer access over xGMI) and
+ *                    from then on WRITES its records -- the norm partials of a product, the raw A'u sums of its two overlap
+ *                    regions, the four sums of phi -- straight into the peers' buffers, announces them with sequence
+ *                    numbers and waits (a bounded number of polls: FPSQ_ERR_TIMEOUT, never a hang) for theirs, one
+ *                    one-workgroup kernel per exchange.  Per joint Krylov iteration: 2 product launches + 3 exchange kernels.
+ *   FPSQ_ROUTE_RCCL  ncclAllGather / grouped ncclSend + ncclRecv on the solver's stream (3 RCCL operations per iteration:
+ *                    latency-bound at the headline size); also what the replicated (non-halo) layout always uses.
+ * fpsq_comm_set_route(h, route), after fpsq_comm_init and BEFORE fpsq_comm_set_halo: FPSQ_ROUTE_AUTO (default) = P2P when
+ * every rank can export and map, else RCCL -- decided unanimously at the first solve (the handles travel through one RCCL
+ * all-gather); FPSQ_ROUTE_RCCL = never try; FPSQ_ROUTE_P2P = fail the first solve with FPSQ_ERR_COMM when it cannot be
+ * set up.  The reference has nothing to mirror here (no parallelism at all). */
+enum { FPSQ_ROUTE_AUTO = 0, FPSQ_ROUTE_RCCL = 1, FPSQ_ROUTE_P2P = 2, FPSQ_ROUTE_LOCAL = 3, FPSQ_ROUTE_LOCAL_P2P = 4 };
+int fpsq_comm_set_route(fpsq_handle h, int32_t route);
 /* HALO MODE (banded Jacobians; SURVEY.md 8e "contract path").  When the rows of a rank touch only a column window
  * [w_lo(r), w_hi(r)) of the n columns, windows tile [0, n) and only overlap between neighbouring ranks, the n-vectors
  * need not be replicated: the rank's handle is created with n = its WINDOW length (column indices relative to
@@ -359,6 +375,8 @@ typedef struct {
   int64_t last_prod_a[2];  /* launches of the A  product during that call with 1 and with 2 right-hand sides */
   int64_t last_prod_at[2]; /* same for the A' product */
   int64_t at_sorted;       /* 1: the row blocks of A' are stored column-sorted (coalesced gathers, see k_spmv<.., CSORT>) */
+  int64_t comm_route;      /* 0: single GPU; else FPSQ_ROUTE_RCCL / _P2P (decided at the first solve of a halo-sharded handle)
+                              / _LOCAL / _LOCAL_P2P (in-process groups) */
 } fpsq_info;
 int fpsq_get_info(fpsq_handle h, fpsq_info *info);
 /* on != 0: bracket every SpMV/SpMM launch with HIP events on the solver's stream so that last_spmv_ms is filled

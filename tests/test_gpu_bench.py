@@ -42,6 +42,7 @@ def test_force_shard_world1_runs_the_sharded_path_through_rccl():
     assert a.returncode == 0 and b.returncode == 0 and c.returncode == 0, (a.stderr[-800:], b.stderr[-800:], c.stderr[-800:])
     db, dc = json.loads(b.stdout.strip().splitlines()[-1]), json.loads(c.stdout.strip().splitlines()[-1])
     assert db["scaling"] == "strong" and "HALO" in db["config"]["parallelism"]
+    assert db["config"]["comm_route"] == "p2p-ipc"  # (auto: the peer-to-peer route; with one rank there is nothing to map)
     assert db["config"]["iters_lsqr_craig_median"] == dc["config"]["iters_lsqr_craig_median"]
     assert len([ln for ln in b.stdout.splitlines() if ln.strip()]) == 1  # the RCCL banner stays off stdout
 
@@ -81,6 +82,9 @@ def test_multi_rank_sharded_bench_runs_through_the_loopback_collectives(ranks):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == ranks and d["scaling"] == "strong" and "HALO" in d["config"]["parallelism"]
+    # the default route of a sharded run: peer to peer between the processes (hipIpc-mapped buffers); the stand-in library only
+    # carries the set-up collectives (unique id, partial counts, the exchange of the IPC handles)
+    assert d["config"]["comm_route"] == "p2p-ipc" and "PEER-TO-PEER" in d["config"]["parallelism"]
     assert d["config"]["all_solved"] is True
     one = _run(["--steps", "2", "--warmup", "1", "--repeats", "1", "--cpu-evals", "0", "--no-roofline-pass"])
     assert one.returncode == 0, one.stderr[-1500:]

@@ -1,0 +1,111 @@
+"""The peer-to-peer exchange route BETWEEN PROCESSES (include/fpsq.h fpsq_comm_set_route, csrc/fpsq.hip IpcComm): 2 and 3
+ranks, one process each, all on this box's one GPU.  hipIpc handles open between processes that share a device exactly as
+between the GPUs of a node, so everything but the link is exercised: export / all-gather / import of the handles at the first
+solve, the unanimous decision, k_p2p_gather / k_p2p_halo writing into the peers' mapped buffers, sequence flags, bounded
+waits, the phi gather.  The set-up collectives go through the loopback stand-in for librccl (tests/shim: RCCL refuses two
+ranks on one device)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import fps_amd  # noqa: F401
+from fps_amd import problems
+from fps_amd.device_qp import DeviceEqQP
+from fps_amd.distributed import halo_plan, row_partition
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+SE = float(np.sqrt(np.finfo(float).eps))
+
+
+def _shim():
+    so = os.path.join(ROOT, "tests", "shim", "libloopback_rccl.so")
+    src = os.path.join(ROOT, "tests", "shim", "loopback_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-Wno-unused-result", "-o", so, src])
+    return so
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _run_ranks(nranks, route, delta, tmp, extra_env=None, timeout=300):
+    env = dict(os.environ, FPSQ_RCCL_LIB=_shim(), FPSQ_SHIM_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), str(nranks), str(tmp),
+                               route, repr(delta)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(nranks)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:  # (exactly the processes started here)
+            if p.poll() is None:
+                p.kill()
+    return [p.returncode for p in procs], outs
+
+
+def _reference(delta):
+    qp = problems.pde_control_like(n=24000, m=2400, per_row=24, window=512, seed=29)
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    out, its, fs = {}, [], []
+    v = np.random.default_rng(3).standard_normal(qp.n)
+    for k in range(3):
+        gx, ys, gs = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n)
+        f, rc = ref.objgrad(qp.point(1 + k), gx=gx, ys=ys, gs=gs)
+        fs.append(f)
+        its.append([ref.stats[0].niter, ref.stats[1].niter])
+        out[f"gx{k}"], out[f"ys{k}"], out[f"gs{k}"] = gx, ys, gs
+    for ha in (2, 1):
+        hv = np.empty(qp.n)
+        assert ref.hprod(v, hv, ha) == 0
+        out[f"hv{ha}"] = hv
+        its.append([ref.stats[0].niter, ref.stats[1].niter])
+    A = qp.scipy_csr()
+    o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+    ref.solve_two_mixed(qp.qdiag * qp.x + qp.d, A @ qp.x - qp.b, *o)
+    its.append([ref.stats[0].niter, ref.stats[1].niter])
+    out["p1"], out["q1"], out["p2"], out["q2"] = o
+    ref.close()
+    return qp, out, np.array(its), fs
+
+
+@pytest.mark.parametrize("nranks,route", [(2, "p2p"), (3, "p2p"), (2, "auto"), (2, "rccl")])
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, route, delta):
+    """Same iteration counts as the single-GPU handle, vectors to 1e-9 (only the order of the reductions differs), phi
+    BITWISE the same on every rank (the four sums are gathered and added in rank order), overlaps bitwise identical on the
+    two ranks sharing them; the handles report the route they run on (p2p and auto: peer to peer; rccl: the collectives)."""
+    qp, want, its_ref, fs_ref = _reference(delta)
+    rcs, outs = _run_ranks(nranks, route, delta, tmp_path)
+    assert all(rc == 0 for rc in rcs), [o[1][-1500:] for o in outs]
+    res = [np.load(os.path.join(tmp_path, f"out_{r}.npz")) for r in range(nranks)]
+    bounds = row_partition(qp.rowptr, nranks)
+    plan = halo_plan(qp.rowptr, qp.colind, qp.n, bounds)
+    for r in range(nranks):
+        assert int(res[r]["route"][0]) == (1 if route == "rccl" else 2)
+        assert np.array_equal(res[r]["its"], its_ref), (r, res[r]["its"], its_ref)
+        assert np.array_equal(res[r]["fs"], res[0]["fs"])  # phi and the return codes: replicated, bitwise
+        assert np.all(res[r]["fs"][:, 1] == 0)
+        for k in range(3):
+            assert abs(res[r]["fs"][k, 0] - fs_ref[k]) <= 1e-9 * abs(fs_ref[k])
+        if r + 1 < nranks:
+            t = plan.overlaps(r)[1]
+            for key in ("gx0", "gs2", "hv2", "p1", "p2"):
+                assert t > 0 and np.array_equal(res[r][key][-t:], res[r + 1][key][:t]), key
+    for key in ("gx0", "gx1", "gx2", "gs0", "gs1", "gs2", "hv2", "hv1", "p1", "p2"):
+        assert _rel(plan.assemble([res[r][key] for r in range(nranks)]), want[key]) < 1e-9, key
+    for key in ("ys0", "ys1", "ys2", "q1", "q2"):
+        assert _rel(np.concatenate([res[r][key] for r in range(nranks)]), want[key]) < 1e-9, key
+
+
+def test_a_missing_peer_ends_in_an_error_not_a_hang(tmp_path):
+    """Rank 1 of 2 leaves after the set-up (FPSQ_TEST_P2P_DESERT): rank 0's exchange kernel polls a bounded number of times,
+    raises the communicator's failure word and the call returns FPSQ_ERR_TIMEOUT -- within the test's time limit."""
+    rcs, outs = _run_ranks(2, "p2p", 0.0, tmp_path, extra_env={"FPSQ_TEST_P2P_DESERT": "1", "FPSQ_P2P_POLLS": "300000"}, timeout=400)
+    assert rcs[1] == 0 and rcs[0] != 0
+    assert "bounded wait" in outs[0][1] or "did not arrive" in outs[0][1], outs[0][1][-1500:]
