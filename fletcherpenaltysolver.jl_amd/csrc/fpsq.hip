@@ -108,7 +108,12 @@ struct P2PRoute {
   int nranks = 1, rank = 0;
   bool armed = false;
   Comm::Buffers mine{};
-  double* peer_gath[2][8] = {};
+  // receive area of the all-gathers: [2 parities][rx_half doubles], rx_half >= nranks x the longest record.  The peers write
+  // into it; the gather kernel copies what arrived into the handle's ordinary buffer (Buffers::gath), which is what the
+  // scalar steps read.  Allocated by the communicator at arm() (exported / fine-grained when the peers are other processes).
+  double* rx = nullptr;
+  int64_t rx_half = 0;
+  double* peer_rx[2][8] = {};
   unsigned long long* peer_flags[8] = {};  // 8 gather words (one per sender), then "from left", "from right"
   double* peer_halo[8] = {};
   int64_t peer_ovl[8] = {}, peer_ovr[8] = {};
@@ -134,10 +139,13 @@ struct P2PRoute {
     P2PPeers P{};
     P.n = nranks;
     for (int r = 0; r < nranks; ++r) {
-      P.buf[r] = peer_gath[par][r];
+      P.rx[r] = peer_rx[par][r];
       P.flag[r] = peer_flags[r];
     }
-    hipLaunchKernelGGL(k_p2p_gather, dim3(1), dim3(1024), 0, s, send, (int64_t)count, P, rank, ++gather_seq, fail_dev, max_spins);
+    // (a long record -- few ranks, many row blocks each -- gets extra workgroups for the copy of the rank's own part)
+    const int extra = (int)std::min<size_t>(7, count / (8 * kBlock));
+    hipLaunchKernelGGL(k_p2p_gather, dim3(nranks + extra), dim3(kBlock), 0, s, send, (int64_t)count, P, rank, ++gather_seq,
+                       rx + (size_t)par * rx_half, recv, fail_dev, max_spins);
   }
   void halo_exchange(const double* vec, int NL, int64_t tl, int64_t tr, const double* recvL, hipStream_t s) {
     P2PHalo H{};
@@ -155,9 +163,11 @@ struct P2PRoute {
       H.right_flag = peer_flags[R] + 8;  // its "from left" word
       H.my_from_right = flags + 9;
     }
-    hipLaunchKernelGGL(k_p2p_halo, dim3(1), dim3(1024), 0, s, vec, tl * NL, tr * NL, H, ++halo_seq, fail_dev, max_spins);
+    hipLaunchKernelGGL(k_p2p_halo, dim3(2), dim3(1024), 0, s, vec, tl * NL, tr * NL, H, ++halo_seq, fail_dev, max_spins);
   }
   void release() {
+    if (rx) hipFree(rx);
+    rx = nullptr;
     if (flags) hipFree(flags);
     if (fail_host) hipHostFree(fail_host);
     flags = nullptr;
@@ -270,8 +280,8 @@ struct IpcComm : RcclComm {
   std::string note;             // why the route fell back to RCCL (fpsq_last_error after a FPSQ_ROUTE_P2P request)
   void* opened[8][3] = {};
   struct Blob {                 // what a rank tells its peers (padded to whole doubles)
-    hipIpcMemHandle_t h[3];     // gather buffers (one allocation, both halves), halo slots, flag words
-    int64_t ovl, ovr, gath_half; // gath_half: doubles between the two gather buffers
+    hipIpcMemHandle_t h[3];     // receive area of the gathers (one allocation, both parities), halo slots, flag words
+    int64_t ovl, ovr, rx_half;  // rx_half: doubles between the two parities of the receive area
     int32_t ok, pid;
   };
   static constexpr size_t kBlobDoubles = (sizeof(Blob) + 7) / 8;
@@ -297,18 +307,23 @@ struct IpcComm : RcclComm {
     me.pid = (int32_t)getpid();
     me.ovl = b.ovl;
     me.ovr = b.ovr;
-    me.gath_half = b.gath[1] - b.gath[0];
-    if (hipExtMallocWithFlags((void**)&rt.flags, 16 * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+    rt.rx_half = b.gath[1] - b.gath[0];
+    me.rx_half = rt.rx_half;
+    if (hipExtMallocWithFlags((void**)&rt.flags, 16 * 8, hipDeviceMallocFinegrained) != hipSuccess ||
+        hipExtMallocWithFlags((void**)&rt.rx, (size_t)rt.rx_half * 2 * 8, hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
+      if (rt.flags) hipFree(rt.flags);
       rt.flags = nullptr;
+      rt.rx = nullptr;
       me.ok = 0;
-      note = "fine-grained allocation of the flag words failed";
+      note = "fine-grained allocation of the flag words / receive area failed";
+      // (the kernels are never launched without them: the route stays unarmed)
     } else {
       hipMemset(rt.flags, 0, 16 * 8);
     }
     if (int rc = rt.alloc_fail_word(err)) return rc;
     if (me.ok && nranks > 1) {
-      void* base[3] = {b.gath[0], b.halo_recv, rt.flags};
+      void* base[3] = {rt.rx, b.halo_recv, rt.flags};
       for (int k = 0; k < 3 && me.ok; ++k)
         if (hipIpcGetMemHandle(&me.h[k], base[k]) != hipSuccess) {
           (void)hipGetLastError();
@@ -383,9 +398,9 @@ struct IpcComm : RcclComm {
     }
     for (int r = 0; r < nranks; ++r) {
       const bool self = r == rank;
-      double* g0 = self ? b.gath[0] : (double*)opened[r][0];
-      rt.peer_gath[0][r] = g0;
-      rt.peer_gath[1][r] = g0 + blobs[r].gath_half;
+      double* g0 = self ? rt.rx : (double*)opened[r][0];
+      rt.peer_rx[0][r] = g0;
+      rt.peer_rx[1][r] = g0 + blobs[r].rx_half;
       rt.peer_halo[r] = self ? b.halo_recv : (double*)opened[r][1];
       rt.peer_flags[r] = self ? rt.flags : (unsigned long long*)opened[r][2];
       rt.peer_ovl[r] = blobs[r].ovl;
@@ -435,7 +450,7 @@ struct LocalGroup {
   // peer-to-peer route (fpsq_local_group_set_p2p): what every shard published at arm()
   bool p2p = false;
   struct Pub {
-    double* gath[2];
+    double* rx[2];
     unsigned long long* flags;  // 8 gather flag words (one per sender), then "from left", "from right"
     double* halo_recv;
     int64_t ovl, ovr;
@@ -531,15 +546,17 @@ struct P2PLocalComm : LocalComm {
     rt.nranks = nranks;
     rt.rank = rank;
     rt.mine = b;
-    if (hipMalloc((void**)&rt.flags, 16 * 8) != hipSuccess || hipMemset(rt.flags, 0, 16 * 8) != hipSuccess) {
+    rt.rx_half = b.gath[1] - b.gath[0];
+    if (hipMalloc((void**)&rt.flags, 16 * 8) != hipSuccess || hipMemset(rt.flags, 0, 16 * 8) != hipSuccess ||
+        hipMalloc((void**)&rt.rx, (size_t)rt.rx_half * 2 * 8) != hipSuccess) {
       err = "p2p arm: allocation failed";
       return FPSQ_ERR_HIP;
     }
     if (int rc = rt.alloc_fail_word(err)) return rc;
     hipDeviceSynchronize();
     LocalGroup::Pub& me = g->pub[rank];
-    me.gath[0] = b.gath[0];
-    me.gath[1] = b.gath[1];
+    me.rx[0] = rt.rx;
+    me.rx[1] = rt.rx + rt.rx_half;
     me.flags = rt.flags;
     me.halo_recv = b.halo_recv;
     me.ovl = b.ovl;
@@ -547,8 +564,8 @@ struct P2PLocalComm : LocalComm {
     g->barrier();  // every shard has published
     for (int r = 0; r < nranks; ++r) {
       const LocalGroup::Pub& q = g->pub[r];
-      rt.peer_gath[0][r] = q.gath[0];
-      rt.peer_gath[1][r] = q.gath[1];
+      rt.peer_rx[0][r] = q.rx[0];
+      rt.peer_rx[1][r] = q.rx[1];
       rt.peer_flags[r] = q.flags;
       rt.peer_halo[r] = q.halo_recv;
       rt.peer_ovl[r] = q.ovl;
@@ -2438,7 +2455,7 @@ int ensure_gather_layout(fpsq_handle h) {
   h->cW = c[3];
   h->seg_len = 2 * (int64_t)h->cE + 2 * (int64_t)h->cT + 2 * (int64_t)h->cA + 7 * (int64_t)h->cW;
   if (int rc = dalloc(h, &h->seg, (size_t)h->seg_len)) return rc;
-  if (int rc = xalloc(h, &h->gath, (size_t)h->seg_len * P * 2)) return rc;
+  if (int rc = dalloc(h, &h->gath, (size_t)h->seg_len * P * 2)) return rc;
   HIPCHK(h, hipMemsetAsync(h->seg, 0, (size_t)h->seg_len * 8, h->stream));  // the padding entries stay zero for good
   HIPCHK(h, hipStreamSynchronize(h->stream));
   double* q = h->seg;

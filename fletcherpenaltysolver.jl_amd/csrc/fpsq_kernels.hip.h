@@ -590,44 +590,79 @@ __global__ __launch_bounds__(kBlock) void k_local_allgather(GatherSrc S, double*
   }
 }
 
-// ---- peer-to-peer route of the halo-sharded loop (P2PLocalComm today: the shards of ONE process on one GPU; the same
-// kernels with hipIpc-mapped pointers are the xGMI route between the GPUs of a node).  No collective library call: a rank
-// WRITES its record straight into its peers' buffers, then a sequence number into their flag words, and waits -- in the
-// same one-workgroup kernel -- until its own flag words carry that number (the guide's "handoff-flag": plain payload ->
-// release fence -> flag; bounded spins: a missing peer ends in an error flag, never in a hang).
+// ---- peer-to-peer route of the halo-sharded loop (fpsq.hip: P2PRoute; P2PLocalComm = the shards of ONE process on one GPU,
+// IpcComm = the ranks of a node with hipIpc-mapped pointers, the stores then travel over xGMI).  No collective library
+// call: a rank WRITES its record straight into its peers' receive areas, then a sequence number into their flag words, and
+// waits -- in the same small kernel -- until its own flag words carry that number (the guide's "handoff-flag": plain
+// payload -> release fence -> flag; bounded spins: a missing peer ends in an error flag, never in a hang).
+// max_spins: the bound of every wait (~1-2 us per poll); *fail != 0 on entry (an earlier exchange of the call gave up): leave
+// at once -- the call is lost anyway and must not pay one waiting time per exchange still enqueued.
 struct P2PPeers {
-  double* buf[8];               // peer p's receive buffer
+  double* rx[8];                // peer p's receive area (this parity): [sender][count]
   unsigned long long* flag[8];  // peer p's flag words (one per sender)
   int32_t n;
 };
-// all-gather: buf[p][rank * count + i] = send[i] for every peer p (itself included); flag[p][rank] = seq; wait own flags
-// max_spins: the bound of every wait (~1-2 us per poll); *fail != 0 on entry (an earlier exchange of the call gave up): leave
-// at once -- the call is lost anyway and must not pay one waiting time per exchange still enqueued.
-__global__ __launch_bounds__(1024) void k_p2p_gather(const double* __restrict__ send, int64_t count, P2PPeers P, int rank,
-                                                     unsigned long long seq, int* fail, long max_spins) {
-  if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
-  for (int p = 0; p < P.n; ++p) {
-    double* dst = P.buf[p] + (size_t)rank * count;
-    for (int64_t i = threadIdx.x; i < count; i += 1024) dst[i] = send[i];
+__device__ __forceinline__ bool p2p_wait(const unsigned long long* f, unsigned long long seq, long max_spins, int* fail) {
+  long spins = 0;
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    if (++spins > max_spins) {
+      __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
   }
-  __threadfence_system();
-  __syncthreads();
-  if ((int)threadIdx.x < P.n)
-    __hip_atomic_store(P.flag[threadIdx.x] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if ((int)threadIdx.x < P.n) {
-    long spins = 0;
-    while (__hip_atomic_load(P.flag[rank] + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (++spins > max_spins) {
-        *fail = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
+  __threadfence_system();  // (acquire: the record behind the flag)
+  return true;
+}
+// dst[i] = src[i], i in [lo, hi), by the calling workgroup: eight loads per thread issued back to back (unconditional, clamped
+// index) before the first store -- a load-then-store loop pays one memory round trip per element
+__device__ __forceinline__ void p2p_copy(const double* __restrict__ src, double* dst, int64_t lo, int64_t hi) {
+  for (int64_t base = lo; base < hi; base += 8 * kBlock) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      v[u] = src[i < hi ? i : hi - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = base + u * kBlock + threadIdx.x;
+      if (i < hi) dst[i] = v[u];
     }
   }
-  __threadfence_system();  // (acquire side: the peers' records are read by the NEXT kernel of this stream)
 }
-// halo exchange: my head region (tl rows) -> the left neighbour's tail slot, my tail region (tr rows) -> the right
-// neighbour's head slot; their flags; then wait for both neighbours' records of this sequence number.
+// All-gather, ONE WORKGROUP PER PEER (the links of a node are point to point: every pair has its own):
+//   workgroup p != rank: rx_p[rank][.] = send[.], release, flag_p[rank] = seq; wait for my flag[p]; local[p][.] = my_rx[p][.]
+//   workgroup rank, and the workgroups past P.n (a long record is cut into slices): local[rank][.] = send[.]
+// `local` is an ordinary device buffer: what the scalar steps read afterwards -- sixteen leader workgroups at the head of
+// every product launch, on its critical path -- never is the fine-grained (uncached) receive area the peers write into.
+__global__ __launch_bounds__(kBlock) void k_p2p_gather(const double* __restrict__ send, int64_t count, P2PPeers P, int rank,
+                                                       unsigned long long seq, const double* my_rx, double* local, int* fail,
+                                                       long max_spins) {
+  __shared__ int ok;
+  if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  const int p = blockIdx.x;
+  if (p == rank || p >= P.n) {  // my own record: slice 0 (workgroup `rank`), slices 1 .. (the workgroups past P.n)
+    const int ns = (int)gridDim.x - P.n + 1, sl = p == rank ? 0 : p - P.n + 1;
+    const int64_t per = (count + ns - 1) / ns;
+    const int64_t lo = sl * per, hi = lo + per < count ? lo + per : count;
+    if (lo < hi) p2p_copy(send, local + (size_t)rank * count, lo, hi);
+    return;
+  }
+  double* loc = local + (size_t)p * count;
+  p2p_copy(send, P.rx[p] + (size_t)rank * count, 0, count);
+  __syncthreads();  // (every wave's stores are complete)
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(P.flag[p] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    ok = p2p_wait(P.flag[rank] + p, seq, max_spins, fail) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!ok) return;
+  p2p_copy(my_rx + (size_t)p * count, loc, 0, count);
+}
+// Halo exchange, one workgroup per neighbour (0: left, 1: right): my head region (nl doubles) -> the left neighbour's tail
+// slot, my tail region (nr doubles) -> the right neighbour's head slot; their flags; then the wait for that neighbour's record.
 struct P2PHalo {
   double *left_dst, *right_dst;                 // where my two regions go (null: no such neighbour)
   unsigned long long *left_flag, *right_flag;   // the neighbours' flag words for records coming from me
@@ -636,26 +671,25 @@ struct P2PHalo {
 __global__ __launch_bounds__(1024) void k_p2p_halo(const double* __restrict__ raw, int64_t nl, int64_t nr, P2PHalo H,
                                                    unsigned long long seq, int* fail, long max_spins) {
   if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
-  if (H.left_dst)
-    for (int64_t i = threadIdx.x; i < nl; i += 1024) H.left_dst[i] = raw[i];
-  if (H.right_dst)
-    for (int64_t i = threadIdx.x; i < nr; i += 1024) H.right_dst[i] = raw[nl + i];
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0 && H.left_flag) __hip_atomic_store(H.left_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (threadIdx.x == 1 && H.right_flag) __hip_atomic_store(H.right_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (threadIdx.x < 2) {
-    unsigned long long* f = threadIdx.x == 0 ? H.my_from_left : H.my_from_right;
-    long spins = 0;
-    while (f && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      if (++spins > max_spins) {
-        *fail = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
+  const bool left = blockIdx.x == 0;
+  double* dst = left ? H.left_dst : H.right_dst;
+  if (!dst) return;
+  const double* src = left ? raw : raw + nl;
+  const int64_t cnt = left ? nl : nr;
+  // (records are whole [row][lane] pairs of doubles in 16-byte aligned buffers whenever two lanes travel)
+  if ((cnt & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    for (int64_t i = threadIdx.x; i < cnt / 2; i += 1024) d2[i] = s2[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < cnt; i += 1024) dst[i] = src[i];
   }
-  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(left ? H.left_flag : H.right_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    p2p_wait(left ? H.my_from_left : H.my_from_right, seq, max_spins, fail);
+  }
 }
 
 // out = a * P + b * y (plain vectors, host-given constants), for the p1 = g - A'q1 and J'c products

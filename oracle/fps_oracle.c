@@ -118,7 +118,68 @@ void fpo_default_options(int64_t n, int64_t m, fpo_options *o) {
 #define FPO_PRAGMA(x)
 #endif
 
+/* ---- summation-order variants (fpo_set_sum_order; tests only).  The restatement sums every row left to right, as a
+ * serial CPU code does; the device sums a LONG row in another -- equally valid -- order.  Where a recurrence is sensitive to
+ * that (a dominant dense row or column: tests/test_gpu_parity.py, the awkward structures), the question "is the device's
+ * different iteration count a different summation order or a bug" is answered by running the restatement itself in the
+ * device's order for those rows:
+ *   1 = FPO_SUM_DEVICE: a row of A with more than 2048 entries (a row group of its own in the device's column-sorted layout,
+ *       csrc/fpsq_spmv.hip.h k_spmv_rgcs: one wave, tiles of 2048 entries in column order) is summed by 64 strided
+ *       accumulators that add four products at a time, (d0 + d1) + (d2 + d3), tile after tile, then a halving tree over the
+ *       64; a row of A' with more than 2048 entries (k_spmv's long-row branch) by 256 strided fused-multiply-add
+ *       accumulators, a halving tree inside every 64 and the four results left to right.  Shorter rows stay as they are.
+ *   2 = FPO_SUM_REVERSED: every row right to left (a plain perturbation of the order, for sensitivity checks).
+ * 0 = the default everywhere else. */
+static int g_sum_order = 0;
+void fpo_set_sum_order(int mode) { g_sum_order = mode; }
+#define FPO_LONG_ROW 2048
+
+static double tree64(double *a) { /* a[i] += a[i + off], off = 32 .. 1: lane 0 of a wave's shuffle-down reduction */
+  for (int off = 32; off > 0; off >>= 1)
+    for (int i = 0; i < off; ++i) a[i] += a[i + off];
+  return a[0];
+}
+
+/* one long row of A in the device's order; entries [k0, k1) must be sorted by column (they are tiled in that order) */
+static double long_row_device_a(const fpo_csr *A, int64_t k0, int64_t k1, const double *x) {
+  double acc[64];
+  for (int l = 0; l < 64; ++l) acc[l] = 0.0;
+  for (int64_t t0 = k0; t0 < k1; t0 += FPO_LONG_ROW) {
+    const int64_t t1 = t0 + FPO_LONG_ROW < k1 ? t0 + FPO_LONG_ROW : k1;
+    for (int l = 0; l < 64; ++l) {
+      int64_t j = t0 + l;
+      for (; j + 3 * 64 < t1; j += 4 * 64) {
+        const double d0 = A->vals[j] * x[A->colind[j]], d1 = A->vals[j + 64] * x[A->colind[j + 64]];
+        const double d2 = A->vals[j + 128] * x[A->colind[j + 128]], d3 = A->vals[j + 192] * x[A->colind[j + 192]];
+        acc[l] += (d0 + d1) + (d2 + d3);
+      }
+      if (j < t1) {
+        const double d0 = A->vals[j] * x[A->colind[j]];
+        const double d1 = j + 64 < t1 ? A->vals[j + 64] * x[A->colind[j + 64]] : 0.0;
+        const double d2 = j + 128 < t1 ? A->vals[j + 128] * x[A->colind[j + 128]] : 0.0;
+        acc[l] += (d0 + d1) + d2;
+      }
+    }
+  }
+  return tree64(acc);
+}
+
 static void csr_mul(const fpo_csr *A, const double *x, double *y) {
+  if (g_sum_order != 0) {
+    for (int64_t i = 0; i < A->m; ++i) {
+      const int64_t k0 = A->rowptr[i], k1 = A->rowptr[i + 1];
+      double s = 0.0;
+      if (g_sum_order == 2) {
+        for (int64_t k = k1 - 1; k >= k0; --k) s += A->vals[k] * x[A->colind[k]];
+      } else if (k1 - k0 > FPO_LONG_ROW) {
+        s = long_row_device_a(A, k0, k1, x);
+      } else {
+        for (int64_t k = k0; k < k1; ++k) s += A->vals[k] * x[A->colind[k]];
+      }
+      y[i] = s;
+    }
+    return;
+  }
   FPO_PRAGMA(omp parallel for schedule(static))
   for (int64_t i = 0; i < A->m; ++i) {
     double s = 0.0;
@@ -220,9 +281,39 @@ static void csr_tmul(const fpo_csr *A, const double *u, double *y) {
   }
 #endif
   memset(y, 0, (size_t)A->n * sizeof(double));
+  if (g_sum_order == 2) { /* every row of A' right to left */
+    for (int64_t i = A->m - 1; i >= 0; --i) {
+      const double ui = u[i];
+      for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) y[A->colind[k]] += A->vals[k] * ui;
+    }
+    return;
+  }
+  int64_t *cnt = NULL;
+  if (g_sum_order == 1) { /* the long rows of A' (columns of A with more than 2048 entries) are left out of the scatter ... */
+    cnt = (int64_t *)calloc((size_t)A->n, sizeof(int64_t));
+    for (int64_t k = 0; k < A->rowptr[A->m]; ++k) cnt[A->colind[k]]++;
+  }
   for (int64_t i = 0; i < A->m; ++i) {
     const double ui = u[i];
-    for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) y[A->colind[k]] += A->vals[k] * ui;
+    for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+      if (!cnt || cnt[A->colind[k]] <= FPO_LONG_ROW) y[A->colind[k]] += A->vals[k] * ui;
+  }
+  if (cnt) { /* ... and summed in the device's order: 256 strided fma accumulators over the row's entries (rows of A ascending) */
+    for (int64_t j = 0; j < A->n; ++j) {
+      if (cnt[j] <= FPO_LONG_ROW) continue;
+      double acc[256];
+      for (int t = 0; t < 256; ++t) acc[t] = 0.0;
+      int64_t pos = 0;
+      for (int64_t i = 0; i < A->m; ++i)
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k)
+          if (A->colind[k] == j) {
+            acc[pos & 255] = fma(A->vals[k], u[i], acc[pos & 255]);
+            ++pos;
+          }
+      const double w0 = tree64(acc), w1 = tree64(acc + 64), w2 = tree64(acc + 128), w3 = tree64(acc + 192);
+      y[j] = w0 + w1 + w2 + w3;
+    }
+    free(cnt);
   }
 }
 

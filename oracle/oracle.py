@@ -65,6 +65,12 @@ def lib(threaded: bool = False):
     return _LIB
 
 
+def set_sum_order(mode: int) -> None:
+    """Summation order of the restatement's products (fps_oracle.c fpo_set_sum_order): 0 = left to right (the default),
+    1 = long rows in the device's order, 2 = right to left.  Tests only; always set back to 0."""
+    lib().fpo_set_sum_order(C.c_int(mode))
+
+
 def default_options(n, m, **kw) -> Options:
     o = Options()
     lib().fpo_default_options(C.c_int64(n), C.c_int64(m), C.byref(o))
