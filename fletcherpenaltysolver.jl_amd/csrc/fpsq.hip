@@ -2378,6 +2378,16 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       if (all_done()) break;
     }
   }
+  if (!h->comm && !all_done()) {
+    // The loop ran out of iterations (itmax) before the host saw every lane end.  The steps still in the stream will publish
+    // those ends into the progress words -- which the NEXT run of this call (the second lane of an unfused call, the extras
+    // lanes of hprod! Val(1)) resets on the host and then polls: a late "done" of THIS run would make it stop enqueueing at
+    // once and leave its recurrence unfinished (found by the fixed-iteration tests: statistics of the second lane all zero).
+    // Drain the stream, so that every word says what this run ended with.  (Only the itmax exit comes here: the other exits
+    // of the loop have seen `done`; a sharded run has synchronised at this boundary already.)
+    if (int rc = flush_pend(true)) return rc;
+    HIPCHK(h, hipStreamSynchronize(s));
+  }
   if (all_done()) {  // the iteration at which the last recurrence finished (its progress word says so)
     int64_t e = 0;
     for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter + lag(l));

@@ -30,6 +30,7 @@
  * Build: make -C oracle   (gcc -O3 -shared -fPIC)
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -132,6 +133,9 @@ void fpo_default_options(int64_t n, int64_t m, fpo_options *o) {
  * 0 = the default everywhere else. */
 static int g_sum_order = 0;
 void fpo_set_sum_order(int mode) { g_sum_order = mode; }
+/* developer aid: lsqr prints, per iteration, every stopping quantity over its threshold (how close a stop was) */
+static int g_trace = 0;
+void fpo_set_trace(int on) { g_trace = on; }
 #define FPO_LONG_ROW 2048
 
 static double tree64(double *a) { /* a[i] += a[i + off], off = 32 .. 1: lane 0 of a wave's shuffle-down reduction */
@@ -509,6 +513,10 @@ int fpo_lsqr_op(const fpo_op *B, const double *b, double lambda, double atol, do
     ill_cond = ill_cond_mach | ill_cond_lim;
     zero_resid = zero_resid_mach | zero_resid_lim;
     solved = solved_mach | solved_lim | solved_opt | zero_resid | fwd_err;
+    if (g_trace) /* every stopping quantity over its threshold: < 1 fires */
+      fprintf(stderr, "lsqr it %3d  solved_lim %.6e  solved_opt %.6e  zero_resid %.6e  fwd_err %.6e  ill_cond %.6e\n", (int)iter,
+              test2 / axtol, ArNorm / (atol + rtol * ArNorm0), test1 / rNormtol,
+              iter >= WINDOW ? err_lbnd / (etol * sqrt(xENorm2)) : INFINITY, ctol > 0 ? test3 / ctol : INFINITY);
   }
   st->status = FPO_ST_UNKNOWN;
   if (tired) st->status = FPO_ST_MAXITER;

@@ -341,3 +341,73 @@ def test_minres_on_k_restatement_matches_exact_kkt(oracle):
     assert st.solved == 1 and np.linalg.norm(x - spla.spsolve(M, c)) <= 1e-6 * np.linalg.norm(x)
     p, q, st = oracle.minres_kkt(300, 3000, A.indptr, A.indices, A.data, 0.0)  # zero right-hand side
     assert st.niter == 0 and st.solved == 1 and not p.any() and not q.any()
+
+
+# ------------------------------------------------------------------------------- summation order (fpo_set_sum_order)
+
+def _counts(oracle, kind, delta, mode):
+    from structures import random_structure
+
+    rng = np.random.default_rng(12)
+    A = random_structure(kind, rng)
+    m, n = A.shape
+    rng.standard_normal(n), rng.standard_normal(m)  # (the same draws as the GPU test: tests/test_gpu_parity._awkward_case)
+    g, c = rng.standard_normal(n), rng.standard_normal(m)
+    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
+    rp, ci, va = A.indptr.astype(np.int64), A.indices.astype(np.int64), np.ascontiguousarray(A.data)
+    oracle.set_sum_order(mode)
+    try:
+        a = oracle.solve_two_mixed(m, n, rp, ci, va, delta, g, c)
+        b = oracle.solve_two_least_squares(m, n, rp, ci, va, delta, r1, r2)
+    finally:
+        oracle.set_sum_order(0)
+    return (a[4][0].niter, a[4][1].niter, b[4][0].niter, b[4][1].niter), (*a[:4], *b[:4])
+
+
+def test_summation_order_variants_compute_the_same_products(oracle):
+    """fpo_set_sum_order only re-associates: A x and A' u of every variant agree with scipy to rounding, on a matrix with a
+    row and a column long enough to take the device-order branches (> 2048 entries)."""
+    rng = np.random.default_rng(5)
+    A = sp.random(2600, 3000, density=0.002, random_state=np.random.RandomState(2), format="lil")
+    A[7, :] = rng.standard_normal(3000)
+    A[:, 11] = rng.standard_normal((2600, 1))
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    x, u = rng.standard_normal(3000), rng.standard_normal(2600)
+    rp, ci, va = A.indptr.astype(np.int64), A.indices.astype(np.int64), np.ascontiguousarray(A.data)
+    for mode in (0, 1, 2):
+        oracle.set_sum_order(mode)
+        try:
+            y = oracle.spmv(2600, 3000, rp, ci, va, x)
+            z = oracle.spmv(2600, 3000, rp, ci, va, u, transposed=True)
+        finally:
+            oracle.set_sum_order(0)
+        assert np.max(np.abs(y - A @ x)) <= 1e-12 * np.max(np.abs(A @ x))
+        assert np.max(np.abs(z - A.T @ u)) <= 1e-12 * np.max(np.abs(A.T @ u))
+
+
+@pytest.mark.parametrize("delta", [SE, 0.25])
+def test_iteration_counts_depend_on_the_summation_order_only_for_a_dominant_row_or_column(oracle, delta):
+    """The MEASUREMENT behind the tolerance of the GPU test of the two order-sensitive structures: the restatement, run with
+    its products summed (0) left to right, (1) long rows in the device's order, (2) right to left -- three mathematically
+    identical programs -- stops at the SAME iteration on the four well-conditioned awkward structures (so the GPU test
+    demands equal counts there; their VECTORS still move with the order, by 1e-16 ... 1e-6 depending on how many iterations
+    ran: the GPU test measures that distance per vector instead of assuming a tolerance), and up to two iterations apart on
+    the dense-row / dense-column ones (the third order-sensitive structure, empty columns, keeps its count under these three
+    orders and loses one iteration under the device's: profiles/r04_fixed_iteration_probe.txt)."""
+    from structures import ORDER_SENSITIVE, WELL_CONDITIONED
+
+    for kind in WELL_CONDITIONED:
+        ref, vref = _counts(oracle, kind, delta, 0)
+        for mode in (1, 2):
+            its, v = _counts(oracle, kind, delta, mode)
+            assert its == ref, (kind, mode, its, ref)
+            assert max(np.max(np.abs(a - b)) / np.max(np.abs(b)) for a, b in zip(v, vref)) < 1e-4
+    moved = 0
+    for kind in ORDER_SENSITIVE:
+        ref, _ = _counts(oracle, kind, delta, 0)
+        for mode in (1, 2):
+            its, _ = _counts(oracle, kind, delta, mode)
+            assert all(abs(a - b) <= 2 for a, b in zip(its, ref)), (kind, mode, its, ref)
+            moved += its != ref
+    assert moved >= 2  # (the sensitivity is real: were it gone, the GPU test could demand equal counts there too)
