@@ -34,7 +34,9 @@ HBM_COPY_GBS = 6290.0    # same guide: measured copy ceiling
 F64_MFMA_PEAK_TF = 78.6  # dense fp64 matrix peak (vendor figure)
 
 WORKLOADS = ["pde-control-like n=1e6 m=1e5 nnz=1e7", "random-eqqp n=1e5 m=1e4 nnz=1e6", "aug2dc-like N=100",
-             "dense-block n=4096 m=2048"]
+             "dense-block n=4096 m=2048",
+             # the headline shape with SURVEY 8(d)'s literal column rule (hashed distinct offsets instead of stratified ones)
+             "pde-control-hashed n=1e6 m=1e5 nnz=1e7"]
 
 
 def parse_args():
@@ -110,6 +112,8 @@ def make_workload(name):
 
     if name.startswith("pde-control-like"):
         return problems.pde_control_like(n=1_000_000, m=100_000)
+    if name.startswith("pde-control-hashed"):
+        return problems.pde_control_hashed(n=1_000_000, m=100_000)
     if name.startswith("random-eqqp"):
         return problems.random_eqqp(n=100_000, m=10_000)
     if name.startswith("aug2dc-like"):

@@ -119,6 +119,52 @@ def pde_control_like(n=1_000_000, m=100_000, per_row=100, window=8192, seed=1234
     return _finish(f"pde-control-like-n{n}-m{m}", n, m, rowptr, cols, vals, seed)
 
 
+def _hashed_rows(m, n, per_row, start, width, seed, diag_col, diag_boost):
+    """SURVEY.md 8(d) as written: row i has `per_row` DISTINCT columns start[i] + off, the offsets hashed over the whole
+    window, off = floor(u(seed, entry, 11 + 16 a) * width) with a = 0 and a re-draw (a + 1, a + 2, ...) of every entry that
+    collides with an EARLIER entry of its row; entry 0 of a row is its centre column diag_col[i] (value + diag_boost), so a row
+    has exactly per_row entries.  Columns sorted within a row; values 2u - 1 by entry."""
+    per = per_row
+    eid = np.arange(m, dtype=np.int64)[:, None] * per + np.arange(per, dtype=np.int64)[None, :]
+    off = np.floor(uniform01(seed, eid, 11) * width).astype(np.int64)
+    off[:, 0] = diag_col - start
+    attempt = np.zeros((m, per), dtype=np.int64)
+    for _ in range(64):
+        order = np.argsort(off, axis=1, kind="stable")          # equal offsets keep their entry order
+        so = np.take_along_axis(off, order, axis=1)
+        dup_sorted = np.zeros((m, per), dtype=bool)
+        dup_sorted[:, 1:] = so[:, 1:] == so[:, :-1]              # every entry but the earliest of a run of equal offsets
+        if not dup_sorted.any():
+            break
+        dup = np.zeros((m, per), dtype=bool)
+        np.put_along_axis(dup, order, dup_sorted, axis=1)
+        attempt[dup] += 1
+        off[dup] = np.floor(uniform01(seed, eid[dup], 11 + 16 * attempt[dup]) * width).astype(np.int64)
+    else:
+        raise RuntimeError("hashed offsets: collisions left after 64 re-draws")
+    vals = 2.0 * uniform01(seed, eid, 12) - 1.0
+    vals[:, 0] += diag_boost
+    cols = start[:, None] + off
+    order = np.argsort(cols, axis=1, kind="stable")
+    cols = np.take_along_axis(cols, order, axis=1)
+    vals = np.take_along_axis(vals, order, axis=1)
+    assert cols.min() >= 0 and cols.max() < n and np.all(cols[:, 1:] > cols[:, :-1])
+    return np.arange(m + 1, dtype=np.int64) * per, cols.ravel(), vals.ravel()
+
+
+def pde_control_hashed(n=1_000_000, m=100_000, per_row=100, window=8192, seed=1234) -> EqQP:
+    """The headline shape with SURVEY.md 8(d)'s LITERAL column rule: row i has `per_row` nonzeros at distinct HASHED offsets
+    of a column window of width `window` centred at floor(i n / m) (clamped), re-drawn on collision, values 2u - 1, and
+    A[i, floor(i n / m)] carries an extra +4.  `pde_control_like` (the bench headline since round 1) draws one column per
+    equal slice of the window instead -- a more regular gather pattern; this variant shows what the layouts do without that
+    regularity (bench.py --workload "pde-control-hashed ...", profiles/r04_configs.md)."""
+    window = min(window, n)
+    center = (np.arange(m, dtype=np.int64) * n) // m
+    start = np.clip(center - window // 2, 0, n - window)
+    rowptr, cols, vals = _hashed_rows(m, n, per_row, start, window, seed, center, 4.0)
+    return _finish(f"pde-control-hashed-n{n}-m{m}", n, m, rowptr, cols, vals, seed)
+
+
 def aug2dc_like(N=100, seed=1234) -> EqQP:
     """configs[3] stand-in ("AUG2DC-like", restated from the published description; CUTEst/SIF is not
     available offline, so this is NOT SIF-verified): variables = edges of an N x N grid graph with a

@@ -1427,14 +1427,18 @@ def test_config_random_eqqp_cfg2_size(oracle):
     dev.close()
 
 
-def test_config_headline_full_size_matches_oracle(oracle):
-    """BASELINE configs[4] / the bench workload (n = 1e6, m = 1e5, nnz = 1e7) against the C restatement of the
+@pytest.mark.parametrize("gen", ["stratified", "hashed"])
+def test_config_headline_full_size_matches_oracle(oracle, gen):
+    """(gen = hashed: the same shape with SURVEY 8(d)'s LITERAL column rule -- distinct hashed offsets in the 8192-column
+    window, re-drawn on collision, problems.pde_control_hashed -- next to the stratified columns of the bench headline: the
+    layouts must not live off the generator's regularity, and the parity bar is the same.)
+    BASELINE configs[4] / the bench workload (n = 1e6, m = 1e5, nnz = 1e7) against the C restatement of the
     reference's iterative path at FULL size (one evaluation takes the single-threaded oracle ~0.5 s): identical
     iteration counts, status and `solved` flags of both Krylov recurrences, ys / gs / grad(phi) / phi to 1e-8 (same
     algorithm and tolerances; the differences are summation-order rounding amplified by sigma = 1e3).  delta = sqrt(eps)
     is the reference's delta_0 (parameters.jl:77): CRAIG then stops on ln_conlim (status ILL_COND, solved = false) in
     both implementations -- whether Krylov.jl does the same is what tests/golden/make_krylov_golden.jl can settle."""
-    qp = problems.pde_control_like(n=1_000_000, m=100_000)
+    qp = (problems.pde_control_like if gen == "stratified" else problems.pde_control_hashed)(n=1_000_000, m=100_000)
     sigma, rho = 1e3, 1.0
     for delta in (0.0, SE):
         dev = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=delta)
