@@ -64,11 +64,13 @@ def parse_args():
                          "BASELINE.json's north_star / configs[1], not a path of the reference) -- with --op hprod-solves")
     ap.add_argument("--lookahead", type=int, default=0, help="override fpsq_options.lookahead (0 = library default)")
     ap.add_argument("--cpu-evals", type=int, default=6, help="evaluations timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--pointers", default="device", choices=["device", "host", "host+jac"],
+    ap.add_argument("--pointers", default="device", choices=["device", "host", "host+jac", "device+jac"],
                     help="device: x / gx resident in HBM (the `value` of the contract).  host: x and gx are host arrays "
                          "(PCIe inside the timed region: what a Julia caller holding host vectors gets).  host+jac: "
                          "additionally hands over new Jacobian values (fpsq_set_jacobian_values, 8 nnz bytes) before "
-                         "every evaluation, like a host-resident NONLINEAR model (solve_linear_system.jl:223-228)")
+                         "every evaluation, like a host-resident NONLINEAR model (solve_linear_system.jl:223-228).  "
+                         "device+jac: everything resident in HBM AND new Jacobian values handed over (a device pointer: one "
+                         "gather launch, stream-ordered) before every evaluation -- a device-resident nonlinear model")
     ap.add_argument("--parallel", default="auto", choices=["auto", "shard", "shard-allreduce", "replicas"],
                     help="N > 1: 'shard' = rows of A sharded over the ranks in HALO layout (column-window n-vectors, "
                          "neighbour exchange + 4-double all-reduces per Krylov iteration; falls back to replicated "
@@ -423,7 +425,7 @@ def main():
     # distinct evaluation points, resident in HBM (sharded: every rank holds its window of the SAME points; replicas:
     # each rank evaluates its own sequence)
     K, W = args.steps, args.warmup
-    host_ptr = args.pointers != "device"
+    host_ptr = args.pointers in ("host", "host+jac")
     win = plan.window(rank) if layout == "halo" else slice(0, n)
 
     def points(off, length=None):
@@ -446,6 +448,8 @@ def main():
         if extras:  # rhs2 of step t: the first m entries of the reversed point
             xm = xr[:, :m].contiguous()
     jac_vals = np.ascontiguousarray(qp.vals) if args.pointers == "host+jac" else None
+    if args.pointers == "device+jac":
+        jac_vals = torch.from_numpy(np.ascontiguousarray(qp.vals)).to(dev)
     torch.cuda.synchronize()
 
     def make_step(mdl, pts, out):
@@ -463,7 +467,7 @@ def main():
             if hp:
                 return None, mdl.solve_two_least_squares(pts[t], xr[t], *hp_out)
             if jac_vals is not None:
-                mdl._check(mdl._lib.fpsq_set_jacobian_values(mdl._h, jac_vals.ctypes.data))
+                mdl.set_jacobian_values(jac_vals)
             return mdl.objgrad(pts[t], gx=out)
         return step
 
@@ -554,7 +558,7 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1 and not hp \
-                        and not host_ptr:
+                        and args.pointers == "device":
                     roofline["traffic"] = pmc["traffic_bytes_per_productive_launch"]
                     roofline["traffic_source"] = (f"committed profile profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / "
                                                   "WRITE_SIZE passes of this command; not measured in this run)")

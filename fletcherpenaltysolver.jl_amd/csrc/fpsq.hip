@@ -607,6 +607,8 @@ struct fpsq_solver_s {
   DevRgcs RA;                   // column-sorted row-group copy of A used by the A product when eligible
   int32_t* permT = nullptr;     // AT.vals[t] = A.vals[permT[t]]
   int64_t nnz_in = 0;           // length of the caller's value array (COO entries or CSR nnz)
+  bool perms_to_input = false;  // COO structure without duplicates: permT / RA.vperm are composed down to the caller's array
+  bool refresh_3pass = false;   // FPSQ_JAC_REFRESH=3: the three grid-stride gathers of rounds 1-3 (A/B, test)
   int32_t* in_perm = nullptr;   // COO path: sorted position -> caller index
   int32_t* in_slotptr = nullptr;// COO path with duplicates: CSR slot -> range of sorted positions
   double* in_vals = nullptr;    // staging of the caller's values (COO path)
@@ -1170,6 +1172,16 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   if (int rc = dalloc(h, &h->permT, perm.size())) return rc;
   if (!perm.empty()) HIPCHK(h, hipMemcpy(h->permT, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
   h->nnz = h->A.nnz;
+  // COO input without duplicates: the value permutations of A' and of the row groups are composed with the COO -> CSR order
+  // once, here, so that a refresh gathers straight from the caller's jac_coord! output (k_refresh) -- no CSR staging pass.
+  // (With duplicates the slots are summed into the CSR array first and the permutations keep pointing there.)
+  h->perms_to_input = false;
+  if (h->in_perm && !h->in_slotptr && !h->refresh_3pass && h->nnz > 0) {
+    hipLaunchKernelGGL(k_compose_perm, dim3(ew_grid(h->AT.nstore)), dim3(kBlock), 0, nullptr, h->permT, h->in_perm, h->AT.nstore);
+    if (h->RA.ok)
+      hipLaunchKernelGGL(k_compose_perm, dim3(ew_grid(h->RA.nstore)), dim3(kBlock), 0, nullptr, h->RA.vperm, h->in_perm, h->RA.nstore);
+    h->perms_to_input = true;
+  }
   if (int rc = alloc_workspaces(h)) return rc;
   HIPCHK(h, hipDeviceSynchronize());  // the set-up used null-stream copies/memsets; the solver stream is non-blocking
   h->have_structure = true;
@@ -2892,6 +2904,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY")) h->ride_delay = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_JAC_REFRESH")) h->refresh_3pass = std::atoi(ev) == 3;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->opt.device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -3099,7 +3112,9 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
   hipSetDevice(h->opt.device);
   hipStream_t s = h->stream;
   order_inputs(h);
-  if (h->nnz_in > 0) {
+  const bool on_dev = h->nnz_in > 0 && on_this_device(h, vals);
+  if (h->nnz_in > 0 && h->refresh_3pass) {
+    // rounds 1-3: a copy into the staging array, then one grid-stride gather per stored copy
     if (h->in_perm) {
       HIPCHK(h, hipMemcpyAsync(h->in_vals, vals, (size_t)h->nnz_in * 8, hipMemcpyDefault, s));
       if (h->in_slotptr)
@@ -3116,8 +3131,55 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
     if (h->RA.ok)
       hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->RA.nstore)), dim3(kBlock), 0, s, h->A.vals, h->RA.vperm, h->RA.vals,
                          h->RA.nstore);
+  } else if (h->nnz_in > 0) {
+    // ONE launch writes every stored copy (k_refresh).  Where the gathers read from:
+    //   CSR input              the caller's array in place when it lives on this GPU, else its copy in the CSR array
+    //   COO, no duplicates     the caller's array in place / its staged copy, through permutations composed at set-up
+    //   COO with duplicates    the CSR array, after the slots were summed into it (one more pass; fixed order)
+    const double* src = vals;
+    bool csr_is_src = false;  // (the CSR array already holds the values the gathers read)
+    if (h->in_perm && h->in_slotptr) {
+      const double* coo = vals;
+      if (!on_dev) {
+        HIPCHK(h, hipMemcpyAsync(h->in_vals, vals, (size_t)h->nnz_in * 8, hipMemcpyDefault, s));
+        coo = h->in_vals;
+      }
+      hipLaunchKernelGGL(k_gather_sum, dim3(ew_grid(h->nnz)), dim3(kBlock), 0, s, coo, h->in_perm, h->in_slotptr, h->A.vals,
+                         h->nnz);
+      src = h->A.vals;
+      csr_is_src = true;
+    } else if (!on_dev) {
+      double* stage = h->in_perm ? h->in_vals : h->A.vals;
+      HIPCHK(h, hipMemcpyAsync(stage, vals, (size_t)h->nnz_in * 8, hipMemcpyDefault, s));
+      src = stage;
+      csr_is_src = !h->in_perm;
+    }
+    auto seg = [](double* out, const int32_t* perm, int64_t n) {
+      return RefreshSeg{out, perm, n, (int32_t)((n + kRefreshChunk - 1) / kRefreshChunk), 0};
+    };
+    const RefreshSeg none{nullptr, nullptr, 0, 0, 0};
+    const RefreshSeg sT = seg(h->AT.vals, h->permT, h->AT.nstore);
+    const RefreshSeg sR = h->RA.ok ? seg(h->RA.vals, h->RA.vperm, h->RA.nstore) : none;
+    // the CSR array itself: only when a product reads it (no row-group copy of A) and it is not the source already
+    const RefreshSeg sC = (!h->RA.ok && !csr_is_src) ? seg(h->A.vals, h->perms_to_input ? h->in_perm : nullptr, h->nnz) : none;
+    if (std::getenv("FPSQ_REFRESH_SPLIT")) {  // (developer: one launch per segment, to time them apart)
+      for (const RefreshSeg* q : {&sT, &sR, &sC})
+        if (q->nchunk) hipLaunchKernelGGL(k_refresh, dim3((q->nchunk + 7) / 8 * 8), dim3(kBlock), 0, s, src, *q, none, none, (q->nchunk + 7) / 8);
+    } else {
+      const int per_xcd = (sT.nchunk + sR.nchunk + sC.nchunk + 7) / 8;
+      hipLaunchKernelGGL(k_refresh, dim3(per_xcd * 8), dim3(kBlock), 0, s, src, sT, sR, sC, per_xcd);
+    }
   }
-  HIPCHK(h, hipStreamSynchronize(s));
+  if (on_dev && h->in_stream_on) {
+    // device-resident values on a registered stream: no host synchronisation -- the caller's stream is made to wait for
+    // the gathers that read its array (it may overwrite the array with the next Jacobian), the solves that follow run on
+    // the library's stream behind them
+    if (!h->ev_out) HIPCHK(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->ev_out, s));
+    HIPCHK(h, hipStreamWaitEvent(h->in_stream, h->ev_out, 0));
+  } else {
+    HIPCHK(h, hipStreamSynchronize(s));
+  }
   h->have_values = true;
   return FPSQ_OK;
 }

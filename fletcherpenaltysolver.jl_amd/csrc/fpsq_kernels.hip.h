@@ -459,6 +459,70 @@ __global__ __launch_bounds__(kBlock) void k_gather(const double* __restrict__ in
   }
 }
 
+// ONE-PASS JACOBIAN REFRESH (fpsq_set_jacobian_values; the reference refreshes its operator at every new x:
+// src/solve_linear_system.jl:118-122, :223-228).  Every stored copy of the values -- the column-sorted row groups of the A
+// product, the (padded, column-sorted) row blocks of A', the CSR array when the CSR fallback serves a product -- is a
+// segment of ONE launch: out[i] = in[perm[i]] with perm composed at structure time down to the CALLER's array (COO order or
+// CSR order), -1 = a padding slot (0.0), perm == null = the identity.  A workgroup fills one chunk of 2048 consecutive
+// destination slots: eight coalesced index loads per thread, then its eight gathers back to back, then eight coalesced
+// stores (a load-gather-store loop per element is one dependent round trip each: the three grid-stride passes this
+// replaces took ~95 us apiece at the headline size, latency-bound at ~1.3 TB/s).  Chunks are dealt to the XCDs in
+// contiguous eighths: consecutive chunks of A' gather from the same few hundred rows of the caller's array, which that
+// XCD's L2 then holds.  Pure copies: bitwise the three-pass result (FPSQ_JAC_REFRESH=3 keeps it, under test).
+// (Measured and dropped: the same refresh in SOURCE order -- stream the caller's array, scatter through inverse
+// permutations: 123 us against 81-87 us for this kernel at the headline size.)
+struct RefreshSeg {
+  double* out;
+  const int32_t* perm;
+  int64_t n;
+  int32_t nchunk, pad_;
+};
+constexpr int kRefreshChunk = 2048;
+__global__ __launch_bounds__(kBlock) void k_refresh(const double* __restrict__ in, const RefreshSeg s0, const RefreshSeg s1,
+                                                    const RefreshSeg s2, int per_xcd) {
+  int c = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  // (the segments are kernel arguments: selected by branch, never through a pointer)
+  double* out;
+  const int32_t* perm;
+  int64_t n;
+  if (c < s0.nchunk) {
+    out = s0.out, perm = s0.perm, n = s0.n;
+  } else if (c < s0.nchunk + s1.nchunk) {
+    c -= s0.nchunk;
+    out = s1.out, perm = s1.perm, n = s1.n;
+  } else if (c < s0.nchunk + s1.nchunk + s2.nchunk) {
+    c -= s0.nchunk + s1.nchunk;
+    out = s2.out, perm = s2.perm, n = s2.n;
+  } else {
+    return;
+  }
+  constexpr int kPer = kRefreshChunk / kBlock;
+  const int64_t base = (int64_t)c * kRefreshChunk + threadIdx.x;
+  int32_t p[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const int64_t i = base + j * kBlock;
+    const int64_t ii = i < n ? i : n - 1;
+    p[j] = perm ? perm[ii] : (int32_t)ii;
+  }
+  double v[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) v[j] = in[p[j] >= 0 ? p[j] : 0];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const int64_t i = base + j * kBlock;
+    if (i < n) out[i] = p[j] >= 0 ? v[j] : 0.0;
+  }
+}
+
+// perm[i] <- inner[perm[i]] (structure time: a value permutation composed with the COO -> CSR order; -1 stays -1)
+__global__ __launch_bounds__(kBlock) void k_compose_perm(int32_t* perm, const int32_t* __restrict__ inner, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t q = perm[i];
+    if (q >= 0) perm[i] = inner[q];
+  }
+}
+
 // CSR slot value = sum of the COO entries that map to it, in sorted (fixed) order: duplicates are summed like
 // SparseArrays.sparse does, deterministically.
 __global__ __launch_bounds__(kBlock) void k_gather_sum(const double* __restrict__ coo, const int32_t* __restrict__ perm,

@@ -91,6 +91,13 @@ class DeviceEqQP:
         self.delta = delta
         self._check(self._lib.fpsq_set_delta(self._h, float(delta)))
 
+    def set_jacobian_values(self, vals):
+        """`jac_coord!` output at a new x (src/solve_linear_system.jl:223-228), in the order of the structure call: numpy array,
+        torch tensor (host or device) or raw address.  Device-resident values are read in place by ONE gather launch, ordered
+        on torch's current stream (no host synchronisation): include/fpsq.h fpsq_set_jacobian_values."""
+        self._order(vals)
+        return self._check(self._lib.fpsq_set_jacobian_values(self._h, _lib.ptr(vals)))
+
     def set_profiling(self, on):
         self._check(self._lib.fpsq_set_profiling(self._h, int(on)))
 

@@ -177,6 +177,84 @@ def test_spmv_random_structures_layouts_agree(seed):
     H1.close()
 
 
+@pytest.mark.parametrize("fmt", [0, 1])  # 1: the CSR fallback serves the A product (its array is then a destination too)
+@pytest.mark.parametrize("how", ["csr", "coo", "coo-dup"])
+def test_one_pass_jacobian_refresh_is_bitwise_the_three_pass_one(monkeypatch, how, fmt):
+    """fpsq_set_jacobian_values = `jac_coord!` at a new x (src/solve_linear_system.jl:118-122, :223-228).  One gather launch
+    (k_refresh: permutations composed down to the caller's array at structure time) writes the row-group copy of A, the
+    column-sorted blocks of A' and -- only where a product reads it -- the CSR array; device-resident values are read in
+    place and ordered on the registered stream.  Pure copies (duplicates summed in the same fixed order): products and
+    solves must be BITWISE those of a handle that refreshes with the three grid-stride passes of rounds 1-3
+    (FPSQ_JAC_REFRESH=3), for CSR input, COO input, COO input with duplicates, host and device values, and after a SECOND
+    refresh with other values (nothing stale)."""
+    import torch
+
+    qp = _small_pde(seed=31, n=30000, m=3000)
+    rng = np.random.default_rng(8)
+    rows = np.repeat(np.arange(qp.m), np.diff(qp.rowptr)).astype(np.int64)
+    cols = qp.colind.astype(np.int64)
+    nnz = qp.nnz
+    if how == "csr":
+        struct = None
+        values = [qp.vals.copy(), qp.vals * (1.0 + 0.1 * rng.standard_normal(nnz))]
+    else:
+        perm = rng.permutation(nnz)  # the model's own (unsorted) triplet order
+        r, c = rows[perm], cols[perm]
+        values = [qp.vals[perm].copy(), (qp.vals * (1.0 + 0.1 * rng.standard_normal(nnz)))[perm]]
+        if how == "coo-dup":  # a tenth of the entries split into two triplets
+            k = rng.choice(nnz, nnz // 10, replace=False)
+            r, c = np.concatenate([r, r[k]]), np.concatenate([c, c[k]])
+            values = [np.concatenate([v * np.where(np.isin(np.arange(nnz), k), 0.25, 1.0), 0.75 * v[k]]) for v in values]
+        struct = (r + 1, c + 1)  # (1-based, as NLPModels hands them over)
+    lib = _lib.load()
+    x, u = rng.standard_normal(qp.n), rng.standard_normal(qp.m)
+    g, cc = rng.standard_normal(qp.n), rng.standard_normal(qp.m)
+
+    def run(where):
+        o = _lib.Options()
+        lib.fpsq_default_options(qp.n, qp.m, C.byref(o))
+        o.jac_format = fmt
+        h = C.c_void_p()
+        assert lib.fpsq_create(C.byref(h), qp.n, qp.m, C.byref(o)) == 0
+        if struct is None:
+            rp, ci = qp.rowptr.astype(np.int32), qp.colind.astype(np.int32)
+            assert lib.fpsq_set_jacobian_structure_csr(h, rp.ctypes.data, ci.ctypes.data) == 0
+        else:
+            rr, cq = np.ascontiguousarray(struct[0]), np.ascontiguousarray(struct[1])
+            assert lib.fpsq_set_jacobian_structure_coo(h, rr.size, rr.ctypes.data, cq.ctypes.data, 1) == 0
+        out = []
+        st = (_lib.Stats * 2)()
+        keep = []
+        for v in values:
+            if where == "device":
+                t = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+                keep.append(t)
+                assert lib.fpsq_set_input_stream(h, 1, int(torch.cuda.current_stream().cuda_stream)) == 0
+                assert lib.fpsq_set_jacobian_values(h, t.data_ptr()) == 0, lib.fpsq_last_error(h)
+                t.mul_(0.0)  # queued on the registered stream BEHIND the gathers that read t: must not reach them
+            else:
+                vv = np.ascontiguousarray(v)
+                assert lib.fpsq_set_jacobian_values(h, vv.ctypes.data) == 0, lib.fpsq_last_error(h)
+            y, z = np.zeros(qp.m), np.zeros(qp.n)
+            assert lib.fpsq_jac_mul(h, 0, 1.0, x.ctypes.data, 0.0, y.ctypes.data) == 0
+            assert lib.fpsq_jac_mul(h, 1, 1.0, u.ctypes.data, 0.0, z.ctypes.data) == 0
+            o4 = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+            assert lib.fpsq_solve_two_mixed(h, g.ctypes.data, cc.ctypes.data, *[a.ctypes.data for a in o4], st) >= 0
+            out += [y, z, *o4, np.array([st[0].niter, st[1].niter], dtype=float)]
+        lib.fpsq_destroy(h)
+        return out
+
+    monkeypatch.setenv("FPSQ_JAC_REFRESH", "3")
+    want = run("host")
+    monkeypatch.setenv("FPSQ_JAC_REFRESH", "1")
+    A0 = sp.csr_matrix((qp.vals, qp.colind, qp.rowptr), shape=(qp.m, qp.n))
+    assert _rel(want[0], A0 @ x) < 1e-13 and _rel(want[1], A0.T @ u) < 1e-13  # (the first set of values IS the model's Jacobian)
+    for where in ("host", "device"):
+        got = run(where)
+        for i, (a_, b_) in enumerate(zip(got, want)):
+            assert np.array_equal(a_, b_), (where, i)
+
+
 def test_coo_structure_with_duplicates_matches_sparse_sum():
     """jac_structure! may repeat (i, j); SparseArrays.sparse sums duplicates (src/solve_linear_system.jl:233)."""
     rng = np.random.default_rng(3)
