@@ -47,8 +47,15 @@ struct DevCsr {
   uint16_t* cs16 = nullptr;    // column-sorted padded blocks (k_spmv<.., CSORT>): slot | (col & 31) << 11 ...
   uint8_t* cs8 = nullptr;      // ... and col >> 5 of every stored entry; col16 is then not kept
   bool sorted = false;
+  // SHARED VALUES (A' only; see pad_blocks): the blocks hold no values of their own -- every entry is read from the row-group
+  // copy of A (`vals_ext` = DevRgcs::vals), located through one 16-byte descriptor per 64 consecutive entries
+  uint4* segdesc = nullptr;
+  const double* vals_ext = nullptr;
+  int64_t zero_pos = 0;
+  bool shared = false;
   CsrView view() const {
-    return CsrView{rowptr, colind, vals, rowblk, nblk, (int32_t)nrows, col16, colbase, blkdesc, cs16, cs8};
+    return CsrView{rowptr, colind, shared ? vals_ext : vals, rowblk, nblk, (int32_t)nrows, col16, colbase, blkdesc, cs16, cs8, segdesc,
+                   (int32_t)zero_pos, vals};
   }
 };
 
@@ -636,6 +643,7 @@ struct fpsq_solver_s {
   LsqrState* lsqr_alt[2];       // second copies: the target of a step that rides in a product launch (see run_krylov)
   CraigState* craig_alt;
   bool at_sorted = true;        // A' blocks stored column-sorted where representable (FPSQ_AT_SORTED=0: row order)
+  bool at_shared = true;        // ... and without values of their own where the row groups of A can serve them (FPSQ_AT_SHARED=0)
   // steps riding with LEADERS (large grids, see fpsq_spmv.hip.h): the leaders' record (one line of device memory), a launch counter
   unsigned long long* ride_rec = nullptr;
   unsigned long long ride_seq = 0;
@@ -886,7 +894,21 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
 
 // Re-store an uploaded CSR in the padded block layout of k_spmv<.., PAD>.  `perm` (value source of every compact entry)
 // is rewritten to the padded numbering with -1 in the padding slots.  No-op when some block is one long row.
-int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevCsr& D) {
+// csr_pos (optional, A' only): for every CSR slot of A its position in the padded row-group copy of A (build_rgcs), and
+// zero_pos, a position of that array that always holds 0.0.  When given -- and the blocks qualify for the column-sorted
+// layout -- the blocks are stored WITHOUT VALUES: an A' block's entries come from the ~10 row groups whose column windows
+// reach its columns, and inside a group (column-sorted) they are a contiguous run; the block's entries are therefore
+// stored in the order of their POSITIONS in the row-group array, 64 consecutive entries (one wave instruction) read at most
+// four runs, and one 16-byte descriptor per such segment says where: four 24-bit bases relative to the block's base
+// (blkdesc.w), three split lanes, the number of valid lanes.  The index planes keep the column-sorted format (slot in the
+// block's row-major order | column relative to colbase), so the products land in the same LDS slots and are summed in the
+// same order: BITWISE the other layouts.  What it buys: the Krylov loop streams ONE copy of the values (80 MB less
+// working set next to a 256 MB Infinity Cache: measured as a what-if in round 3, +3.9 % evaluations/s at the headline
+// size), a Jacobian refresh writes one array instead of two, 82 MB less memory.  The value addresses need the descriptors
+// first -- but so do the gathers of x need the index words, and values and gathers then travel in the same round trip: the
+// workgroup's chain of dependent memory round trips is no longer.
+int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevCsr& D,
+               const std::vector<int32_t>* csr_pos = nullptr, int64_t zero_pos = 0, const double* ext_vals = nullptr) {
   if (D.nnz == 0 || h->opt.jac_format == 1) return 0;
   std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows);
   const int nblk = (int)rb.size() - 1;
@@ -917,6 +939,109 @@ int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevC
     HIPCHK(h, hipMemcpy(base.data(), D.colbase, (size_t)nblk * 4, hipMemcpyDeviceToHost));
   } else {
     pcol.assign(slots, 0);
+  }
+  // ---- shared values.  A block whose entries cannot be described that way (a 64-entry segment touching more than four
+  // runs: the first blocks of the headline generators, where the clamped windows of the top rows pile several groups' last
+  // few columns into one block) keeps 2048 values of its OWN in a small side array (D.vals, refreshed like before); its
+  // blkdesc.w = -128 - (its index there) tells the kernel.  More than a quarter of the blocks like that: not worth it.
+  bool shared = sorted && csr_pos != nullptr && h->at_shared && zero_pos < (int64_t)INT32_MAX;
+  std::vector<uint4> segd;
+  std::vector<int32_t> vbase, own_perm;
+  std::vector<uint16_t> sc16;
+  std::vector<uint8_t> sc8;
+  int nown = 0;
+  if (shared) {
+    segd.assign((size_t)nblk * 32, uint4{0u, 0u, 0u, 0u});
+    vbase.assign(nblk, 0);
+    sc16.resize(slots);
+    sc8.assign(slots, 0);
+    std::vector<int64_t> pos;
+    std::vector<uint4> sd(32);
+    for (int b = 0; b < nblk; ++b) {
+      const int s = H.rowptr[rb[b]], e = H.rowptr[rb[b + 1]], cnt = e - s;
+      ord.resize(cnt);
+      pos.resize(cnt);
+      for (int k = 0; k < cnt; ++k) {
+        ord[k] = k;
+        pos[k] = (*csr_pos)[perm[s + k]];
+      }
+      std::sort(ord.begin(), ord.end(), [&](int a, int c) { return pos[a] < pos[c]; });
+      const int64_t base64 = (cnt ? pos[ord[0]] : 0) - 64;
+      bool ok = true;
+      for (int sg = 0; sg < 32 && ok; ++sg) {
+        const int lo = sg * 64, nvalid = std::max(0, std::min(64, cnt - lo));
+        int64_t vb[4] = {0, 0, 0, 0};
+        int split[3] = {64, 64, 64};
+        int np = 0;
+        for (int l = 0; l < nvalid && ok; ++l) {
+          const int64_t p = pos[ord[lo + l]];
+          if (l == 0 || p != pos[ord[lo + l - 1]] + 1) {  // a new run starts at lane l
+            if (np == 4) {
+              ok = false;
+              break;
+            }
+            if (np > 0) split[np - 1] = l;
+            vb[np++] = p - l - base64;
+          }
+        }
+        for (int i = 0; i < 4; ++i)
+          if (vb[i] < 0 || vb[i] >= (1ll << 24)) ok = false;
+        const uint64_t a0 = (uint64_t)vb[0] | ((uint64_t)vb[1] << 24) | ((uint64_t)vb[2] << 48);
+        uint4 d;
+        d.x = (uint32_t)a0;
+        d.y = (uint32_t)(a0 >> 32);
+        d.z = (uint32_t)(((uint64_t)vb[2] >> 16) | ((uint64_t)vb[3] << 8));
+        d.w = (uint32_t)split[0] | ((uint32_t)split[1] << 7) | ((uint32_t)split[2] << 14) | ((uint32_t)nvalid << 21);
+        sd[sg] = d;
+      }
+      if (ok) {
+        vbase[b] = (int32_t)base64;
+        for (int sg = 0; sg < 32; ++sg) segd[(size_t)b * 32 + sg] = sd[sg];
+      } else {  // its own values, in column-sorted order
+        vbase[b] = -128 - nown;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int c) { return H.colind[s + a] < H.colind[s + c]; });
+        own_perm.resize((size_t)(nown + 1) * kSpmvNnz, -1);
+        for (int t = 0; t < cnt; ++t) own_perm[(size_t)nown * kSpmvNnz + t] = perm[s + ord[t]];
+        ++nown;
+      }
+      for (int t = 0; t < kSpmvNnz; ++t) {  // entry t of the stored order belongs to thread t % 256, its j-th word (j = t / 256)
+        const size_t qi = (size_t)b * kSpmvNnz + 8 * (t % kBlock) + t / kBlock;
+        if (t < cnt) {
+          const int k = ord[t], col = H.colind[s + k] - base[b];
+          sc16[qi] = (uint16_t)(k | ((col & 31) << 11));
+          sc8[qi] = (uint8_t)(col >> 5);
+        } else {
+          sc16[qi] = (uint16_t)t;  // an unused slot of the product buffer; its value is 0 (zero_pos / the side array's padding)
+        }
+      }
+    }
+    if (std::getenv("FPSQ_VERBOSE")) std::fprintf(stderr, "fpsq: shared A' values: %d of %d blocks keep their own\n", nown, nblk);
+    if (nown > nblk / 4) shared = false;
+  }
+  if (shared) {
+    dfree(h, &D.vals);
+    dfree(h, &D.col16);
+    dfree(h, &D.colind);
+    const size_t nown_slots = (size_t)nown * kSpmvNnz;
+    if (int rc = dalloc(h, &D.vals, nown_slots + 1)) return rc;
+    HIPCHK(h, hipMemset(D.vals, 0, (nown_slots + 1) * 8));
+    if (int rc = dalloc(h, &D.cs16, slots)) return rc;
+    if (int rc = dalloc(h, &D.cs8, slots)) return rc;
+    if (int rc = dalloc(h, &D.segdesc, segd.size())) return rc;
+    HIPCHK(h, hipMemcpy(D.cs16, sc16.data(), slots * 2, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(D.cs8, sc8.data(), slots, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(D.segdesc, segd.data(), segd.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    std::vector<int4> bd(nblk);
+    for (int b = 0; b < nblk; ++b) bd[b] = int4{rb[b], rb[b + 1] - rb[b], H.rowptr[rb[b]], vbase[b]};
+    HIPCHK(h, hipMemcpy(D.blkdesc, bd.data(), bd.size() * sizeof(int4), hipMemcpyHostToDevice));
+    D.sorted = true;
+    D.shared = true;
+    D.vals_ext = ext_vals;
+    D.zero_pos = zero_pos;
+    D.padded = true;
+    D.nstore = (int64_t)nown_slots;  // (what a refresh still has to fill: the side array)
+    perm.swap(own_perm);
+    return 0;
   }
   for (int b = 0; b < nblk; ++b) {
     const int s = H.rowptr[rb[b]], e = H.rowptr[rb[b + 1]];
@@ -970,9 +1095,10 @@ int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevC
 }
 
 // Row-group column-sorted copy of A (see k_spmv_rgcs).  Not built (ok = false) when a group spans >= 2^21 columns.
-int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
+int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D, std::vector<int32_t>* csr_pos = nullptr) {
   const int64_t nnz = (int64_t)H.colind.size();
   D.ok = false;
+  if (csr_pos) csr_pos->clear();
   if (nnz == 0 || h->opt.jac_format == 1) return 0;
   std::vector<RgcsGroup> groups;
   std::vector<uint32_t> pidx(nnz);
@@ -1029,7 +1155,15 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
     }
     if (!widths.empty()) {
       std::nth_element(widths.begin(), widths.begin() + widths.size() / 2, widths.end());
-      P = std::max<int64_t>(1, widths[widths.size() / 2]);
+      const int64_t med = std::max<int64_t>(1, widths[widths.size() / 2]);
+      // the period: the WIDEST of the typical windows (those within 1.5 x the median), so that (col mod P) is one-to-one on
+      // every typical group's window -- a pure rotation of its column order.  (The median itself -- rounds 3 -- left half of the
+      // groups a little wider than the period: the first and last few columns of such a window share phases and their
+      // entries INTERLEAVE in the sorted order, which cuts the contiguous per-group runs the shared-value layout of A'
+      // builds on into slivers.)
+      P = med;
+      for (const int64_t w : widths)
+        if (w <= med + med / 2) P = std::max(P, w);
     }
     if (const char* ev = std::getenv("FPSQ_RGCS_PHASE"))  // 0: plain column order (A/B)
       if (std::atoi(ev) == 0) P = INT64_MAX;
@@ -1124,6 +1258,11 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D) {
   HIPCHK(h, hipMemcpy(D.vperm, vperm.data(), (size_t)nstore * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dg, groups.data(), groups.size() * sizeof(RgcsGroup), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(d5, tptr.data(), tptr.size() * 2, hipMemcpyHostToDevice));
+  if (csr_pos && padded) {  // where every CSR slot of A sits in the (padded) row-group array: pad_blocks builds A' on it
+    csr_pos->assign((size_t)nnz, -1);
+    for (int64_t p = 0; p < nstore; ++p)
+      if (vperm[p] >= 0) (*csr_pos)[vperm[p]] = (int32_t)p;
+  }
   D.view = RgcsView{dp, D.vals, dg, d5, (int32_t)groups.size(), (int32_t)H.nrows, padded ? budget : 0};
   D.nstore = nstore;
   D.nnz = nnz;
@@ -1167,8 +1306,10 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   transpose_structure(HA, HT, perm);
   if (int rc = upload_csr(h, HA, h->A)) return rc;
   if (int rc = upload_csr(h, HT, h->AT)) return rc;
-  if (int rc = pad_blocks(h, HT, perm, h->AT)) return rc;
-  if (int rc = build_rgcs(h, HA, h->RA)) return rc;
+  std::vector<int32_t> csr_pos;
+  if (int rc = build_rgcs(h, HA, h->RA, &csr_pos)) return rc;
+  const bool can_share = h->RA.ok && !csr_pos.empty() && !h->refresh_3pass;
+  if (int rc = pad_blocks(h, HT, perm, h->AT, can_share ? &csr_pos : nullptr, h->RA.nstore, h->RA.vals)) return rc;
   if (int rc = dalloc(h, &h->permT, perm.size())) return rc;
   if (!perm.empty()) HIPCHK(h, hipMemcpy(h->permT, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
   h->nnz = h->A.nnz;
@@ -1177,7 +1318,8 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   // (With duplicates the slots are summed into the CSR array first and the permutations keep pointing there.)
   h->perms_to_input = false;
   if (h->in_perm && !h->in_slotptr && !h->refresh_3pass && h->nnz > 0) {
-    hipLaunchKernelGGL(k_compose_perm, dim3(ew_grid(h->AT.nstore)), dim3(kBlock), 0, nullptr, h->permT, h->in_perm, h->AT.nstore);
+    if (h->AT.nstore > 0)
+      hipLaunchKernelGGL(k_compose_perm, dim3(ew_grid(h->AT.nstore)), dim3(kBlock), 0, nullptr, h->permT, h->in_perm, h->AT.nstore);
     if (h->RA.ok)
       hipLaunchKernelGGL(k_compose_perm, dim3(ew_grid(h->RA.nstore)), dim3(kBlock), 0, nullptr, h->RA.vperm, h->in_perm, h->RA.nstore);
     h->perms_to_input = true;
@@ -1191,7 +1333,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   h->info.nnz = h->nnz;
   h->info.spmv_a_blocks = npart_A(h);
   h->info.spmv_at_blocks = h->AT.nblk;
-  h->info.at_sorted = h->AT.sorted ? 1 : 0;
+  h->info.at_sorted = h->AT.shared ? 2 : h->AT.sorted ? 1 : 0;
   return 0;
 }
 
@@ -2900,6 +3042,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_ADAPTIVE_RUNAHEAD")) h->adaptive_runahead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_HOST_TRACE")) h->host_trace = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_AT_SORTED")) h->at_sorted = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_AT_SHARED")) h->at_shared = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
@@ -3126,8 +3269,9 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
     } else {
       HIPCHK(h, hipMemcpyAsync(h->A.vals, vals, (size_t)h->nnz * 8, hipMemcpyDefault, s));
     }
-    hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->AT.nstore)), dim3(kBlock), 0, s, h->A.vals, h->permT, h->AT.vals,
-                       h->AT.nstore);
+    if (h->AT.nstore > 0)
+      hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->AT.nstore)), dim3(kBlock), 0, s, h->A.vals, h->permT, h->AT.vals,
+                         h->AT.nstore);
     if (h->RA.ok)
       hipLaunchKernelGGL(k_gather, dim3(ew_grid(h->RA.nstore)), dim3(kBlock), 0, s, h->A.vals, h->RA.vperm, h->RA.vals,
                          h->RA.nstore);
@@ -3154,11 +3298,11 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
       src = stage;
       csr_is_src = !h->in_perm;
     }
+    const RefreshSeg none{nullptr, nullptr, 0, 0, 0};
     auto seg = [](double* out, const int32_t* perm, int64_t n) {
       return RefreshSeg{out, perm, n, (int32_t)((n + kRefreshChunk - 1) / kRefreshChunk), 0};
     };
-    const RefreshSeg none{nullptr, nullptr, 0, 0, 0};
-    const RefreshSeg sT = seg(h->AT.vals, h->permT, h->AT.nstore);
+    const RefreshSeg sT = h->AT.nstore > 0 ? seg(h->AT.vals, h->permT, h->AT.nstore) : none;
     const RefreshSeg sR = h->RA.ok ? seg(h->RA.vals, h->RA.vperm, h->RA.nstore) : none;
     // the CSR array itself: only when a product reads it (no row-group copy of A) and it is not the source already
     const RefreshSeg sC = (!h->RA.ok && !csr_is_src) ? seg(h->A.vals, h->perms_to_input ? h->in_perm : nullptr, h->nnz) : none;

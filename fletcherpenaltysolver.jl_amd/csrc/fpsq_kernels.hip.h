@@ -46,6 +46,13 @@ struct CsrView {
   // cs16 = slot | (col & 31) << 11, cs8 = col >> 5
   const uint16_t* cs16;
   const uint8_t* cs8;
+  // shared values (fpsq.hip pad_blocks): non-null = the blocks hold no values; `vals` is the row-group array of A and
+  // segdesc[32 L + s] locates the 64 entries of segment s of block L in it (base = blkdesc[L].w)
+  const uint4* segdesc;
+  int32_t zero_pos;  // an entry of that array that always holds 0.0 (the lanes past a segment's valid entries read it)
+  // the few blocks that cannot be described by segment descriptors keep 2048 values of their own here, block i at
+  // [2048 i, ...), i = -128 - blkdesc[L].w (w <= -128 marks such a block)
+  const double* vals_own;
 };
 
 // ------------------------------------------------------------------------------------------------ reductions

@@ -46,8 +46,75 @@ __device__ __forceinline__ void csort_decode(const CsortRaw& r, int cbase, int (
     v[q] = (q & 1) ? r.vv[q >> 1].y : r.vv[q >> 1].x;
   }
 }
-__device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, int tid, int (&cidx)[8], int (&slot)[8],
-                                            double (&v)[8]) {
+// SHARED VALUES (CsrView::segdesc != null): thread t owns the entries t + 256 j of the block's stored order (j = 0..7; its eight
+// index words are contiguous at [8t, 8t + 8) as above), i.e. lane t % 64 of segment 4 j + t / 64.  The segment's descriptor
+// is wave-uniform (scalar loads): four 24-bit bases relative to `vbase`, three split lanes, the number of valid lanes;
+// value address = vbase + base_of_my_run + lane, or the array's zero entry past the valid lanes.  The value loads leave
+// together with the caller's gathers of x.
+__device__ __forceinline__ void cshared_fetch(const CsrView& A, int L, int cbase, int vbase, int zero_pos, int tid, int (&cidx)[8],
+                                              int (&slot)[8], double (&v)[8]) {
+  const size_t b0 = (size_t)L * kSpmvNnz;
+  const uint4 w16 = *reinterpret_cast<const uint4*>(A.cs16 + b0 + 8 * tid);
+  const uint2 w8 = *reinterpret_cast<const uint2*>(A.cs8 + b0 + 8 * tid);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // The eight descriptors of this wave (segments w, w + 4, ...: 64 bytes apart) through the SCALAR cache: as vector loads of
+  // one address they cost the texture path a full wave instruction each (eighteen vector loads per thread instead of six made
+  // the plain A' product 6 us slower).  Inline assembly because the compiler does not prove the address uniform; its wait
+  // stands behind the (already issued) vector loads of the index words, which the address arithmetic needs as well.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 d[8];
+  {
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(A.segdesc + (size_t)L * 32 + w);
+    const unsigned long long pu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(pa & 0xffffffffull));
+    asm volatile(
+        "s_load_dwordx4 %0, %8, 0x0\n\t"
+        "s_load_dwordx4 %1, %8, 0x40\n\t"
+        "s_load_dwordx4 %2, %8, 0x80\n\t"
+        "s_load_dwordx4 %3, %8, 0xc0\n\t"
+        "s_load_dwordx4 %4, %8, 0x100\n\t"
+        "s_load_dwordx4 %5, %8, 0x140\n\t"
+        "s_load_dwordx4 %6, %8, 0x180\n\t"
+        "s_load_dwordx4 %7, %8, 0x1c0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(d[0]), "=&s"(d[1]), "=&s"(d[2]), "=&s"(d[3]), "=&s"(d[4]), "=&s"(d[5]), "=&s"(d[6]), "=&s"(d[7])
+        : "s"(pu)
+        : "memory");
+  }
+  const unsigned h16[4] = {w16.x, w16.y, w16.z, w16.w};
+  const unsigned h8[2] = {w8.x, w8.y};
+  if (vbase <= -128) {  // (block-uniform) a block with values of its own: entry t + 256 j at [2048 own + 256 j + t]
+    const double* ov = A.vals_own + (size_t)(-128 - vbase) * kSpmvNnz + tid;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int pk = (int)((h16[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+      const int hi = (int)((h8[q >> 2] >> (8 * (q & 3))) & 0xffu);
+      cidx[q] = cbase + ((hi << 5) | (pk >> 11));
+      slot[q] = pk & 2047;
+      v[q] = ov[q * kBlock];
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int pk = (int)((h16[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+    const int hi = (int)((h8[q >> 2] >> (8 * (q & 3))) & 0xffu);
+    cidx[q] = cbase + ((hi << 5) | (pk >> 11));
+    slot[q] = pk & 2047;
+    const unsigned s0 = d[q].w & 127u, s1 = (d[q].w >> 7) & 127u, s2 = (d[q].w >> 14) & 127u, nv = (d[q].w >> 21) & 127u;
+    const int b0_ = (int)(d[q].x & 0xffffffu), b1_ = (int)((d[q].x >> 24) | ((d[q].y & 0xffffu) << 8));
+    const int b2_ = (int)((d[q].y >> 16) | ((d[q].z & 0xffu) << 16)), b3_ = (int)(d[q].z >> 8);
+    const int bs = (unsigned)lane < s0 ? b0_ : (unsigned)lane < s1 ? b1_ : (unsigned)lane < s2 ? b2_ : b3_;
+    const int pos = (unsigned)lane < nv ? vbase + bs + lane : zero_pos;
+    v[q] = A.vals[pos];
+  }
+}
+__device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, int vbase, int zero_pos, int tid, int (&cidx)[8],
+                                            int (&slot)[8], double (&v)[8]) {
+  if (A.segdesc != nullptr) {
+    cshared_fetch(A, L, cbase, vbase, zero_pos, tid, cidx, slot, v);
+    return;
+  }
   CsortRaw r;
   csort_fetch_raw(A, L, tid, r);
   csort_decode(r, cbase, cidx, slot, v);
@@ -171,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     int cidx[kPer];
     [[maybe_unused]] int slot[kPer];  // CSORT: where the entry's product goes (its position in the block's row-major order)
     double v[kPer];
-    if constexpr (CSORT) csort_fetch(A, L, cbase, tid, cidx, slot, v);
+    if constexpr (CSORT) csort_fetch(A, L, cbase, bd.w, A.zero_pos, tid, cidx, slot, v);
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       if (CSORT) {
@@ -479,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
     [[maybe_unused]] int slot[kPer];
     double v[kPer];
     if constexpr (CSORT) {
-      csort_fetch(A, L, cbase, tid, cidx, slot, v);
+      csort_fetch(A, L, cbase, bd.w, A.zero_pos, tid, cidx, slot, v);
     } else {
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {

@@ -1142,23 +1142,29 @@ def test_column_phase_order_of_the_row_groups_is_a_reordering_only(oracle, monke
     dev.close()
 
 
+@pytest.mark.parametrize("shared", ["0", "1"])
 @pytest.mark.parametrize("lead", ["0", "1"])
 @pytest.mark.parametrize("delta", [0.0, SE])
-def test_column_sorted_at_blocks_are_bitwise_the_row_order_layout(monkeypatch, delta, lead):
+def test_column_sorted_at_blocks_are_bitwise_the_row_order_layout(monkeypatch, delta, lead, shared):
     """A' of a banded Jacobian is stored with every row block's entries sorted by COLUMN (coalesced gathers: the row-order
     gather is what bounded the A' product), each entry carrying its row-major slot, to which its product is scattered
     (k_spmv<.., CSORT>).  Same values summed in the same order: every output must be BITWISE that of a handle storing the
     blocks in row order (FPSQ_AT_SORTED=0) -- objgrad, hprod (both Hessian approximations), the seam solves, the one-lane
-    kernels of an unfused handle, with the scalar steps riding in the products (leader workgroups) and without."""
+    kernels of an unfused handle, with the scalar steps riding in the products (leader workgroups) and without.
+    shared = 1 (the default since round 4): the blocks hold NO values of their own -- every entry is read from the row-group
+    copy of A through segment descriptors (fpsq.hip pad_blocks, "shared values"): the entries stream in another order
+    again, into the same LDS slots."""
     qp = _small_pde(seed=13, n=30000, m=3000)
     monkeypatch.setenv("FPSQ_RIDE_LEAD", lead)
+    monkeypatch.setenv("FPSQ_AT_SHARED", shared)
     monkeypatch.setenv("FPSQ_AT_SORTED", "0")
     ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
     one_ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, fuse_two_rhs=0)
     monkeypatch.setenv("FPSQ_AT_SORTED", "1")
     dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
     one = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, fuse_two_rhs=0)
-    assert ref.info()["at_sorted"] == 0 and dev.info()["at_sorted"] == 1 and one.info()["at_sorted"] == 1
+    want = 2 if shared == "1" else 1
+    assert ref.info()["at_sorted"] == 0 and dev.info()["at_sorted"] == want and one.info()["at_sorted"] == want
     rng = np.random.default_rng(3)
     A = qp.scipy_csr()
     for k in range(4):
