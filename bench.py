@@ -57,6 +57,11 @@ def parse_args():
                     help="--op hprod: Val(2) (model-Fletcherpenaltynlp.jl:521-570) or Val(1) (:572-634: + the solve_two_extras lanes)")
     ap.add_argument("--delta", type=float, default=None, help="regularisation; default 0 = first outer iteration "
                     "(algo.jl:46); 1e-3 for the dense-block workload")
+    ap.add_argument("--alternate-delta", action="store_true", default=False,
+                    help="side mode (information, not the headline): consecutive evaluations alternate between delta = 0 and "
+                         "delta = sqrt(eps), i.e. between two iteration-count regimes, so that the run-ahead's expectation "
+                         "(the count of the previous evaluation) is WRONG at every call: what a mispredicted speculative "
+                         "epilogue costs")
     ap.add_argument("--fuse", type=int, default=1)
     ap.add_argument("--kkt-method", default="lsqr-craig", choices=["lsqr-craig", "minres-k"],
                     help="lsqr-craig: the reference's iterative path (default, the headline).  minres-k: MINRES on "
@@ -468,6 +473,8 @@ def main():
                 return None, mdl.solve_two_least_squares(pts[t], xr[t], *hp_out)
             if jac_vals is not None:
                 mdl.set_jacobian_values(jac_vals)
+            if args.alternate_delta:
+                mdl.set_delta(0.0 if t % 2 == 0 else float(np.sqrt(np.finfo(float).eps)))
             return mdl.objgrad(pts[t], gx=out)
         return step
 
@@ -490,7 +497,7 @@ def main():
 
     # ---- roofline of the dominant kernel: a second pass over the same K points with per-launch HIP events
     roofline = None
-    if not args.no_roofline_pass and not extras and not (hfull and args.hessian_approx == 1):  # (timing only for those)
+    if not args.no_roofline_pass and not extras and not (hfull and args.hessian_approx == 1) and not args.alternate_delta:  # (timing only for those)
         model.set_profiling(True)
         pa, pat, t_ms, tot_ms = np.zeros(2), np.zeros(2), 0.0, 0.0
         for t in range(W, W + K):
@@ -589,10 +596,12 @@ def main():
         "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": args.workload, "n": n, "m": m, "nnz": nnz, "sigma": sigma, "rho": rho,
-                   "delta": delta, "fuse_two_rhs": args.fuse, "pointers": args.pointers,
+                   "delta": "alternating 0 / sqrt(eps) (every evaluation mispredicts the run-ahead)" if args.alternate_delta else delta,
+                   "fuse_two_rhs": args.fuse, "pointers": args.pointers,
                    "krylov": ("MINRES on K = [I A'; A -delta I], two systems in lock-step" if mk else "LSQR+MINRES" if extras
                               else "LSQR+LSQR" if hp else "LSQR+CRAIG") + ", atol=rtol=sqrt(eps) (reference defaults)",
                    "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
+                   **({"iters_lsqr_craig_seen": sorted(set(its))} if args.alternate_delta else {}),
                    "all_solved": soft[0] == 0, "parallelism": par,
                    **({"comm_route": DeviceEqQP.ROUTE_NAMES.get(route, str(route))} if sharded else {})},
         "roofline": roofline,

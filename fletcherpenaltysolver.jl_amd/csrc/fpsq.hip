@@ -707,7 +707,7 @@ struct fpsq_solver_s {
   const LaneCtl* gate0 = nullptr;
   const LaneCtl* gate1 = nullptr;
   bool tail_was_run = false;   // the caller's epilogue was enqueued (gated) inside run_krylov and the gates were open
-  int64_t expect_iters[5][5] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last such run needed
+  int64_t expect_iters[5][5][2] = {};  // [kind of lane 0][kind of lane NL-1]: iterations the last two such runs needed
   bool adaptive_runahead = true;    // FPSQ_ADAPTIVE_RUNAHEAD=0 disables (A/B)
   // FPSQ_HOST_TRACE=1: host timestamps at fixed points of fpsq_qp_objgrad, averaged and printed at destroy (developer aid)
   bool host_trace = false;
@@ -1939,10 +1939,15 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   int nlsqr = 0;
   // iteration count of the previous run with the same pair of recurrences (0: unknown).  The scalar steps publish their
   // progress to the host only from that iteration on (and when a recurrence ends): see publish().
-  int64_t* expect_slot = &h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
+  int64_t* expect_slot = h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
   // (sharded: only in halo mode, where every rank derives the same count from the replicated recurrence state)
   const bool local_vec = !h->comm || h->halo;  // vector updates touch rank-local data only
-  int64_t expect_v = (h->adaptive_runahead && local_vec) ? *expect_slot : 0;
+  // The LARGER of the last two counts.  The two ways of being wrong cost very differently: one iteration too many is two
+  // launches that exit at their first instruction (~7 us); one too few is a speculative epilogue enqueued for nothing, a host
+  // round trip before the loop goes on and another before the epilogue is enqueued again (measured with evaluations
+  // alternating between a 14- and a 15-iteration regime, bench.py --alternate-delta: +11 % per evaluation when the last
+  // count alone is the expectation, profiles/r04_alternate_delta.txt).
+  int64_t expect_v = (h->adaptive_runahead && local_vec) ? std::max(expect_slot[0], expect_slot[1]) : 0;
   if (h->force_expect >= 0 && local_vec) expect_v = h->force_expect;
   h->force_expect = -1;
   const int64_t expect = expect_v;
@@ -2545,7 +2550,8 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   if (all_done()) {  // the iteration at which the last recurrence finished (its progress word says so)
     int64_t e = 0;
     for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter + lag(l));
-    *expect_slot = e;
+    expect_slot[1] = expect_slot[0];
+    expect_slot[0] = e;
   }
   if (int rc = flush_pend(true)) return rc;
   ht_mark(h, 4);
