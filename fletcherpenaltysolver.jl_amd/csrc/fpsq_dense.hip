@@ -113,11 +113,14 @@ void solve_two_rhs(fpsq_dense d) {
   hipStream_t s = d->stream;
   const int nb = (int)d->nb, ld = (int)d->mpad;
   if (d->chain) {
-    ChainArgs c{d->chain_pub, ++d->chain_seq, 0, nb, 0, 0, 0, d->chain_err};
+    // (tickets: word 1 behind the publication buffer counts every workgroup of every sweep of this handle, nb per launch)
+    ChainArgs c{d->chain_pub, ++d->chain_seq, 0, nb, 0, 0, 0, d->chain_err, d->chain_pub + (size_t)nb * 512 + 1, 0};
     c.pubseq = d->chain_break ? ~c.seq : c.seq;
+    c.ticket_base = (unsigned long long)(d->chain_seq - 1) * nb;
     hipLaunchKernelGGL(k_trsv_chain<true>, dim3(nb), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->r2, d->y2, c);
     c.seq = ++d->chain_seq;
     c.pubseq = d->chain_break ? ~c.seq : c.seq;
+    c.ticket_base = (unsigned long long)(d->chain_seq - 1) * nb;
     hipLaunchKernelGGL(k_trsv_chain<false>, dim3(nb), dim3(256), 0, s, d->M, ld, d->invs, d->invsT, d->y2, d->r2, c);
     return;
   }
@@ -652,11 +655,14 @@ void band_solve(fpsq_band b) {
   hipStream_t s = b->stream;
   const int nb = (int)b->nb, bw = b->band_w - 1;
   if (b->chain) {  // (both elimination chains advance side by side inside the one launch)
-    ChainArgs c{b->chain_pub, ++b->chain_seq, 0, nb, b->band_w, b->chain_safe, b->chain_bw, b->chain_err};
+    ChainArgs c{b->chain_pub, ++b->chain_seq, 0, nb, b->band_w, b->chain_safe, b->chain_bw, b->chain_err,
+                b->chain_pub + (size_t)nb * 512 + 1, 0};
     c.pubseq = b->chain_break ? ~c.seq : c.seq;
+    c.ticket_base = (unsigned long long)(b->chain_seq - 1) * nb;
     hipLaunchKernelGGL(k_trsv_chain<true>, dim3(nb), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT, b->r2, b->y2, c);
     c.seq = ++b->chain_seq;
     c.pubseq = b->chain_break ? ~c.seq : c.seq;
+    c.ticket_base = (unsigned long long)(b->chain_seq - 1) * nb;
     hipLaunchKernelGGL(k_trsv_chain<false>, dim3(nb), dim3(256), 0, s, b->Mb, kDB, b->invs, b->invsT, b->y2, b->r2, c);
     return;
   }

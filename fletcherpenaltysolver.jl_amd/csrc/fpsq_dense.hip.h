@@ -792,8 +792,14 @@ __global__ __launch_bounds__(256) void k_trsv_step3(const double* __restrict__ L
 // solves with the diagonal inverse and publishes.  Publication as in the product kernels' leader records (fpsq_spmv.hip.h):
 // every 8-byte word carries half a double and the launch number `seq`, written through and read with agent-scope atomics,
 // so a reader that sees the number sees the payload: no flag, no fence, one round trip per look, and the look IS the
-// fetch.  Dependencies point to workgroups with a LOWER index only, which the dispatcher has placed before (workgroups of
-// an XCD are dispatched in order): no circular wait; and every wait is bounded (kChainPolls looks, then the error word is
+// fetch.  WHICH block a workgroup owns is decided by a TICKET it draws when it starts (one agent-scope atomic add; round 4),
+// not by its index in the grid: dependencies point to lower tickets only, and a lower ticket is held by a workgroup that
+// is already RUNNING -- whatever else shares the device.  (By grid index -- round 3 -- that only holds inside one kernel:
+// workgroup i is dispatched by XCD i mod 8, in order within that XCD, so with a second sweep on the device -- another
+// handle, stream or process -- XCD a can be full of kernel Y's waiting workgroups while X's lowest unfinished block is not
+// yet dispatched there, and vice versa: the circular wait across kernels that the riding leaders of the product kernels
+// ran into, fpsq_spmv.hip.h "WHO LEADS".  The ticket's round trip, ~1.5 us, is paid once per workgroup at its start, long
+// before its turn in a 50-70 us sweep.)  Every wait is bounded all the same (kChainPolls looks, then the error word is
 // raised and the workgroup goes on publishing, so nobody behind it waits in turn; an abort word behind the buffer, set with
 // it and looked at before and during every wait, keeps the waits that are still to come short: a failed sweep ends after ONE
 // waiting time, not one per link; the call fails with FPSQ_ERR_TIMEOUT).
@@ -807,6 +813,8 @@ struct ChainArgs {
   unsigned int pubseq;      // what a workgroup publishes: `seq` (anything else only in the test of the bounded wait)
   int nb, band_w, cs, cb;
   unsigned long long* err;  // host-mapped
+  unsigned long long* ticket;      // monotone counter (never reset): this launch's workgroups draw ticket_base .. + nb - 1
+  unsigned long long ticket_base;
 };
 __device__ __forceinline__ bool chain_coupled(const ChainArgs& c, int b, int j) {
   const int w = c.band_w > 0 ? c.band_w - 1 : c.nb;
@@ -840,8 +848,12 @@ __global__ __launch_bounds__(256) void k_trsv_chain(const double* __restrict__ L
   __shared__ double rk[kDB * 2];
   __shared__ double part[2][kDB * 2];
   __shared__ double yk[kDB * 2];
+  __shared__ int ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = FORWARD ? (int)blockIdx.x : c.nb - 1 - (int)blockIdx.x;
+  if (tid == 0)
+    ticket = (int)(__hip_atomic_fetch_add(c.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c.ticket_base);
+  __syncthreads();
+  const int b = FORWARD ? ticket : c.nb - 1 - ticket;
   const int i = tid & 127, hf = tid >> 7;
   const double* Xc = (FORWARD ? invT : inv) + (size_t)b * kDB * kDB + (size_t)(hf * 64) * kDB + i;
   const bool xskip = FORWARD ? (hf == 1 && i < 64) : (hf == 0 && i >= 64);  // (wave-uniform) all-zero part of the triangle

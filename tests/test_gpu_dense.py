@@ -643,6 +643,51 @@ def test_chained_sweeps_match_the_step_kernels(oracle, monkeypatch, kind):
         assert _rel(a, b) < 1e-13 and _rel(a, w) < 1e-10
 
 
+def test_two_handles_sweeping_at_once_do_not_wait_on_each_other():
+    """Two direct solvers on the device at the same time (two handles, two host threads, two streams): each chained sweep is a
+    grid of ~50-80 workgroups that WAIT for each other, and both grids compete for the same XCDs.  With the block a workgroup
+    owns decided by the ticket it draws at its start, every block a workgroup waits for is held by a workgroup that is already
+    running, whatever the other kernel occupies (by grid index -- round 3 -- two such kernels could each hold an XCD the
+    other's next link needed: bounded waits expiring, FPSQ_ERR_TIMEOUT).  Forty concurrent solve pairs on a banded handle with
+    782-block-like depth scaled down (two chains) and a dense one: every call succeeds and equals the handle's own
+    single-sweep result bitwise."""
+    import threading
+
+    from fps_amd import problems
+
+    qp = problems.pde_control_like(n=40000, m=10000, per_row=12, window=600, seed=11)
+    HB = _Band(qp.scipy_csr())
+    assert HB.info()["chains"] == 2 and HB.info()["nblocks"] >= 70
+    A = np.random.default_rng(5).uniform(-1, 1, (3000, 3400)) / np.sqrt(3400)
+    HD = _Dense(A)
+    assert HB.factorize(0.25)[0] == 0 and HD.factorize(0.25)[0] == 0
+    rng = np.random.default_rng(9)
+    gb, cb = rng.standard_normal(qp.n), rng.standard_normal(qp.m)
+    gd, cd = rng.standard_normal(3400), rng.standard_normal(3000)
+    want_b = HB.solve(HB.lib.fpsq_band_solve_two_mixed, gb, cb)
+    want_d = HD.solve(HD.lib.fpsq_dense_solve_two_mixed, gd, cd)
+    bad = []
+
+    def work(H, fn, g, c, want):
+        try:
+            for _ in range(40):
+                got = H.solve(fn, g, c)
+                if not all(np.array_equal(a, b) for a, b in zip(got, want)):
+                    bad.append("mismatch")
+        except BaseException as e:  # noqa: BLE001  (an assertion in a thread would otherwise vanish)
+            bad.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(HB, HB.lib.fpsq_band_solve_two_mixed, gb, cb, want_b)),
+          threading.Thread(target=work, args=(HD, HD.lib.fpsq_dense_solve_two_mixed, gd, cd, want_d))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad[:3]
+    HB.close()
+    HD.close()
+
+
 def test_chained_sweep_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
     """Every wait of the chained sweep has an end each wave reaches: with the workgroups made to publish a wrong launch number
     (FPSQ_DEBUG_CHAIN_BREAK=1) the readers give up after their bounded number of looks, raise the handle's error word and go
