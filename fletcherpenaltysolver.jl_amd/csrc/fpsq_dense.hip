@@ -278,6 +278,16 @@ int fpsq_dense_set_structure_coo(fpsq_dense d, int64_t nnz, const int64_t* rows,
   std::vector<int64_t> target(std::max<int64_t>(ns, 1));
   for (int64_t i = 0; i < ns; ++i) target[i] = (int64_t)srow[i] * d->npad + scol[i];
   const bool dup = ns != nnz;
+  // a second structure call replaces the first one's buffers (and must not keep its slot table when the new pattern has no
+  // duplicates: k_coo_to_slots takes a non-null table for one)
+  for (void** q : {(void**)&d->coo_perm, (void**)&d->coo_in, (void**)&d->coo_target, (void**)&d->coo_slotptr}) {
+    if (!*q) continue;
+    auto it = std::find(d->allocs.begin(), d->allocs.end(), *q);
+    if (it != d->allocs.end()) d->allocs.erase(it);
+    hipFree(*q);
+    *q = nullptr;
+  }
+  d->coo_nnz = -1;
   if (dmalloc(d, &d->coo_perm, (size_t)std::max<int64_t>(nnz, 1)) || dmalloc(d, &d->coo_in, (size_t)std::max<int64_t>(nnz, 1)) ||
       dmalloc(d, &d->coo_target, target.size()) || (dup && dmalloc(d, &d->coo_slotptr, slotptr.size())))
     return FPSQ_ERR_HIP;

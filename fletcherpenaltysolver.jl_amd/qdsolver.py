@@ -205,6 +205,7 @@ class HIPDirectQDSolver(QDSolver):
         self.ldlt_r2 = -REG_DROP if ldlt_r2 is None else float(ldlt_r2)    # struct.jl:314 (None: drop, see the docstring)
         self._check(self._lib.fpsq_dense_set_regularization(self._d, self.ldlt_tol, -self.ldlt_r2))
         self._fact_key = None
+        self._owed = self._mixed_at = None
 
     def _check(self, rc):
         if rc < 0:
@@ -246,10 +247,22 @@ class HIPDirectQDSolver(QDSolver):
 
     def solve_two_mixed(self, nlp, x, rhs1, rhs2):
         self._factorize(nlp, x)
+        self._owed, self._mixed_at = None, (np.array(x, dtype=np.float64), float(nlp.delta))
         return self._solve(self._lib.fpsq_dense_solve_two_mixed, rhs1, rhs2)
 
     def solve_two_least_squares(self, nlp, x, rhs1, rhs2):
+        self._restore_factor(nlp)
         return self._solve(self._lib.fpsq_dense_solve_two_least_squares, rhs1, rhs2)
+
+    def _restore_factor(self, nlp):
+        """solve_two_extras may have left the factor of A A' + tau I (tau != delta) in the handle; the reference's extras never
+        touch its LDL' factors, so `solve_two_least_squares` must find the factor of delta at the x of the last
+        `solve_two_mixed` (linear_system.jl:194-195).  Put back LAZILY: only when such a solve actually comes (an hprod!
+        Val(1) then pays one extra factorisation, not two)."""
+        if self._owed is not None:
+            x, delta = self._owed
+            self._owed = None
+            self._factorize(nlp, x, delta)
 
     def solve_two_extras(self, nlp, x, rhs1, rhs2):
         """invJtJJv = (AA' + tau I)^-1 A rhs1, invJtJSsv = (AA' + tau I)^-1 rhs2 (src/solve_linear_system.jl:142-159).
@@ -259,12 +272,10 @@ class HIPDirectQDSolver(QDSolver):
         exactly this x and tau."""
         tau = max(float(nlp.delta), 1e-14)                                            # :148
         if self._fact_key != (np.asarray(x, dtype=np.float64).tobytes(), tau):
+            if tau != float(nlp.delta) and self._owed is None and self._mixed_at is not None:
+                self._owed = self._mixed_at  # (the factor a later solve_two_least_squares is entitled to: restored lazily)
             self._factorize(nlp, x, tau)
         _, q1, _, q2 = self._solve(self._lib.fpsq_dense_solve_two_mixed, rhs1, rhs2)
-        if tau != float(nlp.delta):
-            # the reference's extras never touch the LDL' factors (cgls / minres on the operator): leave the cached factor
-            # the one of delta, which the next solve_two_least_squares re-uses (linear_system.jl:194-195)
-            self._factorize(nlp, x)
         return q1, -q2
 
     def info(self):
@@ -306,6 +317,7 @@ class HIPBandedDirectQDSolver(QDSolver):
         self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)
         self.ldlt_r2 = -REG_DROP if ldlt_r2 is None else float(ldlt_r2)    # (None: drop, see HIPDirectQDSolver)
         self._check(self._lib.fpsq_band_set_regularization(b, self.ldlt_tol, -self.ldlt_r2))
+        self._owed = self._mixed_at = None
         self.factorized = False
         self._fact_key = None
 
@@ -348,18 +360,23 @@ class HIPBandedDirectQDSolver(QDSolver):
 
     def solve_two_mixed(self, nlp, x, rhs1, rhs2):
         self._factorize(nlp, x)
+        self._owed, self._mixed_at = None, (np.array(x, dtype=np.float64), float(nlp.delta))
         return self._solve(self._lib.fpsq_band_solve_two_mixed, rhs1, rhs2)
 
     def solve_two_least_squares(self, nlp, x, rhs1, rhs2):
+        if self._owed is not None:  # (the factor of delta, displaced by solve_two_extras: see HIPDirectQDSolver._restore_factor)
+            x0, delta = self._owed
+            self._owed = None
+            self._factorize(nlp, x0, delta)
         return self._solve(self._lib.fpsq_band_solve_two_least_squares, rhs1, rhs2)
 
     def solve_two_extras(self, nlp, x, rhs1, rhs2):
         tau = max(float(nlp.delta), 1e-14)                                            # solve_linear_system.jl:148
         if self._fact_key != (np.asarray(x, dtype=np.float64).tobytes(), tau):
+            if tau != float(nlp.delta) and self._owed is None and self._mixed_at is not None:
+                self._owed = self._mixed_at
             self._factorize(nlp, x, tau)
         _, q1, _, q2 = self._solve(self._lib.fpsq_band_solve_two_mixed, rhs1, rhs2)
-        if tau != float(nlp.delta):
-            self._factorize(nlp, x)   # (the cached factor stays the one of delta, see HIPDirectQDSolver.solve_two_extras)
         return q1, -q2
 
     def info(self):

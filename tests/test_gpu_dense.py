@@ -442,6 +442,47 @@ def test_banded_qdsolver_through_the_seam(oracle):
     qds.close()
 
 
+@pytest.mark.parametrize("name", ["hip_ldlt", "hip_direct"])
+def test_direct_backends_restore_the_delta_factor_lazily_after_extras(oracle, name):
+    """hprod! Val(1) calls solve_two_least_squares, then solve_two_extras (tau = max(delta, 1e-14) != delta = 0: the direct
+    back-ends refactorise A A' + tau I), and the NEXT hprod!'s solve_two_least_squares must find the factor of delta again --
+    the reference's extras never touch its LDL' factors (linear_system.jl:142-159, :194-195).  Restored lazily (one extra
+    factorisation per Val(1) product, not two: advisor, round 3): the least-squares solves before and after an extras call
+    are bitwise equal, two extras calls in a row factorise once, and both agree with the exact solves.
+    Also pinned here: the DEFAULT regularisation of these back-ends drops a vanishing pivot (FPSQ_REG_DROP; the reference's
+    LDLtSolver default is r2 = -sqrt(eps), struct.jl:314 -- stated in INTEGRATION.md), an explicit ldlt_r2 restores the
+    reference's value."""
+    from fps_amd import problems
+    from fps_amd.qdsolver import REG_DROP, qdsolver_correspondence
+
+    qp = problems.pde_control_like(n=5000, m=500, per_row=20, window=512, seed=4)
+    model = nlpmodels.EqQPModel(qp)
+    qds = qdsolver_correspondence[name](model, 0.0)
+    assert qds.ldlt_r2 == -REG_DROP
+    ref = qdsolver_correspondence[name](model, 0.0, ldlt_r2=-float(np.sqrt(np.finfo(float).eps)))
+    assert ref.ldlt_r2 == -float(np.sqrt(np.finfo(float).eps))   # src/solve_two_systems_struct.jl:314
+    ref.close()
+    fp = FletcherPenaltyNLP(model, 1e3, 1.0, 0.0, 1, qds=qds)
+    rng = np.random.default_rng(2)
+    g, c = rng.standard_normal(qp.n), rng.standard_normal(qp.m)
+    r1, r2 = rng.standard_normal(qp.n), rng.standard_normal(qp.n)
+    qds.solve_two_mixed(fp, qp.x, g, c)
+    before = qds.solve_two_least_squares(fp, qp.x, r1, r2)
+    e1 = qds.solve_two_extras(fp, qp.x, r1, c)
+    assert qds._owed is not None           # (nothing refactorised yet for the least-squares solves)
+    e2 = qds.solve_two_extras(fp, qp.x, r1, c)
+    assert all(np.array_equal(a, b) for a, b in zip(e1, e2))
+    after = qds.solve_two_least_squares(fp, qp.x, r1, r2)
+    assert qds._owed is None
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+    A = qp.scipy_csr()
+    for a, b in zip(after, oracle.exact_two_least_squares(A, 0.0, r1, r2)):
+        assert _rel(a, b) < 1e-9
+    for a, b in zip(e1, oracle.exact_two_extras(A, 0.0, r1, c)):
+        assert _rel(a, b) < 1e-8
+    qds.close()
+
+
 def test_config4_aug2dc_like_through_the_banded_direct_backend(oracle):
     """BASELINE configs[3] (AUG2DC-like grid incidence Jacobian, n = 20200, m = 10000; CUTEst itself is not available):
     the iterative path stops UNSOLVED on ln_conlim here (tests/test_gpu_parity.py) -- the sparse direct back-end (the
@@ -522,6 +563,29 @@ def test_dense_coo_handover_matches_the_dense_array(oracle, where, dup):
     assert F.lib.fpsq_dense_set_jacobian_coo(F.d, vals.ctypes.data) == -1   # structure not set
     for h in (D, D2, E, F):
         h.close()
+
+
+def test_dense_coo_structure_can_be_replaced(oracle):
+    """A second fpsq_dense_set_structure_coo on the same handle replaces the first pattern: buffers released (not leaked until
+    destroy), and a pattern WITHOUT duplicates after one WITH duplicates does not inherit the old slot table; a triplet
+    outside the matrix is an argument error that leaves the handle without a structure."""
+    m, n = 150, 260
+    rng = np.random.default_rng(4)
+    g, c = rng.standard_normal(n), rng.standard_normal(m)
+    E = _Dense(np.ones((m, n)))
+    for dup, seed in ((37, 3), (0, 5), (11, 7)):
+        rows, cols, vals, A = _coo_case(m, n, 9000, seed, dup)
+        assert E.lib.fpsq_dense_set_structure_coo(E.d, rows.size, rows.ctypes.data, cols.ctypes.data, 1) == 0
+        assert E.lib.fpsq_dense_set_jacobian_coo(E.d, vals.ctypes.data) == 0
+        E.factorize(1e-3)
+        got = E.solve(E.lib.fpsq_dense_solve_two_mixed, g, c)
+        for a, b in zip(got, oracle.exact_two_mixed(A, 1e-3, g, c)):
+            assert _rel(a, b) < 1e-10
+    bad = cols.copy()
+    bad[-1] = 0  # (1-based: column 0 does not exist)
+    assert E.lib.fpsq_dense_set_structure_coo(E.d, rows.size, rows.ctypes.data, bad.ctypes.data, 1) == -1
+    assert b"out of range" in E.lib.fpsq_dense_last_error(E.d)
+    E.close()
 
 
 @pytest.mark.parametrize("dup", [0, 25])
