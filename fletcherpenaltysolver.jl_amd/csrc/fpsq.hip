@@ -1922,36 +1922,61 @@ void launch_updates(fpsq_handle h, const UpdSeg& s0, const UpdSeg& s1, const Upd
 // a line search mostly repeat their counts -- the epilogue runs without the host first having to see `done` and only
 // then launching it (a ~30 us bubble per evaluation); if not, the gated kernels exit at once and the loop goes on.
 // h->tail_was_run tells the caller whether its epilogue has been taken care of.
+//
+// Structure (round 4; one 640-line function before): KrylovRun::run() is the loop and knows three things -- a PRODUCT is
+// launched (with whatever rides in it), the STEPS behind it are posted (PendingSteps: they ride in the next product launch
+// or get a launch of their own), the host PACES itself (exchange boundaries of a sharded run, run-ahead, speculation).
+// What a recurrence of a given kind contributes at each of those points -- which step kinds, which update segments,
+// which partial arrays -- is in the builders (lane_*, *_seg, steps_after_*); nothing outside them switches on a lane's kind.
 using TailFn = std::function<int()>;
+
+// ---- what depends on the KIND of a recurrence
+inline int lane_begin_kind(const Lane& L) {
+  return L.kind == LANE_LSQR ? STEP_LSQR_BEGIN : L.kind == LANE_CRAIG ? STEP_CRAIG_BEGIN : L.kind == LANE_LNLQ ? STEP_LNLQ_BEGIN : STEP_MINRES_BEGIN;
+}
+// the step behind the A' product of an iteration (a MINRES lane runs the stopping tests of the previous iteration there)
+inline int lane_kind_after_at(const Lane& L) {
+  return L.kind == LANE_LSQR ? STEP_LSQR_SA : L.kind == LANE_CRAIG ? STEP_CRAIG_SA : L.kind == LANE_LNLQ ? STEP_LNLQ_SA : STEP_MINRES_C;
+}
+// ... and behind the A product (MINRES: step A, between its stages E1 and E2)
+inline int lane_kind_after_a(const Lane& L) {
+  return L.kind == LANE_LSQR ? STEP_LSQR_SB : L.kind == LANE_CRAIG ? STEP_CRAIG_SB : L.kind == LANE_LNLQ ? STEP_LNLQ_SB : STEP_MINRES_A;
+}
+inline const int32_t* lane_iter_ptr(const Lane& L) {
+  return L.kind == LANE_LSQR ? &((LsqrState*)L.state)->iter
+         : L.kind == LANE_CRAIG ? &((CraigState*)L.state)->iter
+         : L.kind == LANE_LNLQ  ? &((LnlqState*)L.state)->iter
+                                : &((MinresState*)L.state)->iter;
+}
+// a MINRES / LNLQ lane reports iteration k (step C; pass k) while the host is enqueueing iteration k + 1
+inline int lane_lag(const Lane& L) { return L.kind == LANE_MINRES || L.kind == LANE_LNLQ ? 1 : 0; }
+// after a product launch that carried the lane's step: the lane lives in its other state copy now
+inline void lane_swap_state(Lane& L) {
+  std::swap(L.state, L.state_alt);
+  L.ctl = reinterpret_cast<LaneCtl*>(L.state);  // LaneCtl is the first member of every state
+  L.ctlT = L.kind == LANE_MINRES ? &reinterpret_cast<MinresState*>(L.state)->ctlT : L.ctl;
+}
+
 template <int NL>
-int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
-  const int64_t n = h->n, m = h->m;
-  h->tail_was_run = false;
-  const fpsq_options& o = h->opt;
-  hipStream_t s = h->stream;
-  const int gn = ew_grid(n), gm = ew_grid(m);
-  const int nbA = npart_A(h);
-  double* LP = h->LP;
-  double* SP = h->SP;
+struct KrylovRun {
+  fpsq_handle h;
+  Lane* lanes;
+  const TailFn* tail;
+  const int64_t n, m;
+  const fpsq_options& o;
+  hipStream_t s;
+  const int gn, gm, nbA;
+  double *LP, *SP;
+  // the run-ahead's expectation (see run())
+  int64_t* expect_slot;
+  const bool local_vec;    // vector updates touch rank-local data only (one GPU, or the halo-sharded layout)
+  int64_t expect = 0;
+  int32_t pub_from = 0;
+  // the lanes
   bool any_lsqr = false;
   int64_t itmax_all = 0;
-  Progress* prog[2];
-  int nlsqr = 0;
-  // iteration count of the previous run with the same pair of recurrences (0: unknown).  The scalar steps publish their
-  // progress to the host only from that iteration on (and when a recurrence ends): see publish().
-  int64_t* expect_slot = h->expect_iters[lanes[0].kind][lanes[NL - 1].kind];
-  // (sharded: only in halo mode, where every rank derives the same count from the replicated recurrence state)
-  const bool local_vec = !h->comm || h->halo;  // vector updates touch rank-local data only
-  // The LARGER of the last two counts.  The two ways of being wrong cost very differently: one iteration too many is two
-  // launches that exit at their first instruction (~7 us); one too few is a speculative epilogue enqueued for nothing, a host
-  // round trip before the loop goes on and another before the epilogue is enqueued again (measured with evaluations
-  // alternating between a 14- and a 15-iteration regime, bench.py --alternate-delta: +11 % per evaluation when the last
-  // count alone is the expectation, profiles/r04_alternate_delta.txt).
-  int64_t expect_v = (h->adaptive_runahead && local_vec) ? std::max(expect_slot[0], expect_slot[1]) : 0;
-  if (h->force_expect >= 0 && local_vec) expect_v = h->force_expect;
-  h->force_expect = -1;
-  const int64_t expect = expect_v;
-  const int32_t pub_from = (int32_t)std::min<int64_t>(expect, INT32_MAX);
+  Progress* prog[2] = {nullptr, nullptr};
+  int minres_lane = -1, affine_lane = -1;
   LsqrState* lsS[2] = {nullptr, nullptr};
   LsqrParams lsP[2] = {};
   CraigState* crS = nullptr;
@@ -1960,76 +1985,129 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
   MinresParams mrP{};
   LnlqState* lqS = nullptr;
   LnlqParams lqP{};
-  int minres_lane = -1;
-  for (int l = 0; l < NL; ++l) {
-    Lane& L = lanes[l];
-    prog[l] = &h->prog_dev[l];
-    h->prog_host[l].iter = 0;
-    h->prog_host[l].done = 0;
-    L.st_dev = h->hstats_dev + (L.st - h->hstats);
-    *L.st = fpsq_stats{};
-    if (L.kind == LANE_LSQR) {
-      any_lsqr = true;
-      LsqrState* S = h->lsqr[nlsqr];
-      L.state_alt = h->lsqr_alt[nlsqr++];
-      L.state = S;
-      L.ctl = &S->ctl;
-      L.itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
-      lsP[nlsqr - 1] = LsqrParams{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax,
-                                  pub_from};
-      lsS[nlsqr - 1] = S;
-    } else if (L.kind == LANE_MINRES) {
-      MinresState* S = h->minres;
-      L.state_alt = h->minres_alt;
-      L.state = S;
-      L.ctl = &S->ctl;
-      L.ctlT = &S->ctlT;
-      L.itmax = o.ne_itmax == 0 ? 2 * m : o.ne_itmax;
-      // (its stopping tests of iteration k run one product later than the other recurrences': see the main loop)
-      mrP = MinresParams{L.lambda, o.ne_atol, o.ne_rtol, o.ne_etol, o.ne_conlim, L.itmax, std::max(pub_from - 1, 0)};
-      mrS = S;
-      minres_lane = l;
-    } else if (L.kind == LANE_LNLQ) {
-      LnlqState* S = h->lnlq;
-      L.state_alt = h->lnlq_alt;
-      L.state = S;
-      L.ctl = &S->ctl;
-      // pass k of lnlq!'s loop is completed (and tested) by the step after the A' product of iteration k + 1
-      L.itmax = (o.ln_itmax == 0 ? n + m : o.ln_itmax) + 1;
-      lqP = LnlqParams{L.delta != 0.0 ? 1.0 / L.delta : 1.0, o.ln_atol, o.ln_rtol, L.xsign, L.itmax - 1, NL == 2 ? 1 : 0,
-                       std::max(pub_from - 1, 0)};
-      lqS = S;
-    } else {
-      CraigState* S = h->craig;
-      L.state_alt = h->craig_alt;
-      L.state = S;
-      L.ctl = &S->ctl;
-      L.itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
-      const bool reg = L.delta != 0.0;
-      crP = CraigParams{reg ? 1.0 / L.delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim,
-                        L.xsign, L.itmax, NL == 2 ? 1 : 0, pub_from};
-      crS = S;
-    }
-    if (!L.ctlT) L.ctlT = L.ctl;
-    itmax_all = std::max(itmax_all, L.itmax);
-  }
-  // Riding steps (two LSQR / CRAIG lanes; one GPU or the halo-sharded layout): instead of a one-workgroup k_step launch
-  // behind every product, the two steps are handed to the NEXT product launch, where leader workgroups compute them and the
-  // others pick the coefficients up on their way to the row epilogue (k_spmv_atl, k_spmv_rgcs<.., LEAD>).  Such a step reads
-  // the lane's current state copy and writes the other one; the lane's pointers (state, ctl) switch to it once the launch
-  // is enqueued.
-  bool lead = NL == 2 && (!h->comm || h->halo) && h->ride_lead && h->AT.padded && (h->AT.sorted || h->AT.col16) && h->RA.ok;
-  // (a MINRES lane -- solve_two_extras -- on one GPU only: its sums run over row-sharded m-vectors)
-  for (int l = 0; l < NL; ++l)
-    lead = lead && (lanes[l].kind == LANE_LSQR || is_ln(lanes[l].kind) || (lanes[l].kind == LANE_MINRES && !h->comm));
-#define c0 (lanes[0].ctl)       /* A product */
-#define c1 (lanes[NL - 1].ctl)
-#define t0 (lanes[0].ctlT)      /* A' product */
-#define t1 (lanes[NL - 1].ctlT)
+  bool lead = false;        // the steps ride in the next product launch (leader workgroups)
+  bool fuse_upd = false;    // the vector updates ride in the product launches
+  bool split_steps = false; // replicated n-sums and per-rank m-sums cannot share a presum launch
+  StepArgs none{};
+  // the steps behind the last product, not launched yet
   StepArgs pend[2];
   bool have_pend = false;
+  // the loop
+  double *SPcur, *SPalt;
+  int look = 1;
+  int64_t it = 0;
+  int64_t spec_it = -1;  // iteration behind which the gated flush + tail were enqueued
+  UpdSeg winit[2] = {seg_none(), seg_none()};
+  UpdSeg lu[2] = {seg_none(), seg_none()};  // what rides in (or precedes) this iteration's products: LSQR's update of the previous one
+  int nlu = 0;
+
+  KrylovRun(fpsq_handle h_, Lane* lanes_, const TailFn* tail_)
+      : h(h_), lanes(lanes_), tail(tail_), n(h_->n), m(h_->m), o(h_->opt), s(h_->stream), gn(ew_grid(h_->n)), gm(ew_grid(h_->m)),
+        nbA(npart_A(h_)), LP(h_->LP), SP(h_->SP), expect_slot(h_->expect_iters[lanes_[0].kind][lanes_[NL - 1].kind]),
+        local_vec(!h_->comm || h_->halo), SPcur(h_->SP), SPalt(h_->SP2) {
+    none.kind = STEP_NONE;
+  }
+
+  // coefficients of the A product / the A' product
+  LaneCtl* c0() const { return lanes[0].ctl; }
+  LaneCtl* c1() const { return lanes[NL - 1].ctl; }
+  LaneCtl* t0() const { return lanes[0].ctlT; }
+  LaneCtl* t1() const { return lanes[NL - 1].ctlT; }
+
+  // ------------------------------------------------------------------ set-up of the lanes
+  void setup() {
+    h->tail_was_run = false;
+    // iteration count of the previous runs with the same pair of recurrences (0: unknown).  The scalar steps publish their
+    // progress to the host only from that iteration on (and when a recurrence ends): see publish().
+    // (sharded: only in halo mode, where every rank derives the same count from the replicated recurrence state)
+    // The LARGER of the last two counts.  The two ways of being wrong cost very differently: one iteration too many is two
+    // launches that exit at their first instruction (~7 us); one too few is a speculative epilogue enqueued for nothing, a host
+    // round trip before the loop goes on and another before the epilogue is enqueued again (measured with evaluations
+    // alternating between a 14- and a 15-iteration regime, bench.py --alternate-delta: +11 % per evaluation when the last
+    // count alone is the expectation, profiles/r04_alternate_delta.txt).
+    int64_t expect_v = (h->adaptive_runahead && local_vec) ? std::max(expect_slot[0], expect_slot[1]) : 0;
+    if (h->force_expect >= 0 && local_vec) expect_v = h->force_expect;
+    h->force_expect = -1;
+    expect = expect_v;
+    pub_from = (int32_t)std::min<int64_t>(expect, INT32_MAX);
+    int nlsqr = 0;
+    for (int l = 0; l < NL; ++l) {
+      Lane& L = lanes[l];
+      prog[l] = &h->prog_dev[l];
+      h->prog_host[l].iter = 0;
+      h->prog_host[l].done = 0;
+      L.st_dev = h->hstats_dev + (L.st - h->hstats);
+      *L.st = fpsq_stats{};
+      if (L.kind == LANE_LSQR) {
+        any_lsqr = true;
+        LsqrState* S = h->lsqr[nlsqr];
+        L.state_alt = h->lsqr_alt[nlsqr++];
+        L.state = S;
+        L.ctl = &S->ctl;
+        L.itmax = o.ls_itmax == 0 ? n + m : o.ls_itmax;
+        lsP[nlsqr - 1] = LsqrParams{L.lambda, o.ls_atol, o.ls_rtol, o.ls_axtol, o.ls_btol, o.ls_etol, o.ls_conlim, L.itmax,
+                                    pub_from};
+        lsS[nlsqr - 1] = S;
+      } else if (L.kind == LANE_MINRES) {
+        MinresState* S = h->minres;
+        L.state_alt = h->minres_alt;
+        L.state = S;
+        L.ctl = &S->ctl;
+        L.ctlT = &S->ctlT;
+        L.itmax = o.ne_itmax == 0 ? 2 * m : o.ne_itmax;
+        // (its stopping tests of iteration k run one product later than the other recurrences': see the main loop)
+        mrP = MinresParams{L.lambda, o.ne_atol, o.ne_rtol, o.ne_etol, o.ne_conlim, L.itmax, std::max(pub_from - 1, 0)};
+        mrS = S;
+        minres_lane = l;
+      } else if (L.kind == LANE_LNLQ) {
+        LnlqState* S = h->lnlq;
+        L.state_alt = h->lnlq_alt;
+        L.state = S;
+        L.ctl = &S->ctl;
+        // pass k of lnlq!'s loop is completed (and tested) by the step after the A' product of iteration k + 1
+        L.itmax = (o.ln_itmax == 0 ? n + m : o.ln_itmax) + 1;
+        lqP = LnlqParams{L.delta != 0.0 ? 1.0 / L.delta : 1.0, o.ln_atol, o.ln_rtol, L.xsign, L.itmax - 1, NL == 2 ? 1 : 0,
+                         std::max(pub_from - 1, 0)};
+        lqS = S;
+      } else {
+        CraigState* S = h->craig;
+        L.state_alt = h->craig_alt;
+        L.state = S;
+        L.ctl = &S->ctl;
+        L.itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
+        const bool reg = L.delta != 0.0;
+        crP = CraigParams{reg ? 1.0 / L.delta : 1.0, reg ? 1.0 : 0.0, o.ln_atol, o.ln_rtol, o.ln_btol, o.ln_conlim,
+                          L.xsign, L.itmax, NL == 2 ? 1 : 0, pub_from};
+        crS = S;
+      }
+      if (!L.ctlT) L.ctlT = L.ctl;
+      itmax_all = std::max(itmax_all, L.itmax);
+    }
+    // Riding steps (two LSQR / CRAIG lanes; one GPU or the halo-sharded layout): instead of a one-workgroup k_step launch
+    // behind every product, the two steps are handed to the NEXT product launch, where leader workgroups compute them and the
+    // others pick the coefficients up on their way to the row epilogue (k_spmv_atl, k_spmv_rgcs<.., LEAD>).  Such a step reads
+    // the lane's current state copy and writes the other one; the lane's pointers (state, ctl) switch to it once the launch
+    // is enqueued.
+    lead = NL == 2 && (!h->comm || h->halo) && h->ride_lead && h->AT.padded && (h->AT.sorted || h->AT.col16) && h->RA.ok;
+    // (a MINRES lane -- solve_two_extras -- on one GPU only: its sums run over row-sharded m-vectors)
+    for (int l = 0; l < NL; ++l)
+      lead = lead && (lanes[l].kind == LANE_LSQR || is_ln(lanes[l].kind) || (lanes[l].kind == LANE_MINRES && !h->comm));
+    // fast start: the CRAIG lane whose right-hand side the LSQR start-up product forms
+    for (int l = 0; l < NL; ++l)
+      if (is_ln(lanes[l].kind) && lanes[l].affine_shift && any_lsqr && NL == 2 && local_vec) affine_lane = l;
+    // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
+    // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
+    // iteration it; CRAIG's updates of iteration it (read the long pair and the OLD short pair) go with the A product,
+    // which therefore writes the alternate short pair (ping-pong).  The same holds for a row-sharded handle in halo mode
+    // (every vector a rank updates is its own).  Sharded with replicated n-vectors: separate update launch, in place.
+    fuse_upd = local_vec;
+    split_steps = h->comm && !h->halo;
+    look = std::max(1, o.lookahead);
+  }
+
+  // ------------------------------------------------------------------ the steps behind a product
   // hands the pending steps to a stand-alone launch (needed whenever the host or a gated kernel must see their effect now)
-  auto flush_pend = [&](bool sharded) -> int {
+  int flush_pend(bool sharded) {
     if (!have_pend) return 0;
     have_pend = false;
     if (h->comm) {  // (prepared -- gathered -- when they were handed over)
@@ -2037,19 +2115,15 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       return 0;
     }
     return launch_step(h, pend[0], pend[1], sharded);
-  };
+  }
   // after a product launch that carried the pending steps: the lanes live in their other state copies now
-  auto adopt_pend = [&]() {
-    for (int l = 0; l < NL; ++l) {
-      if (pend[l].kind == STEP_NONE) continue;
-      std::swap(lanes[l].state, lanes[l].state_alt);
-      lanes[l].ctl = reinterpret_cast<LaneCtl*>(lanes[l].state);  // LaneCtl is the first member of every state
-      lanes[l].ctlT = lanes[l].kind == LANE_MINRES ? &reinterpret_cast<MinresState*>(lanes[l].state)->ctlT : lanes[l].ctl;
-    }
+  void adopt_pend() {
+    for (int l = 0; l < NL; ++l)
+      if (pend[l].kind != STEP_NONE) lane_swap_state(lanes[l]);
     have_pend = false;
-  };
+  }
   // the steps behind a product: riding in the next product launch when both lanes have one, else their own launch now
-  auto post_step = [&](const StepArgs& a0, const StepArgs& a1, bool sharded) -> int {
+  int post_step(const StepArgs& a0, const StepArgs& a1, bool sharded) {
     if (lead && a0.kind != STEP_NONE && a1.kind != STEP_NONE) {
       pend[0] = a0;
       pend[1] = a1;
@@ -2058,11 +2132,10 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       have_pend = true;
       return 0;
     }
-    StepArgs nn{};
-    nn.kind = STEP_NONE;
-    return launch_step(h, a0.kind ? a0 : a1, a0.kind ? a1 : nn, sharded);
-  };
-  auto pre_args = [&](bool for_at) -> const StepArgs* {
+    return launch_step(h, a0.kind ? a0 : a1, a0.kind ? a1 : none, sharded);
+  }
+  // the pending steps as the next product launch takes them (null: nothing pending)
+  const StepArgs* pre_args(bool for_at) {
     if (!have_pend) return nullptr;
     for (int l = 0; l < NL; ++l) {
       pend[l].state = lanes[l].state;
@@ -2070,194 +2143,16 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       pend[l].prod_ctl_off = for_at && lanes[l].kind == LANE_MINRES ? (int32_t)(offsetof(MinresState, ctlT) / 8) : 0;
     }
     return pend;
-  };
-  int affine_lane = -1;  // fast start: the CRAIG lane whose right-hand side the LSQR start-up product forms
-  for (int l = 0; l < NL; ++l)
-    if (is_ln(lanes[l].kind) && lanes[l].affine_shift && any_lsqr && NL == 2 && local_vec) affine_lane = l;
-
-  // ---- start-up: parameters, right-hand sides, beta_1 (one launch), then (LSQR) alpha_1 and w_1
-  StepArgs none{};
-  none.kind = STEP_NONE;
-  StepArgs b0 = none, b1 = none;
-  LoadSeg ld[2] = {};
-  ZeroArgs z{};
-  int nzblk = 0;
-  for (int l = 0; l < NL; ++l) {
-    Lane& L = lanes[l];
-    double* pe = L.kind == LANE_LSQR ? (l == 0 ? h->pE : h->pE2) : h->pEm[l];
-    LoadSeg& g = ld[l];
-    g.src = L.rhs;
-    g.scale = L.rhs_scale;
-    g.lane = l;
-    g.partials = pe;
-    if (L.kind == LANE_LSQR) {
-      // x = 0 is written by the w_1 start-up update (also when the recurrence ends at start-up)
-      g.dst = LP;
-      g.len = n;
-      g.sum_len = n_owned(h);
-      g.nblk = L.preloaded ? 0 : gn;  // fast start: the caller wrote the lane and the ||rhs||^2 partials already
-      (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
-    } else if (L.kind == LANE_MINRES) {
-      // r1 = r2 = b: r2 sits in Mr[1] (iteration 1 reads r2 from Mr[it % 2]) and in the short pair's lane
-      g.dst = SP;
-      g.dst2 = h->Mr[1];
-      g.len = m;
-      g.sum_len = m;
-      g.nblk = gm;
-      z.p[0] = L.x;
-      z.p[1] = h->Mw[0];
-      z.p[2] = h->Mw[1];
-      z.p[3] = h->Mr[0];
-      z.n[0] = z.n[1] = z.n[2] = z.n[3] = m;
-      nzblk = gm;
-    } else {
-      if (L.affine_shift) {  // fast start: the lane receives `shift`; the start-up product turns it into -(A z - shift)
-        g.src = L.affine_shift;
-        g.scale = 1.0;
-      }
-      g.dst = SP;
-      g.len = m;
-      g.sum_len = m;
-      g.nblk = gm;
-      z.p[0] = L.x;
-      z.n[0] = n;
-      z.p[1] = L.y;
-      z.n[1] = m;
-      z.p[2] = h->Cw;
-      z.n[2] = m;
-      if (L.delta != 0.0) {
-        z.p[3] = h->Cw2;
-        z.n[3] = n;
-      }
-      nzblk = gn;
-    }
   }
-  ht_mark(h, 3);
-  hipLaunchKernelGGL(k_startup<NL>, dim3(h->startup_qg.nblk + ld[0].nblk + ld[1].nblk + nzblk), dim3(kBlock), 0, s, lsS[0],
-                     lsP[0], lsS[1], lsP[1], crS, crP, mrS, mrP, lqS, lqP, ld[0], ld[1], z, nzblk, h->startup_qg);
-  h->startup_qg.nblk = 0;
-  h->launches++;
-  // Single GPU: the vector updates ride in the product launches (run_fused_updates).  An update may only read what
-  // its host product reads: the LSQR x/w update of iteration it-1 (reads the short pair) goes with the A' product of
-  // iteration it; CRAIG's updates of iteration it (read the long pair and the OLD short pair) go with the A product,
-  // which therefore writes the alternate short pair (ping-pong).  The same holds for a row-sharded handle in halo mode
-  // (every vector a rank updates is its own).  Sharded with replicated n-vectors: separate update launch, in place.
-  const bool fuse_upd = local_vec;
-  UpdSeg winit[2] = {seg_none(), seg_none()};
-  bool craig_begun = false, minres_begun = false;
-  if (any_lsqr) {
-    // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes.  The CRAIG lane is parked by ctl.skip -- unless its
-    // right-hand side is still to be formed (fast start): then it rides along with the constant pair (-1, +1):
-    // SP[.][l] <- -A z + shift, and the norm partials of the launch are those of its right-hand side.
-    const LaneCtl* s0c = c0;
-    const LaneCtl* s1c = c1;
-    if (affine_lane == 0) s0c = h->ctl_mp;
-    if (affine_lane == NL - 1 && affine_lane >= 0) s1c = h->ctl_mp;
-    if (lead && !h->comm && fuse_upd) {
-      // riding steps: beta_1 of the LSQR lanes goes with THIS product's leaders too; a lane without a step of its own has the
-      // control block it brings to this product published as it is (ride_leader, kind NONE)
-      pend[0] = b0;
-      pend[1] = b1;
-      have_pend = true;
-      const StepArgs* pre = pre_args(false);
-      if (pend[0].kind == STEP_NONE) pend[0].state = const_cast<LaneCtl*>(s0c);
-      if (pend[1].kind == STEP_NONE) pend[1].state = const_cast<LaneCtl*>(s1c);
-      launch_spmv<NL>(h, TAG_A, LP, SP, SP, s0c, s1c, h->pS2, seg_none(), seg_none(), false, pre);
-      adopt_pend();
-    } else {
-      if (int rc = launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none, /*sharded=*/h->halo)) return rc;
-      launch_spmv<NL>(h, TAG_A, LP, SP, SP, s0c, s1c, h->pS2);
-    }
-    StepArgs s0 = none, s1 = none;
-    UpdSeg w0 = seg_none(), w1 = seg_none();
-    for (int l = 0; l < NL; ++l) {
-      Lane& L = lanes[l];
-      if (L.kind != LANE_LSQR) continue;
-      (s0.kind ? s1 : s0) = step_args(STEP_LSQR_BEGIN2, L, 0, h->pS2 + (size_t)l * h->strA, nbA, nullptr, 0, prog[l]);
-      UpdSeg u{};
-      u.kind = UPD_LSQR_WINIT;
-      u.it = 0;
-      u.ctl = L.ctl;
-      u.src = SP;
-      u.lane = l;
-      u.nblk = gm;
-      u.a = L.x;
-      u.b = h->Lw[l];
-      u.len = m;
-      u.partials = h->pW[l];  // (= upd_part(l, 0))
-      (w0.nblk ? w1 : w0) = u;
-    }
-    if (fuse_upd && !s1.kind) {
-      // the CRAIG lane's beta_1 step shares the launch (it un-parks the lane: must follow the start-up product)
-      for (int l = 0; l < NL; ++l)
-        if (is_ln(lanes[l].kind)) {
-          const int kind = lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_BEGIN : STEP_LNLQ_BEGIN;
-          if (l == affine_lane)  // ||rhs||^2 came out of the start-up product
-            s1 = step_args(kind, lanes[l], 0, h->pS2 + (size_t)l * h->strA, nbA, nullptr, 0, prog[l]);
-          else
-            s1 = step_args(kind, lanes[l], 0, h->pEm[l], gm, nullptr, 0, prog[l]);
-          craig_begun = true;
-        }
-      // (riding steps: a MINRES lane's beta_1 step -- it un-parks the lane: must follow the start-up product -- pairs up too)
-      if (!s1.kind && lead && !h->comm && minres_lane == 1) {
-        s1 = step_args(STEP_MINRES_BEGIN, lanes[1], 0, h->pEm[1], gm, nullptr, 0, prog[1]);
-        minres_begun = true;
-      }
-    }
-    if (affine_lane >= 0) {  // keep A z - shift = -rhs before the first A product overwrites the lane
-      UpdSeg u = seg_none();
-      u.kind = UPD_NEG_COPY;
-      u.src = SP;
-      u.lane = affine_lane;
-      u.nblk = gm;
-      u.a = lanes[affine_lane].affine_out;
-      u.len = m;
-      (w0.nblk ? w1 : w0) = u;
-    }
-    // (riding steps: alpha_1 / the CRAIG lane's beta_1 go with the first A' product of the loop)
-    if (lead) {
-      if (int rc = post_step(s0, s1, /*sharded=*/true)) return rc;
-    } else {
-      if (int rc = launch_step(h, s0, s1, /*sharded=*/true)) return rc;
-    }
-    if (fuse_upd) {  // w_1 rides in the first A' product
-      winit[0] = w0;
-      winit[1] = w1;
-    } else {
-      launch_updates<NL>(h, w0, w1, seg_none());
-    }
-  }
-  for (int l = 0; l < NL; ++l)
-    if (is_ln(lanes[l].kind) && !craig_begun)
-      if (int rc = launch_step(h, step_args(lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_BEGIN : STEP_LNLQ_BEGIN, lanes[l], 0,
-                                            h->pEm[l], gm, nullptr, 0, prog[l]),
-                               none, /*sharded=*/true))
-        return rc;
 
-  if (minres_lane >= 0 && !minres_begun)  // (un-parks the lane: must follow the LSQR lane's start-up product)
-    if (int rc = launch_step(h, step_args(STEP_MINRES_BEGIN, lanes[minres_lane], 0, h->pEm[minres_lane], gm,
-                                          nullptr, 0, prog[minres_lane]),
-                             none, /*sharded=*/true))
-      return rc;
-
-  // ---- main loop
-  // A MINRES lane (solve_two_extras) shares the two products of an iteration with the other recurrence: tmp = A' r2
-  // rides in the A' product, q = (A tmp + lambda r2) / beta in the A product; then its element-wise stages E1 -> scalar
-  // step A -> E2 -> step B.  Stage E3 (w, x) only needs the scalars of step B: it rides in the A' product of the NEXT
-  // iteration and its stopping tests (step C) share the step launch that follows that product -- one short
-  // element-wise launch and one scalar launch more per iteration than the other recurrence alone.
-  double* SPcur = SP;
-  double* SPalt = h->SP2;
-  const int look = std::max(1, o.lookahead);
-  int64_t it = 0;
-  int64_t spec_it = -1;  // iteration behind which the gated flush + tail were enqueued
+  // ------------------------------------------------------------------ builders: update segments and step arguments
   // Where the vector update of iteration k leaves its squared-norm partials (read by the step behind the NEXT A product):
   // halves alternate, because the A' launch of iteration k + 1 carries both that step -- riding, computed by sixteen
   // leaders of which any may be late -- and the update of iteration k + 1, whose workgroups only wait for the record of
   // their own XCC's leader before they write.  (CRAIG's update rides one launch later than the step that reads its
   // partials and would be safe in one array; it follows the same parity so that a sharded step gathers one range.)
-  auto upd_part = [&](int l, int64_t k) { return (k & 1) ? h->pWalt[l] : h->pW[l]; };
-  auto lsqr_upd_seg = [&](int l, int64_t it_of_update) {
+  double* upd_part(int l, int64_t k) const { return (k & 1) ? h->pWalt[l] : h->pW[l]; }
+  UpdSeg lsqr_upd_seg(int l, int64_t it_of_update) const {
     UpdSeg u{};
     u.kind = UPD_LSQR;
     u.it = (int)it_of_update;
@@ -2270,14 +2165,50 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     u.len = m;
     u.partials = upd_part(l, it_of_update);
     return u;
-  };
-  auto all_done = [&]() {
-    for (int l = 0; l < NL; ++l)
-      if (!load_progress(&h->prog_host[l]).done) return false;
-    return true;
-  };
+  }
+  UpdSeg lsqr_winit_seg(int l) const {  // w_1 = v_1, x_0 = 0
+    UpdSeg u{};
+    u.kind = UPD_LSQR_WINIT;
+    u.it = 0;
+    u.ctl = lanes[l].ctl;
+    u.src = SP;
+    u.lane = l;
+    u.nblk = gm;
+    u.a = lanes[l].x;
+    u.b = h->Lw[l];
+    u.len = m;
+    u.partials = upd_part(l, 0);
+    return u;
+  }
+  // the least-norm lane's updates of iteration `it`: long (x, w2) and short (w, y)
+  void ln_upd_segs(int l, UpdSeg& lng, UpdSeg& sht) const {
+    const Lane& L = lanes[l];
+    UpdSeg u{};
+    u.kind = L.kind == LANE_LNLQ ? UPD_LNLQ_LONG : L.delta != 0.0 ? UPD_CRAIG_LONG_REG : UPD_CRAIG_LONG;
+    u.it = (int)it;
+    u.ctl = L.ctl;
+    u.src = LP;
+    u.lane = l;
+    u.nblk = gn;
+    u.a = L.x;
+    u.b = h->Cw2;
+    u.len = n;
+    lng = u;
+    UpdSeg v{};
+    v.kind = L.kind == LANE_LNLQ ? UPD_LNLQ_SHORT : UPD_CRAIG_SHORT;
+    v.it = (int)it;
+    v.ctl = L.ctl;
+    v.src = SPcur;
+    v.lane = l;
+    v.nblk = gm;
+    v.a = h->Cw;
+    v.b = L.y;
+    v.len = m;
+    v.partials = upd_part(l, it - 1);
+    sht = v;
+  }
   // MINRES stage segments of iteration `k` (the Lanczos vector under construction sits in lane l of `pair`)
-  auto minres_seg = [&](int stage, int64_t k, double* pair) {
+  UpdSeg minres_seg(int stage, int64_t k, double* pair) const {
     const int l = minres_lane;
     UpdSeg u{};
     u.kind = stage == 1 ? UPD_MINRES_E1 : stage == 2 ? UPD_MINRES_E2 : UPD_MINRES_E3;
@@ -2307,18 +2238,276 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
       u.partials = h->pWalt[l];  // (rides in the launch whose leaders compute step B from E2's partials in pW[l])
     }
     return u;
-  };
-  auto iter_ptr = [&](int l) -> const int32_t* {
-    return lanes[l].kind == LANE_LSQR ? &((LsqrState*)lanes[l].state)->iter
-           : lanes[l].kind == LANE_CRAIG ? &((CraigState*)lanes[l].state)->iter
-           : lanes[l].kind == LANE_LNLQ  ? &((LnlqState*)lanes[l].state)->iter
-                                         : &((MinresState*)lanes[l].state)->iter;
-  };
-  // a MINRES / LNLQ lane reports iteration k (step C; pass k) while the host is enqueueing iteration k + 1
-  auto lag = [&](int l) { return lanes[l].kind == LANE_MINRES || lanes[l].kind == LANE_LNLQ ? 1 : 0; };
-  const bool split_steps = h->comm && !h->halo;  // replicated n-sums and per-rank m-sums cannot share a presum launch
-  // the gated final LSQR flush + the caller's epilogue behind iteration `it` (see the comment above run_krylov)
-  auto enqueue_speculative = [&]() -> int {
+  }
+  StepArgs minres_step(int kind, int64_t k) const {  // B: after E2 (partials in pW); C: after E3 (partials in pWalt)
+    const int l = minres_lane;
+    return step_args(kind, lanes[l], (int)k, kind == STEP_MINRES_C ? h->pWalt[l] : kind == STEP_MINRES_A ? h->pE3 : h->pW[l], gm,
+                     nullptr, 0, prog[l]);
+  }
+  // lane l's step behind the A' product of iteration `it` (npT partials per lane)
+  StepArgs step_after_at(int l, int npT) const {
+    const Lane& L = lanes[l];
+    if (L.kind == LANE_MINRES) return it > 1 ? minres_step(STEP_MINRES_C, it - 1) : none;  // the stopping tests of iteration it - 1
+    return step_args(lane_kind_after_at(L), L, (int)it, h->pS + (size_t)l * h->strT, npT, nullptr, 0, prog[l]);
+  }
+  // ... and behind the A product
+  StepArgs step_after_a(int l) const {
+    const Lane& L = lanes[l];
+    if (L.kind == LANE_MINRES) return minres_step(STEP_MINRES_A, it);
+    return step_args(lane_kind_after_a(L), L, (int)it, h->pS2 + (size_t)l * h->strA, nbA,
+                     L.kind == LANE_LNLQ ? nullptr : upd_part(l, it - 1), gm, prog[l]);
+  }
+  bool all_done() const {
+    for (int l = 0; l < NL; ++l)
+      if (!load_progress(&h->prog_host[l]).done) return false;
+    return true;
+  }
+
+  // ------------------------------------------------------------------ start-up
+  // parameters, right-hand sides, beta_1 (one launch), then (LSQR) alpha_1 and w_1
+  int startup() {
+    StepArgs b0 = none, b1 = none;
+    LoadSeg ld[2] = {};
+    ZeroArgs z{};
+    int nzblk = 0;
+    for (int l = 0; l < NL; ++l) {
+      Lane& L = lanes[l];
+      double* pe = L.kind == LANE_LSQR ? (l == 0 ? h->pE : h->pE2) : h->pEm[l];
+      LoadSeg& g = ld[l];
+      g.src = L.rhs;
+      g.scale = L.rhs_scale;
+      g.lane = l;
+      g.partials = pe;
+      if (L.kind == LANE_LSQR) {
+        // x = 0 is written by the w_1 start-up update (also when the recurrence ends at start-up)
+        g.dst = LP;
+        g.len = n;
+        g.sum_len = n_owned(h);
+        g.nblk = L.preloaded ? 0 : gn;  // fast start: the caller wrote the lane and the ||rhs||^2 partials already
+        (l == 0 ? b0 : b1) = step_args(STEP_LSQR_BEGIN, L, 0, pe, gn, nullptr, 0, prog[l]);
+      } else if (L.kind == LANE_MINRES) {
+        // r1 = r2 = b: r2 sits in Mr[1] (iteration 1 reads r2 from Mr[it % 2]) and in the short pair's lane
+        g.dst = SP;
+        g.dst2 = h->Mr[1];
+        g.len = m;
+        g.sum_len = m;
+        g.nblk = gm;
+        z.p[0] = L.x;
+        z.p[1] = h->Mw[0];
+        z.p[2] = h->Mw[1];
+        z.p[3] = h->Mr[0];
+        z.n[0] = z.n[1] = z.n[2] = z.n[3] = m;
+        nzblk = gm;
+      } else {
+        if (L.affine_shift) {  // fast start: the lane receives `shift`; the start-up product turns it into -(A z - shift)
+          g.src = L.affine_shift;
+          g.scale = 1.0;
+        }
+        g.dst = SP;
+        g.len = m;
+        g.sum_len = m;
+        g.nblk = gm;
+        z.p[0] = L.x;
+        z.n[0] = n;
+        z.p[1] = L.y;
+        z.n[1] = m;
+        z.p[2] = h->Cw;
+        z.n[2] = m;
+        if (L.delta != 0.0) {
+          z.p[3] = h->Cw2;
+          z.n[3] = n;
+        }
+        nzblk = gn;
+      }
+    }
+    ht_mark(h, 3);
+    hipLaunchKernelGGL(k_startup<NL>, dim3(h->startup_qg.nblk + ld[0].nblk + ld[1].nblk + nzblk), dim3(kBlock), 0, s, lsS[0],
+                       lsP[0], lsS[1], lsP[1], crS, crP, mrS, mrP, lqS, lqP, ld[0], ld[1], z, nzblk, h->startup_qg);
+    h->startup_qg.nblk = 0;
+    h->launches++;
+    bool ln_begun = false, minres_begun = false;
+    if (any_lsqr) {
+      // v~_1 = B'u_1 = A u~_1 / beta_1 for the LSQR lanes.  The CRAIG lane is parked by ctl.skip -- unless its
+      // right-hand side is still to be formed (fast start): then it rides along with the constant pair (-1, +1):
+      // SP[.][l] <- -A z + shift, and the norm partials of the launch are those of its right-hand side.
+      const LaneCtl* s0c = c0();
+      const LaneCtl* s1c = c1();
+      if (affine_lane == 0) s0c = h->ctl_mp;
+      if (affine_lane == NL - 1 && affine_lane >= 0) s1c = h->ctl_mp;
+      if (lead && !h->comm && fuse_upd) {
+        // riding steps: beta_1 of the LSQR lanes goes with THIS product's leaders too; a lane without a step of its own has the
+        // control block it brings to this product published as it is (ride_leader, kind NONE)
+        pend[0] = b0;
+        pend[1] = b1;
+        have_pend = true;
+        const StepArgs* pre = pre_args(false);
+        if (pend[0].kind == STEP_NONE) pend[0].state = const_cast<LaneCtl*>(s0c);
+        if (pend[1].kind == STEP_NONE) pend[1].state = const_cast<LaneCtl*>(s1c);
+        launch_spmv<NL>(h, TAG_A, LP, SP, SP, s0c, s1c, h->pS2, seg_none(), seg_none(), false, pre);
+        adopt_pend();
+      } else {
+        if (int rc = launch_step(h, b0.kind ? b0 : b1, b0.kind ? b1 : none, /*sharded=*/h->halo)) return rc;
+        launch_spmv<NL>(h, TAG_A, LP, SP, SP, s0c, s1c, h->pS2);
+      }
+      StepArgs s0 = none, s1 = none;
+      UpdSeg w0 = seg_none(), w1 = seg_none();
+      for (int l = 0; l < NL; ++l) {
+        Lane& L = lanes[l];
+        if (L.kind != LANE_LSQR) continue;
+        (s0.kind ? s1 : s0) = step_args(STEP_LSQR_BEGIN2, L, 0, h->pS2 + (size_t)l * h->strA, nbA, nullptr, 0, prog[l]);
+        (w0.nblk ? w1 : w0) = lsqr_winit_seg(l);
+      }
+      if (fuse_upd && !s1.kind) {
+        // the least-norm lane's beta_1 step shares the launch (it un-parks the lane: must follow the start-up product)
+        for (int l = 0; l < NL; ++l)
+          if (is_ln(lanes[l].kind)) {
+            if (l == affine_lane)  // ||rhs||^2 came out of the start-up product
+              s1 = step_args(lane_begin_kind(lanes[l]), lanes[l], 0, h->pS2 + (size_t)l * h->strA, nbA, nullptr, 0, prog[l]);
+            else
+              s1 = step_args(lane_begin_kind(lanes[l]), lanes[l], 0, h->pEm[l], gm, nullptr, 0, prog[l]);
+            ln_begun = true;
+          }
+        // (riding steps: a MINRES lane's beta_1 step -- it un-parks the lane: must follow the start-up product -- pairs up too)
+        if (!s1.kind && lead && !h->comm && minres_lane == 1) {
+          s1 = step_args(STEP_MINRES_BEGIN, lanes[1], 0, h->pEm[1], gm, nullptr, 0, prog[1]);
+          minres_begun = true;
+        }
+      }
+      if (affine_lane >= 0) {  // keep A z - shift = -rhs before the first A product overwrites the lane
+        UpdSeg u = seg_none();
+        u.kind = UPD_NEG_COPY;
+        u.src = SP;
+        u.lane = affine_lane;
+        u.nblk = gm;
+        u.a = lanes[affine_lane].affine_out;
+        u.len = m;
+        (w0.nblk ? w1 : w0) = u;
+      }
+      // (riding steps: alpha_1 / the least-norm lane's beta_1 go with the first A' product of the loop)
+      if (lead) {
+        if (int rc = post_step(s0, s1, /*sharded=*/true)) return rc;
+      } else {
+        if (int rc = launch_step(h, s0, s1, /*sharded=*/true)) return rc;
+      }
+      if (fuse_upd) {  // w_1 rides in the first A' product
+        winit[0] = w0;
+        winit[1] = w1;
+      } else {
+        launch_updates<NL>(h, w0, w1, seg_none());
+      }
+    }
+    for (int l = 0; l < NL; ++l)
+      if (is_ln(lanes[l].kind) && !ln_begun)
+        if (int rc = launch_step(h, step_args(lane_begin_kind(lanes[l]), lanes[l], 0, h->pEm[l], gm, nullptr, 0, prog[l]), none,
+                                 /*sharded=*/true))
+          return rc;
+    if (minres_lane >= 0 && !minres_begun)  // (un-parks the lane: must follow the LSQR lane's start-up product)
+      if (int rc = launch_step(h, step_args(STEP_MINRES_BEGIN, lanes[minres_lane], 0, h->pEm[minres_lane], gm, nullptr, 0,
+                                            prog[minres_lane]),
+                               none, /*sharded=*/true))
+        return rc;
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ one joint iteration
+  // A MINRES lane (solve_two_extras) shares the two products of an iteration with the other recurrence: tmp = A' r2
+  // rides in the A' product, q = (A tmp + lambda r2) / beta in the A product; then its element-wise stages E1 -> scalar
+  // step A -> E2 -> step B.  Stage E3 (w, x) only needs the scalars of step B: it rides in the A' product of the NEXT
+  // iteration and its stopping tests (step C) share the step launch that follows that product -- one short
+  // element-wise launch and one scalar launch more per iteration than the other recurrence alone.
+  //
+  // first half-step of every lane: the A' product (LSQR's update of the previous iteration and MINRES' stage E3 riding), its steps
+  int half_step_at() {
+    lu[0] = lu[1] = seg_none();
+    nlu = 0;
+    if (it > 1) {
+      for (int l = 0; l < NL; ++l)
+        if (lanes[l].kind == LANE_LSQR) lu[nlu++] = lsqr_upd_seg(l, it - 1);
+    } else {
+      lu[0] = winit[0];  // fused runs: w_1 = v_1 (empty segments otherwise)
+      lu[1] = winit[1];
+    }
+    // MINRES: stage E3 of the PREVIOUS iteration (w, x and ||x||^2 for its stopping tests)
+    if (minres_lane >= 0 && it > 1) {
+      const UpdSeg e3 = minres_seg(3, it - 1, SPcur);
+      if (fuse_upd) lu[nlu < 2 ? nlu : 1] = e3;
+      else launch_updates<NL>(h, e3, seg_none(), seg_none());
+    }
+    int npT = 0;
+    if (fuse_upd) {
+      const StepArgs* pre = pre_args(true);
+      if (int rc = at_product<NL>(h, SPcur, LP, t0(), t1(), h->pS, &npT, lu[0], lu[1], pre)) return rc;
+      if (pre) adopt_pend();
+    } else {
+      if (int rc = at_product<NL>(h, SPcur, LP, t0(), t1(), h->pS, &npT)) return rc;
+    }
+    StepArgs sa[2] = {none, none};
+    for (int l = 0; l < NL; ++l) sa[l] = step_after_at(l, npT);
+    // sums over n-vectors: replicated (no all-reduce) unless the n-vectors are column windows (halo mode); MINRES' sums
+    // run over (row-sharded) m-vectors
+    const bool sh0 = lanes[0].kind == LANE_MINRES ? true : h->halo;
+    const bool sh1 = lanes[NL - 1].kind == LANE_MINRES ? true : h->halo;
+    if (!h->comm) return post_step(sa[0], NL == 2 ? sa[1] : none, false);
+    if (lead && sh0 && sh1) return post_step(sa[0], sa[1], true);  // (halo mode, LSQR / CRAIG lanes: both steps sum gathered n-sums)
+    if (NL == 2 && split_steps && sh0 != sh1) {
+      if (int rc = launch_step(h, sa[0], none, sh0)) return rc;
+      return launch_step(h, sa[1], none, sh1);
+    }
+    if (NL == 2) return launch_step(h, sa[0].kind ? sa[0] : sa[1], sa[0].kind ? sa[1] : none, sa[0].kind ? sh0 : sh1, sa[0].kind ? sh1 : 0);
+    if (sa[0].kind) return launch_step(h, sa[0], none, sh0);
+    return 0;
+  }
+  // second half-step: the A product (the least-norm lane's updates of this iteration riding), its steps, MINRES' stages
+  int half_step_a() {
+    UpdSeg cu[2] = {seg_none(), seg_none()};
+    for (int l = 0; l < NL; ++l)
+      if (is_ln(lanes[l].kind)) ln_upd_segs(l, cu[0], cu[1]);
+    if (fuse_upd) {
+      const StepArgs* pre = pre_args(false);
+      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPalt, c0(), c1(), h->pS2, cu[0], cu[1], false, pre);
+      if (pre) adopt_pend();
+      std::swap(SPcur, SPalt);
+    } else {
+      // (at most three segments: lanes <= 2 and only one of them can be CRAIG)
+      if (nlu == 2) launch_updates<NL>(h, lu[0], lu[1], seg_none());
+      else launch_updates<NL>(h, lu[0], cu[0], cu[1]);
+      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPcur, c0(), c1(), h->pS2);
+    }
+    // A MINRES lane the host has SEEN finished (a zero right-hand side -- hprod! Val(1) on a model without curvature in the
+    // constraints --, or an early convergence): its stand-alone launches would exit at once, ~3.5 us each; skipped.  One GPU
+    // only: sharded, every rank would have to see it at the same iteration.  (Its riding / shared steps stay: they cost nothing.)
+    const bool mdead = minres_lane >= 0 && !h->comm && load_progress(&h->prog_host[minres_lane]).done;
+    // MINRES: E1 on q (now in the current pair's lane) before its scalar step A
+    if (minres_lane >= 0 && !mdead) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
+    StepArgs sb[2] = {none, none};
+    for (int l = 0; l < NL; ++l) sb[l] = step_after_a(l);
+    if (minres_lane >= 0 && lead && NL == 2) {
+      // MINRES' step A must run before E2; the other lane's step is only needed by the NEXT A' launch (its epilogue and its
+      // riding update) and waits for MINRES' step B to ride there with it
+      if (!mdead) {
+        if (int rc = launch_step(h, sb[minres_lane], none, /*sharded=*/true)) return rc;
+        launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
+      }
+      StepArgs pair[2];
+      pair[minres_lane] = minres_step(STEP_MINRES_B, it);
+      pair[1 - minres_lane] = sb[1 - minres_lane];
+      return post_step(pair[0], pair[1], true);
+    }
+    if (!h->comm || lead) {
+      if (int rc = post_step(sb[0], NL == 2 ? sb[1] : none, true)) return rc;
+    } else {
+      if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
+    }
+    if (minres_lane >= 0 && !mdead) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
+      launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
+      if (int rc = launch_step(h, minres_step(STEP_MINRES_B, it), none, /*sharded=*/true)) return rc;
+    }
+    return 0;
+  }
+
+  // ------------------------------------------------------------------ the host's pacing
+  // the gated final LSQR flush + the caller's epilogue behind iteration `it` (see the comment above)
+  int enqueue_speculative() {
     if (tail == nullptr || !fuse_upd) return 0;
     UpdSeg seg[2] = {seg_none(), seg_none()};
     int ns = 0;
@@ -2337,190 +2526,64 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (rc) return rc;
     spec_it = it;
     return 0;
-  };
-  while (it < itmax_all) {
-    ++it;
-    // LSQR's x/w update of the PREVIOUS iteration
-    UpdSeg lu[2] = {seg_none(), seg_none()};
-    int nlu = 0;
-    if (it > 1) {
-      for (int l = 0; l < NL; ++l)
-        if (lanes[l].kind == LANE_LSQR) lu[nlu++] = lsqr_upd_seg(l, it - 1);
-    } else {
-      lu[0] = winit[0];  // fused runs: w_1 = v_1 (empty segments otherwise)
-      lu[1] = winit[1];
-    }
-    // MINRES: stage E3 of the PREVIOUS iteration (w, x and ||x||^2 for its stopping tests)
-    UpdSeg e3 = seg_none();
-    if (minres_lane >= 0 && it > 1) {
-      e3 = minres_seg(3, it - 1, SPcur);
-      if (fuse_upd) lu[nlu < 2 ? nlu : 1] = e3;
-      else launch_updates<NL>(h, e3, seg_none(), seg_none());
-    }
-    // first half-step of every lane: one A' product
-    int npT = 0;
-    if (fuse_upd) {
-      const StepArgs* pre = pre_args(true);
-      if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT, lu[0], lu[1], pre)) return rc;
-      if (pre) adopt_pend();
-    } else {
-      if (int rc = at_product<NL>(h, SPcur, LP, t0, t1, h->pS, &npT)) return rc;
-    }
-    StepArgs sa[2] = {none, none};
+  }
+  // the host waits until every unfinished lane has reported iteration `target` (minus its lag) or has ended
+  int wait_lanes(int64_t target) {
     for (int l = 0; l < NL; ++l) {
-      if (lanes[l].kind == LANE_MINRES) {  // the stopping tests of iteration it - 1
-        if (it > 1) sa[l] = step_args(STEP_MINRES_C, lanes[l], (int)it - 1, h->pWalt[l], gm, nullptr, 0, prog[l]);
-        continue;
-      }
-      sa[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SA : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SA : STEP_LNLQ_SA,
-                        lanes[l], (int)it, h->pS + (size_t)l * h->strT, npT, nullptr, 0, prog[l]);
+      if (load_progress(&h->prog_host[l]).done) continue;
+      const int32_t* ddone = &lanes[l].ctl->done;
+      if (int rc = wait_progress(h, l, (int)target - lane_lag(lanes[l]), ddone, lane_iter_ptr(lanes[l]))) return rc;
     }
-    // sums over n-vectors: replicated (no all-reduce) unless the n-vectors are column windows (halo mode); MINRES' sums
-    // run over (row-sharded) m-vectors
-    {
-      const bool sh0 = lanes[0].kind == LANE_MINRES ? true : h->halo;
-      const bool sh1 = lanes[NL - 1].kind == LANE_MINRES ? true : h->halo;
-      if (!h->comm) {
-        if (int rc = post_step(sa[0], NL == 2 ? sa[1] : none, false)) return rc;
-      } else if (lead && sh0 && sh1) {  // (halo mode, LSQR / CRAIG lanes: both steps sum gathered n-sums)
-        if (int rc = post_step(sa[0], sa[1], true)) return rc;
-      } else if (NL == 2 && split_steps && sh0 != sh1) {
-        if (int rc = launch_step(h, sa[0], none, sh0)) return rc;
-        if (int rc = launch_step(h, sa[1], none, sh1)) return rc;
-      } else if (NL == 2) {
-        if (int rc = launch_step(h, sa[0].kind ? sa[0] : sa[1], sa[0].kind ? sa[1] : none, sa[0].kind ? sh0 : sh1,
-                                 sa[0].kind ? sh1 : 0))
-          return rc;
-      } else if (sa[0].kind) {
-        if (int rc = launch_step(h, sa[0], none, sh0)) return rc;
-      }
-    }
-    // CRAIG's updates of this iteration
-    UpdSeg cu[2] = {seg_none(), seg_none()};
-    for (int l = 0; l < NL; ++l) {
-      const Lane& L = lanes[l];
-      if (!is_ln(L.kind)) continue;
-      UpdSeg u{};
-      u.kind = L.kind == LANE_LNLQ ? UPD_LNLQ_LONG : L.delta != 0.0 ? UPD_CRAIG_LONG_REG : UPD_CRAIG_LONG;
-      u.it = (int)it;
-      u.ctl = L.ctl;
-      u.src = LP;
-      u.lane = l;
-      u.nblk = gn;
-      u.a = L.x;
-      u.b = h->Cw2;
-      u.len = n;
-      cu[0] = u;
-      UpdSeg v{};
-      v.kind = L.kind == LANE_LNLQ ? UPD_LNLQ_SHORT : UPD_CRAIG_SHORT;
-      v.it = (int)it;
-      v.ctl = L.ctl;
-      v.src = SPcur;
-      v.lane = l;
-      v.nblk = gm;
-      v.a = h->Cw;
-      v.b = L.y;
-      v.len = m;
-      v.partials = upd_part(l, it - 1);
-      cu[1] = v;
-    }
-    // second half-step: one A product
-    if (fuse_upd) {
-      const StepArgs* pre = pre_args(false);
-      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPalt, c0, c1, h->pS2, cu[0], cu[1], false, pre);
-      if (pre) adopt_pend();
-      std::swap(SPcur, SPalt);
-    } else {
-      // (at most three segments: lanes <= 2 and only one of them can be CRAIG)
-      if (nlu == 2) launch_updates<NL>(h, lu[0], lu[1], seg_none());
-      else launch_updates<NL>(h, lu[0], cu[0], cu[1]);
-      launch_spmv<NL>(h, TAG_A, LP, SPcur, SPcur, c0, c1, h->pS2);
-    }
-    // A MINRES lane the host has SEEN finished (a zero right-hand side -- hprod! Val(1) on a model without curvature in the
-    // constraints --, or an early convergence): its stand-alone launches would exit at once, ~3.5 us each; skipped.  One GPU
-    // only: sharded, every rank would have to see it at the same iteration.  (Its riding / shared steps stay: they cost nothing.)
-    const bool mdead = minres_lane >= 0 && !h->comm && load_progress(&h->prog_host[minres_lane]).done;
-    // MINRES: E1 on q (now in the current pair's lane) before its scalar step A
-    if (minres_lane >= 0 && !mdead) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
-    StepArgs sb[2] = {none, none};
-    for (int l = 0; l < NL; ++l) {
-      if (lanes[l].kind == LANE_MINRES)
-        sb[l] = step_args(STEP_MINRES_A, lanes[l], (int)it, h->pE3, gm, nullptr, 0, prog[l]);
-      else
-        sb[l] = step_args(lanes[l].kind == LANE_LSQR ? STEP_LSQR_SB : lanes[l].kind == LANE_CRAIG ? STEP_CRAIG_SB : STEP_LNLQ_SB,
-                          lanes[l], (int)it, h->pS2 + (size_t)l * h->strA, nbA, lanes[l].kind == LANE_LNLQ ? nullptr : upd_part(l, it - 1),
-                          gm, prog[l]);
-    }
-    if (minres_lane >= 0 && lead && NL == 2) {
-      // MINRES' step A must run before E2; the other lane's step is only needed by the NEXT A' launch (its epilogue and its
-      // riding update) and waits for MINRES' step B to ride there with it
-      if (!mdead) {
-        if (int rc = launch_step(h, sb[minres_lane], none, /*sharded=*/true)) return rc;
-        launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
-      }
-      StepArgs pair[2];
-      pair[minres_lane] = step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0, prog[minres_lane]);
-      pair[1 - minres_lane] = sb[1 - minres_lane];
-      if (int rc = post_step(pair[0], pair[1], true)) return rc;
-    } else {
-      if (!h->comm || lead) {
-        if (int rc = post_step(sb[0], NL == 2 ? sb[1] : none, true)) return rc;
-      } else {
-        if (int rc = launch_step(h, sb[0], sb[1], /*sharded=*/true)) return rc;
-      }
-      if (minres_lane >= 0 && !mdead) {  // E2 -> scalar step B (beta, the rotation, the coefficients of E3 and of the next products)
-        launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
-        if (int rc = launch_step(h, step_args(STEP_MINRES_B, lanes[minres_lane], (int)it, h->pW[minres_lane], gm, nullptr, 0,
-                                              prog[minres_lane]),
-                                 none, /*sharded=*/true))
-          return rc;
-      }
-    }
-    if (h->comm) {
-      // every rank must enqueue the same collectives: decide at fixed iteration boundaries from the (replicated,
-      // bitwise identical) device state, never from the timing of the progress word.  With the iteration count of the
-      // previous call known (halo mode; the same on every rank) the first look is AT that count, with the gated flush
-      // and epilogue already enqueued behind it: a repeating count costs no stream synchronisation inside the loop.
-      bool boundary = it == itmax_all;
-      if (expect > 0) {
-        if (it == expect) {
-          if (int rc = flush_pend(true)) return rc;  // (the gated kernels must see this iteration's verdict)
-          if (int rc = enqueue_speculative()) return rc;
-          boundary = true;
-        } else if (it > expect && (it - expect) % look == 0) {
-          boundary = true;
-        }
-      } else if (it % look == 0) {
+    return 0;
+  }
+  // Sharded: every rank must enqueue the same collectives: decide at fixed iteration boundaries from the (replicated,
+  // bitwise identical) device state, never from the timing of the progress word.  With the iteration count of the
+  // previous call known (halo mode; the same on every rank) the first look is AT that count, with the gated flush
+  // and epilogue already enqueued behind it: a repeating count costs no stream synchronisation inside the loop.
+  int pace_sharded(bool& stop) {
+    bool boundary = it == itmax_all;
+    if (expect > 0) {
+      if (it == expect) {
+        if (int rc = flush_pend(true)) return rc;  // (the gated kernels must see this iteration's verdict)
+        if (int rc = enqueue_speculative()) return rc;
+        boundary = true;
+      } else if (it > expect && (it - expect) % look == 0) {
         boundary = true;
       }
-      if (boundary) {
-        if (int rc = flush_pend(true)) return rc;  // (so must the host; the same launches on every rank)
-        HIPCHK(h, hipStreamSynchronize(s));
-        if (h->comm->failed()) {  // (peer-to-peer route: a peer's record never came; nothing later in this call can be right)
-          h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
-          return FPSQ_ERR_TIMEOUT;
-        }
-        if (all_done()) break;
-      }
-      continue;
+    } else if (it % look == 0) {
+      boundary = true;
     }
-    if (all_done()) break;
+    if (boundary) {
+      if (int rc = flush_pend(true)) return rc;  // (so must the host; the same launches on every rank)
+      HIPCHK(h, hipStreamSynchronize(s));
+      if (h->comm->failed()) {  // (peer-to-peer route: a peer's record never came; nothing later in this call can be right)
+        h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
+        return FPSQ_ERR_TIMEOUT;
+      }
+      if (all_done()) stop = true;
+    }
+    return 0;
+  }
+  int pace_single(bool& stop) {
+    if (all_done()) {
+      stop = true;
+      return 0;
+    }
     // before the expected count the steps publish nothing (but the end of a recurrence): enqueue on
-    if (it < expect) continue;
+    if (it < expect) return 0;
     // bound the run-ahead of the host on the slowest unfinished lane
     int slow = INT32_MAX;
     for (int l = 0; l < NL; ++l) {
       const Progress ps = load_progress(&h->prog_host[l]);
-      if (!ps.done) slow = std::min(slow, (int)ps.iter + lag(l));
+      if (!ps.done) slow = std::min(slow, (int)ps.iter + lane_lag(lanes[l]));
     }
     if (it > expect && it - slow >= look) {
       if (int rc = flush_pend(true)) return rc;  // (the host is about to wait for the pending steps' progress)
-      for (int l = 0; l < NL; ++l) {
-        if (load_progress(&h->prog_host[l]).done) continue;
-        const int32_t* ddone = &lanes[l].ctl->done;
-        if (int rc = wait_progress(h, l, (int)(it - look + 1) - lag(l), ddone, iter_ptr(l))) return rc;
+      if (int rc = wait_lanes(it - look + 1)) return rc;
+      if (all_done()) {
+        stop = true;
+        return 0;
       }
-      if (all_done()) break;
     }
     // Consecutive calls of one kind (the evaluations of a line search, the CG steps of a Newton iteration) mostly take
     // the same number of iterations: do not enqueue iteration expect + 1 before the device has finished iteration
@@ -2529,40 +2592,39 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     if (expect > 0 && it == expect) {
       if (int rc = flush_pend(true)) return rc;  // (the gated kernels and the host must see this iteration's verdict)
       if (int rc = enqueue_speculative()) return rc;
-      for (int l = 0; l < NL; ++l) {
-        if (load_progress(&h->prog_host[l]).done) continue;
-        const int32_t* ddone = &lanes[l].ctl->done;
-        if (int rc = wait_progress(h, l, (int)it - lag(l), ddone, iter_ptr(l))) return rc;
-      }
-      if (all_done()) break;
+      if (int rc = wait_lanes(it)) return rc;
+      if (all_done()) stop = true;
     }
-  }
-  if (!h->comm && !all_done()) {
-    // The loop ran out of iterations (itmax) before the host saw every lane end.  The steps still in the stream will publish
-    // those ends into the progress words -- which the NEXT run of this call (the second lane of an unfused call, the extras
-    // lanes of hprod! Val(1)) resets on the host and then polls: a late "done" of THIS run would make it stop enqueueing at
-    // once and leave its recurrence unfinished (found by the fixed-iteration tests: statistics of the second lane all zero).
-    // Drain the stream, so that every word says what this run ended with.  (Only the itmax exit comes here: the other exits
-    // of the loop have seen `done`; a sharded run has synchronised at this boundary already.)
-    if (int rc = flush_pend(true)) return rc;
-    HIPCHK(h, hipStreamSynchronize(s));
-  }
-  if (all_done()) {  // the iteration at which the last recurrence finished (its progress word says so)
-    int64_t e = 0;
-    for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter + lag(l));
-    expect_slot[1] = expect_slot[0];
-    expect_slot[0] = e;
-  }
-  if (int rc = flush_pend(true)) return rc;
-  ht_mark(h, 4);
-  if (spec_it >= 0 && spec_it == it && all_done()) {
-    // every recurrence ended at or before the iteration the speculative flush + tail were enqueued behind: their gates
-    // were open, the call's epilogue is already in the stream
-    h->tail_was_run = true;
     return 0;
   }
-  // the last LSQR update (iteration `it`) has not been enqueued yet
-  {
+
+  // ------------------------------------------------------------------ behind the loop
+  int finish() {
+    if (!h->comm && !all_done()) {
+      // The loop ran out of iterations (itmax) before the host saw every lane end.  The steps still in the stream will publish
+      // those ends into the progress words -- which the NEXT run of this call (the second lane of an unfused call, the extras
+      // lanes of hprod! Val(1)) resets on the host and then polls: a late "done" of THIS run would make it stop enqueueing at
+      // once and leave its recurrence unfinished (found by the fixed-iteration tests: statistics of the second lane all zero).
+      // Drain the stream, so that every word says what this run ended with.  (Only the itmax exit comes here: the other exits
+      // of the loop have seen `done`; a sharded run has synchronised at this boundary already.)
+      if (int rc = flush_pend(true)) return rc;
+      HIPCHK(h, hipStreamSynchronize(s));
+    }
+    if (all_done()) {  // the iteration at which the last recurrence finished (its progress word says so)
+      int64_t e = 0;
+      for (int l = 0; l < NL; ++l) e = std::max<int64_t>(e, h->prog_host[l].iter + lane_lag(lanes[l]));
+      expect_slot[1] = expect_slot[0];
+      expect_slot[0] = e;
+    }
+    if (int rc = flush_pend(true)) return rc;
+    ht_mark(h, 4);
+    if (spec_it >= 0 && spec_it == it && all_done()) {
+      // every recurrence ended at or before the iteration the speculative flush + tail were enqueued behind: their gates
+      // were open, the call's epilogue is already in the stream
+      h->tail_was_run = true;
+      return 0;
+    }
+    // the last LSQR update (iteration `it`) has not been enqueued yet
     UpdSeg seg[2] = {seg_none(), seg_none()};
     int ns = 0;
     for (int l = 0; l < NL; ++l)
@@ -2577,16 +2639,28 @@ int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
     else
       launch_updates<NL>(h, seg[0], seg[1], minres_lane >= 0 && it >= 1 ? minres_seg(3, it, SPcur) : seg_none());
     if (minres_lane >= 0 && it >= 1)
-      if (int rc = launch_step(h, step_args(STEP_MINRES_C, lanes[minres_lane], (int)it, h->pWalt[minres_lane], gm, nullptr, 0,
-                                            prog[minres_lane]),
-                               none, /*sharded=*/true))
-        return rc;
+      if (int rc = launch_step(h, minres_step(STEP_MINRES_C, it), none, /*sharded=*/true)) return rc;
+    return 0;  // the final stats were left in lanes[l].st by the step that ended each recurrence
   }
-  return 0;  // the final stats were left in lanes[l].st by the step that ended each recurrence
-#undef c0
-#undef c1
-#undef t0
-#undef t1
+
+  int run() {
+    setup();
+    if (int rc = startup()) return rc;
+    while (it < itmax_all) {
+      ++it;
+      if (int rc = half_step_at()) return rc;
+      if (int rc = half_step_a()) return rc;
+      bool stop = false;
+      if (int rc = h->comm ? pace_sharded(stop) : pace_single(stop)) return rc;
+      if (stop) break;
+    }
+    return finish();
+  }
+};
+
+template <int NL>
+int run_krylov(fpsq_handle h, Lane* lanes, const TailFn* tail = nullptr) {
+  return KrylovRun<NL>(h, lanes, tail).run();
 }
 
 int run_lanes(fpsq_handle h, Lane* lanes, int nlanes, const TailFn* tail = nullptr) {
