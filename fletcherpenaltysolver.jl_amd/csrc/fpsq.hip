@@ -992,7 +992,7 @@ int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevC
         d.y = (uint32_t)(a0 >> 32);
         d.z = (uint32_t)(((uint64_t)vb[2] >> 16) | ((uint64_t)vb[3] << 8));
         d.w = (uint32_t)split[0] | ((uint32_t)split[1] << 7) | ((uint32_t)split[2] << 14) | ((uint32_t)nvalid << 21);
-        sd[sg] = d;
+        sd[(sg % 4) * 8 + sg / 4] = d;  // (stored per wave: segment 4 j + w at [8 w + j], a wave's eight in one 128-byte line)
       }
       if (ok) {
         vbase[b] = (int32_t)base64;

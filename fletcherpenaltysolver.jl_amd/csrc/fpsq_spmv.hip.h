@@ -47,74 +47,97 @@ __device__ __forceinline__ void csort_decode(const CsortRaw& r, int cbase, int (
   }
 }
 // SHARED VALUES (CsrView::segdesc != null): thread t owns the entries t + 256 j of the block's stored order (j = 0..7; its eight
-// index words are contiguous at [8t, 8t + 8) as above), i.e. lane t % 64 of segment 4 j + t / 64.  The segment's descriptor
-// is wave-uniform (scalar loads): four 24-bit bases relative to `vbase`, three split lanes, the number of valid lanes;
-// value address = vbase + base_of_my_run + lane, or the array's zero entry past the valid lanes.  The value loads leave
-// together with the caller's gathers of x.
-__device__ __forceinline__ void cshared_fetch(const CsrView& A, int L, int cbase, int vbase, int zero_pos, int tid, int (&cidx)[8],
-                                              int (&slot)[8], double (&v)[8]) {
+// index words are contiguous at [8t, 8t + 8) as above), i.e. lane t % 64 of segment 4 j + t / 64.  A segment's descriptor
+// is wave-uniform: four 24-bit bases relative to the block's base (blkdesc.w), three split lanes, the number of valid lanes;
+// value address = base of the block + base of my run + lane, or the array's zero entry past the valid lanes.
+//
+// cshared_head -- everything at the HEAD of a block's life that needs nothing but the block's number, in the order that keeps
+// its chain of dependent memory round trips short:
+//   1. the index planes (two vector loads per thread) are REQUESTED;
+//   2. the block descriptor, its column base and the wave's eight segment descriptors come through the SCALAR cache (one
+//      inline-assembly batch of s_load: as vector loads of one address each would cost the texture path a full wave
+//      instruction -- eighteen vector loads per thread instead of six made the plain A' product 6 us slower -- and the compiler
+//      does not prove the addresses uniform).  They are small, hot in L2, and back long before the index planes;
+//   3. the eight VALUE loads leave at once -- they need the descriptors only -- so the values' trip to HBM runs next to the
+//      index planes' one instead of behind it;
+// the caller then requests row bounds and yin (they need r0 from the scalar descriptor), and cshared_decode waits for the
+// index planes and yields the gather addresses: values and gathered x arrive together.  (First build of round 4: descriptor
+// and value loads BEHIND the index planes and behind the vector load of blkdesc: two round trips more in the chain.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// (plain references, no struct: as members of a struct handed through two branches the index words ended up on the stack)
+__device__ __forceinline__ void cshared_head(const CsrView& A, int L, int tid, uint4& w16, uint2& w8, int& r0, int& nr, int& s_,
+                                             int& cbase, double (&v)[8]) {
   const size_t b0 = (size_t)L * kSpmvNnz;
-  const uint4 w16 = *reinterpret_cast<const uint4*>(A.cs16 + b0 + 8 * tid);
-  const uint2 w8 = *reinterpret_cast<const uint2*>(A.cs8 + b0 + 8 * tid);
+  w16 = *reinterpret_cast<const uint4*>(A.cs16 + b0 + 8 * tid);
+  w8 = *reinterpret_cast<const uint2*>(A.cs8 + b0 + 8 * tid);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // The eight descriptors of this wave (segments w, w + 4, ...: 64 bytes apart) through the SCALAR cache: as vector loads of
-  // one address they cost the texture path a full wave instruction each (eighteen vector loads per thread instead of six made
-  // the plain A' product 6 us slower).  Inline assembly because the compiler does not prove the address uniform; its wait
-  // stands behind the (already issued) vector loads of the index words, which the address arithmetic needs as well.
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 d[8];
-  {
-    const unsigned long long pa = reinterpret_cast<unsigned long long>(A.segdesc + (size_t)L * 32 + w);
-    const unsigned long long pu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(pa & 0xffffffffull));
-    asm volatile(
-        "s_load_dwordx4 %0, %8, 0x0\n\t"
-        "s_load_dwordx4 %1, %8, 0x40\n\t"
-        "s_load_dwordx4 %2, %8, 0x80\n\t"
-        "s_load_dwordx4 %3, %8, 0xc0\n\t"
-        "s_load_dwordx4 %4, %8, 0x100\n\t"
-        "s_load_dwordx4 %5, %8, 0x140\n\t"
-        "s_load_dwordx4 %6, %8, 0x180\n\t"
-        "s_load_dwordx4 %7, %8, 0x1c0\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(d[0]), "=&s"(d[1]), "=&s"(d[2]), "=&s"(d[3]), "=&s"(d[4]), "=&s"(d[5]), "=&s"(d[6]), "=&s"(d[7])
-        : "s"(pu)
-        : "memory");
-  }
-  const unsigned h16[4] = {w16.x, w16.y, w16.z, w16.w};
-  const unsigned h8[2] = {w8.x, w8.y};
+  const int Lu = __builtin_amdgcn_readfirstlane(L);
+  typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+  u32x4 bd;
+  unsigned int cb;
+  u32x16 dA, dB;  // the wave's eight descriptors are contiguous (one 128-byte line): segments w, w + 4, ... = words 4 j .. 4 j + 3
+  auto uni = [](const void* q) {
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(q);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(pa & 0xffffffffull));
+  };
+  const unsigned long long pd = uni(A.segdesc + (size_t)Lu * 32 + 8 * w), pb = uni(A.blkdesc + Lu), pc = uni(A.colbase + Lu);
+  // (two batches of four descriptors: forty scalar registers live at once made the kernel spill)
+  asm volatile(
+      "s_load_dwordx4 %1, %4, 0x0\n\t"
+      "s_load_dword %2, %5, 0x0\n\t"
+      "s_load_dwordx16 %0, %3, 0x0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(dA), "=&s"(bd), "=&s"(cb)
+      : "s"(pd), "s"(pb), "s"(pc)
+      : "memory");
+  r0 = (int)bd.x;
+  nr = (int)bd.y;
+  s_ = (int)bd.z;
+  cbase = (int)cb;
+  const int vbase = (int)bd.w;
   if (vbase <= -128) {  // (block-uniform) a block with values of its own: entry t + 256 j at [2048 own + 256 j + t]
     const double* ov = A.vals_own + (size_t)(-128 - vbase) * kSpmvNnz + tid;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int pk = (int)((h16[q >> 1] >> (16 * (q & 1))) & 0xffffu);
-      const int hi = (int)((h8[q >> 2] >> (8 * (q & 3))) & 0xffu);
-      cidx[q] = cbase + ((hi << 5) | (pk >> 11));
-      slot[q] = pk & 2047;
-      v[q] = ov[q * kBlock];
-    }
+    for (int q = 0; q < 8; ++q) v[q] = ov[q * kBlock];
     return;
   }
+  auto value_of = [&](unsigned dx, unsigned dy, unsigned dz, unsigned dw) {
+    const unsigned s0 = dw & 127u, s1 = (dw >> 7) & 127u, s2 = (dw >> 14) & 127u, nv = (dw >> 21) & 127u;
+    const int b0_ = (int)(dx & 0xffffffu), b1_ = (int)((dx >> 24) | ((dy & 0xffffu) << 8));
+    const int b2_ = (int)((dy >> 16) | ((dz & 0xffu) << 16)), b3_ = (int)(dz >> 8);
+    const int bs = (unsigned)lane < s0 ? b0_ : (unsigned)lane < s1 ? b1_ : (unsigned)lane < s2 ? b2_ : b3_;
+    const int pos = (unsigned)lane < nv ? vbase + bs + lane : A.zero_pos;
+    return A.vals[pos];
+  };
+  v[0] = value_of(dA[0], dA[1], dA[2], dA[3]);
+  v[1] = value_of(dA[4], dA[5], dA[6], dA[7]);
+  v[2] = value_of(dA[8], dA[9], dA[10], dA[11]);
+  v[3] = value_of(dA[12], dA[13], dA[14], dA[15]);
+  asm volatile(
+      "s_load_dwordx16 %0, %1, 0x40\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(dB)
+      : "s"(pd)
+      : "memory");
+  v[4] = value_of(dB[0], dB[1], dB[2], dB[3]);
+  v[5] = value_of(dB[4], dB[5], dB[6], dB[7]);
+  v[6] = value_of(dB[8], dB[9], dB[10], dB[11]);
+  v[7] = value_of(dB[12], dB[13], dB[14], dB[15]);
+}
+__device__ __forceinline__ void cshared_decode(const uint4& w16, const uint2& w8, int cbase, int (&cidx)[8], int (&slot)[8]) {
+  const unsigned h16[4] = {w16.x, w16.y, w16.z, w16.w};
+  const unsigned h8[2] = {w8.x, w8.y};
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int pk = (int)((h16[q >> 1] >> (16 * (q & 1))) & 0xffffu);
     const int hi = (int)((h8[q >> 2] >> (8 * (q & 3))) & 0xffu);
     cidx[q] = cbase + ((hi << 5) | (pk >> 11));
     slot[q] = pk & 2047;
-    const unsigned s0 = d[q].w & 127u, s1 = (d[q].w >> 7) & 127u, s2 = (d[q].w >> 14) & 127u, nv = (d[q].w >> 21) & 127u;
-    const int b0_ = (int)(d[q].x & 0xffffffu), b1_ = (int)((d[q].x >> 24) | ((d[q].y & 0xffffu) << 8));
-    const int b2_ = (int)((d[q].y >> 16) | ((d[q].z & 0xffu) << 16)), b3_ = (int)(d[q].z >> 8);
-    const int bs = (unsigned)lane < s0 ? b0_ : (unsigned)lane < s1 ? b1_ : (unsigned)lane < s2 ? b2_ : b3_;
-    const int pos = (unsigned)lane < nv ? vbase + bs + lane : zero_pos;
-    v[q] = A.vals[pos];
   }
 }
-__device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, int vbase, int zero_pos, int tid, int (&cidx)[8],
-                                            int (&slot)[8], double (&v)[8]) {
-  if (A.segdesc != nullptr) {
-    cshared_fetch(A, L, cbase, vbase, zero_pos, tid, cidx, slot, v);
-    return;
-  }
+__device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, int tid, int (&cidx)[8], int (&slot)[8],
+                                            double (&v)[8]) {
   CsortRaw r;
   csort_fetch_raw(A, L, tid, r);
   csort_decode(r, cbase, cidx, slot, v);
@@ -162,9 +185,25 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
   const int L = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
   if (L >= A.nblk) return;
-  // issued before the (dependent) done-check below: one memory round trip at the head of the workgroup, not two
-  const int4 bd = A.blkdesc[L];
-  const int cbase = IDX16 ? A.colbase[L] : 0;
+  // shared values (kernel-uniform): the block's head through the scalar cache, value loads issued first (cshared_head)
+  bool shared = false;
+  if constexpr (CSORT) shared = A.segdesc != nullptr;
+  [[maybe_unused]] uint4 sw16;
+  [[maybe_unused]] uint2 sw8;
+  [[maybe_unused]] double vsh[kSpmvNnz / kBlock];
+  int4 bd;
+  int cbase = 0;
+  if (CSORT && shared) {
+    if constexpr (CSORT) {
+      int hr0, hnr, hs;
+      cshared_head(A, L, (int)threadIdx.x, sw16, sw8, hr0, hnr, hs, cbase, vsh);
+      bd = int4{hr0, hnr, hs, 0};
+    }
+  } else {
+    // issued before the (dependent) done-check below: one memory round trip at the head of the workgroup, not two
+    bd = A.blkdesc[L];
+    cbase = IDX16 ? A.colbase[L] : 0;
+  }
   bool act[NL];
   double ca[NL], cb[NL];
   {
@@ -238,7 +277,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
     int cidx[kPer];
     [[maybe_unused]] int slot[kPer];  // CSORT: where the entry's product goes (its position in the block's row-major order)
     double v[kPer];
-    if constexpr (CSORT) csort_fetch(A, L, cbase, bd.w, A.zero_pos, tid, cidx, slot, v);
+    if constexpr (CSORT) {
+      if (shared) {
+        cshared_decode(sw16, sw8, cbase, cidx, slot);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) v[k] = vsh[k];
+      } else {
+        csort_fetch(A, L, cbase, tid, cidx, slot, v);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       if (CSORT) {
@@ -527,9 +574,21 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
   for (int t = 0; t < 2; ++t) {
     if (t >= nt) break;
     const int L = Lt[t];
-    const int4 bd = A.blkdesc[L];
-    const int cbase = A.colbase[L];
-    const int r0 = bd.x, nr = bd.y, s = bd.z;
+    int cidx[kPer];
+    [[maybe_unused]] int slot[kPer];
+    double v[kPer];
+    bool shared = false;
+    if constexpr (CSORT) shared = A.segdesc != nullptr;  // (kernel-uniform)
+    [[maybe_unused]] uint4 sw16;
+    [[maybe_unused]] uint2 sw8;
+    int r0, nr, s, cbase;
+    if (CSORT && shared) {  // the block's head through the scalar cache, value loads issued first (cshared_head)
+      if constexpr (CSORT) cshared_head(A, L, tid, sw16, sw8, r0, nr, s, cbase, v);
+    } else {
+      const int4 bd = A.blkdesc[L];
+      cbase = A.colbase[L];
+      r0 = bd.x, nr = bd.y, s = bd.z;
+    }
     int G = 1;
     while (G < 64 && G * 2 * nr <= kBlock) G <<= 1;
     const int rows_per_pass = kBlock / G;
@@ -542,11 +601,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
       hypre[t][0] = yy.x;
       hypre[t][1] = yy.y;
     }
-    int cidx[kPer];
-    [[maybe_unused]] int slot[kPer];
-    double v[kPer];
     if constexpr (CSORT) {
-      csort_fetch(A, L, cbase, bd.w, A.zero_pos, tid, cidx, slot, v);
+      if (shared) cshared_decode(sw16, sw8, cbase, cidx, slot);
+      else csort_fetch(A, L, cbase, tid, cidx, slot, v);
     } else {
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
