@@ -561,7 +561,7 @@ def main():
                     "whole_eval_frac_of_peak": round(nbytes / K / (med / K) / 1e9 / HBM_PEAK_GBS, 4) if not sharded else None}
         # HBM traffic per productive launch: PMC counters cannot be read from inside the run (rocprofv3 writes them when
         # the process ends); the number below is from the COMMITTED profile of this same command, labelled as such
-        for prof in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for prof in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1 and not hp \

@@ -63,6 +63,9 @@ out["per_evaluation_mix"] = mix
 out["traffic_bytes_per_productive_launch"] = round(tb / tot)
 out["algorithmic_bytes_per_productive_launch"] = round(ab / tot)
 out["traffic_over_algorithmic"] = round(tb / ab, 3)
-out["note"] = ("A' is stored in column-sorted padded blocks at 11 B per entry (8 value + 16-bit and 8-bit index planes; the algorithmic "
-               "count prices 12 B/nnz) plus its row pointers; the column-sorted A product re-reads part of its x window through L2.")
+out["note"] = ("Round 4: the blocks of A' hold no values of their own -- both products read ONE copy (the row-group array of A: 8 B "
+               "value + 4 B packed index per entry); A' adds 3 B per entry of index planes and 16 B of segment descriptors per 64 "
+               "entries.  The counters sit between the L2s and the fabric: reads served by the 256 MB Infinity Cache count here like "
+               "reads from HBM, so a value A' re-reads right after the A product still shows (the algorithmic count prices 12 B/nnz "
+               "for each product).")
 print(json.dumps(out, indent=1))

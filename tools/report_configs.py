@@ -86,6 +86,24 @@ for delta in (0.0, SE):
     rows.append((f"cfg5 PDE-control-like n={qh.n} m={qh.m} nnz={qh.nnz}", f"LSQR+CRAIG fused, delta={delta:.3g}", f"{1 / dt:.0f} evals/s ({dt * 1e3:.3f} ms)",
                  f"iterations {its}, rc {rc}"))
 
+# the headline shape with SURVEY 8(d)'s LITERAL column rule (hashed distinct offsets, re-drawn on collision) next to the
+# stratified columns of the bench headline: the layouts must not live off the generator's regularity
+import json  # noqa: E402
+qhh = problems.pde_control_hashed(n=1_000_000, m=100_000)
+dt, its, rc = eqqp_rate(qhh, 0.0, 20, warm=3)
+frac = ""
+for rnd in ("r04",):
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_headline_hashed.json")))
+        d0 = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_headline.json")))
+        frac = (f"; bench.py --workload 'pde-control-hashed ...': {d['value']:.0f} evals/s, roofline.frac {d['roofline']['frac']:.3f} "
+                f"(stratified headline, same box: {d0['value']:.0f} evals/s, {d0['roofline']['frac']:.3f}), profiles/{rnd}_bench_headline_hashed.json")
+    except (OSError, KeyError, ValueError):
+        pass
+rows.append((f"cfg5' PDE-control-like, HASHED offsets n={qhh.n} m={qhh.m} nnz={qhh.nnz}", "LSQR+CRAIG fused, delta=0",
+             f"{1 / dt:.0f} evals/s ({dt * 1e3:.3f} ms)", f"iterations {its}, rc {rc}{frac}"))
+del qhh
+
 # the sparse direct (block-banded) back-end on the banded configurations: numeric factorisation + two-system solve
 import ctypes as C
 from fps_amd import _lib  # noqa: E402
