@@ -652,6 +652,7 @@ struct fpsq_solver_s {
   int ride_delay = 0;           // FPSQ_DEBUG_RIDE_DELAY=c+1 (tests): leader c of every launch starts ~100 us late
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
+  bool at_xcd = true;           // k_spmv_atl: every XCD walks a contiguous eighth of the row blocks (FPSQ_AT_XCD=0: grid order)
   MinresState* minres;
   LnlqState* lnlq;
   LnlqState* lnlq_alt;          // (second copy, see lsqr_alt)
@@ -1428,17 +1429,24 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
         done_pre = true;
         // the first resident set of workgroups takes two row blocks each (see k_spmv_atl)
         const int R = h->resident_wgs - kRideCand;
-        const int n2 = !h->atl_two || M.nblk <= R ? 0 : std::min(R, M.nblk - R);
-        const int nwg = M.nblk - n2;
+        int n2 = !h->atl_two || M.nblk <= R ? 0 : std::min(R, M.nblk - R);
+        int nwg = M.nblk - n2;
+        int bpx = 0;
+        if (h->at_xcd) {  // XCD-contiguous eighths of the row blocks (FPSQ_AT_XCD=0: grid order)
+          bpx = (M.nblk + 7) / 8;
+          const int n2e = std::min(n2 / 8, bpx / 2);
+          n2 = 8 * n2e;
+          nwg = 8 * (bpx - n2e);
+        }
         const dim3 lgrid(kRideCand + nwg + nupd);
         if (M.sorted && halo_rows)
-          launch_product(h, k_spmv_atl<true, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
+          launch_product(h, k_spmv_atl<true, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr, bpx);
         else if (M.sorted)
-          launch_product(h, k_spmv_atl<true, false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
+          launch_product(h, k_spmv_atl<true, false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr, bpx);
         else if (halo_rows)
-          launch_product(h, k_spmv_atl<false, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
+          launch_product(h, k_spmv_atl<false, true>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr, bpx);
         else
-          launch_product(h, k_spmv_atl<false, false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr);
+          launch_product(h, k_spmv_atl<false, false>, lgrid, M.view(), x, yin, yout, partials, nwg, n2, u0, u1, ps, z0, z1, ra, hr, bpx);
       }
     }
     if (done_pre) {
@@ -3125,6 +3133,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_AT_SHARED")) h->at_shared = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_AT_XCD")) h->at_xcd = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY")) h->ride_delay = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_JAC_REFRESH")) h->refresh_3pass = std::atoi(ev) == 3;

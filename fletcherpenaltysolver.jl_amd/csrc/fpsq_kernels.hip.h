@@ -144,7 +144,7 @@ __device__ __forceinline__ void row_segment_sum(const double* prod, int first, i
 // accumulation.  The yin values of both lanes are fetched with one (16-byte when NL = 2) load before any arithmetic
 // and written back with one store when both lanes are active -- a per-lane load/use/store chain costs two dependent
 // memory round trips per row.
-template <int NL>
+template <int NL, bool WT = false>
 __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, const double* ca, const double* cb,
                                              const bool* act, const double* yin, double* yout, double* sq,
                                              const double* ypre = nullptr) {
@@ -176,12 +176,35 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
     if (act[l]) sq[l] += o[l] * o[l];
   }
   if (NL == 2 && all) {
+#if defined(FPSQ_WT_AT_AUX) && FPSQ_WT_AT_AUX
+    if (WT) {  // (what-if: ONE 16-byte store with cache-policy bits, the A' product only)
+      typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, 0x7fffffff, 0x00027000);
+      const double2 ov = make_double2(o[0], o[NL - 1]);
+      u32x4_ w;
+      __builtin_memcpy(&w, &ov, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(row * 16), 0, FPSQ_WT_AT_AUX);
+    } else {
+      *reinterpret_cast<double2*>(yout + row * 2) = make_double2(o[0], o[NL - 1]);
+    }
+#else
     *reinterpret_cast<double2*>(yout + row * 2) = make_double2(o[0], o[NL - 1]);
+#endif
   } else {
 #pragma unroll
     for (int l = 0; l < NL; ++l)
       if (act[l]) yout[row * NL + l] = o[l];
   }
+}
+
+__device__ __forceinline__ void st_upd(double* p, double v) {
+#if defined(FPSQ_WT_UPD) && FPSQ_WT_UPD == 1
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif defined(FPSQ_WT_UPD) && FPSQ_WT_UPD == 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
 }
 
 // ---- Krylov vector updates.  Several independent updates (the LSQR x/w update of the previous iteration, the CRAIG
@@ -256,10 +279,10 @@ __device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk, const L
     const double v = s.src[i * NL + s.lane];
     if (REG) {
       const double w2 = s.b[i];
-      s.a[i] += e0 * v + e1 * w2;
-      s.b[i] = e2 * v + e3 * w2;
+      st_upd(s.a + i, s.a[i] + (e0 * v + e1 * w2));
+      st_upd(s.b + i, e2 * v + e3 * w2);
     } else {
-      s.a[i] += e0 * v;
+      st_upd(s.a + i, s.a[i] + e0 * v);
     }
   }
 }

@@ -529,7 +529,7 @@ template <bool CSORT, bool HALO = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __restrict__ x, const double* yin, double* yout,
                                                      double* partials, int nwg, int n2, const UpdSeg u0, const UpdSeg u1,
                                                      int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra,
-                                                     const HaloRows hr) {
+                                                     const HaloRows hr, int bpx) {
   constexpr int NL = 2;
   __shared__ double prod[kSpmvNnz * NL];
   __shared__ __attribute__((aligned(16))) unsigned long long fst[2 * 80];
@@ -548,8 +548,19 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
       run_fused_updates<NL>(u0, u1, nwg + kRideCand, red, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
     return;
   }
-  const int nt = b < n2 ? 2 : 1;
-  const int Lt[2] = {b < n2 ? b : n2 + b, n2 + b};
+  // bpx > 0: XCD-contiguous eighths -- workgroup b runs on XCD b & 7 (the leaders fill a multiple of eight slots) and walks
+  // blocks [e bpx, (e + 1) bpx) of eighth e = b & 7; its first n2 / 8 workgroups take two blocks each.  bpx = 0: grid order.
+  int nt = b < n2 ? 2 : 1;
+  int Lt[2] = {b < n2 ? b : n2 + b, n2 + b};
+  if (bpx > 0) {
+    const int e = b & 7, j = b >> 3, n2e = n2 >> 3;
+    nt = j < n2e ? 2 : 1;
+    Lt[0] = e * bpx + (j < n2e ? j : n2e + j);
+    Lt[1] = e * bpx + n2e + j;
+    const int end = min((e + 1) * bpx, A.nblk);
+    if (Lt[0] >= end) return;
+    if (Lt[1] >= end) nt = 1;
+  }
   if (Lt[0] >= A.nblk) return;
   // Wave 0 looks for the leaders' record at every point where a wait is free anyway: behind the stream (examined behind
   // the gathers), behind the gathers, behind the products, behind the row sums.  Device-scope loads come back later than
@@ -667,10 +678,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
           for (int l = 0; l < NL; ++l)
             if (C.act[l]) dst[l] = hacc[t][p][l];
         } else {
-          row_epilogue<NL>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
+          row_epilogue<NL, true>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
         }
       }
     }
+#if defined(FPSQ_WHATIF_FENCE) && (FPSQ_WHATIF_FENCE & 1)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (what-if: the cost of publishing a block's rows to the other XCDs)
+#endif
     if (partials != nullptr) {
       if (t) lds_barrier();  // (thread 0 has read `red` for the previous block)
       block_sum_lanes<NL>(sq, red);
@@ -793,6 +807,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   if (g >= M.ng) return;
   if (PAD && !LEAD) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
   const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
+#if defined(FPSQ_WHATIF_FENCE) && (FPSQ_WHATIF_FENCE & 2)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (what-if: the cost of an acquire per row group)
+#endif
   double ca[NL], cb[NL];
   bool act[NL];
   [[maybe_unused]] bool ride_ok = false;  // (wave 0's)
@@ -853,7 +870,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
         vq[k] = ok ? v[k] : 0.0;
         const int col = cmin + (int)(pq[k] & ((1u << kRgcsColBits) - 1));
         if (NL == 1) xv[k].x = x[col];
+#if defined(FPSQ_WHATIF_FENCE) && (FPSQ_WHATIF_FENCE & 8)
+        else {  // (what-if: agent-scope gathers)
+          typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7fffffff, 0x00027000);
+          const u32x4_ w = __builtin_amdgcn_raw_buffer_load_b128(rs, col * 16, 0, 16);
+          __builtin_memcpy(&xv[k], &w, 16);
+        }
+#else
         else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
+#endif
       }
 #pragma unroll
       for (int p = 0; p < kRgcsMaxPass; ++p) {
