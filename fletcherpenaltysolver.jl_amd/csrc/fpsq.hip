@@ -38,6 +38,7 @@ struct DevCsr {
   double* vals = nullptr;
   int32_t* rowblk = nullptr;
   int32_t nblk = 0;
+  int32_t row_align = 1;       // make_rowblocks' alignment of the block boundaries (8 for the A' of a fused-iteration handle)
   uint16_t* col16 = nullptr;   // compressed columns (see CsrView), null when not representable
   int32_t* colbase = nullptr;
   int4* blkdesc = nullptr;
@@ -652,6 +653,14 @@ struct fpsq_solver_s {
   int ride_delay = 0;           // FPSQ_DEBUG_RIDE_DELAY=c+1 (tests): leader c of every launch starts ~100 us late
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
+  // one launch per joint iteration (k_iter_fused; FPSQ_FUSE_ITER=0: two launches)
+  bool fuse_iter = true, fuse_ok = false;
+  int2* fz_dep = nullptr;                 // per row group: the A' blocks it waits for
+  unsigned int* fz_flag = nullptr;        // per A' block: launch number of its last completion
+  unsigned long long* fz_ptag = nullptr;  // per A' block: four tagged words (its squared-norm partials)
+  unsigned long long* ride_rec2 = nullptr;  // the mid leaders' record
+  void* state3[3] = {nullptr, nullptr, nullptr};  // third copies of the LSQR (x 2) / CRAIG / LNLQ states: lsqr, craig, lnlq
+  int64_t fused_launches = 0;
   bool at_xcd = true;           // k_spmv_atl: every XCD walks a contiguous eighth of the row blocks (FPSQ_AT_XCD=0: grid order)
   MinresState* minres;
   LnlqState* lnlq;
@@ -800,7 +809,10 @@ struct HostCsr {
   std::vector<int32_t> rowptr, colind;
 };
 
-std::vector<int32_t> make_rowblocks(const std::vector<int32_t>& rowptr, int64_t nrows) {
+// align > 1 (the A' blocks of a handle whose iterations run as one launch, k_iter_fused): a block that holds at least `align` rows
+// ends on a multiple of `align` rows -- with 16-byte rows of the long pair and align = 8 every 128-byte line of the product's
+// output then belongs to ONE block.  (Blocks of fewer rows -- very long rows -- stay as they are: rowblocks_aligned() says so.)
+std::vector<int32_t> make_rowblocks(const std::vector<int32_t>& rowptr, int64_t nrows, int align = 1) {
   std::vector<int32_t> rb;
   rb.push_back(0);
   int64_t r = 0;
@@ -814,10 +826,17 @@ std::vector<int32_t> make_rowblocks(const std::vector<int32_t>& rowptr, int64_t 
       ++r1;
     }
     if (r1 == r) r1 = r + 1;  // a single row longer than kSpmvNnz gets a block of its own
+    else if (align > 1 && r1 < nrows && r1 - r >= align) r1 = r + (r1 - r) / align * align;
     rb.push_back((int32_t)r1);
     r = r1;
   }
   return rb;
+}
+
+bool rowblocks_aligned(const std::vector<int32_t>& rb, int align) {
+  for (size_t i = 0; i + 1 < rb.size(); ++i)
+    if (rb[i] % align) return false;
+  return true;
 }
 
 // transpose structure: returns CSR of A' and perm with AT slot t <- A slot perm[t]
@@ -844,7 +863,7 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
   D.ncols = H.ncols;
   D.nnz = (int64_t)H.colind.size();
   D.nstore = D.nnz;
-  std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows);
+  std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows, D.row_align);
   D.nblk = (int32_t)rb.size() - 1;
   if (int rc = dalloc(h, &D.rowptr, H.rowptr.size())) return rc;
   // one padding entry (column 0, value 0): the product kernels read index `s` of an empty row block unconditionally
@@ -911,7 +930,7 @@ int upload_csr(fpsq_handle h, const HostCsr& H, DevCsr& D) {
 int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevCsr& D,
                const std::vector<int32_t>* csr_pos = nullptr, int64_t zero_pos = 0, const double* ext_vals = nullptr) {
   if (D.nnz == 0 || h->opt.jac_format == 1) return 0;
-  std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows);
+  std::vector<int32_t> rb = make_rowblocks(H.rowptr, H.nrows, D.row_align);
   const int nblk = (int)rb.size() - 1;
   for (int b = 0; b < nblk; ++b)
     if (H.rowptr[rb[b + 1]] - H.rowptr[rb[b]] > kSpmvNnz) return 0;
@@ -1096,7 +1115,8 @@ int pad_blocks(fpsq_handle h, const HostCsr& H, std::vector<int32_t>& perm, DevC
 }
 
 // Row-group column-sorted copy of A (see k_spmv_rgcs).  Not built (ok = false) when a group spans >= 2^21 columns.
-int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D, std::vector<int32_t>* csr_pos = nullptr) {
+int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D, std::vector<int32_t>* csr_pos = nullptr,
+               std::vector<int2>* col_range = nullptr) {
   const int64_t nnz = (int64_t)H.colind.size();
   D.ok = false;
   if (csr_pos) csr_pos->clear();
@@ -1209,6 +1229,7 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D, std::vector<int32_t>
         vperm[e0 + k] = e0 + src;
       }
     }
+    if (col_range) col_range->push_back(make_int2(cmin, cmax));
     RgcsGroup gd{};
     gd.r0 = (int32_t)r;
     gd.R = R;
@@ -1300,15 +1321,48 @@ int alloc_workspaces(fpsq_handle h) {
   return 0;
 }
 
+// One launch per joint iteration (k_iter_fused) -- what it needs beyond the two products' layouts: every A' block boundary on a
+// 128-byte line of the long pair, the main layouts of both products (column-sorted padded blocks, padded row groups), 32-bit
+// byte offsets into the long pair, and per row group the range of A' blocks that own the lines it gathers from.
+int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<int2>& col_range) {
+  h->fuse_ok = false;
+  if (!h->fuse_iter || h->comm || !h->RA.ok || h->RA.view.stride == 0 || !h->AT.sorted || !h->AT.padded || h->AT.nblk < 1) return 0;
+  if ((int64_t)h->n * 16 >= (int64_t)INT32_MAX || (int64_t)h->m * 16 >= (int64_t)INT32_MAX) return 0;
+  if ((int)col_range.size() != h->RA.view.ng) return 0;
+  const std::vector<int32_t> rb = make_rowblocks(HT.rowptr, HT.nrows, h->AT.row_align);
+  if ((int)rb.size() - 1 != h->AT.nblk || !rowblocks_aligned(rb, 8)) return 0;
+  std::vector<int2> dep(col_range.size());
+  for (size_t g = 0; g < col_range.size(); ++g) {
+    const int64_t lo = col_range[g].x & ~7, hi = std::min<int64_t>((int64_t)col_range[g].y | 7, h->n - 1);
+    const int b0 = (int)(std::upper_bound(rb.begin(), rb.end(), (int32_t)lo) - rb.begin()) - 1;
+    const int b1 = (int)(std::upper_bound(rb.begin(), rb.end(), (int32_t)hi) - rb.begin()) - 1;
+    dep[g] = make_int2(std::max(b0, 0), std::min(std::max(b1, 0), h->AT.nblk - 1));
+  }
+  dfree(h, &h->fz_dep);
+  dfree(h, &h->fz_flag);
+  dfree(h, &h->fz_ptag);
+  if (int rc = dalloc(h, &h->fz_dep, dep.size())) return rc;
+  if (int rc = dalloc(h, &h->fz_flag, (size_t)h->AT.nblk)) return rc;
+  if (int rc = dalloc(h, &h->fz_ptag, (size_t)h->AT.nblk * 4)) return rc;
+  HIPCHK(h, hipMemcpy(h->fz_dep, dep.data(), dep.size() * sizeof(int2), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemset(h->fz_flag, 0, (size_t)h->AT.nblk * 4));
+  HIPCHK(h, hipMemset(h->fz_ptag, 0, (size_t)h->AT.nblk * 32));
+  h->fuse_ok = true;
+  return 0;
+}
+
 // after the structure (host CSR of A) is known: transposed copy, uploads, workspaces
 int finish_structure(fpsq_handle h, const HostCsr& HA) {
   HostCsr HT;
   std::vector<int32_t> perm;
   transpose_structure(HA, HT, perm);
   if (int rc = upload_csr(h, HA, h->A)) return rc;
+  h->AT.row_align = h->fuse_iter && !h->comm ? 8 : 1;
+  if (const char* ev = std::getenv("FPSQ_AT_ROW_ALIGN")) h->AT.row_align = std::max(1, std::atoi(ev));  // (tests: the fused layout without the fused launch)
   if (int rc = upload_csr(h, HT, h->AT)) return rc;
   std::vector<int32_t> csr_pos;
-  if (int rc = build_rgcs(h, HA, h->RA, &csr_pos)) return rc;
+  std::vector<int2> col_range;
+  if (int rc = build_rgcs(h, HA, h->RA, &csr_pos, &col_range)) return rc;
   const bool can_share = h->RA.ok && !csr_pos.empty() && !h->refresh_3pass;
   if (int rc = pad_blocks(h, HT, perm, h->AT, can_share ? &csr_pos : nullptr, h->RA.nstore, h->RA.vals)) return rc;
   if (int rc = dalloc(h, &h->permT, perm.size())) return rc;
@@ -1326,6 +1380,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
     h->perms_to_input = true;
   }
   if (int rc = alloc_workspaces(h)) return rc;
+  if (int rc = setup_fused_iteration(h, HT, col_range)) return rc;
   HIPCHK(h, hipDeviceSynchronize());  // the set-up used null-stream copies/memsets; the solver stream is non-blocking
   h->have_structure = true;
   h->have_values = false;
@@ -1797,6 +1852,7 @@ struct Lane {
   // filled by run_krylov
   void* state = nullptr;
   void* state_alt = nullptr;    // the other copy of the state (riding steps alternate between the two)
+  void* state_alt2 = nullptr;   // a third one (fused iterations: the step behind the A' product lands there, see k_iter_fused)
   LaneCtl* ctl = nullptr;       // coefficients of the A product (and of the A' product for LSQR / CRAIG)
   LaneCtl* ctlT = nullptr;      // coefficients of the A' product (MINRES: the raw tmp = A' r2)
   int64_t itmax = 0;
@@ -1996,6 +2052,7 @@ struct KrylovRun {
   bool lead = false;        // the steps ride in the next product launch (leader workgroups)
   bool fuse_upd = false;    // the vector updates ride in the product launches
   bool split_steps = false; // replicated n-sums and per-rank m-sums cannot share a presum launch
+  bool can_fuse = false;    // a joint iteration is ONE launch (k_iter_fused) whenever the previous product's steps are pending
   StepArgs none{};
   // the steps behind the last product, not launched yet
   StepArgs pend[2];
@@ -2049,6 +2106,7 @@ struct KrylovRun {
       if (L.kind == LANE_LSQR) {
         any_lsqr = true;
         LsqrState* S = h->lsqr[nlsqr];
+        L.state_alt2 = reinterpret_cast<LsqrState*>(h->state3[0]) + nlsqr;
         L.state_alt = h->lsqr_alt[nlsqr++];
         L.state = S;
         L.ctl = &S->ctl;
@@ -2070,6 +2128,7 @@ struct KrylovRun {
       } else if (L.kind == LANE_LNLQ) {
         LnlqState* S = h->lnlq;
         L.state_alt = h->lnlq_alt;
+        L.state_alt2 = h->state3[2];
         L.state = S;
         L.ctl = &S->ctl;
         // pass k of lnlq!'s loop is completed (and tested) by the step after the A' product of iteration k + 1
@@ -2080,6 +2139,7 @@ struct KrylovRun {
       } else {
         CraigState* S = h->craig;
         L.state_alt = h->craig_alt;
+        L.state_alt2 = h->state3[1];
         L.state = S;
         L.ctl = &S->ctl;
         L.itmax = o.ln_itmax == 0 ? n + m : o.ln_itmax;
@@ -2110,6 +2170,7 @@ struct KrylovRun {
     // (every vector a rank updates is its own).  Sharded with replicated n-vectors: separate update launch, in place.
     fuse_upd = local_vec;
     split_steps = h->comm && !h->halo;
+    can_fuse = NL == 2 && h->fuse_ok && h->at_xcd && lead && fuse_upd && !h->comm && minres_lane < 0 && !h->ride_break;
     look = std::max(1, o.lookahead);
   }
 
@@ -2513,6 +2574,80 @@ struct KrylovRun {
     return 0;
   }
 
+  // One launch for both half-steps (k_iter_fused): the A' product with what rides in it, the steps behind it (mid leaders), the A
+  // product with what rides in it.  Needs the previous product's steps pending (they are the head leaders' work).
+  int iteration_fused() {
+    lu[0] = lu[1] = seg_none();
+    nlu = 0;
+    if (it > 1) {
+      for (int l = 0; l < NL; ++l)
+        if (lanes[l].kind == LANE_LSQR) lu[nlu++] = lsqr_upd_seg(l, it - 1);
+    } else {
+      lu[0] = winit[0];
+      lu[1] = winit[1];
+    }
+    const StepArgs* pre = pre_args(true);
+    StepArgs sh[2] = {pre[0], pre[NL - 1]}, sm[2];
+    for (int l = 0; l < NL; ++l) {
+      sm[l] = step_after_at(l, h->AT.nblk);
+      sm[l].state = sh[l].state_out;  // (what the head step leaves: the mid leaders recompute it, nobody reads this pointer)
+      sm[l].state_out = lanes[l].state_alt2;
+      sm[l].prod_ctl_off = 0;
+    }
+    UpdSeg cu[2] = {seg_none(), seg_none()};
+    for (int l = 0; l < NL; ++l)
+      if (is_ln(lanes[l].kind)) ln_upd_segs(l, cu[0], cu[1]);
+    FuseGrid fg{};
+    fg.bpx = (h->AT.nblk + 7) / 8;
+    {
+      const int R = h->resident_wgs - kRideCand;
+      const int n2 = !h->atl_two || h->AT.nblk <= R ? 0 : std::min(R, h->AT.nblk - R);
+      const int n2e = std::min(n2 / 8, fg.bpx / 2);
+      fg.n2 = 8 * n2e;
+      fg.nwg_t = 8 * (fg.bpx - n2e);
+    }
+    fg.nupd_t = (lu[0].nblk + lu[1].nblk + 7) / 8 * 8;
+    fg.gpx = (h->RA.view.ng + 7) / 8;
+    RideArgs ra{}, rb{};
+    ra.rec = h->ride_rec;
+    ra.want = (unsigned int)++h->ride_seq;
+    ra.pub = ra.want;
+    ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
+    ra.delay = h->ride_delay;
+    rb = ra;
+    rb.rec = h->ride_rec2;
+    rb.delay = 0;
+    FuseArgs fz{};
+    fz.blkflag = h->fz_flag;
+    fz.ptag = h->fz_ptag;
+    fz.dep = h->fz_dep;
+    fz.want = ra.want;
+    fz.err = ra.err;
+    const dim3 grid(kRideCand + fg.nwg_t + kRideCand + fg.nupd_t + 8 * fg.gpx + cu[0].nblk + cu[1].nblk);
+    launch_product(h, k_iter_fused, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, h->pS2, h->strA, fg, lu[0], lu[1],
+                   cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
+    h->launches++;
+    h->spmv_launches++;
+    h->prod_a[1]++;
+    h->prod_at[1]++;
+    h->fused_launches++;
+    // the lanes live in their third copies now; the other two are free for the next launch's two steps
+    for (int l = 0; l < NL; ++l) {
+      Lane& L = lanes[l];
+      void* s0 = L.state;
+      L.state = L.state_alt2;
+      L.state_alt2 = L.state_alt;
+      L.state_alt = s0;
+      L.ctl = reinterpret_cast<LaneCtl*>(L.state);
+      L.ctlT = L.ctl;
+    }
+    have_pend = false;
+    std::swap(SPcur, SPalt);
+    StepArgs sb[2] = {none, none};
+    for (int l = 0; l < NL; ++l) sb[l] = step_after_a(l);
+    return post_step(sb[0], sb[1], true);
+  }
+
   // ------------------------------------------------------------------ the host's pacing
   // the gated final LSQR flush + the caller's epilogue behind iteration `it` (see the comment above)
   int enqueue_speculative() {
@@ -2656,8 +2791,12 @@ struct KrylovRun {
     if (int rc = startup()) return rc;
     while (it < itmax_all) {
       ++it;
-      if (int rc = half_step_at()) return rc;
-      if (int rc = half_step_a()) return rc;
+      if (can_fuse && have_pend) {
+        if (int rc = iteration_fused()) return rc;
+      } else {
+        if (int rc = half_step_at()) return rc;
+        if (int rc = half_step_a()) return rc;
+      }
       bool stop = false;
       if (int rc = h->comm ? pace_sharded(stop) : pace_single(stop)) return rc;
       if (stop) break;
@@ -2776,6 +2915,7 @@ void call_begin(fpsq_handle h) {
   h->launches = 0;
   h->spmv_launches = 0;
   h->prod_a[0] = h->prod_a[1] = h->prod_at[0] = h->prod_at[1] = 0;
+  h->fused_launches = 0;
   h->ev_used = 0;
   // device-side timing of the whole call only when profiling is on: an event record is a marker packet the GPU has to
   // process (a few us each); otherwise last_solve_ms is the host's wall time of the call
@@ -2811,6 +2951,7 @@ int call_end(fpsq_handle h) {
     h->info.last_prod_a[i] = h->prod_a[i];
     h->info.last_prod_at[i] = h->prod_at[i];
   }
+  h->info.last_fused_launches = h->fused_launches;
   double sp = 0.0;
   for (size_t i = 0; i < h->ev_used; ++i) {
     float t = 0.f;
@@ -2853,6 +2994,7 @@ int call_end_ordered(fpsq_handle h, double seq) {
     h->info.last_prod_a[i] = h->prod_a[i];
     h->info.last_prod_at[i] = h->prod_at[i];
   }
+  h->info.last_fused_launches = h->fused_launches;
   h->info.last_spmv_ms = 0.0;
   return 0;
 }
@@ -3134,6 +3276,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_AT_XCD")) h->at_xcd = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY")) h->ride_delay = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_JAC_REFRESH")) h->refresh_3pass = std::atoi(ev) == 3;
@@ -3153,17 +3296,19 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   void* p = nullptr;
-  const size_t state_bytes = sizeof(LsqrState) * 4 + sizeof(CraigState) * 2 + sizeof(MinresState) * 2 + sizeof(LnlqState) * 2 +
+  const size_t state_bytes = sizeof(LsqrState) * 6 + sizeof(CraigState) * 3 + sizeof(MinresState) * 2 + sizeof(LnlqState) * 3 +
                              4 * sizeof(LaneCtl) + 64 * sizeof(double);
   if ((e = hipMalloc(&p, state_bytes)) != hipSuccess) return fail("hipMalloc", e);
   h->allocs.push_back(p);
   hipMemset(p, 0, state_bytes);
   {
     void* q = nullptr;
-    if ((e = hipMalloc(&q, 8 * 512)) != hipSuccess) return fail("hipMalloc", e);  // (a record copy of 64 words per XCC)
+    // (a record copy of 64 words per XCC; a second record for the mid leaders of fused iterations)
+    if ((e = hipMalloc(&q, 2 * 8 * 512 + 64)) != hipSuccess) return fail("hipMalloc", e);
     h->allocs.push_back(q);
-    hipMemset(q, 0, 8 * 512);
+    hipMemset(q, 0, 2 * 8 * 512 + 64);
     h->ride_rec = (unsigned long long*)q;
+    h->ride_rec2 = h->ride_rec + 512;
   }
   char* cp = (char*)p;
   h->lsqr[0] = (LsqrState*)cp;
@@ -3184,6 +3329,12 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   cp += sizeof(LnlqState);
   h->minres_alt = (MinresState*)cp;
   cp += sizeof(MinresState);
+  h->state3[0] = cp;  // (two LSQR states)
+  cp += sizeof(LsqrState) * 2;
+  h->state3[1] = cp;
+  cp += sizeof(CraigState);
+  h->state3[2] = cp;
+  cp += sizeof(LnlqState);
   h->ctl_tmp = (LaneCtl*)cp;
   cp += sizeof(LaneCtl);
   h->ctl_raw = (LaneCtl*)cp;

@@ -140,6 +140,27 @@ __device__ __forceinline__ void row_segment_sum(const double* prod, int first, i
   }
 }
 
+// Pairs of an interleaved [len][2] vector through buffer instructions with the agent-scope bit (sc1): a load that is coherent
+// across the XCDs' L2s, a store that is written through to its coherence point -- what a workgroup needs to hand rows to a
+// workgroup on another XCD INSIDE a launch (k_iter_fused; the fences of the memory model cost an L2 write-back / invalidate
+// per workgroup there: profiles/r04_coherence_whatif.txt).  Offsets are 32-bit: callers guarantee 16 len < 2^31.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pair_rsrc(const double* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00027000);
+}
+__device__ __forceinline__ double2 ld_pair_ag(const double* base, int row) {
+  const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(pair_rsrc(base), row * 16, 0, /*sc1*/ 16);
+  double2 d;
+  __builtin_memcpy(&d, &w, 16);
+  return d;
+}
+__device__ __forceinline__ void st_pair_wt(double* base, int row, double a, double b) {
+  const double2 ov = make_double2(a, b);
+  u32x4_t w;
+  __builtin_memcpy(&w, &ov, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(w, pair_rsrc(base), row * 16, 0, /*sc1*/ 16);
+}
+
 // Row epilogue shared by the product kernels: out = ca * acc + cb * yin for the active lanes, squared-norm
 // accumulation.  The yin values of both lanes are fetched with one (16-byte when NL = 2) load before any arithmetic
 // and written back with one store when both lanes are active -- a per-lane load/use/store chain costs two dependent
@@ -176,35 +197,19 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
     if (act[l]) sq[l] += o[l] * o[l];
   }
   if (NL == 2 && all) {
-#if defined(FPSQ_WT_AT_AUX) && FPSQ_WT_AT_AUX
-    if (WT) {  // (what-if: ONE 16-byte store with cache-policy bits, the A' product only)
-      typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)yout, 0, 0x7fffffff, 0x00027000);
-      const double2 ov = make_double2(o[0], o[NL - 1]);
-      u32x4_ w;
-      __builtin_memcpy(&w, &ov, 16);
-      __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(row * 16), 0, FPSQ_WT_AT_AUX);
+    if (WT) {  // written through (one 16-byte buffer store, agent scope): see k_iter_fused
+      st_pair_wt(yout, (int)row, o[0], o[NL - 1]);
     } else {
       *reinterpret_cast<double2*>(yout + row * 2) = make_double2(o[0], o[NL - 1]);
     }
-#else
-    *reinterpret_cast<double2*>(yout + row * 2) = make_double2(o[0], o[NL - 1]);
-#endif
   } else {
 #pragma unroll
     for (int l = 0; l < NL; ++l)
-      if (act[l]) yout[row * NL + l] = o[l];
+      if (act[l]) {
+        if (WT) __hip_atomic_store(yout + row * NL + l, o[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else yout[row * NL + l] = o[l];
+      }
   }
-}
-
-__device__ __forceinline__ void st_upd(double* p, double v) {
-#if defined(FPSQ_WT_UPD) && FPSQ_WT_UPD == 1
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif defined(FPSQ_WT_UPD) && FPSQ_WT_UPD == 2
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
 }
 
 // ---- Krylov vector updates.  Several independent updates (the LSQR x/w update of the previous iteration, the CRAIG
@@ -279,10 +284,10 @@ __device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk, const L
     const double v = s.src[i * NL + s.lane];
     if (REG) {
       const double w2 = s.b[i];
-      st_upd(s.a + i, s.a[i] + (e0 * v + e1 * w2));
-      st_upd(s.b + i, e2 * v + e3 * w2);
+      s.a[i] += e0 * v + e1 * w2;
+      s.b[i] = e2 * v + e3 * w2;
     } else {
-      st_upd(s.a + i, s.a[i] + e0 * v);
+      s.a[i] += e0 * v;
     }
   }
 }

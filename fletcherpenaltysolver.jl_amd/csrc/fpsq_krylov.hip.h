@@ -936,6 +936,38 @@ __device__ __forceinline__ int state_bytes(int kind) {
   }
 }
 
+// thread 0: one recurrence advanced in `S` (the staged state) from the sums of its partial arrays
+__device__ __forceinline__ void step_advance(const StepArgs& a, void* S, double s0, double s1, Progress* prog) {
+  switch (a.kind) {
+    case STEP_LSQR_BEGIN: lsqr_begin_step((LsqrState*)S, s0, prog); break;
+    case STEP_LSQR_BEGIN2: lsqr_begin2_step((LsqrState*)S, s0, prog); break;
+    case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)S, s0); break;
+    case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)S, s0, s1, a.it, prog); break;
+    case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)S, s0, prog); break;
+    case STEP_CRAIG_SA: craig_sa_step((CraigState*)S, s0, a.it, prog); break;
+    case STEP_CRAIG_SB: craig_sb_step((CraigState*)S, s0, s1, a.it, prog); break;
+    case STEP_MINRES_BEGIN: minres_begin_step((MinresState*)S, s0, prog); break;
+    case STEP_MINRES_A: minres_a_step((MinresState*)S, s0); break;
+    case STEP_MINRES_B: minres_b_step((MinresState*)S, s0, a.it); break;
+    case STEP_MINRES_C: minres_c_step((MinresState*)S, s0, a.it, prog); break;
+    case STEP_LNLQ_BEGIN: lnlq_begin_step((LnlqState*)S, s0, prog); break;
+    case STEP_LNLQ_SA: lnlq_sa_step((LnlqState*)S, s0, a.it, prog); break;
+    case STEP_LNLQ_SB: lnlq_sb_step((LnlqState*)S, s0); break;
+    default: break;
+  }
+}
+
+// thread 0 of a committing workgroup: the step that ends a recurrence leaves the final statistics in host-mapped memory
+__device__ __forceinline__ void step_final_stats(const StepArgs& a, const void* S) {
+  if (a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
+    const fpsq_stats* fin = a.kind >= STEP_LNLQ_BEGIN ? &((const LnlqState*)S)->stats
+                            : a.kind >= STEP_MINRES_BEGIN ? &((const MinresState*)S)->stats
+                            : a.kind >= STEP_CRAIG_BEGIN ? &((const CraigState*)S)->stats
+                                                         : &((const LsqrState*)S)->stats;
+    *a.host_stats = *fin;
+  }
+}
+
 // One scalar step by the calling workgroup (kStepThreads threads): the state is staged in `st` (LDS, 80 words), the partial
 // sums are reduced in the fixed order, thread 0 advances the recurrence IN `st`.  On return (after the closing barrier) `st`
 // holds the new state for every thread of the workgroup.  commit: this workgroup also performs the step's side effects --
@@ -969,31 +1001,9 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
   if (threadIdx.x == 0 && !skip) {
     void* S = st;
     Progress* prog = commit ? a.prog : nullptr;
-    switch (a.kind) {
-      case STEP_LSQR_BEGIN: lsqr_begin_step((LsqrState*)S, s0, prog); break;
-      case STEP_LSQR_BEGIN2: lsqr_begin2_step((LsqrState*)S, s0, prog); break;
-      case STEP_LSQR_SA: lsqr_sa_step((LsqrState*)S, s0); break;
-      case STEP_LSQR_SB: lsqr_sb_step((LsqrState*)S, s0, s1, a.it, prog); break;
-      case STEP_CRAIG_BEGIN: craig_begin_step((CraigState*)S, s0, prog); break;
-      case STEP_CRAIG_SA: craig_sa_step((CraigState*)S, s0, a.it, prog); break;
-      case STEP_CRAIG_SB: craig_sb_step((CraigState*)S, s0, s1, a.it, prog); break;
-      case STEP_MINRES_BEGIN: minres_begin_step((MinresState*)S, s0, prog); break;
-      case STEP_MINRES_A: minres_a_step((MinresState*)S, s0); break;
-      case STEP_MINRES_B: minres_b_step((MinresState*)S, s0, a.it); break;
-      case STEP_MINRES_C: minres_c_step((MinresState*)S, s0, a.it, prog); break;
-      case STEP_LNLQ_BEGIN: lnlq_begin_step((LnlqState*)S, s0, prog); break;
-      case STEP_LNLQ_SA: lnlq_sa_step((LnlqState*)S, s0, a.it, prog); break;
-      case STEP_LNLQ_SB: lnlq_sb_step((LnlqState*)S, s0); break;
-      default: break;
-    }
+    step_advance(a, S, s0, s1, prog);
     if (hook) hook->advanced();
-    if (commit && a.host_stats && reinterpret_cast<const LaneCtl*>(S)->done) {
-      const fpsq_stats* fin = a.kind >= STEP_LNLQ_BEGIN ? &((LnlqState*)S)->stats
-                              : a.kind >= STEP_MINRES_BEGIN ? &((MinresState*)S)->stats
-                              : a.kind >= STEP_CRAIG_BEGIN ? &((CraigState*)S)->stats
-                                                           : &((LsqrState*)S)->stats;
-      *a.host_stats = *fin;
-    }
+    if (commit) step_final_stats(a, S);
   }
   __syncthreads();
   if (commit && (!skip || a.state_out != nullptr)) {

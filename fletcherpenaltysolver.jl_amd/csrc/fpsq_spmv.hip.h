@@ -525,43 +525,58 @@ __device__ __forceinline__ bool ride_settle(const RideArgs& ra, unsigned long lo
 // slots free up, ~10 us into the launch) take the single block n2 + b.  Same blocks, same per-block arithmetic: bitwise.
 constexpr int kAtlPass = kMaxRowsPerBlk / kBlock;  // row passes of a block (one lane per row at most kBlock rows per pass)
 // HALO: the row-sharded form (see k_spmv<.., HALO>): overlap rows only deposit their raw sums, k_halo_finish completes them.
-template <bool CSORT, bool HALO = false>
-__global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __restrict__ x, const double* yin, double* yout,
-                                                     double* partials, int nwg, int n2, const UpdSeg u0, const UpdSeg u1,
-                                                     int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra,
-                                                     const HaloRows hr, int bpx) {
-  constexpr int NL = 2;
-  __shared__ double prod[kSpmvNnz * NL];
-  __shared__ __attribute__((aligned(16))) unsigned long long fst[2 * 80];
-  __shared__ double fred[32];
-  __shared__ unsigned long long crec[10];
-  __shared__ int okf;
-  double* red = prod;
-  const int tid = threadIdx.x;
-  if (blockIdx.x < kRideCand) {
-    ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
-    return;
-  }
-  const int b = (int)blockIdx.x - kRideCand;
-  if (b >= nwg) {  // a riding-update workgroup (dispatched last: the record is up long before)
-    if (ride_settle<true>(ra, fst, &okf))
-      run_fused_updates<NL>(u0, u1, nwg + kRideCand, red, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
-    return;
-  }
-  // bpx > 0: XCD-contiguous eighths -- workgroup b runs on XCD b & 7 (the leaders fill a multiple of eight slots) and walks
-  // blocks [e bpx, (e + 1) bpx) of eighth e = b & 7; its first n2 / 8 workgroups take two blocks each.  bpx = 0: grid order.
-  int nt = b < n2 ? 2 : 1;
-  int Lt[2] = {b < n2 ? b : n2 + b, n2 + b};
+// Which row blocks product workgroup b of an A' launch with leaders takes (false: none).  The first n2 workgroups take two.
+// bpx > 0: XCD-contiguous eighths -- workgroup b runs on XCD b & 7 (whatever precedes the product workgroups in the grid fills a
+// multiple of eight slots) and walks blocks [e bpx, (e + 1) bpx) of eighth e = b & 7; its first n2 / 8 workgroups take two
+// blocks each.  bpx = 0: grid order.
+__device__ __forceinline__ bool atl_blocks_of(int b, int n2, int bpx, int nblk, int (&Lt)[2], int& nt) {
+  nt = b < n2 ? 2 : 1;
+  Lt[0] = b < n2 ? b : n2 + b;
+  Lt[1] = n2 + b;
   if (bpx > 0) {
     const int e = b & 7, j = b >> 3, n2e = n2 >> 3;
     nt = j < n2e ? 2 : 1;
     Lt[0] = e * bpx + (j < n2e ? j : n2e + j);
     Lt[1] = e * bpx + n2e + j;
-    const int end = min((e + 1) * bpx, A.nblk);
-    if (Lt[0] >= end) return;
+    const int end = min((e + 1) * bpx, nblk);
+    if (Lt[0] >= end) return false;
     if (Lt[1] >= end) nt = 1;
   }
-  if (Lt[0] >= A.nblk) return;
+  return Lt[0] < nblk;
+}
+
+// What a product workgroup of a FUSED launch (k_iter_fused: the A' product and the A product of one iteration in one grid) needs
+// besides the products' own arguments.  An A' block publishes itself once its rows of the long pair are written through; a row
+// group of A starts gathering when the blocks that own the 128-byte lines it reads have done so; the scalar steps behind the
+// A' product are computed by a second set of leaders once every block has counted itself in.
+struct FuseArgs {
+  unsigned int* blkflag;          // [blocks of A']: this launch's number once block L's rows are at their coherence point
+  unsigned long long* ptag;       // [blocks][4] self-validating words: the blocks' squared-norm partials (lane 0 high, low; lane 1 high, low)
+  const int2* dep;                // per row group of A: first and last A' block owning rows on the lines the group gathers from
+  unsigned int want;              // this launch's number
+  unsigned int pad_;
+  unsigned long long* err;        // host-mapped: a bounded wait expired
+};
+__device__ __forceinline__ unsigned long long tag_hi(double v, unsigned int want) {
+  return ((unsigned long long)__double_as_longlong(v) & 0xffffffff00000000ull) | want;
+}
+__device__ __forceinline__ unsigned long long tag_lo(double v, unsigned int want) {
+  return ((unsigned long long)__double_as_longlong(v) << 32) | want;
+}
+
+// The A' product of one workgroup: blocks Lt[0 .. nt) of the padded layout, two lanes, coefficients from the leaders' record.
+// FUSED (k_iter_fused): rows are written through, and behind each block's epilogue -- every wave has waited for the
+// acknowledgement of its stores BEFORE the workgroup barrier of the partial sum -- thread 0 publishes the block: its squared-norm
+// partials as self-validating words and its flag.
+template <bool CSORT, bool HALO, bool FUSED>
+__device__ __forceinline__ void atl_product(const CsrView& A, const double* __restrict__ x, const double* yin, double* yout,
+                                            double* partials, int pstride, const int (&Lt)[2], int nt, const RideArgs& ra,
+                                            const HaloRows& hr, const FuseArgs& fz, double* prod, unsigned long long* crec,
+                                            int* okfp) {
+  constexpr int NL = 2;
+  double* red = prod;
+  const int tid = threadIdx.x;
+#define okf (*okfp)
   // Wave 0 looks for the leaders' record at every point where a wait is free anyway: behind the stream (examined behind
   // the gathers), behind the gathers, behind the products, behind the row sums.  Device-scope loads come back later than
   // ordinary ones and the load counter is in-order, so each look is requested BEHIND the loads whose arrival the next
@@ -678,14 +693,32 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
           for (int l = 0; l < NL; ++l)
             if (C.act[l]) dst[l] = hacc[t][p][l];
         } else {
-          row_epilogue<NL, true>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
+          row_epilogue<NL, FUSED>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
         }
       }
     }
-#if defined(FPSQ_WHATIF_FENCE) && (FPSQ_WHATIF_FENCE & 1)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (what-if: the cost of publishing a block's rows to the other XCDs)
-#endif
-    if (partials != nullptr) {
+    if constexpr (FUSED) {
+      // block_sum_lanes with the store acknowledgements waited for in front of its barrier: behind it every row of the block
+      // is at its coherence point, and what thread 0 issues next may tell other XCDs so
+      if (t) lds_barrier();
+#pragma unroll
+      for (int l = 0; l < NL; ++l) sq[l] = wave_sum(sq[l]);
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) red[(tid >> 6) * NL + l] = sq[l];
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid == 0) {
+        unsigned long long* pt = fz.ptag + (size_t)Lt[t] * 4;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          const double v = (red[l] + red[NL + l]) + (red[2 * NL + l] + red[3 * NL + l]);
+          ride_store(pt + 2 * l, tag_hi(v, fz.want));
+          ride_store(pt + 2 * l + 1, tag_lo(v, fz.want));
+        }
+        __hip_atomic_store(fz.blkflag + Lt[t], fz.want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (partials != nullptr) {
       if (t) lds_barrier();  // (thread 0 has read `red` for the previous block)
       block_sum_lanes<NL>(sq, red);
       if (tid == 0) {
@@ -694,6 +727,33 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
       }
     }
   }
+#undef okf
+}
+
+template <bool CSORT, bool HALO = false>
+__global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __restrict__ x, const double* yin, double* yout,
+                                                     double* partials, int nwg, int n2, const UpdSeg u0, const UpdSeg u1,
+                                                     int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra,
+                                                     const HaloRows hr, int bpx) {
+  constexpr int NL = 2;
+  __shared__ double prod[kSpmvNnz * NL];
+  __shared__ __attribute__((aligned(16))) unsigned long long fst[2 * 80];
+  __shared__ double fred[32];
+  __shared__ unsigned long long crec[10];
+  __shared__ int okf;
+  if (blockIdx.x < kRideCand) {
+    ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
+    return;
+  }
+  const int b = (int)blockIdx.x - kRideCand;
+  if (b >= nwg) {  // a riding-update workgroup (dispatched last: the record is up long before)
+    if (ride_settle<true>(ra, fst, &okf))
+      run_fused_updates<NL>(u0, u1, nwg + kRideCand, prod, reinterpret_cast<const LaneCtl*>(fst), reinterpret_cast<const LaneCtl*>(fst + 80));
+    return;
+  }
+  int Lt[2], nt;
+  if (!atl_blocks_of(b, n2, bpx, A.nblk, Lt, nt)) return;
+  atl_product<CSORT, HALO, false>(A, x, yin, yout, partials, pstride, Lt, nt, ra, hr, FuseArgs{}, prod, crec, &okf);
 }
 
 // ------------------------------------------------------------------------------------------------ RGCS product
@@ -742,41 +802,15 @@ struct RgcsView {
   int32_t stride;         // padded layout: group g's entries start at g * stride (0: compact, start = grp[g].e0)
 };
 
-// PAD: the groups' entries are stored at a fixed stride and zero-padded to whole tiles, so the first tile's stream
-// does not wait for the group descriptor and no load needs a bounds check.
-// LEAD: the launch's first kRideCand workgroups are the candidates for leading the riding steps (see "steps riding with leaders" above); the
-// groups and the riding updates follow, the coefficients are picked up between the tiles.
-template <int NL, bool PAD = false, bool LEAD = false>
-__global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
-                                                      double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
-                                                      double* partials, int grp_per_xcd, const UpdSeg u0,
-                                                      const UpdSeg u1, const LaneCtl* gate0, const LaneCtl* gate1,
-                                                      int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra) {
-  __shared__ double prod[kRgcsTile * NL];
+// One row group of the A product (see above).  LEAD: coefficients from the leaders' record `ra`; FUSED (k_iter_fused, implies
+// LEAD): the group first waits for the A' blocks of the same launch that own what it gathers, and gathers at agent scope.
+template <int NL, bool PAD, bool LEAD, bool FUSED>
+__device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __restrict__ x, const double* yin, double* yout,
+                                           const LaneCtl* ctl0, const LaneCtl* ctl1, double* partials, int pstride, int g,
+                                           const RideArgs& ra, const FuseArgs& fz, double* prod, unsigned long long* crec,
+                                           int* okf) {
   double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
-  static_assert(!LEAD || NL == 2, "riding leaders: two lanes");
-  [[maybe_unused]] unsigned long long* fst = nullptr;
-  [[maybe_unused]] double* fred = nullptr;
-  [[maybe_unused]] unsigned long long* crec = nullptr;
-  [[maybe_unused]] int* okf = nullptr;
-  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
-  if constexpr (LEAD) {
-    __shared__ __attribute__((aligned(16))) unsigned long long fst_[2 * 80];
-    __shared__ double fred_[32];
-    __shared__ unsigned long long crec_[10];
-    __shared__ int okf_;
-    fst = fst_;
-    fred = fred_;
-    crec = crec_;
-    okf = &okf_;
-    if (blockIdx.x < kRideCand) {
-      ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
-      return;
-    }
-  }
-  const int bid = LEAD ? (int)blockIdx.x - kRideCand : (int)blockIdx.x;
-  // (XCD-contiguous eighths: essential here -- with the identity map the product takes 43 us instead of 29 us)
-  const int g = (bid & 7) * grp_per_xcd + (bid >> 3);
+  if (g >= M.ng) return;
   constexpr int kPer = kRgcsTile / kBlock;
   const int tid = threadIdx.x;
   uint32_t pk[kPer];
@@ -791,25 +825,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
       v[k] = M.vals[ii];
     }
   };
+  if (PAD) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
   [[maybe_unused]] unsigned long long look = 0;
-  if constexpr (LEAD) {
-    if (bid >= 8 * grp_per_xcd) {  // a riding-update workgroup
-      if (ride_settle<true>(ra, fst, okf))
-        run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd + kRideCand, red, reinterpret_cast<const LaneCtl*>(fst),
-                              reinterpret_cast<const LaneCtl*>(fst + 80));
-      return;
-    }
-    if (g >= M.ng) return;
-    if (PAD) fetch_stream(g * M.stride, 0, 0);
-  } else {
-    if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, red)) return;
-  }
-  if (g >= M.ng) return;
-  if (PAD && !LEAD) fetch_stream(g * M.stride, 0, 0);  // ahead of the descriptor
   const RgcsGroup gd = M.grp[g];  // before the dependent done-check: one round trip at the head, not two
-#if defined(FPSQ_WHATIF_FENCE) && (FPSQ_WHATIF_FENCE & 2)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (what-if: the cost of an acquire per row group)
-#endif
   double ca[NL], cb[NL];
   bool act[NL];
   [[maybe_unused]] bool ride_ok = false;  // (wave 0's)
@@ -852,6 +870,27 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
   };
   if (PAD) fetch_segs(0);
   else fetch(e0, 0);
+  if constexpr (FUSED) {
+    // the A' blocks that own the lines this group gathers from: wave 0 looks at their flags (agent-scope loads, requested
+    // behind the first tile's stream, which does not depend on them), a bounded number of times
+    if (tid < 64) {
+      const int2 d = fz.dep[g];
+      bool all = false;
+      for (int t = 0; t < kRidePolls && !all; ++t) {
+        if (t) __builtin_amdgcn_s_sleep(8);
+        bool ok = true;
+        for (int L = d.x + tid; L <= d.y; L += 64)
+          ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
+        all = __all(ok);
+      }
+      if (tid == 0) {
+        *okf = all ? 1 : 0;
+        if (!all) __hip_atomic_store(fz.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    lds_barrier();
+    if (!*okf) return;  // (workgroup-uniform: a block never came -- the call fails with FPSQ_ERR_TIMEOUT)
+  }
   if constexpr (LEAD) {  // first look (wave 0): requested BEHIND the first tile's stream (device-scope loads return late, in order)
     if (tid < 64) look = ride_look(ra);
   }
@@ -870,16 +909,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
         vq[k] = ok ? v[k] : 0.0;
         const int col = cmin + (int)(pq[k] & ((1u << kRgcsColBits) - 1));
         if (NL == 1) xv[k].x = x[col];
-#if defined(FPSQ_WHATIF_FENCE) && (FPSQ_WHATIF_FENCE & 8)
-        else {  // (what-if: agent-scope gathers)
-          typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7fffffff, 0x00027000);
-          const u32x4_ w = __builtin_amdgcn_raw_buffer_load_b128(rs, col * 16, 0, 16);
-          __builtin_memcpy(&xv[k], &w, 16);
-        }
-#else
+        else if (FUSED) xv[k] = ld_pair_ag(x, col);  // (agent scope: rows another XCD has just written through)
         else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)col * 2);
-#endif
       }
 #pragma unroll
       for (int p = 0; p < kRgcsMaxPass; ++p) {
@@ -941,6 +972,238 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
 #pragma unroll
       for (int l = 0; l < NL; ++l) partials[(size_t)l * pstride + g] = sq[l];
     }
+  }
+}
+
+// PAD: the groups' entries are stored at a fixed stride and zero-padded to whole tiles, so the first tile's stream
+// does not wait for the group descriptor and no load needs a bounds check.
+// LEAD: the launch's first kRideCand workgroups are the candidates for leading the riding steps (see "steps riding with leaders" above); the
+// groups and the riding updates follow, the coefficients are picked up between the tiles.
+template <int NL, bool PAD = false, bool LEAD = false>
+__global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
+                                                      double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
+                                                      double* partials, int grp_per_xcd, const UpdSeg u0,
+                                                      const UpdSeg u1, const LaneCtl* gate0, const LaneCtl* gate1,
+                                                      int pstride, const StepArgs s0, const StepArgs s1, const RideArgs ra) {
+  __shared__ double prod[kRgcsTile * NL];
+  static_assert(!LEAD || NL == 2, "riding leaders: two lanes");
+  [[maybe_unused]] unsigned long long* fst = nullptr;
+  [[maybe_unused]] double* fred = nullptr;
+  [[maybe_unused]] unsigned long long* crec = nullptr;
+  [[maybe_unused]] int* okf = nullptr;
+  if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
+  if constexpr (LEAD) {
+    __shared__ __attribute__((aligned(16))) unsigned long long fst_[2 * 80];
+    __shared__ double fred_[32];
+    __shared__ unsigned long long crec_[10];
+    __shared__ int okf_;
+    fst = fst_;
+    fred = fred_;
+    crec = crec_;
+    okf = &okf_;
+    if (blockIdx.x < kRideCand) {
+      ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
+      return;
+    }
+  }
+  const int bid = LEAD ? (int)blockIdx.x - kRideCand : (int)blockIdx.x;
+  // (XCD-contiguous eighths: essential here -- with the identity map the product takes 43 us instead of 29 us)
+  const int g = (bid & 7) * grp_per_xcd + (bid >> 3);
+  if constexpr (LEAD) {
+    if (bid >= 8 * grp_per_xcd) {  // a riding-update workgroup
+      if (ride_settle<true>(ra, fst, okf))
+        run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd + kRideCand, prod, reinterpret_cast<const LaneCtl*>(fst),
+                              reinterpret_cast<const LaneCtl*>(fst + 80));
+      return;
+    }
+  } else {
+    if (run_fused_updates<NL>(u0, u1, 8 * grp_per_xcd, prod)) return;
+  }
+  rgcs_group<NL, PAD, LEAD, false>(M, x, yin, yout, ctl0, ctl1, partials, pstride, g, ra, FuseArgs{}, prod, crec, okf);
+}
+
+// ------------------------------------------------------------------------------------------------ one iteration, one launch
+//
+// k_iter_fused: the A' product and the A product of a joint iteration in ONE grid.  Two launches per iteration end twice with a
+// resident set of workgroups draining while nothing new may start, and begin twice with ~3 us until the first streams have
+// landed (profiles/r03_at_phase_probe.txt).  The dependence across the first of the two boundaries is local: a row group of A
+// gathers the long pair on its column window only -- the output of ~40 row blocks of A' -- and needs the scalars behind the
+// A' product (the global norm) only in its row epilogue.  Here the row groups follow the A' blocks in the same grid and start as
+// the blocks drain:
+//
+//   [ 16 head leaders | A' product workgroups | 16 mid leaders | updates riding with A' | row groups of A | updates riding with A ]
+//
+//   * head leaders: the steps behind the PREVIOUS A product, as in k_spmv_atl (record `ra`);
+//   * A' workgroups: atl_product<.., FUSED>: rows written through, then flag + tagged partials per block;
+//   * mid leaders (leader c: lane (c >> 3) & 1, one per lane on every XCD like the head leaders): the head step AGAIN (same
+//     inputs, same bits -- so the state it leaves never travels between workgroups inside the launch), then the step behind the
+//     A' product from that state in LDS and the blocks' tagged partials (bounded looks until every word is this launch's), published in the second record `rb`; leaders 0 and 8 commit it to a THIRD copy of the state (a head
+//     leader held up by another kernel may still be reading the first);
+//   * row groups: rgcs_group<.., FUSED>: wait for the flags of the blocks owning their lines, gather at agent scope, coefficients
+//     from `rb`; their updates likewise.
+// No fence anywhere (an agent-scope release or acquire costs an L2 write-back / invalidate per workgroup: 5-7 x slower,
+// profiles/r04_coherence_whatif.txt).  What it rests on instead: (1) a store with the agent-scope bit is written through, and
+// vmcnt counts it only when it is at its coherence point; (2) nobody reads a line of the long pair before the block that owns it
+// -- blocks start on 128-byte boundaries (make_rowblocks, align = 8 rows) and a group waits for every block owning a line it
+// touches -- is complete, so no XCD's L2 can hold an earlier version; (3) self-validating words wherever a value travels
+// without an ordering guarantee (records, partials).  Every wait is bounded and ends in the handle's error word.
+// Dependences point to workgroups earlier in the grid.  Results: BITWISE the two-launch iteration (same per-block and per-group
+// arithmetic, the partials summed in the same order by the same step code).
+
+// squared-norm partials of lane l of the A' blocks [0, n) from their tagged words, summed like reduce_two sums a plain array
+// (same association per thread, same tree); false: a word did not carry this launch's number after kRidePolls looks
+__device__ __forceinline__ bool reduce_tagged(const unsigned long long* ptag, int n, int l, unsigned int want, double* red,
+                                              int* flag, double& s0) {
+  const int t = threadIdx.x;
+  auto part = [&](int i, bool& good) {
+    const unsigned long long hi = ride_load(ptag + (size_t)i * 4 + 2 * l), lo = ride_load(ptag + (size_t)i * 4 + 2 * l + 1);
+    good = good && (unsigned int)(hi & 0xffffffffull) == want && (unsigned int)(lo & 0xffffffffull) == want;
+    return __longlong_as_double((long long)((hi & 0xffffffff00000000ull) | (lo >> 32)));
+  };
+  double a = 0.0;
+  for (int look = 0; look < kRidePolls; ++look) {
+    bool good = true;
+    a = 0.0;
+    if (n <= kStepThreads * 24) {  // reduce_two's single batch: a thread adds its entries t, t + 256, ... in that order
+      for (int base = 0; base < n; base += kStepThreads * 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * kStepThreads + t;
+          const double w = part(i < n ? i : n - 1, good);
+          v[u] = i < n ? w : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+    } else {  // ... its batches of eight, each summed from zero
+      for (int base = 0; base < n; base += kStepThreads * 8) {
+        double v[8], b = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * kStepThreads + t;
+          const double w = part(i < n ? i : n - 1, good);
+          v[u] = i < n ? w : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b += v[u];
+        a += b;
+      }
+    }
+    if (t == 0) *flag = 0;
+    __syncthreads();
+    if (!good) *flag = 1;
+    __syncthreads();
+    const bool again = *flag != 0;
+    __syncthreads();
+    if (!again) {
+      double dummy = 0.0, s1 = 0.0;
+      block_reduce_two(a, dummy, red, s0, s1);
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return false;
+}
+
+// mid leader c (see above)
+__device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepArgs& sm, int c, const RideArgs& rb, const FuseArgs& fz,
+                                                double* red32, unsigned long long* st80, int* flag) {
+  const int l = (c >> 3) & 1;
+  // 1. the state the head step leaves, recomputed (no side effects)
+  if (sh.kind != STEP_NONE) {
+    step_run(sh, red32, st80, /*commit=*/false);
+  } else {
+    const int nq = state_bytes(sm.kind) / 8;
+    if ((int)threadIdx.x < nq) st80[threadIdx.x] = reinterpret_cast<const unsigned long long*>(sh.state)[threadIdx.x];
+    __syncthreads();
+  }
+  // 2. + 3. the step behind the A' product, from the state in LDS and the blocks' tagged partials: looking at them until every
+  // word carries this launch's number IS the wait for the blocks (a shared counter of completed blocks was built first: five
+  // thousand agent-scope atomics on one address took the launch from ~60 to 106 us)
+  unsigned long long* rec = rb.rec + 64 * ride_xcc();
+  const bool skip = reinterpret_cast<const LaneCtl*>(st80)->done != 0;  // (uniform: LDS)
+  double s0 = 0.0;
+  bool fine = true;
+  if (!skip) fine = reduce_tagged(fz.ptag, sm.n0, l, fz.want, red32, flag, s0);
+  if (!fine) {
+    if (threadIdx.x == 0) __hip_atomic_store(fz.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;  // (nothing published: whoever waits for this record runs into its own bound)
+  }
+  const bool commit = (c & 7) == 0;
+  if (threadIdx.x == 0) {
+    if (!skip) step_advance(sm, st80, s0, 0.0, commit ? sm.prog : nullptr);
+    ride_publish(reinterpret_cast<const LaneCtl*>(st80 + sm.prod_ctl_off), l, rec, rb.pub);
+    if (commit && !skip) step_final_stats(sm, st80);
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const unsigned long long w = st80[threadIdx.x];
+    ride_store(rec + 16 + 24 * l + 2 * threadIdx.x, (w & 0xffffffff00000000ull) | rb.pub);
+    ride_store(rec + 16 + 24 * l + 2 * threadIdx.x + 1, (w << 32) | rb.pub);
+  }
+  if (commit) {
+    const int nq = state_bytes(sm.kind) / 8;
+    unsigned long long* gdst = reinterpret_cast<unsigned long long*>(sm.state_out);
+    if ((int)threadIdx.x < nq) gdst[threadIdx.x] = st80[threadIdx.x];
+  }
+}
+
+struct FuseGrid {
+  int32_t nwg_t, n2, bpx;  // A' product workgroups (a multiple of 8), of which the first n2 take two blocks; blocks per XCD
+  int32_t nupd_t;          // update workgroups riding with A' (padded to a multiple of 8)
+  int32_t gpx;             // row groups per XCD
+};
+
+__global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, const double* sp_in, double* lp, double* sp_out,
+                                                       double* part_a, int pstride_a, const FuseGrid fg, const UpdSeg ut0,
+                                                       const UpdSeg ut1, const UpdSeg ua0, const UpdSeg ua1, const StepArgs sh0,
+                                                       const StepArgs sh1, const StepArgs sm0, const StepArgs sm1,
+                                                       const RideArgs ra, const RideArgs rb, const FuseArgs fz) {
+  constexpr int NL = 2;
+  __shared__ double prod[kSpmvNnz * NL];
+  static_assert(kSpmvNnz == kRgcsTile, "one product buffer serves both products");
+  __shared__ __attribute__((aligned(16))) unsigned long long fst[2 * 80];
+  __shared__ double fred[32];
+  __shared__ unsigned long long crec[10];
+  __shared__ int okf;
+  int b = (int)blockIdx.x;
+  if (b < kRideCand) {
+    ride_leader((b >> 3) & 1 ? sh1 : sh0, b, ra, fred, fst);
+    return;
+  }
+  b -= kRideCand;
+  if (b < fg.nwg_t) {
+    int Lt[2], nt;
+    if (!atl_blocks_of(b, fg.n2, fg.bpx, AT.nblk, Lt, nt)) return;
+    atl_product<true, false, true>(AT, sp_in, lp, lp, nullptr, 0, Lt, nt, ra, HaloRows{}, fz, prod, crec, &okf);
+    return;
+  }
+  b -= fg.nwg_t;
+  if (b < kRideCand) {
+    fuse_mid_leader((b >> 3) & 1 ? sh1 : sh0, (b >> 3) & 1 ? sm1 : sm0, b, rb, fz, fred, fst, &okf);
+    return;
+  }
+  b -= kRideCand;
+  if (b < fg.nupd_t) {
+    if (b >= ut0.nblk + ut1.nblk) return;  // (padding)
+    if (ride_settle<true>(ra, fst, &okf)) {
+      const UpdSeg& u = b < ut0.nblk ? ut0 : ut1;
+      upd_run<NL>(u, b < ut0.nblk ? b : b - ut0.nblk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
+    }
+    return;
+  }
+  b -= fg.nupd_t;
+  if (b < 8 * fg.gpx) {
+    const int g = (b & 7) * fg.gpx + (b >> 3);
+    rgcs_group<NL, true, true, true>(RA, lp, sp_in, sp_out, nullptr, nullptr, part_a, pstride_a, g, rb, fz, prod, crec, &okf);
+    return;
+  }
+  b -= 8 * fg.gpx;
+  if (b >= ua0.nblk + ua1.nblk) return;
+  if (ride_settle<true>(rb, fst, &okf)) {
+    const UpdSeg& u = b < ua0.nblk ? ua0 : ua1;
+    upd_run<NL>(u, b < ua0.nblk ? b : b - ua0.nblk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
   }
 }
 

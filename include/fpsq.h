@@ -377,6 +377,8 @@ typedef struct {
   int64_t at_sorted;       /* 1: the row blocks of A' are stored column-sorted (coalesced gathers, see k_spmv<.., CSORT>) */
   int64_t comm_route;      /* 0: single GPU; else FPSQ_ROUTE_RCCL / _P2P (decided at the first solve of a halo-sharded handle)
                               / _LOCAL / _LOCAL_P2P (in-process groups) */
+  int64_t last_fused_launches; /* of the launches counted in last_prod_a[1] AND last_prod_at[1]: those that carried both products of a
+                                  joint iteration in one grid (k_iter_fused; FPSQ_FUSE_ITER=0 disables) */
 } fpsq_info;
 int fpsq_get_info(fpsq_handle h, fpsq_info *info);
 /* on != 0: bracket every SpMV/SpMM launch with HIP events on the solver's stream so that last_spmv_ms is filled

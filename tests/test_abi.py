@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Stats) == 32
     assert C.sizeof(_lib.Options) == 8 * 17 + 24  # + ln_method, kkt_method
     assert _lib.Options.ln_method.offset == 8 * 17 + 16 and _lib.Options.kkt_method.offset == 8 * 17 + 20
-    assert C.sizeof(_lib.Info) == 72 + 32 + 8 + 8  # + at_sorted (round 3), comm_route (round 4), appended
+    assert C.sizeof(_lib.Info) == 72 + 32 + 8 + 8 + 8  # + at_sorted (round 3), comm_route, last_fused_launches (round 4), appended
 
 
 def test_default_options_follow_reference_defaults():

@@ -1267,6 +1267,47 @@ def test_a_late_leader_changes_nothing(monkeypatch, late):
         assert np.array_equal(a_, b_), i
 
 
+@pytest.mark.parametrize("size", [(6000, 600), (60000, 6000), (300000, 30000)])
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_one_launch_iterations_are_bitwise_the_two_launch_iterations(monkeypatch, delta, size):
+    """A joint iteration of two riding recurrences is ONE launch (k_iter_fused): the row groups of the A product follow the
+    A' blocks in the same grid and start when the blocks owning what they gather have published themselves (written-through
+    rows, per-block flags, agent-scope gathers), the steps behind the A' product are computed by a second set of leaders from
+    tagged partials.  Same per-block and per-group arithmetic, the same sums in the same order: every output and statistic
+    of objgrad, hprod Val(2) and the seam solves must be BITWISE those of a handle that launches the two products separately
+    on the same layout (FPSQ_FUSE_ITER=0 with the A' blocks aligned to 8 rows all the same), over changing points -- the
+    second and later calls also exercise the run-ahead, the speculative epilogue and launches past convergence."""
+    qp = _small_pde(seed=17, n=size[0], m=size[1])
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(8)
+    xs = [qp.xhat + 0.3 * 0.6 ** k * rng.standard_normal(qp.n) for k in range(5)]
+    vs = [rng.standard_normal(qp.n) for _ in range(5)]
+
+    def run(expect_fused):
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+        out, fused = [], 0
+        for k, x in enumerate(xs):
+            gx, ys, gs, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.n)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys, gs=gs)
+            fused += dev.info()["last_fused_launches"]
+            st = [(dev.stats[i].niter, dev.stats[i].status, dev.stats[i].rnorm, dev.stats[i].arnorm) for i in range(2)]
+            rch = dev.hprod(vs[k], hv, 2)
+            o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+            rcm = dev.solve_two_mixed(qp.qdiag * x + qp.d, A @ x - qp.b, *o)
+            out += [np.array([f, rc, rch, rcm]), gx, ys, gs, hv, *o, np.array(st).ravel()]
+        dev.close()
+        assert (fused > 0) == expect_fused, fused
+        return out
+
+    monkeypatch.setenv("FPSQ_AT_ROW_ALIGN", "8")
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "0")
+    want = run(False)
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "1")
+    got = run(True)
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+
+
 def test_riding_leaders_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
     """Every wait of the leader protocol has an end each wave reaches: with the leaders made to publish a wrong launch number
     (FPSQ_DEBUG_RIDE_BREAK=1) the workgroups of the product give up after their bounded number of looks, raise the handle's
