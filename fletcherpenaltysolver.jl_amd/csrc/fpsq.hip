@@ -654,13 +654,20 @@ struct fpsq_solver_s {
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   // one launch per joint iteration (k_iter_fused; FPSQ_FUSE_ITER=0: two launches)
-  bool fuse_iter = true, fuse_ok = false;
+  int fuse_iter = 1;            // 0: never; 1: where it pays (setup_fused_iteration); 2: wherever it is possible (tests)
+  bool fuse_ok = false;
   int2* fz_dep = nullptr;                 // per row group: the A' blocks it waits for
   unsigned int* fz_flag = nullptr;        // per A' block: launch number of its last completion
   unsigned long long* fz_ptag = nullptr;  // per A' block: four tagged words (its squared-norm partials)
   unsigned long long* ride_rec2 = nullptr;  // the mid leaders' record
   void* state3[3] = {nullptr, nullptr, nullptr};  // third copies of the LSQR (x 2) / CRAIG / LNLQ states: lsqr, craig, lnlq
-  int64_t fused_launches = 0;
+  int64_t fused_launches = 0, fused_total = 0;
+  // developer probe (FPSQ_FUSE_PROBE=<file>, FPSQ_FUSE_PROBE_AT=<n-th fused launch of the handle>): per-workgroup time stamps of one launch
+  int64_t fuse_probe_at = 0;
+  unsigned long long* fuse_probe_buf = nullptr;
+  int fuse_probe_grid = 0;
+  std::vector<int> fuse_probe_layout;
+  std::string fuse_probe_path;
   bool at_xcd = true;           // k_spmv_atl: every XCD walks a contiguous eighth of the row blocks (FPSQ_AT_XCD=0: grid order)
   MinresState* minres;
   LnlqState* lnlq;
@@ -1326,7 +1333,8 @@ int alloc_workspaces(fpsq_handle h) {
 // byte offsets into the long pair, and per row group the range of A' blocks that own the lines it gathers from.
 int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<int2>& col_range) {
   h->fuse_ok = false;
-  if (!h->fuse_iter || h->comm || !h->RA.ok || h->RA.view.stride == 0 || !h->AT.sorted || !h->AT.padded || h->AT.nblk < 1) return 0;
+  if (!h->fuse_iter || h->comm || !h->RA.ok || h->RA.view.stride == 0 || !h->AT.padded || !(h->AT.sorted || h->AT.col16) || h->AT.nblk < 1)
+    return 0;
   if ((int64_t)h->n * 16 >= (int64_t)INT32_MAX || (int64_t)h->m * 16 >= (int64_t)INT32_MAX) return 0;
   if ((int)col_range.size() != h->RA.view.ng) return 0;
   const std::vector<int32_t> rb = make_rowblocks(HT.rowptr, HT.nrows, h->AT.row_align);
@@ -1337,6 +1345,16 @@ int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<in
     const int b0 = (int)(std::upper_bound(rb.begin(), rb.end(), (int32_t)lo) - rb.begin()) - 1;
     const int b1 = (int)(std::upper_bound(rb.begin(), rb.end(), (int32_t)hi) - rb.begin()) - 1;
     dep[g] = make_int2(std::max(b0, 0), std::min(std::max(b1, 0), h->AT.nblk - 1));
+  }
+  if (h->fuse_iter == 1) {
+    // Where it pays (measured): a grid of several resident sets -- the row groups then enter as the last A'
+    // blocks drain and find most of what they wait for done -- whose row groups depend on a small part of the A' blocks.
+    // A grid that is resident at once gains nothing from sharing a launch and pays for the flags (cfg2, random columns: every
+    // group waits for every block; 2500 -> 2230 evals/s).
+    double width = 0.0;
+    for (const int2& d : dep) width += d.y - d.x + 1;
+    width /= (double)std::max<size_t>(dep.size(), 1);
+    if (h->AT.nblk < 2 * h->resident_wgs || width > h->AT.nblk / 8.0) return 0;
   }
   dfree(h, &h->fz_dep);
   dfree(h, &h->fz_flag);
@@ -2624,8 +2642,21 @@ struct KrylovRun {
     fz.want = ra.want;
     fz.err = ra.err;
     const dim3 grid(kRideCand + fg.nwg_t + kRideCand + fg.nupd_t + 8 * fg.gpx + cu[0].nblk + cu[1].nblk);
-    launch_product(h, k_iter_fused, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, h->pS2, h->strA, fg, lu[0], lu[1],
-                   cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
+    if (h->fuse_probe_at > 0 && h->fused_total + 1 == h->fuse_probe_at) {  // developer probe: this launch leaves time stamps
+      h->fuse_probe_grid = (int)grid.x;
+      h->fuse_probe_layout = {kRideCand, fg.nwg_t, kRideCand, 8 * fg.gpx, fg.nupd_t, cu[0].nblk + cu[1].nblk};
+      if (dalloc(h, &h->fuse_probe_buf, (size_t)grid.x * 4) == 0) {
+        hipMemsetAsync(h->fuse_probe_buf, 0, (size_t)grid.x * 32, h->stream);
+        fz.dbg = h->fuse_probe_buf;
+      }
+    }
+    h->fused_total++;
+    if (h->AT.sorted)
+      launch_product(h, k_iter_fused<true>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, h->pS2, h->strA, fg, lu[0],
+                     lu[1], cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
+    else
+      launch_product(h, k_iter_fused<false>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, h->pS2, h->strA, fg, lu[0],
+                     lu[1], cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
     h->launches++;
     h->spmv_launches++;
     h->prod_a[1]++;
@@ -3276,7 +3307,12 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_RIDE_LEAD")) h->ride_lead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_AT_XCD")) h->at_xcd = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_FUSE_PROBE")) {
+    h->fuse_probe_path = ev;
+    h->fuse_probe_at = 100;
+    if (const char* at = std::getenv("FPSQ_FUSE_PROBE_AT")) h->fuse_probe_at = std::atoll(at);
+  }
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY")) h->ride_delay = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_JAC_REFRESH")) h->refresh_3pass = std::atoi(ev) == 3;
@@ -3374,6 +3410,18 @@ int fpsq_destroy(fpsq_handle h) {
   }
   hipSetDevice(h->opt.device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->fuse_probe_buf && !h->fuse_probe_path.empty()) {  // developer probe: "grid n0 n1 .. n5" then one line of four stamps per workgroup
+    std::vector<unsigned long long> st((size_t)h->fuse_probe_grid * 4);
+    hipMemcpy(st.data(), h->fuse_probe_buf, st.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = std::fopen(h->fuse_probe_path.c_str(), "w")) {
+      std::fprintf(f, "%d", h->fuse_probe_grid);
+      for (int v : h->fuse_probe_layout) std::fprintf(f, " %d", v);
+      std::fprintf(f, "\n");
+      for (int i = 0; i < h->fuse_probe_grid; ++i)
+        std::fprintf(f, "%llu %llu %llu %llu\n", st[4 * (size_t)i], st[4 * (size_t)i + 1], st[4 * (size_t)i + 2], st[4 * (size_t)i + 3]);
+      std::fclose(f);
+    }
+  }
   delete h->comm;
   for (void* p : h->allocs) hipFree(p);
   for (auto& e : h->ev_pool) {

@@ -441,7 +441,11 @@ struct RideHook {
   int off;                  // StepArgs::prod_ctl_off
   __device__ void advanced() const { ride_publish(reinterpret_cast<const LaneCtl*>(st80 + off), l, rec, ra->pub); }
 };
-__device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const RideArgs& ra, double* red32, unsigned long long* st80) {
+// may_commit = false (the head leaders of a fused launch): nobody here performs the step's side effects -- the mid leaders,
+// which redo the step anyway, do, so that the progress words of the launch's two steps reach the host in order whichever
+// leader is late.
+__device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const RideArgs& ra, double* red32, unsigned long long* st80,
+                                            bool may_commit = true) {
   const int l = (c >> 3) & 1;
   if (ra.delay != 0 && c == ra.delay - 1) {
     const unsigned long long t0 = wall_clock64();  // (100 MHz)
@@ -450,7 +454,7 @@ __device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const Ride
   unsigned long long* rec = ra.rec + 64 * ride_xcc();
   const RideHook hook{&ra, st80, rec, l, a.prod_ctl_off};
   if (a.kind != STEP_NONE) {
-    step_run(a, red32, st80, /*commit=*/(c & 7) == 0, &hook);
+    step_run(a, red32, st80, /*commit=*/may_commit && (c & 7) == 0, &hook);
   } else {
     if (threadIdx.x < 12) st80[threadIdx.x] = reinterpret_cast<const unsigned long long*>(a.state)[threadIdx.x];
     __syncthreads();
@@ -499,13 +503,13 @@ constexpr int kRidePolls = 1 << 15;
 
 // A workgroup whose looks have all failed by the time it needs the coefficients (every thread calls this; workgroup barriers
 // inside): wave 0 keeps looking (CTL: for the whole control blocks, an update workgroup).  Returns false when the bound expired.
-template <bool CTL>
+template <bool CTL, int SLEEP = 4>
 __device__ __forceinline__ bool ride_settle(const RideArgs& ra, unsigned long long* dst, int* got) {
   if (threadIdx.x == 0) *got = 0;
   __syncthreads();
   for (int t = 0; t < kRidePolls; ++t) {
     if (threadIdx.x < 64) {
-      if (t) __builtin_amdgcn_s_sleep(4);
+      if (t) __builtin_amdgcn_s_sleep(SLEEP);
       const bool ok = CTL ? ride_take_ctl(ra, dst) : ride_take(ra, ride_look(ra), dst);
       if (ok && threadIdx.x == 0) *got = 1;
     }
@@ -556,7 +560,13 @@ struct FuseArgs {
   unsigned int want;              // this launch's number
   unsigned int pad_;
   unsigned long long* err;        // host-mapped: a bounded wait expired
+  unsigned long long* dbg;        // developer probe (null in production): four 100 MHz time stamps per workgroup of the launch, see fuse_stamp
 };
+// workgroup's stamp k (thread 0; tools/fuse_probe.py reads them): 0 = entry, 1 = dependences met (row group) / record taken (update),
+// 2 = tiles done (row group) / partials summed (mid leader), 3 = exit
+__device__ __forceinline__ void fuse_stamp(const FuseArgs& fz, int k) {
+  if (fz.dbg != nullptr && threadIdx.x == 0) fz.dbg[(size_t)blockIdx.x * 4 + k] = wall_clock64();
+}
 __device__ __forceinline__ unsigned long long tag_hi(double v, unsigned int want) {
   return ((unsigned long long)__double_as_longlong(v) & 0xffffffff00000000ull) | want;
 }
@@ -890,6 +900,7 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
     }
     lds_barrier();
     if (!*okf) return;  // (workgroup-uniform: a block never came -- the call fails with FPSQ_ERR_TIMEOUT)
+    fuse_stamp(fz, 1);
   }
   if constexpr (LEAD) {  // first look (wave 0): requested BEHIND the first tile's stream (device-scope loads return late, in order)
     if (tid < 64) look = ride_look(ra);
@@ -938,6 +949,7 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
     for (int p = 0; p < kRgcsMaxPass; ++p) row_segment_sum<NL>(prod, sa[p] + gl, sb[p], G, acc[p]);
     lds_barrier();
   }
+  if constexpr (FUSED) fuse_stamp(fz, 2);
   if constexpr (LEAD) {
     if (tid < 64) {
       if (!ride_ok) ride_ok = ride_take(ra, look, crec);
@@ -1031,9 +1043,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
 // A' product (the global norm) only in its row epilogue.  Here the row groups follow the A' blocks in the same grid and start as
 // the blocks drain:
 //
-//   [ 16 head leaders | A' product workgroups | 16 mid leaders | updates riding with A' | row groups of A | updates riding with A ]
+//   [ 16 head leaders | A' product workgroups | 16 mid leaders | row groups of A | updates riding with A' | updates riding with A ]
 //
-//   * head leaders: the steps behind the PREVIOUS A product, as in k_spmv_atl (record `ra`);
+//   * head leaders: the steps behind the PREVIOUS A product, as in k_spmv_atl (record `ra`), but without side effects;
 //   * A' workgroups: atl_product<.., FUSED>: rows written through, then flag + tagged partials per block;
 //   * mid leaders (leader c: lane (c >> 3) & 1, one per lane on every XCD like the head leaders): the head step AGAIN (same
 //     inputs, same bits -- so the state it leaves never travels between workgroups inside the launch), then the step behind the
@@ -1110,9 +1122,11 @@ __device__ __forceinline__ bool reduce_tagged(const unsigned long long* ptag, in
 __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepArgs& sm, int c, const RideArgs& rb, const FuseArgs& fz,
                                                 double* red32, unsigned long long* st80, int* flag) {
   const int l = (c >> 3) & 1;
-  // 1. the state the head step leaves, recomputed (no side effects)
+  const bool commit = (c & 7) == 0;
+  // 1. the state the head step leaves, recomputed; leaders 0 and 8 perform its side effects (progress word, final statistics,
+  // the second copy of the state) -- here, ahead of the next step's, and not in the head leaders
   if (sh.kind != STEP_NONE) {
-    step_run(sh, red32, st80, /*commit=*/false);
+    step_run(sh, red32, st80, commit);
   } else {
     const int nq = state_bytes(sm.kind) / 8;
     if ((int)threadIdx.x < nq) st80[threadIdx.x] = reinterpret_cast<const unsigned long long*>(sh.state)[threadIdx.x];
@@ -1126,11 +1140,11 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
   double s0 = 0.0;
   bool fine = true;
   if (!skip) fine = reduce_tagged(fz.ptag, sm.n0, l, fz.want, red32, flag, s0);
+  fuse_stamp(fz, 2);
   if (!fine) {
     if (threadIdx.x == 0) __hip_atomic_store(fz.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;  // (nothing published: whoever waits for this record runs into its own bound)
   }
-  const bool commit = (c & 7) == 0;
   if (threadIdx.x == 0) {
     if (!skip) step_advance(sm, st80, s0, 0.0, commit ? sm.prog : nullptr);
     ride_publish(reinterpret_cast<const LaneCtl*>(st80 + sm.prod_ctl_off), l, rec, rb.pub);
@@ -1155,6 +1169,7 @@ struct FuseGrid {
   int32_t gpx;             // row groups per XCD
 };
 
+template <bool CSORT>
 __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, const double* sp_in, double* lp, double* sp_out,
                                                        double* part_a, int pstride_a, const FuseGrid fg, const UpdSeg ut0,
                                                        const UpdSeg ut1, const UpdSeg ua0, const UpdSeg ua1, const StepArgs sh0,
@@ -1168,43 +1183,52 @@ __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, 
   __shared__ unsigned long long crec[10];
   __shared__ int okf;
   int b = (int)blockIdx.x;
+  fuse_stamp(fz, 0);
   if (b < kRideCand) {
-    ride_leader((b >> 3) & 1 ? sh1 : sh0, b, ra, fred, fst);
+    ride_leader((b >> 3) & 1 ? sh1 : sh0, b, ra, fred, fst, /*may_commit=*/false);
+    fuse_stamp(fz, 3);
     return;
   }
   b -= kRideCand;
   if (b < fg.nwg_t) {
     int Lt[2], nt;
     if (!atl_blocks_of(b, fg.n2, fg.bpx, AT.nblk, Lt, nt)) return;
-    atl_product<true, false, true>(AT, sp_in, lp, lp, nullptr, 0, Lt, nt, ra, HaloRows{}, fz, prod, crec, &okf);
+    atl_product<CSORT, false, true>(AT, sp_in, lp, lp, nullptr, 0, Lt, nt, ra, HaloRows{}, fz, prod, crec, &okf);
+    fuse_stamp(fz, 3);
     return;
   }
   b -= fg.nwg_t;
   if (b < kRideCand) {
     fuse_mid_leader((b >> 3) & 1 ? sh1 : sh0, (b >> 3) & 1 ? sm1 : sm0, b, rb, fz, fred, fst, &okf);
+    fuse_stamp(fz, 3);
     return;
   }
   b -= kRideCand;
-  if (b < fg.nupd_t) {
-    if (b >= ut0.nblk + ut1.nblk) return;  // (padding)
-    if (ride_settle<true>(ra, fst, &okf)) {
-      const UpdSeg& u = b < ut0.nblk ? ut0 : ut1;
-      upd_run<NL>(u, b < ut0.nblk ? b : b - ut0.nblk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
-    }
-    return;
-  }
-  b -= fg.nupd_t;
   if (b < 8 * fg.gpx) {
     const int g = (b & 7) * fg.gpx + (b >> 3);
     rgcs_group<NL, true, true, true>(RA, lp, sp_in, sp_out, nullptr, nullptr, part_a, pstride_a, g, rb, fz, prod, crec, &okf);
+    fuse_stamp(fz, 3);
     return;
   }
   b -= 8 * fg.gpx;
+  if (b < fg.nupd_t) {  // (behind the row groups: nothing in this launch waits for them, and the row groups should enter as the A' blocks drain)
+    if (b >= ut0.nblk + ut1.nblk) return;  // (padding)
+    if (ride_settle<true>(ra, fst, &okf)) {
+      fuse_stamp(fz, 1);
+      const UpdSeg& u = b < ut0.nblk ? ut0 : ut1;
+      upd_run<NL>(u, b < ut0.nblk ? b : b - ut0.nblk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
+    }
+    fuse_stamp(fz, 3);
+    return;
+  }
+  b -= fg.nupd_t;
   if (b >= ua0.nblk + ua1.nblk) return;
-  if (ride_settle<true>(rb, fst, &okf)) {
+  if (ride_settle<true, 48>(rb, fst, &okf)) {  // (released late in the launch: look rarely, the record's lines are busy)
+    fuse_stamp(fz, 1);
     const UpdSeg& u = b < ua0.nblk ? ua0 : ua1;
     upd_run<NL>(u, b < ua0.nblk ? b : b - ua0.nblk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
   }
+  fuse_stamp(fz, 3);
 }
 
 }  // namespace fpsq

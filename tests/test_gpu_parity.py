@@ -1302,7 +1302,39 @@ def test_one_launch_iterations_are_bitwise_the_two_launch_iterations(monkeypatch
     monkeypatch.setenv("FPSQ_AT_ROW_ALIGN", "8")
     monkeypatch.setenv("FPSQ_FUSE_ITER", "0")
     want = run(False)
-    monkeypatch.setenv("FPSQ_FUSE_ITER", "1")
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "2")  # (2: wherever possible; the default, 1, keeps small grids on two launches)
+    got = run(True)
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+
+
+@pytest.mark.parametrize("late", [0, 8, 5])
+@pytest.mark.parametrize("ln_method", [0, 1])
+def test_one_launch_iterations_with_a_late_leader_and_lnlq(monkeypatch, late, ln_method):
+    """The same with a head leader held back by ~100 us (a committing one of either lane, a publishing-only one) -- the mid
+    leaders then finish the step behind the A' product while a head leader has not even read the state yet, which is why that
+    step lands in a THIRD copy of the state -- and with LNLQ (ln_method = 1) as the least-norm recurrence."""
+    qp = _small_pde(seed=23, n=60000, m=6000)
+    rng = np.random.default_rng(9)
+    xs = [qp.xhat + 0.3 * rng.standard_normal(qp.n) for _ in range(3)]
+
+    def run(expect_fused):
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, ln_method=ln_method)
+        out, fused = [], 0
+        for x in xs:
+            gx, ys = np.empty(qp.n), np.empty(qp.m)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys)
+            fused += dev.info()["last_fused_launches"]
+            out += [np.array([f, rc, dev.stats[0].niter, dev.stats[1].niter, dev.stats[0].rnorm, dev.stats[1].rnorm]), gx, ys]
+        dev.close()
+        assert (fused > 0) == expect_fused
+        return out
+
+    monkeypatch.setenv("FPSQ_AT_ROW_ALIGN", "8")
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "0")
+    want = run(False)
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
+    monkeypatch.setenv("FPSQ_DEBUG_RIDE_DELAY", str(late + 1))
     got = run(True)
     for i, (a_, b_) in enumerate(zip(got, want)):
         assert np.array_equal(a_, b_), i
