@@ -1340,6 +1340,49 @@ def test_one_launch_iterations_with_a_late_leader_and_lnlq(monkeypatch, late, ln
         assert np.array_equal(a_, b_), i
 
 
+def test_two_handles_iterating_at_once_with_one_launch_iterations(monkeypatch):
+    """Two handles evaluating at the same time (two host threads, two streams): both grids are full of workgroups that wait for
+    other workgroups of their own launch -- row groups for A' blocks, mid leaders for every block, updates for records -- and
+    compete for the same XCDs.  Every dependence points to a workgroup EARLIER in its own grid, every XCD has its own leaders,
+    and a waiting workgroup holds a quarter of a CU, not an XCD: the waits must end, and every result must equal the
+    handle's own single-threaded one bitwise.  (Grids of several resident sets each: 1.3 resident sets of A' blocks + the row
+    groups per handle.)"""
+    import threading
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
+    qps = [_small_pde(seed=31, n=300000, m=30000), _small_pde(seed=32, n=260000, m=26000)]
+    devs = [DeviceEqQP(q, sigma=1e3, rho=1.0, delta=0.0) for q in qps]
+    rng = np.random.default_rng(12)
+    xs = [[q.xhat + 0.3 * rng.standard_normal(q.n) for _ in range(3)] for q in qps]
+
+    def evaluate(dev, q, x):
+        gx, ys = np.empty(q.n), np.empty(q.m)
+        f, rc = dev.objgrad(x, gx=gx, ys=ys)
+        return [np.array([f, rc, dev.stats[0].niter, dev.stats[1].niter, dev.info()["last_fused_launches"] > 0]), gx, ys]
+
+    want = [[evaluate(d, q, x) for x in xx] for d, q, xx in zip(devs, qps, xs)]
+    assert all(w[0][4] for ww in want for w in ww)
+    bad = []
+
+    def work(k):
+        try:
+            for rep in range(12):
+                for x, w in zip(xs[k], want[k]):
+                    got = evaluate(devs[k], qps[k], x)
+                    if not all(np.array_equal(a, b) for a, b in zip(got, w)):
+                        bad.append(f"mismatch handle {k} rep {rep}")
+        except BaseException as e:  # noqa: BLE001  (an assertion in a thread would otherwise vanish)
+            bad.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad[:3]
+    for d in devs:
+        d.close()
+
+
 def test_riding_leaders_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
     """Every wait of the leader protocol has an end each wave reaches: with the leaders made to publish a wrong launch number
     (FPSQ_DEBUG_RIDE_BREAK=1) the workgroups of the product give up after their bounded number of looks, raise the handle's

@@ -36,17 +36,26 @@ a2, at2 = pb(2)
 upd_at, upd_a = 8 * 5 * m, 8 * (3 * n + 5 * m)
 # One evaluation (fast start + paired epilogue product, bench.py default): J + 1 two-RHS A products (the start-up one
 # without riding updates), J two-RHS A' products with the LSQR update riding + ONE raw two-RHS A' product (no yin read).
-alg = {  # average algorithmic bytes of a productive launch (products + the vector updates riding in them)
-    "k_spmv_rgcs<2": (J * (a2 + upd_a) + a2) / (J + 1),
-    "k_spmv<2, 1": (J * at2 + upd_at * (J - 1) + (at2 - 8 * 2 * n)) / (J + 1),
-}
-mix = {"k_spmv_rgcs<2": J + 1, "k_spmv<2, 1": J + 1}
+fused = any("k_iter_fused" in k for k in f)
+if fused:
+    # one launch per joint iteration (k_iter_fused: A' product + LSQR update + A product + CRAIG updates), the start-up A product
+    # and the raw two-RHS A' product of the epilogue on their own
+    alg = {"k_iter_fused": (J * (at2 + a2 + upd_a) + (J - 1) * upd_at) / J, "k_spmv_rgcs<2": float(a2),
+           "k_spmv<2, 1": float(at2 - 8 * 2 * n)}
+    mix = {"k_iter_fused": J, "k_spmv_rgcs<2": 1, "k_spmv<2, 1": 1}
+    family = {"k_iter_fused": ("k_iter_fused",), "k_spmv_rgcs<2": ("k_spmv_rgcs<2",), "k_spmv<2, 1": ("k_spmv<2, 1", "k_spmv_atl<")}
+else:
+    alg = {  # average algorithmic bytes of a productive launch (products + the vector updates riding in them)
+        "k_spmv_rgcs<2": (J * (a2 + upd_a) + a2) / (J + 1),
+        "k_spmv<2, 1": (J * at2 + upd_at * (J - 1) + (at2 - 8 * 2 * n)) / (J + 1),
+    }
+    mix = {"k_spmv_rgcs<2": J + 1, "k_spmv<2, 1": J + 1}
+    # (the loop's products are the variants with riding leaders -- k_spmv_rgcs<.., LEAD>, k_spmv_atl -- the start-up and
+    # epilogue products the plain ones: one kernel family per matrix)
+    family = {"k_spmv_rgcs<2": ("k_spmv_rgcs<2",), "k_spmv<2, 1": ("k_spmv<2, 1", "k_spmv_atl<")}
 out = {"_how": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "workload": "pde-control-like n=1e6 m=1e5 nnz=1e7",
-       "joint_iterations": J, "kernels": {}}
+       "joint_iterations": J, "fused_iterations": fused, "kernels": {}}
 tb = ab = 0.0
-# (the loop's products are the variants with riding leaders -- k_spmv_rgcs<.., LEAD>, k_spmv_atl -- the start-up and
-# epilogue products the plain ones: one kernel family per matrix)
-family = {"k_spmv_rgcs<2": ("k_spmv_rgcs<2",), "k_spmv<2, 1": ("k_spmv<2, 1", "k_spmv_atl<")}
 for key in alg:
     kn = [k for k in f if any(pat in k for pat in family[key])]
     assert len(kn) >= 1, (key, list(f))

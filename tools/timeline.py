@@ -12,6 +12,8 @@ import numpy as np
 
 
 def short(name):
+    if "k_iter_fused" in name:
+        return "k_iter_fused"
     if "k_spmv_atl" in name:
         return "k_spmv_atl"
     if "k_spmv_rgcs" in name and name.split("(")[0].rstrip(">").endswith("true"):
