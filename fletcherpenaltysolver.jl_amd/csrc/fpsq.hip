@@ -654,6 +654,7 @@ struct fpsq_solver_s {
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   // one launch per joint iteration (k_iter_fused; FPSQ_FUSE_ITER=0: two launches)
+  bool fuse_break = false;      // FPSQ_DEBUG_FUSE_BREAK=1 (tests): the A' blocks of a fused launch publish a wrong number, every wait for them expires
   int fuse_iter = 1;            // 0: never; 1: where it pays (setup_fused_iteration); 2: wherever it is possible (tests)
   bool fuse_ok = false;
   int2* fz_dep = nullptr;                 // per row group: the A' blocks it waits for
@@ -2640,6 +2641,7 @@ struct KrylovRun {
     fz.ptag = h->fz_ptag;
     fz.dep = h->fz_dep;
     fz.want = ra.want;
+    fz.pub = h->fuse_break ? ~ra.want : ra.want;
     fz.err = ra.err;
     const dim3 grid(kRideCand + fg.nwg_t + kRideCand + fg.nupd_t + 8 * fg.gpx + cu[0].nblk + cu[1].nblk);
     if (h->fuse_probe_at > 0 && h->fused_total + 1 == h->fuse_probe_at) {  // developer probe: this launch leaves time stamps
@@ -3308,6 +3310,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_ATL_TWO")) h->atl_two = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_AT_XCD")) h->at_xcd = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev);
+  if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_PROBE")) {
     h->fuse_probe_path = ev;
     h->fuse_probe_at = 100;

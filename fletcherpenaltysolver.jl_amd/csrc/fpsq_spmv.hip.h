@@ -558,7 +558,7 @@ struct FuseArgs {
   unsigned long long* ptag;       // [blocks][4] self-validating words: the blocks' squared-norm partials (lane 0 high, low; lane 1 high, low)
   const int2* dep;                // per row group of A: first and last A' block owning rows on the lines the group gathers from
   unsigned int want;              // this launch's number
-  unsigned int pad_;
+  unsigned int pub;               // what the blocks publish: `want` (anything else only in the test of the bounded waits)
   unsigned long long* err;        // host-mapped: a bounded wait expired
   unsigned long long* dbg;        // developer probe (null in production): four 100 MHz time stamps per workgroup of the launch, see fuse_stamp
 };
@@ -723,10 +723,10 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
           const double v = (red[l] + red[NL + l]) + (red[2 * NL + l] + red[3 * NL + l]);
-          ride_store(pt + 2 * l, tag_hi(v, fz.want));
-          ride_store(pt + 2 * l + 1, tag_lo(v, fz.want));
+          ride_store(pt + 2 * l, tag_hi(v, fz.pub));
+          ride_store(pt + 2 * l + 1, tag_lo(v, fz.pub));
         }
-        __hip_atomic_store(fz.blkflag + Lt[t], fz.want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fz.blkflag + Lt[t], fz.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else if (partials != nullptr) {
       if (t) lds_barrier();  // (thread 0 has read `red` for the previous block)

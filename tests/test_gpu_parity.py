@@ -1383,6 +1383,30 @@ def test_two_handles_iterating_at_once_with_one_launch_iterations(monkeypatch):
         d.close()
 
 
+def test_one_launch_iteration_bounded_waits_end_in_an_error_not_a_hang(monkeypatch):
+    """Every wait of the fused launch has an end each wave reaches: with the A' blocks made to publish a wrong launch number
+    (FPSQ_DEBUG_FUSE_BREAK=1) the row groups give up on their flags and the mid leaders on the tagged partials after their
+    bounded numbers of looks, whoever waits for the mid leaders' record after its own; the handle's error word is raised and
+    the call returns FPSQ_ERR_TIMEOUT (-5) with a message, within seconds.  A fresh handle without the switch works."""
+    import time
+    qp = _small_pde(seed=5, n=60000, m=6000)
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
+    monkeypatch.setenv("FPSQ_DEBUG_FUSE_BREAK", "1")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, ls_itmax=3, ln_itmax=3)
+    gx = np.empty(qp.n)
+    t0 = time.perf_counter()
+    with pytest.raises(Exception) as ei:
+        dev.objgrad(qp.x, gx=gx)
+    assert time.perf_counter() - t0 < 60.0
+    assert "bounded wait" in str(ei.value)
+    dev.close()
+    monkeypatch.setenv("FPSQ_DEBUG_FUSE_BREAK", "0")
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+    f, rc = dev.objgrad(qp.x, gx=gx)
+    assert rc == 0 and np.all(np.isfinite(gx)) and dev.info()["last_fused_launches"] > 0
+    dev.close()
+
+
 def test_riding_leaders_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
     """Every wait of the leader protocol has an end each wave reaches: with the leaders made to publish a wrong launch number
     (FPSQ_DEBUG_RIDE_BREAK=1) the workgroups of the product give up after their bounded number of looks, raise the handle's
