@@ -1267,7 +1267,7 @@ def test_a_late_leader_changes_nothing(monkeypatch, late):
         assert np.array_equal(a_, b_), i
 
 
-@pytest.mark.parametrize("size", [(6000, 600), (60000, 6000), (300000, 30000)])
+@pytest.mark.parametrize("size", [(6000, 600), (60000, 6000), (300000, 30000), (300000, 30000, "headline density")])
 @pytest.mark.parametrize("delta", [0.0, SE])
 def test_one_launch_iterations_are_bitwise_the_two_launch_iterations(monkeypatch, delta, size):
     """A joint iteration of two riding recurrences is ONE launch (k_iter_fused): the row groups of the A product follow the
@@ -1276,8 +1276,12 @@ def test_one_launch_iterations_are_bitwise_the_two_launch_iterations(monkeypatch
     tagged partials.  Same per-block and per-group arithmetic, the same sums in the same order: every output and statistic
     of objgrad, hprod Val(2) and the seam solves must be BITWISE those of a handle that launches the two products separately
     on the same layout (FPSQ_FUSE_ITER=0 with the A' blocks aligned to 8 rows all the same), over changing points -- the
-    second and later calls also exercise the run-ahead, the speculative epilogue and launches past convergence."""
-    qp = _small_pde(seed=17, n=size[0], m=size[1])
+    second and later calls also exercise the run-ahead, the speculative epilogue and launches past convergence.
+    "headline density" (100 entries per row in an 8192-column window, ~205-row A' blocks, several resident sets): blocks
+    there reach their epilogue with the leaders' record taken at the LAST of their looks, which the sparser cases never do
+    (an experimental build -- tools/experiments/ln_update_in_at_blocks.patch -- that mishandled that look passed the three
+    other sizes and left half the rows of p2 wrong at this one)."""
+    qp = _small_pde(seed=17, n=size[0], m=size[1]) if len(size) == 2 else problems.pde_control_like(n=size[0], m=size[1], seed=31)
     A = qp.scipy_csr()
     rng = np.random.default_rng(8)
     xs = [qp.xhat + 0.3 * 0.6 ** k * rng.standard_normal(qp.n) for k in range(5)]
