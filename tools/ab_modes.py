@@ -23,7 +23,10 @@ if os.environ.get("AB_OPT"):  # an fpsq_options field, e.g. AB_OPT="lookahead=2,
     optname, vals = os.environ["AB_OPT"].split("=")
     optvals = [int(v) for v in vals.split(",")]
 workload = os.environ.get("AB_WORKLOAD", "headline")
-qp = problems.pde_control_like(n=1_000_000, m=100_000) if workload == "headline" else problems.random_eqqp(n=100_000, m=10_000)
+if workload.startswith("pde:"):  # AB_WORKLOAD=pde:n:m -- the headline generator at another size
+    qp = problems.pde_control_like(n=int(workload.split(":")[1]), m=int(workload.split(":")[2]))
+else:
+    qp = problems.pde_control_like(n=1_000_000, m=100_000) if workload == "headline" else problems.random_eqqp(n=100_000, m=10_000)
 dev = torch.device("cuda", 0)
 models = {}
 import ctypes as _C
