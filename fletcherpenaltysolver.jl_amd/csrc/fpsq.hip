@@ -1355,7 +1355,9 @@ int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<in
     double width = 0.0;
     for (const int2& d : dep) width += d.y - d.x + 1;
     width /= (double)std::max<size_t>(dep.size(), 1);
-    if (h->AT.nblk < 2 * h->resident_wgs || width > h->AT.nblk / 8.0) return 0;
+    // (the size threshold: profiles/r04_fused_sizes.txt -- headline generator, one launch against two: -3.2 % at 1225 blocks,
+    // -2.4 % at 1617, +2.3 % at 1764, +7.7 % at 1862, +8.4 % at 1960, +7.3 % at 2450, +2.5 to +4 % at 4900, -0.5 % at 9800)
+    if (h->AT.nblk < 17 * h->resident_wgs / 10 || width > h->AT.nblk / 8.0) return 0;
   }
   dfree(h, &h->fz_dep);
   dfree(h, &h->fz_flag);
