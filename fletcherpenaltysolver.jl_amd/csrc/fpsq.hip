@@ -94,6 +94,8 @@ struct Comm {
     double* halo_recv;    // [(ovl + ovr)][2]
     int64_t ovl, ovr;
   };
+  // peer-to-peer routes: the exchange and the finish of the overlap rows as ONE launch (k_p2p_halo_finish); false: not here
+  virtual bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) { return false; }
   virtual int arm(const Buffers&, hipStream_t) { return 0; }
   virtual bool failed() { return false; }  // a bounded wait of the peer-to-peer route expired
   // Memory a peer may write into (the gather buffers, the halo slots): a communicator that exports it to other processes
@@ -133,6 +135,7 @@ struct P2PRoute {
   bool failed() const { return fail_host && *fail_host != 0; }
   int alloc_fail_word(std::string& err) {
     if (const char* ev = std::getenv("FPSQ_P2P_POLLS")) max_spins = std::max(1L, std::atol(ev));
+    if (const char* ev = std::getenv("FPSQ_HALO_FUSE")) fuse_halo = std::atoi(ev) != 0;
     if (hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&fail_dev, fail_host, 0) != hipSuccess) {
       err = "p2p arm: allocation failed";
@@ -156,6 +159,10 @@ struct P2PRoute {
                        rx + (size_t)par * rx_half, recv, fail_dev, max_spins);
   }
   void halo_exchange(const double* vec, int NL, int64_t tl, int64_t tr, const double* recvL, hipStream_t s) {
+    const P2PHalo H = halo_peers(NL, tl, tr, recvL);
+    hipLaunchKernelGGL(k_p2p_halo, dim3(2), dim3(1024), 0, s, vec, tl * NL, tr * NL, H, ++halo_seq, fail_dev, max_spins);
+  }
+  P2PHalo halo_peers(int NL, int64_t tl, int64_t tr, const double* recvL) const {
     P2PHalo H{};
     const int par = recvL != mine.halo_recv;  // which half of the (double-buffered) slots this exchange uses: the same on
                                               // every rank (all ranks make the same sequence of exchanges)
@@ -171,7 +178,19 @@ struct P2PRoute {
       H.right_flag = peer_flags[R] + 8;  // its "from left" word
       H.my_from_right = flags + 9;
     }
-    hipLaunchKernelGGL(k_p2p_halo, dim3(2), dim3(1024), 0, s, vec, tl * NL, tr * NL, H, ++halo_seq, fail_dev, max_spins);
+    return H;
+  }
+  bool fuse_halo = true;  // FPSQ_HALO_FUSE=0: exchange and finish as two launches
+  bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) {
+    if (!armed || !fuse_halo) return false;
+    const P2PHalo H = halo_peers(NL, fa.tl, fa.tr, fa.recv);
+    const dim3 grid(2 * kHaloCopy + finish_wgs);
+    unsigned long long* arrive = flags + 12;  // (words 12, 13 of my flag block: arrival counters of the copy slices, per side)
+    if (NL == 2)
+      hipLaunchKernelGGL(k_p2p_halo_finish<2>, grid, dim3(kBlock), 0, s, H, ++halo_seq, fail_dev, max_spins, arrive, fa);
+    else
+      hipLaunchKernelGGL(k_p2p_halo_finish<1>, grid, dim3(kBlock), 0, s, H, ++halo_seq, fail_dev, max_spins, arrive, fa);
+    return true;
   }
   void release() {
     if (rx) hipFree(rx);
@@ -428,6 +447,9 @@ struct IpcComm : RcclComm {
     rt.halo_exchange(vec, NL, tl, tr, recvL, s);
     return 0;
   }
+  bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) override {
+    return rt.halo_exchange_finish(NL, fa, finish_wgs, s);
+  }
   void close_peers() {
     for (int r = 0; r < 8; ++r)
       for (int k = 0; k < 3; ++k)
@@ -594,6 +616,9 @@ struct P2PLocalComm : LocalComm {
     if (!rt.armed) return LocalComm::halo_exchange(vec, n_loc, NL, tl, tr, recvL, recvR, s);
     rt.halo_exchange(vec, NL, tl, tr, recvL, s);
     return 0;
+  }
+  bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) override {
+    return rt.halo_exchange_finish(NL, fa, finish_wgs, s);
   }
   ~P2PLocalComm() override { rt.release(); }
 };
@@ -1592,6 +1617,14 @@ int halo_finish(fpsq_handle h, const double* yin, double* yout, const LaneCtl* c
   const int64_t t = h->ovl + h->ovr;
   if (t == 0) return 0;
   double* rl = h->halo_recv + (size_t)(h->halo_calls++ & 1) * (size_t)t * 2;
+  {  // peer-to-peer routes: exchange + finish in one launch
+    const HaloFinishArgs fa{h->halo_raw, rl, h->ovl, h->ovr, h->n - h->ovr, yin, yout, c0, c1,
+                            partials ? partials + h->AT.nblk : nullptr, h->strT, 0, h->gate0, h->gate1};
+    if (h->comm->halo_exchange_finish(NL, fa, h->halo_gf, h->stream)) {
+      h->launches++;
+      return 0;
+    }
+  }
   if (int rc = h->comm->halo_exchange(h->halo_raw, t, NL, h->ovl, h->ovr, rl, rl + (size_t)h->ovl * NL, h->stream)) {
     h->err = h->comm->err;
     return rc;

@@ -791,6 +791,94 @@ __global__ __launch_bounds__(1024) void k_p2p_halo(const double* __restrict__ ra
   }
 }
 
+// The exchange AND the finish of the overlap rows in one launch (peer-to-peer route; FPSQ_HALO_FUSE=0: k_p2p_halo, then
+// k_halo_finish): workgroups [0, 2 kHaloCopy) push my two regions into the neighbours' slots (kHaloCopy slices per side; the
+// last slice to arrive -- a monotone counter per side -- raises the neighbour's flag word) and leave; the others are
+// k_halo_finish's workgroups, which first wait (bounded) for the neighbours' records.  A rank's launch e + 1 follows its launch e
+// in stream order and launch e ends only when its finish workgroups have consumed slot e: the slot a neighbour overwrites
+// with its push e + 2 (after ITS launch e + 1, whose finish workgroups waited for my push e + 1) is free, as with two kernels.
+constexpr int kHaloCopy = 4;
+struct HaloFinishArgs {
+  const double* raw;
+  const double* recv;
+  int64_t tl, tr, tail0;
+  const double* yin;
+  double* yout;
+  const LaneCtl *ctl0, *ctl1;
+  double* partials;
+  int32_t pstride, pad_;
+  const LaneCtl *gate0, *gate1;
+};
+template <int NL>
+__global__ __launch_bounds__(kBlock) void k_p2p_halo_finish(P2PHalo H, unsigned long long seq, int* fail, long max_spins,
+                                                            unsigned long long* arrive /* [2] */, HaloFinishArgs a) {
+  if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+  __shared__ int ok;
+  int b = (int)blockIdx.x;
+  if (b < 2 * kHaloCopy) {
+    const bool left = b < kHaloCopy;
+    const int sl = left ? b : b - kHaloCopy;
+    double* dst = left ? H.left_dst : H.right_dst;
+    if (!dst) return;
+    const int64_t nl = a.tl * NL, cnt = left ? nl : a.tr * NL;
+    const double* src = left ? a.raw : a.raw + nl;
+    const int64_t per = ((cnt + kHaloCopy - 1) / kHaloCopy + 1) & ~(int64_t)1, lo = sl * per, hi = lo + per < cnt ? lo + per : cnt;
+    if (lo < hi) p2p_copy(src, dst, lo, hi);
+    __syncthreads();  // (every wave's stores are complete)
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      const unsigned long long got = __hip_atomic_fetch_add(arrive + (left ? 0 : 1), 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      if (got % kHaloCopy == 0)
+        __hip_atomic_store(left ? H.left_flag : H.right_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  b -= 2 * kHaloCopy;
+  const int nb = (int)gridDim.x - 2 * kHaloCopy;
+  if (a.gate0 != nullptr && !(a.gate0->done && a.gate1->done)) return;
+  const LaneCtl* c[2] = {a.ctl0, a.ctl1};
+  bool act[NL];
+  double ca[NL], cb[NL];
+  bool any = false;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    act[l] = !(c[l]->done | c[l]->skip);
+    ca[l] = c[l]->ca;
+    cb[l] = c[l]->cb;
+    any |= act[l];
+  }
+  if (!any) return;
+  if (threadIdx.x == 0) {
+    bool in = true;
+    if (H.my_from_left) in = p2p_wait(H.my_from_left, seq, max_spins, fail);
+    if (in && H.my_from_right) in = p2p_wait(H.my_from_right, seq, max_spins, fail);
+    ok = in ? 1 : 0;
+  }
+  __syncthreads();
+  if (!ok) return;
+  __shared__ double red[4];
+  double sq[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+  for (int64_t i = (int64_t)b * kBlock + threadIdx.x; i < a.tl + a.tr; i += (int64_t)nb * kBlock) {
+    const int64_t row = i < a.tl ? i : a.tail0 + (i - a.tl);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (!act[l]) continue;
+      const double o = ca[l] * (a.raw[i * NL + l] + a.recv[i * NL + l]) + (cb[l] != 0.0 ? cb[l] * a.yin[row * NL + l] : 0.0);
+      a.yout[row * NL + l] = o;
+      if (i < a.tl) sq[l] += o * o;
+    }
+  }
+  if (a.partials != nullptr) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double t = block_sum(sq[l], red);
+      if (threadIdx.x == 0) a.partials[(size_t)l * a.pstride + b] = t;
+    }
+  }
+}
+
 // out = a * P + b * y (plain vectors, host-given constants), for the p1 = g - A'q1 and J'c products
 __global__ __launch_bounds__(kBlock) void k_axpby_plain(const double* __restrict__ P, double a, const double* y,
                                                         double b, double* out, int64_t len) {

@@ -74,14 +74,20 @@ def _reference(delta):
     return qp, out, np.array(its), fs
 
 
-@pytest.mark.parametrize("nranks,route", [(2, "p2p"), (3, "p2p"), (2, "auto"), (2, "rccl")])
+@pytest.mark.parametrize("nranks,route", [(2, "p2p"), (3, "p2p"), (2, "auto"), (2, "rccl"), (3, "p2p-two-launch-halo")])
 @pytest.mark.parametrize("delta", [0.0, SE])
 def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, route, delta):
     """Same iteration counts as the single-GPU handle, vectors to 1e-9 (only the order of the reductions differs), phi
     BITWISE the same on every rank (the four sums are gathered and added in rank order), overlaps bitwise identical on the
-    two ranks sharing them; the handles report the route they run on (p2p and auto: peer to peer; rccl: the collectives)."""
+    two ranks sharing them; the handles report the route they run on (p2p and auto: peer to peer; rccl: the collectives).
+    On the peer-to-peer route the halo exchange and the finish of the overlap rows are ONE launch (k_p2p_halo_finish: the
+    finish workgroups wait for the neighbours' records themselves); "p2p-two-launch-halo" (FPSQ_HALO_FUSE=0) keeps the
+    exchange kernel and the finish kernel apart."""
     qp, want, its_ref, fs_ref = _reference(delta)
-    rcs, outs = _run_ranks(nranks, route, delta, tmp_path)
+    extra = None
+    if route == "p2p-two-launch-halo":
+        route, extra = "p2p", {"FPSQ_HALO_FUSE": "0"}
+    rcs, outs = _run_ranks(nranks, route, delta, tmp_path, extra_env=extra)
     assert all(rc == 0 for rc in rcs), [o[1][-1500:] for o in outs]
     res = [np.load(os.path.join(tmp_path, f"out_{r}.npz")) for r in range(nranks)]
     bounds = row_partition(qp.rowptr, nranks)
