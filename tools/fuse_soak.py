@@ -1,5 +1,5 @@
 """Developer soak (GPU box, one run): one-launch iterations (k_iter_fused) against two-launch iterations, BITWISE, over many
-evaluations.   usage: python tools/fuse_soak.py [evaluations] [n] [m] [delta]
+evaluations.   usage: python tools/fuse_soak.py [evaluations] [n] [m] [delta] [stratified|hashed]
 Two handles on the same problem and the same block partition (FPSQ_FUSE_ITER=0 + FPSQ_AT_ROW_ALIGN=8 / FPSQ_FUSE_ITER=2), the
 same random points at changing distances from the solution (so iteration counts move and the run-ahead mispredicts);
 every output and statistic of objgrad and of hprod Val(2) must agree bit for bit.  The fused launch hands rows between
@@ -17,7 +17,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 m = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
 delta = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
-qp = problems.pde_control_like(n=n, m=m)
+gen = sys.argv[5] if len(sys.argv) > 5 else "stratified"  # "hashed": SURVEY 8(d)'s literal generator
+qp = problems.pde_control_hashed(n=n, m=m) if gen == "hashed" else problems.pde_control_like(n=n, m=m)
 os.environ["FPSQ_AT_ROW_ALIGN"] = "8"
 os.environ["FPSQ_FUSE_ITER"] = "0"
 ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
@@ -50,6 +51,6 @@ for k in range(N):
         print("MISMATCH at evaluation", k, flush=True)
     if k % 250 == 249:
         print(f"{k + 1} evaluations, {bad} mismatches, {fused} fused launches, {time.time() - t0:.0f} s", flush=True)
-print(f"compared {N} objgrad + {N} hprod calls (n={n}, m={m}, delta={delta}): {bad} mismatches; {fused} fused launches; "
+print(f"compared {N} objgrad + {N} hprod calls (n={n}, m={m}, delta={delta}, {gen} offsets): {bad} mismatches; {fused} fused launches; "
       f"iteration counts (lsqr, craig | hprod lsqr, lsqr) seen: {sorted(counts.items(), key=lambda kv: -kv[1])[:8]}")
 sys.exit(1 if bad else 0)
