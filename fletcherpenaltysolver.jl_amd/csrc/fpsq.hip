@@ -679,6 +679,7 @@ struct fpsq_solver_s {
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   // one launch per joint iteration (k_iter_fused; FPSQ_FUSE_ITER=0: two launches)
+  int fuse_rotate = 0;          // FPSQ_DEBUG_FUSE_ROTATE=r (tests): the A' blocks of eighth e are written on XCD (e - r) & 7, gathered on XCD e
   bool fuse_break = false;      // FPSQ_DEBUG_FUSE_BREAK=1 (tests): the A' blocks of a fused launch publish a wrong number, every wait for them expires
   int fuse_iter = 1;            // 0: never; 1: where it pays (setup_fused_iteration); 2: wherever it is possible (tests)
   bool fuse_ok = false;
@@ -2662,6 +2663,7 @@ struct KrylovRun {
     }
     fg.nupd_t = (lu[0].nblk + lu[1].nblk + 7) / 8 * 8;
     fg.gpx = (h->RA.view.ng + 7) / 8;
+    fg.rot = h->fuse_rotate;
     RideArgs ra{}, rb{};
     ra.rec = h->ride_rec;
     ra.want = (unsigned int)++h->ride_seq;
@@ -3346,6 +3348,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_AT_XCD")) h->at_xcd = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_ROTATE")) h->fuse_rotate = std::atoi(ev) & 7;
   if (const char* ev = std::getenv("FPSQ_FUSE_PROBE")) {
     h->fuse_probe_path = ev;
     h->fuse_probe_at = 100;

@@ -533,12 +533,14 @@ constexpr int kAtlPass = kMaxRowsPerBlk / kBlock;  // row passes of a block (one
 // bpx > 0: XCD-contiguous eighths -- workgroup b runs on XCD b & 7 (whatever precedes the product workgroups in the grid fills a
 // multiple of eight slots) and walks blocks [e bpx, (e + 1) bpx) of eighth e = b & 7; its first n2 / 8 workgroups take two
 // blocks each.  bpx = 0: grid order.
-__device__ __forceinline__ bool atl_blocks_of(int b, int n2, int bpx, int nblk, int (&Lt)[2], int& nt) {
+// rot (tests of the fused launch only, FPSQ_DEBUG_FUSE_ROTATE): the workgroup on XCD b & 7 walks eighth (b + rot) & 7 -- every
+// row a row group waits for has then been written on ANOTHER XCD.
+__device__ __forceinline__ bool atl_blocks_of(int b, int n2, int bpx, int nblk, int (&Lt)[2], int& nt, int rot = 0) {
   nt = b < n2 ? 2 : 1;
   Lt[0] = b < n2 ? b : n2 + b;
   Lt[1] = n2 + b;
   if (bpx > 0) {
-    const int e = b & 7, j = b >> 3, n2e = n2 >> 3;
+    const int e = (b + rot) & 7, j = b >> 3, n2e = n2 >> 3;
     nt = j < n2e ? 2 : 1;
     Lt[0] = e * bpx + (j < n2e ? j : n2e + j);
     Lt[1] = e * bpx + n2e + j;
@@ -1167,6 +1169,7 @@ struct FuseGrid {
   int32_t nwg_t, n2, bpx;  // A' product workgroups (a multiple of 8), of which the first n2 take two blocks; blocks per XCD
   int32_t nupd_t;          // update workgroups riding with A' (padded to a multiple of 8)
   int32_t gpx;             // row groups per XCD
+  int32_t rot;             // atl_blocks_of's rotation (0; tests: 1..7)
 };
 
 template <bool CSORT>
@@ -1192,7 +1195,7 @@ __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, 
   b -= kRideCand;
   if (b < fg.nwg_t) {
     int Lt[2], nt;
-    if (!atl_blocks_of(b, fg.n2, fg.bpx, AT.nblk, Lt, nt)) return;
+    if (!atl_blocks_of(b, fg.n2, fg.bpx, AT.nblk, Lt, nt, fg.rot)) return;
     atl_product<CSORT, false, true>(AT, sp_in, lp, lp, nullptr, 0, Lt, nt, ra, HaloRows{}, fz, prod, crec, &okf);
     fuse_stamp(fz, 3);
     return;

@@ -1312,6 +1312,38 @@ def test_one_launch_iterations_are_bitwise_the_two_launch_iterations(monkeypatch
         assert np.array_equal(a_, b_), i
 
 
+@pytest.mark.parametrize("rot", [1, 3, 4])
+def test_one_launch_iterations_with_every_hand_over_across_xcds(monkeypatch, rot):
+    """Both products of a fused launch walk XCD-contiguous eighths, so most rows a row group gathers were written on its own
+    XCD, where one L2 makes the hand-over trivially coherent.  FPSQ_DEBUG_FUSE_ROTATE=r lets the A' workgroups of XCD x walk
+    eighth (x + r) mod 8 instead: EVERY row a row group waits for has then been written through from another XCD, and the
+    written-through stores + flags + agent-scope gathers carry the whole exchange.  Bitwise the two-launch iteration."""
+    qp = problems.pde_control_like(n=300000, m=30000, seed=37)
+    rng = np.random.default_rng(14)
+    xs = [qp.xhat + 0.3 * 0.5 ** k * rng.standard_normal(qp.n) for k in range(4)]
+
+    def run(expect_fused):
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+        out, fused = [], 0
+        for x in xs:
+            gx, ys, gs = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys, gs=gs)
+            fused += dev.info()["last_fused_launches"]
+            out += [np.array([f, rc, dev.stats[0].niter, dev.stats[1].niter]), gx, ys, gs]
+        dev.close()
+        assert (fused > 0) == expect_fused
+        return out
+
+    monkeypatch.setenv("FPSQ_AT_ROW_ALIGN", "8")
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "0")
+    want = run(False)
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
+    monkeypatch.setenv("FPSQ_DEBUG_FUSE_ROTATE", str(rot))
+    got = run(True)
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+
+
 @pytest.mark.parametrize("late", [0, 8, 5])
 @pytest.mark.parametrize("ln_method", [0, 1])
 def test_one_launch_iterations_with_a_late_leader_and_lnlq(monkeypatch, late, ln_method):

@@ -1,5 +1,5 @@
 """Developer soak (GPU box, one run): one-launch iterations (k_iter_fused) against two-launch iterations, BITWISE, over many
-evaluations.   usage: python tools/fuse_soak.py [evaluations] [n] [m] [delta] [stratified|hashed]
+evaluations.   usage: python tools/fuse_soak.py [evaluations] [n] [m] [delta] [stratified|hashed] [rotate]
 Two handles on the same problem and the same block partition (FPSQ_FUSE_ITER=0 + FPSQ_AT_ROW_ALIGN=8 / FPSQ_FUSE_ITER=2), the
 same random points at changing distances from the solution (so iteration counts move and the run-ahead mispredicts);
 every output and statistic of objgrad and of hprod Val(2) must agree bit for bit.  The fused launch hands rows between
@@ -23,6 +23,8 @@ os.environ["FPSQ_AT_ROW_ALIGN"] = "8"
 os.environ["FPSQ_FUSE_ITER"] = "0"
 ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
 os.environ["FPSQ_FUSE_ITER"] = "2"
+if len(sys.argv) > 6:  # every hand-over across XCDs (see test_one_launch_iterations_with_every_hand_over_across_xcds)
+    os.environ["FPSQ_DEBUG_FUSE_ROTATE"] = sys.argv[6]
 dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
 rng = np.random.default_rng(7)
 t0 = time.time()
@@ -51,6 +53,6 @@ for k in range(N):
         print("MISMATCH at evaluation", k, flush=True)
     if k % 250 == 249:
         print(f"{k + 1} evaluations, {bad} mismatches, {fused} fused launches, {time.time() - t0:.0f} s", flush=True)
-print(f"compared {N} objgrad + {N} hprod calls (n={n}, m={m}, delta={delta}, {gen} offsets): {bad} mismatches; {fused} fused launches; "
+print(f"compared {N} objgrad + {N} hprod calls (n={n}, m={m}, delta={delta}, {gen} offsets, rotate {os.environ.get('FPSQ_DEBUG_FUSE_ROTATE', '0')}): {bad} mismatches; {fused} fused launches; "
       f"iteration counts (lsqr, craig | hprod lsqr, lsqr) seen: {sorted(counts.items(), key=lambda kv: -kv[1])[:8]}")
 sys.exit(1 if bad else 0)
