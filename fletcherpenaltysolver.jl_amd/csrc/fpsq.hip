@@ -680,6 +680,8 @@ struct fpsq_solver_s {
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   // one launch per joint iteration (k_iter_fused; FPSQ_FUSE_ITER=0: two launches)
   int fuse_rotate = 0;          // FPSQ_DEBUG_FUSE_ROTATE=r (tests): the A' blocks of eighth e are written on XCD (e - r) & 7, gathered on XCD e
+  bool minres_merge = true;     // MINRES lane: stage E1, step A and stage E2 as one launch (k_minres_mid; FPSQ_MINRES_MERGE=0: three)
+  unsigned long long* mm_ptag = nullptr;  // its tagged partials (two words per element-wise workgroup)
   bool fuse_break = false;      // FPSQ_DEBUG_FUSE_BREAK=1 (tests): the A' blocks of a fused launch publish a wrong number, every wait for them expires
   int fuse_iter = 1;            // 0: never; 1: where it pays (setup_fused_iteration); 2: wherever it is possible (tests)
   bool fuse_ok = false;
@@ -1352,6 +1354,10 @@ int alloc_workspaces(fpsq_handle h) {
                    &h->pEm[0], &h->pEm[1]};
   for (auto p : ev)
     if (int rc = dalloc(h, p, (size_t)kEwBlocksMax * 2)) return rc;
+  if (!h->mm_ptag) {
+    if (int rc = dalloc(h, &h->mm_ptag, (size_t)kEwBlocksMax * 2)) return rc;
+    HIPCHK(h, hipMemset(h->mm_ptag, 0, (size_t)kEwBlocksMax * 16));
+  }
   return 0;
 }
 
@@ -2601,14 +2607,21 @@ struct KrylovRun {
     // constraints --, or an early convergence): its stand-alone launches would exit at once, ~3.5 us each; skipped.  One GPU
     // only: sharded, every rank would have to see it at the same iteration.  (Its riding / shared steps stay: they cost nothing.)
     const bool mdead = minres_lane >= 0 && !h->comm && load_progress(&h->prog_host[minres_lane]).done;
-    // MINRES: E1 on q (now in the current pair's lane) before its scalar step A
-    if (minres_lane >= 0 && !mdead) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
+    // MINRES: E1 on q (now in the current pair's lane) before its scalar step A -- with riding steps on one GPU, E1, the step
+    // and E2 are ONE launch (k_minres_mid: every workgroup does E1, waits for the leader's record, does E2 on the same elements)
+    const bool mmid = minres_lane >= 0 && !mdead && lead && NL == 2 && !h->comm && h->minres_merge && h->mm_ptag != nullptr;
+    if (minres_lane >= 0 && !mdead && !mmid) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
     StepArgs sb[2] = {none, none};
     for (int l = 0; l < NL; ++l) sb[l] = step_after_a(l);
     if (minres_lane >= 0 && lead && NL == 2) {
       // MINRES' step A must run before E2; the other lane's step is only needed by the NEXT A' launch (its epilogue and its
       // riding update) and waits for MINRES' step B to ride there with it
-      if (!mdead) {
+      if (mmid) {
+        const UpdSeg e1 = minres_seg(1, it, SPcur), e2 = minres_seg(2, it, SPcur);
+        hipLaunchKernelGGL(k_minres_mid, dim3(1 + e1.nblk), dim3(kBlock), 0, s, e1, e2, sb[minres_lane], h->mm_ptag, h->ride_rec2,
+                           (unsigned int)++h->ride_seq, reinterpret_cast<unsigned long long*>(h->hscal_dev + 15));
+        h->launches++;
+      } else if (!mdead) {
         if (int rc = launch_step(h, sb[minres_lane], none, /*sharded=*/true)) return rc;
         launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
       }
@@ -3348,6 +3361,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_AT_XCD")) h->at_xcd = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_MINRES_MERGE")) h->minres_merge = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_ROTATE")) h->fuse_rotate = std::atoi(ev) & 7;
   if (const char* ev = std::getenv("FPSQ_FUSE_PROBE")) {
     h->fuse_probe_path = ev;

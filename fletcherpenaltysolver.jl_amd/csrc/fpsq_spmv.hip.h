@@ -1067,10 +1067,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
 // squared-norm partials of lane l of the A' blocks [0, n) from their tagged words, summed like reduce_two sums a plain array
 // (same association per thread, same tree); false: a word did not carry this launch's number after kRidePolls looks
 __device__ __forceinline__ bool reduce_tagged(const unsigned long long* ptag, int n, int l, unsigned int want, double* red,
-                                              int* flag, double& s0) {
+                                              int* flag, double& s0, int wpb = 4 /* words per block */) {
   const int t = threadIdx.x;
   auto part = [&](int i, bool& good) {
-    const unsigned long long hi = ride_load(ptag + (size_t)i * 4 + 2 * l), lo = ride_load(ptag + (size_t)i * 4 + 2 * l + 1);
+    const unsigned long long hi = ride_load(ptag + (size_t)i * wpb + 2 * l), lo = ride_load(ptag + (size_t)i * wpb + 2 * l + 1);
     good = good && (unsigned int)(hi & 0xffffffffull) == want && (unsigned int)(lo & 0xffffffffull) == want;
     return __longlong_as_double((long long)((hi & 0xffffffff00000000ull) | (lo >> 32)));
   };
@@ -1232,6 +1232,112 @@ __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, 
     upd_run<NL>(u, b < ua0.nblk ? b : b - ua0.nblk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
   }
   fuse_stamp(fz, 3);
+}
+
+// ------------------------------------------------------------------------------------------------ MINRES: E1 -> step A -> E2, one launch
+//
+// A MINRES lane (solve_two_extras: hprod! Val(1)) needs two global sums per iteration beyond the products': alpha = <r2, y0> / beta
+// between its element-wise stages E1 and E2, beta_new = ||y|| behind E2.  E1, the scalar step A and E2 were three launches
+// (~5 + 6 + 5 us on m-vectors); here they are one: workgroup 0 is the leader, workgroups 1 .. nblk do stage E1 on their elements,
+// publish their partial of <r2, y0> as self-validating words, wait for the leader's record (it sums the partials in
+// reduce_two's order, runs minres_a_step, publishes the coefficients of E2) and go on with stage E2 on the SAME elements --
+// what a thread wrote in E1 it reads itself in E2.  Every workgroup of the grid must be resident at once (the waiting ones
+// hold their slots): <= 1025 workgroups of 256 threads without LDS to speak of -- the host checks.  Bounded waits as everywhere.
+// Bitwise the three launches.
+__global__ __launch_bounds__(kBlock) void k_minres_mid(const UpdSeg e1, const UpdSeg e2, const StepArgs sa, unsigned long long* ptag,
+                                                       unsigned long long* rec /* 10 words */, unsigned int want,
+                                                       unsigned long long* err) {
+  constexpr int NL = 2;
+  __shared__ __attribute__((aligned(16))) unsigned long long st[80];
+  __shared__ double red[32];
+  __shared__ unsigned long long crec[10];
+  __shared__ int flag;
+  const LaneCtl* gctl = reinterpret_cast<const LaneCtl*>(sa.state);
+  const bool done = gctl->done != 0;  // (uniform; the state was committed before this launch)
+  if (blockIdx.x == 0) {  // the leader
+    const int nq = state_bytes(sa.kind) / 8;
+    if ((int)threadIdx.x < nq) st[threadIdx.x] = reinterpret_cast<const unsigned long long*>(sa.state)[threadIdx.x];
+    __syncthreads();
+    double s0 = 0.0;
+    bool fine = true;
+    if (!done) fine = reduce_tagged(ptag, sa.n0, 0, want, red, &flag, s0, 2);
+    if (!fine) {
+      if (threadIdx.x == 0) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    if (threadIdx.x == 0) {
+      if (!done) step_advance(sa, st, s0, 0.0, sa.prog);
+      const LaneCtl* c = reinterpret_cast<const LaneCtl*>(st);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // e[1..4]: the coefficients of E2
+        ride_store(rec + 2 * k, tag_hi(c->e[1 + k], want));
+        ride_store(rec + 2 * k + 1, tag_lo(c->e[1 + k], want));
+      }
+      ride_store(rec + 8, ((unsigned long long)(c->done != 0 ? 1u : 0u) << 32) | want);
+    }
+    __syncthreads();
+    if (!done) {
+      unsigned long long* gdst = reinterpret_cast<unsigned long long*>(sa.state);
+      if ((int)threadIdx.x < nq) gdst[threadIdx.x] = st[threadIdx.x];
+    }
+    return;
+  }
+  if (done) return;  // (stages E1 and E2 of a finished lane do nothing)
+  const int blk = (int)blockIdx.x - 1;
+  double* sp = const_cast<double*>(e1.src);
+  {  // stage E1 (upd_minres<1>): y0 = q - e0 r1, partial <r2, y0>
+    const double e0 = gctl->e[0];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < e1.len; i += (int64_t)e1.nblk * kBlock) {
+      const double y0 = sp[i * NL + e1.lane] - (e0 != 0.0 ? e0 * e1.a[i] : 0.0);
+      sp[i * NL + e1.lane] = y0;
+      acc += e1.b[i] * y0;
+    }
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+      ride_store(ptag + 2 * (size_t)blk, tag_hi(t, want));
+      ride_store(ptag + 2 * (size_t)blk + 1, tag_lo(t, want));
+      flag = 0;
+    }
+  }
+  __syncthreads();
+  // the leader's record
+  for (int t = 0; t < kRidePolls; ++t) {
+    if (threadIdx.x < 64) {
+      if (t) __builtin_amdgcn_s_sleep(4);
+      const int lane = threadIdx.x & 63;
+      const unsigned long long w = lane < 9 ? ride_load(rec + lane) : 0ull;
+      const bool good = lane >= 9 || (unsigned int)(w & 0xffffffffull) == want;
+      if (__all(good)) {
+        if (lane < 9) crec[lane] = w;
+        if (lane == 0) flag = 1;
+      }
+    }
+    __syncthreads();
+    if (flag) break;
+  }
+  if (!flag) {
+    if (threadIdx.x == 0) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  if ((crec[8] >> 32) != 0) return;  // (the step ended the recurrence: no E2)
+  double e[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e[k] = __longlong_as_double((long long)((crec[2 * k] & 0xffffffff00000000ull) | (crec[2 * k + 1] >> 32)));
+  {  // stage E2 (upd_minres<2>): y = y0 - e1 r2; r_new = y; w~ = e2 r2 - e3 w2 - e4 w1; partial ||y||^2
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < e2.len; i += (int64_t)e2.nblk * kBlock) {
+      const double r = e2.a[i];
+      const double y = sp[i * NL + e2.lane] - e[0] * r;
+      sp[i * NL + e2.lane] = y;
+      e2.b[i] = y;
+      e2.d[i] = e[1] * r - e[2] * e2.c[i] - e[3] * e2.d[i];
+      acc += y * y;
+    }
+    __syncthreads();  // (`red` of stage E1)
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) e2.partials[blk] = t;
+  }
 }
 
 }  // namespace fpsq

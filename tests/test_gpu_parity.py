@@ -1376,6 +1376,48 @@ def test_one_launch_iterations_with_a_late_leader_and_lnlq(monkeypatch, late, ln
         assert np.array_equal(a_, b_), i
 
 
+@pytest.mark.parametrize("size", [(6000, 600), (300000, 30000)])
+def test_minres_stages_in_one_launch_are_bitwise_the_three_launches(monkeypatch, size):
+    """A MINRES lane (solve_two_extras, hprod! Val(1)) runs its stage E1, the scalar step A and stage E2 as ONE launch
+    (k_minres_mid: every workgroup does E1 on its elements, publishes its partial as self-validating words, waits for the
+    leader's record and does E2 on the same elements).  Same sums in the same order: every output and statistic of
+    solve_two_extras and hprod Val(1) must be BITWISE those of a handle that launches the three separately
+    (FPSQ_MINRES_MERGE=0), including a zero second right-hand side (the lane ends at once) and repeated calls."""
+    qp = _small_pde(seed=41, n=size[0], m=size[1])
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(15)
+    r1s = [rng.standard_normal(qp.n) for _ in range(3)]
+    r2s = [rng.standard_normal(qp.m), np.zeros(qp.m), rng.standard_normal(qp.m)]
+    vs = [rng.standard_normal(qp.n) for _ in range(2)]
+
+    def run():
+        raw = _Handle(A, 0.0)
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+        out = []
+        for r1, r2 in zip(r1s, r2s):
+            e1, e2, rc = raw.solve_two_extras(r1, r2)
+            st = [(raw.st[i].niter, raw.st[i].status, raw.st[i].rnorm, raw.st[i].arnorm) for i in range(2)]
+            out += [e1, e2, np.array([rc]), np.array(st).ravel()]
+        gx = np.empty(qp.n)
+        dev.objgrad(qp.xhat + 0.2 * vs[0], gx=gx)
+        for v in vs:
+            hv = np.empty(qp.n)
+            rch = dev.hprod(v, hv, 1)
+            st = [(dev.stats4[i].niter, dev.stats4[i].status, dev.stats4[i].rnorm) for i in range(4)]
+            out += [hv, np.array([rch]), np.array(st).ravel()]
+        raw.close()
+        dev.close()
+        return out
+
+    monkeypatch.setenv("FPSQ_MINRES_MERGE", "0")
+    want = run()
+    monkeypatch.setenv("FPSQ_MINRES_MERGE", "1")
+    got = run()
+    assert int(want[3][4]) > 2  # (the MINRES lane iterated)
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+
+
 def test_two_handles_iterating_at_once_with_one_launch_iterations(monkeypatch):
     """Two handles evaluating at the same time (two host threads, two streams): both grids are full of workgroups that wait for
     other workgroups of their own launch -- row groups for A' blocks, mid leaders for every block, updates for records -- and
