@@ -656,6 +656,7 @@ struct fpsq_solver_s {
   double *Lw[2], *Lx[2], *Cw, *Cy, *in_m, *ys, *c, *Mr[2], *Mw[2], *Mx;
   // partial-sum buffers
   double *pS, *pS2, *pW[2], *pE, *pE2, *pE3, *pQ[2], *pC[2];
+  double* pS2b = nullptr;  // second array for the A product's partials: fused launches alternate (KrylovRun::pa_last)
   // second halves of the update partials.  A riding step and a riding update of ONE launch must never share an array:
   // the leaders of the step (sixteen workgroups, any of which another kernel may hold up) read, the update workgroups --
   // released by the record of their own XCC's leader -- write.  LSQR's / CRAIG's update partials therefore alternate
@@ -679,6 +680,7 @@ struct fpsq_solver_s {
   int resident_wgs = 1024;      // product workgroups (32 KB of LDS) the device holds at once: 4 per CU, measured
   bool atl_two = true;          // k_spmv_atl: two row blocks for the first resident set (FPSQ_ATL_TWO=0: one each)
   // one launch per joint iteration (k_iter_fused; FPSQ_FUSE_ITER=0: two launches)
+  int ride_delay_mid = 0;       // FPSQ_DEBUG_RIDE_DELAY_MID=c+1 (tests): mid leader c of every fused launch starts ~100 us late
   int fuse_rotate = 0;          // FPSQ_DEBUG_FUSE_ROTATE=r (tests): the A' blocks of eighth e are written on XCD (e - r) & 7, gathered on XCD e
   bool minres_merge = true;     // MINRES lane: stage E1, step A and stage E2 as one launch (k_minres_mid; FPSQ_MINRES_MERGE=0: three)
   unsigned long long* mm_ptag = nullptr;  // its tagged partials (two words per element-wise workgroup)
@@ -1348,6 +1350,7 @@ int alloc_workspaces(fpsq_handle h) {
   h->npS = std::max(std::max(std::max(h->A.nblk, h->AT.nblk), kEwBlocksMax), npart_A(h));
   if (int rc = dalloc(h, &h->pS, (size_t)h->npS * 2)) return rc;
   if (int rc = dalloc(h, &h->pS2, (size_t)h->npS * 2)) return rc;
+  if (int rc = dalloc(h, &h->pS2b, (size_t)h->npS * 2)) return rc;
   h->strT = h->AT.nblk;
   h->strA = npart_A(h);
   double** ev[] = {&h->pW[0], &h->pW[1], &h->pWalt[0], &h->pWalt[1], &h->pE, &h->pE2, &h->pE3, &h->pQ[0], &h->pQ[1], &h->pC[0], &h->pC[1],
@@ -2114,6 +2117,10 @@ struct KrylovRun {
   bool fuse_upd = false;    // the vector updates ride in the product launches
   bool split_steps = false; // replicated n-sums and per-rank m-sums cannot share a presum launch
   bool can_fuse = false;    // a joint iteration is ONE launch (k_iter_fused) whenever the previous product's steps are pending
+  // Where the last A product left its squared-norm partials.  A fused launch READS them (head leaders; mid leaders redoing the
+  // head step, any of which another kernel may hold up) while its own row groups -- released per XCC -- WRITE theirs: the
+  // launch writes the other array (found by test_one_launch_iterations_with_a_late_mid_leader, which fails with one array)
+  double* pa_last = nullptr;
   StepArgs none{};
   // the steps behind the last product, not launched yet
   StepArgs pend[2];
@@ -2231,6 +2238,7 @@ struct KrylovRun {
     // (every vector a rank updates is its own).  Sharded with replicated n-vectors: separate update launch, in place.
     fuse_upd = local_vec;
     split_steps = h->comm && !h->halo;
+    pa_last = h->pS2;
     can_fuse = NL == 2 && h->fuse_ok && h->at_xcd && lead && fuse_upd && !h->comm && minres_lane < 0 && !h->ride_break;
     look = std::max(1, o.lookahead);
   }
@@ -2384,7 +2392,7 @@ struct KrylovRun {
   StepArgs step_after_a(int l) const {
     const Lane& L = lanes[l];
     if (L.kind == LANE_MINRES) return minres_step(STEP_MINRES_A, it);
-    return step_args(lane_kind_after_a(L), L, (int)it, h->pS2 + (size_t)l * h->strA, nbA,
+    return step_args(lane_kind_after_a(L), L, (int)it, pa_last + (size_t)l * h->strA, nbA,
                      L.kind == LANE_LNLQ ? nullptr : upd_part(l, it - 1), gm, prog[l]);
   }
   bool all_done() const {
@@ -2595,6 +2603,7 @@ struct KrylovRun {
     if (fuse_upd) {
       const StepArgs* pre = pre_args(false);
       launch_spmv<NL>(h, TAG_A, LP, SPcur, SPalt, c0(), c1(), h->pS2, cu[0], cu[1], false, pre);
+      pa_last = h->pS2;
       if (pre) adopt_pend();
       std::swap(SPcur, SPalt);
     } else {
@@ -2602,6 +2611,7 @@ struct KrylovRun {
       if (nlu == 2) launch_updates<NL>(h, lu[0], lu[1], seg_none());
       else launch_updates<NL>(h, lu[0], cu[0], cu[1]);
       launch_spmv<NL>(h, TAG_A, LP, SPcur, SPcur, c0(), c1(), h->pS2);
+      pa_last = h->pS2;
     }
     // A MINRES lane the host has SEEN finished (a zero right-hand side -- hprod! Val(1) on a model without curvature in the
     // constraints --, or an early convergence): its stand-alone launches would exit at once, ~3.5 us each; skipped.  One GPU
@@ -2685,7 +2695,7 @@ struct KrylovRun {
     ra.delay = h->ride_delay;
     rb = ra;
     rb.rec = h->ride_rec2;
-    rb.delay = 0;
+    rb.delay = h->ride_delay_mid;
     FuseArgs fz{};
     fz.blkflag = h->fz_flag;
     fz.ptag = h->fz_ptag;
@@ -2693,6 +2703,7 @@ struct KrylovRun {
     fz.want = ra.want;
     fz.pub = h->fuse_break ? ~ra.want : ra.want;
     fz.err = ra.err;
+    double* part_a = pa_last == h->pS2 ? h->pS2b : h->pS2;  // (not the array this launch's leaders read)
     const dim3 grid(kRideCand + fg.nwg_t + kRideCand + fg.nupd_t + 8 * fg.gpx + cu[0].nblk + cu[1].nblk);
     if (h->fuse_probe_at > 0 && h->fused_total + 1 == h->fuse_probe_at) {  // developer probe: this launch leaves time stamps
       h->fuse_probe_grid = (int)grid.x;
@@ -2704,16 +2715,17 @@ struct KrylovRun {
     }
     h->fused_total++;
     if (h->AT.sorted)
-      launch_product(h, k_iter_fused<true>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, h->pS2, h->strA, fg, lu[0],
+      launch_product(h, k_iter_fused<true>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, part_a, h->strA, fg, lu[0],
                      lu[1], cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
     else
-      launch_product(h, k_iter_fused<false>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, h->pS2, h->strA, fg, lu[0],
+      launch_product(h, k_iter_fused<false>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, part_a, h->strA, fg, lu[0],
                      lu[1], cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
     h->launches++;
     h->spmv_launches++;
     h->prod_a[1]++;
     h->prod_at[1]++;
     h->fused_launches++;
+    pa_last = part_a;
     // the lanes live in their third copies now; the other two are free for the next launch's two steps
     for (int l = 0; l < NL; ++l) {
       Lane& L = lanes[l];
@@ -3363,6 +3375,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_MINRES_MERGE")) h->minres_merge = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_ROTATE")) h->fuse_rotate = std::atoi(ev) & 7;
+  if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY_MID")) h->ride_delay_mid = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_FUSE_PROBE")) {
     h->fuse_probe_path = ev;
     h->fuse_probe_at = 100;

@@ -1125,6 +1125,10 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
                                                 double* red32, unsigned long long* st80, int* flag) {
   const int l = (c >> 3) & 1;
   const bool commit = (c & 7) == 0;
+  if (rb.delay != 0 && c == rb.delay - 1) {  // (tests: this mid leader starts ~100 us late, as behind another kernel's workgroups)
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(32);
+  }
   // 1. the state the head step leaves, recomputed; leaders 0 and 8 perform its side effects (progress word, final statistics,
   // the second copy of the state) -- here, ahead of the next step's, and not in the head leaders
   if (sh.kind != STEP_NONE) {

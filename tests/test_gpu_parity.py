@@ -1312,6 +1312,39 @@ def test_one_launch_iterations_are_bitwise_the_two_launch_iterations(monkeypatch
         assert np.array_equal(a_, b_), i
 
 
+@pytest.mark.parametrize("late", [0, 8, 3, 13])
+def test_one_launch_iterations_with_a_late_mid_leader(monkeypatch, late):
+    """The mid leaders of a fused launch publish per XCC, so the row groups of the other XCCs do not wait for a mid leader that
+    another kernel holds up -- and when they reach their epilogues they WRITE the A product's norm partials, which that late
+    leader, still redoing the head step, reads as the partials of the PREVIOUS A product.  The A partials therefore alternate
+    between two arrays from launch to launch.  FPSQ_DEBUG_RIDE_DELAY_MID=c+1 holds mid leader c back by ~100 us (a committing
+    one of either lane, two publishing-only ones): bitwise the two-launch iteration."""
+    qp = problems.pde_control_like(n=300000, m=30000, seed=43)
+    rng = np.random.default_rng(16)
+    xs = [qp.xhat + 0.3 * 0.5 ** k * rng.standard_normal(qp.n) for k in range(3)]
+
+    def run(expect_fused):
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+        out, fused = [], 0
+        for x in xs:
+            gx, ys, gs = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys, gs=gs)
+            fused += dev.info()["last_fused_launches"]
+            out += [np.array([f, rc, dev.stats[0].niter, dev.stats[1].niter, dev.stats[0].rnorm, dev.stats[1].rnorm]), gx, ys, gs]
+        dev.close()
+        assert (fused > 0) == expect_fused
+        return out
+
+    monkeypatch.setenv("FPSQ_AT_ROW_ALIGN", "8")
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "0")
+    want = run(False)
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
+    monkeypatch.setenv("FPSQ_DEBUG_RIDE_DELAY_MID", str(late + 1))
+    got = run(True)
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+
+
 @pytest.mark.parametrize("rot", [1, 3, 4])
 def test_one_launch_iterations_with_every_hand_over_across_xcds(monkeypatch, rot):
     """Both products of a fused launch walk XCD-contiguous eighths, so most rows a row group gathers were written on its own
