@@ -3024,7 +3024,11 @@ bool ride_failed(fpsq_handle h) {
   volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(h->hscal + 15);
   if (*w == 0) return false;
   *w = 0;
-  h->err = "riding scalar steps: the leaders' record did not arrive (bounded wait expired); FPSQ_RIDE_LEAD=0 avoids the path";
+  h->err = "a bounded wait inside a product launch expired (the leaders' record did not arrive, or -- one-launch iterations -- a block's "
+           "flag / partials did not): FPSQ_FUSE_ITER=0 keeps two launches per iteration, FPSQ_RIDE_LEAD=0 the stand-alone steps";
+  // (something else held the device for longer than the bound: this handle goes on with two launches per iteration, whose
+  // waits involve the leaders only)
+  if (h->fused_launches > 0) h->fuse_ok = false;
   return true;
 }
 

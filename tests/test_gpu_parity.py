@@ -1498,7 +1498,8 @@ def test_one_launch_iteration_bounded_waits_end_in_an_error_not_a_hang(monkeypat
     """Every wait of the fused launch has an end each wave reaches: with the A' blocks made to publish a wrong launch number
     (FPSQ_DEBUG_FUSE_BREAK=1) the row groups give up on their flags and the mid leaders on the tagged partials after their
     bounded numbers of looks, whoever waits for the mid leaders' record after its own; the handle's error word is raised and
-    the call returns FPSQ_ERR_TIMEOUT (-5) with a message, within seconds.  A fresh handle without the switch works."""
+    the call returns FPSQ_ERR_TIMEOUT (-5) with a message, within seconds; the handle then keeps two launches per iteration.
+    A fresh handle without the switch works (and fuses)."""
     import time
     qp = _small_pde(seed=5, n=60000, m=6000)
     monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
@@ -1510,11 +1511,15 @@ def test_one_launch_iteration_bounded_waits_end_in_an_error_not_a_hang(monkeypat
         dev.objgrad(qp.x, gx=gx)
     assert time.perf_counter() - t0 < 60.0
     assert "bounded wait" in str(ei.value)
+    # the handle itself goes on with two launches per iteration (whose waits involve the leaders only): the next call works
+    f, rc = dev.objgrad(qp.x, gx=gx)
+    assert np.all(np.isfinite(gx)) and dev.info()["last_fused_launches"] == 0
     dev.close()
     monkeypatch.setenv("FPSQ_DEBUG_FUSE_BREAK", "0")
     dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
-    f, rc = dev.objgrad(qp.x, gx=gx)
-    assert rc == 0 and np.all(np.isfinite(gx)) and dev.info()["last_fused_launches"] > 0
+    gx2 = np.empty(qp.n)
+    f2, rc = dev.objgrad(qp.x, gx=gx2)
+    assert rc == 0 and np.all(np.isfinite(gx2)) and dev.info()["last_fused_launches"] > 0
     dev.close()
 
 
