@@ -684,6 +684,7 @@ struct fpsq_solver_s {
   int fuse_rotate = 0;          // FPSQ_DEBUG_FUSE_ROTATE=r (tests): the A' blocks of eighth e are written on XCD (e - r) & 7, gathered on XCD e
   bool minres_merge = true;     // MINRES lane: stage E1, step A and stage E2 as one launch (k_minres_mid; FPSQ_MINRES_MERGE=0: three)
   unsigned long long* mm_ptag = nullptr;  // its tagged partials (two words per element-wise workgroup)
+  bool fuse_fell_back = false;  // an expired wait of a fused launch has just switched the handle to two launches per iteration
   bool fuse_break = false;      // FPSQ_DEBUG_FUSE_BREAK=1 (tests): the A' blocks of a fused launch publish a wrong number, every wait for them expires
   int fuse_iter = 1;            // 0: never; 1: where it pays (setup_fused_iteration); 2: wherever it is possible (tests)
   bool fuse_ok = false;
@@ -3028,7 +3029,10 @@ bool ride_failed(fpsq_handle h) {
            "flag / partials did not): FPSQ_FUSE_ITER=0 keeps two launches per iteration, FPSQ_RIDE_LEAD=0 the stand-alone steps";
   // (something else held the device for longer than the bound: this handle goes on with two launches per iteration, whose
   // waits involve the leaders only)
-  if (h->fused_launches > 0) h->fuse_ok = false;
+  if (h->fused_launches > 0 && h->fuse_ok) {
+    h->fuse_ok = false;
+    h->fuse_fell_back = true;  // (the entry point repeats the call once: with_fuse_fallback)
+  }
   return true;
 }
 
@@ -3301,6 +3305,25 @@ int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2, 
 }  // namespace
 
 // ===================================================================================== C ABI
+
+// One-launch iterations assume that this process has the device's workgroup slots to itself: their waiting workgroups hold slots
+// that the workgroups they wait for may still need, which cannot deadlock inside one process (dependences point to earlier
+// workgroups of the same grid) but can stall for longer than the bounds when OTHER processes fill the device with waiting
+// workgroups of their own (seen with three ranks rehearsed on one GPU, each timing an unsharded handle).  Such a call ends
+// in FPSQ_ERR_TIMEOUT, every kernel gone; the handle then keeps two launches per iteration (ride_failed) and the call is
+// REPEATED once -- its inputs are untouched -- so the caller only sees the delay.
+template <class F>
+int with_fuse_fallback(fpsq_handle h, F&& call) {
+  int rc = call();
+  if (rc == FPSQ_ERR_TIMEOUT && h && h->fuse_fell_back) {
+    h->fuse_fell_back = false;
+    std::fprintf(stderr, "fpsq: a bounded wait of a one-launch iteration expired (is the GPU shared with other processes?); this handle "
+                         "continues with two launches per iteration, the call is repeated\n");
+    rc = call();
+  }
+  if (h) h->fuse_fell_back = false;
+  return rc;
+}
 
 extern "C" {
 
@@ -3714,7 +3737,7 @@ int fpsq_set_delta(fpsq_handle h, double delta) {
   return FPSQ_OK;
 }
 
-int fpsq_solve_two_mixed(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1, double* p2,
+static int impl_solve_two_mixed(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1, double* p2,
                          double* q2, fpsq_stats st[2]) {
   if (int rc = check_ready(h)) return rc;
   if (!rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2 || !st) {
@@ -3739,7 +3762,7 @@ int fpsq_solve_two_mixed(fpsq_handle h, const double* rhs1, const double* rhs2, 
   return soft_rc(st);
 }
 
-int fpsq_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1,
+static int impl_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1,
                                  double* p2, double* q2, fpsq_stats st[2]) {
   if (int rc = check_ready(h)) return rc;
   if (!rhs1 || !rhs2 || !p1 || !q1 || !p2 || !q2 || !st) {
@@ -3764,7 +3787,7 @@ int fpsq_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double
   return soft_rc(st);
 }
 
-int fpsq_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2, double* out1, double* out2,
+static int impl_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2, double* out1, double* out2,
                           fpsq_stats st[2]) {
   if (int rc = check_ready(h)) return rc;
   if (!rhs1 || !rhs2 || !out1 || !out2 || !st) {
@@ -3894,7 +3917,7 @@ __global__ __launch_bounds__(kBlock) void k_qp_fx(const FxArgs a, const LaneCtl*
 
 extern "C" {
 
-int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, double rho, double eta,
+static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, double rho, double eta,
                     const double* xk, double* fx, double* gx, double* ys, double* gs, fpsq_stats st[2]) {
   if (h && h->ab_dynamic)
     if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
@@ -4073,7 +4096,7 @@ int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, do
   return soft_rc(st);
 }
 
-int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta,
+static int impl_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta,
                   int32_t hessian_approx, double* Hv, fpsq_stats* st) {
   if (int rc = check_ready(h)) return rc;
   if (!qp || qp->h != h || !v || !Hv || !st || (hessian_approx != 1 && hessian_approx != 2)) {
@@ -4304,4 +4327,25 @@ int fpsq_set_profiling(fpsq_handle h, int32_t on) {
   return FPSQ_OK;
 }
 
+// the solve entries, each repeated once on two launches per iteration when a one-launch iteration ran into a bounded wait
+int fpsq_solve_two_mixed(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1, double* p2,
+                         double* q2, fpsq_stats st[2]) {
+  return with_fuse_fallback(h, [&]() { return impl_solve_two_mixed(h, rhs1, rhs2, p1, q1, p2, q2, st); });
+}
+int fpsq_solve_two_least_squares(fpsq_handle h, const double* rhs1, const double* rhs2, double* p1, double* q1,
+                                 double* p2, double* q2, fpsq_stats st[2]) {
+  return with_fuse_fallback(h, [&]() { return impl_solve_two_least_squares(h, rhs1, rhs2, p1, q1, p2, q2, st); });
+}
+int fpsq_solve_two_extras(fpsq_handle h, const double* rhs1, const double* rhs2, double* out1, double* out2,
+                          fpsq_stats st[2]) {
+  return with_fuse_fallback(h, [&]() { return impl_solve_two_extras(h, rhs1, rhs2, out1, out2, st); });
+}
+int fpsq_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double sigma, double rho, double eta,
+                    const double* xk, double* fx, double* gx, double* ys, double* gs, fpsq_stats st[2]) {
+  return with_fuse_fallback(h, [&]() { return impl_qp_objgrad(h, qp, x, sigma, rho, eta, xk, fx, gx, ys, gs, st); });
+}
+int fpsq_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigma, double rho, double eta,
+                  int32_t hessian_approx, double* Hv, fpsq_stats* st) {
+  return with_fuse_fallback(h, [&]() { return impl_qp_hprod(h, qp, v, sigma, rho, eta, hessian_approx, Hv, st); });
+}
 }  // extern "C"

@@ -835,6 +835,18 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo_finish(P2PHalo H, unsigned 
   }
   b -= 2 * kHaloCopy;
   const int nb = (int)gridDim.x - 2 * kHaloCopy;
+  // The wait comes FIRST and is unconditional -- also when the recurrences have ended or a gate is closed and there is
+  // nothing to finish: it is what paces the ranks.  A launch that ended without it would let this rank's NEXT push go out
+  // while a slower neighbour is still reading the slot of the same parity (the first build returned early here: a rare wrong
+  // last iteration with three ranks sharing one GPU; k_p2p_halo, the two-launch form, has always waited unconditionally).
+  if (threadIdx.x == 0) {
+    bool in = true;
+    if (H.my_from_left) in = p2p_wait(H.my_from_left, seq, max_spins, fail);
+    if (in && H.my_from_right) in = p2p_wait(H.my_from_right, seq, max_spins, fail);
+    ok = in ? 1 : 0;
+  }
+  __syncthreads();
+  if (!ok) return;
   if (a.gate0 != nullptr && !(a.gate0->done && a.gate1->done)) return;
   const LaneCtl* c[2] = {a.ctl0, a.ctl1};
   bool act[NL];
@@ -848,14 +860,6 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo_finish(P2PHalo H, unsigned 
     any |= act[l];
   }
   if (!any) return;
-  if (threadIdx.x == 0) {
-    bool in = true;
-    if (H.my_from_left) in = p2p_wait(H.my_from_left, seq, max_spins, fail);
-    if (in && H.my_from_right) in = p2p_wait(H.my_from_right, seq, max_spins, fail);
-    ok = in ? 1 : 0;
-  }
-  __syncthreads();
-  if (!ok) return;
   __shared__ double red[4];
   double sq[NL];
 #pragma unroll
