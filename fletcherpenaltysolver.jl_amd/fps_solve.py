@@ -45,10 +45,11 @@ class AlgoData:
     subpb_unbounded_threshold: float = 1.0 / _SE
     lagrange_bound: float = 1.0 / _SE
     hessian_approx: int = 2
-    # key of qdsolver_correspondence.  The reference's default is :ldlt (parameters.jl:290); here "auto" = the device's direct
+    # key of qdsolver_correspondence: the reference's default :ldlt (parameters.jl:290).  On the device "ldlt" = the direct
     # back-end ("hip_ldlt") whenever the normal equations have a narrow band (every small model does), the iterative one
-    # ("hip") otherwise -- see qdsolver.AutoQDSolver.  "hip_direct": the dense direct back-end.
-    qds_solver: str = "auto"
+    # ("hip" = "iterative") otherwise -- qdsolver.AutoQDSolver; which one ran is in stats.solver_specific["qds_backend"].
+    # "hip_direct": the dense direct back-end.
+    qds_solver: str = "ldlt"
     subproblem_solver: str = "lbfgs"
 
 
@@ -413,7 +414,8 @@ def feasibility_step(nlp, x, cx, rho, ctol, *, eta1=1e-3, eta2=0.66, sigma1=0.25
 def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0, verbose=0, qds=None, callback=None,
               **kwargs):
     """stats = fps_solve(nlp, x0; kwargs...)   (src/FletcherPenaltySolver.jl:127-186 -> src/algo.jl:26-288).
-    Keyword arguments are the fields of `AlgoData`; `qds` overrides the back-end instance.  `callback(nlp, pen, stats)` is
+    Keyword arguments are the fields of `AlgoData`, the others go to the back-end's constructor (parameters.jl:299: e.g.
+    `ldlt_r2`); `qds` overrides the back-end instance.  `callback(nlp, pen, stats)` is
     called before the first and after every outer iteration (algo.jl:109, :283) with the running statistics (solution,
     objective, residuals, multipliers, iter); setting `stats.status = "user"` stops the loop."""
     meta = AlgoData(**{k: v for k, v in kwargs.items() if k in AlgoData.__dataclass_fields__})
@@ -438,10 +440,18 @@ def fps_solve(nlp, x0=None, *, atol=_SE, rtol=_SE, max_iter=100, max_time=300.0,
         nlp = SlackModel(nlp)
     if has_bounds(nlp):
         x = np.minimum(np.maximum(x, nlp.meta.lvar), nlp.meta.uvar)
-    qds = qds if qds is not None else qdsolver_correspondence[meta.qds_solver](nlp, 0.0)
+    # src/parameters.jl:299: the back-end's constructor receives the keyword arguments that are not AlgoData's
+    # (LDLtSolver's ldlt_tol / ldlt_r1 / ldlt_r2, IterativeSolver's tolerances)
+    qkw = {k: v for k, v in kwargs.items() if k not in AlgoData.__dataclass_fields__}
+    qds = qds if qds is not None else qdsolver_correspondence[meta.qds_solver](nlp, 0.0, **qkw)
     fp = FletcherPenaltyNLP(nlp, sigma=meta.sigma_0, rho=meta.rho_0, delta=0.0, hessian_approx=meta.hessian_approx,
                             x0=x, qds=qds)                                                     # algo.jl:45-52
     stats = _outer_loop(_HostPenalty(fp, nlp), x, meta, atol, rtol, max_iter, max_time, verbose, callback)
+    # which back-end served the seam (a registry key may route: "ldlt" -> the banded direct or the iterative one)
+    stats.solver_specific["qds_solver"] = meta.qds_solver
+    stats.solver_specific["qds_backend"] = getattr(qds, "qds_backend", type(qds).__name__)
+    if getattr(qds, "ldlt_r2", None) is not None:
+        stats.solver_specific["ldlt_r2"] = qds.ldlt_r2
     if nlp is not orig:                                                          # :153-170: back to the user's variables
         stats.solver_specific["slack"] = stats.solution[orig.meta.nvar:].copy()
         stats.solution = stats.solution[: orig.meta.nvar].copy()

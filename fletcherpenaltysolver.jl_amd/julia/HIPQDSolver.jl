@@ -138,7 +138,7 @@ mutable struct HIPLDLtSolver{T, S} <: QDSolver
 end
 
 function HIPLDLtSolver(nlp::AbstractNLPModel{T, S}, ::T; explicit_linear_constraints = false,
-                       ldlt_tol = √eps(T), ldlt_r1 = √eps(T), ldlt_r2 = -1e200 #= FPSQ_REG_DROP: a vanishing pivot of M is dropped; pass -√eps(T) for LDLFactorizations' value (include/fpsq.h) =#, kwargs...) where {T, S}
+                       ldlt_tol = √eps(T), ldlt_r1 = √eps(T), ldlt_r2 = -√eps(T) #= struct.jl:314, the reference's default; ldlt_r2 = -1e200 (FPSQ_REG_DROP, include/fpsq.h) drops a vanishing pivot of M instead =#, kwargs...) where {T, S}
   T == Float64 || error("HIPLDLtSolver is fp64 only")
   nvar = nlp.meta.nvar
   ncon = explicit_linear_constraints ? nlp.meta.nnln : nlp.meta.ncon

@@ -44,6 +44,18 @@ def _coord_values(vals):
 
 REG_DROP = 1e200  # include/fpsq.h FPSQ_REG_DROP: a vanishing pivot of M is dropped (its multiplier comes out as zero)
 
+
+def _ldlt_r2(ldlt_r2):
+    """`ldlt_r2` of `LDLtSolver` (src/solve_two_systems_struct.jl:314): the reference's default -sqrt(eps) when omitted;
+    "drop" (or any value <= -REG_DROP) asks for the drop rule of include/fpsq.h instead."""
+    if ldlt_r2 is None:
+        return -float(np.sqrt(np.finfo(float).eps))
+    if isinstance(ldlt_r2, str):
+        if ldlt_r2 != "drop":
+            raise ValueError('ldlt_r2: a number or "drop"')
+        return -REG_DROP
+    return float(ldlt_r2)
+
 class FpsqError(RuntimeError):
     pass
 
@@ -172,14 +184,16 @@ class HIPDirectQDSolver(QDSolver):
     Keywords of `LDLtSolver` (struct.jl:308-316): ldlt_tol (sqrt(eps)) and ldlt_r2 drive the DYNAMIC REGULARISATION of
     the factorisation; ldlt_r1 concerns the identity block of K, whose pivots are 1 and never regularised.  A pivot of M
     not above ldlt_tol marks a constraint row that depends linearly on the earlier ones at working precision.
-    * ldlt_r2 given: the pivot is replaced by -ldlt_r2 -- the value LDLFactorizations.jl puts in the (2,2) block of K.
-    * ldlt_r2 = None (default): the pivot is DROPPED (replaced by FPSQ_REG_DROP = 1e200: that row's multiplier comes out
-      as zero, the basic solution of the consistent normal equations).  The reference's -sqrt(eps) acts on pivots of K in a
-      fill-reducing order (on FLT, test/test-2.jl:264-287, AMD eliminates both constraint nodes first, which amounts to the
-      uniform shift M + sqrt(eps) I); the same number on a pivot of M in natural order is NOT the same rule, and either way
-      the multiplier estimates grow like 1 / sqrt(eps) on an inconsistent right-hand side (phi ~ 1e10 at FLT's x0: the
-      Newton-CG sub-solver crawls).  Dropping keeps them bounded like the exact back-end's minimum-norm solve; all of
-      test-2.jl and rank-deficient.jl then pass with every sub-solver.  Dense storage: m <= 65536."""
+    * ldlt_r2 (default -sqrt(eps), the reference's `LDLtSolver` default, struct.jl:314): the pivot is replaced by -ldlt_r2 --
+      the value LDLFactorizations.jl puts in the (2,2) block of K.
+    * ldlt_r2 = "drop" (or -REG_DROP): the pivot is DROPPED instead (FPSQ_REG_DROP = 1e200: that row's multiplier comes out
+      as zero, the basic solution of the consistent normal equations).  An OPTION, not the default: the reference's
+      -sqrt(eps) acts on pivots of K in a fill-reducing order (on FLT, test/test-2.jl:264-287, AMD eliminates both
+      constraint nodes first, which amounts to the uniform shift M + sqrt(eps) I); the same number on a pivot of M in
+      natural order is not the same rule, and either way the multiplier estimates grow like 1 / sqrt(eps) on an
+      inconsistent right-hand side (phi ~ 1e10 at FLT's x0: a Newton-CG sub-solver crawls).  Dropping keeps them bounded
+      like the exact back-end's minimum-norm solve.
+    Dense storage: m <= 65536."""
 
     def __init__(self, nlp, _zero=0.0, *, explicit_linear_constraints=False, ldlt_tol=None, ldlt_r1=None, ldlt_r2=None,
                  **kwargs):
@@ -202,7 +216,7 @@ class HIPDirectQDSolver(QDSolver):
         self.factorized = False
         se = float(np.sqrt(np.finfo(float).eps))
         self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)        # struct.jl:312
-        self.ldlt_r2 = -REG_DROP if ldlt_r2 is None else float(ldlt_r2)    # struct.jl:314 (None: drop, see the docstring)
+        self.ldlt_r2 = _ldlt_r2(ldlt_r2)                                   # struct.jl:314: -sqrt(eps) unless given ("drop": see the docstring)
         self._check(self._lib.fpsq_dense_set_regularization(self._d, self.ldlt_tol, -self.ldlt_r2))
         self._fact_key = None
         self._owed = self._mixed_at = None
@@ -315,7 +329,7 @@ class HIPBandedDirectQDSolver(QDSolver):
         self._b = b
         se = float(np.sqrt(np.finfo(float).eps))
         self.ldlt_tol = se if ldlt_tol is None else float(ldlt_tol)
-        self.ldlt_r2 = -REG_DROP if ldlt_r2 is None else float(ldlt_r2)    # (None: drop, see HIPDirectQDSolver)
+        self.ldlt_r2 = _ldlt_r2(ldlt_r2)                                   # (struct.jl:314; "drop": see HIPDirectQDSolver)
         self._check(self._lib.fpsq_band_set_regularization(b, self.ldlt_tol, -self.ldlt_r2))
         self._owed = self._mixed_at = None
         self.factorized = False
@@ -414,21 +428,31 @@ def band_analysis(nlp, explicit_linear_constraints=False):
 
 
 def AutoQDSolver(nlp, _zero=0.0, *, explicit_linear_constraints=False, **kwargs):
-    """`qdsolver_correspondence["auto"]` -- the default of `fps_solve`.  The reference defaults to its direct back-end
-    (`qds_solver = :ldlt`, src/parameters.jl:290), whose general sparse LDL' copes with any pattern; on the device the direct
-    route is the block-banded factorisation of M = A A' + delta I ("hip_ldlt"), which is exact AND fast only when that band
-    is narrow (small models, grid / PDE-like Jacobians: cfg4 runs at 295 evaluations/s there against 206, unsolved, on the
-    iterative path), and falls off an O(m^3) cliff when the band is full (cfg2: the random Jacobian makes A A' dense).  So:
-    direct when the symbolic phase reports a half bandwidth <= AUTO_MAX_BAND_BLOCKS blocks and <= AUTO_MAX_BLOCKS blocks
-    (chain length), the iterative back-end ("hip", the reference's `:iterative`) otherwise.  `"hip_ldlt"` forces the
-    reference's default behaviour, `"hip"` the matrix-free one."""
+    """`qdsolver_correspondence["ldlt"]` -- the reference's key and DEFAULT (`qds_solver = :ldlt`, src/parameters.jl:290), hence
+    the default of `fps_solve` here (also registered as "auto").  The reference's general sparse LDL' copes with any
+    pattern; on the device the direct route is the block-banded factorisation of M = A A' + delta I ("hip_ldlt"), which is
+    exact AND fast only when that band is narrow (small models, grid / PDE-like Jacobians: cfg4 runs at 295 evaluations/s
+    there against 206, unsolved, on the iterative path), and falls off an O(m^3) cliff when the band is full (cfg2: the
+    random Jacobian makes A A' dense).  So: direct when the symbolic phase reports a half bandwidth <=
+    AUTO_MAX_BAND_BLOCKS blocks and <= AUTO_MAX_BLOCKS blocks (chain length), the iterative back-end ("hip" = "iterative",
+    the reference's `:iterative`) otherwise.  WHICH one was taken is on record: the solver object carries
+    `qds_backend` ("hip_ldlt" | "hip") and `qds_routed_from`, and `fps_solve` copies both into
+    `stats.solver_specific`.  `"hip_ldlt"` forces the direct factorisation whatever the band, `"hip"` the matrix-free one."""
     info = band_analysis(nlp, explicit_linear_constraints)
+    q = None
     if info is not None and info["bandwidth_blocks"] <= AUTO_MAX_BAND_BLOCKS and info["nblocks"] <= AUTO_MAX_BLOCKS:
         try:
-            return HIPBandedDirectQDSolver(nlp, _zero, explicit_linear_constraints=explicit_linear_constraints, **kwargs)
+            q = HIPBandedDirectQDSolver(nlp, _zero, explicit_linear_constraints=explicit_linear_constraints, **kwargs)
         except FpsqError:
-            pass   # (does not fit the device after all)
-    return HIPQDSolver(nlp, _zero, explicit_linear_constraints=explicit_linear_constraints, **kwargs)
+            q = None   # (does not fit the device after all)
+    if q is None:
+        kw = {k: v for k, v in kwargs.items() if not k.startswith("ldlt_")}   # (LDLtSolver's keywords mean nothing to Krylov)
+        q = HIPQDSolver(nlp, _zero, explicit_linear_constraints=explicit_linear_constraints, **kw)
+    q.qds_backend = "hip_ldlt" if isinstance(q, HIPBandedDirectQDSolver) else "hip"
+    q.qds_routed_from = "ldlt"
+    return q
 
 
-qdsolver_correspondence["auto"] = AutoQDSolver
+qdsolver_correspondence["ldlt"] = AutoQDSolver        # src/parameters.jl:197: the reference's :ldlt (its default, :290)
+qdsolver_correspondence["auto"] = AutoQDSolver        # (the name of rounds 3-4)
+qdsolver_correspondence["iterative"] = HIPQDSolver    # src/parameters.jl:197: the reference's :iterative

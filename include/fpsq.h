@@ -295,7 +295,7 @@ int fpsq_dense_factorize(fpsq_dense d, double delta, int32_t *info);
  * reg = FPSQ_REG_DROP drops the pivot instead: the row counts as linearly dependent on the earlier ones, its multiplier comes
  * out as (numerically) zero and the other rows solve the consistent part of the normal equations -- multiplier estimates
  * stay bounded on rank-deficient Jacobians (test/test-2.jl:264-287 FLT), where a pivot of sqrt(eps) makes them ~ 1/sqrt(eps).
- * The host bindings use it when the caller gives no ldlt_r2. */
+ * The host bindings default to the reference's ldlt_r2 = -sqrt(eps) (reg = sqrt(eps)); the drop rule is their explicit option. */
 #define FPSQ_REG_DROP 1e200
 int fpsq_dense_set_regularization(fpsq_dense d, double tol, double reg);
 int fpsq_dense_solve_two_mixed(fpsq_dense d, const double *rhs1, const double *rhs2, double *p1, double *q1, double *p2,

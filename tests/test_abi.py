@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 import fps_amd  # noqa: F401
@@ -120,9 +121,10 @@ def test_band_symbolic_phase_on_the_host():
 
 
 def test_auto_backend_choice_follows_the_band(monkeypatch):
-    """qdsolver_correspondence["auto"] (fps_solve's default; the reference's default is :ldlt, parameters.jl:290): the banded
-    direct back-end when the symbolic phase (fpsq_band_analyze: host only) reports a narrow band of A A', the iterative one
-    otherwise.  The constructors are stubbed: no device is needed for the decision."""
+    """qdsolver_correspondence["ldlt"] -- the reference's key and default (parameters.jl:197, :290), fps_solve's default here
+    too ("auto" is the same entry): the banded direct back-end when the symbolic phase (fpsq_band_analyze: host only)
+    reports a narrow band of A A', the iterative one otherwise, and the object says which.  "iterative" is the reference's
+    other key.  The constructors are stubbed: no device is needed for the decision."""
     import fps_amd  # noqa: F401
     from fps_amd import nlpmodels, problems, qdsolver
 
@@ -132,17 +134,46 @@ def test_auto_backend_choice_follows_the_band(monkeypatch):
     assert a["bandwidth_blocks"] <= qdsolver.AUTO_MAX_BAND_BLOCKS and a["nblocks"] == (grid.meta.ncon + 127) // 128
     assert r["bandwidth_blocks"] == r["nblocks"] - 1 > qdsolver.AUTO_MAX_BAND_BLOCKS
     made = []
-    monkeypatch.setattr(qdsolver, "HIPBandedDirectQDSolver", lambda nlp, z, **kw: made.append("hip_ldlt") or "direct")
-    monkeypatch.setattr(qdsolver, "HIPQDSolver", lambda nlp, z, **kw: made.append("hip") or "iterative")
-    assert qdsolver.qdsolver_correspondence["auto"](grid, 0.0) == "direct"
-    assert qdsolver.qdsolver_correspondence["auto"](rnd, 0.0) == "iterative"
-    assert qdsolver.qdsolver_correspondence["auto"](nlpmodels.HS6(), 0.0) == "direct"   # every small model goes direct
-    assert made == ["hip_ldlt", "hip", "hip_ldlt"]
 
-    def refuse(nlp, z, **kw):
-        raise qdsolver.FpsqError("does not fit")
+    class Direct:
+        def __init__(self, nlp, z, **kw):
+            made.append(("hip_ldlt", kw))
 
-    monkeypatch.setattr(qdsolver, "HIPBandedDirectQDSolver", refuse)   # the device says no after all: iterative
-    assert qdsolver.qdsolver_correspondence["auto"](grid, 0.0) == "iterative"
+    class Iterative:
+        def __init__(self, nlp, z, **kw):
+            made.append(("hip", kw))
+
+    monkeypatch.setattr(qdsolver, "HIPBandedDirectQDSolver", Direct)
+    monkeypatch.setattr(qdsolver, "HIPQDSolver", Iterative)
+    reg = qdsolver.qdsolver_correspondence
+    assert reg["ldlt"] is reg["auto"] and {"ldlt", "iterative", "hip", "hip_ldlt", "hip_direct"} <= set(reg)
+    q = reg["ldlt"](grid, 0.0)
+    assert isinstance(q, Direct) and q.qds_backend == "hip_ldlt" and q.qds_routed_from == "ldlt"
+    q = reg["ldlt"](rnd, 0.0, ldlt_r2=-1e-8)
+    assert isinstance(q, Iterative) and q.qds_backend == "hip"
+    assert isinstance(reg["auto"](nlpmodels.HS6(), 0.0), Direct)   # every small model goes direct
+    assert [k for k, _ in made] == ["hip_ldlt", "hip", "hip_ldlt"]
+    assert "ldlt_r2" not in made[1][1]   # (LDLtSolver's keywords are not handed to the Krylov back-end)
+
+    class Refuse:
+        def __init__(self, nlp, z, **kw):
+            raise qdsolver.FpsqError("does not fit")
+
+    monkeypatch.setattr(qdsolver, "HIPBandedDirectQDSolver", Refuse)   # the device says no after all: iterative
+    assert isinstance(reg["ldlt"](grid, 0.0), Iterative)
     from fps_amd.fps_solve import AlgoData
-    assert AlgoData().qds_solver == "auto"
+    assert AlgoData().qds_solver == "ldlt"   # src/parameters.jl:290
+
+
+def test_ldlt_r2_defaults_to_the_reference_value():
+    """`LDLtSolver(...; ldlt_r2 = -sqrt(eps))` (src/solve_two_systems_struct.jl:314) is the default of both direct back-ends;
+    dropping a vanishing pivot (include/fpsq.h FPSQ_REG_DROP) is the explicit option "drop"."""
+    import fps_amd  # noqa: F401
+    from fps_amd import qdsolver
+
+    se = float(np.sqrt(np.finfo(float).eps))
+    assert qdsolver._ldlt_r2(None) == -se
+    assert qdsolver._ldlt_r2(-1e-6) == -1e-6
+    assert qdsolver._ldlt_r2("drop") == -qdsolver.REG_DROP
+    with pytest.raises(ValueError):
+        qdsolver._ldlt_r2("shift")

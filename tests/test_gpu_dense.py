@@ -449,19 +449,18 @@ def test_direct_backends_restore_the_delta_factor_lazily_after_extras(oracle, na
     the reference's extras never touch its LDL' factors (linear_system.jl:142-159, :194-195).  Restored lazily (one extra
     factorisation per Val(1) product, not two: advisor, round 3): the least-squares solves before and after an extras call
     are bitwise equal, two extras calls in a row factorise once, and both agree with the exact solves.
-    Also pinned here: the DEFAULT regularisation of these back-ends drops a vanishing pivot (FPSQ_REG_DROP; the reference's
-    LDLtSolver default is r2 = -sqrt(eps), struct.jl:314 -- stated in INTEGRATION.md), an explicit ldlt_r2 restores the
-    reference's value."""
+    Also pinned here: the DEFAULT regularisation of these back-ends is the reference's (LDLtSolver: r2 = -sqrt(eps),
+    src/solve_two_systems_struct.jl:314); dropping a vanishing pivot (FPSQ_REG_DROP) is the explicit option "drop"."""
     from fps_amd import problems
     from fps_amd.qdsolver import REG_DROP, qdsolver_correspondence
 
     qp = problems.pde_control_like(n=5000, m=500, per_row=20, window=512, seed=4)
     model = nlpmodels.EqQPModel(qp)
     qds = qdsolver_correspondence[name](model, 0.0)
-    assert qds.ldlt_r2 == -REG_DROP
-    ref = qdsolver_correspondence[name](model, 0.0, ldlt_r2=-float(np.sqrt(np.finfo(float).eps)))
-    assert ref.ldlt_r2 == -float(np.sqrt(np.finfo(float).eps))   # src/solve_two_systems_struct.jl:314
-    ref.close()
+    assert qds.ldlt_r2 == -float(np.sqrt(np.finfo(float).eps))   # src/solve_two_systems_struct.jl:314
+    drop = qdsolver_correspondence[name](model, 0.0, ldlt_r2="drop")
+    assert drop.ldlt_r2 == -REG_DROP
+    drop.close()
     fp = FletcherPenaltyNLP(model, 1e3, 1.0, 0.0, 1, qds=qds)
     rng = np.random.default_rng(2)
     g, c = rng.standard_normal(qp.n), rng.standard_normal(qp.m)

@@ -162,10 +162,10 @@ def test_fps_solve_through_the_banded_direct_backend(sub, ha):
     assert np.linalg.norm(stats.multipliers - lam) <= 1e-5 * max(1.0, np.linalg.norm(lam))
 
 
-def test_default_backend_is_auto_and_goes_direct_on_small_models():
-    """fps_solve without `qds_solver`: "auto" (the reference's default is its direct back-end, parameters.jl:290) -- the
-    banded direct back-end on every small model (exact: the reference's acceptance bounds AND its LDLt-level accuracy), the
-    iterative one where A A' has no narrow band."""
+def test_default_backend_is_ldlt_and_goes_direct_on_small_models():
+    """fps_solve without `qds_solver`: the reference's default key "ldlt" (parameters.jl:290) with the reference's
+    ldlt_r2 = -sqrt(eps) (struct.jl:314) -- the banded direct back-end on every small model (exact: the reference's
+    acceptance bounds AND its LDLt-level accuracy), the iterative one where A A' has no narrow band; the statistics say which."""
     from fps_amd import problems
     from fps_amd.qdsolver import HIPBandedDirectQDSolver, HIPQDSolver, qdsolver_correspondence
 
@@ -173,14 +173,16 @@ def test_default_backend_is_auto_and_goes_direct_on_small_models():
     stats = fps_solve(nlp, nlp.meta.x0)
     _accept(stats, nlp.meta.x0)
     assert np.linalg.norm(stats.solution - np.array([1.0, 1.0])) < 1e-5
-    q = qdsolver_correspondence["auto"](nlp, 0.0)
-    assert isinstance(q, HIPBandedDirectQDSolver)
+    assert stats.solver_specific["qds_solver"] == "ldlt" and stats.solver_specific["qds_backend"] == "hip_ldlt"
+    assert stats.solver_specific["ldlt_r2"] == -float(np.sqrt(np.finfo(float).eps))
+    q = qdsolver_correspondence["ldlt"](nlp, 0.0)
+    assert isinstance(q, HIPBandedDirectQDSolver) and q.qds_backend == "hip_ldlt"
     q.close()
     q = qdsolver_correspondence["auto"](nlpmodels.EqQPModel(problems.aug2dc_like(N=40)), 0.0)   # cfg4's family
     assert isinstance(q, HIPBandedDirectQDSolver) and q.info()["bandwidth_blocks"] <= 4
     q.close()
-    q = qdsolver_correspondence["auto"](nlpmodels.EqQPModel(problems.random_eqqp(n=20000, m=2000)), 0.0)  # cfg2's family
-    assert isinstance(q, HIPQDSolver)
+    q = qdsolver_correspondence["ldlt"](nlpmodels.EqQPModel(problems.random_eqqp(n=20000, m=2000)), 0.0)  # cfg2's family
+    assert isinstance(q, HIPQDSolver) and q.qds_backend == "hip"
     q.close()
 
 
