@@ -40,7 +40,9 @@ class Info(C.Structure):
                 ("last_solve_ms", C.c_double), ("last_spmv_ms", C.c_double),
                 ("last_spmv_launches", C.c_int64), ("last_kernel_launches", C.c_int64),
                 ("last_prod_a", C.c_int64 * 2), ("last_prod_at", C.c_int64 * 2), ("at_sorted", C.c_int64),
-                ("comm_route", C.c_int64), ("last_fused_launches", C.c_int64)]
+                ("comm_route", C.c_int64), ("last_fused_launches", C.c_int64),
+                ("fuse_fallbacks", C.c_int64), ("wait_timeouts", C.c_int64), ("p2p_timeouts", C.c_int64),
+                ("last_loop_iterations", C.c_int64), ("last_loop_launches", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

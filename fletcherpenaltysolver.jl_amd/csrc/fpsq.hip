@@ -114,6 +114,11 @@ struct Comm {
 // xGMI).  Ordering: gathers alternate between two buffers -- a peer can be at most one reduction ahead, and what it then
 // overwrites was consumed before this rank's previous push (which the peer's current one waited for); halo slots alternate
 // the same way.
+// Every peer table of the peer-to-peer route (here, IpcComm::opened, LocalGroup, P2PPeers in the kernel arguments) has this many
+// entries: the GPUs of one node.  More ranks (two nodes, 16 logical ranks) stay on RCCL -- decided in arm(), unanimously.
+constexpr int kMaxP2PRanks = 8;
+static_assert(sizeof(P2PPeers::rx) / sizeof(double*) == kMaxP2PRanks && sizeof(P2PPeers::flag) / sizeof(unsigned long long*) == kMaxP2PRanks,
+              "k_p2p_gather's peer table");
 struct P2PRoute {
   int nranks = 1, rank = 0;
   bool armed = false;
@@ -123,10 +128,10 @@ struct P2PRoute {
   // scalar steps read.  Allocated by the communicator at arm() (exported / fine-grained when the peers are other processes).
   double* rx = nullptr;
   int64_t rx_half = 0;
-  double* peer_rx[2][8] = {};
-  unsigned long long* peer_flags[8] = {};  // 8 gather words (one per sender), then "from left", "from right"
-  double* peer_halo[8] = {};
-  int64_t peer_ovl[8] = {}, peer_ovr[8] = {};
+  double* peer_rx[2][kMaxP2PRanks] = {};
+  unsigned long long* peer_flags[kMaxP2PRanks] = {};  // 8 gather words (one per sender), then "from left", "from right"
+  double* peer_halo[kMaxP2PRanks] = {};
+  int64_t peer_ovl[kMaxP2PRanks] = {}, peer_ovr[kMaxP2PRanks] = {};
   unsigned long long* flags = nullptr;  // mine (device; sequence numbers, monotone)
   int* fail_host = nullptr;             // host-mapped: a bounded wait expired
   int* fail_dev = nullptr;
@@ -305,7 +310,7 @@ struct IpcComm : RcclComm {
   int want = FPSQ_ROUTE_AUTO;   // fpsq_comm_set_route / FPSQ_COMM_ROUTE
   P2PRoute rt;
   std::string note;             // why the route fell back to RCCL (fpsq_last_error after a FPSQ_ROUTE_P2P request)
-  void* opened[8][3] = {};
+  void* opened[kMaxP2PRanks][3] = {};
   struct Blob {                 // what a rank tells its peers (padded to whole doubles)
     hipIpcMemHandle_t h[3];     // receive area of the gathers (one allocation, both parities), halo slots, flag words
     int64_t ovl, ovr, rx_half;  // rx_half: doubles between the two parities of the receive area
@@ -326,6 +331,14 @@ struct IpcComm : RcclComm {
   bool failed() override { return rt.failed(); }
   int arm(const Buffers& b, hipStream_t s) override {
     if (want == FPSQ_ROUTE_RCCL) return 0;
+    if (nranks > kMaxP2PRanks) {  // (every rank sees the same nranks: the same decision everywhere, no exchange needed)
+      note = "more than " + std::to_string(kMaxP2PRanks) + " ranks: the peer tables of the peer-to-peer route hold one node's GPUs";
+      if (want == FPSQ_ROUTE_P2P) {
+        err = "peer-to-peer route requested but not available: " + note;
+        return FPSQ_ERR_COMM;
+      }
+      return 0;
+    }
     rt.nranks = nranks;
     rt.rank = rank;
     rt.mine = b;
@@ -451,7 +464,7 @@ struct IpcComm : RcclComm {
     return rt.halo_exchange_finish(NL, fa, finish_wgs, s);
   }
   void close_peers() {
-    for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < kMaxP2PRanks; ++r)
       for (int k = 0; k < 3; ++k)
         if (opened[r][k]) {
           hipIpcCloseMemHandle(opened[r][k]);
@@ -688,6 +701,14 @@ struct fpsq_solver_s {
   bool fuse_break = false;      // FPSQ_DEBUG_FUSE_BREAK=1 (tests): the A' blocks of a fused launch publish a wrong number, every wait for them expires
   int fuse_iter = 1;            // 0: never; 1: where it pays (setup_fused_iteration); 2: wherever it is possible (tests)
   bool fuse_ok = false;
+  // The in-launch hand-overs (riding leaders' records per XCC, written-through rows, blocks dealt to XCDs by blockIdx & 7) were
+  // validated on gfx942 / gfx950 in SPX mode with 8 XCCs (tools/coherence_probe.hip): anything else keeps two launches per
+  // iteration from the start instead of finding out through expired waits (advisor, round 4)
+  bool fuse_hw_ok = false;
+  bool verbose = false;         // FPSQ_VERBOSE=1: one line on stderr when a call is repeated on two launches per iteration
+  int64_t mmid_launches = 0;    // k_minres_mid launches of the current call
+  int mmid_cap = 0;             // workgroups of k_minres_mid the device holds at once (occupancy x CUs): its grid must fit with a margin
+  int64_t loop_launches = 0, loop_iters = 0;  // the Krylov loop(s) of the current call (fpsq_info.last_loop_*)
   int2* fz_dep = nullptr;                 // per row group: the A' blocks it waits for
   unsigned int* fz_flag = nullptr;        // per A' block: launch number of its last completion
   unsigned long long* fz_ptag = nullptr;  // per A' block: four tagged words (its squared-norm partials)
@@ -1370,7 +1391,7 @@ int alloc_workspaces(fpsq_handle h) {
 // byte offsets into the long pair, and per row group the range of A' blocks that own the lines it gathers from.
 int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<int2>& col_range) {
   h->fuse_ok = false;
-  if (!h->fuse_iter || h->comm || !h->RA.ok || h->RA.view.stride == 0 || !h->AT.padded || !(h->AT.sorted || h->AT.col16) || h->AT.nblk < 1)
+  if (!h->fuse_iter || !h->fuse_hw_ok || h->comm || !h->RA.ok || h->RA.view.stride == 0 || !h->AT.padded || !(h->AT.sorted || h->AT.col16) || h->AT.nblk < 1)
     return 0;
   if ((int64_t)h->n * 16 >= (int64_t)INT32_MAX || (int64_t)h->m * 16 >= (int64_t)INT32_MAX) return 0;
   if ((int)col_range.size() != h->RA.view.ng) return 0;
@@ -2620,7 +2641,11 @@ struct KrylovRun {
     const bool mdead = minres_lane >= 0 && !h->comm && load_progress(&h->prog_host[minres_lane]).done;
     // MINRES: E1 on q (now in the current pair's lane) before its scalar step A -- with riding steps on one GPU, E1, the step
     // and E2 are ONE launch (k_minres_mid: every workgroup does E1, waits for the leader's record, does E2 on the same elements)
-    const bool mmid = minres_lane >= 0 && !mdead && lead && NL == 2 && !h->comm && h->minres_merge && h->mm_ptag != nullptr;
+    // (every workgroup of that launch must be resident at once -- the waiting ones hold their slots: the grid has to fit the
+    // device with a margin for whatever else runs; should another kernel take the slots all the same, the bounded waits end the
+    // call, ride_failed() switches the merge off and the call is repeated on three launches)
+    const bool mmid = minres_lane >= 0 && !mdead && lead && NL == 2 && !h->comm && h->minres_merge && h->mm_ptag != nullptr &&
+                      4 * (1 + gm) <= 3 * h->mmid_cap;
     if (minres_lane >= 0 && !mdead && !mmid) launch_updates<NL>(h, minres_seg(1, it, SPcur), seg_none(), seg_none());
     StepArgs sb[2] = {none, none};
     for (int l = 0; l < NL; ++l) sb[l] = step_after_a(l);
@@ -2632,6 +2657,7 @@ struct KrylovRun {
         hipLaunchKernelGGL(k_minres_mid, dim3(1 + e1.nblk), dim3(kBlock), 0, s, e1, e2, sb[minres_lane], h->mm_ptag, h->ride_rec2,
                            (unsigned int)++h->ride_seq, reinterpret_cast<unsigned long long*>(h->hscal_dev + 15));
         h->launches++;
+        h->mmid_launches++;
       } else if (!mdead) {
         if (int rc = launch_step(h, sb[minres_lane], none, /*sharded=*/true)) return rc;
         launch_updates<NL>(h, minres_seg(2, it, SPcur), seg_none(), seg_none());
@@ -2796,6 +2822,7 @@ struct KrylovRun {
       if (int rc = flush_pend(true)) return rc;  // (so must the host; the same launches on every rank)
       HIPCHK(h, hipStreamSynchronize(s));
       if (h->comm->failed()) {  // (peer-to-peer route: a peer's record never came; nothing later in this call can be right)
+        h->info.p2p_timeouts++;
         h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
         return FPSQ_ERR_TIMEOUT;
       }
@@ -2885,6 +2912,7 @@ struct KrylovRun {
   int run() {
     setup();
     if (int rc = startup()) return rc;
+    const int64_t launches0 = h->launches;
     while (it < itmax_all) {
       ++it;
       if (can_fuse && have_pend) {
@@ -2897,6 +2925,8 @@ struct KrylovRun {
       if (int rc = h->comm ? pace_sharded(stop) : pace_single(stop)) return rc;
       if (stop) break;
     }
+    h->loop_iters += it;
+    h->loop_launches += h->launches - launches0;
     return finish();
   }
 };
@@ -3012,6 +3042,8 @@ void call_begin(fpsq_handle h) {
   h->spmv_launches = 0;
   h->prod_a[0] = h->prod_a[1] = h->prod_at[0] = h->prod_at[1] = 0;
   h->fused_launches = 0;
+  h->mmid_launches = 0;
+  h->loop_launches = h->loop_iters = 0;
   h->ev_used = 0;
   // device-side timing of the whole call only when profiling is on: an event record is a marker packet the GPU has to
   // process (a few us each); otherwise last_solve_ms is the host's wall time of the call
@@ -3025,6 +3057,7 @@ bool ride_failed(fpsq_handle h) {
   volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(h->hscal + 15);
   if (*w == 0) return false;
   *w = 0;
+  h->info.wait_timeouts++;
   h->err = "a bounded wait inside a product launch expired (the leaders' record did not arrive, or -- one-launch iterations -- a block's "
            "flag / partials did not): FPSQ_FUSE_ITER=0 keeps two launches per iteration, FPSQ_RIDE_LEAD=0 the stand-alone steps";
   // (something else held the device for longer than the bound: this handle goes on with two launches per iteration, whose
@@ -3033,6 +3066,12 @@ bool ride_failed(fpsq_handle h) {
     h->fuse_ok = false;
     h->fuse_fell_back = true;  // (the entry point repeats the call once: with_fuse_fallback)
   }
+  // the same for a MINRES lane's merged launch (k_minres_mid: every workgroup of its grid must be resident at once): back to
+  // three launches, whose workgroups wait for nobody, and the call is repeated
+  if (h->mmid_launches > 0 && h->minres_merge) {
+    h->minres_merge = false;
+    h->fuse_fell_back = true;
+  }
   return true;
 }
 
@@ -3040,6 +3079,7 @@ int call_end(fpsq_handle h) {
   if (h->profile) hipEventRecord(h->ev1, h->stream);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->comm && h->comm->failed()) {
+    h->info.p2p_timeouts++;
     h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
     return FPSQ_ERR_TIMEOUT;
   }
@@ -3055,6 +3095,8 @@ int call_end(fpsq_handle h) {
     h->info.last_prod_at[i] = h->prod_at[i];
   }
   h->info.last_fused_launches = h->fused_launches;
+  h->info.last_loop_iterations = h->loop_iters;
+  h->info.last_loop_launches = h->loop_launches;
   double sp = 0.0;
   for (size_t i = 0; i < h->ev_used; ++i) {
     float t = 0.f;
@@ -3098,6 +3140,8 @@ int call_end_ordered(fpsq_handle h, double seq) {
     h->info.last_prod_at[i] = h->prod_at[i];
   }
   h->info.last_fused_launches = h->fused_launches;
+  h->info.last_loop_iterations = h->loop_iters;
+  h->info.last_loop_launches = h->loop_launches;
   h->info.last_spmv_ms = 0.0;
   return 0;
 }
@@ -3317,8 +3361,10 @@ int with_fuse_fallback(fpsq_handle h, F&& call) {
   int rc = call();
   if (rc == FPSQ_ERR_TIMEOUT && h && h->fuse_fell_back) {
     h->fuse_fell_back = false;
-    std::fprintf(stderr, "fpsq: a bounded wait of a one-launch iteration expired (is the GPU shared with other processes?); this handle "
-                         "continues with two launches per iteration, the call is repeated\n");
+    h->info.fuse_fallbacks++;  // (fpsq_info: a benchmark or a test sees that it happened)
+    if (h->verbose)
+      std::fprintf(stderr, "fpsq: a bounded wait of a one-launch iteration expired (is the GPU shared with other processes?); this handle "
+                           "continues with two launches per iteration, the call is repeated\n");
     rc = call();
   }
   if (h) h->fuse_fell_back = false;
@@ -3413,9 +3459,24 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_JAC_REFRESH")) h->refresh_3pass = std::atoi(ev) == 3;
   {
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->opt.device) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDeviceProperties(&prop, h->opt.device) == hipSuccess && prop.multiProcessorCount > 0) {
       h->resident_wgs = 4 * prop.multiProcessorCount;
+      int xccs = 0;
+      if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, h->opt.device) != hipSuccess) {
+        (void)hipGetLastError();
+        xccs = 0;
+      }
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minres_mid, kBlock, 0) == hipSuccess && per_cu > 0)
+        h->mmid_cap = per_cu * prop.multiProcessorCount;
+      else
+        (void)hipGetLastError();
+      const std::string arch = prop.gcnArchName;
+      h->fuse_hw_ok = xccs == 8 && (arch.rfind("gfx950", 0) == 0 || arch.rfind("gfx942", 0) == 0);
+    }
   }
+  if (const char* ev = std::getenv("FPSQ_FUSE_ANY_DEVICE")) h->fuse_hw_ok = h->fuse_hw_ok || std::atoi(ev) != 0;  // (bring-up on other parts)
+  if (const char* ev = std::getenv("FPSQ_VERBOSE")) h->verbose = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_AB_MASK")) h->ab_mask = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_AB_DYNAMIC")) h->ab_dynamic = std::atoi(ev) != 0;
   std::memset(h->hstats, 0, 4 * sizeof(fpsq_stats));

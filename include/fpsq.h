@@ -379,6 +379,16 @@ typedef struct {
                               / _LOCAL / _LOCAL_P2P (in-process groups) */
   int64_t last_fused_launches; /* of the launches counted in last_prod_a[1] AND last_prod_at[1]: those that carried both products of a
                                   joint iteration in one grid (k_iter_fused; FPSQ_FUSE_ITER=0 disables) */
+  /* CUMULATIVE over the life of the handle -- all three are 0 on a healthy run; a test or a benchmark asserts so:
+   *   fuse_fallbacks  calls that ran into a bounded wait of a one-launch iteration and were REPEATED on two launches per
+   *                   iteration (the caller saw a delay and rc = the repeated call's; the handle stays on two launches);
+   *   wait_timeouts   calls in which a bounded wait inside a product launch expired (leaders' record, block flags, tagged
+   *                   partials) -- every fuse_fallback is one of them, the others ended in FPSQ_ERR_TIMEOUT;
+   *   p2p_timeouts    calls in which a bounded wait for a PEER's record expired (peer-to-peer route): FPSQ_ERR_TIMEOUT. */
+  int64_t fuse_fallbacks, wait_timeouts, p2p_timeouts;
+  /* the Krylov loop of the last call: joint iterations enqueued and kernel launches enqueued for them (exchanges and stand-alone
+   * steps included; start-up and epilogue excluded): launches / iterations = launches per joint iteration */
+  int64_t last_loop_iterations, last_loop_launches;
 } fpsq_info;
 int fpsq_get_info(fpsq_handle h, fpsq_info *info);
 /* on != 0: bracket every SpMV/SpMM launch with HIP events on the solver's stream so that last_spmv_ms is filled

@@ -27,7 +27,8 @@
 
 namespace {
 
-constexpr int kMaxRanks = 8;
+constexpr int kMaxRanks = 16;  // (the product's peer-to-peer tables hold 8: a 9-rank communicator must stay on the collectives)
+constexpr size_t kCtlBytes = 8192;
 constexpr size_t kSlotBytes = (size_t)20 << 20;  // per rank (collectives): 2 n doubles of the largest test problem; sparse until touched
 constexpr size_t kMailBytes = (size_t)1 << 20;   // per ordered pair (send / recv): a halo is <= 2 x 8192 x 2 doubles
 
@@ -42,12 +43,14 @@ struct Control {
 
 struct ShimComm {
   int nranks = 0, rank = 0;
+  int real = 0;  // processes that take part in the barriers: nranks, or 1 with FPSQ_SHIM_PHANTOM=1 (the other ranks are phantoms
+                 // whose slots stay zero -- lets ONE process hold a communicator of 9+ ranks for the set-up decisions)
   std::string name;
   size_t total = 0;
   char* base = nullptr;
   Control* ctl = nullptr;
-  char* slot(int r) { return base + 4096 + (size_t)r * kSlotBytes; }
-  char* mail(int src, int dst) { return base + 4096 + (size_t)kMaxRanks * kSlotBytes + (size_t)(src * kMaxRanks + dst) * kMailBytes; }
+  char* slot(int r) { return base + kCtlBytes + (size_t)r * kSlotBytes; }
+  char* mail(int src, int dst) { return base + kCtlBytes + (size_t)kMaxRanks * kSlotBytes + (size_t)(src * kMaxRanks + dst) * kMailBytes; }
 };
 
 struct Pending {
@@ -83,7 +86,7 @@ bool wait_until(F cond) {
 bool barrier(ShimComm* c) {
   Control* k = c->ctl;
   const int gen = k->generation.load(std::memory_order_acquire);
-  if (k->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->nranks) {
+  if (k->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->real) {
     k->arrived.store(0, std::memory_order_relaxed);
     k->generation.store(gen + 1, std::memory_order_release);
     return true;
@@ -153,8 +156,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   ShimComm* c = new ShimComm();
   c->nranks = nranks;
   c->rank = rank;
+  c->real = std::getenv("FPSQ_SHIM_PHANTOM") && std::atoi(std::getenv("FPSQ_SHIM_PHANTOM")) != 0 ? 1 : nranks;
   c->name = std::string(id.internal, strnlen(id.internal, sizeof(id.internal)));
-  c->total = 4096 + (size_t)kMaxRanks * kSlotBytes + (size_t)kMaxRanks * kMaxRanks * kMailBytes;
+  c->total = kCtlBytes + (size_t)kMaxRanks * kSlotBytes + (size_t)kMaxRanks * kMaxRanks * kMailBytes;
   const int fd = open(c->name.c_str(), O_CREAT | O_RDWR, 0600);
   if (fd < 0 || ftruncate(fd, (off_t)c->total) != 0) {
     if (fd >= 0) close(fd);
@@ -169,9 +173,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
   }
   c->base = (char*)p;
   c->ctl = (Control*)p;  // (a fresh file is zero-filled: all counters start at 0)
-  static_assert(sizeof(Control) <= 4096, "control block");
+  static_assert(sizeof(Control) <= kCtlBytes, "control block");
   c->ctl->attached.fetch_add(1, std::memory_order_acq_rel);
-  if (!wait_until([&] { return c->ctl->attached.load(std::memory_order_acquire) >= nranks; }) || !barrier(c)) {
+  if (!wait_until([&] { return c->ctl->attached.load(std::memory_order_acquire) >= c->real; }) || !barrier(c)) {
     munmap(c->base, c->total);
     unlink(c->name.c_str());
     delete c;

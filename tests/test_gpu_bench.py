@@ -77,7 +77,10 @@ def test_multi_rank_sharded_bench_runs_through_the_loopback_collectives(ranks):
     env = {"FPSQ_BENCH_REHEARSE": "1", "FPSQ_RCCL_LIB": _shim(), "FPSQ_BENCH_WATCHDOG": "400", "FPSQ_SHIM_TIMEOUT": "120"}
     r = _run(["--gpus", str(ranks), "--parallel", "shard", "--steps", "2", "--warmup", "1", "--repeats", "1", "--cpu-evals", "0",
               "--no-roofline-pass"], env=env, timeout=900)
-    if r.returncode != 0:  # (pytest shortens the assertion's text: keep what the ranks said where a developer finds it)
+    if r.returncode != 0:
+        # pytest shortens the assertion's text: what the ranks said goes into the REPORT ITSELF (captured output of a failed
+        # test is printed in full) -- a side file under gpurun_out/ does not come back from the driver's run
+        print(f"==== bench.py --gpus {ranks}: rc {r.returncode} ==== stdout ====\n{r.stdout}\n==== stderr ====\n{r.stderr}")
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", f"bench_ranks{ranks}_failed.txt"), "w") as fh:
             fh.write(r.stdout + "\n---- stderr ----\n" + r.stderr)

@@ -1494,13 +1494,15 @@ def test_two_handles_iterating_at_once_with_one_launch_iterations(monkeypatch):
         d.close()
 
 
+@pytest.mark.expects_wait_timeouts
 def test_one_launch_iteration_bounded_waits_end_and_the_call_is_repeated_on_two_launches(monkeypatch, capfd):
     """Every wait of the fused launch has an end each wave reaches: with the A' blocks made to publish a wrong launch number
     (FPSQ_DEBUG_FUSE_BREAK=1) the row groups give up on their flags and the mid leaders on the tagged partials after their
     bounded numbers of looks, whoever waits for the mid leaders' record after its own; the handle's error word is raised,
     every kernel of the call ends, the handle switches to two launches per iteration and the entry point REPEATS the call --
-    what a process sharing its GPU with others would see when their waiting workgroups starve its own (one line on
-    stderr, a delay, the right answer: bitwise a two-launch handle's).  Within seconds."""
+    what a process sharing its GPU with others would see when their waiting workgroups starve its own (a delay, the right
+    answer -- bitwise a two-launch handle's --, fpsq_info.fuse_fallbacks = wait_timeouts = 1, and with FPSQ_VERBOSE=1 one
+    line on stderr).  Within seconds."""
     import time
     qp = _small_pde(seed=5, n=60000, m=6000)
     monkeypatch.setenv("FPSQ_AT_ROW_ALIGN", "8")
@@ -1511,15 +1513,19 @@ def test_one_launch_iteration_bounded_waits_end_and_the_call_is_repeated_on_two_
     ref.close()
     monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
     monkeypatch.setenv("FPSQ_DEBUG_FUSE_BREAK", "1")
+    monkeypatch.setenv("FPSQ_VERBOSE", "1")
     dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
     gx = np.empty(qp.n)
     t0 = time.perf_counter()
     f, rc = dev.objgrad(qp.x, gx=gx)
     assert time.perf_counter() - t0 < 60.0
-    assert rc == rc0 and f == f0 and np.array_equal(gx, gx0) and dev.info()["last_fused_launches"] == 0
+    i = dev.info()
+    assert rc == rc0 and f == f0 and np.array_equal(gx, gx0) and i["last_fused_launches"] == 0
+    assert i["fuse_fallbacks"] == 1 and i["wait_timeouts"] == 1 and i["p2p_timeouts"] == 0
     assert "bounded wait of a one-launch iteration expired" in capfd.readouterr().err
     f, rc = dev.objgrad(qp.x, gx=gx)  # (and stays there)
-    assert np.array_equal(gx, gx0) and dev.info()["last_fused_launches"] == 0
+    i = dev.info()
+    assert np.array_equal(gx, gx0) and i["last_fused_launches"] == 0 and i["fuse_fallbacks"] == 1 and i["wait_timeouts"] == 1
     dev.close()
     monkeypatch.setenv("FPSQ_DEBUG_FUSE_BREAK", "0")
     dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
@@ -1529,6 +1535,7 @@ def test_one_launch_iteration_bounded_waits_end_and_the_call_is_repeated_on_two_
     dev.close()
 
 
+@pytest.mark.expects_wait_timeouts
 def test_riding_leaders_bounded_wait_ends_in_an_error_not_a_hang(monkeypatch):
     """Every wait of the leader protocol has an end each wave reaches: with the leaders made to publish a wrong launch number
     (FPSQ_DEBUG_RIDE_BREAK=1) the workgroups of the product give up after their bounded number of looks, raise the handle's
