@@ -33,10 +33,12 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0    # same guide: measured copy ceiling
 F64_MFMA_PEAK_TF = 78.6  # dense fp64 matrix peak (vendor figure)
 
-WORKLOADS = ["pde-control-like n=1e6 m=1e5 nnz=1e7", "random-eqqp n=1e5 m=1e4 nnz=1e6", "aug2dc-like N=100",
+# WORKLOADS[0] = the default = the headline: SURVEY 8(d)'s LITERAL generator (distinct hashed offsets in the 8192-column window;
+# round 5 -- rounds 1-4 timed the stratified variant "pde-control-like", which stays available by name)
+WORKLOADS = ["pde-control-hashed n=1e6 m=1e5 nnz=1e7", "random-eqqp n=1e5 m=1e4 nnz=1e6", "aug2dc-like N=100",
              "dense-block n=4096 m=2048",
-             # the headline shape with SURVEY 8(d)'s literal column rule (hashed distinct offsets instead of stratified ones)
-             "pde-control-hashed n=1e6 m=1e5 nnz=1e7"]
+             # the headline shape with one offset drawn per stratum of the window instead of hashed distinct offsets
+             "pde-control-like n=1e6 m=1e5 nnz=1e7"]
 
 
 def parse_args():
@@ -569,22 +571,46 @@ def main():
                     "spmv_share_of_eval_time": round(t_ms / tot_ms, 3) if tot_ms > 0 else None,
                     "whole_eval_frac_of_peak": round(nbytes / K / (med / K) / 1e9 / HBM_PEAK_GBS, 4) if not sharded else None}
         # HBM traffic per productive launch: PMC counters cannot be read from inside the run (rocprofv3 writes them when
-        # the process ends); the number below is from the COMMITTED profile of this same command, labelled as such
-        for prof in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
-                if pmc["workload"] == args.workload and args.fuse and not sharded and world == 1 and not hp \
-                        and args.pointers == "device":
-                    roofline["traffic"] = pmc["traffic_bytes_per_productive_launch"]
-                    roofline["traffic_source"] = (f"committed profile profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / "
-                                                  "WRITE_SIZE passes of this command; not measured in this run)")
-                    break
-            except (OSError, KeyError, ValueError):
-                continue
+        # the process ends); the number below is from the COMMITTED profile of this same command, labelled as such -- and
+        # only while the kernel sources are the ones the profile was taken on (tools/pmc_traffic.py stores their hash):
+        # a stale profile is refused, not quoted
+        import hashlib
 
-    route = model.info()["comm_route"] if sharded else 0
-    how = ("PEER-TO-PEER route: records written straight into the peers' hipIpc-mapped buffers + sequence flags, one "
+        hh = hashlib.sha256()
+        cs = os.path.join(ROOT, "fletcherpenaltysolver.jl_amd", "csrc")
+        for fn in sorted(os.listdir(cs)):
+            if fn.endswith(".hip") or fn.endswith(".hip.h"):
+                hh.update(fn.encode())
+                hh.update(open(os.path.join(cs, fn), "rb").read())
+        sha = hh.hexdigest()[:16]
+        if args.fuse and not sharded and world == 1 and not hp and args.pointers == "device":
+            roofline["traffic_source"] = "no committed PMC profile of this workload (profiles/rNN_pmc_traffic.json)"
+            for prof in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                    if pmc["workload"] != args.workload:
+                        continue
+                    if pmc.get("kernel_sources_sha16") != sha:
+                        roofline["traffic_source"] = (f"REFUSED: profiles/{prof} was taken on other kernel sources (sha16 "
+                                                      f"{pmc.get('kernel_sources_sha16')}, this tree {sha}): re-take it with tools/r5_profiles.sh")
+                        break
+                    roofline["traffic"] = pmc["traffic_bytes_per_productive_launch"]
+                    roofline["traffic_source"] = (f"committed profile profiles/{prof} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                  f"this command on kernel sources sha16 {sha}, git {pmc.get('git_head_when_post_processed')}; "
+                                                  "not measured in this run)")
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
+
+    final = model.info()
+    route = final["comm_route"] if sharded else 0
+    insum = bool(final.get("comm_in_launch_sums", 0)) if sharded else False
+    how = ("PEER-TO-PEER route, sums over the ranks formed INSIDE the launches that need them (the leader workgroups write their "
+           "rank's local sums into the peers' hipIpc-mapped receive areas and add the ranks' rows up in rank order; no gather "
+           "kernel, no collective call inside the loop)" if route == 2 and insum
+           else "PEER-TO-PEER route: records written straight into the peers' hipIpc-mapped buffers + sequence flags, one "
            "one-workgroup kernel per exchange, no collective call inside the loop" if route == 2
+           else "RCCL route (a communicator of ONE rank: nothing to exchange)" if insum
            else "RCCL route: grouped ncclSend/ncclRecv + ncclAllGather on the solver's stream")
     par = {"single": "single GPU",
            "halo": f"rows of A sharded over {world} GPUs, HALO layout: each rank holds its column window of the n-vectors and "
@@ -612,7 +638,13 @@ def main():
                    "iters_lsqr_craig_median": [int(np.median([i[0] for i in its])), int(np.median([i[1] for i in its]))],
                    **({"iters_lsqr_craig_seen": sorted(set(its))} if args.alternate_delta else {}),
                    "all_solved": soft[0] == 0, "parallelism": par,
-                   **({"comm_route": DeviceEqQP.ROUTE_NAMES.get(route, str(route))} if sharded else {})},
+                   # the Krylov loop of the LAST evaluation: kernel launches per joint iteration (products, exchanges, stand-alone
+                   # steps); and the handle's cumulative "something waited too long" counters (fpsq_info): all 0 on a healthy run
+                   "loop_launches_per_iteration": round(final["last_loop_launches"] / max(final["last_loop_iterations"], 1), 3),
+                   "fuse_fallbacks": final["fuse_fallbacks"], "wait_timeouts": final["wait_timeouts"],
+                   "p2p_timeouts": final["p2p_timeouts"],
+                   **({"comm_route": DeviceEqQP.ROUTE_NAMES.get(route, str(route)), "comm_in_launch_sums": insum}
+                      if sharded else {})},
         "roofline": roofline,
     }
 

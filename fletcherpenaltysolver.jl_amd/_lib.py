@@ -42,7 +42,8 @@ class Info(C.Structure):
                 ("last_prod_a", C.c_int64 * 2), ("last_prod_at", C.c_int64 * 2), ("at_sorted", C.c_int64),
                 ("comm_route", C.c_int64), ("last_fused_launches", C.c_int64),
                 ("fuse_fallbacks", C.c_int64), ("wait_timeouts", C.c_int64), ("p2p_timeouts", C.c_int64),
-                ("last_loop_iterations", C.c_int64), ("last_loop_launches", C.c_int64)]
+                ("last_loop_iterations", C.c_int64), ("last_loop_launches", C.c_int64),
+                ("comm_in_launch_sums", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

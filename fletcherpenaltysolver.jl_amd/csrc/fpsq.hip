@@ -103,6 +103,9 @@ struct Comm {
   virtual hipError_t alloc_exchange(void** p, size_t bytes) { return hipMalloc(p, bytes); }
   // how the exchanges of the Krylov loop travel (fpsq_info.comm_route)
   virtual int route() const { return FPSQ_ROUTE_RCCL; }
+  // Sums over the ranks formed INSIDE the launches that need them (fpsq_krylov.hip.h xch_sum): the device-resident peer table,
+  // null when this communicator does not do that (RCCL route; ranks sharing a device).  Known after arm().
+  virtual const XchTable* xch_table() const { return nullptr; }
   virtual ~Comm() {}
 };
 
@@ -132,7 +135,12 @@ struct P2PRoute {
   unsigned long long* peer_flags[kMaxP2PRanks] = {};  // 8 gather words (one per sender), then "from left", "from right"
   double* peer_halo[kMaxP2PRanks] = {};
   int64_t peer_ovl[kMaxP2PRanks] = {}, peer_ovr[kMaxP2PRanks] = {};
-  unsigned long long* flags = nullptr;  // mine (device; sequence numbers, monotone)
+  unsigned long long* flags = nullptr;  // mine (device; sequence numbers, monotone); behind the 16 flag words: the receive
+                                        // area of the in-launch sums (xch_sum), so that ONE mapped allocation serves both
+  static constexpr size_t kFlagWords = 16 + (size_t)kXchRing * kXchRanks * kXchWords;
+  XchTable* xt_dev = nullptr;           // non-null: the sums over the ranks are formed inside the launches (lx)
+  int lx_want = 1;                      // FPSQ_LX: 0 never, 1 (default) when every rank has a device of its own, 2 always (tests with small grids)
+  int xch_delay_rank = 0;               // FPSQ_DEBUG_XCH_DELAY (tests)
   int* fail_host = nullptr;             // host-mapped: a bounded wait expired
   int* fail_dev = nullptr;
   unsigned long long gather_seq = 0, halo_seq = 0;
@@ -141,12 +149,30 @@ struct P2PRoute {
   int alloc_fail_word(std::string& err) {
     if (const char* ev = std::getenv("FPSQ_P2P_POLLS")) max_spins = std::max(1L, std::atol(ev));
     if (const char* ev = std::getenv("FPSQ_HALO_FUSE")) fuse_halo = std::atoi(ev) != 0;
+    if (const char* ev = std::getenv("FPSQ_LX")) lx_want = std::atoi(ev);
+    if (const char* ev = std::getenv("FPSQ_DEBUG_XCH_DELAY")) xch_delay_rank = std::atoi(ev);
     if (hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&fail_dev, fail_host, 0) != hipSuccess) {
       err = "p2p arm: allocation failed";
       return FPSQ_ERR_HIP;
     }
     *fail_host = 0;
+    return 0;
+  }
+  // the peer table of the in-launch sums, once peer_flags[] is known
+  int make_xch_table(std::string& err) {
+    XchTable T{};
+    for (int r = 0; r < nranks; ++r) T.peer[r] = peer_flags[r] + 16;
+    T.nranks = nranks;
+    T.rank = rank;
+    T.max_polls = (int32_t)std::min<long>(max_spins, (long)INT32_MAX);
+    T.delay_rank = xch_delay_rank;
+    T.fail = fail_dev;
+    if (hipMalloc((void**)&xt_dev, sizeof(XchTable)) != hipSuccess ||
+        hipMemcpy(xt_dev, &T, sizeof T, hipMemcpyHostToDevice) != hipSuccess) {
+      err = "p2p arm: allocation failed";
+      return FPSQ_ERR_HIP;
+    }
     return 0;
   }
   bool is_gather_buffer(const double* recv) const { return armed && (recv == mine.gath[0] || recv == mine.gath[1]); }
@@ -198,6 +224,8 @@ struct P2PRoute {
     return true;
   }
   void release() {
+    if (xt_dev) hipFree(xt_dev);
+    xt_dev = nullptr;
     if (rx) hipFree(rx);
     rx = nullptr;
     if (flags) hipFree(flags);
@@ -315,6 +343,8 @@ struct IpcComm : RcclComm {
     hipIpcMemHandle_t h[3];     // receive area of the gathers (one allocation, both parities), halo slots, flag words
     int64_t ovl, ovr, rx_half;  // rx_half: doubles between the two parities of the receive area
     int32_t ok, pid;
+    int32_t lx_want, pad;       // FPSQ_LX of that rank (the in-launch sums are switched on unanimously)
+    char dev[48];               // PCI bus id of its device: two ranks on ONE device keep the exchange kernels (see xch_sum)
   };
   static constexpr size_t kBlobDoubles = (sizeof(Blob) + 7) / 8;
   hipError_t alloc_exchange(void** p, size_t bytes) override {
@@ -328,6 +358,7 @@ struct IpcComm : RcclComm {
     return e;
   }
   int route() const override { return rt.armed ? FPSQ_ROUTE_P2P : FPSQ_ROUTE_RCCL; }
+  const XchTable* xch_table() const override { return rt.armed ? rt.xt_dev : nullptr; }
   bool failed() override { return rt.failed(); }
   int arm(const Buffers& b, hipStream_t s) override {
     if (want == FPSQ_ROUTE_RCCL) return 0;
@@ -349,7 +380,7 @@ struct IpcComm : RcclComm {
     me.ovr = b.ovr;
     rt.rx_half = b.gath[1] - b.gath[0];
     me.rx_half = rt.rx_half;
-    if (hipExtMallocWithFlags((void**)&rt.flags, 16 * 8, hipDeviceMallocFinegrained) != hipSuccess ||
+    if (hipExtMallocWithFlags((void**)&rt.flags, P2PRoute::kFlagWords * 8, hipDeviceMallocFinegrained) != hipSuccess ||
         hipExtMallocWithFlags((void**)&rt.rx, (size_t)rt.rx_half * 2 * 8, hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
       if (rt.flags) hipFree(rt.flags);
@@ -359,9 +390,17 @@ struct IpcComm : RcclComm {
       note = "fine-grained allocation of the flag words / receive area failed";
       // (the kernels are never launched without them: the route stays unarmed)
     } else {
-      hipMemset(rt.flags, 0, 16 * 8);
+      hipMemset(rt.flags, 0, P2PRoute::kFlagWords * 8);
     }
     if (int rc = rt.alloc_fail_word(err)) return rc;
+    me.lx_want = rt.lx_want;
+    {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(me.dev, (int)sizeof me.dev, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        std::snprintf(me.dev, sizeof me.dev, "?");  // (unknown: counts as shared)
+      }
+    }
     if (me.ok && nranks > 1) {
       void* base[3] = {rt.rx, b.halo_recv, rt.flags};
       for (int k = 0; k < 3 && me.ok; ++k)
@@ -445,6 +484,19 @@ struct IpcComm : RcclComm {
       rt.peer_flags[r] = self ? rt.flags : (unsigned long long*)opened[r][2];
       rt.peer_ovl[r] = blobs[r].ovl;
       rt.peer_ovr[r] = blobs[r].ovr;
+    }
+    // In-launch sums over the ranks (xch_sum): every rank must want them, and either every rank has a device of its own or every
+    // rank forces them (FPSQ_LX=2: tests whose grids are resident all at once).  Every rank sees the same blobs: same decision.
+    {
+      bool all_on = true, all_force = true, distinct = true;
+      for (int r = 0; r < nranks; ++r) {
+        all_on = all_on && blobs[r].lx_want >= 1;
+        all_force = all_force && blobs[r].lx_want >= 2;
+        for (int q = 0; q < r; ++q)
+          if (std::strncmp(blobs[r].dev, blobs[q].dev, sizeof blobs[r].dev) == 0 || blobs[r].dev[0] == '?') distinct = false;
+      }
+      if (nranks > 1 && all_on && (distinct || all_force))
+        if (int rc2 = rt.make_xch_table(err)) return rc2;
     }
     rt.armed = true;
     return 0;
@@ -585,12 +637,14 @@ struct LocalComm : Comm {
 struct P2PLocalComm : LocalComm {
   P2PRoute rt;
   int route() const override { return FPSQ_ROUTE_LOCAL_P2P; }
+  const XchTable* xch_table() const override { return rt.armed ? rt.xt_dev : nullptr; }
   int arm(const Buffers& b, hipStream_t) override {
     rt.nranks = nranks;
     rt.rank = rank;
     rt.mine = b;
     rt.rx_half = b.gath[1] - b.gath[0];
-    if (hipMalloc((void**)&rt.flags, 16 * 8) != hipSuccess || hipMemset(rt.flags, 0, 16 * 8) != hipSuccess ||
+    if (hipMalloc((void**)&rt.flags, P2PRoute::kFlagWords * 8) != hipSuccess ||
+        hipMemset(rt.flags, 0, P2PRoute::kFlagWords * 8) != hipSuccess ||
         hipMalloc((void**)&rt.rx, (size_t)rt.rx_half * 2 * 8) != hipSuccess) {
       err = "p2p arm: allocation failed";
       return FPSQ_ERR_HIP;
@@ -614,6 +668,9 @@ struct P2PLocalComm : LocalComm {
       rt.peer_ovl[r] = q.ovl;
       rt.peer_ovr[r] = q.ovr;
     }
+    // (the shards share ONE device: the in-launch sums only when a test with small grids forces them -- one environment, one decision)
+    if (nranks > 1 && rt.lx_want >= 2)
+      if (int rc = rt.make_xch_table(err)) return rc;
     rt.armed = true;
     g->barrier();
     return 0;
@@ -756,6 +813,7 @@ struct fpsq_solver_s {
   int64_t seg_len = 0;
   int cE = 0, cT = 0, cA = 0, cW = 0;
   bool gather_ready = false;
+  uint32_t xch_seq = 0;         // sequence number of the last in-launch sum over the ranks (xch_sum; the same on every rank)
   uint64_t gather_calls = 0;    // the all-gathers alternate between the two halves of `gath`: a peer that is one reduction
                                 // ahead never overwrites a record its neighbour has not read yet
   double* comm_vec = nullptr;   // [n][2] all-reduce payload (partial A' products)
@@ -1353,6 +1411,13 @@ int build_rgcs(fpsq_handle h, const HostCsr& H, DevRgcs& D, std::vector<int32_t>
 }
 
 inline int npart_A(fpsq_handle h) { return h->RA.ok ? h->RA.view.ng : h->A.nblk; }
+// Sums over the ranks need no launch of their own: one GPU; a communicator of ONE rank (nobody to add to); or the halo-sharded
+// layout on a peer-to-peer route whose ranks form them inside the launches that need them (Comm::xch_table, known after arm()).
+inline bool insum(fpsq_handle h) {
+  return !h->comm || (h->halo && (h->comm->nranks == 1 || h->comm->xch_table() != nullptr));
+}
+// ... and when other ranks exist: the table the kernels are given (null: one GPU, or a communicator of one)
+inline const XchTable* insum_table(fpsq_handle h) { return h->comm && h->comm->nranks > 1 ? h->comm->xch_table() : nullptr; }
 inline int64_t n_owned(fpsq_handle h) { return h->halo ? h->n - h->ovr : h->n; }
 
 int alloc_workspaces(fpsq_handle h) {
@@ -1391,7 +1456,7 @@ int alloc_workspaces(fpsq_handle h) {
 // byte offsets into the long pair, and per row group the range of A' blocks that own the lines it gathers from.
 int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<int2>& col_range) {
   h->fuse_ok = false;
-  if (!h->fuse_iter || !h->fuse_hw_ok || h->comm || !h->RA.ok || h->RA.view.stride == 0 || !h->AT.padded || !(h->AT.sorted || h->AT.col16) || h->AT.nblk < 1)
+  if (!h->fuse_iter || !h->fuse_hw_ok || !h->RA.ok || h->RA.view.stride == 0 || !h->AT.padded || !(h->AT.sorted || h->AT.col16) || h->AT.nblk < 1)
     return 0;
   if ((int64_t)h->n * 16 >= (int64_t)INT32_MAX || (int64_t)h->m * 16 >= (int64_t)INT32_MAX) return 0;
   if ((int)col_range.size() != h->RA.view.ng) return 0;
@@ -1435,7 +1500,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   std::vector<int32_t> perm;
   transpose_structure(HA, HT, perm);
   if (int rc = upload_csr(h, HA, h->A)) return rc;
-  h->AT.row_align = h->fuse_iter && !h->comm ? 8 : 1;
+  h->AT.row_align = h->fuse_iter ? 8 : 1;  // (whether a sharded handle may use the launch is decided per run: KrylovRun::setup)
   if (const char* ev = std::getenv("FPSQ_AT_ROW_ALIGN")) h->AT.row_align = std::max(1, std::atoi(ev));  // (tests: the fused layout without the fused launch)
   if (int rc = upload_csr(h, HT, h->AT)) return rc;
   std::vector<int32_t> csr_pos;
@@ -1981,6 +2046,23 @@ int seg_count(fpsq_handle h, const double* p) {
 // product launch is prepared when it is handed over (the collective must precede that launch in the stream).
 int prepare_step(fpsq_handle h, StepArgs& a0, StepArgs& a1, bool sharded = false, int sharded1 = -1) {
   const bool sh[2] = {sharded, sharded1 < 0 ? sharded : sharded1 != 0};  // per step: its partials are per-rank sums
+  if (h->comm && h->halo && insum(h)) {
+    // the step's workgroup forms the sum over the ranks itself (xch_sum): the arguments stay the rank's local arrays and get
+    // the exchange's number -- one per prepared pair, the same sequence on every rank.  A communicator of one: nothing at all.
+    if (const XchTable* xt = insum_table(h)) {
+      if ((sh[0] && a0.kind != STEP_NONE) || (sh[1] && a1.kind != STEP_NONE)) {
+        const uint32_t seq = ++h->xch_seq;
+        StepArgs* w[2] = {&a0, &a1};
+        for (int k = 0; k < 2; ++k) {
+          if (w[k]->kind == STEP_NONE || !sh[k]) continue;
+          w[k]->xt = xt;
+          w[k]->xseq = seq;
+          w[k]->xlane = k;
+        }
+      }
+    }
+    return 0;
+  }
   if (h->comm && h->halo && (sh[0] || sh[1])) {
     // Halo mode: ONE all-gather of the contiguous segment range holding the arrays these steps read; the step kernel then
     // sums the nranks copies of every array in rank-major order (no local pre-sum launch, no reduction by the library).
@@ -2261,7 +2343,10 @@ struct KrylovRun {
     fuse_upd = local_vec;
     split_steps = h->comm && !h->halo;
     pa_last = h->pS2;
-    can_fuse = NL == 2 && h->fuse_ok && h->at_xcd && lead && fuse_upd && !h->comm && minres_lane < 0 && !h->ride_break;
+    // (a halo-sharded handle: when its sums over the ranks need no launch of their own and -- for now -- no row of its window is
+    // shared with a neighbour: a communicator of one, a block-diagonal Jacobian)
+    can_fuse = NL == 2 && h->fuse_ok && h->at_xcd && lead && fuse_upd && minres_lane < 0 && !h->ride_break &&
+               (!h->comm || (h->halo && h->ovl == 0 && h->ovr == 0 && insum(h)));
     look = std::max(1, o.lookahead);
   }
 
@@ -2494,11 +2579,13 @@ struct KrylovRun {
       const LaneCtl* s1c = c1();
       if (affine_lane == 0) s0c = h->ctl_mp;
       if (affine_lane == NL - 1 && affine_lane >= 0) s1c = h->ctl_mp;
-      if (lead && !h->comm && fuse_upd) {
+      if (lead && insum(h) && fuse_upd) {
         // riding steps: beta_1 of the LSQR lanes goes with THIS product's leaders too; a lane without a step of its own has the
         // control block it brings to this product published as it is (ride_leader, kind NONE)
         pend[0] = b0;
         pend[1] = b1;
+        if (h->comm)  // (halo mode: ||rhs||^2 runs over the ranks' owned parts)
+          if (int rc = prepare_step(h, pend[0], pend[1], /*sharded=*/true)) return rc;
         have_pend = true;
         const StepArgs* pre = pre_args(false);
         if (pend[0].kind == STEP_NONE) pend[0].state = const_cast<LaneCtl*>(s0c);
@@ -2699,6 +2786,8 @@ struct KrylovRun {
       sm[l].state_out = lanes[l].state_alt2;
       sm[l].prod_ctl_off = 0;
     }
+    if (h->comm)  // (halo mode: the mid leaders' sums run over the ranks -- the exchange behind the head steps')
+      if (int rc = prepare_step(h, sm[0], sm[1], true)) return rc;
     UpdSeg cu[2] = {seg_none(), seg_none()};
     for (int l = 0; l < NL; ++l)
       if (is_ln(lanes[l].kind)) ln_upd_segs(l, cu[0], cu[1]);
@@ -3013,6 +3102,7 @@ int ensure_gather_layout(fpsq_handle h) {
   }
   h->gather_ready = true;
   h->info.comm_route = h->comm->route();
+  h->info.comm_in_launch_sums = insum(h) ? 1 : 0;
   return 0;
 }
 
@@ -3130,6 +3220,11 @@ int call_end_ordered(fpsq_handle h, double seq) {
         return FPSQ_ERR_TIMEOUT;
       }
     }
+  }
+  if (h->comm && h->comm->failed()) {
+    h->info.p2p_timeouts++;
+    h->err = "peer-to-peer exchange: a peer's record did not arrive (bounded wait expired)";
+    return FPSQ_ERR_TIMEOUT;
   }
   if (ride_failed(h)) return FPSQ_ERR_TIMEOUT;
   h->info.last_solve_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h->t_call).count();
@@ -3971,7 +4066,7 @@ namespace {
 // stand-alone form of qp_fx (sharded runs: the m-vector sums pass through an all-reduce first)
 __global__ __launch_bounds__(kBlock) void k_qp_fx(const FxArgs a, const LaneCtl* gate0, const LaneCtl* gate1) {
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
-  __shared__ double red[16];
+  __shared__ double red[kFxRed];
   qp_fx(a, red);
 }
 }  // namespace
@@ -4058,6 +4153,12 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
     fa.eta = eta;
     fa.out = h->hscal_dev;
     fa.stride = 1;
+    // (row-sharded with in-launch sums: the reduction adds the ranks' four local sums up itself, in rank order -- xch_sum)
+    const bool in_launch = insum(h);
+    if (const XchTable* xt = in_launch ? insum_table(h) : nullptr) {
+      fa.xt = xt;
+      fa.xseq = ++h->xch_seq;
+    }
     FxArgs none = fa;
     none.out = nullptr;
     if (paired) {
@@ -4067,7 +4168,7 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
       // extra launch costs more than the earlier return gains.  (Round 3 first let it ride in the product launch as its
       // first workgroup: the extra case in the product kernel's update switch cost the A' kernel 11 VGPRs and ~5 % of its
       // time -- 2 % of an evaluation.)
-      const bool early_fx = !h->comm && (h->ab_mask & 4);
+      const bool early_fx = in_launch && (h->ab_mask & 4);
       if (early_fx) {
         hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa, h->gate0, h->gate1);
         h->launches++;
@@ -4075,7 +4176,7 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
       launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), h->halo);
       if (h->halo)
         if (int rc = halo_finish<2>(h, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr)) return rc;
-      const bool grad_fx = !h->comm && !early_fx;
+      const bool grad_fx = in_launch && !early_fx;
       hipLaunchKernelGGL(k_qp_penalty_grad, dim3(grad_fx ? gn + 1 : gn), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
                          h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, grad_fx ? fa : none,
                          h->gate0, h->gate1);
@@ -4083,12 +4184,12 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
     } else {
       if (rho > 0.0)
         if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)
-      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(h->comm ? gn : gn + 1), dim3(kBlock), 0, s, h->p1, h->g,
+      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(in_launch ? gn + 1 : gn), dim3(kBlock), 0, s, h->p1, h->g,
                          (const double*)nullptr, h->Cx, qp->q, h->jc, dx, dxk, sigma, rho, eta, h->gs, dgx, n,
-                         h->comm ? none : fa, h->gate0, h->gate1);
+                         in_launch ? fa : none, h->gate0, h->gate1);
       h->launches++;
     }
-    if (h->comm) {  // phi: c'ys and c'c are sums over the rank's rows only
+    if (!in_launch) {  // phi: c'ys and c'c are sums over the rank's rows only
       PresumArgs P{};
       P.p[0] = fa.pcy;
       P.n[0] = gm;
@@ -4138,7 +4239,7 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
   ht_mark(h, 5);
   // Stream-ordered outputs (fpsq_set_output_ordering): with every vector argument resident on this GPU the call returns
   // once phi and the statistics are on the host; the registered stream is made to wait for the rest of the epilogue.
-  const bool ordered = h->out_ordered && !(h->ab_mask & 8) && h->in_stream_on && !h->profile && !h->comm && paired && dx == x &&
+  const bool ordered = h->out_ordered && !(h->ab_mask & 8) && h->in_stream_on && !h->profile && insum(h) && paired && dx == x &&
                        (!gx || dgx == gx) && (!ys || on_this_device(h, ys)) && (!gs || on_this_device(h, gs));
   if (ordered) {
     if (int rc = call_end_ordered(h, seq)) return rc;

@@ -384,9 +384,14 @@ __device__ __forceinline__ void upd_lnlq_short(const UpdSeg& s, int blk, const L
 // semantics, so a host that polls it (stream-ordered outputs, see fpsq_set_output_ordering) finds the three values there.
 // stride: distance (doubles) between consecutive entries of every array (4 when the arrays are the ranks' gathered
 // quadruples of a sharded run: entry r of array k at [4 r + k]; summed in rank order)
+// xt (row-sharded runs whose sums over the ranks are formed inside the launch, fpsq_krylov.hip.h xch_sum): the arrays are this
+// rank's local partials; the four local sums travel as exchange `xseq` and are added in rank order.  red16: 16 + 36 doubles then.
+struct XchTable;
+template <int NV>
+__device__ __forceinline__ void xch_sum(const XchTable* xt, unsigned int seq, int half, double (&v)[NV], double* red);
 __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, const double* pcy, const double* pcc, int np_n,
                                            int np_m, double rho, double eta, double* out, double seq, double* red16,
-                                           int stride = 1) {
+                                           int stride = 1, const XchTable* xt = nullptr, unsigned int xseq = 0) {
   // All four arrays in ONE batch of loads (<= 4 entries per thread and array: the grids of the kernels that wrote them
   // are capped at kEwBlocksMax = 4 x kBlock), unconditional with clamped indices like k_step's partial_batch; a longer
   // array falls back to the strided loop.  Fixed summation order.
@@ -425,11 +430,16 @@ __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, 
     for (int k = 0; k < 4; ++k) red16[w * 4 + k] = v[k];
   }
   __syncthreads();
+  double q4[4] = {0.0, 0.0, 0.0, 0.0};
   if (t == 0) {
-    const double f = (red16[0] + red16[4]) + (red16[8] + red16[12]);
-    const double dx = (red16[1] + red16[5]) + (red16[9] + red16[13]);
-    const double cy = (red16[2] + red16[6]) + (red16[10] + red16[14]);
-    const double cc = (red16[3] + red16[7]) + (red16[11] + red16[15]);
+    q4[0] = (red16[0] + red16[4]) + (red16[8] + red16[12]);
+    q4[1] = (red16[1] + red16[5]) + (red16[9] + red16[13]);
+    q4[2] = (red16[2] + red16[6]) + (red16[10] + red16[14]);
+    q4[3] = (red16[3] + red16[7]) + (red16[11] + red16[15]);
+  }
+  if (xt != nullptr) xch_sum<4>(xt, xseq, 0, q4, red16 + 16);  // (uniform)
+  if (t == 0) {
+    const double f = q4[0], dx = q4[1], cy = q4[2], cc = q4[3];
     double fx = f - cy;
     if (rho > 0.0) fx += rho / 2 * cc;
     if (eta > 0.0) fx += eta / 2 * dx;
@@ -1029,10 +1039,13 @@ struct FxArgs {
   double rho, eta;
   double* out;  // null: not computed by this launch
   double seq;   // call sequence number stored behind the results (out[3])
-  int32_t stride, pad_;  // see qp_fx_core
+  int32_t stride;  // see qp_fx_core
+  uint32_t xseq;
+  const XchTable* xt;  // non-null: the local sums are added up over the ranks inside this launch (qp_fx_core)
 };
-__device__ __forceinline__ void qp_fx(const FxArgs& a, double* red) {
-  qp_fx_core(a.pf, a.pdx, a.pcy, a.pcc, a.np_n, a.np_m, a.rho, a.eta, a.out, a.seq, red, a.stride);
+constexpr int kFxRed = 16 + 36;  // LDS doubles of qp_fx (the block reduction + xch_sum<4>'s scratch)
+__device__ __forceinline__ void qp_fx(const FxArgs& a, double* red /* kFxRed */) {
+  qp_fx_core(a.pf, a.pdx, a.pcy, a.pcc, a.np_n, a.np_m, a.rho, a.eta, a.out, a.seq, red, a.stride, a.xt, a.xseq);
 }
 
 // QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2.
@@ -1051,7 +1064,7 @@ __global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __rest
   if (fx.out) {
     --nb;
     if ((int)blockIdx.x == nb) {
-      __shared__ double red[16];
+      __shared__ double red[kFxRed];
       qp_fx(fx, red);
       return;
     }

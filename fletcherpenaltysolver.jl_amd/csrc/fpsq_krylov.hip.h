@@ -751,6 +751,119 @@ __device__ __forceinline__ void minres_c_step(MinresState* S, double xx, int it,
   }
 }
 
+// =============================================================================================== sums over the ranks, inside a launch
+// Row-sharded runs in halo mode on the peer-to-peer route: a sum over the ranks is formed BY THE WORKGROUP THAT NEEDS IT, inside the
+// launch it belongs to -- no gather kernel, no collective call between two product launches (round 5; the all-gathered arrays of
+// round 4, StepArgs::nseg, remain for the RCCL route and for ranks sharing one device).  Every rank owns a small receive area
+//     rx[kXchRing][nranks][8 words]          (fine-grained memory, mapped by the peers: hipIpcOpenMemHandle / the same device)
+// of self-validating 8-byte words -- the exchange's sequence number in the low half, half a double in the high half, like the
+// leaders' records: a word is written and read in one piece, so no flag, no fence, no ordering between the words.  A workgroup that
+// holds its rank's local sums (a scalar-step leader: two sums of its lane; the phi reduction: four) WRITES them into every
+// peer's area (row = its own rank), then polls its own area until every peer's row carries this exchange's number, and adds the
+// P rows up IN RANK ORDER: the same bits on every rank whatever arrives first, so the replicated recurrence scalars -- and with
+// them iteration counts, loop exits and the host's launch sequence -- stay identical by construction.
+//  * Redundant writers are harmless: the eight leaders of a lane (one per XCD) all hold the same bits and all push them.
+//  * The ring: exchange k uses slot k mod 4.  A launch carries at most two exchanges per lane (the head and the mid step of a
+//    one-launch iteration) and a rank cannot START exchange k + 2 before every workgroup of the launch that held exchange k has
+//    ended (stream order); a peer can be at most one exchange ahead of the slowest rank (it needs that rank's row to go on).  So
+//    slot k mod 4 is rewritten (by exchange k + 4) only after every reader of exchange k is gone -- including a mid leader
+//    that repeats the head step's exchange, and a leader that another kernel held up for a whole launch.
+//  * Every wait is bounded (max_polls looks with a sleep in between); an expired wait raises the communicator's host-mapped
+//    failure word, the sums come out as NaN, and every later exchange of the call leaves at once when it finds the word set:
+//    the call returns FPSQ_ERR_TIMEOUT (fpsq_info.p2p_timeouts), never hangs.
+// ONE PROCESS PER GPU is assumed here: the waiting leaders keep the other workgroups of their launch waiting for the record, and
+// those hold workgroup slots -- ranks that SHARE a device (the one-GPU rehearsals of tests/) could starve each other of the
+// slots their own leaders need.  The communicator therefore switches this on only when every rank has a device of its own
+// (IpcComm::arm), or when a test with small grids forces it (FPSQ_LX=2).
+constexpr int kXchRanks = 8;
+constexpr int kXchRing = 4;
+constexpr int kXchWords = 8;  // per (slot, sender): lane 0's two sums (4 words), lane 1's (4 words); phi uses all eight for its four
+struct XchTable {
+  unsigned long long* peer[kXchRanks];  // rank p's receive area; peer[rank] is this rank's own
+  int32_t nranks, rank;
+  int32_t max_polls;
+  int32_t delay_rank;                   // tests (FPSQ_DEBUG_XCH_DELAY = r + 1): rank r holds every push back by ~100 us
+  int* fail;                            // host-mapped: a bounded wait for a peer expired
+};
+__device__ __forceinline__ unsigned long long xch_hi(double v, unsigned int seq) {
+  return ((unsigned long long)__double_as_longlong(v) & 0xffffffff00000000ull) | seq;
+}
+__device__ __forceinline__ unsigned long long xch_lo(double v, unsigned int seq) {
+  return ((unsigned long long)__double_as_longlong(v) << 32) | seq;
+}
+// Every thread of the workgroup calls this (>= 64 threads; workgroup barriers inside).  In: v[0 .. NV) valid in thread 0 = this
+// rank's local sums.  Out: v[] in thread 0 = the sums over the ranks.  `half`: which half of the sender's row (NV = 2: the lane
+// of the step; NV = 4: 0).  red: LDS scratch, >= 9 * NV doubles.
+template <int NV>
+__device__ __forceinline__ void xch_sum(const XchTable* xt, unsigned int seq, int half, double (&v)[NV], double* red) {
+  static_assert(NV == 2 || NV == 4, "a step's two sums or phi's four");
+  const int t = threadIdx.x;
+  const int P = xt->nranks, me = xt->rank;
+  __syncthreads();  // (red may still be read by the reduction that produced v)
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[k] = v[k];
+  }
+  __syncthreads();
+  const int woff = NV == 2 ? 4 * half : 0;
+  const size_t slot = (size_t)(seq & (kXchRing - 1)) * (size_t)P * kXchWords;
+  if (t < P) {
+    double got[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) got[k] = red[k];
+    if (t != me) {
+      const bool dead = __hip_atomic_load(xt->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+      if (!dead) {
+        if (xt->delay_rank == me + 1) {  // (tests: what a rank that is late with its push does to the others)
+          const unsigned long long t0 = wall_clock64();
+          while (wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(32);
+        }
+        unsigned long long* dst = xt->peer[t] + slot + (size_t)me * kXchWords + woff;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          __hip_atomic_store(dst + 2 * k, xch_hi(got[k], seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(dst + 2 * k + 1, xch_lo(got[k], seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      const unsigned long long* src = xt->peer[me] + slot + (size_t)t * kXchWords + woff;
+      unsigned long long w[2 * NV];
+      bool ok = false;
+      for (int look = 0; look < xt->max_polls && !dead && !ok; ++look) {
+        if (look) {
+          __builtin_amdgcn_s_sleep(8);
+          if ((look & 255) == 0 && __hip_atomic_load(xt->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        }
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < 2 * NV; ++k) {
+          w[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          ok = ok && (unsigned int)(w[k] & 0xffffffffull) == seq;
+        }
+      }
+      if (ok) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+          got[k] = __longlong_as_double((long long)((w[2 * k] & 0xffffffff00000000ull) | (w[2 * k + 1] >> 32)));
+      } else {
+        if (!dead) __hip_atomic_store(xt->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) got[k] = __builtin_nan("");
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[NV + t * NV + k] = got[k];
+  }
+  __syncthreads();
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double a = 0.0;
+      for (int r = 0; r < P; ++r) a += red[NV + r * NV + k];  // rank order
+      v[k] = a;
+    }
+  }
+}
+
 // =============================================================================================== step kernel
 // One launch advances up to two recurrences: workgroup b handles step[b]; the norm partials of a product are summed in a
 // fixed order (reproducible).
@@ -782,7 +895,12 @@ struct StepArgs {
   void* state_out;
   // riding steps: the 8-byte-word offset, inside the state, of the control block whose ca / cb / done / skip the NEXT product
   // reads (0: the state's first member; a MINRES lane has a second block, ctlT, for A' products)
-  int32_t prod_ctl_off, pad_;
+  int32_t prod_ctl_off;
+  // Row-sharded runs with the sums over the ranks formed inside the launch (xch_sum above; xt null: not this step): p0 / p1 are
+  // the rank's LOCAL arrays, the step's two sums travel as exchange `xseq`, in half `xlane` of the rows
+  int32_t xlane;
+  const XchTable* xt;
+  uint32_t xseq, pad_;
 };
 
 // 256 threads: the <= ~5000 norm partials are still summed with a few batches of independent loads per thread, and a
@@ -994,6 +1112,12 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
     // (contains the workgroup barrier that publishes `st`)
     if (a.nseg > 1) reduce_two_seg(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, a.nseg, a.seg_stride, red, s0, s1);
     else reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);
+    if (a.xt != nullptr) {  // (uniform; `skip` is too, on every rank: the states are replicated)
+      double v[2] = {s0, s1};
+      xch_sum<2>(a.xt, a.xseq, a.xlane, v, red);
+      s0 = v[0];
+      s1 = v[1];
+    }
   } else {
     __syncthreads();
   }

@@ -1151,6 +1151,11 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
     if (threadIdx.x == 0) __hip_atomic_store(fz.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;  // (nothing published: whoever waits for this record runs into its own bound)
   }
+  if (!skip && sm.xt != nullptr) {  // (row-sharded: the sum over the ranks, formed here -- fpsq_krylov.hip.h xch_sum; uniform)
+    double v[2] = {s0, 0.0};
+    xch_sum<2>(sm.xt, sm.xseq, sm.xlane, v, red32);
+    s0 = v[0];
+  }
   if (threadIdx.x == 0) {
     if (!skip) step_advance(sm, st80, s0, 0.0, commit ? sm.prog : nullptr);
     ride_publish(reinterpret_cast<const LaneCtl*>(st80 + sm.prod_ctl_off), l, rec, rb.pub);

@@ -225,7 +225,11 @@ int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id
  *                    from then on WRITES its records -- the norm partials of a product, the raw A'u sums of its two overlap
  *                    regions, the four sums of phi -- straight into the peers' buffers, announces them with sequence
  *                    numbers and waits (a bounded number of polls: FPSQ_ERR_TIMEOUT, never a hang) for theirs, one
- *                    one-workgroup kernel per exchange.  Per joint Krylov iteration: 2 product launches + 3 exchange kernels.
+ *                    one-workgroup kernel per exchange.  Per joint Krylov iteration: 2 product launches + 3 exchange kernels --
+ *                    or, when every rank has a device of its own (round 5), NO exchange kernel for the sums: the leader
+ *                    workgroups of the product launches write their rank's local sums into the peers' mapped receive
+ *                    areas and add the ranks' rows up in rank order themselves (fpsq_info.comm_in_launch_sums = 1:
+ *                    2 product launches + the halo launch; one launch per iteration when no row is shared with a neighbour).
  *   FPSQ_ROUTE_RCCL  ncclAllGather / grouped ncclSend + ncclRecv on the solver's stream (3 RCCL operations per iteration:
  *                    latency-bound at the headline size); also what the replicated (non-halo) layout always uses.
  * fpsq_comm_set_route(h, route), after fpsq_comm_init and BEFORE fpsq_comm_set_halo: FPSQ_ROUTE_AUTO (default) = P2P when
@@ -389,6 +393,9 @@ typedef struct {
   /* the Krylov loop of the last call: joint iterations enqueued and kernel launches enqueued for them (exchanges and stand-alone
    * steps included; start-up and epilogue excluded): launches / iterations = launches per joint iteration */
   int64_t last_loop_iterations, last_loop_launches;
+  int64_t comm_in_launch_sums; /* 1: a sharded handle whose sums over the ranks need no launch of their own -- formed inside the
+                                  launches that need them (peer-to-peer route, every rank on a device of its own: csrc
+                                  fpsq_krylov.hip.h xch_sum), or a communicator of one rank; 0: gather / collective launches */
 } fpsq_info;
 int fpsq_get_info(fpsq_handle h, fpsq_info *info);
 /* on != 0: bracket every SpMV/SpMM launch with HIP events on the solver's stream so that last_spmv_ms is filled

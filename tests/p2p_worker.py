@@ -72,7 +72,8 @@ def main():
     fs.append([0.0, rc])
     out["p1"], out["q1"], out["p2"], out["q2"] = o
     out["fs"], out["its"] = np.array(fs), np.array(its)
-    out["route"] = np.array([dev.info()["comm_route"]])
+    i = dev.info()
+    out["route"] = np.array([i["comm_route"], i["comm_in_launch_sums"], i["p2p_timeouts"]])
     dev.close()
     np.savez(os.path.join(d, f"out_{rank}.npz"), **out)
 

@@ -33,7 +33,24 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Stats) == 32
     assert C.sizeof(_lib.Options) == 8 * 17 + 24  # + ln_method, kkt_method
     assert _lib.Options.ln_method.offset == 8 * 17 + 16 and _lib.Options.kkt_method.offset == 8 * 17 + 20
-    assert C.sizeof(_lib.Info) == 72 + 32 + 8 + 8 + 8  # + at_sorted (round 3), comm_route, last_fused_launches (round 4), appended
+    # + at_sorted (round 3), comm_route, last_fused_launches (round 4), the three counters, the loop's two, comm_in_launch_sums (round 5)
+    assert C.sizeof(_lib.Info) == 72 + 32 + 8 + 8 + 8 + 24 + 16 + 8
+    assert _lib.Info.fuse_fallbacks.offset == 128 and _lib.Info.comm_in_launch_sums.offset == 168
+
+
+def test_struct_sizes_against_the_c_compiler(tmp_path):
+    """The ctypes mirrors against include/fpsq.h as gcc lays it out (sizes and the offsets of the last members)."""
+    import subprocess
+
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "fpsq.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '
+                   "sizeof(fpsq_info), offsetof(fpsq_info, comm_in_launch_sums), sizeof(fpsq_options), sizeof(fpsq_stats), "
+                   "sizeof(fpsq_dense_info), sizeof(fpsq_band_info)); return 0; }\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(_lib.Info), _lib.Info.comm_in_launch_sums.offset, C.sizeof(_lib.Options), C.sizeof(_lib.Stats),
+                   C.sizeof(_lib.DenseInfo), C.sizeof(_lib.BandInfo)]
 
 
 def test_default_options_follow_reference_defaults():

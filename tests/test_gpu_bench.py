@@ -36,14 +36,23 @@ def test_bench_prints_one_contract_line():
 
 def test_force_shard_world1_runs_the_sharded_path_through_rccl():
     """The halo-sharded code path with a real RCCL communicator of size 1: same iteration counts as the single-GPU run."""
-    a = _run(SMALL + ["--cpu-evals", "0"])
-    b = _run(SMALL + ["--cpu-evals", "0", "--force-shard", "--workload", "pde-control-like n=1e6 m=1e5 nnz=1e7"])
-    c = _run(["--steps", "3", "--warmup", "1", "--repeats", "1", "--cpu-evals", "0"])
-    assert a.returncode == 0 and b.returncode == 0 and c.returncode == 0, (a.stderr[-800:], b.stderr[-800:], c.stderr[-800:])
-    db, dc = json.loads(b.stdout.strip().splitlines()[-1]), json.loads(c.stdout.strip().splitlines()[-1])
+    head = ["--steps", "3", "--warmup", "1", "--repeats", "1", "--cpu-evals", "0"]
+    b = _run(head + ["--force-shard"])
+    b2 = _run(head + ["--force-shard", "--comm-route", "rccl"])
+    c = _run(head)
+    assert b.returncode == 0 and b2.returncode == 0 and c.returncode == 0, (b.stderr[-800:], b2.stderr[-800:], c.stderr[-800:])
+    db, db2, dc = (json.loads(r.stdout.strip().splitlines()[-1]) for r in (b, b2, c))
     assert db["scaling"] == "strong" and "HALO" in db["config"]["parallelism"]
     assert db["config"]["comm_route"] == "p2p-ipc"  # (auto: the peer-to-peer route; with one rank there is nothing to map)
-    assert db["config"]["iters_lsqr_craig_median"] == dc["config"]["iters_lsqr_craig_median"]
+    assert db2["config"]["comm_route"] == "rccl"
+    for d in (db, db2):
+        assert d["config"]["iters_lsqr_craig_median"] == dc["config"]["iters_lsqr_craig_median"]
+        # a communicator of one: nothing to exchange -- the sharded handle runs the single-GPU launch pattern, ONE launch per
+        # joint iteration (plus the stand-alone step in front of the gated epilogue), and nothing waited too long
+        assert d["config"]["comm_in_launch_sums"] is True
+        assert d["config"]["loop_launches_per_iteration"] <= 1.2, d["config"]
+        assert d["config"]["fuse_fallbacks"] == d["config"]["wait_timeouts"] == d["config"]["p2p_timeouts"] == 0
+    assert dc["config"]["loop_launches_per_iteration"] <= 1.2 and dc["config"]["fuse_fallbacks"] == 0
     assert len([ln for ln in b.stdout.splitlines() if ln.strip()]) == 1  # the RCCL banner stays off stdout
 
 

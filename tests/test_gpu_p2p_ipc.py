@@ -74,7 +74,8 @@ def _reference(delta):
     return qp, out, np.array(its), fs
 
 
-@pytest.mark.parametrize("nranks,route", [(2, "p2p"), (3, "p2p"), (2, "auto"), (2, "rccl"), (3, "p2p-two-launch-halo")])
+@pytest.mark.parametrize("nranks,route", [(2, "p2p"), (3, "p2p"), (2, "auto"), (2, "rccl"), (3, "p2p-two-launch-halo"),
+                                          (2, "p2p-in-launch"), (3, "p2p-in-launch"), (3, "p2p-in-launch-late-rank")])
 @pytest.mark.parametrize("delta", [0.0, SE])
 def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, route, delta):
     """Same iteration counts as the single-GPU handle, vectors to 1e-9 (only the order of the reductions differs), phi
@@ -82,11 +83,21 @@ def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, rou
     two ranks sharing them; the handles report the route they run on (p2p and auto: peer to peer; rccl: the collectives).
     On the peer-to-peer route the halo exchange and the finish of the overlap rows are ONE launch (k_p2p_halo_finish: the
     finish workgroups wait for the neighbours' records themselves); "p2p-two-launch-halo" (FPSQ_HALO_FUSE=0) keeps the
-    exchange kernel and the finish kernel apart."""
+    exchange kernel and the finish kernel apart.  "p2p-in-launch" (round 5): the sums over the ranks are formed inside the
+    launches that need them (fpsq_krylov.hip.h xch_sum) -- what ranks with a device of their own do by default; between
+    processes SHARING this box's GPU it has to be forced (FPSQ_LX=2; the grids of this problem are resident all at once);
+    "-late-rank": rank 1 holds every one of its pushes back by ~100 us (FPSQ_DEBUG_XCH_DELAY): nothing may depend on when a
+    row arrives."""
     qp, want, its_ref, fs_ref = _reference(delta)
     extra = None
+    in_launch = route.startswith("p2p-in-launch")
     if route == "p2p-two-launch-halo":
         route, extra = "p2p", {"FPSQ_HALO_FUSE": "0"}
+    elif in_launch:
+        extra = {"FPSQ_LX": "2"}
+        if route.endswith("late-rank"):
+            extra["FPSQ_DEBUG_XCH_DELAY"] = "2"
+        route = "p2p"
     rcs, outs = _run_ranks(nranks, route, delta, tmp_path, extra_env=extra)
     assert all(rc == 0 for rc in rcs), [o[1][-1500:] for o in outs]
     res = [np.load(os.path.join(tmp_path, f"out_{r}.npz")) for r in range(nranks)]
@@ -94,6 +105,8 @@ def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, rou
     plan = halo_plan(qp.rowptr, qp.colind, qp.n, bounds)
     for r in range(nranks):
         assert int(res[r]["route"][0]) == (1 if route == "rccl" else 2)
+        assert int(res[r]["route"][1]) == (1 if in_launch else 0)   # fpsq_info.comm_in_launch_sums
+        assert int(res[r]["route"][2]) == 0                          # p2p_timeouts
         assert np.array_equal(res[r]["its"], its_ref), (r, res[r]["its"], its_ref)
         assert np.array_equal(res[r]["fs"], res[0]["fs"])  # phi and the return codes: replicated, bitwise
         assert np.all(res[r]["fs"][:, 1] == 0)
@@ -115,3 +128,49 @@ def test_a_missing_peer_ends_in_an_error_not_a_hang(tmp_path):
     rcs, outs = _run_ranks(2, "p2p", 0.0, tmp_path, extra_env={"FPSQ_TEST_P2P_DESERT": "1", "FPSQ_P2P_POLLS": "300000"}, timeout=400)
     assert rcs[1] == 0 and rcs[0] != 0
     assert "bounded wait" in outs[0][1] or "did not arrive" in outs[0][1], outs[0][1][-1500:]
+
+
+_NINE = r'''
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch  # noqa: F401
+import fps_amd  # noqa: F401
+from fps_amd import problems
+from fps_amd.device_qp import DeviceEqQP, rccl_unique_id
+from fps_amd.qdsolver import FpsqError
+qp = problems.pde_control_like(n=24000, m=2400, per_row=24, window=512, seed=29)
+ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0)
+g0 = np.empty(qp.n)
+f0, rc0 = ref.objgrad(qp.x, gx=g0)
+its0 = (ref.stats[0].niter, ref.stats[1].niter)
+ref.close()
+# rank 0 of NINE (the other eight are phantoms of the stand-in library: their records are zeros), holding every row
+dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, comm=("rccl", 9, 0, rccl_unique_id()), halo=(0, 0), comm_route="auto")
+g = np.empty(qp.n)
+f, rc = dev.objgrad(qp.x, gx=g)
+i = dev.info()
+assert i["comm_route"] == 1, i                      # FPSQ_ROUTE_RCCL: the peer tables hold 8 ranks
+assert rc == rc0 and (dev.stats[0].niter, dev.stats[1].niter) == its0
+assert abs(f - f0) <= 1e-9 * abs(f0) and np.max(np.abs(g - g0)) <= 1e-9 * np.max(np.abs(g0))
+assert i["p2p_timeouts"] == 0 and i["wait_timeouts"] == 0
+dev.close()
+dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=0.0, comm=("rccl", 9, 0, rccl_unique_id()), halo=(0, 0), comm_route="p2p")
+try:
+    dev.objgrad(qp.x, gx=g)
+except FpsqError as e:
+    assert "more than 8 ranks" in str(e), str(e)
+    print("NINE-OK")
+else:
+    raise SystemExit("an explicit peer-to-peer request with 9 ranks must fail")
+'''
+
+
+def test_more_ranks_than_a_node_stay_on_the_collectives():
+    """The peer tables of the peer-to-peer route hold the GPUs of ONE node (kMaxP2PRanks = 8).  A communicator of 9 ranks (two
+    nodes, or 16 logical ranks) must stay on RCCL under FPSQ_ROUTE_AUTO -- decided before any table is indexed -- and fail
+    an explicit FPSQ_ROUTE_P2P request with FPSQ_ERR_COMM (advisor, round 4: it indexed the tables out of bounds).  One process
+    holds rank 0 of 9; the other ranks are phantoms of the stand-in library (FPSQ_SHIM_PHANTOM: zero records)."""
+    env = dict(os.environ, FPSQ_RCCL_LIB=_shim(), FPSQ_SHIM_PHANTOM="1", FPSQ_SHIM_TIMEOUT="60")
+    r = subprocess.run([sys.executable, "-c", _NINE, ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NINE-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

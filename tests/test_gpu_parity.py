@@ -1621,9 +1621,9 @@ def test_row_sharded_objgrad_matches_single_gpu(oracle, nshards, delta):
     group.close()
 
 
-@pytest.mark.parametrize("nshards,p2p", [(2, False), (3, False), (8, False), (2, True), (3, True)])
+@pytest.mark.parametrize("nshards,p2p", [(2, False), (3, False), (8, False), (2, True), (3, True), (2, "in-launch"), (3, "in-launch")])
 @pytest.mark.parametrize("delta", [0.0, SE])
-def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta):
+def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta, monkeypatch):
     """HALO mode (include/fpsq.h fpsq_comm_set_halo; the SURVEY 8e contract path): every shard holds only its column
     window of the n-vectors and exchanges the partial A'u products of its two overlap regions with its neighbours
     (in-process communicator: copy kernels instead of ncclSend/ncclRecv) plus 4-double all-reduces.  objgrad and hprod
@@ -1631,10 +1631,17 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta
     the reductions differs); overlaps are bitwise identical on the two ranks that share them; phi is bitwise
     identical on all shards (replicated scalars).  p2p: the same through the PEER-TO-PEER route (fpsq_local_group_set_p2p:
     halo records and norm partials written straight into the peers' buffers, sequence flags, bounded waits -- the protocol
-    of the xGMI route, no collective call in the loop)."""
+    of the xGMI route, no collective call in the loop).  "in-launch" (round 5; FPSQ_LX=2 forces it between shards of one device,
+    whose small grids are resident all at once): the sums over the ranks are formed INSIDE the launches that need them -- the
+    leader workgroups and the phi reduction write their local sums into the peers' receive areas and add the rows up in rank
+    order (fpsq_krylov.hip.h xch_sum): no gather kernel; fpsq_info.comm_in_launch_sums = 1."""
     from fps_amd.device_qp import LocalGroup
     from fps_amd.distributed import halo_plan, row_partition, shard_qp_halo
 
+    in_launch = p2p == "in-launch"
+    if in_launch:
+        monkeypatch.setenv("FPSQ_LX", "2")
+        p2p = True
     qp = problems.pde_control_like(n=24000, m=2400, per_row=24, window=512, seed=29)
     sigma, rho = 1e3, 1.0
     ref = DeviceEqQP(qp, sigma=sigma, rho=rho, delta=delta)
@@ -1663,6 +1670,10 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta
         assert rc == rc_ref == 0
         assert (shards[r].stats[0].niter, shards[r].stats[1].niter) == it_ref
         assert f == res[0][0] and abs(f - f_ref) <= 1e-9 * abs(f_ref)
+        i = shards[r].info()
+        assert i["comm_in_launch_sums"] == (1 if in_launch else 0) and i["p2p_timeouts"] == 0
+        if in_launch:  # per joint iteration: the two product launches + the halo launch, no gather kernel
+            assert i["last_loop_launches"] <= 3 * i["last_loop_iterations"] + 2, i
         if r + 1 < nshards:  # the overlap with the right neighbour: same global columns, bitwise equal
             t = plan.overlaps(r)[1]
             assert t > 0 and np.array_equal(gx[r][-t:], gx[r + 1][:t]) and np.array_equal(gs[r][-t:], gs[r + 1][:t])

@@ -7,9 +7,23 @@
 J = joint Krylov iterations per evaluation (max of the LSQR / CRAIG counts bench.py prints).  Corrections per
 MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KB and reports half of the bytes of coalesced streaming reads on
 gfx950 (hbm_read = 2 * 1024 * FETCH_SIZE); WRITE_SIZE is exact (hbm_write = 1024 * WRITE_SIZE)."""
-import collections, csv, json, sys
+import collections, csv, hashlib, json, os, subprocess, sys
 
 fetch_csv, write_csv, J = sys.argv[1], sys.argv[2], int(sys.argv[3])
+WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "pde-control-hashed n=1e6 m=1e5 nnz=1e7"  # (bench.py's default)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_sha16():
+    """sha256 over the kernel sources the profile was taken on (csrc/*.hip, *.hip.h, sorted by name): bench.py computes the same
+    and REFUSES a profile whose kernels are no longer the ones it runs (roofline.traffic = null, traffic_source says why)."""
+    d = os.path.join(ROOT, "fletcherpenaltysolver.jl_amd", "csrc")
+    hh = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(".hip") or fn.endswith(".hip.h"):
+            hh.update(fn.encode())
+            hh.update(open(os.path.join(d, fn), "rb").read())
+    return hh.hexdigest()[:16]
 n, m, nnz = 1_000_000, 100_000, 10_000_000
 
 
@@ -53,7 +67,12 @@ else:
     # (the loop's products are the variants with riding leaders -- k_spmv_rgcs<.., LEAD>, k_spmv_atl -- the start-up and
     # epilogue products the plain ones: one kernel family per matrix)
     family = {"k_spmv_rgcs<2": ("k_spmv_rgcs<2",), "k_spmv<2, 1": ("k_spmv<2, 1", "k_spmv_atl<")}
-out = {"_how": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "workload": "pde-control-like n=1e6 m=1e5 nnz=1e7",
+try:
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    head = None
+out = {"_how": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "workload": WORKLOAD,
+       "kernel_sources_sha16": kernel_sources_sha16(), "git_head_when_post_processed": head,
        "joint_iterations": J, "fused_iterations": fused, "kernels": {}}
 tb = ab = 0.0
 for key in alg:
