@@ -96,6 +96,9 @@ struct Comm {
   };
   // peer-to-peer routes: the exchange and the finish of the overlap rows as ONE launch (k_p2p_halo_finish); false: not here
   virtual bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) { return false; }
+  // ... and both INSIDE the one-launch iteration (k_iter_fused<.., HALO>): fills the peers' part of the launch's FuseHalo (slots,
+  // flag words, the exchange's sequence number); false: this communicator cannot (RCCL: the exchange is a library call)
+  virtual bool halo_fused_args(const double* recv, int64_t tl, int64_t tr, FuseHalo& fh) { return false; }
   virtual int arm(const Buffers&, hipStream_t) { return 0; }
   virtual bool failed() { return false; }  // a bounded wait of the peer-to-peer route expired
   // Memory a peer may write into (the gather buffers, the halo slots): a communicator that exports it to other processes
@@ -212,6 +215,15 @@ struct P2PRoute {
     return H;
   }
   bool fuse_halo = true;  // FPSQ_HALO_FUSE=0: exchange and finish as two launches
+  bool halo_fused_args(const double* recv, int64_t tl, int64_t tr, FuseHalo& fh) {
+    if (!armed) return false;
+    fh.H = halo_peers(2, tl, tr, recv);
+    fh.seq = ++halo_seq;
+    fh.fail = fail_dev;
+    fh.max_spins = max_spins;
+    fh.arrive = flags + 12;
+    return true;
+  }
   bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) {
     if (!armed || !fuse_halo) return false;
     const P2PHalo H = halo_peers(NL, fa.tl, fa.tr, fa.recv);
@@ -515,6 +527,7 @@ struct IpcComm : RcclComm {
   bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) override {
     return rt.halo_exchange_finish(NL, fa, finish_wgs, s);
   }
+  bool halo_fused_args(const double* recv, int64_t tl, int64_t tr, FuseHalo& fh) override { return rt.halo_fused_args(recv, tl, tr, fh); }
   void close_peers() {
     for (int r = 0; r < kMaxP2PRanks; ++r)
       for (int k = 0; k < 3; ++k)
@@ -690,6 +703,7 @@ struct P2PLocalComm : LocalComm {
   bool halo_exchange_finish(int NL, const HaloFinishArgs& fa, int finish_wgs, hipStream_t s) override {
     return rt.halo_exchange_finish(NL, fa, finish_wgs, s);
   }
+  bool halo_fused_args(const double* recv, int64_t tl, int64_t tr, FuseHalo& fh) override { return rt.halo_fused_args(recv, tl, tr, fh); }
   ~P2PLocalComm() override { rt.release(); }
 };
 
@@ -767,6 +781,14 @@ struct fpsq_solver_s {
   int mmid_cap = 0;             // workgroups of k_minres_mid the device holds at once (occupancy x CUs): its grid must fit with a margin
   int64_t loop_launches = 0, loop_iters = 0;  // the Krylov loop(s) of the current call (fpsq_info.last_loop_*)
   int2* fz_dep = nullptr;                 // per row group: the A' blocks it waits for
+  // halo-sharded handles (setup_fused_halo, at fpsq_comm_set_halo): the finish workgroups a row group waits for, the A' blocks
+  // that deposit the raw sums of the two overlap regions; what the set-up needs again then (block boundaries, column ranges)
+  int2* fz_dep2 = nullptr;
+  int2 fz_depL{1, 0}, fz_depR{1, 0};
+  bool fuse_halo_ok = false;
+  bool fuse_halo_on = true;               // FPSQ_FUSE_HALO=0: a handle with shared rows keeps the halo launch between two product launches
+  std::vector<int32_t> fz_rb;
+  std::vector<int2> fz_colrange;
   unsigned int* fz_flag = nullptr;        // per A' block: launch number of its last completion
   unsigned long long* fz_ptag = nullptr;  // per A' block: four tagged words (its squared-norm partials)
   unsigned long long* ride_rec2 = nullptr;  // the mid leaders' record
@@ -1485,12 +1507,39 @@ int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<in
   dfree(h, &h->fz_flag);
   dfree(h, &h->fz_ptag);
   if (int rc = dalloc(h, &h->fz_dep, dep.size())) return rc;
-  if (int rc = dalloc(h, &h->fz_flag, (size_t)h->AT.nblk)) return rc;
-  if (int rc = dalloc(h, &h->fz_ptag, (size_t)h->AT.nblk * 4)) return rc;
+  // (+ kEwBlocksMax entries: the finish workgroups of a halo-sharded handle publish themselves behind the blocks)
+  if (int rc = dalloc(h, &h->fz_flag, (size_t)h->AT.nblk + kEwBlocksMax)) return rc;
+  if (int rc = dalloc(h, &h->fz_ptag, ((size_t)h->AT.nblk + kEwBlocksMax) * 4)) return rc;
   HIPCHK(h, hipMemcpy(h->fz_dep, dep.data(), dep.size() * sizeof(int2), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemset(h->fz_flag, 0, (size_t)h->AT.nblk * 4));
-  HIPCHK(h, hipMemset(h->fz_ptag, 0, (size_t)h->AT.nblk * 32));
+  HIPCHK(h, hipMemset(h->fz_flag, 0, ((size_t)h->AT.nblk + kEwBlocksMax) * 4));
+  HIPCHK(h, hipMemset(h->fz_ptag, 0, ((size_t)h->AT.nblk + kEwBlocksMax) * 32));
+  h->fz_rb = rb;
+  h->fz_colrange = col_range;
   h->fuse_ok = true;
+  return 0;
+}
+
+// The one-launch iteration of a halo-sharded handle (fpsq_comm_set_halo, or a new structure on such a handle): which A' blocks
+// deposit the raw sums of the two overlap regions, and which row groups gather from a region (they wait for the finish
+// workgroups).  Needs the regions on 128-byte lines of the long pair (8 rows): distributed.halo_plan rounds its windows so.
+int setup_fused_halo(fpsq_handle h) {
+  h->fuse_halo_ok = false;
+  if (!h->fuse_ok || !h->halo || h->ovl + h->ovr == 0) return 0;
+  if (h->ovl % 8 != 0 || (h->n - h->ovr) % 8 != 0 || h->halo_gf > kEwBlocksMax) return 0;
+  const std::vector<int32_t>& rb = h->fz_rb;
+  auto block_of = [&](int64_t row) { return (int)(std::upper_bound(rb.begin(), rb.end(), (int32_t)row) - rb.begin()) - 1; };
+  h->fz_depL = h->ovl > 0 ? make_int2(0, std::max(block_of(h->ovl - 1), 0)) : make_int2(1, 0);
+  h->fz_depR = h->ovr > 0 ? make_int2(std::max(block_of(h->n - h->ovr), 0), h->AT.nblk - 1) : make_int2(1, 0);
+  std::vector<int2> dep2(h->fz_colrange.size());
+  for (size_t g = 0; g < dep2.size(); ++g) {
+    const int64_t lo = h->fz_colrange[g].x & ~7, hi = std::min<int64_t>((int64_t)h->fz_colrange[g].y | 7, h->n - 1);
+    const bool touches = lo < h->ovl || hi >= h->n - h->ovr;
+    dep2[g] = touches ? make_int2(h->AT.nblk, h->AT.nblk + h->halo_gf - 1) : make_int2(1, 0);
+  }
+  dfree(h, &h->fz_dep2);
+  if (int rc = dalloc(h, &h->fz_dep2, dep2.size())) return rc;
+  HIPCHK(h, hipMemcpy(h->fz_dep2, dep2.data(), dep2.size() * sizeof(int2), hipMemcpyHostToDevice));
+  h->fuse_halo_ok = true;
   return 0;
 }
 
@@ -1524,6 +1573,7 @@ int finish_structure(fpsq_handle h, const HostCsr& HA) {
   }
   if (int rc = alloc_workspaces(h)) return rc;
   if (int rc = setup_fused_iteration(h, HT, col_range)) return rc;
+  if (int rc = setup_fused_halo(h)) return rc;  // (a halo-sharded handle given a new structure)
   HIPCHK(h, hipDeviceSynchronize());  // the set-up used null-stream copies/memsets; the solver stream is non-blocking
   h->have_structure = true;
   h->have_values = false;
@@ -2234,6 +2284,7 @@ struct KrylovRun {
   int look = 1;
   int64_t it = 0;
   int64_t spec_it = -1;  // iteration behind which the gated flush + tail were enqueued
+  int64_t tail_launches = 0;
   UpdSeg winit[2] = {seg_none(), seg_none()};
   UpdSeg lu[2] = {seg_none(), seg_none()};  // what rides in (or precedes) this iteration's products: LSQR's update of the previous one
   int nlu = 0;
@@ -2346,7 +2397,7 @@ struct KrylovRun {
     // (a halo-sharded handle: when its sums over the ranks need no launch of their own and -- for now -- no row of its window is
     // shared with a neighbour: a communicator of one, a block-diagonal Jacobian)
     can_fuse = NL == 2 && h->fuse_ok && h->at_xcd && lead && fuse_upd && minres_lane < 0 && !h->ride_break &&
-               (!h->comm || (h->halo && h->ovl == 0 && h->ovr == 0 && insum(h)));
+               (!h->comm || (h->halo && insum(h) && (h->ovl + h->ovr == 0 || (h->fuse_halo_ok && h->fuse_halo_on))));
     look = std::max(1, o.lookahead);
   }
 
@@ -2780,8 +2831,31 @@ struct KrylovRun {
     }
     const StepArgs* pre = pre_args(true);
     StepArgs sh[2] = {pre[0], pre[NL - 1]}, sm[2];
+    // halo-sharded with rows shared with the neighbours: the exchange and the finish of the overlap rows ride in this launch
+    // (fuse_halo_wg); the finish workgroups' partials follow the blocks'
+    const bool with_halo = h->comm && h->halo && h->ovl + h->ovr > 0;
+    FuseHalo fh{};
+    HaloRows hr{};
+    if (with_halo) {
+      const int64_t t = h->ovl + h->ovr;
+      double* rl = h->halo_recv + (size_t)(h->halo_calls++ & 1) * (size_t)t * 2;
+      if (!h->comm->halo_fused_args(rl, h->ovl, h->ovr, fh)) {
+        h->err = "internal: one-launch iteration on a communicator without in-launch halo exchange";
+        return FPSQ_ERR_STATE;
+      }
+      fh.raw = h->halo_raw;
+      fh.recv = rl;
+      fh.tl = h->ovl;
+      fh.tr = h->ovr;
+      fh.tail0 = h->n - h->ovr;
+      fh.gf = h->halo_gf;
+      fh.nwg = (2 * kHaloCopy + h->halo_gf + 7) / 8 * 8;
+      fh.depL = h->fz_depL;
+      fh.depR = h->fz_depR;
+      hr = HaloRows{h->ovl, h->n - h->ovr, h->halo_raw};
+    }
     for (int l = 0; l < NL; ++l) {
-      sm[l] = step_after_at(l, h->AT.nblk);
+      sm[l] = step_after_at(l, h->AT.nblk + (with_halo ? h->halo_gf : 0));
       sm[l].state = sh[l].state_out;  // (what the head step leaves: the mid leaders recompute it, nobody reads this pointer)
       sm[l].state_out = lanes[l].state_alt2;
       sm[l].prod_ctl_off = 0;
@@ -2816,26 +2890,29 @@ struct KrylovRun {
     fz.blkflag = h->fz_flag;
     fz.ptag = h->fz_ptag;
     fz.dep = h->fz_dep;
+    fz.dep2 = with_halo ? h->fz_dep2 : nullptr;
     fz.want = ra.want;
     fz.pub = h->fuse_break ? ~ra.want : ra.want;
     fz.err = ra.err;
     double* part_a = pa_last == h->pS2 ? h->pS2b : h->pS2;  // (not the array this launch's leaders read)
-    const dim3 grid(kRideCand + fg.nwg_t + kRideCand + fg.nupd_t + 8 * fg.gpx + cu[0].nblk + cu[1].nblk);
+    const dim3 grid(kRideCand + fg.nwg_t + fh.nwg + kRideCand + fg.nupd_t + 8 * fg.gpx + cu[0].nblk + cu[1].nblk);
     if (h->fuse_probe_at > 0 && h->fused_total + 1 == h->fuse_probe_at) {  // developer probe: this launch leaves time stamps
       h->fuse_probe_grid = (int)grid.x;
-      h->fuse_probe_layout = {kRideCand, fg.nwg_t, kRideCand, 8 * fg.gpx, fg.nupd_t, cu[0].nblk + cu[1].nblk};
+      h->fuse_probe_layout = {kRideCand, fg.nwg_t + fh.nwg, kRideCand, 8 * fg.gpx, fg.nupd_t, cu[0].nblk + cu[1].nblk};
       if (dalloc(h, &h->fuse_probe_buf, (size_t)grid.x * 4) == 0) {
         hipMemsetAsync(h->fuse_probe_buf, 0, (size_t)grid.x * 32, h->stream);
         fz.dbg = h->fuse_probe_buf;
       }
     }
     h->fused_total++;
-    if (h->AT.sorted)
-      launch_product(h, k_iter_fused<true>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, part_a, h->strA, fg, lu[0],
-                     lu[1], cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
-    else
-      launch_product(h, k_iter_fused<false>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, part_a, h->strA, fg, lu[0],
-                     lu[1], cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz);
+#define FPSQ_LAUNCH_FUSED(...)                                                                                                        \
+    launch_product(h, k_iter_fused<__VA_ARGS__>, grid, h->AT.view(), h->RA.view, (const double*)SPcur, LP, SPalt, part_a, h->strA, fg, \
+                   lu[0], lu[1], cu[0], cu[1], sh[0], sh[1], sm[0], sm[1], ra, rb, fz, hr, fh)
+    if (h->AT.sorted && with_halo) FPSQ_LAUNCH_FUSED(true, true);
+    else if (h->AT.sorted) FPSQ_LAUNCH_FUSED(true, false);
+    else if (with_halo) FPSQ_LAUNCH_FUSED(false, true);
+    else FPSQ_LAUNCH_FUSED(false, false);
+#undef FPSQ_LAUNCH_FUSED
     h->launches++;
     h->spmv_launches++;
     h->prod_a[1]++;
@@ -2874,7 +2951,9 @@ struct KrylovRun {
     else launch_updates<NL>(h, seg[0], seg[1], seg_none());
     h->gate0 = lanes[0].ctl;
     h->gate1 = lanes[NL - 1].ctl;
+    const int64_t l0 = h->launches;
     const int rc = (*tail)();
+    tail_launches += h->launches - l0;  // (the caller's epilogue, not the loop: fpsq_info.last_loop_launches)
     h->gate0 = h->gate1 = nullptr;
     h->pending_flush.kind = UPD_NONE;
     if (rc) return rc;
@@ -3015,7 +3094,7 @@ struct KrylovRun {
       if (stop) break;
     }
     h->loop_iters += it;
-    h->loop_launches += h->launches - launches0;
+    h->loop_launches += h->launches - launches0 - tail_launches;
     return finish();
   }
 };
@@ -3541,6 +3620,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_AT_XCD")) h->at_xcd = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_FUSE_HALO")) h->fuse_halo_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_MINRES_MERGE")) h->minres_merge = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_ROTATE")) h->fuse_rotate = std::atoi(ev) & 7;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY_MID")) h->ride_delay_mid = std::atoi(ev);
@@ -4468,6 +4548,8 @@ int fpsq_comm_set_halo(fpsq_handle h, int64_t overlap_left, int64_t overlap_righ
   h->halo = true;
   h->ovl = overlap_left;
   h->ovr = overlap_right;
+  if (h->have_structure)
+    if (int rc = setup_fused_halo(h)) return rc;
   return FPSQ_OK;
 }
 

@@ -559,6 +559,8 @@ struct FuseArgs {
   unsigned int* blkflag;          // [blocks of A']: this launch's number once block L's rows are at their coherence point
   unsigned long long* ptag;       // [blocks][4] self-validating words: the blocks' squared-norm partials (lane 0 high, low; lane 1 high, low)
   const int2* dep;                // per row group of A: first and last A' block owning rows on the lines the group gathers from
+  const int2* dep2;               // halo-sharded handles (null otherwise): a second range per group -- the finish workgroups of
+                                  // the overlap rows (their flags follow the blocks': index nblk + b), {1, 0} = none
   unsigned int want;              // this launch's number
   unsigned int pub;               // what the blocks publish: `want` (anything else only in the test of the bounded waits)
   unsigned long long* err;        // host-mapped: a bounded wait expired
@@ -703,7 +705,11 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
           double* dst = hr.raw + (size_t)(row < hr.lo ? row : hr.lo + (row - hr.hi)) * NL;
 #pragma unroll
           for (int l = 0; l < NL; ++l)
-            if (C.act[l]) dst[l] = hacc[t][p][l];
+            if (C.act[l]) {
+              // (FUSED: the halo workgroups of the SAME launch read the raw sums -- written through like the rows)
+              if constexpr (FUSED) __hip_atomic_store(dst + l, hacc[t][p][l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else dst[l] = hacc[t][p][l];
+            }
         } else {
           row_epilogue<NL, FUSED>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
         }
@@ -887,11 +893,14 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
     // behind the first tile's stream, which does not depend on them), a bounded number of times
     if (tid < 64) {
       const int2 d = fz.dep[g];
+      const int2 d2 = fz.dep2 != nullptr ? fz.dep2[g] : make_int2(1, 0);
       bool all = false;
       for (int t = 0; t < kRidePolls && !all; ++t) {
         if (t) __builtin_amdgcn_s_sleep(8);
         bool ok = true;
         for (int L = d.x + tid; L <= d.y; L += 64)
+          ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
+        for (int L = d2.x + tid; L <= d2.y; L += 64)
           ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
         all = __all(ok);
       }
@@ -1174,6 +1183,141 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
   }
 }
 
+// ---- the halo of a row-sharded handle INSIDE the one-launch iteration (round 5).  Behind the A' workgroups the grid carries
+//   2 kHaloCopy push workgroups: wait (bounded) for the flags of the A' blocks that deposit the raw sums of my head / tail region,
+//     then write their slice into the neighbour's slot; the last slice to arrive raises the neighbour's flag word (as
+//     k_p2p_halo_finish does between two product launches);
+//   gf finish workgroups: wait for those blocks AND (bounded, unconditionally: it paces the ranks) for the neighbours' records,
+//     complete the overlap rows -- yout = ca (own + neighbour's) + cb yin, the coefficients from the head leaders' record,
+//     written through -- and publish themselves like A' blocks: flag + tagged squared-norm partials at index nblk + b.
+// Row groups whose lines reach into an overlap region wait for the finish workgroups too (FuseArgs::dep2); the mid leaders sum
+// nblk + gf tagged partials -- the order of the two-launch form's array.  The regions start and end on 128-byte lines of the
+// long pair (8 rows: distributed.halo_plan rounds the windows), so a line has one owner here as well.
+struct FuseHalo {
+  P2PHalo H;
+  unsigned long long seq;
+  int* fail;
+  long max_spins;
+  unsigned long long* arrive;  // [2]: arrival counters of the push slices, per side
+  const double* raw;           // [(tl + tr)][2]: my raw sums on the two regions (head first)
+  const double* recv;          // the neighbours' (this exchange's half of the slots)
+  int64_t tl, tr, tail0;
+  int32_t gf, nwg;             // finish workgroups; halo workgroups in the grid (2 kHaloCopy + gf, padded to a multiple of 8)
+  int2 depL, depR;             // the A' blocks holding rows of the head / tail region
+};
+__device__ __forceinline__ double ld_ag(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+// wave 0 of the workgroup: every A' block of [d.x, d.y] has published this launch's number (bounded); the verdict in *okf
+__device__ __forceinline__ bool fuse_wait_blocks(const FuseArgs& fz, int2 d, int2 e, int* okf) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    bool all = false;
+    for (int t = 0; t < kRidePolls && !all; ++t) {
+      if (t) __builtin_amdgcn_s_sleep(8);
+      bool ok = true;
+      for (int L = d.x + tid; L <= d.y; L += 64)
+        ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
+      for (int L = e.x + tid; L <= e.y; L += 64)
+        ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
+      all = __all(ok);
+    }
+    if (tid == 0) {
+      *okf = all ? 1 : 0;
+      if (!all) __hip_atomic_store(fz.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  return *okf != 0;
+}
+__device__ __forceinline__ void fuse_halo_wg(int b, const FuseHalo& fh, const FuseArgs& fz, const RideArgs& ra, int nblk, double* lp,
+                                             double* red, unsigned long long* crec, int* okf) {
+  constexpr int NL = 2;
+  const int tid = threadIdx.x;
+  if (__hip_atomic_load(fh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;  // (an earlier exchange of the call gave up)
+  const int2 none = make_int2(1, 0);
+  if (b < 2 * kHaloCopy) {  // ---- push
+    const bool left = b < kHaloCopy;
+    const int sl = left ? b : b - kHaloCopy;
+    double* dst = left ? fh.H.left_dst : fh.H.right_dst;
+    if (!dst) return;
+    if (!fuse_wait_blocks(fz, left ? fh.depL : fh.depR, none, okf)) return;
+    const int64_t nl = fh.tl * NL, cnt = left ? nl : fh.tr * NL;
+    const double* src = left ? fh.raw : fh.raw + nl;
+    const int64_t per = ((cnt + kHaloCopy - 1) / kHaloCopy + 1) & ~(int64_t)1, lo = sl * per, hi = lo + per < cnt ? lo + per : cnt;
+    for (int64_t base = lo; base < hi; base += 8 * kBlock) {  // (p2p_copy with agent-scope loads: the sums were written through by other XCDs)
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = base + u * kBlock + tid;
+        v[u] = ld_ag(src + (i < hi ? i : hi - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = base + u * kBlock + tid;
+        if (i < hi) dst[i] = v[u];
+      }
+    }
+    __syncthreads();  // (every wave's stores are complete)
+    if (tid == 0) {
+      __threadfence_system();
+      const unsigned long long got = __hip_atomic_fetch_add(fh.arrive + (left ? 0 : 1), 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      if (got % kHaloCopy == 0)
+        __hip_atomic_store(left ? fh.H.left_flag : fh.H.right_flag, fh.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  b -= 2 * kHaloCopy;
+  if (b >= fh.gf) return;  // (padding)
+  // ---- finish.  Both waits come first and are unconditional (see k_p2p_halo_finish: the wait for the neighbours paces the ranks)
+  bool fine = fuse_wait_blocks(fz, fh.tl > 0 ? fh.depL : none, fh.tr > 0 ? fh.depR : none, okf);
+  if (fine) {
+    if (tid == 0) {
+      bool in = true;
+      if (fh.H.my_from_left) in = p2p_wait(fh.H.my_from_left, fh.seq, fh.max_spins, fh.fail);
+      if (in && fh.H.my_from_right) in = p2p_wait(fh.H.my_from_right, fh.seq, fh.max_spins, fh.fail);
+      *okf = in ? 1 : 0;
+    }
+    __syncthreads();
+    fine = *okf != 0;
+  }
+  if (!fine) return;  // (nothing published: whoever waits for this workgroup runs into its own bound; the call fails)
+  __syncthreads();
+  if (!ride_settle<false>(ra, crec, okf)) return;
+  RideCoef C;
+  ride_decode(crec, C);
+  double sq[NL] = {0.0, 0.0}, sq_tail[NL] = {0.0, 0.0};
+  for (int64_t i = (int64_t)b * kBlock + tid; i < fh.tl + fh.tr; i += (int64_t)fh.gf * kBlock) {
+    const int64_t row = i < fh.tl ? i : fh.tail0 + (i - fh.tl);
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+      acc[l] = ld_ag(fh.raw + i * NL + l) +
+               __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(fh.recv + i * NL + l),
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    row_epilogue<NL, true>((size_t)row, acc, C.ca, C.cb, C.act, lp, lp, i < fh.tl ? sq : sq_tail);
+  }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq[l] = wave_sum(sq[l]);
+  __syncthreads();  // (`red` may alias what ride_settle used)
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) red[(tid >> 6) * NL + l] = sq[l];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (every row is at its coherence point)
+  if (tid == 0) {
+    unsigned long long* pt = fz.ptag + (size_t)(nblk + b) * 4;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const double v = ((red[l] + red[NL + l]) + red[2 * NL + l]) + red[3 * NL + l];  // (block_sum's order: k_p2p_halo_finish's bits)
+      ride_store(pt + 2 * l, tag_hi(v, fz.pub));
+      ride_store(pt + 2 * l + 1, tag_lo(v, fz.pub));
+    }
+    __hip_atomic_store(fz.blkflag + nblk + b, fz.pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 struct FuseGrid {
   int32_t nwg_t, n2, bpx;  // A' product workgroups (a multiple of 8), of which the first n2 take two blocks; blocks per XCD
   int32_t nupd_t;          // update workgroups riding with A' (padded to a multiple of 8)
@@ -1181,12 +1325,13 @@ struct FuseGrid {
   int32_t rot;             // atl_blocks_of's rotation (0; tests: 1..7)
 };
 
-template <bool CSORT>
+template <bool CSORT, bool HALO = false>
 __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, const double* sp_in, double* lp, double* sp_out,
                                                        double* part_a, int pstride_a, const FuseGrid fg, const UpdSeg ut0,
                                                        const UpdSeg ut1, const UpdSeg ua0, const UpdSeg ua1, const StepArgs sh0,
                                                        const StepArgs sh1, const StepArgs sm0, const StepArgs sm1,
-                                                       const RideArgs ra, const RideArgs rb, const FuseArgs fz) {
+                                                       const RideArgs ra, const RideArgs rb, const FuseArgs fz, const HaloRows hr,
+                                                       const FuseHalo fh) {
   constexpr int NL = 2;
   __shared__ double prod[kSpmvNnz * NL];
   static_assert(kSpmvNnz == kRgcsTile, "one product buffer serves both products");
@@ -1205,11 +1350,19 @@ __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, 
   if (b < fg.nwg_t) {
     int Lt[2], nt;
     if (!atl_blocks_of(b, fg.n2, fg.bpx, AT.nblk, Lt, nt, fg.rot)) return;
-    atl_product<CSORT, false, true>(AT, sp_in, lp, lp, nullptr, 0, Lt, nt, ra, HaloRows{}, fz, prod, crec, &okf);
+    atl_product<CSORT, HALO, true>(AT, sp_in, lp, lp, nullptr, 0, Lt, nt, ra, hr, fz, prod, crec, &okf);
     fuse_stamp(fz, 3);
     return;
   }
   b -= fg.nwg_t;
+  if constexpr (HALO) {  // (a multiple of 8 workgroups: the row groups behind keep their XCDs)
+    if (b < fh.nwg) {
+      fuse_halo_wg(b, fh, fz, ra, AT.nblk, lp, prod, crec, &okf);
+      fuse_stamp(fz, 3);
+      return;
+    }
+    b -= fh.nwg;
+  }
   if (b < kRideCand) {
     fuse_mid_leader((b >> 3) & 1 ? sh1 : sh0, (b >> 3) & 1 ? sm1 : sm0, b, rb, fz, fred, fst, &okf);
     fuse_stamp(fz, 3);

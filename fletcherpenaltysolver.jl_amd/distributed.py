@@ -101,6 +101,11 @@ def halo_plan(rowptr, colind, n: int, bounds) -> HaloPlan | None:
         lo[r], hi[r] = int(cols.min()), int(cols.max()) + 1
     if np.any(np.diff(lo) < 0) or np.any(np.diff(hi) < 0):
         return None
+    # Window boundaries on multiples of 8 columns (round 5): a rank's overlap regions and its owned part then start and end on
+    # 128-byte lines of its interleaved [n][2] fp64 vectors -- what lets the exchange and the finish of the overlap rows ride
+    # inside the one-launch iteration (csrc fuse_halo_wg: every line of the long pair has ONE owner).  A window only grows.
+    lo = (lo // 8) * 8
+    hi = np.minimum(((hi + 7) // 8) * 8, n)
     lo[0], hi[-1] = 0, n  # the windows must tile [0, n): columns no row touches still carry x, g, gx entries
     for r in range(P - 1):
         if lo[r + 1] > hi[r]:

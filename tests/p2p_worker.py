@@ -73,7 +73,7 @@ def main():
     out["p1"], out["q1"], out["p2"], out["q2"] = o
     out["fs"], out["its"] = np.array(fs), np.array(its)
     i = dev.info()
-    out["route"] = np.array([i["comm_route"], i["comm_in_launch_sums"], i["p2p_timeouts"]])
+    out["route"] = np.array([i["comm_route"], i["comm_in_launch_sums"], i["p2p_timeouts"], i["last_fused_launches"]])
     dev.close()
     np.savez(os.path.join(d, f"out_{rank}.npz"), **out)
 

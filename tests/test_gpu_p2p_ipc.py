@@ -75,7 +75,8 @@ def _reference(delta):
 
 
 @pytest.mark.parametrize("nranks,route", [(2, "p2p"), (3, "p2p"), (2, "auto"), (2, "rccl"), (3, "p2p-two-launch-halo"),
-                                          (2, "p2p-in-launch"), (3, "p2p-in-launch"), (3, "p2p-in-launch-late-rank")])
+                                          (2, "p2p-in-launch"), (3, "p2p-in-launch"), (3, "p2p-in-launch-late-rank"),
+                                          (2, "p2p-in-launch-fused"), (3, "p2p-in-launch-fused")])
 @pytest.mark.parametrize("delta", [0.0, SE])
 def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, route, delta):
     """Same iteration counts as the single-GPU handle, vectors to 1e-9 (only the order of the reductions differs), phi
@@ -90,6 +91,7 @@ def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, rou
     row arrives."""
     qp, want, its_ref, fs_ref = _reference(delta)
     extra = None
+    fused = False
     in_launch = route.startswith("p2p-in-launch")
     if route == "p2p-two-launch-halo":
         route, extra = "p2p", {"FPSQ_HALO_FUSE": "0"}
@@ -97,6 +99,9 @@ def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, rou
         extra = {"FPSQ_LX": "2"}
         if route.endswith("late-rank"):
             extra["FPSQ_DEBUG_XCH_DELAY"] = "2"
+        if route.endswith("fused"):   # ONE launch per joint iteration, the halo exchange and finish inside (k_iter_fused<.., HALO>)
+            extra["FPSQ_FUSE_ITER"] = "2"
+        fused = route.endswith("fused")
         route = "p2p"
     rcs, outs = _run_ranks(nranks, route, delta, tmp_path, extra_env=extra)
     assert all(rc == 0 for rc in rcs), [o[1][-1500:] for o in outs]
@@ -107,6 +112,7 @@ def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, rou
         assert int(res[r]["route"][0]) == (1 if route == "rccl" else 2)
         assert int(res[r]["route"][1]) == (1 if in_launch else 0)   # fpsq_info.comm_in_launch_sums
         assert int(res[r]["route"][2]) == 0                          # p2p_timeouts
+        assert (int(res[r]["route"][3]) > 0) == fused                # last_fused_launches of the last call
         assert np.array_equal(res[r]["its"], its_ref), (r, res[r]["its"], its_ref)
         assert np.array_equal(res[r]["fs"], res[0]["fs"])  # phi and the return codes: replicated, bitwise
         assert np.all(res[r]["fs"][:, 1] == 0)

@@ -1621,7 +1621,8 @@ def test_row_sharded_objgrad_matches_single_gpu(oracle, nshards, delta):
     group.close()
 
 
-@pytest.mark.parametrize("nshards,p2p", [(2, False), (3, False), (8, False), (2, True), (3, True), (2, "in-launch"), (3, "in-launch")])
+@pytest.mark.parametrize("nshards,p2p", [(2, False), (3, False), (8, False), (2, True), (3, True), (2, "in-launch"), (3, "in-launch"),
+                                         (2, "in-launch-fused"), (3, "in-launch-fused")])
 @pytest.mark.parametrize("delta", [0.0, SE])
 def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta, monkeypatch):
     """HALO mode (include/fpsq.h fpsq_comm_set_halo; the SURVEY 8e contract path): every shard holds only its column
@@ -1634,13 +1635,17 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta
     of the xGMI route, no collective call in the loop).  "in-launch" (round 5; FPSQ_LX=2 forces it between shards of one device,
     whose small grids are resident all at once): the sums over the ranks are formed INSIDE the launches that need them -- the
     leader workgroups and the phi reduction write their local sums into the peers' receive areas and add the rows up in rank
-    order (fpsq_krylov.hip.h xch_sum): no gather kernel; fpsq_info.comm_in_launch_sums = 1."""
+    order (fpsq_krylov.hip.h xch_sum): no gather kernel; fpsq_info.comm_in_launch_sums = 1.  "in-launch-fused": additionally
+    ONE launch per joint iteration on every shard (FPSQ_FUSE_ITER=2: wherever possible) -- the exchange and the finish of the
+    overlap rows ride in it too (k_iter_fused<.., HALO>, fuse_halo_wg)."""
     from fps_amd.device_qp import LocalGroup
     from fps_amd.distributed import halo_plan, row_partition, shard_qp_halo
 
-    in_launch = p2p == "in-launch"
+    fused = p2p == "in-launch-fused"
+    in_launch = p2p in ("in-launch", "in-launch-fused")
     if in_launch:
         monkeypatch.setenv("FPSQ_LX", "2")
+        monkeypatch.setenv("FPSQ_FUSE_ITER", "2" if fused else "0")
         p2p = True
     qp = problems.pde_control_like(n=24000, m=2400, per_row=24, window=512, seed=29)
     sigma, rho = 1e3, 1.0
@@ -1672,7 +1677,10 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta
         assert f == res[0][0] and abs(f - f_ref) <= 1e-9 * abs(f_ref)
         i = shards[r].info()
         assert i["comm_in_launch_sums"] == (1 if in_launch else 0) and i["p2p_timeouts"] == 0
-        if in_launch:  # per joint iteration: the two product launches + the halo launch, no gather kernel
+        if fused:      # per joint iteration: ONE launch (+ the stand-alone step in front of the gated epilogue)
+            assert i["last_fused_launches"] >= i["last_loop_iterations"] - 1 > 0, i
+            assert i["last_loop_launches"] <= i["last_loop_iterations"] + 3, i
+        elif in_launch:  # per joint iteration: the two product launches + the halo launch, no gather kernel
             assert i["last_loop_launches"] <= 3 * i["last_loop_iterations"] + 2, i
         if r + 1 < nshards:  # the overlap with the right neighbour: same global columns, bitwise equal
             t = plan.overlaps(r)[1]
@@ -1720,6 +1728,62 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta
     for sh in shards:
         sh.close()
     group.close()
+
+
+@pytest.mark.parametrize("nshards", [2, 3])
+@pytest.mark.parametrize("delta", [0.0, SE])
+def test_sharded_one_launch_iterations_are_bitwise_the_three_launch_iterations(nshards, delta, monkeypatch):
+    """A halo-sharded handle with rows shared with its neighbours: ONE launch per joint iteration (A' product, the push of the raw
+    overlap sums into the neighbours' slots, the finish of the overlap rows, both steps with their sums over the ranks, the A
+    product -- k_iter_fused<.., HALO>) against the same handle on three launches per iteration (A' product, k_p2p_halo_finish, A
+    product; FPSQ_FUSE_ITER=0): same per-block, per-row and per-rank arithmetic, the partials summed in the same order --
+    BITWISE equal gradients, multipliers, Hessian products, phi and statistics, over changing points."""
+    from fps_amd.device_qp import LocalGroup
+    from fps_amd.distributed import halo_plan, row_partition, shard_qp_halo
+
+    qp = problems.pde_control_like(n=24000, m=2400, per_row=24, window=512, seed=31)
+    bounds = row_partition(qp.rowptr, nshards)
+    plan = halo_plan(qp.rowptr, qp.colind, qp.n, bounds)
+    assert plan is not None
+    locs = [shard_qp_halo(qp, plan, r) for r in range(nshards)]
+    for r in range(nshards):
+        left, right = plan.overlaps(r)
+        assert left % 8 == 0 and (locs[r].n - right) % 8 == 0 and left + right > 0   # (halo_plan: regions on 128-byte lines)
+    monkeypatch.setenv("FPSQ_LX", "2")
+    v = np.random.default_rng(5).standard_normal(qp.n)
+    got = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("FPSQ_FUSE_ITER", mode)
+        group = LocalGroup(nshards, p2p=True)
+        shards = [DeviceEqQP(locs[r], sigma=1e3, rho=1.0, delta=delta, comm=("local", group.ptr, r), halo=plan.overlaps(r))
+                  for r in range(nshards)]
+        rec = []
+        for k in range(4):
+            xk = qp.point(1 + k)
+            gx = [np.empty(l.n) for l in locs]
+            ys = [np.empty(l.m) for l in locs]
+            res = group.run([lambda r=r: shards[r].objgrad(np.ascontiguousarray(xk[plan.window(r)]), gx=gx[r], ys=ys[r])
+                             for r in range(nshards)])
+            rec.append((res, gx, ys, [(s_.stats[0].niter, s_.stats[1].niter, s_.stats[0].rnorm, s_.stats[1].rnorm) for s_ in shards]))
+        hv = [np.empty(l.n) for l in locs]
+        rcs = group.run([lambda r=r: shards[r].hprod(np.ascontiguousarray(v[plan.window(r)]), hv[r]) for r in range(nshards)])
+        rec.append((rcs, hv, [(s_.stats[0].niter, s_.stats[1].niter) for s_ in shards]))
+        infos = [s_.info() for s_ in shards]
+        for i in infos:
+            assert i["comm_in_launch_sums"] == 1 and i["p2p_timeouts"] == 0 and i["wait_timeouts"] == 0
+            assert (i["last_fused_launches"] > 0) == (mode == "2"), i
+        got[mode] = rec
+        for s_ in shards:
+            s_.close()
+        group.close()
+    a, b = got["0"], got["2"]
+    for k in range(4):
+        assert a[k][0] == b[k][0] and a[k][3] == b[k][3]
+        for r in range(nshards):
+            assert np.array_equal(a[k][1][r], b[k][1][r]) and np.array_equal(a[k][2][r], b[k][2][r])
+    assert a[4][0] == b[4][0] and a[4][2] == b[4][2]
+    for r in range(nshards):
+        assert np.array_equal(a[4][1][r], b[4][1][r])
 
 
 def test_halo_mode_argument_checks():
