@@ -668,15 +668,17 @@ __global__ __launch_bounds__(kBlock) void k_halo_finish(const double* __restrict
   double sq[NL];
 #pragma unroll
   for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+  double sq_tail[NL];  // (the tail region is owned -- and counted -- by the right neighbour)
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq_tail[l] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < tl + tr; i += (int64_t)gridDim.x * kBlock) {
     const int64_t row = i < tl ? i : tail0 + (i - tl);
+    double acc[NL];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      if (!act[l]) continue;
-      const double o = ca[l] * (raw[i * NL + l] + recv[i * NL + l]) + (cb[l] != 0.0 ? cb[l] * yin[row * NL + l] : 0.0);
-      yout[row * NL + l] = o;
-      if (i < tl) sq[l] += o * o;
-    }
+    for (int l = 0; l < NL; ++l) acc[l] = raw[i * NL + l] + recv[i * NL + l];
+    // (ONE row routine for the three forms of the finish -- this kernel, k_p2p_halo_finish, the halo workgroups of k_iter_fused:
+    // the same instructions, the same bits)
+    row_epilogue<NL>((size_t)row, acc, ca, cb, act, yin, yout, i < tl ? sq : sq_tail);
   }
   if (partials != nullptr) {
 #pragma unroll
@@ -874,15 +876,15 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo_finish(P2PHalo H, unsigned 
   double sq[NL];
 #pragma unroll
   for (int l = 0; l < NL; ++l) sq[l] = 0.0;
+  double sq_tail[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) sq_tail[l] = 0.0;
   for (int64_t i = (int64_t)b * kBlock + threadIdx.x; i < a.tl + a.tr; i += (int64_t)nb * kBlock) {
     const int64_t row = i < a.tl ? i : a.tail0 + (i - a.tl);
+    double acc[NL];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      if (!act[l]) continue;
-      const double o = ca[l] * (a.raw[i * NL + l] + a.recv[i * NL + l]) + (cb[l] != 0.0 ? cb[l] * a.yin[row * NL + l] : 0.0);
-      a.yout[row * NL + l] = o;
-      if (i < a.tl) sq[l] += o * o;
-    }
+    for (int l = 0; l < NL; ++l) acc[l] = a.raw[i * NL + l] + a.recv[i * NL + l];
+    row_epilogue<NL>((size_t)row, acc, ca, cb, act, a.yin, a.yout, i < a.tl ? sq : sq_tail);  // (see k_halo_finish)
   }
   if (a.partials != nullptr) {
 #pragma unroll

@@ -1678,10 +1678,12 @@ def test_halo_sharded_objgrad_hprod_match_single_gpu(oracle, nshards, p2p, delta
         i = shards[r].info()
         assert i["comm_in_launch_sums"] == (1 if in_launch else 0) and i["p2p_timeouts"] == 0
         if fused:      # per joint iteration: ONE launch (+ the stand-alone step in front of the gated epilogue)
-            assert i["last_fused_launches"] >= i["last_loop_iterations"] - 1 > 0, i
-            assert i["last_loop_launches"] <= i["last_loop_iterations"] + 3, i
+            # (a first call has no expected count: every `lookahead` = 4 iterations a stand-alone step shows the host where it is,
+            # and the iteration behind it runs on separate launches)
+            assert i["last_fused_launches"] >= i["last_loop_iterations"] - i["last_loop_iterations"] // 4 - 1 > 0, i
+            assert i["last_loop_launches"] <= i["last_loop_iterations"] + 3 * (i["last_loop_iterations"] // 4) + 3, i
         elif in_launch:  # per joint iteration: the two product launches + the halo launch, no gather kernel
-            assert i["last_loop_launches"] <= 3 * i["last_loop_iterations"] + 2, i
+            assert i["last_loop_launches"] <= 3 * i["last_loop_iterations"] + i["last_loop_iterations"] // 4 + 3, i
         if r + 1 < nshards:  # the overlap with the right neighbour: same global columns, bitwise equal
             t = plan.overlaps(r)[1]
             assert t > 0 and np.array_equal(gx[r][-t:], gx[r + 1][:t]) and np.array_equal(gs[r][-t:], gs[r + 1][:t])
@@ -1750,6 +1752,7 @@ def test_sharded_one_launch_iterations_are_bitwise_the_three_launch_iterations(n
         left, right = plan.overlaps(r)
         assert left % 8 == 0 and (locs[r].n - right) % 8 == 0 and left + right > 0   # (halo_plan: regions on 128-byte lines)
     monkeypatch.setenv("FPSQ_LX", "2")
+    monkeypatch.setenv("FPSQ_AT_ROW_ALIGN", "8")   # (the block boundaries of the one-launch layout for both handles: same partial sums)
     v = np.random.default_rng(5).standard_normal(qp.n)
     got = {}
     for mode in ("0", "2"):
