@@ -144,6 +144,8 @@ struct P2PRoute {
   XchTable* xt_dev = nullptr;           // non-null: the sums over the ranks are formed inside the launches (lx)
   int lx_want = 1;                      // FPSQ_LX: 0 never, 1 (default) when every rank has a device of its own, 2 always (tests with small grids)
   int xch_delay_rank = 0;               // FPSQ_DEBUG_XCH_DELAY (tests)
+  int halo_dbg = 0;                     // HaloFinishArgs::dbg (tests: FPSQ_DEBUG_P2P_DELAY = r + 1)
+  int halo_delay_rank = 0;
   int* fail_host = nullptr;             // host-mapped: a bounded wait expired
   int* fail_dev = nullptr;
   unsigned long long gather_seq = 0, halo_seq = 0;
@@ -154,6 +156,8 @@ struct P2PRoute {
     if (const char* ev = std::getenv("FPSQ_HALO_FUSE")) fuse_halo = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("FPSQ_LX")) lx_want = std::atoi(ev);
     if (const char* ev = std::getenv("FPSQ_DEBUG_XCH_DELAY")) xch_delay_rank = std::atoi(ev);
+    if (const char* ev = std::getenv("FPSQ_DEBUG_P2P_DELAY")) halo_delay_rank = std::atoi(ev);
+    halo_dbg = halo_delay_rank == rank + 1 ? 1 : 0;
     if (hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&fail_dev, fail_host, 0) != hipSuccess) {
       err = "p2p arm: allocation failed";
@@ -229,10 +233,12 @@ struct P2PRoute {
     const P2PHalo H = halo_peers(NL, fa.tl, fa.tr, fa.recv);
     const dim3 grid(2 * kHaloCopy + finish_wgs);
     unsigned long long* arrive = flags + 12;  // (words 12, 13 of my flag block: arrival counters of the copy slices, per side)
+    HaloFinishArgs fb = fa;
+    fb.dbg = halo_dbg;
     if (NL == 2)
-      hipLaunchKernelGGL(k_p2p_halo_finish<2>, grid, dim3(kBlock), 0, s, H, ++halo_seq, fail_dev, max_spins, arrive, fa);
+      hipLaunchKernelGGL(k_p2p_halo_finish<2>, grid, dim3(kBlock), 0, s, H, ++halo_seq, fail_dev, max_spins, arrive, fb);
     else
-      hipLaunchKernelGGL(k_p2p_halo_finish<1>, grid, dim3(kBlock), 0, s, H, ++halo_seq, fail_dev, max_spins, arrive, fa);
+      hipLaunchKernelGGL(k_p2p_halo_finish<1>, grid, dim3(kBlock), 0, s, H, ++halo_seq, fail_dev, max_spins, arrive, fb);
     return true;
   }
   void release() {
@@ -1766,7 +1772,7 @@ int halo_finish(fpsq_handle h, const double* yin, double* yout, const LaneCtl* c
   double* rl = h->halo_recv + (size_t)(h->halo_calls++ & 1) * (size_t)t * 2;
   {  // peer-to-peer routes: exchange + finish in one launch
     const HaloFinishArgs fa{h->halo_raw, rl, h->ovl, h->ovr, h->n - h->ovr, yin, yout, c0, c1,
-                            partials ? partials + h->AT.nblk : nullptr, h->strT, 0, h->gate0, h->gate1};
+                            partials ? partials + h->AT.nblk : nullptr, h->strT, 0 /* dbg: the route's */, h->gate0, h->gate1};
     if (h->comm->halo_exchange_finish(NL, fa, h->halo_gf, h->stream)) {
       h->launches++;
       return 0;

@@ -818,7 +818,10 @@ struct HaloFinishArgs {
   double* yout;
   const LaneCtl *ctl0, *ctl1;
   double* partials;
-  int32_t pstride, pad_;
+  int32_t pstride;
+  // tests only (P2PRoute: FPSQ_DEBUG_P2P_DELAY = r + 1): bit 0 -- this rank's finish workgroups idle ~100 us before they READ the
+  // neighbours' records (a slow reader)
+  int32_t dbg;
   const LaneCtl *gate0, *gate1;
 };
 template <int NL>
@@ -851,15 +854,6 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo_finish(P2PHalo H, unsigned 
   // nothing to finish: it is what paces the ranks.  A launch that ended without it would let this rank's NEXT push go out
   // while a slower neighbour is still reading the slot of the same parity (the first build returned early here: a rare wrong
   // last iteration with three ranks sharing one GPU; k_p2p_halo, the two-launch form, has always waited unconditionally).
-  if (threadIdx.x == 0) {
-    bool in = true;
-    if (H.my_from_left) in = p2p_wait(H.my_from_left, seq, max_spins, fail);
-    if (in && H.my_from_right) in = p2p_wait(H.my_from_right, seq, max_spins, fail);
-    ok = in ? 1 : 0;
-  }
-  __syncthreads();
-  if (!ok) return;
-  if (a.gate0 != nullptr && !(a.gate0->done && a.gate1->done)) return;
   const LaneCtl* c[2] = {a.ctl0, a.ctl1};
   bool act[NL];
   double ca[NL], cb[NL];
@@ -871,7 +865,20 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo_finish(P2PHalo H, unsigned 
     cb[l] = c[l]->cb;
     any |= act[l];
   }
-  if (!any) return;
+  const bool open = a.gate0 == nullptr || (a.gate0->done && a.gate1->done);
+  if (threadIdx.x == 0) {
+    bool in = true;
+    if (H.my_from_left) in = p2p_wait(H.my_from_left, seq, max_spins, fail);
+    if (in && H.my_from_right) in = p2p_wait(H.my_from_right, seq, max_spins, fail);
+    ok = in ? 1 : 0;
+    if (a.dbg & 1) {  // (tests: a slow reader)
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  __syncthreads();
+  if (!ok) return;
+  if (!open || !any) return;
   __shared__ double red[4];
   double sq[NL];
 #pragma unroll

@@ -1789,6 +1789,45 @@ def test_sharded_one_launch_iterations_are_bitwise_the_three_launch_iterations(n
         assert np.array_equal(a[4][1][r], b[4][1][r])
 
 
+@pytest.mark.parametrize("extra", [1, 2])
+def test_a_slow_reader_of_the_halo_slots_is_waited_for(monkeypatch, extra):
+    """The wait of k_p2p_halo_finish for the neighbours comes first and is unconditional -- also in a launch with nothing to finish
+    (the recurrences have ended, a gate is closed): it is what keeps a rank's next push of the same parity out of a slot a
+    slower neighbour is still reading when no sum over the ranks lies between the two pushes (advisor / verdict, round 4).
+    Set up here: two shards, sums over the ranks inside the launches (no gather kernel paces the ranks), three launches per
+    iteration; shard 1 READS its halo slots ~100 us late in every launch (FPSQ_DEBUG_P2P_DELAY=2); the second evaluation is
+    told to expect `extra` iterations more than it needs (fpsq_debug_expect_iterations): shard 0 runs launches with nothing to
+    finish, then the epilogue's product, whose push goes into a slot shard 1 used shortly before.  Bitwise the first evaluation
+    on both shards.  (A deterministic FAILING interleaving for the first build's early exit could not be constructed: in every
+    launch sequence the host issues today a data-carrying exchange is followed by a sum over the ranks -- which needs the
+    slow shard's finish workgroups -- before the next push of the same parity; an attempt with a debug switch that restored the
+    early exit passed this very test.  The unconditional wait makes the slots safe by themselves, whatever the host enqueues.)"""
+    from fps_amd.device_qp import LocalGroup
+    from fps_amd.distributed import halo_plan, row_partition, shard_qp_halo
+
+    qp = problems.pde_control_like(n=24000, m=2400, per_row=24, window=512, seed=37)
+    plan = halo_plan(qp.rowptr, qp.colind, qp.n, row_partition(qp.rowptr, 2))
+    locs = [shard_qp_halo(qp, plan, r) for r in range(2)]
+    for k, v in (("FPSQ_LX", "2"), ("FPSQ_FUSE_ITER", "0"), ("FPSQ_DEBUG_P2P_DELAY", "2")):
+        monkeypatch.setenv(k, v)
+    group = LocalGroup(2, p2p=True)
+    shards = [DeviceEqQP(locs[r], sigma=1e3, rho=1.0, delta=0.0, comm=("local", group.ptr, r), halo=plan.overlaps(r)) for r in range(2)]
+    out = []
+    for rep in range(2):
+        gx = [np.empty(l.n) for l in locs]
+        res = group.run([lambda r=r: shards[r].objgrad(locs[r].x, gx=gx[r]) for r in range(2)])
+        its = [(s_.stats[0].niter, s_.stats[1].niter) for s_ in shards]
+        out.append((res, gx, its))
+        for s_ in shards:
+            assert s_._lib.fpsq_debug_expect_iterations(s_._h, max(its[0]) + extra) == 0
+    (r0, g0, i0), (r1, g1, i1) = out
+    assert r0 == r1 and i0 == i1 and r0[0] == r0[1] and all(np.array_equal(a, b) for a, b in zip(g0, g1))
+    for s_ in shards:
+        assert s_.info()["p2p_timeouts"] == 0
+        s_.close()
+    group.close()
+
+
 def test_halo_mode_argument_checks():
     """fpsq_comm_set_halo: needs a communicator; overlaps must fit the window and vanish at the outer ends."""
     from fps_amd.device_qp import LocalGroup
