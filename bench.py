@@ -88,6 +88,9 @@ def parse_args():
                     help="halo-sharded runs: how the per-iteration exchanges travel (include/fpsq.h fpsq_comm_set_route).  auto = "
                          "peer to peer (records written into the peers' hipIpc-mapped buffers, sequence flags, no collective "
                          "call in the loop) when every rank can export and map, else RCCL; config.parallelism names what ran")
+    ap.add_argument("--fell-back-from", default=None,
+                    help="(set by bench.py itself) this process is the FRESH CHILD a rank started after the named route timed out in "
+                         "the warm-up of the sharded phase; recorded as config.fell_back_from")
     ap.add_argument("--force-shard", action="store_true", default=False,
                     help="rehearsal on one GPU: run the sharded code path (RCCL communicator of size 1)")
     ap.add_argument("--no-roofline-pass", action="store_true", default=False,
@@ -151,8 +154,8 @@ class Timer:
             return float(t.item())
         return v
 
-    def run(self, step, W, K, repeats, collect=None):
-        for t in range(W):
+    def run(self, step, W, K, repeats, collect=None, warmed=False):
+        for t in range(0 if warmed else W):
             step(t)
         times = []
         R = repeats if repeats > 0 else 1
@@ -487,8 +490,51 @@ def main():
         soft[0] |= out[1]
         its.append((model.stats[0].niter, model.stats[1].niter))
 
+    # ---- first contact with an N-GPU node: the peer-to-peer route may set up and THEN time out (a link that maps but does not
+    # deliver, a peer that is too slow for the bounds).  The warm-up of the sharded phase is where that shows: every rank takes
+    # the verdict of ALL ranks (max over the ranks of "my warm-up failed") and, if the route was not RCCL already, starts a FRESH
+    # CHILD of itself -- a new process, never an exec from one that touched the GPU -- with --comm-route rccl on the next port,
+    # relays its output and exits with its code.  The child's line says so (config.fell_back_from); only a child that fails too
+    # ends the run with a non-zero code and an empty stdout.
+    warm_err = None
+    if sharded and world > 1:
+        try:
+            for t in range(W):
+                step(t)
+        except Exception as e:  # noqa: BLE001
+            warm_err = e
+        try:
+            flag = torch.tensor([1.0 if warm_err is not None else 0.0], dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            any_failed = bool(flag.item() > 0)
+        except Exception as e:  # noqa: BLE001  (the process group itself is gone)
+            fail(f"warm-up of the sharded phase failed ({warm_err}) and the ranks could not agree on a fallback: {e}")
+        if any_failed:
+            route_now = DeviceEqQP.ROUTE_NAMES.get(model.info()["comm_route"], "?")
+            if args.comm_route == "rccl" or args.fell_back_from is not None or route_now == "rccl":
+                fail(f"warm-up of the sharded phase failed on the {route_now} route: {warm_err}")
+            sys.stderr.write(f"bench.py: rank {rank}: the {route_now} route failed in the warm-up ({warm_err}); every rank starts a "
+                             "fresh child with --comm-route rccl\n")
+            sys.stderr.flush()
+            try:
+                model.close()
+            except Exception:  # noqa: BLE001
+                pass
+            if watchdog is not None:
+                watchdog.cancel()  # (the child has its own)
+            argv = [a for a in sys.argv[1:]]
+            if "--comm-route" in argv:
+                i = argv.index("--comm-route")
+                del argv[i:i + 2]
+            # (a rendezvous of its own: the children's rank 0 hosts the store on the next port -- torchrun's agent store stays
+            # with the parents)
+            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1),
+                       TORCHELASTIC_USE_AGENT_STORE="False")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv, "--comm-route", "rccl", "--fell-back-from", route_now],
+                               env=env)
+            os._exit(r.returncode)
     try:
-        times = timer.run(step, W, K, args.repeats, collect)
+        times = timer.run(step, W, K, args.repeats, collect, warmed=sharded and world > 1)
     except Exception as e:  # noqa: BLE001  (a collective failed: every rank must end, non-zero)
         if world == 1:
             raise
@@ -644,7 +690,8 @@ def main():
                    "fuse_fallbacks": final["fuse_fallbacks"], "wait_timeouts": final["wait_timeouts"],
                    "p2p_timeouts": final["p2p_timeouts"],
                    **({"comm_route": DeviceEqQP.ROUTE_NAMES.get(route, str(route)), "comm_in_launch_sums": insum}
-                      if sharded else {})},
+                      if sharded else {}),
+                   **({"fell_back_from": args.fell_back_from} if args.fell_back_from else {})},
         "roofline": roofline,
     }
 

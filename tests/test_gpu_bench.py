@@ -107,3 +107,24 @@ def test_multi_rank_sharded_bench_runs_through_the_loopback_collectives(ranks):
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     assert d["config"]["iters_lsqr_craig_median"] == d1["config"]["iters_lsqr_craig_median"]
     assert "replicas_alternative" in d and d["replicas_alternative"]["scaling"] == "weak"
+
+
+def test_a_route_that_times_out_in_the_warm_up_falls_back_to_rccl_in_a_fresh_child():
+    """First contact with a node: the peer-to-peer route sets up (handles exported, mapped, unanimous) and then its first waits
+    expire (here: FPSQ_P2P_POLLS=1 -- a wait gives up after one look).  Every rank sees the verdict of all ranks after the
+    warm-up, starts a FRESH child of itself with --comm-route rccl (never an exec from a process that touched the GPU) and
+    exits with its code: rc 0, ONE JSON line, labelled config.comm_route = rccl and config.fell_back_from = p2p-ipc."""
+    env = {"FPSQ_BENCH_REHEARSE": "1", "FPSQ_RCCL_LIB": _shim(), "FPSQ_BENCH_WATCHDOG": "400", "FPSQ_SHIM_TIMEOUT": "120",
+           "FPSQ_P2P_POLLS": "1"}
+    r = _run(["--gpus", "2", "--parallel", "shard", "--steps", "2", "--warmup", "1", "--repeats", "1", "--cpu-evals", "0",
+              "--no-roofline-pass", "--workload", "pde-control-like n=1e6 m=1e5 nnz=1e7"], env=env, timeout=900)
+    if r.returncode != 0:
+        print(f"==== rc {r.returncode} ==== stdout ====\n{r.stdout}\n==== stderr ====\n{r.stderr}")
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["comm_route"] == "rccl" and d["config"]["fell_back_from"] == "p2p-ipc"
+    assert d["config"]["all_solved"] is True and d["config"]["p2p_timeouts"] == 0
+    assert "fresh child with --comm-route rccl" in r.stderr
