@@ -547,13 +547,14 @@ def main():
     roofline = None
     if not args.no_roofline_pass and not extras and not (hfull and args.hessian_approx == 1) and not args.alternate_delta:  # (timing only for those)
         model.set_profiling(True)
-        pa, pat, t_ms, tot_ms, nfused = np.zeros(2), np.zeros(2), 0.0, 0.0, 0
+        pa, pat, t_ms, tot_ms, nfused, nmulti_saved = np.zeros(2), np.zeros(2), 0.0, 0.0, 0, 0
         for t in range(W, W + K):
             step(t)
             info = model.info()
             pa += info["last_prod_a"]
             pat += info["last_prod_at"]
             nfused += info.get("last_fused_launches", 0)
+            nmulti_saved += info.get("last_multi_iterations", 0) - info.get("last_multi_launches", 0)
             t_ms += info["last_spmv_ms"]
             tot_ms += info["last_solve_ms"]
         model.set_profiling(False)
@@ -600,6 +601,9 @@ def main():
         launches = int(pa.sum() + pat.sum()) - nfused
         if nfused:
             productive -= sum(min(max(il, ic), nfused // max(len(its), 1)) for il, ic in its)
+        # several iterations per launch (k_iter_multi): K iterations are ONE launch -- and one productive launch
+        launches -= nmulti_saved
+        productive -= nmulti_saved
         achieved = nbytes / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -609,6 +613,7 @@ def main():
                                "fpsq::k_spmv_rgcs (A) + fpsq::k_spmv_atl / k_spmv (A'): SpMV/SpMM with fused axpby + norm "
                                "partials + riding vector updates + the previous product's scalar steps (leader workgroups)"),
                     "fused_iteration_launches_per_eval": nfused / K,
+                    "iterations_sharing_a_launch_per_eval": (nmulti_saved / K) if nmulti_saved else 0,
                     "productive_launches_per_eval": productive / K, "launches_per_eval": launches / K,
                     "avg_launch_us": round(1e3 * t_ms / max(launches, 1), 2),
                     "avg_productive_launch_us": round(1e3 * t_ms / max(productive, 1), 2),

@@ -43,6 +43,7 @@ class Info(C.Structure):
                 ("comm_route", C.c_int64), ("last_fused_launches", C.c_int64),
                 ("fuse_fallbacks", C.c_int64), ("wait_timeouts", C.c_int64), ("p2p_timeouts", C.c_int64),
                 ("last_loop_iterations", C.c_int64), ("last_loop_launches", C.c_int64),
+                ("last_multi_launches", C.c_int64), ("last_multi_iterations", C.c_int64),
                 ("comm_in_launch_sums", C.c_int64)]
 
     def as_dict(self):

@@ -5,6 +5,7 @@
 // (FletcherPenaltySolver.jl v0.3.0), whose arithmetic runs in Krylov.jl on the CPU.
 #include "../../include/fpsq.h"
 #include "fpsq_spmv.hip.h"
+#include "fpsq_multi.hip.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -791,6 +792,18 @@ struct fpsq_solver_s {
   // that deposit the raw sums of the two overlap regions; what the set-up needs again then (block boundaries, column ranges)
   int2* fz_dep2 = nullptr;
   int2 fz_depL{1, 0}, fz_depR{1, 0};
+  // several iterations per launch (k_iter_multi, fpsq_multi.hip.h; FPSQ_MULTI_ITER=k: at most k per launch, 1: off)
+  int multi_max = kMultiMax;
+  bool multi_ok = false;
+  int2* mz_bdep = nullptr;
+  unsigned int* mz_flag2 = nullptr;          // second parity of fz_flag / fz_ptag
+  unsigned long long* mz_ptag2 = nullptr;
+  unsigned int* mz_gflag[2] = {nullptr, nullptr};
+  unsigned long long* mz_atag[2] = {nullptr, nullptr};
+  unsigned long long* mz_utag[2] = {nullptr, nullptr};
+  unsigned long long *mz_rec_h = nullptr, *mz_rec_m = nullptr, *mz_srec = nullptr, *mz_hdone = nullptr;
+  double* LP2 = nullptr;                      // the second long pair
+  int64_t multi_launches = 0, multi_iters = 0;
   bool fuse_halo_ok = false;
   bool fuse_halo_on = true;               // FPSQ_FUSE_HALO=0: a handle with shared rows keeps the halo launch between two product launches
   std::vector<int32_t> fz_rb;
@@ -1522,6 +1535,55 @@ int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<in
   h->fz_rb = rb;
   h->fz_colrange = col_range;
   h->fuse_ok = true;
+  // ---- several iterations per launch (fpsq_multi.hip.h): per A' block the row groups whose rows of the short pair it gathers
+  // (the mirror image of `dep`; a cover by ONE range -- waiting for more is safe; a block nobody gathers from -- empty columns --
+  // waits for every group: its own previous incarnation is then complete too), second copies of the flags and tagged words,
+  // records, the second long pair
+  h->multi_ok = false;
+  if (h->multi_max > 1) {
+    const int ng = h->RA.view.ng, nb = h->AT.nblk;
+    std::vector<int2> bdep((size_t)nb, make_int2(INT32_MAX, -1));
+    for (int g = 0; g < ng; ++g)
+      for (int L = dep[g].x; L <= dep[g].y; ++L) {
+        bdep[L].x = std::min(bdep[L].x, g);
+        bdep[L].y = std::max(bdep[L].y, g);
+      }
+    const bool dbg_full = std::getenv("FPSQ_DEBUG_MULTI_FULLDEP") && std::atoi(std::getenv("FPSQ_DEBUG_MULTI_FULLDEP")) != 0;  // (developer: every block waits for every group)
+    for (int L = 0; L < nb; ++L)
+      if (bdep[L].y < bdep[L].x || dbg_full) bdep[L] = make_int2(0, ng - 1);
+    dfree(h, &h->mz_bdep);
+    dfree(h, &h->mz_flag2);
+    dfree(h, &h->mz_ptag2);
+    if (int rc = dalloc(h, &h->mz_bdep, bdep.size())) return rc;
+    HIPCHK(h, hipMemcpy(h->mz_bdep, bdep.data(), bdep.size() * sizeof(int2), hipMemcpyHostToDevice));
+    if (int rc = dalloc(h, &h->mz_flag2, (size_t)nb + kEwBlocksMax)) return rc;
+    if (int rc = dalloc(h, &h->mz_ptag2, ((size_t)nb + kEwBlocksMax) * 4)) return rc;
+    HIPCHK(h, hipMemset(h->mz_flag2, 0, ((size_t)nb + kEwBlocksMax) * 4));
+    HIPCHK(h, hipMemset(h->mz_ptag2, 0, ((size_t)nb + kEwBlocksMax) * 32));
+    for (int q = 0; q < 2; ++q) {
+      dfree(h, &h->mz_gflag[q]);
+      dfree(h, &h->mz_atag[q]);
+      if (int rc = dalloc(h, &h->mz_gflag[q], (size_t)ng)) return rc;
+      if (int rc = dalloc(h, &h->mz_atag[q], (size_t)ng * 4)) return rc;
+      HIPCHK(h, hipMemset(h->mz_gflag[q], 0, (size_t)ng * 4));
+      HIPCHK(h, hipMemset(h->mz_atag[q], 0, (size_t)ng * 32));
+      if (!h->mz_utag[q]) {
+        if (int rc = dalloc(h, &h->mz_utag[q], (size_t)4 * kEwBlocksMax * 2)) return rc;
+        HIPCHK(h, hipMemset(h->mz_utag[q], 0, (size_t)4 * kEwBlocksMax * 16));
+      }
+    }
+    if (!h->mz_rec_h) {
+      const size_t words = (size_t)2 * kRecRing * 512 + (size_t)kRecRing * 2 * kSrecSlot + 8;
+      if (int rc = dalloc(h, &h->mz_rec_h, words)) return rc;
+      HIPCHK(h, hipMemset(h->mz_rec_h, 0, words * 8));
+      h->mz_rec_m = h->mz_rec_h + (size_t)kRecRing * 512;
+      h->mz_srec = h->mz_rec_m + (size_t)kRecRing * 512;
+      h->mz_hdone = h->mz_srec + (size_t)kRecRing * 2 * kSrecSlot;
+    }
+    if (!h->LP2)
+      if (int rc = dalloc(h, &h->LP2, 2 * (size_t)h->n)) return rc;
+    h->multi_ok = true;
+  }
   return 0;
 }
 
@@ -2255,6 +2317,8 @@ struct KrylovRun {
   hipStream_t s;
   const int gn, gm, nbA;
   double *LP, *SP;
+  double* LPalt = nullptr;  // the second long pair (several iterations per launch alternate; nullptr: not available)
+  bool can_multi = false;   // ... whenever the previous product's steps are pending and the expected count leaves room for >= 2
   // the run-ahead's expectation (see run())
   int64_t* expect_slot;
   const bool local_vec;    // vector updates touch rank-local data only (one GPU, or the halo-sharded layout)
@@ -2405,6 +2469,11 @@ struct KrylovRun {
     can_fuse = NL == 2 && h->fuse_ok && h->at_xcd && lead && fuse_upd && minres_lane < 0 && !h->ride_break &&
                (!h->comm || (h->halo && insum(h) && (h->ovl + h->ovr == 0 || (h->fuse_halo_ok && h->fuse_halo_on))));
     look = std::max(1, o.lookahead);
+    // several iterations per launch: LSQR / CRAIG lanes of a single-GPU handle whose iterations may share a launch at all
+    can_multi = can_fuse && !h->comm && h->multi_ok && h->multi_max > 1 && h->fuse_probe_at == 0;
+    for (int l = 0; l < NL; ++l) can_multi = can_multi && (lanes[l].kind == LANE_LSQR || lanes[l].kind == LANE_CRAIG);
+    LPalt = can_multi ? h->LP2 : nullptr;
+    if (can_multi) hipMemsetAsync(h->mz_hdone, 0, 8, s);  // (nobody has ended yet)
   }
 
   // ------------------------------------------------------------------ the steps behind a product
@@ -2942,6 +3011,113 @@ struct KrylovRun {
     return post_step(sb[0], sb[1], true);
   }
 
+  // K joint iterations in ONE launch (k_iter_multi, fpsq_multi.hip.h): iterations it .. it + K - 1.  Needs what iteration_fused
+  // needs (the previous product's steps pending) and it >= 2 (iteration 1 carries the start-up's w_1 segments).
+  int iteration_multi(int K) {
+    MultiArgs M{};
+    M.K = K;
+    M.it0 = (int32_t)it;
+    const StepArgs* pre = pre_args(true);
+    int nut = 0;
+    for (int l = 0; l < NL; ++l) {
+      M.sh[l] = pre[l];
+      M.sm[l] = step_after_at(l, h->AT.nblk);
+      M.sm[l].state = nullptr;
+      M.sm[l].state_out = nullptr;
+      M.sm[l].prod_ctl_off = 0;
+      M.commit[l][0] = lanes[l].state_alt;
+      M.commit[l][1] = lanes[l].state_alt2;
+      M.pw[l][0] = h->pW[l];
+      M.pw[l][1] = h->pWalt[l];
+      M.p1seg[l] = 3;
+      if (lanes[l].kind == LANE_LSQR) {
+        M.p1seg[l] = nut;
+        M.ut[nut++] = lsqr_upd_seg(l, it - 1);
+      }
+    }
+    for (int k = nut; k < 2; ++k) M.ut[k] = seg_none();
+    M.ua[0] = M.ua[1] = seg_none();
+    for (int l = 0; l < NL; ++l)
+      if (is_ln(lanes[l].kind)) ln_upd_segs(l, M.ua[0], M.ua[1]);
+    M.n1 = gm;
+    FuseGrid& fg = M.fg;
+    fg.bpx = (h->AT.nblk + 7) / 8;
+    {
+      const int R = h->resident_wgs - kRideCand;
+      const int n2 = !h->atl_two || h->AT.nblk <= R ? 0 : std::min(R, h->AT.nblk - R);
+      const int n2e = std::min(n2 / 8, fg.bpx / 2);
+      fg.n2 = 8 * n2e;
+      fg.nwg_t = 8 * (fg.bpx - n2e);
+    }
+    fg.nupd_t = (M.ut[0].nblk + M.ut[1].nblk + 7) / 8 * 8;
+    fg.gpx = (h->RA.view.ng + 7) / 8;
+    fg.rot = h->fuse_rotate;
+    M.nupd_a = (M.ua[0].nblk + M.ua[1].nblk + 7) / 8 * 8;
+    M.per_iter = kRideCand + fg.nwg_t + kRideCand + 8 * fg.gpx + fg.nupd_t + M.nupd_a;
+    M.seq0 = (uint32_t)(h->ride_seq + 1);
+    h->ride_seq += (unsigned long long)K;
+    M.sp[0] = SPcur;
+    M.sp[1] = SPalt;
+    M.sp0 = 0;
+    M.lp[0] = LP;
+    M.lp[1] = LPalt;
+    M.lp0 = 0;
+    M.part_last = pa_last == h->pS2 ? h->pS2b : h->pS2;  // (not the array this launch's first leaders read)
+    M.pstride_a = h->strA;
+    M.rec_h = h->mz_rec_h;
+    M.rec_m = h->mz_rec_m;
+    M.srec = h->mz_srec;
+    M.flag[0] = h->fz_flag;
+    M.flag[1] = h->mz_flag2;
+    M.ptag[0] = h->fz_ptag;
+    M.ptag[1] = h->mz_ptag2;
+    for (int q = 0; q < 2; ++q) {
+      M.gflag[q] = h->mz_gflag[q];
+      M.atag[q] = h->mz_atag[q];
+      M.utag[q] = h->mz_utag[q];
+    }
+    M.dep = h->fz_dep;
+    M.bdep = h->mz_bdep;
+    M.hdone = h->mz_hdone;
+    M.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
+    M.delay_h = h->ride_delay;
+    M.delay_m = h->ride_delay_mid;
+    M.break_pub = h->fuse_break ? ~0u : 0u;
+    const dim3 grid((unsigned)M.per_iter * (unsigned)K);
+    if (h->AT.sorted) launch_product(h, k_iter_multi<true>, grid, h->AT.view(), h->RA.view, M);
+    else launch_product(h, k_iter_multi<false>, grid, h->AT.view(), h->RA.view, M);
+    h->launches++;
+    h->spmv_launches++;
+    h->prod_a[1] += K;
+    h->prod_at[1] += K;
+    h->fused_launches += K;
+    h->fused_total += K;
+    h->multi_launches++;
+    h->multi_iters += K;
+    pa_last = M.part_last;
+    // the lanes live where the last iteration's mid leaders committed; the other two copies are free for the next launch
+    for (int l = 0; l < NL; ++l) {
+      Lane& L = lanes[l];
+      void* cur = L.state;
+      void* fin = M.commit[l][(K - 1) & 1];
+      void* oth = M.commit[l][K & 1];
+      L.state = fin;
+      L.state_alt = cur;
+      L.state_alt2 = oth;
+      L.ctl = reinterpret_cast<LaneCtl*>(L.state);
+      L.ctlT = L.ctl;
+    }
+    have_pend = false;
+    if (K & 1) {
+      std::swap(SPcur, SPalt);
+      std::swap(LP, LPalt);
+    }
+    it += K - 1;  // (run() counted the first one)
+    StepArgs sb[2] = {none, none};
+    for (int l = 0; l < NL; ++l) sb[l] = step_after_a(l);
+    return post_step(sb[0], sb[1], true);
+  }
+
   // ------------------------------------------------------------------ the host's pacing
   // the gated final LSQR flush + the caller's epilogue behind iteration `it` (see the comment above)
   int enqueue_speculative() {
@@ -3089,7 +3265,18 @@ struct KrylovRun {
     const int64_t launches0 = h->launches;
     while (it < itmax_all) {
       ++it;
-      if (can_fuse && have_pend) {
+      // several iterations per launch while the expected count (or itmax) leaves room for at least two; never across the count:
+      // the gated flush and the epilogue go right behind it
+      int K = 1;
+      if (can_multi && have_pend && it >= 2 && expect > 0 && it <= expect)
+        K = (int)std::min<int64_t>(std::min<int64_t>(h->multi_max, expect - it + 1), itmax_all - it + 1);
+      static const bool dbg_k1 = std::getenv("FPSQ_DEBUG_MULTI_K1") && std::atoi(std::getenv("FPSQ_DEBUG_MULTI_K1")) != 0;  // (developer: the multi kernel with ONE iteration per launch)
+      if (dbg_k1 && K >= 2) K = -1;
+      if (K == -1) {
+        if (int rc = iteration_multi(1)) return rc;
+      } else if (K >= 2) {
+        if (int rc = iteration_multi(K)) return rc;
+      } else if (can_fuse && have_pend) {
         if (int rc = iteration_fused()) return rc;
       } else {
         if (int rc = half_step_at()) return rc;
@@ -3218,6 +3405,7 @@ void call_begin(fpsq_handle h) {
   h->prod_a[0] = h->prod_a[1] = h->prod_at[0] = h->prod_at[1] = 0;
   h->fused_launches = 0;
   h->mmid_launches = 0;
+  h->multi_launches = h->multi_iters = 0;
   h->loop_launches = h->loop_iters = 0;
   h->ev_used = 0;
   // device-side timing of the whole call only when profiling is on: an event record is a marker packet the GPU has to
@@ -3270,6 +3458,8 @@ int call_end(fpsq_handle h) {
     h->info.last_prod_at[i] = h->prod_at[i];
   }
   h->info.last_fused_launches = h->fused_launches;
+  h->info.last_multi_launches = h->multi_launches;
+  h->info.last_multi_iterations = h->multi_iters;
   h->info.last_loop_iterations = h->loop_iters;
   h->info.last_loop_launches = h->loop_launches;
   double sp = 0.0;
@@ -3320,6 +3510,8 @@ int call_end_ordered(fpsq_handle h, double seq) {
     h->info.last_prod_at[i] = h->prod_at[i];
   }
   h->info.last_fused_launches = h->fused_launches;
+  h->info.last_multi_launches = h->multi_launches;
+  h->info.last_multi_iterations = h->multi_iters;
   h->info.last_loop_iterations = h->loop_iters;
   h->info.last_loop_launches = h->loop_launches;
   h->info.last_spmv_ms = 0.0;
@@ -3627,6 +3819,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_FUSE_ITER")) h->fuse_iter = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_HALO")) h->fuse_halo_on = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_MULTI_ITER")) h->multi_max = std::min(std::max(std::atoi(ev), 1), kMultiMax);
   if (const char* ev = std::getenv("FPSQ_MINRES_MERGE")) h->minres_merge = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_ROTATE")) h->fuse_rotate = std::atoi(ev) & 7;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY_MID")) h->ride_delay_mid = std::atoi(ev);

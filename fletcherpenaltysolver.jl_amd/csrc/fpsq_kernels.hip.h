@@ -229,7 +229,9 @@ struct UpdSeg {
   const double* src; // interleaved Golub-Kahan vector [len][NL]
   int32_t lane;      // which interleaved lane of src
   int32_t nblk;      // workgroups assigned to this segment
-  int32_t pad_[2];
+  int32_t ag;        // != 0 (several iterations per launch, k_iter_multi): `src` was written through by OTHER XCDs earlier in the same
+                     // launch -- read it at agent scope (an XCD's own L2 may hold the values of two iterations ago)
+  int32_t pad_;
   // Speculatively enqueued final flush: runs only if this recurrence AND the one behind `gate` have ended (null:
   // ungated).  While any lane of the call still iterates the loop goes on and the next product launch carries this
   // update -- it must not be applied twice.
@@ -241,6 +243,13 @@ struct UpdSeg {
   int64_t len;
   double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
 };
+
+__device__ __forceinline__ double upd_src(const UpdSeg& s, int64_t idx) {
+  if (s.ag)
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(s.src + idx), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+  return s.src[idx];
+}
 
 // LSQR (Krylov.jl lsqr!): x += (phi/rho) w; w = v - (theta/rho) w, with v = vt / alpha deferred.
 //   e[0] = phi/rho, e[1] = theta/rho, e[2] = 1/alpha.   WINIT: w = vt / alpha only (w_1 = v_1).
@@ -257,12 +266,12 @@ __device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red, 
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
     double wn;
     if (WINIT) {
-      wn = s.src[i * NL + s.lane] * ia;
+      wn = upd_src(s, i * NL + s.lane) * ia;
       s.a[i] = 0.0;  // x_0 = 0
     } else {
       const double wi = s.b[i];
       s.a[i] += sg * wi;
-      wn = s.src[i * NL + s.lane] * ia - tr * wi;
+      wn = upd_src(s, i * NL + s.lane) * ia - tr * wi;
     }
     s.b[i] = wn;
     sq += wn * wn;
@@ -281,7 +290,7 @@ __device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk, const L
   if (ctl->done && ctl->upd_iter != s.it) return;
   const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3];
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    const double v = s.src[i * NL + s.lane];
+    const double v = upd_src(s, i * NL + s.lane);
     if (REG) {
       const double w2 = s.b[i];
       s.a[i] += e0 * v + e1 * w2;
@@ -300,7 +309,7 @@ __device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double
   const double e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6];
   double sq = 0.0;
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    const double wn = e4 * s.src[i * NL + s.lane] - e5 * s.a[i];
+    const double wn = e4 * upd_src(s, i * NL + s.lane) - e5 * s.a[i];
     s.a[i] = wn;
     s.b[i] += e6 * wn;
     sq += wn * wn;

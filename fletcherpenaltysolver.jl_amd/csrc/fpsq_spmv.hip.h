@@ -578,15 +578,60 @@ __device__ __forceinline__ unsigned long long tag_lo(double v, unsigned int want
   return ((unsigned long long)__double_as_longlong(v) << 32) | want;
 }
 
+// ---- SEVERAL joint iterations in one launch (k_iter_multi, fpsq_multi.hip.h; round 5): what a product workgroup of iteration j
+// needs beyond the one-launch iteration's FuseArgs.  The A -> A' boundary between two iterations is inside the launch too: an A'
+// block of iteration j + 1 starts gathering the short pair when the row groups of iteration j that wrote what it gathers have
+// published themselves (rows written through, per-group flags -- the mirror image of blocks -> row groups), and a row group
+// leaves its squared-norm partials as tagged words for the head leaders of iteration j + 1.
+struct MultiCtx {
+  const unsigned int* gflag_prev;  // per row group: launch number of iteration j - 1 once its rows are at their coherence point
+                                   // (null: the previous iteration was another launch -- nothing to wait for)
+  unsigned int want_prev;
+  const int2* bdep;                // per A' block: first and last row group whose rows of the short pair it gathers
+  unsigned int* gflag;             // this iteration's row-group flags ...
+  unsigned long long* atag;        // ... and tagged partials [group][4] (lane 0 high, low; lane 1 high, low)
+  unsigned int want;               // this iteration's number
+  const unsigned long long* hdone; // both 32-bit halves non-zero: every recurrence of the call has ended.  A workgroup that finds it
+                                   // so AT ITS ENTRY publishes itself (flag / tagged words, payload void) and leaves without streaming --
+                                   // nobody who waits for it is left waiting, whatever the order the XCDs dispatch in; past its entry a
+                                   // workgroup never looks again (what it waits for was entered, or publishes on leaving, too)
+};
+__device__ __forceinline__ bool multi_all_done(const unsigned long long* hdone) {
+  const unsigned long long w = __hip_atomic_load(hdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned int)w != 0u && (unsigned int)(w >> 32) != 0u;
+}
+// wave 0 of the workgroup: the row groups [d.x, d.y] of the previous iteration have published themselves (bounded looks).
+// Every thread calls it (one LDS barrier inside).  false: the bound expired (error word raised): leave
+__device__ __forceinline__ bool multi_wait_groups(const MultiCtx& mx, int2 d, unsigned long long* err, int* okf) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    bool all = false;
+    for (int t = 0; t < kRidePolls && !all; ++t) {
+      if (t) __builtin_amdgcn_s_sleep(8);
+      bool ok = true;
+      for (int g = d.x + tid; g <= d.y; g += 64)
+        ok &= __hip_atomic_load(mx.gflag_prev + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mx.want_prev;
+      all = __all(ok);
+    }
+    if (tid == 0) {
+      *okf = all ? 1 : 0;
+      if (!all) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  return *okf != 0;
+}
+
 // The A' product of one workgroup: blocks Lt[0 .. nt) of the padded layout, two lanes, coefficients from the leaders' record.
 // FUSED (k_iter_fused): rows are written through, and behind each block's epilogue -- every wave has waited for the
 // acknowledgement of its stores BEFORE the workgroup barrier of the partial sum -- thread 0 publishes the block: its squared-norm
 // partials as self-validating words and its flag.
-template <bool CSORT, bool HALO, bool FUSED>
+template <bool CSORT, bool HALO, bool FUSED, bool MULTI = false>
 __device__ __forceinline__ void atl_product(const CsrView& A, const double* __restrict__ x, const double* yin, double* yout,
                                             double* partials, int pstride, const int (&Lt)[2], int nt, const RideArgs& ra,
                                             const HaloRows& hr, const FuseArgs& fz, double* prod, unsigned long long* crec,
-                                            int* okfp) {
+                                            int* okfp, const MultiCtx* mx = nullptr) {
+  static_assert(!MULTI || (FUSED && !HALO), "several iterations per launch: the one-launch iteration's hand-overs, one GPU");
   constexpr int NL = 2;
   double* red = prod;
   const int tid = threadIdx.x;
@@ -636,7 +681,7 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
     const int rq0 = g < nr ? g : 0;
     const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
     hypre[t][0] = hypre[t][1] = 0.0;
-    if (yin != nullptr) {
+    if (!MULTI && yin != nullptr) {
       const double2 yy = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
       hypre[t][0] = yy.x;
       hypre[t][1] = yy.y;
@@ -653,9 +698,23 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
       }
     }
     if (t == 0) peek();  // (requests the first look)
+    if constexpr (MULTI) {
+      // the row groups of the previous iteration that wrote what this block gathers (the stream above does not depend on them).
+      // They in turn waited for this block's own previous incarnation: only behind this wait are its `yin` rows -- written one
+      // iteration ago into the other long pair -- there to be read (the one-launch iteration prefetches them at the block's head)
+      if (mx->gflag_prev != nullptr && !multi_wait_groups(*mx, mx->bdep[L], fz.err, okfp)) return;
+      if (yin != nullptr) {
+        const double2 yy = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
+        hypre[t][0] = yy.x;
+        hypre[t][1] = yy.y;
+      }
+    }
     double2 xv[kPer];
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+    for (int k = 0; k < kPer; ++k) {
+      if constexpr (MULTI) xv[k] = ld_pair_ag(x, cidx[k]);  // (agent scope: rows other XCDs have just written through)
+      else xv[k] = *reinterpret_cast<const double2*>(x + (size_t)cidx[k] * 2);
+    }
     peek();
 #pragma unroll
     for (int k = 0; k < kPer; ++k)
@@ -822,11 +881,12 @@ struct RgcsView {
 
 // One row group of the A product (see above).  LEAD: coefficients from the leaders' record `ra`; FUSED (k_iter_fused, implies
 // LEAD): the group first waits for the A' blocks of the same launch that own what it gathers, and gathers at agent scope.
-template <int NL, bool PAD, bool LEAD, bool FUSED>
+template <int NL, bool PAD, bool LEAD, bool FUSED, bool MULTI = false>
 __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __restrict__ x, const double* yin, double* yout,
                                            const LaneCtl* ctl0, const LaneCtl* ctl1, double* partials, int pstride, int g,
                                            const RideArgs& ra, const FuseArgs& fz, double* prod, unsigned long long* crec,
-                                           int* okf) {
+                                           int* okf, const MultiCtx* mx = nullptr) {
+  static_assert(!MULTI || (FUSED && NL == 2), "several iterations per launch: built on the one-launch iteration");
   double* red = prod;  // aliases the product buffer (free again after the tile loop's closing barrier): exactly 32 KB
   if (g >= M.ng) return;
   constexpr int kPer = kRgcsTile / kBlock;
@@ -893,14 +953,19 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
     // behind the first tile's stream, which does not depend on them), a bounded number of times
     if (tid < 64) {
       const int2 d = fz.dep[g];
-      const int2 d2 = fz.dep2 != nullptr ? fz.dep2[g] : make_int2(1, 0);
+      int d2x = 1, d2y = 0;  // (scalars, not a conditional of structs: that one costs a stack slot)
+      if (fz.dep2 != nullptr) {
+        const int2 t2 = fz.dep2[g];
+        d2x = t2.x;
+        d2y = t2.y;
+      }
       bool all = false;
       for (int t = 0; t < kRidePolls && !all; ++t) {
         if (t) __builtin_amdgcn_s_sleep(8);
         bool ok = true;
         for (int L = d.x + tid; L <= d.y; L += 64)
           ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
-        for (int L = d2.x + tid; L <= d2.y; L += 64)
+        for (int L = d2x + tid; L <= d2y; L += 64)
           ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
         all = __all(ok);
       }
@@ -987,9 +1052,31 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
       for (int l = 0; l < NL; ++l) acc[p][l] += __shfl_down(acc[p][l], off, 64);
     }
     const int rr = p * rpp + gid;
-    if (rr < R && gl == 0) row_epilogue<NL>((size_t)(r0 + rr), acc[p], ca, cb, act, yin, yout, sq);
+    if (rr < R && gl == 0) row_epilogue<NL, MULTI>((size_t)(r0 + rr), acc[p], ca, cb, act, yin, yout, sq);
   }
-  if (partials != nullptr) {
+  if constexpr (MULTI) {
+    // the A' blocks of the NEXT iteration of this launch gather these rows: written through (row_epilogue<.., WT>), their
+    // acknowledgements waited for in front of the barrier of the partial sum (block_sum_lanes' arithmetic), then thread 0
+    // publishes the group: partials (plain, for a consumer in a later launch, and tagged, for the next head leaders) and its flag
+#pragma unroll
+    for (int l = 0; l < NL; ++l) sq[l] = wave_sum(sq[l]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) red[(tid >> 6) * NL + l] = sq[l];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == 0) {
+      unsigned long long* pt = mx->atag + (size_t)g * 4;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const double v = (red[l] + red[NL + l]) + (red[2 * NL + l] + red[3 * NL + l]);
+        if (partials != nullptr) partials[(size_t)l * pstride + g] = v;
+        ride_store(pt + 2 * l, tag_hi(v, mx->want));
+        ride_store(pt + 2 * l + 1, tag_lo(v, mx->want));
+      }
+      __hip_atomic_store(mx->gflag + g, mx->want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (partials != nullptr) {
     block_sum_lanes<NL>(sq, red);
     if (tid == 0) {
 #pragma unroll
@@ -1165,8 +1252,14 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
     xch_sum<2>(sm.xt, sm.xseq, sm.xlane, v, red32);
     s0 = v[0];
   }
+#ifdef FPSQ_DEBUG_PRINT
+  if (threadIdx.x == 0 && commit) printf("FM it=%d kind=%d skip=%d s0=%.17g\n", sm.it, sm.kind, (int)skip, s0);
+#endif
   if (threadIdx.x == 0) {
     if (!skip) step_advance(sm, st80, s0, 0.0, commit ? sm.prog : nullptr);
+#ifdef FPSQ_DEBUG_PRINT
+    if (commit) { const LaneCtl* cc = reinterpret_cast<const LaneCtl*>(st80); printf("FM-> it=%d kind=%d ca=%.17g cb=%.17g e0=%.17g e4=%.17g\n", sm.it, sm.kind, cc->ca, cc->cb, cc->e[0], cc->e[4]); }
+#endif
     ride_publish(reinterpret_cast<const LaneCtl*>(st80 + sm.prod_ctl_off), l, rec, rb.pub);
     if (commit && !skip) step_final_stats(sm, st80);
   }
@@ -1210,16 +1303,16 @@ __device__ __forceinline__ double ld_ag(const double* p) {
                                                            __HIP_MEMORY_SCOPE_AGENT));
 }
 // wave 0 of the workgroup: every A' block of [d.x, d.y] has published this launch's number (bounded); the verdict in *okf
-__device__ __forceinline__ bool fuse_wait_blocks(const FuseArgs& fz, int2 d, int2 e, int* okf) {
+__device__ __forceinline__ bool fuse_wait_blocks(const FuseArgs& fz, int dx, int dy, int ex, int ey, int* okf) {
   const int tid = threadIdx.x;
   if (tid < 64) {
     bool all = false;
     for (int t = 0; t < kRidePolls && !all; ++t) {
       if (t) __builtin_amdgcn_s_sleep(8);
       bool ok = true;
-      for (int L = d.x + tid; L <= d.y; L += 64)
+      for (int L = dx + tid; L <= dy; L += 64)
         ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
-      for (int L = e.x + tid; L <= e.y; L += 64)
+      for (int L = ex + tid; L <= ey; L += 64)
         ok &= __hip_atomic_load(fz.blkflag + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz.want;
       all = __all(ok);
     }
@@ -1236,13 +1329,12 @@ __device__ __forceinline__ void fuse_halo_wg(int b, const FuseHalo& fh, const Fu
   constexpr int NL = 2;
   const int tid = threadIdx.x;
   if (__hip_atomic_load(fh.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;  // (an earlier exchange of the call gave up)
-  const int2 none = make_int2(1, 0);
   if (b < 2 * kHaloCopy) {  // ---- push
     const bool left = b < kHaloCopy;
     const int sl = left ? b : b - kHaloCopy;
     double* dst = left ? fh.H.left_dst : fh.H.right_dst;
     if (!dst) return;
-    if (!fuse_wait_blocks(fz, left ? fh.depL : fh.depR, none, okf)) return;
+    if (!fuse_wait_blocks(fz, left ? fh.depL.x : fh.depR.x, left ? fh.depL.y : fh.depR.y, 1, 0, okf)) return;
     const int64_t nl = fh.tl * NL, cnt = left ? nl : fh.tr * NL;
     const double* src = left ? fh.raw : fh.raw + nl;
     const int64_t per = ((cnt + kHaloCopy - 1) / kHaloCopy + 1) & ~(int64_t)1, lo = sl * per, hi = lo + per < cnt ? lo + per : cnt;
@@ -1271,7 +1363,7 @@ __device__ __forceinline__ void fuse_halo_wg(int b, const FuseHalo& fh, const Fu
   b -= 2 * kHaloCopy;
   if (b >= fh.gf) return;  // (padding)
   // ---- finish.  Both waits come first and are unconditional (see k_p2p_halo_finish: the wait for the neighbours paces the ranks)
-  bool fine = fuse_wait_blocks(fz, fh.tl > 0 ? fh.depL : none, fh.tr > 0 ? fh.depR : none, okf);
+  bool fine = fuse_wait_blocks(fz, fh.tl > 0 ? fh.depL.x : 1, fh.tl > 0 ? fh.depL.y : 0, fh.tr > 0 ? fh.depR.x : 1, fh.tr > 0 ? fh.depR.y : 0, okf);
   if (fine) {
     if (tid == 0) {
       bool in = true;

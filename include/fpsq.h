@@ -393,6 +393,10 @@ typedef struct {
   /* the Krylov loop of the last call: joint iterations enqueued and kernel launches enqueued for them (exchanges and stand-alone
    * steps included; start-up and epilogue excluded): launches / iterations = launches per joint iteration */
   int64_t last_loop_iterations, last_loop_launches;
+  int64_t last_multi_launches, last_multi_iterations; /* of last_fused_launches: joint iterations that shared a launch with others
+                                  (k_iter_multi: several iterations per launch, FPSQ_MULTI_ITER=1 disables), and how many launches
+                                  carried them: launches of the call = last_prod_a + last_prod_at - last_fused_launches
+                                  - (last_multi_iterations - last_multi_launches) */
   int64_t comm_in_launch_sums; /* 1: a sharded handle whose sums over the ranks need no launch of their own -- formed inside the
                                   launches that need them (peer-to-peer route, every rank on a device of its own: csrc
                                   fpsq_krylov.hip.h xch_sum), or a communicator of one rank; 0: gather / collective launches */

@@ -34,8 +34,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Options) == 8 * 17 + 24  # + ln_method, kkt_method
     assert _lib.Options.ln_method.offset == 8 * 17 + 16 and _lib.Options.kkt_method.offset == 8 * 17 + 20
     # + at_sorted (round 3), comm_route, last_fused_launches (round 4), the three counters, the loop's two, comm_in_launch_sums (round 5)
-    assert C.sizeof(_lib.Info) == 72 + 32 + 8 + 8 + 8 + 24 + 16 + 8
-    assert _lib.Info.fuse_fallbacks.offset == 128 and _lib.Info.comm_in_launch_sums.offset == 168
+    assert C.sizeof(_lib.Info) == 72 + 32 + 8 + 8 + 8 + 24 + 16 + 16 + 8
+    assert _lib.Info.fuse_fallbacks.offset == 128 and _lib.Info.comm_in_launch_sums.offset == 184
 
 
 def test_struct_sizes_against_the_c_compiler(tmp_path):

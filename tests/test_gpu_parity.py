@@ -1312,6 +1312,52 @@ def test_one_launch_iterations_are_bitwise_the_two_launch_iterations(monkeypatch
         assert np.array_equal(a_, b_), i
 
 
+@pytest.mark.parametrize("kmax", [2, 3, 8])
+@pytest.mark.parametrize("size,delta", [((60000, 6000), 0.0), ((300000, 30000, "headline density"), 0.0),
+                                        ((300000, 30000, "headline density"), SE)])
+def test_several_iterations_per_launch_are_bitwise_one_iteration_per_launch(monkeypatch, kmax, size, delta):
+    """k_iter_multi (csrc/fpsq_multi.hip.h): up to `kmax` joint iterations share ONE launch -- the A' blocks of iteration j + 1 start
+    when the row groups of iteration j that wrote what they gather have published themselves, the recurrence state travels from
+    leader set to leader set as self-validating words, the long pair alternates between two buffers.  Per block, per group, per
+    update workgroup and per step the arithmetic is the one-launch iteration's: every output and statistic of objgrad,
+    hprod Val(2) and solve_two_mixed BITWISE those of FPSQ_MULTI_ITER=1, over changing points (a first call has no expected
+    count and runs one iteration per launch; from the second on the expected count is cut into launches of <= kmax)."""
+    qp = _small_pde(seed=19, n=size[0], m=size[1]) if len(size) == 2 else problems.pde_control_like(n=size[0], m=size[1], seed=33)
+    A = qp.scipy_csr()
+    rng = np.random.default_rng(9)
+    xs = [qp.xhat + 0.3 * 0.6 ** k * rng.standard_normal(qp.n) for k in range(4)]
+    vs = [rng.standard_normal(qp.n) for _ in range(4)]
+
+    def run(expect_multi):
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+        out, shared = [], 0
+        for k, x in enumerate(xs):
+            gx, ys, gs, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.n)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys, gs=gs)
+            i = dev.info()
+            shared += i["last_multi_iterations"]
+            assert i["last_multi_iterations"] <= i["last_fused_launches"] and i["last_multi_launches"] * kmax >= i["last_multi_iterations"]
+            st = [(dev.stats[q].niter, dev.stats[q].status, dev.stats[q].rnorm, dev.stats[q].arnorm) for q in range(2)]
+            rch = dev.hprod(vs[k], hv, 2)
+            shared += dev.info()["last_multi_iterations"]
+            o = [np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.m)]
+            rcm = dev.solve_two_mixed(qp.qdiag * x + qp.d, A @ x - qp.b, *o)
+            out += [np.array([f, rc, rch, rcm]), gx, ys, gs, hv, *o, np.array(st).ravel()]
+        i = dev.info()
+        assert i["wait_timeouts"] == 0 and i["fuse_fallbacks"] == 0
+        dev.close()
+        assert (shared > 0) == expect_multi, shared
+        return out
+
+    monkeypatch.setenv("FPSQ_FUSE_ITER", "2")
+    monkeypatch.setenv("FPSQ_MULTI_ITER", "1")
+    want = run(False)
+    monkeypatch.setenv("FPSQ_MULTI_ITER", str(kmax))
+    got = run(True)
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+
+
 @pytest.mark.parametrize("late", [0, 8, 3, 13])
 def test_one_launch_iterations_with_a_late_mid_leader(monkeypatch, late):
     """The mid leaders of a fused launch publish per XCC, so the row groups of the other XCCs do not wait for a mid leader that
