@@ -165,7 +165,9 @@ __device__ __forceinline__ void st_pair_wt(double* base, int row, double a, doub
 // accumulation.  The yin values of both lanes are fetched with one (16-byte when NL = 2) load before any arithmetic
 // and written back with one store when both lanes are active -- a per-lane load/use/store chain costs two dependent
 // memory round trips per row.
-template <int NL, bool WT = false>
+// AG (several iterations per launch): yin was written by ANOTHER workgroup earlier in the same launch -- read it at agent scope
+// (a plain load may hit a line this CU's L1 has kept from two iterations ago; the L1s are only invalidated between kernels)
+template <int NL, bool WT = false, bool AG = false>
 __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, const double* ca, const double* cb,
                                              const bool* act, const double* yin, double* yout, double* sq,
                                              const double* ypre = nullptr) {
@@ -181,7 +183,9 @@ __device__ __forceinline__ void row_epilogue(size_t row, const double* acc, cons
     for (int l = 0; l < NL; ++l) yv[l] = ypre[l];
   } else if (need) {
     if (NL == 2) {
-      const double2 t = *reinterpret_cast<const double2*>(yin + row * 2);
+      double2 t;
+      if (AG) t = ld_pair_ag(yin, (int)row);
+      else t = *reinterpret_cast<const double2*>(yin + row * 2);
       yv[0] = t.x;
       yv[NL - 1] = t.y;
     } else {
@@ -244,6 +248,19 @@ struct UpdSeg {
   double* partials;  // [nblk] partial sums of ||w_new||^2 (LSQR, CRAIG short)
 };
 
+// ... and, in that mode, the vectors an update rewrites in place (x, w, y): the workgroup of the same index of the PREVIOUS iteration
+// wrote them, on whatever CU / XCD it ran -- loads at agent scope, stores written through
+__device__ __forceinline__ double upd_ld(const UpdSeg& s, const double* p, int64_t idx) {
+  if (s.ag)
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + idx), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+  return p[idx];
+}
+__device__ __forceinline__ void upd_st(const UpdSeg& s, double* p, int64_t idx, double v) {
+  if (s.ag) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + idx), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+  else p[idx] = v;
+}
 __device__ __forceinline__ double upd_src(const UpdSeg& s, int64_t idx) {
   if (s.ag)
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(s.src + idx), __ATOMIC_RELAXED,
@@ -269,11 +286,11 @@ __device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red, 
       wn = upd_src(s, i * NL + s.lane) * ia;
       s.a[i] = 0.0;  // x_0 = 0
     } else {
-      const double wi = s.b[i];
-      s.a[i] += sg * wi;
+      const double wi = upd_ld(s, s.b, i);
+      upd_st(s, s.a, i, upd_ld(s, s.a, i) + sg * wi);
       wn = upd_src(s, i * NL + s.lane) * ia - tr * wi;
     }
-    s.b[i] = wn;
+    upd_st(s, s.b, i, wn);
     sq += wn * wn;
   }
   const double t = block_sum(sq, red);
@@ -292,11 +309,11 @@ __device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk, const L
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
     const double v = upd_src(s, i * NL + s.lane);
     if (REG) {
-      const double w2 = s.b[i];
-      s.a[i] += e0 * v + e1 * w2;
-      s.b[i] = e2 * v + e3 * w2;
+      const double w2 = upd_ld(s, s.b, i);
+      upd_st(s, s.a, i, upd_ld(s, s.a, i) + (e0 * v + e1 * w2));
+      upd_st(s, s.b, i, e2 * v + e3 * w2);
     } else {
-      s.a[i] += e0 * v;
+      upd_st(s, s.a, i, upd_ld(s, s.a, i) + e0 * v);
     }
   }
 }
@@ -309,9 +326,9 @@ __device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double
   const double e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6];
   double sq = 0.0;
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    const double wn = e4 * upd_src(s, i * NL + s.lane) - e5 * s.a[i];
-    s.a[i] = wn;
-    s.b[i] += e6 * wn;
+    const double wn = e4 * upd_src(s, i * NL + s.lane) - e5 * upd_ld(s, s.a, i);
+    upd_st(s, s.a, i, wn);
+    upd_st(s, s.b, i, upd_ld(s, s.b, i) + e6 * wn);
     sq += wn * wn;
   }
   const double t = block_sum(sq, red);

@@ -704,7 +704,7 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
       // iteration ago into the other long pair -- there to be read (the one-launch iteration prefetches them at the block's head)
       if (mx->gflag_prev != nullptr && !multi_wait_groups(*mx, mx->bdep[L], fz.err, okfp)) return;
       if (yin != nullptr) {
-        const double2 yy = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
+        const double2 yy = ld_pair_ag(yin, r0 + rq0);  // (agent scope: not a line this CU's L1 kept from two iterations ago)
         hypre[t][0] = yy.x;
         hypre[t][1] = yy.y;
       }
@@ -770,7 +770,7 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
               else dst[l] = hacc[t][p][l];
             }
         } else {
-          row_epilogue<NL, FUSED>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
+          row_epilogue<NL, FUSED, MULTI>((size_t)row, hacc[t][p], C.ca, C.cb, C.act, yin, yout, sq, p == 0 && yin != nullptr ? hypre[t] : nullptr);
         }
       }
     }
@@ -1052,7 +1052,7 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
       for (int l = 0; l < NL; ++l) acc[p][l] += __shfl_down(acc[p][l], off, 64);
     }
     const int rr = p * rpp + gid;
-    if (rr < R && gl == 0) row_epilogue<NL, MULTI>((size_t)(r0 + rr), acc[p], ca, cb, act, yin, yout, sq);
+    if (rr < R && gl == 0) row_epilogue<NL, MULTI, MULTI>((size_t)(r0 + rr), acc[p], ca, cb, act, yin, yout, sq);
   }
   if constexpr (MULTI) {
     // the A' blocks of the NEXT iteration of this launch gather these rows: written through (row_epilogue<.., WT>), their

@@ -11,7 +11,7 @@ kmax = sys.argv[1] if len(sys.argv) > 1 else "2"
 qp = problems.pde_control_like(n=60000, m=6000, per_row=20, window=1024, seed=19)
 os.environ["FPSQ_FUSE_ITER"] = "2"
 A = qp.scipy_csr()
-for cut in (3, 5, 8, 12):
+for cut in (4, 7, 10, 13):
     got = {}
     for mode in ("1", kmax):
         os.environ["FPSQ_MULTI_ITER"] = mode
