@@ -793,7 +793,15 @@ struct fpsq_solver_s {
   int2* fz_dep2 = nullptr;
   int2 fz_depL{1, 0}, fz_depR{1, 0};
   // several iterations per launch (k_iter_multi, fpsq_multi.hip.h; FPSQ_MULTI_ITER=k: at most k per launch, 1: off)
-  int multi_max = kMultiMax;
+  // Default 1 = off.  Measured at the headline size (profiles/r05_multi_iter.txt): bitwise the one-launch iterations, 9 launches per
+  // evaluation instead of 21, and NO gain -- 0.99-1.00 x: the kernel boundary it removes (2.6 us per iteration) is paid back inside the
+  // launch (agent-scope gathers of the short pair, the second long pair, tagged publications: +2.8 us per iteration)
+  int multi_max = 1;
+  // real workgroups of the LSQR / CRAIG updates in a multi launch (FPSQ_MULTI_UPD=t,a; multiples of 8).  Default: one per
+  // segment workgroup.  Fewer, each walking several -- so that the next iteration's A' blocks are dispatched sooner -- was measured
+  // SLOWER at the headline size (64 / 192: 854 evals/s, 128 / 384: 926, all: 940 against 952 with one iteration per launch: the long
+  // update then cannot keep up and the next mid leaders wait for it)
+  int multi_upd_t = 1 << 20, multi_upd_a = 1 << 20;
   bool multi_ok = false;
   int2* mz_bdep = nullptr;
   unsigned int* mz_flag2 = nullptr;          // second parity of fz_flag / fz_ptag
@@ -1548,9 +1556,8 @@ int setup_fused_iteration(fpsq_handle h, const HostCsr& HT, const std::vector<in
         bdep[L].x = std::min(bdep[L].x, g);
         bdep[L].y = std::max(bdep[L].y, g);
       }
-    const bool dbg_full = std::getenv("FPSQ_DEBUG_MULTI_FULLDEP") && std::atoi(std::getenv("FPSQ_DEBUG_MULTI_FULLDEP")) != 0;  // (developer: every block waits for every group)
     for (int L = 0; L < nb; ++L)
-      if (bdep[L].y < bdep[L].x || dbg_full) bdep[L] = make_int2(0, ng - 1);
+      if (bdep[L].y < bdep[L].x) bdep[L] = make_int2(0, ng - 1);
     dfree(h, &h->mz_bdep);
     dfree(h, &h->mz_flag2);
     dfree(h, &h->mz_ptag2);
@@ -3049,10 +3056,11 @@ struct KrylovRun {
       fg.n2 = 8 * n2e;
       fg.nwg_t = 8 * (fg.bpx - n2e);
     }
-    fg.nupd_t = (M.ut[0].nblk + M.ut[1].nblk + 7) / 8 * 8;
+    // (few real update workgroups, each walking several virtual ones: see k_iter_multi)
+    fg.nupd_t = std::min((M.ut[0].nblk + M.ut[1].nblk + 7) / 8 * 8, h->multi_upd_t);
     fg.gpx = (h->RA.view.ng + 7) / 8;
     fg.rot = h->fuse_rotate;
-    M.nupd_a = (M.ua[0].nblk + M.ua[1].nblk + 7) / 8 * 8;
+    M.nupd_a = std::min((M.ua[0].nblk + M.ua[1].nblk + 7) / 8 * 8, h->multi_upd_a);
     M.per_iter = kRideCand + fg.nwg_t + kRideCand + 8 * fg.gpx + fg.nupd_t + M.nupd_a;
     M.seq0 = (uint32_t)(h->ride_seq + 1);
     h->ride_seq += (unsigned long long)K;
@@ -3270,11 +3278,7 @@ struct KrylovRun {
       int K = 1;
       if (can_multi && have_pend && it >= 2 && expect > 0 && it <= expect)
         K = (int)std::min<int64_t>(std::min<int64_t>(h->multi_max, expect - it + 1), itmax_all - it + 1);
-      static const bool dbg_k1 = std::getenv("FPSQ_DEBUG_MULTI_K1") && std::atoi(std::getenv("FPSQ_DEBUG_MULTI_K1")) != 0;  // (developer: the multi kernel with ONE iteration per launch)
-      if (dbg_k1 && K >= 2) K = -1;
-      if (K == -1) {
-        if (int rc = iteration_multi(1)) return rc;
-      } else if (K >= 2) {
+      if (K >= 2) {
         if (int rc = iteration_multi(K)) return rc;
       } else if (can_fuse && have_pend) {
         if (int rc = iteration_fused()) return rc;
@@ -3820,6 +3824,13 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_HALO")) h->fuse_halo_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_MULTI_ITER")) h->multi_max = std::min(std::max(std::atoi(ev), 1), kMultiMax);
+  if (const char* ev = std::getenv("FPSQ_MULTI_UPD")) {
+    int a = 0, b = 0;
+    if (std::sscanf(ev, "%d,%d", &a, &b) == 2 && a >= 8 && b >= 8) {
+      h->multi_upd_t = a / 8 * 8;
+      h->multi_upd_a = b / 8 * 8;
+    }
+  }
   if (const char* ev = std::getenv("FPSQ_MINRES_MERGE")) h->minres_merge = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_ROTATE")) h->fuse_rotate = std::atoi(ev) & 7;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY_MID")) h->ride_delay_mid = std::atoi(ev);

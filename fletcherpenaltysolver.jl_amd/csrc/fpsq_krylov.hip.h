@@ -1122,16 +1122,10 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
     __syncthreads();
   }
   if (threadIdx.x == 0 && hook && skip) hook->advanced();  // (a finished lane: its state stands as it is)
-#ifdef FPSQ_DEBUG_PRINT
-  if (threadIdx.x == 0 && commit) printf("SR it=%d kind=%d skip=%d s0=%.17g s1=%.17g\n", a.it, a.kind, (int)skip, s0, s1);
-#endif
   if (threadIdx.x == 0 && !skip) {
     void* S = st;
     Progress* prog = commit ? a.prog : nullptr;
     step_advance(a, S, s0, s1, prog);
-#ifdef FPSQ_DEBUG_PRINT
-    if (commit) { const LaneCtl* cc = reinterpret_cast<const LaneCtl*>(S); printf("SR-> it=%d kind=%d ca=%.17g cb=%.17g e0=%.17g e1=%.17g e2=%.17g e4=%.17g\n", a.it, a.kind, cc->ca, cc->cb, cc->e[0], cc->e[1], cc->e[2], cc->e[4]); }
-#endif
     if (hook) hook->advanced();
     if (commit) step_final_stats(a, S);
   }

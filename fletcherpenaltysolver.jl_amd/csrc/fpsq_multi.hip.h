@@ -231,17 +231,11 @@ __device__ __forceinline__ void multi_head_leader(const MultiArgs& M, int j, int
       if (!reduce_two_tagged(M.atag[pq], a.n0, l, t1, a.p1 ? M.n1 : 0, seq - 1, red32, flag, s0, s1)) return multi_fail(M);
     }
   }
-#ifdef FPSQ_DEBUG_PRINT
-  if (threadIdx.x == 0 && commit) printf("MH j=%d l=%d it=%d kind=%d skip=%d s0=%.17g s1=%.17g\n", j, l, a.it, a.kind, (int)skip, s0, s1);
-#endif
   if (threadIdx.x == 0 && !skip) {
     step_advance(a, st80, s0, s1, commit ? a.prog : nullptr);
     if (commit) step_final_stats(a, st80);
   }
   __syncthreads();
-#ifdef FPSQ_DEBUG_PRINT
-  if (threadIdx.x == 0 && commit) { const LaneCtl* cc = reinterpret_cast<const LaneCtl*>(st80); printf("MH-> j=%d l=%d ca=%.17g cb=%.17g e0=%.17g e1=%.17g e2=%.17g\n", j, l, cc->ca, cc->cb, cc->e[0], cc->e[1], cc->e[2]); }
-#endif
   multi_publish_coef(st80, l, rec, seq);
   srec_put(srec_at(M, seq, 0, xcc, l), st80, nq, seq);
 }
@@ -285,17 +279,11 @@ __device__ __forceinline__ void multi_mid_leader(const MultiArgs& M, int j, int 
   const bool skip = reinterpret_cast<const LaneCtl*>(st80)->done != 0;
   double s0 = 0.0;
   if (!skip && !reduce_tagged(M.ptag[q], a.n0, l, seq, red32, flag, s0)) return multi_fail(M);
-#ifdef FPSQ_DEBUG_PRINT
-  if (threadIdx.x == 0 && commit) printf("MM j=%d l=%d it=%d kind=%d skip=%d s0=%.17g\n", j, l, a.it, a.kind, (int)skip, s0);
-#endif
   if (threadIdx.x == 0 && !skip) {
     step_advance(a, st80, s0, 0.0, commit ? a.prog : nullptr);
     if (commit) step_final_stats(a, st80);
   }
   __syncthreads();
-#ifdef FPSQ_DEBUG_PRINT
-  if (threadIdx.x == 0 && commit) { const LaneCtl* cc = reinterpret_cast<const LaneCtl*>(st80); printf("MM-> j=%d l=%d ca=%.17g cb=%.17g e0=%.17g e4=%.17g\n", j, l, cc->ca, cc->cb, cc->e[0], cc->e[4]); }
-#endif
   multi_publish_coef(st80, l, rec, seq);
   srec_put(srec_at(M, seq, 1, xcc, l), st80, nq, seq);
   if (commit) {
@@ -365,10 +353,12 @@ __global__ __launch_bounds__(kBlock) void k_iter_multi(CsrView AT, RgcsView RA, 
   int b = (int)blockIdx.x - j * M.per_iter;
   const unsigned int seq = M.seq0 + (unsigned int)j;
   const int it = M.it0 + j, q = it & 1;
-  const bool over = multi_all_done(M.hdone);  // (at entry, and only here: see MultiCtx::hdone)
+  // (the first load of every workgroup; leaders and update workgroups -- which wait for records anyway -- act on it at once, product
+  // workgroups behind their first stream loads: MultiCtx::hd)
+  const unsigned long long hd = __hip_atomic_load(M.hdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const FuseGrid& fg = M.fg;
   if (b < kRideCand) {
-    if (over) multi_publish_void((b >> 3) & 1, M.rec_h + (size_t)(seq & (kRecRing - 1)) * 512 + 64 * ride_xcc(), seq);
+    if (multi_over(hd)) multi_publish_void((b >> 3) & 1, M.rec_h + (size_t)(seq & (kRecRing - 1)) * 512 + 64 * ride_xcc(), seq);
     else multi_head_leader(M, j, b, fred, fst, &okf);
     return;
   }
@@ -395,26 +385,18 @@ __global__ __launch_bounds__(kBlock) void k_iter_multi(CsrView AT, RgcsView RA, 
   mx.atag = M.atag[q];
   mx.want = seq;
   mx.hdone = M.hdone;
+  mx.hd = hd;
   const int rd = (M.sp0 + j) & 1;          // the short pair this iteration gathers (and its updates read)
   const int ly = (M.lp0 + j) & 1;          // the long pair its A' blocks read their yin rows from; they write the other
   if (b < fg.nwg_t) {
     int Lt[2], nt;
     if (!atl_blocks_of(b, fg.n2, fg.bpx, AT.nblk, Lt, nt, fg.rot)) return;
-    if (over) {
-      if (threadIdx.x == 0)
-        for (int t = 0; t < nt; ++t) {
-          unsigned long long* pt = fz.ptag + (size_t)Lt[t] * 4;
-          for (int w = 0; w < 4; ++w) ride_store(pt + w, (w & 1) ? tag_lo(0.0, seq) : tag_hi(0.0, seq));
-          __hip_atomic_store(fz.blkflag + Lt[t], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      return;
-    }
     atl_product<CSORT, false, true, true>(AT, M.sp[rd], M.lp[ly], M.lp[ly ^ 1], nullptr, 0, Lt, nt, ra, HaloRows{}, fz, prod, crec, &okf, &mx);
     return;
   }
   b -= fg.nwg_t;
   if (b < kRideCand) {
-    if (over) multi_publish_void((b >> 3) & 1, rb.rec + 64 * ride_xcc(), seq);
+    if (multi_over(hd)) multi_publish_void((b >> 3) & 1, rb.rec + 64 * ride_xcc(), seq);
     else multi_mid_leader(M, j, b, AT.nblk, fred, fst, &okf);
     return;
   }
@@ -422,29 +404,32 @@ __global__ __launch_bounds__(kBlock) void k_iter_multi(CsrView AT, RgcsView RA, 
   if (b < 8 * fg.gpx) {
     const int g = (b & 7) * fg.gpx + (b >> 3);
     if (g >= RA.ng) return;
-    if (over) {
-      if (threadIdx.x == 0) {
-        unsigned long long* pt = mx.atag + (size_t)g * 4;
-        for (int w = 0; w < 4; ++w) ride_store(pt + w, (w & 1) ? tag_lo(0.0, seq) : tag_hi(0.0, seq));
-        __hip_atomic_store(mx.gflag + g, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      return;
-    }
     rgcs_group<NL, true, true, true, true>(RA, M.lp[ly ^ 1], M.sp[rd], M.sp[rd ^ 1], nullptr, nullptr, j == M.K - 1 ? M.part_last : nullptr,
                                            M.pstride_a, g, rb, fz, prod, crec, &okf, &mx);
     return;
   }
   b -= 8 * fg.gpx;
+  // The riding updates: FEW real workgroups, each walking several of the segments' (virtual) workgroups -- same arithmetic, same
+  // partials per virtual workgroup.  They sit between this iteration's row groups and the next iteration's leaders and A' blocks in
+  // the grid: a thousand of them would take every slot the draining row groups free for ~10 us, and the next A' blocks -- whose early
+  // start is the point of this kernel -- would be dispatched only behind them.
   if (b < fg.nupd_t) {
-    if (b >= M.ut[0].nblk + M.ut[1].nblk) return;  // (padding)
-    const int s = b < M.ut[0].nblk ? 0 : 1;
-    multi_update_wg(M, j, s, s == 0 ? b : b - M.ut[0].nblk, over, prod, fst, &okf);
+    const int tot = M.ut[0].nblk + M.ut[1].nblk;
+    for (int vb = b; vb < tot; vb += fg.nupd_t) {
+      const int s = vb < M.ut[0].nblk ? 0 : 1;
+      multi_update_wg(M, j, s, s == 0 ? vb : vb - M.ut[0].nblk, multi_over(hd), prod, fst, &okf);
+      __syncthreads();
+    }
     return;
   }
   b -= fg.nupd_t;
-  if (b >= M.ua[0].nblk + M.ua[1].nblk) return;
-  const int s = b < M.ua[0].nblk ? 2 : 3;
-  multi_update_wg(M, j, s, s == 2 ? b : b - M.ua[0].nblk, over, prod, fst, &okf);
+  // (CRAIG: the short update -- whose partials the next head leaders wait for -- first)
+  const int tot = M.ua[0].nblk + M.ua[1].nblk;
+  for (int vb = b; vb < tot; vb += M.nupd_a) {
+    const int s = vb < M.ua[1].nblk ? 3 : 2;
+    multi_update_wg(M, j, s, s == 3 ? vb : vb - M.ua[1].nblk, multi_over(hd), prod, fst, &okf);
+    __syncthreads();
+  }
 }
 
 }  // namespace fpsq

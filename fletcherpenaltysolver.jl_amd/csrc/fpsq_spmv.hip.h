@@ -595,31 +595,37 @@ struct MultiCtx {
                                    // so AT ITS ENTRY publishes itself (flag / tagged words, payload void) and leaves without streaming --
                                    // nobody who waits for it is left waiting, whatever the order the XCDs dispatch in; past its entry a
                                    // workgroup never looks again (what it waits for was entered, or publishes on leaving, too)
+  unsigned long long hd;           // ... the word as this workgroup's FIRST load found it.  A product workgroup examines it only behind
+                                   // its first stream loads (requested earlier, it returns first: no round trip of its own at the head --
+                                   // measured: a dependent look at the entry of every workgroup cost the launch ~6 % )
 };
+__device__ __forceinline__ bool multi_over(unsigned long long w) { return (unsigned int)w != 0u && (unsigned int)(w >> 32) != 0u; }
 __device__ __forceinline__ bool multi_all_done(const unsigned long long* hdone) {
   const unsigned long long w = __hip_atomic_load(hdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return (unsigned int)w != 0u && (unsigned int)(w >> 32) != 0u;
 }
-// wave 0 of the workgroup: the row groups [d.x, d.y] of the previous iteration have published themselves (bounded looks).
-// Every thread calls it (one LDS barrier inside).  false: the bound expired (error word raised): leave
-__device__ __forceinline__ bool multi_wait_groups(const MultiCtx& mx, int2 d, unsigned long long* err, int* okf) {
-  const int tid = threadIdx.x;
-  if (tid < 64) {
-    bool all = false;
-    for (int t = 0; t < kRidePolls && !all; ++t) {
-      if (t) __builtin_amdgcn_s_sleep(8);
-      bool ok = true;
-      for (int g = d.x + tid; g <= d.y; g += 64)
-        ok &= __hip_atomic_load(mx.gflag_prev + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mx.want_prev;
-      all = __all(ok);
-    }
-    if (tid == 0) {
-      *okf = all ? 1 : 0;
-      if (!all) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+// EVERY wave of the workgroup looks for itself (no LDS, no barrier): the row groups [dx, dy] of the previous iteration have published
+// themselves.  `first`: what this wave's lanes found with the look requested at the block's head (ahead of the stream loads, so it is
+// back before them); only if that was too early does the wave poll (bounded; an expired bound raises the error word and the
+// wave goes on -- the call fails anyway, and nobody leaves a barrier behind).
+__device__ __forceinline__ unsigned int multi_look_groups(const MultiCtx& mx, int dx, int dy) {
+  const int g = dx + (int)(threadIdx.x & 63);
+  return g <= dy ? __hip_atomic_load(mx.gflag_prev + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mx.want_prev;
+}
+__device__ __forceinline__ void multi_wait_groups(const MultiCtx& mx, int dx, int dy, unsigned int first, unsigned long long* err) {
+  const int lane = threadIdx.x & 63;
+  bool ok = first == mx.want_prev;
+  for (int g = dx + 64 + lane; g <= dy; g += 64)  // (a range of more than 64 groups: the rest)
+    ok = ok && __hip_atomic_load(mx.gflag_prev + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mx.want_prev;
+  if (__all(ok)) return;
+  for (int t = 0; t < kRidePolls; ++t) {
+    __builtin_amdgcn_s_sleep(4);
+    ok = true;
+    for (int g = dx + lane; g <= dy; g += 64)
+      ok = ok && __hip_atomic_load(mx.gflag_prev + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mx.want_prev;
+    if (__all(ok)) return;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  return *okf != 0;
+  if (lane == 0) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The A' product of one workgroup: blocks Lt[0 .. nt) of the padded layout, two lanes, coefficients from the leaders' record.
@@ -667,6 +673,14 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
     [[maybe_unused]] uint4 sw16;
     [[maybe_unused]] uint2 sw8;
     int r0, nr, s, cbase;
+    [[maybe_unused]] unsigned int gl0 = 0;
+    [[maybe_unused]] int2 bd2 = make_int2(1, 0);
+    if constexpr (MULTI) {  // the first look at the row groups this block waits for: requested ahead of everything else
+      if (mx->gflag_prev != nullptr) {
+        bd2 = mx->bdep[L];
+        gl0 = multi_look_groups(*mx, bd2.x, bd2.y);
+      }
+    }
     if (CSORT && shared) {  // the block's head through the scalar cache, value loads issued first (cshared_head)
       if constexpr (CSORT) cshared_head(A, L, tid, sw16, sw8, r0, nr, s, cbase, v);
     } else {
@@ -702,7 +716,16 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
       // the row groups of the previous iteration that wrote what this block gathers (the stream above does not depend on them).
       // They in turn waited for this block's own previous incarnation: only behind this wait are its `yin` rows -- written one
       // iteration ago into the other long pair -- there to be read (the one-launch iteration prefetches them at the block's head)
-      if (mx->gflag_prev != nullptr && !multi_wait_groups(*mx, mx->bdep[L], fz.err, okfp)) return;
+      if (t == 0 && multi_over(mx->hd)) {  // (the call has ended: publish the blocks with a void payload, stream nothing more)
+        if (tid == 0)
+          for (int u = 0; u < nt; ++u) {
+            unsigned long long* pt = fz.ptag + (size_t)Lt[u] * 4;
+            for (int w = 0; w < 4; ++w) ride_store(pt + w, (w & 1) ? tag_lo(0.0, fz.want) : tag_hi(0.0, fz.want));
+            __hip_atomic_store(fz.blkflag + Lt[u], fz.want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        return;
+      }
+      if (mx->gflag_prev != nullptr) multi_wait_groups(*mx, bd2.x, bd2.y, gl0, fz.err);
       if (yin != nullptr) {
         const double2 yy = ld_pair_ag(yin, r0 + rq0);  // (agent scope: not a line this CU's L1 kept from two iterations ago)
         hypre[t][0] = yy.x;
@@ -948,6 +971,16 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
   };
   if (PAD) fetch_segs(0);
   else fetch(e0, 0);
+  if constexpr (MULTI) {
+    if (multi_over(mx->hd)) {  // (the call has ended: publish the group with a void payload; examined behind the first stream loads)
+      if (tid == 0) {
+        unsigned long long* pt = mx->atag + (size_t)g * 4;
+        for (int w = 0; w < 4; ++w) ride_store(pt + w, (w & 1) ? tag_lo(0.0, mx->want) : tag_hi(0.0, mx->want));
+        __hip_atomic_store(mx->gflag + g, mx->want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
   if constexpr (FUSED) {
     // the A' blocks that own the lines this group gathers from: wave 0 looks at their flags (agent-scope loads, requested
     // behind the first tile's stream, which does not depend on them), a bounded number of times
@@ -1252,14 +1285,8 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
     xch_sum<2>(sm.xt, sm.xseq, sm.xlane, v, red32);
     s0 = v[0];
   }
-#ifdef FPSQ_DEBUG_PRINT
-  if (threadIdx.x == 0 && commit) printf("FM it=%d kind=%d skip=%d s0=%.17g\n", sm.it, sm.kind, (int)skip, s0);
-#endif
   if (threadIdx.x == 0) {
     if (!skip) step_advance(sm, st80, s0, 0.0, commit ? sm.prog : nullptr);
-#ifdef FPSQ_DEBUG_PRINT
-    if (commit) { const LaneCtl* cc = reinterpret_cast<const LaneCtl*>(st80); printf("FM-> it=%d kind=%d ca=%.17g cb=%.17g e0=%.17g e4=%.17g\n", sm.it, sm.kind, cc->ca, cc->cb, cc->e[0], cc->e[4]); }
-#endif
     ride_publish(reinterpret_cast<const LaneCtl*>(st80 + sm.prod_ctl_off), l, rec, rb.pub);
     if (commit && !skip) step_final_stats(sm, st80);
   }
