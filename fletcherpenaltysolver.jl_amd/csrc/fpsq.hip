@@ -802,6 +802,10 @@ struct fpsq_solver_s {
   // SLOWER at the headline size (64 / 192: 854 evals/s, 128 / 384: 926, all: 940 against 952 with one iteration per launch: the long
   // update then cannot keep up and the next mid leaders wait for it)
   int multi_upd_t = 1 << 20, multi_upd_a = 1 << 20;
+  // FPSQ_MULTI_DEFER_LONG=1: CRAIG's long update one iteration later, behind the NEXT iteration's A' blocks, so that only the small
+  // m-vector updates stand between an iteration's row groups and the next A' blocks in the dispatch order.  Measured SLOWER (909
+  // against 949 evals/s at 8 iterations per launch: the long update then competes with the A' phase and holds the mid leaders up)
+  bool multi_defer_long = false;
   bool multi_ok = false;
   int2* mz_bdep = nullptr;
   unsigned int* mz_flag2 = nullptr;          // second parity of fz_flag / fz_ptag
@@ -3060,8 +3064,10 @@ struct KrylovRun {
     fg.nupd_t = std::min((M.ut[0].nblk + M.ut[1].nblk + 7) / 8 * 8, h->multi_upd_t);
     fg.gpx = (h->RA.view.ng + 7) / 8;
     fg.rot = h->fuse_rotate;
-    M.nupd_a = std::min((M.ua[0].nblk + M.ua[1].nblk + 7) / 8 * 8, h->multi_upd_a);
-    M.per_iter = kRideCand + fg.nwg_t + kRideCand + 8 * fg.gpx + fg.nupd_t + M.nupd_a;
+    // CRAIG's long update one iteration later, behind the next A' blocks (FPSQ_MULTI_DEFER_LONG=0: with the short one)
+    M.nlong = h->multi_defer_long ? (M.ua[0].nblk + 7) / 8 * 8 : 0;
+    M.nupd_a = std::min(((M.nlong ? 0 : M.ua[0].nblk) + M.ua[1].nblk + 7) / 8 * 8, h->multi_upd_a);
+    M.per_iter = kRideCand + fg.nwg_t + M.nlong + kRideCand + 8 * fg.gpx + fg.nupd_t + M.nupd_a;
     M.seq0 = (uint32_t)(h->ride_seq + 1);
     h->ride_seq += (unsigned long long)K;
     M.sp[0] = SPcur;
@@ -3091,7 +3097,7 @@ struct KrylovRun {
     M.delay_h = h->ride_delay;
     M.delay_m = h->ride_delay_mid;
     M.break_pub = h->fuse_break ? ~0u : 0u;
-    const dim3 grid((unsigned)M.per_iter * (unsigned)K);
+    const dim3 grid((unsigned)M.per_iter * (unsigned)K + (unsigned)M.nlong);
     if (h->AT.sorted) launch_product(h, k_iter_multi<true>, grid, h->AT.view(), h->RA.view, M);
     else launch_product(h, k_iter_multi<false>, grid, h->AT.view(), h->RA.view, M);
     h->launches++;
@@ -3824,6 +3830,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
   if (const char* ev = std::getenv("FPSQ_DEBUG_FUSE_BREAK")) h->fuse_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_FUSE_HALO")) h->fuse_halo_on = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_MULTI_ITER")) h->multi_max = std::min(std::max(std::atoi(ev), 1), kMultiMax);
+  if (const char* ev = std::getenv("FPSQ_MULTI_DEFER_LONG")) h->multi_defer_long = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_MULTI_UPD")) {
     int a = 0, b = 0;
     if (std::sscanf(ev, "%d,%d", &a, &b) == 2 && a >= 8 && b >= 8) {

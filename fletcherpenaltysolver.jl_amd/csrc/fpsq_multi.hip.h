@@ -48,7 +48,10 @@ struct MultiArgs {
   int32_t it0;                 // iteration number of j = 0
   uint32_t seq0;               // launch number of iteration 0 (iteration j: seq0 + j)
   FuseGrid fg;                 // one iteration's layout: A' workgroups, LSQR-update workgroups (padded), row groups per XCD
-  int32_t nupd_a;              // CRAIG-update workgroups, padded to a multiple of 8
+  int32_t nupd_a;              // workgroups of CRAIG's SHORT update (whose partials the next head leaders wait for), padded to a multiple of 8
+  int32_t nlong;               // ... of its LONG update, padded: they run ONE ITERATION LATER, behind the next iteration's A' blocks (and behind the
+                               // last iteration's grid), so that only the small m-vector updates stand between an iteration's row groups and
+                               // the next A' blocks in the dispatch order; 0: CRAIG's long update rides with the short one
   int32_t sp0, lp0;            // which of the two buffers iteration 0 READS (short pair: gathers, yin of the row groups; long pair: yin of the blocks)
   int32_t pstride_a;
   double* sp[2];
@@ -351,6 +354,14 @@ __global__ __launch_bounds__(kBlock) void k_iter_multi(CsrView AT, RgcsView RA, 
   __shared__ int okf;
   const int j = (int)blockIdx.x / M.per_iter;
   int b = (int)blockIdx.x - j * M.per_iter;
+  if (j >= M.K) {  // (behind the last iteration: its long update)
+    const unsigned long long hd_ = __hip_atomic_load(M.hdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int vb = b; vb < M.ua[0].nblk; vb += M.nlong) {
+      multi_update_wg(M, M.K - 1, 2, vb, multi_over(hd_), prod, fst, &okf);
+      __syncthreads();
+    }
+    return;
+  }
   const unsigned int seq = M.seq0 + (unsigned int)j;
   const int it = M.it0 + j, q = it & 1;
   // (the first load of every workgroup; leaders and update workgroups -- which wait for records anyway -- act on it at once, product
@@ -395,6 +406,15 @@ __global__ __launch_bounds__(kBlock) void k_iter_multi(CsrView AT, RgcsView RA, 
     return;
   }
   b -= fg.nwg_t;
+  if (b < M.nlong) {  // CRAIG's long update of the PREVIOUS iteration (iteration 0: of the previous launch -- done there)
+    if (j > 0)
+      for (int vb = b; vb < M.ua[0].nblk; vb += M.nlong) {
+        multi_update_wg(M, j - 1, 2, vb, multi_over(hd), prod, fst, &okf);
+        __syncthreads();
+      }
+    return;
+  }
+  b -= M.nlong;
   if (b < kRideCand) {
     if (multi_over(hd)) multi_publish_void((b >> 3) & 1, rb.rec + 64 * ride_xcc(), seq);
     else multi_mid_leader(M, j, b, AT.nblk, fred, fst, &okf);
@@ -423,11 +443,11 @@ __global__ __launch_bounds__(kBlock) void k_iter_multi(CsrView AT, RgcsView RA, 
     return;
   }
   b -= fg.nupd_t;
-  // (CRAIG: the short update -- whose partials the next head leaders wait for -- first)
-  const int tot = M.ua[0].nblk + M.ua[1].nblk;
+  // CRAIG: the short update (and the long one too when it is not deferred: M.nlong == 0), the short one first
+  const int nshort = M.ua[1].nblk, tot = nshort + (M.nlong == 0 ? M.ua[0].nblk : 0);
   for (int vb = b; vb < tot; vb += M.nupd_a) {
-    const int s = vb < M.ua[1].nblk ? 3 : 2;
-    multi_update_wg(M, j, s, s == 3 ? vb : vb - M.ua[1].nblk, multi_over(hd), prod, fst, &okf);
+    const int s = vb < nshort ? 3 : 2;
+    multi_update_wg(M, j, s, s == 3 ? vb : vb - nshort, multi_over(hd), prod, fst, &okf);
     __syncthreads();
   }
 }
