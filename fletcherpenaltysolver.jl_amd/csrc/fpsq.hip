@@ -1932,6 +1932,12 @@ int wait_progress(fpsq_handle h, int lane, int target, const int32_t* dev_done, 
   };
   while (!reached()) {
     if ((++spins & 63) == 0) {
+      // a bounded wait inside a launch has expired (the handle's error word): nothing later in this call can be right, and the
+      // recurrences' progress words will not move any more -- leave the loop now, not at itmax (advisor, round 4)
+      if (*reinterpret_cast<volatile uint64_t*>(h->hscal + 15) != 0) {
+        h->err = "a bounded wait inside a product launch expired while the host was waiting for the device's progress";
+        return FPSQ_ERR_TIMEOUT;
+      }
       hipError_t q = hipStreamQuery(h->stream);
       if (q == hipSuccess) {
         if (reached()) break;
@@ -3199,6 +3205,10 @@ struct KrylovRun {
       stop = true;
       return 0;
     }
+    if (*reinterpret_cast<volatile uint64_t*>(h->hscal + 15) != 0) {  // (an expired wait inside a launch: see wait_progress)
+      stop = true;
+      return 0;  // (call_end reports it -- and switches the handle to two launches per iteration: ride_failed)
+    }
     // before the expected count the steps publish nothing (but the end of a recurrence): enqueue on
     if (it < expect) return 0;
     // bound the run-ahead of the host on the slowest unfinished lane
@@ -3732,12 +3742,17 @@ int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2, 
 
 // ===================================================================================== C ABI
 
-// One-launch iterations assume that this process has the device's workgroup slots to itself: their waiting workgroups hold slots
-// that the workgroups they wait for may still need, which cannot deadlock inside one process (dependences point to earlier
-// workgroups of the same grid) but can stall for longer than the bounds when OTHER processes fill the device with waiting
-// workgroups of their own (seen with three ranks rehearsed on one GPU, each timing an unsharded handle).  Such a call ends
-// in FPSQ_ERR_TIMEOUT, every kernel gone; the handle then keeps two launches per iteration (ride_failed) and the call is
-// REPEATED once -- its inputs are untouched -- so the caller only sees the delay.
+// One-launch iterations and workgroup slots.  The waiting workgroups of a fused launch hold slots that the workgroups they wait for
+// may still need.  WITHIN ONE LAUNCH that cannot deadlock: every dependence points to a workgroup earlier in the grid, a queue
+// dispatches its grid in order (workgroup i through XCD i mod 8, in order within the XCD), and the leaders are one per lane on
+// EVERY XCD -- so whatever a running workgroup waits for has been dispatched ahead of it on the XCD that dispatches it, and
+// the earliest unfinished workgroup of the grid waits for nothing.  ACROSS LAUNCHES that argument does not hold -- two handles
+// of this process iterating from two host threads are two queues, exactly like two processes: each queue's waiting workgroups
+// can fill slots the OTHER queue's not-yet-dispatched workgroups need.  No circular wait was ever observed inside one process
+// (tools/fuse_soak_two.py: 2.4 M fused launches of two handles sharing the device), three ranks rehearsed on ONE GPU did run into
+// it; the answer is the same for both: every wait is bounded, the call ends in FPSQ_ERR_TIMEOUT with every kernel gone, the
+// handle keeps two launches per iteration from then on (ride_failed -- their waits involve the leaders only) and the call is
+// REPEATED once -- its inputs are untouched -- so the caller sees a delay and fpsq_info.fuse_fallbacks, not an error.
 template <class F>
 int with_fuse_fallback(fpsq_handle h, F&& call) {
   int rc = call();
