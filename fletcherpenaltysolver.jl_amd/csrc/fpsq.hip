@@ -867,6 +867,8 @@ struct fpsq_solver_s {
   int cE = 0, cT = 0, cA = 0, cW = 0;
   bool gather_ready = false;
   uint32_t xch_seq = 0;         // sequence number of the last in-launch sum over the ranks (xch_sum; the same on every rank)
+  uint32_t last_xseq = 0;       // what prepare_step gave the pair it has just prepared (0: no exchange): travels NEXT to the steps --
+  uint32_t ride_xseq = 0;       // k_step's arguments, the RideArgs of the launch whose leaders compute them (pre_args sets ride_xseq)
   uint64_t gather_calls = 0;    // the all-gathers alternate between the two halves of `gath`: a peer that is one reduction
                                 // ahead never overwrites a record its neighbour has not read yet
   double* comm_vec = nullptr;   // [n][2] all-reduce payload (partial A' products)
@@ -1728,6 +1730,8 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     ra.pub = h->ride_break ? ~ra.want : ra.want;
     ra.err = reinterpret_cast<unsigned long long*>(h->hscal_dev + 15);
     ra.delay = h->ride_delay;
+    ra.xseq = h->ride_xseq;
+    ra.xt = h->ride_xseq ? insum_table(h) : nullptr;
   }
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
@@ -1735,7 +1739,10 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     launch_product(h, k_spmv_rgcs<__VA_ARGS__>, dim3(per_xcd * 8 + nupd + (lead ? kRideCand : 0)), h->RA.view, x, yin, yout, c0, c1, partials, \
                    per_xcd, u0, u1, h->gate0, h->gate1, h->strA, z0, z1, ra)
     if constexpr (NL == 2) {
-      if (lead && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true);
+      // (a sharded handle whose leaders form their sums over the ranks in the launch: the variants with the exchange compiled in)
+      if (lead && ra.xt != nullptr && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true, true);
+      else if (lead && ra.xt != nullptr) FPSQ_LAUNCH_RGCS(2, false, true, true);
+      else if (lead && h->RA.view.stride) FPSQ_LAUNCH_RGCS(2, true, true);
       else if (lead) FPSQ_LAUNCH_RGCS(2, false, true);
     }
     if (!pre) {
@@ -2158,9 +2165,11 @@ StepArgs step_args(int kind, const Lane& L, int it, const double* p0, int n0, co
   return a;
 }
 
-void launch_step_raw(fpsq_handle h, const StepArgs& a0, const StepArgs& a1) {
+void launch_step_raw(fpsq_handle h, const StepArgs& a0, const StepArgs& a1, uint32_t xseq = 0) {
   const int nb = a1.kind != STEP_NONE ? 2 : 1;
-  hipLaunchKernelGGL(k_step, dim3(nb), dim3(kStepThreads), 0, h->stream, a0, a1);
+  const XchTable* xt = xseq ? insum_table(h) : nullptr;
+  if (xt) hipLaunchKernelGGL(k_step<true>, dim3(nb), dim3(kStepThreads), 0, h->stream, a0, a1, xt, (unsigned int)xseq);
+  else hipLaunchKernelGGL(k_step<false>, dim3(nb), dim3(kStepThreads), 0, h->stream, a0, a1, xt, 0u);
   h->launches++;
 }
 
@@ -2181,21 +2190,12 @@ int seg_count(fpsq_handle h, const double* p) {
 // product launch is prepared when it is handed over (the collective must precede that launch in the stream).
 int prepare_step(fpsq_handle h, StepArgs& a0, StepArgs& a1, bool sharded = false, int sharded1 = -1) {
   const bool sh[2] = {sharded, sharded1 < 0 ? sharded : sharded1 != 0};  // per step: its partials are per-rank sums
+  h->last_xseq = 0;
   if (h->comm && h->halo && insum(h)) {
-    // the step's workgroup forms the sum over the ranks itself (xch_sum): the arguments stay the rank's local arrays and get
-    // the exchange's number -- one per prepared pair, the same sequence on every rank.  A communicator of one: nothing at all.
-    if (const XchTable* xt = insum_table(h)) {
-      if ((sh[0] && a0.kind != STEP_NONE) || (sh[1] && a1.kind != STEP_NONE)) {
-        const uint32_t seq = ++h->xch_seq;
-        StepArgs* w[2] = {&a0, &a1};
-        for (int k = 0; k < 2; ++k) {
-          if (w[k]->kind == STEP_NONE || !sh[k]) continue;
-          w[k]->xt = xt;
-          w[k]->xseq = seq;
-          w[k]->xlane = k;
-        }
-      }
-    }
+    // the step's workgroup forms the sum over the ranks itself (xch_sum): the arguments stay the rank's local arrays, and the pair
+    // gets an exchange number -- the same sequence on every rank -- which travels next to the steps (h->last_xseq: the caller
+    // hands it to k_step or to the launch whose leaders compute the pair).  A communicator of one: nothing at all.
+    if (insum_table(h) != nullptr && ((sh[0] && a0.kind != STEP_NONE) || (sh[1] && a1.kind != STEP_NONE))) h->last_xseq = ++h->xch_seq;
     return 0;
   }
   if (h->comm && h->halo && (sh[0] || sh[1])) {
@@ -2265,7 +2265,7 @@ int prepare_step(fpsq_handle h, StepArgs& a0, StepArgs& a1, bool sharded = false
 
 int launch_step(fpsq_handle h, StepArgs a0, StepArgs a1, bool sharded = false, int sharded1 = -1) {
   if (int rc = prepare_step(h, a0, a1, sharded, sharded1)) return rc;
-  launch_step_raw(h, a0, a1);
+  launch_step_raw(h, a0, a1, h->last_xseq);
   return 0;
 }
 
@@ -2366,6 +2366,7 @@ struct KrylovRun {
   // the steps behind the last product, not launched yet
   StepArgs pend[2];
   bool have_pend = false;
+  uint32_t pend_xseq = 0;  // ... and the number of their exchange (sharded, in-launch sums; 0: none)
   // the loop
   double *SPcur, *SPalt;
   int look = 1;
@@ -2498,8 +2499,8 @@ struct KrylovRun {
   int flush_pend(bool sharded) {
     if (!have_pend) return 0;
     have_pend = false;
-    if (h->comm) {  // (prepared -- gathered -- when they were handed over)
-      launch_step_raw(h, pend[0], pend[1]);
+    if (h->comm) {  // (prepared -- gathered, or numbered -- when they were handed over)
+      launch_step_raw(h, pend[0], pend[1], pend_xseq);
       return 0;
     }
     return launch_step(h, pend[0], pend[1], sharded);
@@ -2515,8 +2516,11 @@ struct KrylovRun {
     if (lead && a0.kind != STEP_NONE && a1.kind != STEP_NONE) {
       pend[0] = a0;
       pend[1] = a1;
-      if (h->comm)
+      pend_xseq = 0;
+      if (h->comm) {
         if (int rc = prepare_step(h, pend[0], pend[1], sharded)) return rc;
+        pend_xseq = h->last_xseq;
+      }
       have_pend = true;
       return 0;
     }
@@ -2524,6 +2528,7 @@ struct KrylovRun {
   }
   // the pending steps as the next product launch takes them (null: nothing pending)
   const StepArgs* pre_args(bool for_at) {
+    h->ride_xseq = have_pend ? pend_xseq : 0;  // (the launch that takes the steps also takes their exchange's number: launch_spmv)
     if (!have_pend) return nullptr;
     for (int l = 0; l < NL; ++l) {
       pend[l].state = lanes[l].state;
@@ -2727,8 +2732,11 @@ struct KrylovRun {
         // control block it brings to this product published as it is (ride_leader, kind NONE)
         pend[0] = b0;
         pend[1] = b1;
-        if (h->comm)  // (halo mode: ||rhs||^2 runs over the ranks' owned parts)
+        pend_xseq = 0;
+        if (h->comm) {  // (halo mode: ||rhs||^2 runs over the ranks' owned parts)
           if (int rc = prepare_step(h, pend[0], pend[1], /*sharded=*/true)) return rc;
+          pend_xseq = h->last_xseq;
+        }
         have_pend = true;
         const StepArgs* pre = pre_args(false);
         if (pend[0].kind == STEP_NONE) pend[0].state = const_cast<LaneCtl*>(s0c);
@@ -2925,10 +2933,13 @@ struct KrylovRun {
     StepArgs sh[2] = {pre[0], pre[NL - 1]}, sm[2];
     // halo-sharded with rows shared with the neighbours: the exchange and the finish of the overlap rows ride in this launch
     // (fuse_halo_wg); the finish workgroups' partials follow the blocks'
-    const bool with_halo = h->comm && h->halo && h->ovl + h->ovr > 0;
+    // (the HALO kernel also whenever the leaders exchange -- its leaders have the exchange compiled in; no shared rows: no halo workgroups)
+    const bool shared_rows = h->comm && h->halo && h->ovl + h->ovr > 0;
+    const bool with_halo = shared_rows || (h->comm && h->halo && insum_table(h) != nullptr);
     FuseHalo fh{};
     HaloRows hr{};
-    if (with_halo) {
+    if (with_halo && !shared_rows) hr = HaloRows{0, h->n, h->halo_raw};
+    if (shared_rows) {
       const int64_t t = h->ovl + h->ovr;
       double* rl = h->halo_recv + (size_t)(h->halo_calls++ & 1) * (size_t)t * 2;
       if (!h->comm->halo_fused_args(rl, h->ovl, h->ovr, fh)) {
@@ -2947,13 +2958,16 @@ struct KrylovRun {
       hr = HaloRows{h->ovl, h->n - h->ovr, h->halo_raw};
     }
     for (int l = 0; l < NL; ++l) {
-      sm[l] = step_after_at(l, h->AT.nblk + (with_halo ? h->halo_gf : 0));
+      sm[l] = step_after_at(l, h->AT.nblk + (shared_rows ? h->halo_gf : 0));
       sm[l].state = sh[l].state_out;  // (what the head step leaves: the mid leaders recompute it, nobody reads this pointer)
       sm[l].state_out = lanes[l].state_alt2;
       sm[l].prod_ctl_off = 0;
     }
-    if (h->comm)  // (halo mode: the mid leaders' sums run over the ranks -- the exchange behind the head steps')
+    uint32_t mid_xseq = 0;
+    if (h->comm) {  // (halo mode: the mid leaders' sums run over the ranks -- the exchange behind the head steps')
       if (int rc = prepare_step(h, sm[0], sm[1], true)) return rc;
+      mid_xseq = h->last_xseq;
+    }
     UpdSeg cu[2] = {seg_none(), seg_none()};
     for (int l = 0; l < NL; ++l)
       if (is_ln(lanes[l].kind)) ln_upd_segs(l, cu[0], cu[1]);
@@ -2978,11 +2992,15 @@ struct KrylovRun {
     rb = ra;
     rb.rec = h->ride_rec2;
     rb.delay = h->ride_delay_mid;
+    ra.xseq = h->ride_xseq;  // (pre_args: the pending head steps' exchange)
+    ra.xt = ra.xseq ? insum_table(h) : nullptr;
+    rb.xseq = mid_xseq;
+    rb.xt = mid_xseq ? insum_table(h) : nullptr;
     FuseArgs fz{};
     fz.blkflag = h->fz_flag;
     fz.ptag = h->fz_ptag;
     fz.dep = h->fz_dep;
-    fz.dep2 = with_halo ? h->fz_dep2 : nullptr;
+    fz.dep2 = shared_rows ? h->fz_dep2 : nullptr;
     fz.want = ra.want;
     fz.pub = h->fuse_break ? ~ra.want : ra.want;
     fz.err = ra.err;

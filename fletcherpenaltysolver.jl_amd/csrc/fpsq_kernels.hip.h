@@ -233,9 +233,7 @@ struct UpdSeg {
   const double* src; // interleaved Golub-Kahan vector [len][NL]
   int32_t lane;      // which interleaved lane of src
   int32_t nblk;      // workgroups assigned to this segment
-  int32_t ag;        // != 0 (several iterations per launch, k_iter_multi): `src` was written through by OTHER XCDs earlier in the same
-                     // launch -- read it at agent scope (an XCD's own L2 may hold the values of two iterations ago)
-  int32_t pad_;
+  int32_t pad_[2];
   // Speculatively enqueued final flush: runs only if this recurrence AND the one behind `gate` have ended (null:
   // ungated).  While any lane of the call still iterates the loop goes on and the next product launch carries this
   // update -- it must not be applied twice.
@@ -250,19 +248,22 @@ struct UpdSeg {
 
 // ... and, in that mode, the vectors an update rewrites in place (x, w, y): the workgroup of the same index of the PREVIOUS iteration
 // wrote them, on whatever CU / XCD it ran -- loads at agent scope, stores written through
+template <bool AG>
 __device__ __forceinline__ double upd_ld(const UpdSeg& s, const double* p, int64_t idx) {
-  if (s.ag)
+  if constexpr (AG)
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + idx), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT));
   return p[idx];
 }
+template <bool AG>
 __device__ __forceinline__ void upd_st(const UpdSeg& s, double* p, int64_t idx, double v) {
-  if (s.ag) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + idx), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+  if constexpr (AG) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + idx), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
   else p[idx] = v;
 }
+template <bool AG>
 __device__ __forceinline__ double upd_src(const UpdSeg& s, int64_t idx) {
-  if (s.ag)
+  if constexpr (AG)
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(s.src + idx), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_AGENT));
   return s.src[idx];
@@ -270,7 +271,10 @@ __device__ __forceinline__ double upd_src(const UpdSeg& s, int64_t idx) {
 
 // LSQR (Krylov.jl lsqr!): x += (phi/rho) w; w = v - (theta/rho) w, with v = vt / alpha deferred.
 //   e[0] = phi/rho, e[1] = theta/rho, e[2] = 1/alpha.   WINIT: w = vt / alpha only (w_1 = v_1).
-template <int NL, bool WINIT>
+// AG (several iterations per launch, k_iter_multi): the operands were written by OTHER workgroups earlier in the same launch -- loads
+// at agent scope, in-place stores written through (see upd_ld).  A template parameter: as a run-time switch in these inner loops it
+// cost every one-launch iteration ~2 us (measured against round 4's library on one box: 978 -> 945 evals/s).
+template <int NL, bool WINIT, bool AG = false>
 __device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red, const LaneCtl* ctl) {
   if (WINIT && ctl->done) {  // the recurrence ended at start-up (b = 0 or B'b = 0): the solution is x = 0
     for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) s.a[i] = 0.0;
@@ -283,14 +287,14 @@ __device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red, 
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
     double wn;
     if (WINIT) {
-      wn = upd_src(s, i * NL + s.lane) * ia;
+      wn = upd_src<AG>(s, i * NL + s.lane) * ia;
       s.a[i] = 0.0;  // x_0 = 0
     } else {
-      const double wi = upd_ld(s, s.b, i);
-      upd_st(s, s.a, i, upd_ld(s, s.a, i) + sg * wi);
-      wn = upd_src(s, i * NL + s.lane) * ia - tr * wi;
+      const double wi = upd_ld<AG>(s, s.b, i);
+      upd_st<AG>(s, s.a, i, upd_ld<AG>(s, s.a, i) + sg * wi);
+      wn = upd_src<AG>(s, i * NL + s.lane) * ia - tr * wi;
     }
-    upd_st(s, s.b, i, wn);
+    upd_st<AG>(s, s.b, i, wn);
     sq += wn * wn;
   }
   const double t = block_sum(sq, red);
@@ -302,33 +306,33 @@ __device__ __forceinline__ void upd_lsqr(const UpdSeg& s, int blk, double* red, 
 //   lambda > 0:  xs += e0 * vt + e1 * w2s;   w2s = e2 * vt + e3 * w2s
 //       e0 = sgn xi c1 / alpha, e1 = sgn xi s1 omega, e2 = s1 / alpha, e3 = -c1 omega
 //   lambda = 0:  xs += e0 * vt                      (e0 = sgn xi / alpha)
-template <int NL, bool REG>
+template <int NL, bool REG, bool AG = false>
 __device__ __forceinline__ void upd_craig_long(const UpdSeg& s, int blk, const LaneCtl* ctl) {
   if (ctl->done && ctl->upd_iter != s.it) return;
   const double e0 = ctl->e[0], e1 = ctl->e[1], e2 = ctl->e[2], e3 = ctl->e[3];
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    const double v = upd_src(s, i * NL + s.lane);
+    const double v = upd_src<AG>(s, i * NL + s.lane);
     if (REG) {
-      const double w2 = upd_ld(s, s.b, i);
-      upd_st(s, s.a, i, upd_ld(s, s.a, i) + (e0 * v + e1 * w2));
-      upd_st(s, s.b, i, e2 * v + e3 * w2);
+      const double w2 = upd_ld<AG>(s, s.b, i);
+      upd_st<AG>(s, s.a, i, upd_ld<AG>(s, s.a, i) + (e0 * v + e1 * w2));
+      upd_st<AG>(s, s.b, i, e2 * v + e3 * w2);
     } else {
-      upd_st(s, s.a, i, upd_ld(s, s.a, i) + e0 * v);
+      upd_st<AG>(s, s.a, i, upd_ld<AG>(s, s.a, i) + e0 * v);
     }
   }
 }
 
 // CRAIG short (m) part:  w = u - (theta/rho_prev) w with u = e4 * mut (= mu Mu~ / beta);  y += e6 * w.
 //   e4 = mu/beta, e5 = theta/rho_prev, e6 = xi/rho
-template <int NL>
+template <int NL, bool AG = false>
 __device__ __forceinline__ void upd_craig_short(const UpdSeg& s, int blk, double* red, const LaneCtl* ctl) {
   if (ctl->done && ctl->upd_iter != s.it) return;
   const double e4 = ctl->e[4], e5 = ctl->e[5], e6 = ctl->e[6];
   double sq = 0.0;
   for (int64_t i = (int64_t)blk * kBlock + threadIdx.x; i < s.len; i += (int64_t)s.nblk * kBlock) {
-    const double wn = e4 * upd_src(s, i * NL + s.lane) - e5 * upd_ld(s, s.a, i);
-    upd_st(s, s.a, i, wn);
-    upd_st(s, s.b, i, upd_ld(s, s.b, i) + e6 * wn);
+    const double wn = e4 * upd_src<AG>(s, i * NL + s.lane) - e5 * upd_ld<AG>(s, s.a, i);
+    upd_st<AG>(s, s.a, i, wn);
+    upd_st<AG>(s, s.b, i, upd_ld<AG>(s, s.b, i) + e6 * wn);
     sq += wn * wn;
   }
   const double t = block_sum(sq, red);
@@ -478,6 +482,17 @@ __device__ __forceinline__ void qp_fx_core(const double* pf, const double* pdx, 
 
 // ctl: the recurrence's control block the update reads its coefficients from -- s.ctl in global memory, or (product kernels
 // with riding leaders) the copy the workgroup has taken from the leaders' record into LDS
+// the segments of a k_iter_multi launch (LSQR / CRAIG lanes only), operands at agent scope
+template <int NL>
+__device__ __forceinline__ void upd_run_ag(const UpdSeg& s, int blk, double* red, const LaneCtl* ctl) {
+  switch (s.kind) {
+    case UPD_LSQR: upd_lsqr<NL, false, true>(s, blk, red, ctl); break;
+    case UPD_CRAIG_LONG_REG: upd_craig_long<NL, true, true>(s, blk, ctl); break;
+    case UPD_CRAIG_LONG: upd_craig_long<NL, false, true>(s, blk, ctl); break;
+    case UPD_CRAIG_SHORT: upd_craig_short<NL, true>(s, blk, red, ctl); break;
+    default: break;
+  }
+}
 template <int NL>
 __device__ __forceinline__ void upd_run(const UpdSeg& s, int blk, double* red, const LaneCtl* ctl) {
   switch (s.kind) {

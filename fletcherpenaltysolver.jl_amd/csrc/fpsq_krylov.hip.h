@@ -895,12 +895,10 @@ struct StepArgs {
   void* state_out;
   // riding steps: the 8-byte-word offset, inside the state, of the control block whose ca / cb / done / skip the NEXT product
   // reads (0: the state's first member; a MINRES lane has a second block, ctlT, for A' products)
-  int32_t prod_ctl_off;
-  // Row-sharded runs with the sums over the ranks formed inside the launch (xch_sum above; xt null: not this step): p0 / p1 are
-  // the rank's LOCAL arrays, the step's two sums travel as exchange `xseq`, in half `xlane` of the rows
-  int32_t xlane;
-  const XchTable* xt;
-  uint32_t xseq, pad_;
+  int32_t prod_ctl_off, pad_;
+  // (Row-sharded runs with the sums over the ranks formed inside the launch, xch_sum above: p0 / p1 are the rank's LOCAL arrays;
+  // the peer table and the exchange's number travel NEXT to the steps -- RideArgs, k_step's own arguments -- not in this struct:
+  // four copies of it are kernel arguments of the one-launch iteration, and 24 more bytes in each cost that kernel 3 %, measured)
 };
 
 // 256 threads: the <= ~5000 norm partials are still summed with a few batches of independent loads per thread, and a
@@ -1097,9 +1095,13 @@ __device__ __forceinline__ void step_final_stats(const StepArgs& a, const void* 
 struct NoStepHook {
   __device__ void advanced() const {}
 };
-template <class Hook = NoStepHook>
+// xt != null (row-sharded, in-launch sums): the two sums travel as exchange `xseq`, in half `xlane` of the ranks' rows (xch_sum)
+// XCH is a TEMPLATE parameter: the exchange's code merely being PRESENT in the leaders' path cost the one-launch iteration of a
+// single-GPU handle 3 % (978 -> 950 evals/s against round 4's library on one box, bisected to this: the product workgroups
+// of the same kernel pay for the leaders' registers) -- kernels of handles that never exchange are instantiated without it.
+template <class Hook = NoStepHook, bool XCH = false>
 __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */, unsigned long long* st /* 80 */, bool commit,
-                                         const Hook* hook = nullptr) {
+                                         const Hook* hook = nullptr, const XchTable* xt = nullptr, unsigned int xseq = 0, int xlane = 0) {
   // The recurrence state (<= 0.5 KB) is staged in LDS with one coalesced read issued together with the partial-sum
   // loads, advanced there by thread 0, and written back with one coalesced store: the ~40 dependent scalar accesses of
   // a step then cost LDS latency instead of a global round trip each.
@@ -1112,11 +1114,13 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
     // (contains the workgroup barrier that publishes `st`)
     if (a.nseg > 1) reduce_two_seg(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, a.nseg, a.seg_stride, red, s0, s1);
     else reduce_two(a.p0, a.n0, a.p1, a.p1 ? a.n1 : 0, red, s0, s1);
-    if (a.xt != nullptr) {  // (uniform; `skip` is too, on every rank: the states are replicated)
-      double v[2] = {s0, s1};
-      xch_sum<2>(a.xt, a.xseq, a.xlane, v, red);
-      s0 = v[0];
-      s1 = v[1];
+    if constexpr (XCH) {
+      if (xt != nullptr) {  // (uniform; `skip` is too, on every rank: the states are replicated)
+        double v[2] = {s0, s1};
+        xch_sum<2>(xt, xseq, xlane, v, red);
+        s0 = v[0];
+        s1 = v[1];
+      }
     }
   } else {
     __syncthreads();
@@ -1136,13 +1140,14 @@ __device__ __forceinline__ void step_run(const StepArgs& a, double* red /* 32 */
   }
 }
 
-__global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1) {
+template <bool XCH = false>
+__global__ __launch_bounds__(kStepThreads) void k_step(StepArgs a0, StepArgs a1, const XchTable* xt, unsigned int xseq) {
   const StepArgs& a = blockIdx.x == 0 ? a0 : a1;
   if (a.kind == STEP_NONE) return;
   if (a.state_out == nullptr && lane_done(a)) return;  // (in place and nothing to do)
   __shared__ double red[32];
   __shared__ __attribute__((aligned(16))) unsigned long long st[80];
-  step_run(a, red, st, true);
+  step_run<NoStepHook, XCH>(a, red, st, true, nullptr, xt, xseq, (int)blockIdx.x);
 }
 
 static_assert(sizeof(LsqrState) % 8 == 0 && sizeof(LsqrState) <= 640, "state staging");

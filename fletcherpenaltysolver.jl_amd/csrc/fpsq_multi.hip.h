@@ -321,7 +321,6 @@ __device__ __forceinline__ void multi_update_wg(const MultiArgs& M, int j, int s
   ra.want = seq;
   ra.err = M.err;
   if (!(s < 2 ? ride_settle<true>(ra, fst, okf) : ride_settle<true, 48>(ra, fst, okf))) return;
-  u.ag = 1;
   if (s < 2) {  // LSQR's update of iteration it - 1 (KrylovRun::lsqr_upd_seg)
     u.it = it - 1;
     u.src = M.sp[(M.sp0 + j) & 1];
@@ -335,7 +334,7 @@ __device__ __forceinline__ void multi_update_wg(const MultiArgs& M, int j, int s
     u.partials = M.pw[u.lane][(it - 1) & 1];
   }
   if (threadIdx.x == 0 && u.partials != nullptr) u.partials[blk] = 0.0;  // (a finished lane's update returns without writing it)
-  upd_run<2>(u, blk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
+  upd_run_ag<2>(u, blk, prod, reinterpret_cast<const LaneCtl*>(u.lane == 0 ? fst : fst + 80));
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (every store of the workgroup has reached the L2 of its XCD)
   if (threadIdx.x == 0) {
     const double v = u.partials != nullptr ? u.partials[blk] : 0.0;

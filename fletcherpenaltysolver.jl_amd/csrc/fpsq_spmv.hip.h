@@ -379,6 +379,8 @@ struct RideArgs {
   unsigned long long* err;  // host-mapped: set when a bounded wait for the record expired (the call then fails)
   int delay;                // tests only (FPSQ_DEBUG_RIDE_DELAY = c + 1): leader c idles ~100 us before it starts -- what another
                             // kernel holding its XCD would do to it; results must not depend on it
+  unsigned int xseq;        // row-sharded handles whose sums over the ranks are formed inside the launch (fpsq_krylov.hip.h xch_sum): the
+  const XchTable* xt;       // number of THIS leader set's exchange and the peer table (null: one GPU, a communicator of one, other routes)
 };
 struct RideCoef {
   double ca[2], cb[2];
@@ -444,6 +446,7 @@ struct RideHook {
 // may_commit = false (the head leaders of a fused launch): nobody here performs the step's side effects -- the mid leaders,
 // which redo the step anyway, do, so that the progress words of the launch's two steps reach the host in order whichever
 // leader is late.
+template <bool XCH = false>
 __device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const RideArgs& ra, double* red32, unsigned long long* st80,
                                             bool may_commit = true) {
   const int l = (c >> 3) & 1;
@@ -454,7 +457,7 @@ __device__ __forceinline__ void ride_leader(const StepArgs& a, int c, const Ride
   unsigned long long* rec = ra.rec + 64 * ride_xcc();
   const RideHook hook{&ra, st80, rec, l, a.prod_ctl_off};
   if (a.kind != STEP_NONE) {
-    step_run(a, red32, st80, /*commit=*/may_commit && (c & 7) == 0, &hook);
+    step_run<RideHook, XCH>(a, red32, st80, /*commit=*/may_commit && (c & 7) == 0, &hook, ra.xt, ra.xseq, l);
   } else {
     if (threadIdx.x < 12) st80[threadIdx.x] = reinterpret_cast<const unsigned long long*>(a.state)[threadIdx.x];
     __syncthreads();
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_atl(CsrView A, const double* __
   __shared__ unsigned long long crec[10];
   __shared__ int okf;
   if (blockIdx.x < kRideCand) {
-    ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
+    ride_leader<HALO>(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);  // (HALO = a sharded handle: may exchange)
     return;
   }
   const int b = (int)blockIdx.x - kRideCand;
@@ -1122,7 +1125,8 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
 // does not wait for the group descriptor and no load needs a bounds check.
 // LEAD: the launch's first kRideCand workgroups are the candidates for leading the riding steps (see "steps riding with leaders" above); the
 // groups and the riding updates follow, the coefficients are picked up between the tiles.
-template <int NL, bool PAD = false, bool LEAD = false>
+// XCH (with LEAD): the leaders may form their sums over the ranks in the launch (a sharded handle; see step_run)
+template <int NL, bool PAD = false, bool LEAD = false, bool XCH = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* __restrict__ x, const double* yin,
                                                       double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                       double* partials, int grp_per_xcd, const UpdSeg u0,
@@ -1145,7 +1149,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
     crec = crec_;
     okf = &okf_;
     if (blockIdx.x < kRideCand) {
-      ride_leader(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
+      ride_leader<XCH>(((int)blockIdx.x >> 3) & 1 ? s1 : s0, (int)blockIdx.x, ra, fred, fst);
       return;
     }
   }
@@ -1250,8 +1254,9 @@ __device__ __forceinline__ bool reduce_tagged(const unsigned long long* ptag, in
 }
 
 // mid leader c (see above)
-__device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepArgs& sm, int c, const RideArgs& rb, const FuseArgs& fz,
-                                                double* red32, unsigned long long* st80, int* flag) {
+template <bool XCH = false>
+__device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepArgs& sm, int c, const RideArgs& ra, const RideArgs& rb,
+                                                const FuseArgs& fz, double* red32, unsigned long long* st80, int* flag) {
   const int l = (c >> 3) & 1;
   const bool commit = (c & 7) == 0;
   if (rb.delay != 0 && c == rb.delay - 1) {  // (tests: this mid leader starts ~100 us late, as behind another kernel's workgroups)
@@ -1261,7 +1266,7 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
   // 1. the state the head step leaves, recomputed; leaders 0 and 8 perform its side effects (progress word, final statistics,
   // the second copy of the state) -- here, ahead of the next step's, and not in the head leaders
   if (sh.kind != STEP_NONE) {
-    step_run(sh, red32, st80, commit);
+    step_run<NoStepHook, XCH>(sh, red32, st80, commit, nullptr, ra.xt, ra.xseq, l);  // (the head step's exchange again: its rows are still in the ring)
   } else {
     const int nq = state_bytes(sm.kind) / 8;
     if ((int)threadIdx.x < nq) st80[threadIdx.x] = reinterpret_cast<const unsigned long long*>(sh.state)[threadIdx.x];
@@ -1280,10 +1285,12 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
     if (threadIdx.x == 0) __hip_atomic_store(fz.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;  // (nothing published: whoever waits for this record runs into its own bound)
   }
-  if (!skip && sm.xt != nullptr) {  // (row-sharded: the sum over the ranks, formed here -- fpsq_krylov.hip.h xch_sum; uniform)
-    double v[2] = {s0, 0.0};
-    xch_sum<2>(sm.xt, sm.xseq, sm.xlane, v, red32);
-    s0 = v[0];
+  if constexpr (XCH) {
+    if (!skip && rb.xt != nullptr) {  // (row-sharded: the sum over the ranks, formed here -- fpsq_krylov.hip.h xch_sum; uniform)
+      double v[2] = {s0, 0.0};
+      xch_sum<2>(rb.xt, rb.xseq, l, v, red32);
+      s0 = v[0];
+    }
   }
   if (threadIdx.x == 0) {
     if (!skip) step_advance(sm, st80, s0, 0.0, commit ? sm.prog : nullptr);
@@ -1461,7 +1468,7 @@ __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, 
   int b = (int)blockIdx.x;
   fuse_stamp(fz, 0);
   if (b < kRideCand) {
-    ride_leader((b >> 3) & 1 ? sh1 : sh0, b, ra, fred, fst, /*may_commit=*/false);
+    ride_leader<HALO>((b >> 3) & 1 ? sh1 : sh0, b, ra, fred, fst, /*may_commit=*/false);  // (HALO = a sharded handle: may exchange)
     fuse_stamp(fz, 3);
     return;
   }
@@ -1483,7 +1490,7 @@ __global__ __launch_bounds__(kBlock) void k_iter_fused(CsrView AT, RgcsView RA, 
     b -= fh.nwg;
   }
   if (b < kRideCand) {
-    fuse_mid_leader((b >> 3) & 1 ? sh1 : sh0, (b >> 3) & 1 ? sm1 : sm0, b, rb, fz, fred, fst, &okf);
+    fuse_mid_leader<HALO>((b >> 3) & 1 ? sh1 : sh0, (b >> 3) & 1 ? sm1 : sm0, b, ra, rb, fz, fred, fst, &okf);
     fuse_stamp(fz, 3);
     return;
   }
