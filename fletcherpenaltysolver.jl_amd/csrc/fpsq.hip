@@ -1941,10 +1941,9 @@ int wait_progress(fpsq_handle h, int lane, int target, const int32_t* dev_done, 
     if ((++spins & 63) == 0) {
       // a bounded wait inside a launch has expired (the handle's error word): nothing later in this call can be right, and the
       // recurrences' progress words will not move any more -- leave the loop now, not at itmax (advisor, round 4)
-      if (*reinterpret_cast<volatile uint64_t*>(h->hscal + 15) != 0) {
-        h->err = "a bounded wait inside a product launch expired while the host was waiting for the device's progress";
-        return FPSQ_ERR_TIMEOUT;
-      }
+      // (stop WAITING, not the call: the end of the call reads the word, switches the handle to two launches per iteration and has
+      // the entry point repeat the call -- ride_failed / with_fuse_fallback; pace_single ends the loop on the same word)
+      if (*reinterpret_cast<volatile uint64_t*>(h->hscal + 15) != 0) return 0;
       hipError_t q = hipStreamQuery(h->stream);
       if (q == hipSuccess) {
         if (reached()) break;
