@@ -110,6 +110,9 @@ struct Comm {
   // Sums over the ranks formed INSIDE the launches that need them (fpsq_krylov.hip.h xch_sum): the device-resident peer table,
   // null when this communicator does not do that (RCCL route; ranks sharing a device).  Known after arm().
   virtual const XchTable* xch_table() const { return nullptr; }
+  // ... and the looks the OTHER workgroups of such a launch get beyond kRidePolls (RideArgs::more / FuseArgs::more): they wait for
+  // leaders that may be waiting for a late peer, so their bound has to outlast the leaders' (4 x: a follower's look is shorter)
+  virtual int wait_more() const { return 0; }
   virtual ~Comm() {}
 };
 
@@ -152,11 +155,17 @@ struct P2PRoute {
   unsigned long long gather_seq = 0, halo_seq = 0;
   long max_spins = 50000000L;           // bound of every in-kernel wait (FPSQ_P2P_POLLS; ~1-2 us per poll)
   bool failed() const { return fail_host && *fail_host != 0; }
+  int wait_more() const {
+    if (const char* ev = std::getenv("FPSQ_DEBUG_WAIT_MORE")) return std::max(0, std::atoi(ev));  // (tests: 0 = the bound of one GPU)
+    return (int)std::min<long>(4 * std::min<long>(max_spins, (long)INT32_MAX / 8), (long)INT32_MAX / 2);
+  }
+  int xch_long_delay_ms = 0;            // FPSQ_DEBUG_XCH_LONG_DELAY_MS (tests; with FPSQ_DEBUG_XCH_DELAY naming the rank)
   int alloc_fail_word(std::string& err) {
     if (const char* ev = std::getenv("FPSQ_P2P_POLLS")) max_spins = std::max(1L, std::atol(ev));
     if (const char* ev = std::getenv("FPSQ_HALO_FUSE")) fuse_halo = std::atoi(ev) != 0;
     if (const char* ev = std::getenv("FPSQ_LX")) lx_want = std::atoi(ev);
     if (const char* ev = std::getenv("FPSQ_DEBUG_XCH_DELAY")) xch_delay_rank = std::atoi(ev);
+    if (const char* ev = std::getenv("FPSQ_DEBUG_XCH_LONG_DELAY_MS")) xch_long_delay_ms = std::max(0, std::min(2000, std::atoi(ev)));
     if (const char* ev = std::getenv("FPSQ_DEBUG_P2P_DELAY")) halo_delay_rank = std::atoi(ev);
     halo_dbg = halo_delay_rank == rank + 1 ? 1 : 0;
     if (hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -175,6 +184,7 @@ struct P2PRoute {
     T.rank = rank;
     T.max_polls = (int32_t)std::min<long>(max_spins, (long)INT32_MAX);
     T.delay_rank = xch_delay_rank;
+    T.long_delay_ticks = (unsigned int)xch_long_delay_ms * 100000u;  // (100 MHz)
     T.fail = fail_dev;
     if (hipMalloc((void**)&xt_dev, sizeof(XchTable)) != hipSuccess ||
         hipMemcpy(xt_dev, &T, sizeof T, hipMemcpyHostToDevice) != hipSuccess) {
@@ -378,6 +388,7 @@ struct IpcComm : RcclComm {
   }
   int route() const override { return rt.armed ? FPSQ_ROUTE_P2P : FPSQ_ROUTE_RCCL; }
   const XchTable* xch_table() const override { return rt.armed ? rt.xt_dev : nullptr; }
+  int wait_more() const override { return rt.armed && rt.xt_dev ? rt.wait_more() : 0; }
   bool failed() override { return rt.failed(); }
   int arm(const Buffers& b, hipStream_t s) override {
     if (want == FPSQ_ROUTE_RCCL) return 0;
@@ -658,6 +669,7 @@ struct P2PLocalComm : LocalComm {
   P2PRoute rt;
   int route() const override { return FPSQ_ROUTE_LOCAL_P2P; }
   const XchTable* xch_table() const override { return rt.armed ? rt.xt_dev : nullptr; }
+  int wait_more() const override { return rt.armed && rt.xt_dev ? rt.wait_more() : 0; }
   int arm(const Buffers& b, hipStream_t) override {
     rt.nranks = nranks;
     rt.rank = rank;
@@ -1732,6 +1744,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
     ra.delay = h->ride_delay;
     ra.xseq = h->ride_xseq;
     ra.xt = h->ride_xseq ? insum_table(h) : nullptr;
+    ra.more = ra.xt ? h->comm->wait_more() : 0;  // (the leaders may be waiting for a late peer: whoever waits for them outlasts that)
   }
   if (tag == TAG_A && h->RA.ok) {
     const int per_xcd = (h->RA.view.ng + 7) / 8;
@@ -2995,7 +3008,11 @@ struct KrylovRun {
     ra.xt = ra.xseq ? insum_table(h) : nullptr;
     rb.xseq = mid_xseq;
     rb.xt = mid_xseq ? insum_table(h) : nullptr;
+    // (leaders that wait for a late peer keep everything behind them waiting: blocks, row groups, the other leader set, updates)
+    const int more = ra.xt || rb.xt ? h->comm->wait_more() : 0;
+    ra.more = rb.more = more;
     FuseArgs fz{};
+    fz.more = more;
     fz.blkflag = h->fz_flag;
     fz.ptag = h->fz_ptag;
     fz.dep = h->fz_dep;
@@ -3773,7 +3790,10 @@ int two_least_squares_device(fpsq_handle h, const double* r1, const double* r2, 
 template <class F>
 int with_fuse_fallback(fpsq_handle h, F&& call) {
   int rc = call();
-  if (rc == FPSQ_ERR_TIMEOUT && h && h->fuse_fell_back) {
+  // (a rank of several cannot repeat a call on its own -- its peers are not repeating theirs: there the expired wait is the call's
+  // result, FPSQ_ERR_TIMEOUT on this rank and, through the peers' own bounded waits, on the others; the job decides what next --
+  // bench.py starts over on the collectives.  Their waits are long for that reason: RideArgs::more.)
+  if (rc == FPSQ_ERR_TIMEOUT && h && h->fuse_fell_back && !(h->comm && h->comm->nranks > 1)) {
     h->fuse_fell_back = false;
     h->info.fuse_fallbacks++;  // (fpsq_info: a benchmark or a test sees that it happened)
     if (h->verbose)

@@ -784,6 +784,8 @@ struct XchTable {
   int32_t max_polls;
   int32_t delay_rank;                   // tests (FPSQ_DEBUG_XCH_DELAY = r + 1): rank r holds every push back by ~100 us
   int* fail;                            // host-mapped: a bounded wait for a peer expired
+  unsigned int long_delay_ticks;        // tests (FPSQ_DEBUG_XCH_LONG_DELAY_MS): instead, that rank holds the pushes of every 128th exchange
+  unsigned int pad_;                    // back by this long (100 MHz ticks) -- a host that was descheduled in the middle of a solve
 };
 __device__ __forceinline__ unsigned long long xch_hi(double v, unsigned int seq) {
   return ((unsigned long long)__double_as_longlong(v) & 0xffffffff00000000ull) | seq;
@@ -815,8 +817,9 @@ __device__ __forceinline__ void xch_sum(const XchTable* xt, unsigned int seq, in
       const bool dead = __hip_atomic_load(xt->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
       if (!dead) {
         if (xt->delay_rank == me + 1) {  // (tests: what a rank that is late with its push does to the others)
+          const unsigned long long ticks = xt->long_delay_ticks == 0 ? 10000ull : (seq & 127u) == 100u ? xt->long_delay_ticks : 0ull;
           const unsigned long long t0 = wall_clock64();
-          while (wall_clock64() - t0 < 10000ull) __builtin_amdgcn_s_sleep(32);
+          while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
         }
         unsigned long long* dst = xt->peer[t] + slot + (size_t)me * kXchWords + woff;
 #pragma unroll

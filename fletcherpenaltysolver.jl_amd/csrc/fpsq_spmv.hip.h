@@ -381,6 +381,8 @@ struct RideArgs {
                             // kernel holding its XCD would do to it; results must not depend on it
   unsigned int xseq;        // row-sharded handles whose sums over the ranks are formed inside the launch (fpsq_krylov.hip.h xch_sum): the
   const XchTable* xt;       // number of THIS leader set's exchange and the peer table (null: one GPU, a communicator of one, other routes)
+  int more;                 // looks granted to the workgroups that wait for the record BEYOND kRidePolls: 0 on one GPU; with leaders that
+                            // themselves wait for the peers' sums (xt != null on some leader set of the call), more than those may take
 };
 struct RideCoef {
   double ca[2], cb[2];
@@ -510,7 +512,7 @@ template <bool CTL, int SLEEP = 4>
 __device__ __forceinline__ bool ride_settle(const RideArgs& ra, unsigned long long* dst, int* got) {
   if (threadIdx.x == 0) *got = 0;
   __syncthreads();
-  for (int t = 0; t < kRidePolls; ++t) {
+  for (int t = 0; t < kRidePolls + ra.more; ++t) {
     if (threadIdx.x < 64) {
       if (t) __builtin_amdgcn_s_sleep(SLEEP);
       const bool ok = CTL ? ride_take_ctl(ra, dst) : ride_take(ra, ride_look(ra), dst);
@@ -568,6 +570,7 @@ struct FuseArgs {
   unsigned int pub;               // what the blocks publish: `want` (anything else only in the test of the bounded waits)
   unsigned long long* err;        // host-mapped: a bounded wait expired
   unsigned long long* dbg;        // developer probe (null in production): four 100 MHz time stamps per workgroup of the launch, see fuse_stamp
+  int more;                       // looks beyond kRidePolls (see RideArgs::more: what a block waits for may be waiting for the peers)
 };
 // workgroup's stamp k (thread 0; tools/fuse_probe.py reads them): 0 = entry, 1 = dependences met (row group) / record taken (update),
 // 2 = tiles done (row group) / partials summed (mid leader), 3 = exit
@@ -996,7 +999,7 @@ __device__ __forceinline__ void rgcs_group(const RgcsView& M, const double* __re
         d2y = t2.y;
       }
       bool all = false;
-      for (int t = 0; t < kRidePolls && !all; ++t) {
+      for (int t = 0; t < kRidePolls + fz.more && !all; ++t) {
         if (t) __builtin_amdgcn_s_sleep(8);
         bool ok = true;
         for (int L = d.x + tid; L <= d.y; L += 64)
@@ -1200,7 +1203,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_rgcs(RgcsView M, const double* 
 // squared-norm partials of lane l of the A' blocks [0, n) from their tagged words, summed like reduce_two sums a plain array
 // (same association per thread, same tree); false: a word did not carry this launch's number after kRidePolls looks
 __device__ __forceinline__ bool reduce_tagged(const unsigned long long* ptag, int n, int l, unsigned int want, double* red,
-                                              int* flag, double& s0, int wpb = 4 /* words per block */) {
+                                              int* flag, double& s0, int wpb = 4 /* words per block */, int more = 0) {
   const int t = threadIdx.x;
   auto part = [&](int i, bool& good) {
     const unsigned long long hi = ride_load(ptag + (size_t)i * wpb + 2 * l), lo = ride_load(ptag + (size_t)i * wpb + 2 * l + 1);
@@ -1208,7 +1211,7 @@ __device__ __forceinline__ bool reduce_tagged(const unsigned long long* ptag, in
     return __longlong_as_double((long long)((hi & 0xffffffff00000000ull) | (lo >> 32)));
   };
   double a = 0.0;
-  for (int look = 0; look < kRidePolls; ++look) {
+  for (int look = 0; look < kRidePolls + more; ++look) {
     bool good = true;
     a = 0.0;
     if (n <= kStepThreads * 24) {  // reduce_two's single batch: a thread adds its entries t, t + 256, ... in that order
@@ -1279,7 +1282,7 @@ __device__ __forceinline__ void fuse_mid_leader(const StepArgs& sh, const StepAr
   const bool skip = reinterpret_cast<const LaneCtl*>(st80)->done != 0;  // (uniform: LDS)
   double s0 = 0.0;
   bool fine = true;
-  if (!skip) fine = reduce_tagged(fz.ptag, sm.n0, l, fz.want, red32, flag, s0);
+  if (!skip) fine = reduce_tagged(fz.ptag, sm.n0, l, fz.want, red32, flag, s0, 4, XCH ? fz.more : 0);
   fuse_stamp(fz, 2);
   if (!fine) {
     if (threadIdx.x == 0) __hip_atomic_store(fz.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1341,7 +1344,7 @@ __device__ __forceinline__ bool fuse_wait_blocks(const FuseArgs& fz, int dx, int
   const int tid = threadIdx.x;
   if (tid < 64) {
     bool all = false;
-    for (int t = 0; t < kRidePolls && !all; ++t) {
+    for (int t = 0; t < kRidePolls + fz.more && !all; ++t) {
       if (t) __builtin_amdgcn_s_sleep(8);
       bool ok = true;
       for (int L = dx + tid; L <= dy; L += 64)

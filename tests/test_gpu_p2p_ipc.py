@@ -76,7 +76,8 @@ def _reference(delta):
 
 @pytest.mark.parametrize("nranks,route", [(2, "p2p"), (3, "p2p"), (2, "auto"), (2, "rccl"), (3, "p2p-two-launch-halo"),
                                           (2, "p2p-in-launch"), (3, "p2p-in-launch"), (3, "p2p-in-launch-late-rank"),
-                                          (2, "p2p-in-launch-fused"), (3, "p2p-in-launch-fused")])
+                                          (2, "p2p-in-launch-fused"), (3, "p2p-in-launch-fused"),
+                                          (2, "p2p-in-launch-fused-hiccup"), (3, "p2p-in-launch-hiccup")])
 @pytest.mark.parametrize("delta", [0.0, SE])
 def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, route, delta):
     """Same iteration counts as the single-GPU handle, vectors to 1e-9 (only the order of the reductions differs), phi
@@ -88,7 +89,9 @@ def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, rou
     launches that need them (fpsq_krylov.hip.h xch_sum) -- what ranks with a device of their own do by default; between
     processes SHARING this box's GPU it has to be forced (FPSQ_LX=2; the grids of this problem are resident all at once);
     "-late-rank": rank 1 holds every one of its pushes back by ~100 us (FPSQ_DEBUG_XCH_DELAY): nothing may depend on when a
-    row arrives."""
+    row arrives.  "-hiccup": rank 1 holds the pushes of every 128th exchange back by 150 ms (FPSQ_DEBUG_XCH_LONG_DELAY_MS) -- a host
+    that was descheduled in the middle of a solve: the leaders of the other ranks wait for it, and so must every workgroup that
+    waits for THEM (RideArgs::more; with one GPU's bound of tens of milliseconds those gave up -- the test below)."""
     qp, want, its_ref, fs_ref = _reference(delta)
     extra = None
     fused = False
@@ -99,6 +102,9 @@ def test_ranks_in_separate_processes_exchange_peer_to_peer(tmp_path, nranks, rou
         extra = {"FPSQ_LX": "2"}
         if route.endswith("late-rank"):
             extra["FPSQ_DEBUG_XCH_DELAY"] = "2"
+        if route.endswith("-hiccup"):
+            extra.update(FPSQ_DEBUG_XCH_DELAY="2", FPSQ_DEBUG_XCH_LONG_DELAY_MS="150")
+            route = route[:-len("-hiccup")]
         if route.endswith("fused"):   # ONE launch per joint iteration, the halo exchange and finish inside (k_iter_fused<.., HALO>)
             extra["FPSQ_FUSE_ITER"] = "2"
         fused = route.endswith("fused")
@@ -134,6 +140,19 @@ def test_a_missing_peer_ends_in_an_error_not_a_hang(tmp_path):
     rcs, outs = _run_ranks(2, "p2p", 0.0, tmp_path, extra_env={"FPSQ_TEST_P2P_DESERT": "1", "FPSQ_P2P_POLLS": "300000"}, timeout=400)
     assert rcs[1] == 0 and rcs[0] != 0
     assert "bounded wait" in outs[0][1] or "did not arrive" in outs[0][1], outs[0][1][-1500:]
+
+
+def test_a_rank_late_by_more_than_one_gpus_bound_fails_without_the_longer_waits(tmp_path):
+    """The control of "-hiccup" above: with the followers' waits cut back to the bound of one GPU (FPSQ_DEBUG_WAIT_MORE=0: 2^15 looks,
+    tens of milliseconds) the workgroups behind leaders that wait 150 ms for rank 1's push give up; the call ends in
+    FPSQ_ERR_TIMEOUT -- on that rank from its own expired wait (which a rank of several does not answer with a repeat of its own),
+    on the late rank, which then waits for a peer that has stopped, from the exchange's bound -- within the test's time limit."""
+    rcs, outs = _run_ranks(2, "p2p", 0.0, tmp_path, timeout=400,
+                           extra_env={"FPSQ_LX": "2", "FPSQ_FUSE_ITER": "2", "FPSQ_DEBUG_XCH_DELAY": "2", "FPSQ_DEBUG_XCH_LONG_DELAY_MS": "150",
+                                      "FPSQ_DEBUG_WAIT_MORE": "0", "FPSQ_P2P_POLLS": "2000000"})
+    assert rcs[0] != 0 and rcs[1] != 0, rcs
+    assert "bounded wait" in outs[0][1], outs[0][1][-1500:]
+    assert "bounded wait" in outs[1][1] or "did not arrive" in outs[1][1], outs[1][1][-1500:]
 
 
 _NINE = r'''

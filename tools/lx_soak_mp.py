@@ -1,0 +1,130 @@
+"""Soak of the round-5 sharded path BETWEEN PROCESSES on one GPU: NRANKS processes (one rank each, as the product runs -- one
+process per GPU -- except that here they share this box's device), peer-to-peer route over hipIpc-mapped buffers, sums over the
+ranks inside the launches (FPSQ_LX=2), one launch per joint iteration with the halo exchange and finish inside (FPSQ_FUSE_ITER=2).
+
+    python tools/lx_soak_mp.py [evaluations=1000] [nranks=3] [delta=0] [n=200000]
+
+Every rank evaluates the same E points; the parent then checks: return codes 0 everywhere, phi BITWISE equal on every rank, the
+iteration counts equal on every rank, the overlap rows' checksums equal on the ranks sharing them, phi within 1e-9 of a single-GPU
+handle on a sample of the points, and the handles' wait counters (fuse_fallbacks, wait_timeouts, p2p_timeouts) all zero.
+Set-up collectives go through the loopback stand-in for librccl (tests/shim; RCCL refuses two ranks on one device)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def problem(n):
+    from fps_amd import problems
+    return problems.pde_control_like(n=n, m=n // 10, per_row=40, window=2048, seed=41)
+
+
+def point(qp, e):
+    rng = np.random.default_rng(1000 + e)
+    return qp.xhat + (0.3 * 0.97 ** (e % 60)) * rng.standard_normal(qp.n)
+
+
+def worker():
+    rank, nranks, d, E, delta, n = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), float(sys.argv[6]), int(sys.argv[7])
+    import torch  # noqa: F401
+    import fps_amd  # noqa: F401
+    from fps_amd.device_qp import DeviceEqQP, rccl_unique_id
+    from fps_amd.distributed import halo_plan, row_partition, shard_qp_halo
+    idf = os.path.join(d, "id.bin")
+    if rank == 0:
+        with open(idf + ".tmp", "wb") as f:
+            f.write(rccl_unique_id())
+        os.rename(idf + ".tmp", idf)
+    t0 = time.time()
+    while not os.path.exists(idf):
+        if time.time() - t0 > 120:
+            sys.exit("no unique id after 120 s")
+        time.sleep(0.01)
+    ident = open(idf, "rb").read()
+    qp = problem(n)
+    plan = halo_plan(qp.rowptr, qp.colind, qp.n, row_partition(qp.rowptr, nranks))
+    loc = shard_qp_halo(qp, plan, rank)
+    dev = DeviceEqQP(loc, sigma=1e3, rho=1.0, delta=delta, comm=("rccl", nranks, rank, ident), halo=plan.overlaps(rank), comm_route="p2p")
+    w = plan.window(rank)
+    tl, tr = plan.overlaps(rank)
+    rec = np.zeros((E, 7))
+    fused = 0
+    gx, ys = np.empty(loc.n), np.empty(loc.m)
+    for e in range(E):
+        x = np.ascontiguousarray(point(qp, e)[w])
+        try:
+            f, rc = dev.objgrad(x, gx=gx, ys=ys)
+        except Exception as exc:
+            i = dev.info()
+            print(f"rank {rank} evaluation {e}: {exc}; counters {(i['fuse_fallbacks'], i['wait_timeouts'], i['p2p_timeouts'])}", flush=True)
+            sys.exit(3)
+        rec[e] = (f, rc, dev.stats[0].niter, dev.stats[1].niter, gx[:tl].sum() if tl else 0.0, gx[loc.n - tr:].sum() if tr else 0.0, ys.sum())
+        fused += dev.info()["last_fused_launches"]
+        if rank == 0 and e % 250 == 249:
+            print(f"{e + 1} evaluations, {time.time() - t0:.0f} s", flush=True)
+    i = dev.info()
+    np.savez(os.path.join(d, f"soak_{rank}.npz"), rec=rec, info=np.array([i["comm_route"], i["comm_in_launch_sums"], i["fuse_fallbacks"],
+                                                                           i["wait_timeouts"], i["p2p_timeouts"], fused]))
+    dev.close()
+
+
+def main():
+    E = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    P = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    delta = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 200_000
+    import tempfile
+    d = tempfile.mkdtemp(prefix="lx_soak_")
+    so = os.path.join(ROOT, "tests", "shim", "libloopback_rccl.so")
+    src = os.path.join(ROOT, "tests", "shim", "loopback_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-Wno-unused-result", "-o", so, src])
+    env = dict(os.environ, FPSQ_RCCL_LIB=so, FPSQ_SHIM_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0", FPSQ_LX="2", FPSQ_FUSE_ITER="2")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), str(P), d, str(E), repr(delta), str(n)], env=env)
+             for r in range(P)]
+    rcs = []
+    try:
+        for p in procs:
+            rcs.append(p.wait(timeout=900))
+    finally:
+        for p in procs:  # (exactly the processes started here)
+            if p.poll() is None:
+                p.kill()
+    if any(rcs):
+        print(f"ranks ended with {rcs}")
+        sys.exit(1)
+    res = [np.load(os.path.join(d, f"soak_{r}.npz")) for r in range(P)]
+    rec = [r["rec"] for r in res]
+    bad = {"rc": int(sum((q[:, 1] != 0).sum() for q in rec)),
+           "phi": int(sum((q[:, 0] != rec[0][:, 0]).sum() for q in rec)),
+           "iters": int(sum((q[:, 2:4] != rec[0][:, 2:4]).any(axis=1).sum() for q in rec)),
+           "overlap": int(sum((rec[r][:, 5] != rec[r + 1][:, 4]).sum() for r in range(P - 1)))}
+    import torch  # noqa: F401
+    import fps_amd  # noqa: F401
+    from fps_amd.device_qp import DeviceEqQP
+    qp = problem(n)
+    ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    off, val = 0, 0
+    sample = list(range(0, E, max(1, E // 100)))
+    for e in sample:
+        f, _ = ref.objgrad(point(qp, e))
+        same = (ref.stats[0].niter, ref.stats[1].niter) == tuple(int(t) for t in rec[0][e, 2:4])
+        off += not same
+        val += abs(f - rec[0][e, 0]) > (1e-9 if same else 1e-6) * abs(f)
+    ref.close()
+    bad["value"] = int(val)
+    infos = [[int(t) for t in r["info"]] for r in res]
+    print(f"{E} evaluations on {P} ranks in {P} processes (n = {n}, delta = {delta}): mismatches {bad}; of {len(sample)} sampled points "
+          f"{off} stopped one iteration apart from the single-GPU handle; per rank (route, in-launch sums, fuse_fallbacks, wait_timeouts, "
+          f"p2p_timeouts, fused launches) {infos}; {time.time() - t0:.0f} s")
+    sys.exit(1 if any(bad.values()) or any(any(i[2:5]) for i in infos) else 0)
+
+
+if __name__ == "__main__":
+    worker() if len(sys.argv) > 1 and sys.argv[1] == "--rank" else main()
