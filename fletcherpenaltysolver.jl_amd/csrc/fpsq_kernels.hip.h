@@ -754,6 +754,10 @@ struct P2PPeers {
   unsigned long long* flag[8];  // peer p's flag words (one per sender)
   int32_t n;
 };
+// Workgroup barrier behind which EVERY wave's stores have been acknowledged.  __syncthreads() is not that: its release fence has
+// workgroup scope, which on this hardware (waves of a workgroup share their CU's L1) waits for no store at all -- a flag that
+// thread 0 raises behind it, however it fences, can overtake the other waves' data (vmcnt is a per-wave counter).
+__device__ __forceinline__ void barrier_stores_done() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ bool p2p_wait(const unsigned long long* f, unsigned long long seq, long max_spins, int* fail) {
   long spins = 0;
   while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_p2p_gather(const double* __restrict_
   }
   double* loc = local + (size_t)p * count;
   p2p_copy(send, P.rx[p] + (size_t)rank * count, 0, count);
-  __syncthreads();  // (every wave's stores are complete)
+  barrier_stores_done();
   if (threadIdx.x == 0) {
     __threadfence_system();
     __hip_atomic_store(P.flag[p] + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(1024) void k_p2p_halo(const double* __restrict__ ra
   } else {
     for (int64_t i = threadIdx.x; i < cnt; i += 1024) dst[i] = src[i];
   }
-  __syncthreads();
+  barrier_stores_done();
   if (threadIdx.x == 0) {
     __threadfence_system();
     __hip_atomic_store(left ? H.left_flag : H.right_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(kBlock) void k_p2p_halo_finish(P2PHalo H, unsigned 
     const double* src = left ? a.raw : a.raw + nl;
     const int64_t per = ((cnt + kHaloCopy - 1) / kHaloCopy + 1) & ~(int64_t)1, lo = sl * per, hi = lo + per < cnt ? lo + per : cnt;
     if (lo < hi) p2p_copy(src, dst, lo, hi);
-    __syncthreads();  // (every wave's stores are complete)
+    barrier_stores_done();
     if (threadIdx.x == 0) {
       __threadfence_system();
       const unsigned long long got = __hip_atomic_fetch_add(arrive + (left ? 0 : 1), 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;

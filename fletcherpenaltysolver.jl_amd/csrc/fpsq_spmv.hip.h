@@ -701,7 +701,11 @@ __device__ __forceinline__ void atl_product(const CsrView& A, const double* __re
     const int rq0 = g < nr ? g : 0;
     const int seg_a0 = A.rowptr[r0 + rq0], seg_b0 = A.rowptr[r0 + rq0 + 1];
     hypre[t][0] = hypre[t][1] = 0.0;
-    if (!MULTI && yin != nullptr) {
+    // (HALO: never an overlap row -- this workgroup does not finish those, a finish workgroup on ANOTHER CU writes them later in
+    // the same launch, and a line this load left in the CU's L1 would be served, stale, to the long-vector update workgroups that
+    // read the finished rows at the end of the launch.  Found by tools/lx_soak_mp.py, round 5: ~1 evaluation in 10^3 with a few
+    // 128-byte lines of the solution's overlap rows one iteration behind.)
+    if (!MULTI && yin != nullptr && !(HALO && (r0 + rq0 < hr.lo || r0 + rq0 >= hr.hi))) {
       const double2 yy = *reinterpret_cast<const double2*>(yin + (size_t)(r0 + rq0) * 2);
       hypre[t][0] = yy.x;
       hypre[t][1] = yy.y;
@@ -1388,7 +1392,7 @@ __device__ __forceinline__ void fuse_halo_wg(int b, const FuseHalo& fh, const Fu
         if (i < hi) dst[i] = v[u];
       }
     }
-    __syncthreads();  // (every wave's stores are complete)
+    barrier_stores_done();
     if (tid == 0) {
       __threadfence_system();
       const unsigned long long got = __hip_atomic_fetch_add(fh.arrive + (left ? 0 : 1), 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;

@@ -155,6 +155,19 @@ def test_a_rank_late_by_more_than_one_gpus_bound_fails_without_the_longer_waits(
     assert "bounded wait" in outs[1][1] or "did not arrive" in outs[1][1], outs[1][1][-1500:]
 
 
+def test_three_ranks_soak_overlap_rows_stay_bitwise():
+    """tools/lx_soak_mp.py, 1500 evaluations on three ranks (three processes) at n = 100000, sums over the ranks inside the launches,
+    one launch per joint iteration with the halo exchange and finish inside: phi and the iteration counts bitwise the same on every
+    rank, the overlap rows of grad(phi) bitwise the same on the two ranks sharing them, no expired wait.  This is the run that found
+    round 5's stale-line bug (an A' workgroup prefetched the old values of overlap rows it does not finish; the line stayed in its
+    CU's L1 and was served to the update workgroups that read the finished rows later in the same launch: one or two evaluations in
+    a thousand came back with a few 128-byte lines of grad(phi) wrong on ONE of the two ranks, everything else in order)."""
+    env = dict(os.environ, FPSQ_P2P_POLLS="3000000")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lx_soak_mp.py"), "1500", "3", "0", "100000"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2500:], r.stderr[-1500:])
+
+
 _NINE = r'''
 import sys
 import numpy as np

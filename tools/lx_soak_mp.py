@@ -7,7 +7,13 @@ ranks inside the launches (FPSQ_LX=2), one launch per joint iteration with the h
 Every rank evaluates the same E points; the parent then checks: return codes 0 everywhere, phi BITWISE equal on every rank, the
 iteration counts equal on every rank, the overlap rows' checksums equal on the ranks sharing them, phi within 1e-9 of a single-GPU
 handle on a sample of the points, and the handles' wait counters (fuse_fallbacks, wait_timeouts, p2p_timeouts) all zero.
-Set-up collectives go through the loopback stand-in for librccl (tests/shim; RCCL refuses two ranks on one device)."""
+Set-up collectives go through the loopback stand-in for librccl (tests/shim; RCCL refuses two ranks on one device).
+LX_SOAK_KEEP=1: the overlap rows of gx / gs of every evaluation are kept, and for an evaluation whose ranks disagree the rows that are
+off the single-GPU handle's are listed per rank.  LX_SOAK_CHUNKS=1: EVERY row of gx of every evaluation against the single-GPU
+handle, 64 rows at a time.  FPSQ_FUSE_ITER=0 in the environment: three launches per iteration.
+(Round 5, three ranks at n = 100000: ~1-2 evaluations in 10^3 came back with a few 128-byte lines of the overlap rows of gx / gs
+wrong on ONE of the two ranks sharing them -- phi, iteration counts and return codes all fine.  Cause: see atl_product's comment on
+the yin prefetch in csrc/fpsq_spmv.hip.h.  profiles/r05_soak.txt has the runs before and after.)"""
 import os
 import subprocess
 import sys
@@ -54,22 +60,35 @@ def worker():
     tl, tr = plan.overlaps(rank)
     rec = np.zeros((E, 7))
     fused = 0
-    gx, ys = np.empty(loc.n), np.empty(loc.m)
+    gx, ys, gs = np.empty(loc.n), np.empty(loc.m), np.empty(loc.n)
+    keep = os.environ.get("LX_SOAK_KEEP") == "1"  # (diagnosis: the overlap rows of gx and gs of every evaluation)
+    ov = np.zeros((E, 2, tl + tr)) if keep else None
+    nch = (loc.n + 63) // 64
+    chunks = np.zeros((E, nch)) if os.environ.get("LX_SOAK_CHUNKS") == "1" else None  # (diagnosis: sums of gx over every 64 rows of the window)
     for e in range(E):
         x = np.ascontiguousarray(point(qp, e)[w])
         try:
-            f, rc = dev.objgrad(x, gx=gx, ys=ys)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys, gs=gs if keep else None)
         except Exception as exc:
             i = dev.info()
             print(f"rank {rank} evaluation {e}: {exc}; counters {(i['fuse_fallbacks'], i['wait_timeouts'], i['p2p_timeouts'])}", flush=True)
             sys.exit(3)
         rec[e] = (f, rc, dev.stats[0].niter, dev.stats[1].niter, gx[:tl].sum() if tl else 0.0, gx[loc.n - tr:].sum() if tr else 0.0, ys.sum())
         fused += dev.info()["last_fused_launches"]
+        if chunks is not None:
+            chunks[e] = np.add.reduceat(gx, np.arange(0, loc.n, 64))
+        if keep:
+            ov[e, 0] = np.concatenate([gx[:tl], gx[loc.n - tr:]])
+            ov[e, 1] = np.concatenate([gs[:tl], gs[loc.n - tr:]])
         if rank == 0 and e % 250 == 249:
             print(f"{e + 1} evaluations, {time.time() - t0:.0f} s", flush=True)
     i = dev.info()
     np.savez(os.path.join(d, f"soak_{rank}.npz"), rec=rec, info=np.array([i["comm_route"], i["comm_in_launch_sums"], i["fuse_fallbacks"],
                                                                            i["wait_timeouts"], i["p2p_timeouts"], fused]))
+    if keep:
+        np.save(os.path.join(d, f"ov_{rank}.npy"), ov)
+    if chunks is not None:
+        np.save(os.path.join(d, f"chunks_{rank}.npy"), chunks)
     dev.close()
 
 
@@ -84,7 +103,7 @@ def main():
     src = os.path.join(ROOT, "tests", "shim", "loopback_rccl.cpp")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-Wno-unused-result", "-o", so, src])
-    env = dict(os.environ, FPSQ_RCCL_LIB=so, FPSQ_SHIM_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0", FPSQ_LX="2", FPSQ_FUSE_ITER="2")
+    env = dict(os.environ, FPSQ_RCCL_LIB=so, FPSQ_SHIM_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0", FPSQ_LX="2", FPSQ_FUSE_ITER=os.environ.get("FPSQ_FUSE_ITER", "2"))
     t0 = time.time()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), str(P), d, str(E), repr(delta), str(n)], env=env)
              for r in range(P)]
@@ -108,8 +127,63 @@ def main():
     import torch  # noqa: F401
     import fps_amd  # noqa: F401
     from fps_amd.device_qp import DeviceEqQP
+    from fps_amd.distributed import halo_plan, row_partition
     qp = problem(n)
     ref = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta)
+    keep = os.environ.get("LX_SOAK_KEEP") == "1"
+    plan = halo_plan(qp.rowptr, qp.colind, qp.n, row_partition(qp.rowptr, P))
+    ovs = [np.load(os.path.join(d, f"ov_{r}.npy")) for r in range(P)] if keep else None
+    for r in range(P - 1):
+        for e in np.nonzero(rec[r][:, 5] != rec[r + 1][:, 4])[0]:
+            print(f"overlap of ranks {r} | {r + 1}, evaluation {e}: checksums {rec[r][e, 5]!r} | {rec[r + 1][e, 4]!r}, iterations {rec[r][e, 2:4]}")
+            if keep:
+                g_ref, gs_ref, ys_ref = np.empty(qp.n), np.empty(qp.n), np.empty(qp.m)
+                xe = point(qp, e)
+                ref.objgrad(xe, gx=g_ref, gs=gs_ref, ys=ys_ref)
+                A = qp.scipy_csr()
+                bounds = row_partition(qp.rowptr, P)
+                grad = qp.qdiag * xe + qp.d
+                for q in (r, r + 1):
+                    w = plan.window(q)
+                    tl, tr = plan.overlaps(q)
+                    for nm, k, full in (("gx", 0, g_ref), ("gs", 1, gs_ref)):
+                        want = np.concatenate([full[w][:tl], full[w][full[w].size - tr:]])
+                        dlt = np.abs(ovs[q][e, k] - want)
+                        wrong = np.nonzero(dlt > 1e-8 * np.max(np.abs(want)))[0]
+                        print(f"   rank {q} {nm}: overlap rows (head {tl}, tail {tr}) off the single-GPU handle's: {wrong.size}"
+                              + (f", indices {wrong[:6]} .. {wrong[-3:]}, largest {dlt.max():.3e} (scale {np.max(np.abs(want)):.3e})" if wrong.size else ""))
+                        if wrong.size and nm == "gs":
+                            print(f"      lines of 8 rows: {sorted(set((wrong // 8).tolist()))}")
+                        if wrong.size and nm == "gs":  # gs = grad f - A' ys: what was added up in the rows that are off?
+                            cols = np.concatenate([np.arange(w.start, w.start + tl), np.arange(w.stop - tr, w.stop)])
+                            own = (A[bounds[q]:bounds[q + 1]].T @ ys_ref[bounds[q]:bounds[q + 1]])[cols]
+                            tot = (A.T @ ys_ref)[cols]
+                            used = grad[cols] - ovs[q][e, 1]
+                            if e > 0:   # the previous evaluation's rows?
+                                gs_prev = np.empty(qp.n)
+                                ref.objgrad(point(qp, e - 1), gs=gs_prev)
+                                same_prev = np.abs(ovs[q][e, 1][wrong] - gs_prev[cols][wrong]) <= 1e-9 * np.max(np.abs(gs_prev))
+                                print(f"      of the {wrong.size} rows, {int(same_prev.sum())} carry the PREVIOUS evaluation's gs")
+                            for i in wrong[:4]:
+                                print(f"      row {i}: A'ys used {used[i]:.6e}, true {tot[i]:.6e}; this rank's part {own[i]:.6e}, the neighbour's {tot[i] - own[i]:.6e}; "
+                                      f"used - own = {used[i] - own[i]:.6e}")
+    if os.environ.get("LX_SOAK_CHUNKS") == "1":  # every evaluation against the single-GPU handle, 64 rows at a time
+        ch = [np.load(os.path.join(d, f"chunks_{r}.npy")) for r in range(P)]
+        g_ref = np.empty(qp.n)
+        nbad = 0
+        for e in range(E):
+            ref.objgrad(point(qp, e), gx=g_ref)
+            scale = np.max(np.abs(g_ref))
+            for r in range(P):
+                w = plan.window(r)
+                want = np.add.reduceat(g_ref[w], np.arange(0, w.stop - w.start, 64))
+                wrong = np.nonzero(np.abs(ch[r][e] - want) > 1e-7 * scale)[0]
+                if wrong.size:
+                    nbad += 1
+                    tl, tr = plan.overlaps(r)
+                    print(f"evaluation {e} rank {r} (window of {w.stop - w.start} rows, head {tl}, tail {tr}): chunks of 64 rows off: {wrong.size}: {wrong[:12]}"
+                          f"{' ..' if wrong.size > 12 else ''}; largest {np.max(np.abs(ch[r][e] - want)):.3e} (scale {scale:.3e})")
+        print(f"(evaluation, rank) pairs with rows of gx off the single-GPU handle's: {nbad}")
     off, val = 0, 0
     sample = list(range(0, E, max(1, E // 100)))
     for e in sample:
