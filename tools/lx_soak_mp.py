@@ -1,6 +1,7 @@
 """Soak of the round-5 sharded path BETWEEN PROCESSES on one GPU: NRANKS processes (one rank each, as the product runs -- one
 process per GPU -- except that here they share this box's device), peer-to-peer route over hipIpc-mapped buffers, sums over the
-ranks inside the launches (FPSQ_LX=2), one launch per joint iteration with the halo exchange and finish inside (FPSQ_FUSE_ITER=2).
+ranks inside the launches (FPSQ_LX=2; FPSQ_LX=0 in the environment: round 4's gather kernels, what ranks sharing a device run by
+default), one launch per joint iteration with the halo exchange and finish inside (FPSQ_FUSE_ITER=2; 0: three launches).
 
     python tools/lx_soak_mp.py [evaluations=1000] [nranks=3] [delta=0] [n=200000]
 
@@ -58,7 +59,8 @@ def worker():
     dev = DeviceEqQP(loc, sigma=1e3, rho=1.0, delta=delta, comm=("rccl", nranks, rank, ident), halo=plan.overlaps(rank), comm_route="p2p")
     w = plan.window(rank)
     tl, tr = plan.overlaps(rank)
-    rec = np.zeros((E, 7))
+    rec = np.zeros((E, 9))
+    hv = np.empty(loc.n)
     fused = 0
     gx, ys, gs = np.empty(loc.n), np.empty(loc.m), np.empty(loc.n)
     keep = os.environ.get("LX_SOAK_KEEP") == "1"  # (diagnosis: the overlap rows of gx and gs of every evaluation)
@@ -73,7 +75,10 @@ def worker():
             i = dev.info()
             print(f"rank {rank} evaluation {e}: {exc}; counters {(i['fuse_fallbacks'], i['wait_timeouts'], i['p2p_timeouts'])}", flush=True)
             sys.exit(3)
-        rec[e] = (f, rc, dev.stats[0].niter, dev.stats[1].niter, gx[:tl].sum() if tl else 0.0, gx[loc.n - tr:].sum() if tr else 0.0, ys.sum())
+        rec[e, :7] = (f, rc, dev.stats[0].niter, dev.stats[1].niter, gx[:tl].sum() if tl else 0.0, gx[loc.n - tr:].sum() if tr else 0.0, ys.sum())
+        if e % 10 == 9:  # an hprod! Val(2) too: the checksums of its overlap rows
+            dev.hprod(np.ascontiguousarray(point(qp, e + 7)[w] - qp.xhat[w]), hv, 2)
+            rec[e, 7:] = (hv[:tl].sum() if tl else 0.0, hv[loc.n - tr:].sum() if tr else 0.0)
         fused += dev.info()["last_fused_launches"]
         if chunks is not None:
             chunks[e] = np.add.reduceat(gx, np.arange(0, loc.n, 64))
@@ -103,7 +108,7 @@ def main():
     src = os.path.join(ROOT, "tests", "shim", "loopback_rccl.cpp")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-Wno-unused-result", "-o", so, src])
-    env = dict(os.environ, FPSQ_RCCL_LIB=so, FPSQ_SHIM_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0", FPSQ_LX="2", FPSQ_FUSE_ITER=os.environ.get("FPSQ_FUSE_ITER", "2"))
+    env = dict(os.environ, FPSQ_RCCL_LIB=so, FPSQ_SHIM_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0", FPSQ_LX=os.environ.get("FPSQ_LX", "2"), FPSQ_FUSE_ITER=os.environ.get("FPSQ_FUSE_ITER", "2"))
     t0 = time.time()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), str(P), d, str(E), repr(delta), str(n)], env=env)
              for r in range(P)]
@@ -123,7 +128,8 @@ def main():
     bad = {"rc": int(sum((q[:, 1] != 0).sum() for q in rec)),
            "phi": int(sum((q[:, 0] != rec[0][:, 0]).sum() for q in rec)),
            "iters": int(sum((q[:, 2:4] != rec[0][:, 2:4]).any(axis=1).sum() for q in rec)),
-           "overlap": int(sum((rec[r][:, 5] != rec[r + 1][:, 4]).sum() for r in range(P - 1)))}
+           "overlap": int(sum((rec[r][:, 5] != rec[r + 1][:, 4]).sum() for r in range(P - 1))),
+           "overlap_hprod": int(sum((rec[r][:, 8] != rec[r + 1][:, 7]).sum() for r in range(P - 1)))}
     import torch  # noqa: F401
     import fps_amd  # noqa: F401
     from fps_amd.device_qp import DeviceEqQP
