@@ -155,8 +155,9 @@ struct P2PRoute {
   unsigned long long gather_seq = 0, halo_seq = 0;
   long max_spins = 50000000L;           // bound of every in-kernel wait (FPSQ_P2P_POLLS; ~1-2 us per poll)
   bool failed() const { return fail_host && *fail_host != 0; }
+  int wait_more_dbg = -1;               // FPSQ_DEBUG_WAIT_MORE (tests: 0 = the bound of one GPU)
   int wait_more() const {
-    if (const char* ev = std::getenv("FPSQ_DEBUG_WAIT_MORE")) return std::max(0, std::atoi(ev));  // (tests: 0 = the bound of one GPU)
+    if (wait_more_dbg >= 0) return wait_more_dbg;
     return (int)std::min<long>(4 * std::min<long>(max_spins, (long)INT32_MAX / 8), (long)INT32_MAX / 2);
   }
   int xch_long_delay_ms = 0;            // FPSQ_DEBUG_XCH_LONG_DELAY_MS (tests; with FPSQ_DEBUG_XCH_DELAY naming the rank)
@@ -166,6 +167,7 @@ struct P2PRoute {
     if (const char* ev = std::getenv("FPSQ_LX")) lx_want = std::atoi(ev);
     if (const char* ev = std::getenv("FPSQ_DEBUG_XCH_DELAY")) xch_delay_rank = std::atoi(ev);
     if (const char* ev = std::getenv("FPSQ_DEBUG_XCH_LONG_DELAY_MS")) xch_long_delay_ms = std::max(0, std::min(2000, std::atoi(ev)));
+    if (const char* ev = std::getenv("FPSQ_DEBUG_WAIT_MORE")) wait_more_dbg = std::max(0, std::atoi(ev));
     if (const char* ev = std::getenv("FPSQ_DEBUG_P2P_DELAY")) halo_delay_rank = std::atoi(ev);
     halo_dbg = halo_delay_rank == rank + 1 ? 1 : 0;
     if (hipHostMalloc((void**)&fail_host, 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
