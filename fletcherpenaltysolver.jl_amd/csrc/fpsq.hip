@@ -841,6 +841,8 @@ struct fpsq_solver_s {
   int64_t fused_launches = 0, fused_total = 0;
   // developer probe (FPSQ_FUSE_PROBE=<file>, FPSQ_FUSE_PROBE_AT=<n-th fused launch of the handle>): per-workgroup time stamps of one launch
   int64_t fuse_probe_at = 0;
+  bool fuse_tail = true;               // FPSQ_FUSE_TAIL=0: the raw A'[q1, c] product and k_qp_penalty_grad as two launches (one GPU; bitwise the same)
+  const GradEpi* tail_grad = nullptr;  // set around the tail's product launch: launch_spmv then picks k_spmv<.., GRAD>
   unsigned long long* fuse_probe_buf = nullptr;
   int fuse_probe_grid = 0;
   std::vector<int> fuse_probe_layout;
@@ -1768,10 +1770,13 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
-    const dim3 grid(per_xcd * 8 + nupd);
+    bool grad = false;  // the tail of an evaluation on one GPU: the raw product's rows go straight into grad(phi)
+    if constexpr (NL == 2) grad = h->tail_grad != nullptr && tag == TAG_AT && !lead && !halo_rows && M.sorted && nupd == 0;
+    const GradEpi ge = grad ? *h->tail_grad : GradEpi{};
+    const dim3 grid(per_xcd * 8 + nupd + (grad && ge.fx.out != nullptr ? 1 : 0));
     const int ps = tag == TAG_A ? h->strA : h->strT;
 #define FPSQ_LAUNCH_SPMV(...) \
-    launch_product(h, k_spmv<__VA_ARGS__>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1, ps, hr)
+    launch_product(h, k_spmv<__VA_ARGS__>, grid, M.view(), x, yin, yout, c0, c1, partials, per_xcd, u0, u1, h->gate0, h->gate1, ps, hr, ge)
     bool done_pre = false;
     if constexpr (NL == 2) {
       if (lead) {  // (tag == TAG_AT: padded blocks with block-relative columns)
@@ -1807,6 +1812,8 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
       else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, false, true);
       else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true, true);
       else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, false, true);
+    } else if (grad) {
+      if constexpr (NL == 2) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true, true);
     } else if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, false, true);
     else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true);
     else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true);
@@ -3900,6 +3907,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     h->fuse_probe_at = 100;
     if (const char* at = std::getenv("FPSQ_FUSE_PROBE_AT")) h->fuse_probe_at = std::atoll(at);
   }
+  if (const char* ev = std::getenv("FPSQ_FUSE_TAIL")) h->fuse_tail = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY")) h->ride_delay = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_JAC_REFRESH")) h->refresh_3pass = std::atoi(ev) == 3;
@@ -4524,14 +4532,35 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
         hipLaunchKernelGGL(k_qp_fx, dim3(1), dim3(kBlock), 0, s, fa, h->gate0, h->gate1);
         h->launches++;
       }
-      launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), h->halo);
-      if (h->halo)
-        if (int rc = halo_finish<2>(h, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr)) return rc;
       const bool grad_fx = in_launch && !early_fx;
-      hipLaunchKernelGGL(k_qp_penalty_grad, dim3(grad_fx ? gn + 1 : gn), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
-                         h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, grad_fx ? fa : none,
-                         h->gate0, h->gate1);
-      h->launches++;
+      // one GPU: the rows of the raw product go straight into grad(phi) -- one launch, and the 16 MB product is neither written nor
+      // re-read (k_spmv<.., GRAD>; bitwise the two launches below, FPSQ_FUSE_TAIL=0)
+      const bool one_launch = h->fuse_tail && !h->comm && !h->halo && h->AT.sorted && h->AT.padded;
+      if (one_launch) {
+        GradEpi ge{};
+        ge.g = h->g;
+        ge.v = h->Cx;
+        ge.q = qp->q;
+        ge.x = dx;
+        ge.xk = dxk;
+        ge.sigma = sigma;
+        ge.rho = rho;
+        ge.eta = eta;
+        ge.gs = h->gs;
+        ge.gx = dgx;
+        ge.fx = grad_fx ? fa : none;
+        h->tail_grad = &ge;
+        launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), false);
+        h->tail_grad = nullptr;
+      } else {
+        launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), h->halo);
+        if (h->halo)
+          if (int rc = halo_finish<2>(h, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr)) return rc;
+        hipLaunchKernelGGL(k_qp_penalty_grad, dim3(grad_fx ? gn + 1 : gn), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
+                           h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, grad_fx ? fa : none,
+                           h->gate0, h->gate1);
+        h->launches++;
+      }
     } else {
       if (rho > 0.0)
         if (int rc = at_product_const(h, 1.0, h->c, 0.0, nullptr, h->jc)) return rc;  // J'c   (:424-428)

@@ -1102,6 +1102,27 @@ __device__ __forceinline__ void qp_fx(const FxArgs& a, double* red /* kFxRed */)
   qp_fx_core(a.pf, a.pdx, a.pcy, a.pcc, a.np_n, a.np_m, a.rho, a.eta, a.out, a.seq, red, a.stride, a.xt, a.xseq);
 }
 
+// One row of grad(phi) (src/model-Fletcherpenaltynlp.jl:403-437 on the eq-QP model), from row i of the raw two-right-hand-side product
+// pj = {(A'q1)_i, (A'c)_i}:   gs = (g - A'q1) + sigma v,   gx = gs - q v + sigma v (+ rho A'c) (+ eta (x - xk)).
+// ONE spelling of the arithmetic (explicit fused multiply-adds) for the two kernels that compute it -- k_qp_penalty_grad and the row
+// epilogue of the raw A' product (k_spmv<.., GRAD>) -- so that the two tails agree bit for bit whatever the compiler would contract.
+__device__ __forceinline__ void qp_grad_row(double gi, double lp0, double lp1, double vi, double qi, double sigma, double rho, double eta,
+                                            const double* x, const double* xk, int64_t i, double& gs, double& gx) {
+  const double p1i = gi - lp0;
+  gs = fma(sigma, vi, p1i);
+  double gg = fma(sigma, vi, fma(-qi, vi, gs));
+  if (rho > 0.0) gg = fma(lp1, rho, gg);
+  if (eta > 0.0) gg = fma(eta, x[i] - xk[i], gg);
+  gx = gg;
+}
+// what the raw A' product needs to write grad(phi) instead of its own rows (k_spmv<.., GRAD>: the tail of an evaluation on one GPU)
+struct GradEpi {
+  const double *g, *v, *q, *x, *xk;
+  double sigma, rho, eta;
+  double *gs, *gx;
+  FxArgs fx;  // fx.out != null: the LAST workgroup of the grid reduces the evaluation's partial sums to phi (as k_qp_penalty_grad's does)
+};
+
 // QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2.
 // pj != null: p1 and Jc come from ONE two-right-hand-side raw product pj[i] = {(A'q1)_i, (A'c)_i}: p1 = g - pj[.][0].
 // The last workgroup of the grid does no streaming: it reduces the evaluation's partial sums to phi (fx.out != null),
@@ -1125,20 +1146,20 @@ __global__ __launch_bounds__(kBlock) void k_qp_penalty_grad(const double* __rest
   }
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)nb * kBlock) {
     const double vi = v[i];
-    double p1i, jci = 0.0;
+    double gi, lp0, jci = 0.0;
     if (pj) {
       const double2 t = *reinterpret_cast<const double2*>(pj + 2 * i);
-      p1i = g[i] - t.x;
+      gi = g[i];
+      lp0 = t.x;
       jci = t.y;
-    } else {
-      p1i = p1[i];
+    } else {  // (p1 = g - A'q1 was formed by the caller: the same subtraction with a zero)
+      gi = p1[i];
+      lp0 = 0.0;
       if (rho > 0.0) jci = jc[i];
     }
-    const double gsi = p1i + sigma * vi;
+    double gsi, gg;
+    qp_grad_row(gi, lp0, jci, vi, q[i], sigma, rho, eta, x, xk, i, gsi, gg);
     gs[i] = gsi;
-    double gg = gsi - q[i] * vi + sigma * vi;
-    if (rho > 0.0) gg += jci * rho;
-    if (eta > 0.0) gg += eta * (x[i] - xk[i]);
     gx[i] = gg;
   }
 }

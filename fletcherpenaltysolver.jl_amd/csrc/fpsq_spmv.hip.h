@@ -166,12 +166,17 @@ __device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, 
 // builds at the headline size: one address for all lanes 31 -> 20 us, the sorted order's addresses 31 -> 22 us).  In column
 // order 64 consecutive entries read ~4 lines; the products are scattered to their row-major LDS slots and phase 2 is
 // unchanged -- same values summed in the same order: BITWISE the row-order layout.
-template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool CSORT = false>
+// GRAD (the tail of an evaluation on one GPU: NL = 2, the raw product A'[q1, c], round 5): the rows are not written -- each goes
+// straight into the gradient row it is needed for (qp_grad_row: gs and gx), which saves writing and re-reading the 16 MB product and
+// the launch of k_qp_penalty_grad; the last workgroup of the grid reduces phi like that kernel's did.  Bitwise the two-kernel tail
+// (FPSQ_FUSE_TAIL=0).
+template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool CSORT = false, bool GRAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
                                                  double* yout, const LaneCtl* ctl0, const LaneCtl* ctl1,
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
                                                  const LaneCtl* gate0, const LaneCtl* gate1, int pstride,
-                                                 const HaloRows hr) {
+                                                 const HaloRows hr, const GradEpi ge) {
+  static_assert(!GRAD || (NL == 2 && TAG == 1 && !HALO), "the gradient epilogue: the raw two-lane A' product of one GPU");
   // exactly 32 KB of LDS for two right-hand sides (FOUR workgroups per CU -- measured, tools/stream_probe.hip: 30 KB would
   // admit five, 24 KB six; tiles of 1536 entries were slower all the same): the reduction scratch
   // aliases the head of the product buffer
@@ -180,6 +185,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   // speculatively enqueued epilogue product: runs only once both recurrences of the call have ended
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   static_assert(!CSORT || (IDX16 && PAD && TAG == 1), "column-sorted blocks: padded A' with block-relative columns only");
+  if constexpr (GRAD) {
+    if (ge.fx.out != nullptr && blockIdx.x == gridDim.x - 1) {  // (everything phi sums was complete before this launch)
+      qp_fx(ge.fx, red);
+      return;
+    }
+  }
   if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   // A (TAG 0): XCD-contiguous eighths, so an XCD's L2 holds one slice of the long gathered vector.  A' (TAG 1): the gathered
   // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
@@ -273,6 +284,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
         ypre[0] = yin[r0 + rq0];
       }
     }
+    [[maybe_unused]] double gpre[3] = {0.0, 0.0, 0.0};  // GRAD: g, v, q of the first row pass, requested here like yin
+    if constexpr (GRAD) {
+      gpre[0] = ge.g[r0 + rq0];
+      gpre[1] = ge.v[r0 + rq0];
+      gpre[2] = ge.q[r0 + rq0];
+    }
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
     [[maybe_unused]] int slot[kPer];  // CSORT: where the entry's product goes (its position in the block's row-major order)
@@ -340,6 +357,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 #pragma unroll
           for (int l = 0; l < NL; ++l)
             if (act[l]) dst[l] = acc[l];
+        } else if constexpr (GRAD) {
+          const double gi = base == 0 ? gpre[0] : ge.g[row], vi = base == 0 ? gpre[1] : ge.v[row], qi = base == 0 ? gpre[2] : ge.q[row];
+          double gsi, gg;
+          qp_grad_row(gi, acc[0], acc[NL - 1], vi, qi, ge.sigma, ge.rho, ge.eta, ge.x, ge.xk, row, gsi, gg);
+          ge.gs[row] = gsi;
+          ge.gx[row] = gg;
         } else {
           row_epilogue<NL>((size_t)row, acc, ca, cb, act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
         }

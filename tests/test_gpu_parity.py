@@ -1358,6 +1358,43 @@ def test_several_iterations_per_launch_are_bitwise_one_iteration_per_launch(monk
         assert np.array_equal(a_, b_), i
 
 
+@pytest.mark.parametrize("size,delta,eta", [((24000, 2400), 0.0, 2.0), ((60000, 6000), SE, 0.0),
+                                            ((300000, 30000, "headline density"), 0.0, 0.0), ((300000, 30000, "headline density"), SE, 0.5)])
+def test_one_launch_tail_is_bitwise_the_two_launch_tail(monkeypatch, size, delta, eta):
+    """The tail of an evaluation on one GPU (round 5): the rows of the raw product A'[q1, c] go straight into grad(phi) -- k_spmv<.., GRAD>,
+    csrc/fpsq_spmv.hip.h; its last workgroup reduces phi -- instead of being written, re-read and combined by k_qp_penalty_grad
+    (FPSQ_FUSE_TAIL=0: those two launches).  One spelling of the row's arithmetic serves both (qp_grad_row): phi, gx, gs, ys, the
+    statistics and an hprod! behind the evaluation BITWISE the same, with and without the proximal term, one launch fewer per
+    evaluation; speculative (gated) tails included -- the points change so that the expected iteration count is wrong now and then."""
+    qp = _small_pde(seed=23, n=size[0], m=size[1]) if len(size) == 2 else problems.pde_control_like(n=size[0], m=size[1], seed=35)
+    rng = np.random.default_rng(13)
+    xs = [qp.xhat + 0.5 ** (k % 5) * (1.0 if k % 3 else 1e-2) * rng.standard_normal(qp.n) for k in range(8)]
+    xks = [qp.xhat + 0.1 * rng.standard_normal(qp.n) for _ in xs]
+    vs = [rng.standard_normal(qp.n) for _ in xs]
+
+    def run():
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=delta, eta=eta)
+        out, launches = [], []
+        for k, x in enumerate(xs):
+            gx, ys, gs, hv = np.empty(qp.n), np.empty(qp.m), np.empty(qp.n), np.empty(qp.n)
+            f, rc = dev.objgrad(x, gx=gx, ys=ys, gs=gs, xk=xks[k] if eta > 0 else None)
+            launches.append(dev.info()["last_kernel_launches"])
+            st = [(dev.stats[q].niter, dev.stats[q].status, dev.stats[q].rnorm, dev.stats[q].arnorm) for q in range(2)]
+            rch = dev.hprod(vs[k], hv, 2) if k % 2 else 0
+            out += [np.array([f, rc, rch]), gx, ys, gs, hv if k % 2 else np.zeros(1), np.array(st).ravel()]
+        dev.close()
+        return out, launches
+
+    monkeypatch.setenv("FPSQ_FUSE_TAIL", "0")
+    want, l2 = run()
+    monkeypatch.setenv("FPSQ_FUSE_TAIL", "1")
+    got, l1 = run()
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+    # (one launch fewer per ENQUEUED tail: a speculative tail whose gates stay closed is enqueued again behind the loop)
+    assert all(a <= b for a, b in zip(l1, l2)) and all(a < b for a, b in zip(l1[1:], l2[1:])) and l1[-1] + 1 == l2[-1], (l1, l2)
+
+
 @pytest.mark.parametrize("late", [0, 8, 3, 13])
 def test_one_launch_iterations_with_a_late_mid_leader(monkeypatch, late):
     """The mid leaders of a fused launch publish per XCC, so the row groups of the other XCCs do not wait for a mid leader that
