@@ -4535,7 +4535,9 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
       const bool grad_fx = in_launch && !early_fx;
       // one GPU: the rows of the raw product go straight into grad(phi) -- one launch, and the 16 MB product is neither written nor
       // re-read (k_spmv<.., GRAD>; bitwise the two launches below, FPSQ_FUSE_TAIL=0)
-      const bool one_launch = h->fuse_tail && !h->comm && !h->halo && h->AT.sorted && h->AT.padded;
+      // (a communicator of ONE rank has no overlap rows and no peers: the single-GPU tail)
+      const bool alone = !h->comm || (h->comm->nranks == 1 && in_launch && h->ovl + h->ovr == 0);
+      const bool one_launch = h->fuse_tail && alone && h->AT.sorted && h->AT.padded;
       if (one_launch) {
         GradEpi ge{};
         ge.g = h->g;

@@ -1392,7 +1392,8 @@ def test_one_launch_tail_is_bitwise_the_two_launch_tail(monkeypatch, size, delta
     for i, (a_, b_) in enumerate(zip(got, want)):
         assert np.array_equal(a_, b_), i
     # (one launch fewer per ENQUEUED tail: a speculative tail whose gates stay closed is enqueued again behind the loop)
-    assert all(a <= b for a, b in zip(l1, l2)) and all(a < b for a, b in zip(l1[1:], l2[1:])) and l1[-1] + 1 == l2[-1], (l1, l2)
+    # (the first call has no expected count: how many look-ahead launches it enqueues depends on timing)
+    assert all(a < b for a, b in zip(l1[1:], l2[1:])) and l1[-1] + 1 == l2[-1], (l1, l2)
 
 
 @pytest.mark.parametrize("late", [0, 8, 3, 13])
