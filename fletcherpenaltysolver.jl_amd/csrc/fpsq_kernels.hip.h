@@ -1120,7 +1120,7 @@ struct GradEpi {
   const double *g, *v, *q, *x, *xk;
   double sigma, rho, eta;
   double *gs, *gx;
-  FxArgs fx;  // fx.out != null: the LAST workgroup of the grid reduces the evaluation's partial sums to phi (as k_qp_penalty_grad's does)
+  FxArgs fx;  // fx.out != null: workgroup 0 of the grid reduces the evaluation's partial sums to phi (k_qp_penalty_grad's last one does)
 };
 
 // QP penalty gradient, one pass:  gs = p1 + sigma v;  gx = gs - q.*v + sigma v (+ rho Jc) (+ eta (x - xk)),  v = p2.

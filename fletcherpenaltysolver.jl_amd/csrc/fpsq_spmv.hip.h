@@ -168,7 +168,7 @@ __device__ __forceinline__ void csort_fetch(const CsrView& A, int L, int cbase, 
 // unchanged -- same values summed in the same order: BITWISE the row-order layout.
 // GRAD (the tail of an evaluation on one GPU: NL = 2, the raw product A'[q1, c], round 5): the rows are not written -- each goes
 // straight into the gradient row it is needed for (qp_grad_row: gs and gx), which saves writing and re-reading the 16 MB product and
-// the launch of k_qp_penalty_grad; the last workgroup of the grid reduces phi like that kernel's did.  Bitwise the two-kernel tail
+// the launch of k_qp_penalty_grad; the FIRST workgroup of the grid reduces phi (that kernel's last one did).  Bitwise the two-kernel tail
 // (FPSQ_FUSE_TAIL=0).
 template <int NL, int TAG, bool IDX16 = false, bool PAD = false, bool HALO = false, bool CSORT = false, bool GRAD = false>
 __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __restrict__ x, const double* yin,
@@ -185,16 +185,22 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
   // speculatively enqueued epilogue product: runs only once both recurrences of the call have ended
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   static_assert(!CSORT || (IDX16 && PAD && TAG == 1), "column-sorted blocks: padded A' with block-relative columns only");
+  // GRAD: workgroup 0 reduces phi -- everything it sums was complete before this launch, so the scalar is on the host while the
+  // product is still streaming (stream-ordered outputs: the caller's next call is enqueued behind it meanwhile) -- and the row
+  // blocks follow from workgroup 1 on; no updates ride in this launch (the host checks).
+  int shift = 0;
   if constexpr (GRAD) {
-    if (ge.fx.out != nullptr && blockIdx.x == gridDim.x - 1) {  // (everything phi sums was complete before this launch)
+    shift = ge.fx.out != nullptr ? 1 : 0;
+    if (shift && blockIdx.x == 0) {
       qp_fx(ge.fx, red);
       return;
     }
+  } else {
+    if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   }
-  if (run_fused_updates<NL>(u0, u1, 8 * blk_per_xcd, red)) return;
   // A (TAG 0): XCD-contiguous eighths, so an XCD's L2 holds one slice of the long gathered vector.  A' (TAG 1): the gathered
   // vector is short (L2-resident everywhere) and the identity map keeps all XCDs streaming adjacent addresses: ~1 us faster.
-  const int L = TAG == 1 ? (int)blockIdx.x : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
+  const int L = TAG == 1 ? (int)blockIdx.x - shift : (int)((blockIdx.x & 7) * blk_per_xcd + (blockIdx.x >> 3));
   if (L >= A.nblk) return;
   // shared values (kernel-uniform): the block's head through the scalar cache, value loads issued first (cshared_head)
   bool shared = false;
