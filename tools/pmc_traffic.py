@@ -68,7 +68,7 @@ else:
     # epilogue products the plain ones: one kernel family per matrix)
     family = {"k_spmv_rgcs<2": ("k_spmv_rgcs<2",), "k_spmv<2, 1": ("k_spmv<2, 1", "k_spmv_atl<")}
 try:
-    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    head = os.environ.get("FPSQ_GIT_HEAD") or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
 except OSError:
     head = None
 out = {"_how": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "workload": WORKLOAD,

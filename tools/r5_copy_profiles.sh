@@ -12,7 +12,7 @@ cp $O/pw/w_counter_collection.csv profiles/r05_pmc_write_counter_collection.csv
 python - <<'PY'
 import json, subprocess
 d = json.load(open('gpurun_out/r5prof/pmc_traffic.json'))
-d['git_head_when_post_processed'] = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD']).decode().strip()
+d["git_head_when_post_processed"] = d.get("git_head_when_post_processed") or subprocess.check_output(["git", "rev-parse", "--short", "HEAD"]).decode().strip()
 json.dump(d, open('profiles/r05_pmc_traffic.json', 'w'), indent=1)
 print('traffic profile: kernel sources', d['kernel_sources_sha16'], 'git', d['git_head_when_post_processed'])
 import glob, os

@@ -4,6 +4,12 @@ export TMPDIR=/tmp
 O=gpurun_out/r5prof
 mkdir -p $O
 B="timeout -k 10 200 python bench.py"
+# the traffic passes FIRST: the bench lines below then find a profile of THESE kernel sources (bench.py refuses any other) -- the
+# box has no .git, so the caller passes the commit: FPSQ_GIT_HEAD=$(git rev-parse --short HEAD) in front of the gpurun command
+rm -rf $O/pf; timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -o f -- python3 bench.py --steps 2 --warmup 1 --cpu-evals 0 --repeats 1 --no-roofline-pass > $O/pf.log 2>&1; echo "pmc fetch rc=$?"
+rm -rf $O/pw; timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -o w -- python3 bench.py --steps 2 --warmup 1 --cpu-evals 0 --repeats 1 --no-roofline-pass > $O/pw.log 2>&1; echo "pmc write rc=$?"
+python3 tools/pmc_traffic.py $O/pf/f_counter_collection.csv $O/pw/w_counter_collection.csv 15 > $O/pmc_traffic.json 2> $O/pmc_traffic.err; echo "pmc post rc=$?"
+cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json
 $B > $O/bench_headline.json 2> $O/err.log; echo "headline rc=$?"
 $B --delta 1.4901161193847656e-08 --cpu-evals 0 > $O/bench_headline_delta_sqrteps.json 2>> $O/err.log; echo "delta rc=$?"
 $B --workload "pde-control-like n=1e6 m=1e5 nnz=1e7" --cpu-evals 0 > $O/bench_headline_stratified.json 2>> $O/err.log; echo "stratified rc=$?"
@@ -21,9 +27,6 @@ rm -rf $O/ks; timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format
 python3 tools/timeline.py $O/ks/k_kernel_trace.csv k_startup > $O/timeline.txt 2>&1
 rm -rf $O/ksf; timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ksf -o k -- python3 bench.py --steps 20 --warmup 3 --cpu-evals 0 --repeats 2 --force-shard > $O/ksf.log 2>&1; echo "kernel stats force-shard rc=$?"
 python3 tools/timeline.py $O/ksf/k_kernel_trace.csv k_startup > $O/timeline_force_shard.txt 2>&1
-rm -rf $O/pf; timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -o f -- python3 bench.py --steps 2 --warmup 1 --cpu-evals 0 --repeats 1 --no-roofline-pass > $O/pf.log 2>&1; echo "pmc fetch rc=$?"
-rm -rf $O/pw; timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -o w -- python3 bench.py --steps 2 --warmup 1 --cpu-evals 0 --repeats 1 --no-roofline-pass > $O/pw.log 2>&1; echo "pmc write rc=$?"
-python3 tools/pmc_traffic.py $O/pf/f_counter_collection.csv $O/pw/w_counter_collection.csv 15 > $O/pmc_traffic.json 2> $O/pmc_traffic.err; echo "pmc post rc=$?"
 # SQ / TCP counters of the FINAL loop kernel (k_iter_fused): separate --pmc passes, --kernel-trace only
 rm -f $O/pmc_sq.txt
 n=0
