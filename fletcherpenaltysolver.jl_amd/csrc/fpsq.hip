@@ -737,6 +737,11 @@ struct fpsq_solver_s {
   hipStream_t stream = nullptr;
   bool in_stream_on = false;     // fpsq_set_input_stream: producer stream of device-resident arguments
   hipStream_t in_stream = nullptr;
+  // One GPU, a registered producer stream (FPSQ_ADOPT_STREAM=0 switches it off): the library enqueues ON that stream instead of on one of its own -- inputs and outputs
+  // are then ordered by the stream itself: no event record / wait pair at either end of a call, and no hops between two queues from
+  // the last kernel of an evaluation to the first of the next (the caller's stream waits for the tail, the library's for the caller's)
+  bool adopt_streams = true, adopted = false;
+  hipStream_t own_stream = nullptr;
   hipEvent_t ev_in = nullptr;
   bool have_structure = false, have_values = false;
   std::string err;
@@ -3453,8 +3458,15 @@ int check_ready(fpsq_handle h) {
 
 // Device-resident arguments are produced on the caller's stream: everything queued there so far must be complete
 // before the first kernel / copy of this call touches them (include/fpsq.h, "INPUT READINESS").
+// back to the handle's own stream (see fpsq_set_input_stream)
+void unadopt_stream(fpsq_handle h) {
+  if (!h->adopted) return;
+  hipStreamSynchronize(h->stream);
+  h->stream = h->own_stream;
+  h->adopted = false;
+}
 void order_inputs(fpsq_handle h) {
-  if (!h->in_stream_on) return;
+  if (!h->in_stream_on || h->adopted) return;
   hipEventRecord(h->ev_in, h->in_stream);
   hipStreamWaitEvent(h->stream, h->ev_in, 0);
 }
@@ -3540,8 +3552,10 @@ int call_end(fpsq_handle h) {
 // the call's sequence number behind its results (host-mapped memory, release store: the values and, from the earlier
 // step kernels, the final statistics are there when the number is).
 int call_end_ordered(fpsq_handle h, double seq) {
-  HIPCHK(h, hipEventRecord(h->ev_out, h->stream));
-  HIPCHK(h, hipStreamWaitEvent(h->in_stream, h->ev_out, 0));
+  if (!h->adopted) {
+    HIPCHK(h, hipEventRecord(h->ev_out, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->in_stream, h->ev_out, 0));
+  }
   volatile double* flag = h->hscal + 3;
   const auto t0 = std::chrono::steady_clock::now();
   int spins = 0;
@@ -3908,6 +3922,7 @@ int fpsq_create(fpsq_handle* out, int64_t n, int64_t m, const fpsq_options* opts
     if (const char* at = std::getenv("FPSQ_FUSE_PROBE_AT")) h->fuse_probe_at = std::atoll(at);
   }
   if (const char* ev = std::getenv("FPSQ_FUSE_TAIL")) h->fuse_tail = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("FPSQ_ADOPT_STREAM")) h->adopt_streams = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_BREAK")) h->ride_break = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("FPSQ_DEBUG_RIDE_DELAY")) h->ride_delay = std::atoi(ev);
   if (const char* ev = std::getenv("FPSQ_JAC_REFRESH")) h->refresh_3pass = std::atoi(ev) == 3;
@@ -4045,7 +4060,11 @@ int fpsq_destroy(fpsq_handle h) {
   if (h->prog_host) hipHostFree(h->prog_host);
   if (h->hstats) hipHostFree(h->hstats);
   if (h->hscal) hipHostFree(h->hscal);
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->own_stream && h->own_stream != h->stream) {  // (an adopted stream is the caller's)
+    hipStreamDestroy(h->own_stream);
+  } else if (h->stream && !h->adopted) {
+    hipStreamDestroy(h->stream);
+  }
   delete h;
   return FPSQ_OK;
 }
@@ -4212,7 +4231,9 @@ int fpsq_set_jacobian_values(fpsq_handle h, const double* vals) {
       hipLaunchKernelGGL(k_refresh, dim3(per_xcd * 8), dim3(kBlock), 0, s, src, sT, sR, sC, per_xcd);
     }
   }
-  if (on_dev && h->in_stream_on) {
+  if (on_dev && h->adopted) {
+    // (the gathers were enqueued on the caller's own stream)
+  } else if (on_dev && h->in_stream_on) {
     // device-resident values on a registered stream: no host synchronisation -- the caller's stream is made to wait for
     // the gathers that read its array (it may overwrite the array with the next Jacobian), the solves that follow run on
     // the library's stream behind them
@@ -4230,6 +4251,13 @@ int fpsq_set_input_stream(fpsq_handle h, int32_t enabled, void* hip_stream) {
   if (!h) return FPSQ_ERR_ARG;
   hipSetDevice(h->opt.device);
   if (enabled && !h->ev_in) HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+  if (h->adopt_streams && (!h->comm || h->comm->nranks == 1)) {  // (a communicator of one rank has no peers)
+    // everything enqueued so far is on the stream in use: finish it, then move
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->own_stream) h->own_stream = h->stream;
+    h->adopted = enabled != 0;
+    h->stream = h->adopted ? (hipStream_t)hip_stream : h->own_stream;
+  }
   h->in_stream_on = enabled != 0;
   h->in_stream = (hipStream_t)hip_stream;
   return FPSQ_OK;
@@ -4765,6 +4793,7 @@ int fpsq_comm_init(fpsq_handle h, int32_t nranks, int32_t rank, const uint8_t id
     delete c;
     return FPSQ_ERR_COMM;
   }
+  if (c->nranks > 1) unadopt_stream(h);  // (a sharded handle keeps a stream of its own: its peers' launches must not queue behind the caller's work)
   h->comm = c;
   h->info.comm_route = c->route();
   return FPSQ_OK;
@@ -4826,6 +4855,7 @@ int fpsq_comm_init_local(fpsq_handle h, void* group, int32_t shard) {
   c->nranks = g->n;
   c->rank = shard;
   c->g = g;
+  if (c->nranks > 1) unadopt_stream(h);  // (a sharded handle keeps a stream of its own: its peers' launches must not queue behind the caller's work)
   h->comm = c;
   h->info.comm_route = c->route();
   return FPSQ_OK;

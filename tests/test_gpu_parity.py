@@ -1396,6 +1396,64 @@ def test_one_launch_tail_is_bitwise_the_two_launch_tail(monkeypatch, size, delta
     assert all(a < b for a, b in zip(l1[1:], l2[1:])) and l1[-1] + 1 == l2[-1], (l1, l2)
 
 
+@pytest.mark.parametrize("size", [(24000, 2400), (300000, 30000, "headline density")])
+def test_enqueueing_on_the_registered_stream_is_bitwise_the_own_stream(monkeypatch, size):
+    """include/fpsq.h INPUT READINESS (round 5): with device-resident arguments whose producer stream is registered
+    (fpsq_set_input_stream -- DeviceEqQP does that for torch tensors), a single-GPU handle enqueues ON that stream; FPSQ_ADOPT_STREAM=0
+    keeps its own stream and orders with an event pair at both ends of a call.  Same kernels, same order: objgrad / hprod / the
+    Jacobian refresh BITWISE the same -- on torch's default stream, on a side stream with work of the caller's queued in front
+    (x is produced by a kernel of that stream: the evaluation must see the produced values) and after switching streams between
+    calls; stream-ordered outputs are consumed on the same stream without a host synchronisation in between."""
+    torch = pytest.importorskip("torch")
+    qp = _small_pde(seed=27, n=size[0], m=size[1]) if len(size) == 2 else problems.pde_control_like(n=size[0], m=size[1], seed=37)
+    dev0 = torch.device("cuda:0")
+    rng = np.random.default_rng(17)
+    xs_h = [qp.xhat + 0.5 ** (k % 4) * rng.standard_normal(qp.n) for k in range(6)]
+    vs_h = [rng.standard_normal(qp.n) for _ in xs_h]
+
+    def run():
+        dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=SE)
+        side = torch.cuda.Stream(device=dev0)
+        out = []
+        base = torch.from_numpy(np.stack(xs_h)).to(dev0)
+        vs = torch.from_numpy(np.stack(vs_h)).to(dev0)
+        vals = torch.from_numpy(np.ascontiguousarray(qp.vals)).to(dev0)
+        torch.cuda.synchronize()
+        for k in range(len(xs_h)):
+            stream = torch.cuda.current_stream() if k < 2 else side if k < 5 else torch.cuda.current_stream()   # (two switches)
+            with torch.cuda.stream(stream):
+                x = base[k] * 2.0 - base[k]             # produced on `stream`, right in front of the call
+                gx = torch.empty(qp.n, dtype=torch.float64, device=dev0)
+                ys = torch.empty(qp.m, dtype=torch.float64, device=dev0)
+                if k == 3:
+                    dev.set_jacobian_values(vals * 1.0)  # (a refresh from a device array produced on the same stream)
+                f, rc = dev.objgrad(x, gx=gx, ys=ys)
+                chk = (gx * gx).sum()                    # consumed on the same stream, no host synchronisation in between
+                hv = torch.empty(qp.n, dtype=torch.float64, device=dev0)
+                rch = dev.hprod(vs[k], hv, 2) if k % 2 else 0
+                st = [(dev.stats[q].niter, dev.stats[q].rnorm) for q in range(2)]
+                stream.synchronize()
+                out += [np.array([f, rc, rch, float(chk)]), gx.cpu().numpy(), ys.cpu().numpy(), hv.cpu().numpy() if k % 2 else np.zeros(1),
+                        np.array(st).ravel()]
+        i = dev.info()
+        assert i["wait_timeouts"] == 0 and i["fuse_fallbacks"] == 0
+        dev.close()
+        return out
+
+    monkeypatch.setenv("FPSQ_ADOPT_STREAM", "0")
+    want = run()
+    monkeypatch.setenv("FPSQ_ADOPT_STREAM", "1")
+    got = run()
+    for i, (a_, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a_, b_), i
+    # ... and the host-pointer path (nothing registered) agrees with both
+    dev = DeviceEqQP(qp, sigma=1e3, rho=1.0, delta=SE)
+    gx, ys = np.empty(qp.n), np.empty(qp.m)
+    f, rc = dev.objgrad(xs_h[0], gx=gx, ys=ys)
+    dev.close()
+    assert f == got[0][0] and np.array_equal(gx, got[1]) and np.array_equal(ys, got[2])
+
+
 @pytest.mark.parametrize("late", [0, 8, 3, 13])
 def test_one_launch_iterations_with_a_late_mid_leader(monkeypatch, late):
     """The mid leaders of a fused launch publish per XCC, so the row groups of the other XCCs do not wait for a mid leader that
