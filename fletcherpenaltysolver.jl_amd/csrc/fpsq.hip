@@ -4252,6 +4252,7 @@ int fpsq_set_input_stream(fpsq_handle h, int32_t enabled, void* hip_stream) {
   hipSetDevice(h->opt.device);
   if (enabled && !h->ev_in) HIPCHK(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
   if (h->adopt_streams && (!h->comm || h->comm->nranks == 1)) {  // (a communicator of one rank has no peers)
+    if (enabled && h->adopted && h->stream == (hipStream_t)hip_stream) return FPSQ_OK;  // (registered again: nothing to do)
     // everything enqueued so far is on the stream in use: finish it, then move
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!h->own_stream) h->own_stream = h->stream;
