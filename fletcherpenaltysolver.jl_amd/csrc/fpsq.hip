@@ -848,6 +848,7 @@ struct fpsq_solver_s {
   int64_t fuse_probe_at = 0;
   bool fuse_tail = true;               // FPSQ_FUSE_TAIL=0: the raw A'[q1, c] product and k_qp_penalty_grad as two launches (one GPU; bitwise the same)
   const GradEpi* tail_grad = nullptr;  // set around the tail's product launch: launch_spmv then picks k_spmv<.., GRAD>
+  bool tail_grad_used = false;         // ... and says so (a layout it has no GRAD variant for: the caller launches k_qp_penalty_grad)
   unsigned long long* fuse_probe_buf = nullptr;
   int fuse_probe_grid = 0;
   std::vector<int> fuse_probe_layout;
@@ -1819,6 +1820,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
       else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, false, true);
     } else if (grad) {
       if constexpr (NL == 2) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true, true);
+      h->tail_grad_used = true;
     } else if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, false, true);
     else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true);
     else if (M.col16) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true);
@@ -4581,8 +4583,15 @@ static int impl_qp_objgrad(fpsq_handle h, fpsq_qp qp, const double* x, double si
         ge.gx = dgx;
         ge.fx = grad_fx ? fa : none;
         h->tail_grad = &ge;
+        h->tail_grad_used = false;
         launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), false);
         h->tail_grad = nullptr;
+        if (!h->tail_grad_used) {  // (the product wrote its rows as ever: combine them in a launch of their own)
+          hipLaunchKernelGGL(k_qp_penalty_grad, dim3(grad_fx ? gn + 1 : gn), dim3(kBlock), 0, s, (const double*)nullptr, h->g, h->LP,
+                             h->Cx, qp->q, (const double*)nullptr, dx, dxk, sigma, rho, eta, h->gs, dgx, n, grad_fx ? fa : none,
+                             h->gate0, h->gate1);
+          h->launches++;
+        }
       } else {
         launch_spmv<2>(h, TAG_AT, h->SP, nullptr, h->LP, h->ctl_raw, h->ctl_raw, nullptr, seg_none(), seg_none(), h->halo);
         if (h->halo)
