@@ -1776,8 +1776,8 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
   } else {
     const DevCsr& M = tag == TAG_A ? h->A : h->AT;
     const int per_xcd = (M.nblk + 7) / 8;
-    bool grad = false;  // the tail of an evaluation on one GPU: the raw product's rows go straight into grad(phi)
-    if constexpr (NL == 2) grad = h->tail_grad != nullptr && tag == TAG_AT && !lead && !halo_rows && M.sorted && nupd == 0;
+    // the tail of a call on one GPU: the raw product's rows go straight into the call's result (grad(phi): two lanes; Hv: one)
+    const bool grad = h->tail_grad != nullptr && tag == TAG_AT && !lead && !halo_rows && M.sorted && nupd == 0;
     const GradEpi ge = grad ? *h->tail_grad : GradEpi{};
     const dim3 grid(per_xcd * 8 + nupd + (grad && ge.fx.out != nullptr ? 1 : 0));
     const int ps = tag == TAG_A ? h->strA : h->strT;
@@ -1819,7 +1819,7 @@ void launch_spmv(fpsq_handle h, int tag, const double* x, const double* yin, dou
       else if (M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, true, true);
       else FPSQ_LAUNCH_SPMV(NL, TAG_AT, false, false, true);
     } else if (grad) {
-      if constexpr (NL == 2) FPSQ_LAUNCH_SPMV(2, TAG_AT, true, true, false, true, true);
+      FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, false, true, true);
       h->tail_grad_used = true;
     } else if (M.sorted) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true, false, true);
     else if (M.col16 && M.padded) FPSQ_LAUNCH_SPMV(NL, TAG_AT, true, true);
@@ -4701,13 +4701,35 @@ static int impl_qp_hprod(fpsq_handle h, fpsq_qp qp, const double* v, double sigm
   call_begin(h);
   hipLaunchKernelGGL(k_qp_hsv, dim3(gn), dim3(kBlock), 0, s, qp->q, dv, h->in_n2, n);                    // :537
   TailFn epi = [&]() -> int {
+    bool fin_done = false;
     if (rho > 0.0) {                                                                                      // :557-558
       spmv_const(h, TAG_A, 1.0, dv, 0.0, nullptr, h->in_m);
-      if (int rc = at_product_const(h, 1.0, h->in_m, 0.0, nullptr, h->jc)) return rc;
+      // one GPU: the rows of A'(A v) go straight into Hv (k_spmv<1, .., GRAD>; bitwise the product + k_qp_hprod_fin, FPSQ_FUSE_TAIL=0)
+      const bool alone = !h->comm || (h->comm->nranks == 1 && h->ovl + h->ovr == 0);
+      GradEpi ge{};
+      if (h->fuse_tail && alone && h->AT.sorted && h->AT.padded) {
+        ge.p1 = h->p1;
+        ge.p2 = h->p2b;
+        ge.v = dv;
+        ge.q = qp->q;
+        ge.sigma = sigma;
+        ge.rho = rho;
+        ge.eta = eta;
+        ge.hv = dhv;
+        h->tail_grad = &ge;
+        h->tail_grad_used = false;
+      }
+      const int rc = at_product_const(h, 1.0, h->in_m, 0.0, nullptr, h->jc);
+      fin_done = h->tail_grad != nullptr && h->tail_grad_used;
+      h->tail_grad = nullptr;
+      if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_qp_hprod_fin, dim3(gn), dim3(kBlock), 0, s, h->p1, h->p2b, qp->q, dv, h->jc, sigma, rho, eta, dhv,
-                       n, h->gate0, h->gate1);                                                            // :543-562
-    h->launches += 2;
+    if (!fin_done) {
+      hipLaunchKernelGGL(k_qp_hprod_fin, dim3(gn), dim3(kBlock), 0, s, h->p1, h->p2b, qp->q, dv, h->jc, sigma, rho, eta, dhv,
+                         n, h->gate0, h->gate1);                                                          // :543-562
+      h->launches++;
+    }
+    h->launches++;
     return 0;
   };
   const bool local_vec = !h->comm || h->halo;

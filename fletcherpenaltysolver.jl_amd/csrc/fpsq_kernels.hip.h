@@ -1115,11 +1115,24 @@ __device__ __forceinline__ void qp_grad_row(double gi, double lp0, double lp1, d
   if (eta > 0.0) gg = fma(eta, x[i] - xk[i], gg);
   gx = gg;
 }
-// what the raw A' product needs to write grad(phi) instead of its own rows (k_spmv<.., GRAD>: the tail of an evaluation on one GPU)
+// One row of hprod! Val(2)'s result (src/model-Fletcherpenaltynlp.jl:543-562 on the eq-QP model):
+//   Hv = p2 - q (v - p1) + 2 sigma (v - p1) (+ rho (J'J v)) (+ eta v).   One spelling, for k_qp_hprod_fin and for the row epilogue of the
+// single-lane product A'(A v) (k_spmv<1, .., GRAD>).
+__device__ __forceinline__ double qp_hfin_row(double vi, double p1i, double p2i, double qi, double jtjv, double sigma, double rho, double eta) {
+  const double pt = vi - p1i;
+  double r = fma(2.0 * sigma, pt, fma(-qi, pt, p2i));
+  if (rho > 0.0) r = fma(rho, jtjv, r);
+  if (eta > 0.0) r = fma(eta, vi, r);
+  return r;
+}
+// what a raw A' product needs to write the END RESULT of its call instead of its own rows (k_spmv<.., GRAD>, one GPU):
+//   two lanes  (A'[q1, c], the tail of objgrad!):  gs and gx = grad(phi)                 -- qp_grad_row
+//   one lane   (A'(A v),   the tail of hprod!):    hv                                    -- qp_hfin_row (p1, p2 of the two solves)
 struct GradEpi {
   const double *g, *v, *q, *x, *xk;
+  const double *p1, *p2;
   double sigma, rho, eta;
-  double *gs, *gx;
+  double *gs, *gx, *hv;
   FxArgs fx;  // fx.out != null: workgroup 0 of the grid reduces the evaluation's partial sums to phi (k_qp_penalty_grad's last one does)
 };
 
@@ -1177,12 +1190,7 @@ __global__ __launch_bounds__(kBlock) void k_qp_hprod_fin(const double* __restric
                                                          const LaneCtl* gate1) {
   if (gate0 != nullptr && !(gate0->done && gate1->done)) return;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double vi = v[i];
-    const double pt = vi - p1[i];
-    double r = p2[i] - q[i] * pt + 2.0 * sigma * pt;
-    if (rho > 0.0) r += rho * jtjv[i];
-    if (eta > 0.0) r += eta * vi;
-    hv[i] = r;
+    hv[i] = qp_hfin_row(v[i], p1[i], p2[i], q[i], rho > 0.0 ? jtjv[i] : 0.0, sigma, rho, eta);
   }
 }
 

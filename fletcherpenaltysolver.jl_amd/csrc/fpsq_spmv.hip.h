@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
                                                  double* partials, int blk_per_xcd, const UpdSeg u0, const UpdSeg u1,
                                                  const LaneCtl* gate0, const LaneCtl* gate1, int pstride,
                                                  const HaloRows hr, const GradEpi ge) {
-  static_assert(!GRAD || (NL == 2 && TAG == 1 && !HALO), "the gradient epilogue: the raw two-lane A' product of one GPU");
+  static_assert(!GRAD || (TAG == 1 && !HALO && PAD), "the result epilogues: raw A' products of one GPU, padded blocks");
   // exactly 32 KB of LDS for two right-hand sides (FOUR workgroups per CU -- measured, tools/stream_probe.hip: 30 KB would
   // admit five, 24 KB six; tiles of 1536 entries were slower all the same): the reduction scratch
   // aliases the head of the product buffer
@@ -290,11 +290,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
         ypre[0] = yin[r0 + rq0];
       }
     }
-    [[maybe_unused]] double gpre[3] = {0.0, 0.0, 0.0};  // GRAD: g, v, q of the first row pass, requested here like yin
+    [[maybe_unused]] double gpre[4] = {0.0, 0.0, 0.0, 0.0};  // GRAD: the epilogue's operands of the first row pass, requested here like yin
     if constexpr (GRAD) {
-      gpre[0] = ge.g[r0 + rq0];
+      gpre[0] = NL == 2 ? ge.g[r0 + rq0] : ge.p1[r0 + rq0];
       gpre[1] = ge.v[r0 + rq0];
       gpre[2] = ge.q[r0 + rq0];
+      if (NL == 1) gpre[3] = ge.p2[r0 + rq0];
     }
     constexpr int kPer = kSpmvNnz / kBlock;
     int cidx[kPer];
@@ -363,12 +364,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(CsrView A, const double* __rest
 #pragma unroll
           for (int l = 0; l < NL; ++l)
             if (act[l]) dst[l] = acc[l];
-        } else if constexpr (GRAD) {
+        } else if constexpr (GRAD && NL == 2) {
           const double gi = base == 0 ? gpre[0] : ge.g[row], vi = base == 0 ? gpre[1] : ge.v[row], qi = base == 0 ? gpre[2] : ge.q[row];
           double gsi, gg;
           qp_grad_row(gi, acc[0], acc[NL - 1], vi, qi, ge.sigma, ge.rho, ge.eta, ge.x, ge.xk, row, gsi, gg);
           ge.gs[row] = gsi;
           ge.gx[row] = gg;
+        } else if constexpr (GRAD) {
+          const double p1i = base == 0 ? gpre[0] : ge.p1[row], vi = base == 0 ? gpre[1] : ge.v[row], qi = base == 0 ? gpre[2] : ge.q[row];
+          const double p2i = base == 0 ? gpre[3] : ge.p2[row];
+          ge.hv[row] = qp_hfin_row(vi, p1i, p2i, qi, acc[0], ge.sigma, ge.rho, ge.eta);
         } else {
           row_epilogue<NL>((size_t)row, acc, ca, cb, act, yin, yout, sq, base == 0 && yin != nullptr ? ypre : nullptr);
         }

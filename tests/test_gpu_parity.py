@@ -1364,8 +1364,8 @@ def test_one_launch_tail_is_bitwise_the_two_launch_tail(monkeypatch, size, delta
     """The tail of an evaluation on one GPU (round 5): the rows of the raw product A'[q1, c] go straight into grad(phi) -- k_spmv<.., GRAD>,
     csrc/fpsq_spmv.hip.h; its last workgroup reduces phi -- instead of being written, re-read and combined by k_qp_penalty_grad
     (FPSQ_FUSE_TAIL=0: those two launches).  One spelling of the row's arithmetic serves both (qp_grad_row): phi, gx, gs, ys, the
-    statistics and an hprod! behind the evaluation BITWISE the same, with and without the proximal term, one launch fewer per
-    evaluation; speculative (gated) tails included -- the points change so that the expected iteration count is wrong now and then."""
+    statistics BITWISE the same, with and without the proximal term, one launch fewer per evaluation; the same for hprod! Val(2), whose
+    single-lane product A'(A v) writes Hv as its row epilogue instead of handing J'Jv to k_qp_hprod_fin (qp_hfin_row); speculative (gated) tails included -- the points change so that the expected iteration count is wrong now and then."""
     qp = _small_pde(seed=23, n=size[0], m=size[1]) if len(size) == 2 else problems.pde_control_like(n=size[0], m=size[1], seed=35)
     rng = np.random.default_rng(13)
     xs = [qp.xhat + 0.5 ** (k % 5) * (1.0 if k % 3 else 1e-2) * rng.standard_normal(qp.n) for k in range(8)]
